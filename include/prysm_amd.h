@@ -1,0 +1,199 @@
+/* prysm_amd -- C ABI of the MI355X (gfx950) physical-optics propagation engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of brandondube/prysm v0.22
+ * named in BASELINE.json: pupil<->focus FFT propagation, angular-spectrum free
+ * space propagation, the matrix-DFT fixed-sampling focus and the |.|^2
+ * intensity / incoherent polychromatic sum.  The reference is pure Python and has
+ * no FFI; its plug surface is the `prysm.mathops` backend shim
+ * (prysm/mathops.py:11-45) through which every hot-path module reaches
+ * numpy / scipy.fft / BLAS.  Each entry point below names the reference call
+ * site(s) whose arithmetic it replaces.  The host-side mirror of the reference's
+ * Python interface (same names, arguments, error behaviour) is the `prysm_amd`
+ * package, which binds these symbols with ctypes; INTEGRATION.md shows the
+ * binding a prysm maintainer would add.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers (HBM) unless stated otherwise; buffers are
+ *    owned by the caller (PyTorch allocates them).  The library allocates only
+ *    immutable per-(N, dtype, device) twiddle tables in a plan cache.
+ *  - Arrays are row-major `a[y][x]` (prysm convention), leading dimension in
+ *    ELEMENTS.  Complex values are interleaved (re, im).
+ *  - Every function only ENQUEUES work on `stream` (a hipStream_t; NULL = the
+ *    default stream) and never synchronises.
+ *  - Return value: 0 = ok, < 0 = argument error (see pm_last_error()),
+ *    > 0 = a hipError_t.
+ *  - gfx950 only.  There is no CPU path: without a GPU every compute entry
+ *    point fails with a hipError_t.
+ */
+#ifndef PRYSM_AMD_H
+#define PRYSM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_VERSION 100 /* 0.1.0 */
+
+/* dtype codes */
+enum { PM_C64 = 0, PM_C128 = 1, PM_F32 = 2, PM_F64 = 3, PM_BOOL = 4 };
+
+/* error codes (negative) */
+enum {
+    PM_OK = 0,
+    PM_ERR_ARG = -1,         /* bad argument (null pointer, negative size, bad enum) */
+    PM_ERR_UNSUPPORTED = -2, /* size / dtype combination not implemented */
+    PM_ERR_WORKSPACE = -3    /* workspace too small; query with pm_fft2_workspace() */
+};
+
+/* epilogues of the last FFT pass */
+enum {
+    PM_EPI_NONE = 0,       /* complex output */
+    PM_EPI_ABS2 = 1,       /* real output  |scale * X|^2           (Wavefront.intensity fused) */
+    PM_EPI_ABS2_ACCUM = 2  /* real output  out += weight*|scale*X|^2 (incoherent polychromatic sum) */
+};
+
+/* multiplier applied to the complex result before it is stored */
+enum { PM_MUL_NONE = 0, PM_MUL_FULL = 1, PM_MUL_SEPARABLE = 2 };
+
+/* flags */
+enum {
+    PM_FLAG_PASS1_ONLY = 1, /* profiling: run only the row pass    */
+    PM_FLAG_PASS2_ONLY = 2  /* profiling: run only the column pass */
+};
+
+/* One axis of a windowed, rotated view.  A logical (transform-sized) axis of
+ * length n is related to memory by
+ *     position p = (i + shift) mod n,   memory index q = p - off,   0 <= q < len.
+ * On the INPUT side logical element i reads mem[q] (zero outside the window):
+ *     fft.ifftshift            -> shift = n/2            (prysm/propagation/fft.py:24)
+ *     fttools.pad2d            -> off = ceil((n-len)/2)  (prysm/fttools.py:88-94), never materialised
+ * On the OUTPUT side transform bin k is written to mem[q] (dropped outside):
+ *     fft.fftshift             -> shift = n/2
+ *     fttools.crop_center      -> off = ceil((n-len)/2)  (prysm/fttools.py:122-124)
+ */
+typedef struct pm_axis {
+    int64_t n;
+    int64_t len;
+    int64_t off;
+    int64_t shift;
+} pm_axis;
+
+/* 2-D complex transform with fused pad / shift / crop / scale / multiply / |.|^2.
+ * Replaces, in one call:
+ *   fft.fftshift(fft.fft2(fft.ifftshift(pad2d(x, Q)), norm=...))      prysm/propagation/fft.py:23-25 (focus)
+ *   ... ifft2 ...                                                      fft.py:44,65,84 (unfocus, adjoints) + crop_center
+ *   fft.fft2(field) * tf  and  fft.ifft2(.)                            prysm/propagation/angular_spectrum.py:35,41-42,76
+ *   re*re + im*im of the result                                        prysm/propagation/wavefront.py:146-151
+ *   fft.fftshift(fft.fft2(fft.ifftshift(psf)))                         prysm/otf.py:31
+ */
+typedef struct pm_fft2_desc {
+    int32_t dtype;      /* PM_C64 or PM_C128 */
+    int32_t direction;  /* -1: exp(-2 pi i ..) (fft2), +1: exp(+2 pi i ..) (ifft2, unnormalised) */
+    int32_t epilogue;   /* PM_EPI_* */
+    int32_t flags;      /* PM_FLAG_* */
+    double scale;       /* multiplies the complex result: 1/sqrt(MN) for norm='ortho', 1/(MN) for ifft2 */
+    double weight;      /* PM_EPI_ABS2_ACCUM weight */
+    pm_axis in_y, in_x;   /* input view  (rows, columns) */
+    pm_axis out_y, out_x; /* output view (rows, columns) */
+    int64_t in_ld, out_ld;
+    int32_t mul_kind;   /* PM_MUL_*: result *= mul[k_y][k_x] (FULL) or mul_y[k_y]*mul_x[k_x] (SEPARABLE), */
+    int32_t mul_conj;   /*           indexed by the unshifted transform bin; conj -> multiply by conj(mul) */
+    const void* mul;    /* FULL: (M x N) complex array; SEPARABLE: length-M complex vector (rows) */
+    const void* mul_x;  /* SEPARABLE: length-N complex vector (columns) */
+    int64_t mul_ld;
+} pm_fft2_desc;
+
+/* bytes of workspace pm_fft2 needs for this descriptor (the tiled intermediate) */
+size_t pm_fft2_workspace(const pm_fft2_desc* d);
+
+int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes,
+            void* stream);
+
+/* Batched 1-D complex transform along one axis of a 2-D array, zero padded or
+ * truncated to n on input (numpy `fft.fft(x, n, axis=)` semantics).
+ * Replaces fft.fft / fft.ifft at prysm/fttools.py:301-321,335-355,387,519-533 (CZT, FFTDFT).
+ *   axis = 1: transform each row;  axis = 0: transform each column.
+ *   `t` describes the transform axis on the input (zero pad: len < n) and `t_out` on the output
+ *   (crop / shift); `batch` is the extent of the other axis.  */
+int pm_fft1(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in,
+            const pm_axis* t_out, double scale, const void* in, int64_t in_ld, void* out, int64_t out_ld,
+            void* stream);
+
+/* --- pointwise / synthesis kernels -------------------------------------------------------- */
+
+/* out = a * b (op 0), a * conj(b) (op 1); complex, same shape (rows x cols).
+ * Wavefront.__mul__ (prysm/propagation/wavefront.py:360-411), _adjoint_multiply (_kernels.py:29-37). */
+int pm_cmul(int32_t dtype, int32_t op, int64_t rows, int64_t cols, const void* a, int64_t a_ld, const void* b,
+            int64_t b_ld, void* out, int64_t out_ld, void* stream);
+
+/* out[i][j] = in[i][j] * ry[i] * cx[j] * scale, ry / cx optional complex vectors, each optionally conjugated.
+ * The chirp / phase-ramp multiplies of CZT and FFTDFT (prysm/fttools.py:297-323,508-535). */
+int pm_scale_sep(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t in_ld, const void* ry,
+                 int32_t ry_conj, const void* cx, int32_t cx_conj, double scale, void* out, int64_t out_ld,
+                 void* stream);
+
+/* out = re^2 + im^2 (accumulate = 0) or out += weight * (re^2 + im^2).  wavefront.py:146-151;
+ * polynomials.sum_of_2d_modes (prysm/polynomials/fitting.py:7-37) as a running weighted sum. */
+int pm_abs2(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t in_ld, void* out, int64_t out_ld,
+            int32_t accumulate, double weight, void* stream);
+
+/* P = amp * exp(i * k * opd), k = 2 pi / (wavelength_um * 1e3) for opd in nm.
+ * amp may be NULL (unit amplitude: phase_screen).  amp_dtype in {PM_F32, PM_F64, PM_BOOL}.
+ * Wavefront.from_amp_and_phase / phase_screen (wavefront.py:58-96), phase_prefix (_kernels.py:40-43). */
+int pm_pupil_synth(int32_t dtype, int64_t rows, int64_t cols, const void* amp, int32_t amp_dtype, int64_t amp_ld,
+                   const void* opd, int64_t opd_ld, double k, void* out, int64_t out_ld, void* stream);
+
+/* out[i][j] = exp(i * c * (x[i][j]^2 + y[i][j]^2)); Wavefront.thin_lens (wavefront.py:98-144), c = -pi/(w f). */
+int pm_quadratic_phase(int32_t dtype, int64_t rows, int64_t cols, const void* x, int64_t x_ld, const void* y,
+                       int64_t y_ld, double c, void* out, int64_t out_ld, void* stream);
+
+/* Separable Fresnel transfer-function factors: hy[i] = exp(-i pi wvl_mm z ky[i]^2), ky = fftfreq(rows, dx)
+ * rounded to the real dtype first (angular_spectrum.py:105-113).  hx likewise.  Vectors of length rows / cols. */
+int pm_as_tf_vectors(int32_t dtype, int64_t rows, int64_t cols, double wvl_um, double dx, double z, void* hy,
+                     void* hx, void* stream);
+
+/* out = outer(hy, hx) -- materialises the transfer function for API parity (angular_spectrum.py:114). */
+int pm_outer(int32_t dtype, int64_t rows, int64_t cols, const void* hy, const void* hx, void* out, int64_t out_ld,
+             void* stream);
+
+/* out window copy: out (orows x ocols) = fill everywhere, then in placed at (off_y, off_x); negative offsets
+ * crop.  fttools.pad2d constant mode / crop_center (prysm/fttools.py:43-125).  elem_bytes in {1,4,8,16}. */
+int pm_embed(int32_t elem_bytes, int64_t irows, int64_t icols, const void* in, int64_t in_ld, int64_t orows,
+             int64_t ocols, int64_t off_y, int64_t off_x, const void* fill_elem_host, void* out, int64_t out_ld,
+             void* stream);
+
+/* --- matrix DFT --------------------------------------------------------------------------- */
+
+/* E[m][n] = exp(sign * 2 pi i * f[m] * x[n]) (M x N), phases reduced in fp64, rounded once.
+ * f and x are real device vectors of the complex dtype's real type.  fttools.MDFT.__init__
+ * (prysm/fttools.py:187-191). */
+int pm_mdft_basis(int32_t dtype, int64_t M, int64_t N, const void* f, const void* x, int32_t sign, void* E,
+                  int64_t E_ld, void* stream);
+
+/* C (M x N) = alpha * opA(A) (M x K) @ opB(B) (K x N), complex, on the MFMA matrix cores.
+ *   opA: 0 = A, 1 = conj(A), 2 = A^T, 3 = A^H     (A stored M x K for 0/1, K x M for 2/3)
+ *   opB: likewise                                   (B stored K x N for 0/1, N x K for 2/3)
+ * The two GEMMs of fttools.MDFT.__call__ / .adjoint (prysm/fttools.py:201-228). */
+int pm_cgemm(int32_t dtype, int32_t opA, int32_t opB, int64_t M, int64_t N, int64_t K, double alpha,
+             const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, void* workspace,
+             size_t workspace_bytes, void* stream);
+/* bytes of split-K workspace pm_cgemm wants for this shape (0 = none; without it the GEMM runs unsplit) */
+size_t pm_cgemm_workspace(int32_t dtype, int64_t M, int64_t N, int64_t K);
+
+/* --- housekeeping ------------------------------------------------------------------------- */
+int pm_version(void);
+const char* pm_last_error(void);   /* thread-local message for the last negative return */
+int pm_plan_prepare(int32_t dtype, int64_t n);   /* build + cache the twiddle table for length n now */
+void pm_shutdown(void);            /* free cached tables */
+/* time `reps` launches of each pass of the transform with hipEvents on `stream`; ms[0] = row pass,
+ * ms[1] = column pass (average per launch).  Used by bench.py for the roofline object. */
+int pm_fft2_time_passes(const pm_fft2_desc* d, const void* in, void* out, void* workspace,
+                        size_t workspace_bytes, int reps, double* ms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRYSM_AMD_H */

@@ -1,0 +1,346 @@
+// extern "C" entry points of libprysm_amd.so: plan cache, 2-D / 1-D transform dispatch.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "pm_internal.h"
+
+namespace pm {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---------------------------------------------------------------- plan cache
+// Immutable twiddle tables keyed by (device, element size, n).  Built on the host in long double,
+// rounded once, uploaded with a blocking copy at first use (or via pm_plan_prepare); the hot
+// path afterwards only reads the map under a mutex.
+static std::mutex g_mu;
+static std::map<std::tuple<int, int, int64_t>, void*> g_tables;
+
+template <typename T>
+static const cx<T>* table_get(int64_t n, int* err) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        *err = int(e);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(dev, int(sizeof(T)), n);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) return reinterpret_cast<const cx<T>*>(it->second);
+    std::vector<cx<T>> h(size_t(n > 0 ? n : 1));
+    const long double pi = acosl(-1.0L);
+    for (int64_t i = 0; i < n; ++i) {
+        // octant symmetry is not needed for accuracy in long double; one rounding per entry
+        const long double a = -2.0L * pi * (long double)i / (long double)n;
+        h[size_t(i)] = {T(cosl(a)), T(sinl(a))};
+    }
+    void* d = nullptr;
+    e = hipMalloc(&d, h.size() * sizeof(cx<T>));
+    if (e != hipSuccess) {
+        *err = int(e);
+        return nullptr;
+    }
+    e = hipMemcpy(d, h.data(), h.size() * sizeof(cx<T>), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        *err = int(e);
+        return nullptr;
+    }
+    g_tables[key] = d;
+    return reinterpret_cast<const cx<T>*>(d);
+}
+
+template <> const cx<float>* twiddles<float>(int64_t n, int* err) { return table_get<float>(n, err); }
+template <> const cx<double>* twiddles<double>(int64_t n, int* err) { return table_get<double>(n, err); }
+const cx<double>* twiddles_f64(int64_t n, int* err) { return table_get<double>(n, err); }
+
+static AxisMap to_map(const pm_axis& a) { return AxisMap{int(a.n), int(a.len), int(a.off), int(a.shift)}; }
+
+static int check_axis(const pm_axis& a, const char* name) {
+    if (a.n < 1 || a.n > (int64_t(1) << 30)) return fail(PM_ERR_ARG, "%s.n = %lld out of range", name, (long long)a.n);
+    if (a.len < 0 || a.len > a.n) return fail(PM_ERR_ARG, "%s.len = %lld must be in [0, n]", name, (long long)a.len);
+    if (a.off < 0 || a.off + a.len > a.n) return fail(PM_ERR_ARG, "%s window [off, off+len) must lie in [0, n]", name);
+    if (a.shift < 0 || a.shift >= a.n) return fail(PM_ERR_ARG, "%s.shift must be in [0, n)", name);
+    return 0;
+}
+
+// ---------------------------------------------------------------- 2-D transform
+struct Fft2Plan {
+    int logn, logm;       // engine log2 sizes or -1 (direct)
+    int tc;               // tile width when both passes run on the engine, else 0 (natural intermediate)
+    size_t ws_bytes;
+};
+
+static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
+    Fft2Plan p;
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    p.logn = engine_log2(N);
+    p.logm = engine_log2(M);
+    const size_t es = d->dtype == PM_C64 ? 8 : 16;
+    const int64_t rows = d->in_y.len;   // only stored input rows are transformed in pass 1
+    if (p.logn >= 0 && p.logm >= 0) {
+        p.tc = col_tile_width_for(d->dtype, p.logm);
+        const int64_t ntiles = (N + p.tc - 1) / p.tc;
+        p.ws_bytes = size_t(ntiles) * size_t(rows) * size_t(p.tc) * es;
+    } else {
+        p.tc = 0;
+        p.ws_bytes = size_t(rows) * size_t(N) * es;
+    }
+    if (p.ws_bytes == 0) p.ws_bytes = es;
+    return p;
+}
+
+template <typename T>
+static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out) {
+    ColStoreNat<T> cs{};
+    cs.dst = out;
+    cs.ld = d->out_ld;
+    cs.ay = to_map(d->out_y);
+    cs.ax = to_map(d->out_x);
+    cs.conj = d->direction > 0 ? 1 : 0;
+    cs.epilogue = d->epilogue;
+    cs.scale = T(d->scale);
+    cs.weight = T(d->weight);
+    cs.mul_kind = d->mul_kind;
+    cs.mul_conj = d->mul_conj;
+    cs.mul = reinterpret_cast<const cx<T>*>(d->mul);
+    cs.mul_x = reinterpret_cast<const cx<T>*>(d->mul_x);
+    cs.mul_ld = d->mul_ld;
+    bool vec = true;
+    if (d->epilogue == PM_EPI_NONE && sizeof(T) == 4)
+        vec = (d->out_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    cs.vec_ok = vec ? 1 : 0;
+    return cs;
+}
+
+template <typename T>
+static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st) {
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    const int rows = int(d->in_y.len);
+    const int conj = d->direction > 0 ? 1 : 0;
+    int err = 0;
+    cx<T>* W = reinterpret_cast<cx<T>*>(ws);
+    const bool run1 = !(d->flags & PM_FLAG_PASS2_ONLY), run2 = !(d->flags & PM_FLAG_PASS1_ONLY);
+
+    // ---- pass 1: one transform of length N per STORED input row (all-zero padded rows are skipped)
+    if (run1 && rows > 0) {
+        if (p.logn >= 0) {
+            const cx<T>* tw = twiddles<T>(N, &err);
+            if (!tw) return err;
+            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, conj};
+            int rc;
+            if (p.tc) {
+                int ltc = 0;
+                while ((1 << ltc) < p.tc) ++ltc;
+                RowStoreTiled<T> sp{W, rows, ltc};
+                rc = launch_row_tiled<T>(p.logn, lp, sp, tw, rows, st);
+            } else {
+                RowStoreNat<T> sp{W, N, AxisMap{int(N), int(N), 0, 0}, rows, 0, T(1)};
+                rc = launch_row_nat<T>(p.logn, lp, sp, tw, rows, st);
+            }
+            if (rc) return rc;
+        } else {
+            const cx<double>* tw = twiddles_f64(N, &err);
+            if (!tw) return err;
+            DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), d->in_ld, 1, to_map(d->in_x), rows, conj};
+            int rc = direct_rows<T>(di, W, N, tw, st);
+            if (rc) return rc;
+        }
+    }
+    if (!run2) return 0;
+
+    // ---- pass 2: transforms of length M down the columns, epilogue fused into the store
+    ColStoreNat<T> cs = make_colstore<T>(d, out);
+    if (p.logm >= 0) {
+        const cx<T>* tw = twiddles<T>(M, &err);
+        if (!tw) return err;
+        if (p.tc) {
+            const int ntiles = int((N + p.tc - 1) / p.tc);
+            ColLoadTiled<T> cl{W, rows, to_map(d->in_y), ntiles};
+            return launch_col_tiled<T>(p.logm, cl, cs, tw, ntiles, st);
+        }
+        const int tc = col_tile_width_for(d->dtype, p.logm);
+        const int ntiles = int((N + tc - 1) / tc);
+        ColLoadNat<T> cl{W, N, to_map(d->in_y), int(N), 0, (N % 2 == 0) ? 1 : 0};
+        return launch_col_nat<T>(p.logm, cl, cs, tw, ntiles, st);
+    }
+    const cx<double>* tw = twiddles_f64(M, &err);
+    if (!tw) return err;
+    DirectIn<T> di{W, 1, N, to_map(d->in_y), int(N), 0};   // sequence = column c at W[c], element stride N
+    return direct_cols<T>(di, cs, tw, st);
+}
+
+static int check_fft2(const pm_fft2_desc* d) {
+    if (!d) return fail(PM_ERR_ARG, "pm_fft2: null descriptor");
+    if (d->dtype != PM_C64 && d->dtype != PM_C128) return fail(PM_ERR_ARG, "pm_fft2: dtype must be PM_C64 or PM_C128");
+    if (d->direction != 1 && d->direction != -1) return fail(PM_ERR_ARG, "pm_fft2: direction must be -1 or +1");
+    if (d->epilogue < PM_EPI_NONE || d->epilogue > PM_EPI_ABS2_ACCUM) return fail(PM_ERR_ARG, "pm_fft2: bad epilogue");
+    if (d->mul_kind < PM_MUL_NONE || d->mul_kind > PM_MUL_SEPARABLE) return fail(PM_ERR_ARG, "pm_fft2: bad mul_kind");
+    if (d->mul_kind != PM_MUL_NONE && !d->mul) return fail(PM_ERR_ARG, "pm_fft2: mul is null");
+    if (d->mul_kind == PM_MUL_SEPARABLE && !d->mul_x) return fail(PM_ERR_ARG, "pm_fft2: mul_x is null");
+    int rc;
+    if ((rc = check_axis(d->in_y, "in_y")) || (rc = check_axis(d->in_x, "in_x")) ||
+        (rc = check_axis(d->out_y, "out_y")) || (rc = check_axis(d->out_x, "out_x")))
+        return rc;
+    if (d->in_y.n != d->out_y.n || d->in_x.n != d->out_x.n)
+        return fail(PM_ERR_ARG, "pm_fft2: input and output views must share the transform size");
+    if (d->in_ld < d->in_x.len || d->out_ld < d->out_x.len) return fail(PM_ERR_ARG, "pm_fft2: leading dimension < row length");
+    const int64_t lim = int64_t(1) << 15;
+    if ((engine_log2(d->in_x.n) < 0 && d->in_x.n > lim) || (engine_log2(d->in_y.n) < 0 && d->in_y.n > lim))
+        return fail(PM_ERR_UNSUPPORTED, "pm_fft2: length %lld x %lld: powers of two up to 8192 run on the FFT engine, other "
+                    "lengths up to 32768 on the direct DFT",
+                    (long long)d->in_y.n, (long long)d->in_x.n);
+    return 0;
+}
+
+template <typename T>
+static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, const pm_axis* to, double scale,
+                    const void* in, int64_t in_ld, void* out, int64_t out_ld, hipStream_t st) {
+    const int64_t n = ti->n;
+    const int lg = engine_log2(n);
+    const int conj = direction > 0 ? 1 : 0;
+    int err = 0;
+    if (axis == 1) {
+        RowStoreNat<T> sp{reinterpret_cast<cx<T>*>(out), out_ld, to_map(*to), int(batch), conj, T(scale)};
+        if (lg >= 0) {
+            const cx<T>* tw = twiddles<T>(n, &err);
+            if (!tw) return err;
+            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), in_ld, to_map(*ti), int(batch), conj};
+            return launch_row_nat<T>(lg, lp, sp, tw, int(batch), st);
+        }
+        const cx<double>* tw = twiddles_f64(n, &err);
+        if (!tw) return err;
+        DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), in_ld, 1, to_map(*ti), int(batch), conj};
+        return direct_rows_out<T>(di, sp, tw, st);
+    }
+    // axis == 0: sequences are the `batch` columns
+    ColStoreNat<T> cs{};
+    cs.dst = out;
+    cs.ld = out_ld;
+    cs.ay = to_map(*to);
+    cs.ax = AxisMap{int(batch), int(batch), 0, 0};
+    cs.conj = conj;
+    cs.epilogue = EPI_NONE;
+    cs.scale = T(scale);
+    cs.weight = T(1);
+    cs.mul_kind = MUL_NONE;
+    cs.vec_ok = (sizeof(T) != 4 || ((out_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0))) ? 1 : 0;
+    if (lg >= 0) {
+        const cx<T>* tw = twiddles<T>(n, &err);
+        if (!tw) return err;
+        const int tc = col_tile_width_for(sizeof(T) == 4 ? PM_C64 : PM_C128, lg);
+        const int ntiles = int((batch + tc - 1) / tc);
+        const int vec = (sizeof(T) != 4 || ((in_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0))) ? 1 : 0;
+        ColLoadNat<T> cl{reinterpret_cast<const cx<T>*>(in), in_ld, to_map(*ti), int(batch), conj, vec};
+        return launch_col_nat<T>(lg, cl, cs, tw, ntiles, st);
+    }
+    const cx<double>* tw = twiddles_f64(n, &err);
+    if (!tw) return err;
+    DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), 1, in_ld, to_map(*ti), int(batch), conj};
+    return direct_cols<T>(di, cs, tw, st);
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+extern "C" {
+
+int pm_version(void) { return PM_VERSION; }
+const char* pm_last_error(void) { return g_err; }
+
+int pm_plan_prepare(int32_t dtype, int64_t n) {
+    if (n < 1) return fail(PM_ERR_ARG, "pm_plan_prepare: n < 1");
+    int err = 0;
+    if (engine_log2(n) < 0) return twiddles_f64(n, &err) ? 0 : err;
+    if (dtype == PM_C64) return twiddles<float>(n, &err) ? 0 : err;
+    if (dtype == PM_C128) return twiddles<double>(n, &err) ? 0 : err;
+    return fail(PM_ERR_ARG, "pm_plan_prepare: dtype");
+}
+
+void pm_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_tables) (void)hipFree(kv.second);
+    g_tables.clear();
+}
+
+size_t pm_fft2_workspace(const pm_fft2_desc* d) {
+    if (check_fft2(d)) return 0;
+    return plan_fft2(d).ws_bytes;
+}
+
+int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_fft2(d);
+    if (rc) return rc;
+    if (!in || !out) return fail(PM_ERR_ARG, "pm_fft2: null buffer");
+    const Fft2Plan p = plan_fft2(d);
+    if (!workspace || workspace_bytes < p.ws_bytes)
+        return fail(PM_ERR_WORKSPACE, "pm_fft2: workspace of %zu bytes required, %zu given", p.ws_bytes, workspace_bytes);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == PM_C64) return fft2_run<float>(d, p, in, out, workspace, st);
+    return fft2_run<double>(d, p, in, out, workspace, st);
+}
+
+int pm_fft2_time_passes(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes,
+                        int reps, double* ms, void* stream) {
+    if (!ms || reps < 1) return fail(PM_ERR_ARG, "pm_fft2_time_passes: bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    hipError_t he;
+    if ((he = hipEventCreate(&e0)) != hipSuccess) return int(he);
+    if ((he = hipEventCreate(&e1)) != hipSuccess) return int(he);
+    pm_fft2_desc dd = *d;
+    int rc = 0;
+    // full transform once so both passes have valid inputs, then each pass alone
+    dd.flags = 0;
+    rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
+    for (int pass = 0; pass < 2 && !rc; ++pass) {
+        dd.flags = pass == 0 ? PM_FLAG_PASS1_ONLY : PM_FLAG_PASS2_ONLY;
+        rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);   // warm
+        if (rc) break;
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < reps && !rc; ++i) rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        ms[pass] = double(t) / reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int pm_fft1(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in, const pm_axis* t_out,
+            double scale, const void* in, int64_t in_ld, void* out, int64_t out_ld, void* stream) {
+    if (!t_in || !t_out || !in || !out) return fail(PM_ERR_ARG, "pm_fft1: null argument");
+    if (dtype != PM_C64 && dtype != PM_C128) return fail(PM_ERR_ARG, "pm_fft1: dtype must be PM_C64 or PM_C128");
+    if (direction != 1 && direction != -1) return fail(PM_ERR_ARG, "pm_fft1: direction must be -1 or +1");
+    if (axis != 0 && axis != 1) return fail(PM_ERR_ARG, "pm_fft1: axis must be 0 or 1");
+    if (batch < 0) return fail(PM_ERR_ARG, "pm_fft1: batch < 0");
+    int rc;
+    if ((rc = check_axis(*t_in, "t_in")) || (rc = check_axis(*t_out, "t_out"))) return rc;
+    if (t_in->n != t_out->n) return fail(PM_ERR_ARG, "pm_fft1: t_in.n != t_out.n");
+    if (engine_log2(t_in->n) < 0 && t_in->n > (int64_t(1) << 15))
+        return fail(PM_ERR_UNSUPPORTED, "pm_fft1: length %lld not supported", (long long)t_in->n);
+    if (batch == 0) return 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == PM_C64) return fft1_run<float>(direction, axis, batch, t_in, t_out, scale, in, in_ld, out, out_ld, st);
+    return fft1_run<double>(direction, axis, batch, t_in, t_out, scale, in, in_ld, out, out_ld, st);
+}
+
+}  // extern "C"

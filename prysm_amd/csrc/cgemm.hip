@@ -1,0 +1,281 @@
+// Complex GEMM on the CDNA4 matrix cores -- the two dense contractions of the matrix DFT
+// (fttools.MDFT.__call__ / .adjoint, prysm/fttools.py:201-228).
+//
+//   C (M x N) = alpha * opA(A) (M x K) @ opB(B) (K x N)
+//
+// complex64  : v_mfma_f32_32x32x2_f32  (exact f32, 157.3 TF peak = the whole f32 rate of the chip)
+// complex128 : v_mfma_f64_16x16x4_f64
+//
+// A complex product is four real MFMA chains on split (planar) operands:
+//     Cr += Ar Br + (-Ai) Bi        Ci += Ar Bi + Ai Br
+// Global memory stays interleaved (re, im); the de-interleave, the transposes of opA / opB and the
+// conjugations happen once per K-tile while staging into LDS, where both operands are held
+// k-major ([k][row]) so each MFMA operand read is one conflict-free ds_read of consecutive words.
+//
+// Work decomposition for the MDFT shapes (e.g. 512 x 2048 x 2048 then 512 x 512 x 2048): 64 x 64
+// output tiles alone give only 256 / 64 workgroups for 256 CUs, so K is split (blockIdx.z) into
+// slabs reduced by a second tiny kernel in a FIXED order -- deterministic, unlike atomics.
+#include "pm_internal.h"
+
+namespace pm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct MfmaTraits;
+
+template <>
+struct MfmaTraits<float> {
+    static constexpr int TM = 32;   // MFMA tile edge
+    static constexpr int KS = 2;    // k per instruction
+    static constexpr int NR = 16;   // accumulator registers per lane
+    using acc_t = f32x16;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row_of(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+    static __device__ __forceinline__ int col_of(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int op_row(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int op_k(int lane) { return lane >> 5; }
+};
+
+template <>
+struct MfmaTraits<double> {
+    static constexpr int TM = 16;
+    static constexpr int KS = 4;
+    static constexpr int NR = 4;
+    using acc_t = f64x4;
+    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // f64 C/D layout differs from the f32 family: row = (lane >> 4) + 4 * reg
+    static __device__ __forceinline__ int row_of(int r, int lane) { return (lane >> 4) + 4 * r; }
+    static __device__ __forceinline__ int col_of(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int op_row(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int op_k(int lane) { return lane >> 4; }
+};
+
+// logical element (r, k) of op(X) where X is stored with leading dimension ld
+//   op 0: X[r][k]   op 1: conj X[r][k]   op 2: X[k][r]   op 3: conj X[k][r]
+template <typename T>
+__device__ __forceinline__ cx<T> fetch(const cx<T>* X, int64_t ld, int op, int64_t r, int64_t k, int64_t R, int64_t K) {
+    cx<T> v = {T(0), T(0)};
+    if (r < R && k < K) {
+        v = (op & 2) ? X[k * ld + r] : X[r * ld + k];
+        if (op & 1) v.y = -v.y;
+    }
+    return v;
+}
+
+template <typename T, int BM, int BN, int BK>
+__global__ void __launch_bounds__(256) cgemm_kernel(int opA, int opB, int64_t M, int64_t N, int64_t K, int64_t ksplit,
+                                                    T alpha, const cx<T>* __restrict__ A, int64_t lda,
+                                                    const cx<T>* __restrict__ B, int64_t ldb, cx<T>* __restrict__ C,
+                                                    int64_t ldc, int64_t slab_stride) {
+    using MT = MfmaTraits<T>;
+    constexpr int TM = MT::TM, KS = MT::KS, NR = MT::NR;
+    constexpr int WM = BM / 2, WN = BN / 2;      // 2 x 2 waves
+    constexpr int TI = WM / TM, TJ = WN / TM;    // MFMA tiles per wave
+    constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
+    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;   // complex elements staged per thread per K-tile
+    static_assert(EA >= 1 && EB >= 1, "tile too small for 256 threads");
+
+    __shared__ T As_r[2][BK][LDA_S], As_i[2][BK][LDA_S], Bs_r[2][BK][LDB_S], Bs_i[2][BK][LDB_S];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t m0 = int64_t(blockIdx.y) * BM, n0 = int64_t(blockIdx.x) * BN;
+    const int64_t kbeg = int64_t(blockIdx.z) * ksplit;
+    const int64_t kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
+
+    typename MT::acc_t acc_r[TI][TJ], acc_i[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                acc_r[i][j][r] = T(0);
+                acc_i[i][j][r] = T(0);
+            }
+
+    // staging map: the memory-contiguous index varies fastest across lanes
+    const bool a_kfast = !(opA & 2), b_kfast = (opB & 2) != 0;
+    cx<T> ra[EA], rb[EB];
+
+    auto g_load = [&](int64_t k0) {
+#pragma unroll
+        for (int s = 0; s < EA; ++s) {
+            const int e = tid + s * 256;
+            const int kk = a_kfast ? e % BK : e / BM, ii = a_kfast ? e / BK : e % BM;
+            ra[s] = fetch(A, lda, opA, m0 + ii, k0 + kk, M, kend);
+        }
+#pragma unroll
+        for (int s = 0; s < EB; ++s) {
+            const int e = tid + s * 256;
+            const int kk = b_kfast ? e % BK : e / BN, jj = b_kfast ? e / BK : e % BN;
+            // op(B) logical (k, j): stored B[k][j] (op 0/1) or B[j][k] (op 2/3)
+            cx<T> v = {T(0), T(0)};
+            const int64_t k = k0 + kk, j = n0 + jj;
+            if (k < kend && j < N) {
+                v = (opB & 2) ? B[j * ldb + k] : B[k * ldb + j];
+                if (opB & 1) v.y = -v.y;
+            }
+            rb[s] = v;
+        }
+    };
+    auto s_store = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < EA; ++s) {
+            const int e = tid + s * 256;
+            const int kk = a_kfast ? e % BK : e / BM, ii = a_kfast ? e / BK : e % BM;
+            As_r[buf][kk][ii] = ra[s].x;
+            As_i[buf][kk][ii] = ra[s].y;
+        }
+#pragma unroll
+        for (int s = 0; s < EB; ++s) {
+            const int e = tid + s * 256;
+            const int kk = b_kfast ? e % BK : e / BN, jj = b_kfast ? e / BK : e % BN;
+            Bs_r[buf][kk][jj] = rb[s].x;
+            Bs_i[buf][kk][jj] = rb[s].y;
+        }
+    };
+
+    int buf = 0;
+    if (kbeg < kend) {
+        g_load(kbeg);
+        s_store(0);
+    }
+    __syncthreads();
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) g_load(k0 + BK);   // prefetch the next K-tile into registers (in flight under the MFMAs)
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += KS) {
+            const int kk = ks + MT::op_k(lane);
+            T ar[TI], ai[TI], nai[TI], br[TJ], bi[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int row = wr * WM + i * TM + MT::op_row(lane);
+                ar[i] = As_r[buf][kk][row];
+                ai[i] = As_i[buf][kk][row];
+                nai[i] = -ai[i];
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int col = wc * WN + j * TM + MT::op_row(lane);
+                br[j] = Bs_r[buf][kk][col];
+                bi[j] = Bs_i[buf][kk][col];
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    acc_r[i][j] = MT::mfma(ar[i], br[j], acc_r[i][j]);
+                    acc_i[i][j] = MT::mfma(ar[i], bi[j], acc_i[i][j]);
+                    acc_r[i][j] = MT::mfma(nai[i], bi[j], acc_r[i][j]);
+                    acc_i[i][j] = MT::mfma(ai[i], br[j], acc_i[i][j]);
+                }
+        }
+        if (more) s_store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue: lanes of a row are adjacent columns -> contiguous interleaved stores
+    cx<T>* Cout = C + int64_t(blockIdx.z) * slab_stride;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int64_t row = m0 + wr * WM + i * TM + MT::row_of(r, lane);
+                const int64_t col = n0 + wc * WN + j * TM + MT::col_of(lane);
+                if (row < M && col < N) Cout[row * ldc + col] = {acc_r[i][j][r] * alpha, acc_i[i][j][r] * alpha};
+            }
+}
+
+template <typename T>
+__global__ void splitk_reduce_kernel(int64_t M, int64_t N, int S, T alpha, const cx<T>* __restrict__ slabs,
+                                     int64_t slab_stride, cx<T>* __restrict__ C, int64_t ldc) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= M * N) return;
+    const int64_t r = g / N, c = g % N;
+    T sr = T(0), si = T(0);
+    for (int s = 0; s < S; ++s) {   // fixed order: bitwise reproducible
+        const cx<T> v = slabs[int64_t(s) * slab_stride + g];
+        sr += v.x;
+        si += v.y;
+    }
+    C[r * ldc + c] = {sr * alpha, si * alpha};
+}
+
+size_t cgemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int* S_out) {
+    const int BM = 64, BN = 64, BK = 16;
+    const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int S = 1;
+    // aim for >= 2 workgroups per CU (512) while keeping >= 8 K-tiles per slab
+    while (tiles * S < 512 && (K / (S * 2)) >= 8 * BK && S < 32) S *= 2;
+    if (S_out) *S_out = S;
+    if (S == 1) return 0;
+    return size_t(S) * size_t(M) * size_t(N) * (dtype == PM_C64 ? 8 : 16);
+}
+
+template <typename T>
+int cgemm_ws(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, const cx<T>* A, int64_t lda,
+             const cx<T>* B, int64_t ldb, cx<T>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int BM = 64, BN = 64, BK = sizeof(T) == 4 ? 16 : 8;   // 33 KiB of LDS either way
+    int S = 1;
+    const size_t need = cgemm_workspace_bytes(sizeof(T) == 4 ? PM_C64 : PM_C128, M, N, K, &S);
+    if (S > 1 && (!ws || ws_bytes < need)) S = 1;   // no workspace: fall back to unsplit (still correct)
+    int64_t ksplit = (K + S - 1) / S;
+    ksplit = (ksplit + BK - 1) / BK * BK;
+    if (ksplit < BK) ksplit = BK;
+    S = int((K + ksplit - 1) / ksplit);
+    if (S < 1) S = 1;
+    dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)S);
+    if (S == 1) {
+        hipLaunchKernelGGL((cgemm_kernel<T, BM, BN, BK>), grid, dim3(256), 0, st, opA, opB, M, N, K, ksplit, T(alpha), A, lda, B,
+                           ldb, C, ldc, int64_t(0));
+        return int(hipGetLastError());
+    }
+    cx<T>* slabs = reinterpret_cast<cx<T>*>(ws);
+    hipLaunchKernelGGL((cgemm_kernel<T, BM, BN, BK>), grid, dim3(256), 0, st, opA, opB, M, N, K, ksplit, T(1), A, lda, B, ldb,
+                       slabs, N, M * N);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return int(e);
+    const int64_t total = M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, S, T(alpha),
+                       slabs, M * N, C, ldc);
+    return int(hipGetLastError());
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+extern "C" {
+
+size_t pm_cgemm_workspace(int32_t dtype, int64_t M, int64_t N, int64_t K) {
+    return cgemm_workspace_bytes(dtype, M, N, K, nullptr);
+}
+
+int pm_cgemm(int32_t dtype, int32_t opA, int32_t opB, int64_t M, int64_t N, int64_t K, double alpha, const void* A,
+             int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, void* workspace, size_t workspace_bytes,
+             void* stream) {
+    if (!A || !B || !C) return fail(PM_ERR_ARG, "pm_cgemm: null buffer");
+    if (M < 0 || N < 0 || K < 0 || opA < 0 || opA > 3 || opB < 0 || opB > 3) return fail(PM_ERR_ARG, "pm_cgemm: bad argument");
+    if (M == 0 || N == 0) return 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == PM_C64)
+        return cgemm_ws<float>(opA, opB, M, N, K, alpha, (const cx<float>*)A, lda, (const cx<float>*)B, ldb, (cx<float>*)C, ldc,
+                               workspace, workspace_bytes, st);
+    if (dtype == PM_C128)
+        return cgemm_ws<double>(opA, opB, M, N, K, alpha, (const cx<double>*)A, lda, (const cx<double>*)B, ldb, (cx<double>*)C,
+                                ldc, workspace, workspace_bytes, st);
+    return fail(PM_ERR_ARG, "pm_cgemm: dtype must be PM_C64 or PM_C128");
+}
+
+}  // extern "C"

@@ -1,0 +1,285 @@
+// Register-resident Stockham FFT engine for gfx950 (MI355X).
+//
+// One workgroup transforms SEQ_PER_WG sequences of length N = 2^LOGN.  Every
+// thread owns P = min(16, N) points of E sequences and keeps them in VGPRs for
+// the whole transform; LDS (160 KiB / CU) is used only as an exchange fabric
+// between radix-P stages, one "chunk" (one of the thread's E sequences, or the
+// real / imaginary halves when COMP == 2) at a time.  That is what lets one
+// workgroup hold 256 KiB of field data (8 columns x 4096 rows of complex64, or
+// 4 columns of complex128) on a CU whose LDS is only 160 KiB: the 512 KiB VGPR
+// file is the big on-chip store on CDNA4, not the LDS.
+//
+// Data layout invariant: thread slot t of a sequence holds
+//     v[m] = x[t + m * N/P],  m = 0..P-1
+// before the first stage and after the last one (natural order in, natural
+// order out -- Stockham autosort), so a second transform (e.g. the inverse of
+// the angular-spectrum step) can start from the registers of the first.
+//
+// Stage s (radix R, Ns = P^s):  butterfly j = t + q*N/P (q < P/R) takes
+// x[j + k*N/R] = v[k*(P/R) + q], multiplies by W_N^{(j mod Ns) * k * N/(Ns R)},
+// applies a DFT-R and scatters to y[(j/Ns) Ns R + (j mod Ns) + k Ns].
+//
+// Everything below the kernels is __host__ __device__ so that
+// tools/emu_fft.cpp can run the exact index arithmetic on the CPU (this
+// container has no GPU); it is test scaffolding for the kernel, not a product
+// code path.
+#pragma once
+#include "pm_common.h"
+
+namespace pm {
+
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
+
+template <typename T_, int LOGN_, int CI_, int E_, int BO_, int COMP_>
+struct FftCfg {
+    using T = T_;
+    static constexpr int LOGN = LOGN_;
+    static constexpr int N = 1 << LOGN_;
+    static constexpr int P = N >= 16 ? 16 : N;          // points per thread per sequence
+    static constexpr int LOGP = ilog2(P);
+    static constexpr int TPS = N / P;                    // threads per sequence
+    static constexpr int CI = CI_;                       // sequences interleaved over adjacent lanes
+    static constexpr int E = E_;                         // adjacent sequences owned by one thread
+    static constexpr int BO = BO_;                       // outer sequence groups per workgroup
+    static constexpr int COMP = COMP_;                   // 1: exchange complex, 2: exchange re then im
+    static constexpr int NT = CI * TPS * BO;             // threads per workgroup
+    static constexpr int SEQ_PER_WG = CI * E * BO;
+    static constexpr int NSTAGE = (LOGN + LOGP - 1) / LOGP;
+    static constexpr int PADN = N + (N >> 4);            // +1 element every 16: conflict-free stride-16 scatter
+    static constexpr int LDS_ELEMS = BO * PADN * CI;     // per exchange chunk
+    static constexpr size_t LDS_BYTES =
+        NSTAGE > 1 ? size_t(LDS_ELEMS) * sizeof(T_) * (COMP_ == 1 ? 2 : 1) : 0;
+    static constexpr int radix(int s) { return (s < LOGN / LOGP) ? P : (1 << (LOGN % LOGP)); }
+    static constexpr int ns(int s) { return ipow(P, s); }
+};
+
+struct ThreadPos {
+    int cl, t, bo;
+};
+template <typename C>
+PM_HD ThreadPos thread_pos(int tid) {
+    return {tid % C::CI, (tid / C::CI) % C::TPS, tid / (C::CI * C::TPS)};
+}
+
+// ---------------------------------------------------------------------------
+// small DFTs, forward (exp(-2 pi i nk/R)), natural order in and out
+// ---------------------------------------------------------------------------
+template <typename T>
+PM_HD void dft2(cx<T>& a, cx<T>& b) {
+    cx<T> t = a;
+    a = t + b;
+    b = t - b;
+}
+
+template <typename T>
+PM_HD void dft4(cx<T>& a0, cx<T>& a1, cx<T>& a2, cx<T>& a3) {
+    cx<T> s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    cx<T> m = mul_mi(d13);  // -i (a1 - a3)
+    a0 = s02 + s13;
+    a2 = s02 - s13;
+    a1 = d02 + m;
+    a3 = d02 - m;
+}
+
+template <typename T, int R>
+struct Dft;
+
+template <typename T>
+struct Dft<T, 1> {
+    static PM_HD void run(cx<T>*) {}
+};
+template <typename T>
+struct Dft<T, 2> {
+    static PM_HD void run(cx<T>* a) { dft2(a[0], a[1]); }
+};
+template <typename T>
+struct Dft<T, 4> {
+    static PM_HD void run(cx<T>* a) { dft4(a[0], a[1], a[2], a[3]); }
+};
+template <typename T>
+struct Dft<T, 8> {
+    static PM_HD void run(cx<T>* a) {
+        const T r = T(0.70710678118654752440);
+        dft4(a[0], a[2], a[4], a[6]);  // even samples -> E[k] in a[0],a[2],a[4],a[6]
+        dft4(a[1], a[3], a[5], a[7]);  // odd samples  -> O[k] in a[1],a[3],a[5],a[7]
+        cx<T> o0 = a[1];
+        cx<T> o1 = {r * (a[3].x + a[3].y), r * (a[3].y - a[3].x)};    // * w8^1
+        cx<T> o2 = mul_mi(a[5]);                                        // * w8^2
+        cx<T> o3 = {r * (a[7].y - a[7].x), -r * (a[7].x + a[7].y)};   // * w8^3
+        cx<T> e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
+        a[0] = e0 + o0; a[4] = e0 - o0;
+        a[1] = e1 + o1; a[5] = e1 - o1;
+        a[2] = e2 + o2; a[6] = e2 - o2;
+        a[3] = e3 + o3; a[7] = e3 - o3;
+    }
+};
+template <typename T>
+struct Dft<T, 16> {
+    static PM_HD void run(cx<T>* a) {
+        const T c1 = T(0.92387953251128673848), s1 = T(0.38268343236508978178);
+        const T r = T(0.70710678118654752440);
+        // step 1: DFT-4 over n1 for each n2; a[n2 + 4 k1] = b[n2][k1]
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) dft4(a[n2], a[n2 + 4], a[n2 + 8], a[n2 + 12]);
+        // step 2: b[n2][k1] *= w16^(n2 k1)
+        a[5] = cmul(a[5], cx<T>{c1, -s1});     // n2=1,k1=1 : w^1
+        a[9] = cmul(a[9], cx<T>{r, -r});       // n2=1,k1=2 : w^2
+        a[13] = cmul(a[13], cx<T>{s1, -c1});   // n2=1,k1=3 : w^3
+        a[6] = cmul(a[6], cx<T>{r, -r});       // n2=2,k1=1 : w^2
+        a[10] = mul_mi(a[10]);                 // n2=2,k1=2 : w^4
+        a[14] = cmul(a[14], cx<T>{-r, -r});    // n2=2,k1=3 : w^6
+        a[7] = cmul(a[7], cx<T>{s1, -c1});     // n2=3,k1=1 : w^3
+        a[11] = cmul(a[11], cx<T>{-r, -r});    // n2=3,k1=2 : w^6
+        a[15] = cmul(a[15], cx<T>{-c1, s1});   // n2=3,k1=3 : w^9
+        // step 3: DFT-4 over n2 for each k1; a[4 k1 + k2] = X[k1 + 4 k2]
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) dft4(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
+        // transpose the 4x4 so that a[k] = X[k]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = i + 1; jj < 4; ++jj) {
+                cx<T> tmp = a[4 * i + jj];
+                a[4 * i + jj] = a[4 * jj + i];
+                a[4 * jj + i] = tmp;
+            }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// one radix-R stage on the registers of a thread (all E sequences share the
+// twiddles: in column mode they are adjacent columns with the same row index)
+// ---------------------------------------------------------------------------
+template <typename C, int S>
+PM_HD void stage_compute(cx<typename C::T> (&v)[C::E][C::P], int t, const cx<typename C::T>* __restrict__ tw) {
+    using T = typename C::T;
+    constexpr int R = C::radix(S), NS = C::ns(S), Q = C::P / R, NP = C::TPS;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if constexpr (S > 0 && R > 1) {
+            const int j = t + q * NP;
+            const int base = (j & (NS - 1)) * (C::N / (NS * R));
+            if constexpr (R == 2) {
+                const cx<T> w1 = tw[base];
+#pragma unroll
+                for (int e = 0; e < C::E; ++e) v[e][Q + q] = cmul(v[e][Q + q], w1);
+            } else {
+                // R in {4, 8, 16}: W^(4a+b) = W^(4a) W^b, a < R/4, b < 4 -> R/4 - 1 + 3 table loads
+                cx<T> wa[(R / 4 > 1) ? R / 4 : 1];
+#pragma unroll
+                for (int a = 1; a < R / 4; ++a) {
+                    wa[a] = tw[4 * a * base];
+#pragma unroll
+                    for (int e = 0; e < C::E; ++e) v[e][(4 * a) * Q + q] = cmul(v[e][(4 * a) * Q + q], wa[a]);
+                }
+#pragma unroll
+                for (int b = 1; b < 4; ++b) {
+                    const cx<T> wb = tw[b * base];
+#pragma unroll
+                    for (int e = 0; e < C::E; ++e) v[e][b * Q + q] = cmul(v[e][b * Q + q], wb);
+#pragma unroll
+                    for (int a = 1; a < R / 4; ++a) {
+                        const cx<T> wab = cmul(wa[a], wb);
+#pragma unroll
+                        for (int e = 0; e < C::E; ++e)
+                            v[e][(4 * a + b) * Q + q] = cmul(v[e][(4 * a + b) * Q + q], wab);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) {
+            cx<T> a[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) a[k] = v[e][k * Q + q];
+            Dft<T, R>::run(a);
+#pragma unroll
+            for (int k = 0; k < R; ++k) v[e][k * Q + q] = a[k];
+        }
+    }
+}
+
+template <typename C>
+PM_HD int lds_addr(int bo, int cl, int idx) {
+    return bo * (C::PADN * C::CI) + (idx + (idx >> 4)) * C::CI + cl;
+}
+
+// scatter the outputs of stage S (chunk = sequence e, component comp) into LDS.
+// pad(ex + k*NS) == pad(ex) + k*(NS + NS/16) for NS >= 16 (ex is a multiple of 16 when NS == 1), so the
+// R scatter addresses are one base + compile-time offsets (ds_write immediates).
+template <typename C, int S, typename LT>
+PM_HD void exch_write(const cx<typename C::T> (&v)[C::E][C::P], int e, int comp, ThreadPos pos, LT* lds) {
+    constexpr int R = C::radix(S), NS = C::ns(S), Q = C::P / R, NP = C::TPS;
+    constexpr int KSTEP = (NS >= 16 ? NS + NS / 16 : NS) * C::CI;
+    constexpr bool AFFINE = (NS >= 16) || (R == 16);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int j = pos.t + q * NP;
+        const int ex = (j / NS) * (NS * R) + (j & (NS - 1));
+        const int a0 = lds_addr<C>(pos.bo, pos.cl, ex);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int a = AFFINE ? a0 + k * KSTEP : lds_addr<C>(pos.bo, pos.cl, ex + k * NS);
+            if constexpr (C::COMP == 1)
+                lds[a] = v[e][k * Q + q];
+            else
+                lds[a] = comp == 0 ? v[e][k * Q + q].x : v[e][k * Q + q].y;
+        }
+    }
+}
+
+// gather v[m] = y[t + m N/P]; pad(t + m*TPS) == pad(t) + m*(TPS + TPS/16) when 16 | TPS
+template <typename C, typename LT>
+PM_HD void exch_read(cx<typename C::T> (&v)[C::E][C::P], int e, int comp, ThreadPos pos, const LT* lds) {
+    constexpr bool AFFINE = (C::TPS % 16) == 0;
+    constexpr int MSTEP = (C::TPS + C::TPS / 16) * C::CI;
+    const int a0 = lds_addr<C>(pos.bo, pos.cl, pos.t);
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const int a = AFFINE ? a0 + m * MSTEP : lds_addr<C>(pos.bo, pos.cl, pos.t + m * C::TPS);
+        if constexpr (C::COMP == 1) {
+            v[e][m] = lds[a];
+        } else {
+            if (comp == 0)
+                v[e][m].x = lds[a];
+            else
+                v[e][m].y = lds[a];
+        }
+    }
+}
+
+template <typename C>
+struct LdsType {
+    using type = cx<typename C::T>;
+};
+template <typename T, int L, int CI, int E, int BO>
+struct LdsType<FftCfg<T, L, CI, E, BO, 2>> {
+    using type = T;
+};
+
+#if defined(__HIPCC__)
+// full transform of the registers of this thread; all threads of the workgroup must call it
+template <typename C, int S = 0>
+__device__ __forceinline__ void fft_run(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw,
+                                        const cx<typename C::T>* __restrict__ tw) {
+    using LT = typename LdsType<C>::type;
+    LT* lds = reinterpret_cast<LT*>(lds_raw);
+    stage_compute<C, S>(v, pos.t, tw);
+    if constexpr (S + 1 < C::NSTAGE) {
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) {
+#pragma unroll
+            for (int comp = 0; comp < C::COMP; ++comp) {
+                exch_write<C, S>(v, e, comp, pos, lds);
+                __syncthreads();
+                exch_read<C>(v, e, comp, pos, lds);
+                __syncthreads();
+            }
+        }
+        fft_run<C, S + 1>(v, pos, lds_raw, tw);
+    }
+}
+#endif
+
+}  // namespace pm

@@ -1,0 +1,394 @@
+// Global-memory loaders / storers for the FFT engine.
+//
+// "Row" mode: the transform axis is contiguous in memory, one sequence per row
+// (CI = E = 1).  "Col" mode: the transform axis is strided; a workgroup owns a
+// tile of TC = CI*E adjacent columns so that every row of the tile is one
+// TC*sizeof(complex) = 64 B segment (complex64: 8 columns, complex128: 4).
+//
+// The private intermediate of the 2-D transform is stored TILED:
+//     W[tile = c / TC][row q][c % TC]
+// so the column pass streams one contiguous block per workgroup, and the row
+// pass writes 64 B segments whose 128 B line partner (row q^1) is written by
+// the same or an adjacent workgroup on the same XCD (merged in that XCD's L2).
+//
+// Register discipline: a thread's P points sit at logical indices t + m*TPS.
+// The rotation of fftshift / ifftshift is by N/2 = (P/2)*TPS, i.e. a rotation
+// of the REGISTER SLOT index m by P/2 -- resolved at compile time (ROT
+// template argument), so addresses stay affine (one base + constant offsets)
+// and no per-element modulo arithmetic is executed.  Arbitrary rotations take
+// the generic (ROT = -1) path.
+//
+// All functions are __host__ __device__: tools/emu_fft.cpp runs them on the CPU.
+#pragma once
+#include "fft_engine.h"
+
+namespace pm {
+
+enum : int { EPI_NONE = 0, EPI_ABS2 = 1, EPI_ABS2_ACCUM = 2 };
+enum : int { MUL_NONE = 0, MUL_FULL = 1, MUL_SEPARABLE = 2 };
+
+template <typename T>
+struct RowLoadNat {
+    const cx<T>* src;
+    int64_t ld;     // elements between consecutive sequences
+    AxisMap ax;     // along the transform axis
+    int nseq;       // number of sequences (memory rows)
+    int conj;
+};
+
+template <typename T>
+struct RowStoreTiled {
+    cx<T>* dst;
+    int nseq;       // rows of the intermediate
+    int log_tc;     // log2(tile width)
+};
+
+template <typename T>
+struct RowStoreNat {
+    cx<T>* dst;
+    int64_t ld;
+    AxisMap ax;
+    int nseq;
+    int conj;
+    T scale;
+};
+
+template <typename T>
+struct ColLoadTiled {
+    const cx<T>* src;
+    int nrows;      // rows stored in the intermediate (memory rows)
+    AxisMap ay;     // logical row -> stored row
+    int ntiles;
+};
+
+template <typename T>
+struct ColLoadNat {
+    const cx<T>* src;
+    int64_t ld;
+    AxisMap ay;     // along the transform axis (rows)
+    int ncols;      // number of columns in memory
+    int conj;
+    int vec_ok;     // base and ld allow 16-byte loads of column pairs
+};
+
+template <typename T>
+struct ColStoreNat {
+    void* dst;      // cx<T>* or T* (abs2 epilogues)
+    int64_t ld;
+    AxisMap ay;     // output rows (shift / crop)
+    AxisMap ax;     // output columns (shift / crop)
+    int conj;
+    int epilogue;
+    T scale;        // multiplies the complex value
+    T weight;       // EPI_ABS2_ACCUM: dst += weight * |scale * v|^2
+    int mul_kind;   // multiplier indexed by the LOGICAL (unshifted) bin (row k, col c)
+    int mul_conj;
+    const cx<T>* mul;     // MUL_FULL: mul[k*mul_ld + c]; MUL_SEPARABLE: row factor hy[k]
+    const cx<T>* mul_x;   // MUL_SEPARABLE: column factor hx[c]
+    int64_t mul_ld;
+    int vec_ok;
+};
+
+// slot rotation helper: memory index (before the window offset) of register slot m.
+//   ROT >= 0 : shift == ROT * TPS  ->  p = t + ((m + ROT) mod P) * TPS      (compile-time slot)
+//   ROT <  0 : generic             ->  p = (t + m*TPS + shift) mod N
+template <typename C, int ROT>
+PM_HD int slot_pos(int t, int m, int shift) {
+    if constexpr (ROT >= 0) {
+        return t + ((m + ROT) & (C::P - 1)) * C::TPS;
+    } else {
+        int p = t + m * C::TPS + shift;
+        if (p >= C::N) p -= C::N;
+        return p;
+    }
+}
+
+// classify a shift for length-N transforms of config C: returns ROT (>= 0) or -1
+template <typename C>
+PM_HD int rot_of(int shift) {
+    if (shift == 0) return 0;
+    if (C::P >= 2 && shift == C::N / 2) return C::P / 2;
+    return -1;
+}
+
+template <typename T>
+struct alignas(16) Vec4 {
+    T a, b, c, d;
+};
+
+// ------------------------------------------------------------------ row mode
+template <typename C, int ROT>
+PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
+                    cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    static_assert(C::CI == 1 && C::E == 1, "row mode");
+    const int seq = blk * C::BO + pos.bo;
+    const bool ok = seq < p.nseq;
+    const cx<T>* row = p.src + int64_t(ok ? seq : 0) * p.ld - p.ax.off;
+    const int lo = p.ax.off, hi = ok ? p.ax.off + p.ax.len : -1;
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const int pp = slot_pos<C, ROT>(pos.t, m, p.ax.shift);
+        cx<T> val = {T(0), T(0)};
+        if (pp >= lo && pp < hi) val = row[pp];
+        v[0][m] = val;
+    }
+    if (p.conj) {
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) v[0][m].y = -v[0][m].y;
+    }
+}
+
+template <typename C>
+PM_HD void load(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
+    const int rot = rot_of<C>(p.ax.shift);
+    if (rot == 0)
+        load_rot<C, 0>(p, blk, pos, v);
+    else if (rot > 0)
+        load_rot<C, (C::P >= 2 ? C::P / 2 : 0)>(p, blk, pos, v);
+    else
+        load_rot<C, -1>(p, blk, pos, v);
+}
+
+template <typename C>
+PM_HD void store(const RowStoreTiled<typename C::T>& p, int blk, ThreadPos pos,
+                 const cx<typename C::T> (&v)[C::E][C::P]) {
+    const int seq = blk * C::BO + pos.bo;
+    if (seq >= p.nseq) return;
+    const int tcm = (1 << p.log_tc) - 1;
+    // element (seq, c) -> ((c >> ltc) * nseq + seq) << ltc  +  (c & tcm); c = t + m*TPS
+    if (C::TPS > tcm) {
+        // TPS is a multiple of the tile width: tile index and in-tile column separate cleanly
+        const int64_t base = ((int64_t(pos.t >> p.log_tc) * p.nseq + seq) << p.log_tc) + (pos.t & tcm);
+        const int64_t step = int64_t(C::TPS >> p.log_tc) * p.nseq << p.log_tc;
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) p.dst[base + m * step] = v[0][m];
+    } else {
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) {
+            const int c = pos.t + m * C::TPS;
+            const int64_t a = ((int64_t(c >> p.log_tc) * p.nseq + seq) << p.log_tc) + (c & tcm);
+            p.dst[a] = v[0][m];
+        }
+    }
+}
+
+template <typename C, int ROT>
+PM_HD void store_rot(const RowStoreNat<typename C::T>& p, int blk, ThreadPos pos,
+                     const cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    const int seq = blk * C::BO + pos.bo;
+    if (seq >= p.nseq) return;
+    cx<T>* row = p.dst + int64_t(seq) * p.ld - p.ax.off;
+    const int lo = p.ax.off, hi = p.ax.off + p.ax.len;
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const int pp = slot_pos<C, ROT>(pos.t, m, p.ax.shift);
+        if (pp < lo || pp >= hi) continue;
+        cx<T> val = cscale(v[0][m], p.scale);
+        if (p.conj) val.y = -val.y;
+        row[pp] = val;
+    }
+}
+
+template <typename C>
+PM_HD void store(const RowStoreNat<typename C::T>& p, int blk, ThreadPos pos,
+                 const cx<typename C::T> (&v)[C::E][C::P]) {
+    const int rot = rot_of<C>(p.ax.shift);
+    if (rot == 0)
+        store_rot<C, 0>(p, blk, pos, v);
+    else if (rot > 0)
+        store_rot<C, (C::P >= 2 ? C::P / 2 : 0)>(p, blk, pos, v);
+    else
+        store_rot<C, -1>(p, blk, pos, v);
+}
+
+// ------------------------------------------------------------------ col mode
+// tile handled by (blk, bo): XCD-aware pairing so that workgroups g and g+8 (same XCD,
+// dispatched back to back) own the two 64 B halves of the same 128 B lines.
+PM_HD int pair_remap(int g, int total) {
+    if ((total & 15) != 0) return g;
+    const int xcd = g & 7, idx = g >> 3;
+    return (((idx >> 1) << 3) + xcd) * 2 + (idx & 1);
+}
+
+template <typename C, int ROT>
+PM_HD void load_rot(const ColLoadTiled<typename C::T>& p, int tile, ThreadPos pos,
+                    cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    constexpr int TC = C::CI * C::E;
+    const bool ok = tile < p.ntiles;
+    // element (row q, col) of the tile at base[(q)*TC + col]; q = p - off
+    const cx<T>* base = p.src + (int64_t(ok ? tile : 0) * p.nrows - p.ay.off) * TC + pos.cl * C::E;
+    const int lo = p.ay.off, hi = ok ? p.ay.off + p.ay.len : -1;
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const int pp = slot_pos<C, ROT>(pos.t, m, p.ay.shift);
+        if (pp >= lo && pp < hi) {
+            const cx<T>* a = base + int64_t(pp) * TC;
+            if constexpr (C::E == 2 && sizeof(T) == 4) {
+                const Vec4<T> w = *reinterpret_cast<const Vec4<T>*>(a);  // two adjacent complex64 columns
+                v[0][m] = {w.a, w.b};
+                v[1][m] = {w.c, w.d};
+            } else {
+#pragma unroll
+                for (int e = 0; e < C::E; ++e) v[e][m] = a[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) v[e][m] = {T(0), T(0)};
+        }
+    }
+}
+
+template <typename C>
+PM_HD void load(const ColLoadTiled<typename C::T>& p, int tile, ThreadPos pos,
+                cx<typename C::T> (&v)[C::E][C::P]) {
+    const int rot = rot_of<C>(p.ay.shift);
+    if (rot == 0)
+        load_rot<C, 0>(p, tile, pos, v);
+    else if (rot > 0)
+        load_rot<C, (C::P >= 2 ? C::P / 2 : 0)>(p, tile, pos, v);
+    else
+        load_rot<C, -1>(p, tile, pos, v);
+}
+
+template <typename C>
+PM_HD void load(const ColLoadNat<typename C::T>& p, int tile, ThreadPos pos,
+                cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    constexpr int TC = C::CI * C::E;
+    const int col0 = tile * TC + pos.cl * C::E;
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const int q = p.ay.map(pos.t + m * C::TPS);
+        const cx<T>* a = p.src + int64_t(q >= 0 ? q : 0) * p.ld + col0;
+        bool done = false;
+        if constexpr (C::E == 2 && sizeof(T) == 4) {
+            if (p.vec_ok && q >= 0 && col0 + 1 < p.ncols) {
+                const Vec4<T> w = *reinterpret_cast<const Vec4<T>*>(a);
+                v[0][m] = {w.a, w.b};
+                v[1][m] = {w.c, w.d};
+                done = true;
+            }
+        }
+        if (!done) {
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) {
+                cx<T> val = {T(0), T(0)};
+                if (q >= 0 && col0 + e < p.ncols) val = a[e];
+                v[e][m] = val;
+            }
+        }
+        if (p.conj) {
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) v[e][m].y = -v[e][m].y;
+        }
+    }
+}
+
+// one output element (row bin k, column bin c) through the full epilogue -- shared by the
+// generic store path and the direct-DFT kernels
+template <typename T>
+PM_HD void store_one(const ColStoreNat<T>& p, int k, int c, cx<T> x) {
+    const int qy = p.ay.map(k);
+    const int qx = p.ax.map(c);
+    if (qy < 0 || qx < 0) return;
+    x = cscale(x, p.scale);
+    if (p.conj) x.y = -x.y;
+    if (p.mul_kind == MUL_FULL) {
+        const cx<T> h = p.mul[int64_t(k) * p.mul_ld + c];
+        x = p.mul_conj ? cmulc(x, h) : cmul(x, h);
+    } else if (p.mul_kind == MUL_SEPARABLE) {
+        const cx<T> h = cmul(p.mul[k], p.mul_x[c]);
+        x = p.mul_conj ? cmulc(x, h) : cmul(x, h);
+    }
+    if (p.epilogue == EPI_NONE) {
+        reinterpret_cast<cx<T>*>(p.dst)[int64_t(qy) * p.ld + qx] = x;
+    } else {
+        T* o = reinterpret_cast<T*>(p.dst) + int64_t(qy) * p.ld + qx;
+        const T i2 = x.x * x.x + x.y * x.y;
+        if (p.epilogue == EPI_ABS2)
+            *o = i2;
+        else
+            *o += p.weight * i2;
+    }
+}
+
+// fast path: no multiplier, full-width aligned columns (no crop along x, even rotation), complex or
+// |.|^2 output.  Row window handled by a compare; addresses affine in the slot index.
+template <typename C, int ROT>
+PM_HD void store_fast(const ColStoreNat<typename C::T>& p, int tile, ThreadPos pos,
+                      const cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    constexpr int TC = C::CI * C::E;
+    const int col0 = tile * TC + pos.cl * C::E;
+    if (col0 >= p.ax.n) return;
+    int qx = col0 + p.ax.shift;              // columns: rotation only (len == n, off == 0)
+    if (qx >= p.ax.n) qx -= p.ax.n;
+    const int lo = p.ay.off, hi = p.ay.off + p.ay.len;
+    if (p.epilogue == EPI_NONE) {
+        cx<T>* base = reinterpret_cast<cx<T>*>(p.dst) - int64_t(p.ay.off) * p.ld + qx;
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) {
+            const int pp = slot_pos<C, ROT>(pos.t, m, p.ay.shift);
+            if (pp < lo || pp >= hi) continue;
+            cx<T>* a = base + int64_t(pp) * p.ld;
+            cx<T> val[C::E];
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) {
+                val[e] = cscale(v[e][m], p.scale);
+                if (p.conj) val[e].y = -val[e].y;
+            }
+            if constexpr (C::E == 2 && sizeof(T) == 4) {
+                *reinterpret_cast<Vec4<T>*>(a) = Vec4<T>{val[0].x, val[0].y, val[1].x, val[1].y};
+            } else {
+#pragma unroll
+                for (int e = 0; e < C::E; ++e) a[e] = val[e];
+            }
+        }
+    } else {
+        T* base = reinterpret_cast<T*>(p.dst) - int64_t(p.ay.off) * p.ld + qx;
+        const T s2 = p.scale * p.scale;
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) {
+            const int pp = slot_pos<C, ROT>(pos.t, m, p.ay.shift);
+            if (pp < lo || pp >= hi) continue;
+            T* a = base + int64_t(pp) * p.ld;
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) {
+                const T i2 = (v[e][m].x * v[e][m].x + v[e][m].y * v[e][m].y) * s2;
+                if (p.epilogue == EPI_ABS2)
+                    a[e] = i2;
+                else
+                    a[e] += p.weight * i2;
+            }
+        }
+    }
+}
+
+template <typename C>
+PM_HD void store(const ColStoreNat<typename C::T>& p, int tile, ThreadPos pos,
+                 const cx<typename C::T> (&v)[C::E][C::P]) {
+    constexpr int TC = C::CI * C::E;
+    const int rot = rot_of<C>(p.ay.shift);
+    const bool fast = p.mul_kind == MUL_NONE && p.vec_ok && p.ax.off == 0 && p.ax.len == p.ax.n &&
+                      (p.ax.n % TC) == 0 && (p.ax.shift % TC) == 0 && rot >= 0;
+    if (fast) {
+        if (rot == 0)
+            store_fast<C, 0>(p, tile, pos, v);
+        else
+            store_fast<C, (C::P >= 2 ? C::P / 2 : 0)>(p, tile, pos, v);
+        return;
+    }
+    const int col0 = tile * TC + pos.cl * C::E;
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const int k = pos.t + m * C::TPS;
+#pragma unroll
+        for (int e = 0; e < C::E; ++e)
+            if (col0 + e < p.ax.n) store_one(p, k, col0 + e, v[e][m]);
+    }
+}
+
+}  // namespace pm

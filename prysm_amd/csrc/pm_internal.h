@@ -1,0 +1,54 @@
+// Internal host-side declarations shared by the translation units of libprysm_amd.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/prysm_amd.h"
+#include "fft_io.h"
+
+namespace pm {
+
+// error plumbing (capi.hip)
+int fail(int code, const char* fmt, ...);
+inline int hip_rc(hipError_t e) { return int(e); }
+
+// plan cache (capi.hip): W_n^k = exp(-2 pi i k / n), k in [0, n), rounded once from long double
+template <typename T> const cx<T>* twiddles(int64_t n, int* err);
+const cx<double>* twiddles_f64(int64_t n, int* err);
+
+// direct (any length) DFT, dft_direct.hip.  One transform axis with an input AxisMap, `nseq`
+// sequences; element (seq, q) at src[seq*s_seq + q*s_i].
+template <typename T>
+struct DirectIn {
+    const cx<T>* src;
+    int64_t s_seq, s_i;
+    AxisMap ax;
+    int nseq;
+    int conj;
+};
+// rows: out[seq*ld + k] (natural complex intermediate, k in [0,n))
+template <typename T>
+int direct_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, const cx<double>* tw, hipStream_t st);
+// rows with full output treatment (1-D API): AxisMap / scale / conj on the output
+template <typename T>
+int direct_rows_out(const DirectIn<T>& in, const RowStoreNat<T>& out, const cx<double>* tw, hipStream_t st);
+// columns: sequences are columns (seq = column index c), output through the ColStoreNat epilogue
+template <typename T>
+int direct_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, const cx<double>* tw, hipStream_t st);
+
+// engine launchers (fft_row_*.hip / fft_col_*.hip)
+template <typename T> int launch_row_tiled(int logn, const RowLoadNat<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, hipStream_t);
+template <typename T> int launch_row_nat(int logn, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t);
+template <typename T> int launch_col_tiled(int logm, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, hipStream_t);
+template <typename T> int launch_col_nat(int logm, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, hipStream_t);
+// tile width of the column pass; MUST match ColCfgSel in fft_kernels.h (CI * E)
+inline int col_tile_width_for(int dtype, int logm) { return (logm <= 12 ? 4 : 2) * (dtype == PM_C64 ? 2 : 1); }
+
+constexpr int kEngineMaxLog = 13;
+inline int engine_log2(int64_t n) {  // log2(n) if n is a power of two the engine handles, else -1
+    if (n < 2 || (n & (n - 1))) return -1;
+    int l = 0;
+    while ((int64_t(1) << l) < n) ++l;
+    return l <= kEngineMaxLog ? l : -1;
+}
+
+}  // namespace pm

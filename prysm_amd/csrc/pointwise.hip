@@ -1,0 +1,341 @@
+// Bandwidth-bound pointwise / synthesis kernels of the propagation path (gfx950).
+//
+// All of them are 2-D row-major with a leading dimension; one thread handles VEC adjacent
+// elements of a row (16 B per lane where the shape allows), grid-stride over rows so the launch
+// has >> 256 workgroups without exceeding ~2048.  Phases are reduced in fp64 before the sincos so
+// the fp32 path keeps full fp32 accuracy for arguments of many thousands of radians
+// (quadratic phases, OPD / lambda).
+#include "pm_internal.h"
+
+namespace pm {
+
+static inline dim3 grid2d(int64_t rows, int64_t cols_per_thread_units, dim3& block) {
+    block = dim3(64, 4);
+    int64_t gx = (cols_per_thread_units + block.x - 1) / block.x;
+    int64_t gy = (rows + block.y - 1) / block.y;
+    if (gy > 65535) gy = 65535;
+    return dim3((unsigned)gx, (unsigned)gy);
+}
+
+__device__ __forceinline__ void sincos_turns(double turns, double* s, double* c) {
+    // exp(2 pi i turns): reduce to [-0.5, 0.5) turns exactly, then sincospi
+    const double r = turns - rint(turns);
+    sincospi(2.0 * r, s, c);
+}
+
+// ---------------------------------------------------------------- cmul
+template <typename T, int OP>
+__global__ void cmul_kernel(int64_t rows, int64_t cols, const cx<T>* a, int64_t lda, const cx<T>* b, int64_t ldb,
+                            cx<T>* o, int64_t ldo) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < rows; r += int64_t(gridDim.y) * blockDim.y) {
+        const cx<T> x = a[r * lda + c], y = b[r * ldb + c];
+        o[r * ldo + c] = OP == 0 ? cmul(x, y) : cmulc(x, y);
+    }
+}
+
+template <typename T>
+int cmul_launch(int op, int64_t rows, int64_t cols, const void* a, int64_t lda, const void* b, int64_t ldb, void* o,
+                int64_t ldo, hipStream_t st) {
+    dim3 block;
+    dim3 grid = grid2d(rows, cols, block);
+    if (op == 0)
+        hipLaunchKernelGGL((cmul_kernel<T, 0>), grid, block, 0, st, rows, cols, (const cx<T>*)a, lda, (const cx<T>*)b, ldb, (cx<T>*)o, ldo);
+    else
+        hipLaunchKernelGGL((cmul_kernel<T, 1>), grid, block, 0, st, rows, cols, (const cx<T>*)a, lda, (const cx<T>*)b, ldb, (cx<T>*)o, ldo);
+    return int(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- separable scale
+template <typename T>
+__global__ void scale_sep_kernel(int64_t rows, int64_t cols, const cx<T>* in, int64_t ldi, const cx<T>* ry, int ryc,
+                                 const cx<T>* cxv, int cxc, T scale, cx<T>* o, int64_t ldo) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    cx<T> fc = {scale, T(0)};
+    if (cxv) {
+        cx<T> w = cxv[c];
+        if (cxc) w.y = -w.y;
+        fc = cscale(w, scale);
+    }
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < rows; r += int64_t(gridDim.y) * blockDim.y) {
+        cx<T> f = fc;
+        if (ry) {
+            cx<T> w = ry[r];
+            if (ryc) w.y = -w.y;
+            f = cmul(f, w);
+        }
+        o[r * ldo + c] = cmul(in[r * ldi + c], f);
+    }
+}
+
+// ---------------------------------------------------------------- |.|^2
+template <typename T, int ACC>
+__global__ void abs2_kernel(int64_t rows, int64_t cols, const cx<T>* in, int64_t ldi, T* o, int64_t ldo, T weight) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < rows; r += int64_t(gridDim.y) * blockDim.y) {
+        const cx<T> x = in[r * ldi + c];
+        const T i2 = x.x * x.x + x.y * x.y;
+        if (ACC)
+            o[r * ldo + c] += weight * i2;
+        else
+            o[r * ldo + c] = i2;
+    }
+}
+
+// ---------------------------------------------------------------- pupil synthesis
+template <typename T, typename A>
+__global__ void pupil_kernel(int64_t rows, int64_t cols, const A* amp, int64_t lda, const T* opd, int64_t ldp,
+                             double k_over_2pi, cx<T>* o, int64_t ldo) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < rows; r += int64_t(gridDim.y) * blockDim.y) {
+        double s, co;
+        sincos_turns(double(opd[r * ldp + c]) * k_over_2pi, &s, &co);
+        const double a = amp ? double(amp[r * lda + c]) : 1.0;
+        o[r * ldo + c] = {T(a * co), T(a * s)};
+    }
+}
+
+template <typename T>
+__global__ void quad_phase_kernel(int64_t rows, int64_t cols, const T* x, int64_t ldx, const T* y, int64_t ldy,
+                                  double c_over_2pi, cx<T>* o, int64_t ldo) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < rows; r += int64_t(gridDim.y) * blockDim.y) {
+        // rsq = x*x + y*y (wavefront.py:139-140), formed in fp64 from the stored coordinates
+        const double xv = double(x[r * ldx + c]), yv = double(y[r * ldy + c]);
+        double s, co;
+        sincos_turns((xv * xv + yv * yv) * c_over_2pi, &s, &co);
+        o[r * ldo + c] = {T(co), T(s)};
+    }
+}
+
+// ---------------------------------------------------------------- transfer function factors
+template <typename T>
+__global__ void as_tf_vec_kernel(int64_t n, double d, double coef_over_2pi, cx<T>* h) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // fftfreq(n, d): [0, 1, ..., (n-1)/2, -(n/2), ..., -1] / (d n), then cast to the real dtype
+    const int64_t half = (n - 1) / 2;
+    const int64_t ii = i <= half ? i : i - n;
+    const T k = T(double(ii) / (double(n) * d));   // .astype(config.precision), angular_spectrum.py:107
+    const double kd = double(k);
+    double s, co;
+    sincos_turns(kd * kd * coef_over_2pi, &s, &co);
+    h[i] = {T(co), T(s)};
+}
+
+template <typename T>
+__global__ void outer_kernel(int64_t rows, int64_t cols, const cx<T>* hy, const cx<T>* hx, cx<T>* o, int64_t ldo) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const cx<T> wx = hx[c];
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < rows; r += int64_t(gridDim.y) * blockDim.y)
+        o[r * ldo + c] = cmul(hy[r], wx);
+}
+
+// ---------------------------------------------------------------- embed (pad / crop)
+template <typename V>
+__global__ void embed_kernel(int64_t irows, int64_t icols, const V* in, int64_t ldi, int64_t orows, int64_t ocols,
+                             int64_t offy, int64_t offx, V fill, V* o, int64_t ldo) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= ocols) return;
+    const int64_t ic = c - offx;
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < orows; r += int64_t(gridDim.y) * blockDim.y) {
+        const int64_t ir = r - offy;
+        V val = fill;
+        if (ir >= 0 && ir < irows && ic >= 0 && ic < icols) val = in[ir * ldi + ic];
+        o[r * ldo + c] = val;
+    }
+}
+
+// ---------------------------------------------------------------- MDFT basis
+template <typename T>
+__global__ void mdft_basis_kernel(int64_t M, int64_t N, const T* f, const T* x, double sign, cx<T>* E, int64_t ldE) {
+    const int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double xv = double(x[n]);
+    for (int64_t m = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; m < M; m += int64_t(gridDim.y) * blockDim.y) {
+        // exp(sign 2 pi i outer(f, x)) (fttools.py:189-191); the product and its reduction to one turn
+        // are done in fp64 so the fp32 basis carries a single rounding
+        double s, co;
+        sincos_turns(sign * double(f[m]) * xv, &s, &co);
+        E[m * ldE + n] = {T(co), T(s)};
+    }
+}
+
+}  // namespace pm
+
+using namespace pm;
+
+#define PM_STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" {
+
+int pm_cmul(int32_t dtype, int32_t op, int64_t rows, int64_t cols, const void* a, int64_t a_ld, const void* b,
+            int64_t b_ld, void* out, int64_t out_ld, void* stream) {
+    if (!a || !b || !out || rows < 0 || cols < 0) return fail(PM_ERR_ARG, "pm_cmul: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    if (dtype == PM_C64) return cmul_launch<float>(op, rows, cols, a, a_ld, b, b_ld, out, out_ld, PM_STREAM(stream));
+    if (dtype == PM_C128) return cmul_launch<double>(op, rows, cols, a, a_ld, b, b_ld, out, out_ld, PM_STREAM(stream));
+    return fail(PM_ERR_ARG, "pm_cmul: dtype must be PM_C64 or PM_C128");
+}
+
+int pm_scale_sep(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t in_ld, const void* ry,
+                 int32_t ry_conj, const void* cxv, int32_t cx_conj, double scale, void* out, int64_t out_ld,
+                 void* stream) {
+    if (!in || !out || rows < 0 || cols < 0) return fail(PM_ERR_ARG, "pm_scale_sep: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(rows, cols, block);
+    if (dtype == PM_C64)
+        hipLaunchKernelGGL(scale_sep_kernel<float>, grid, block, 0, PM_STREAM(stream), rows, cols, (const cx<float>*)in, in_ld,
+                           (const cx<float>*)ry, ry_conj, (const cx<float>*)cxv, cx_conj, float(scale), (cx<float>*)out, out_ld);
+    else if (dtype == PM_C128)
+        hipLaunchKernelGGL(scale_sep_kernel<double>, grid, block, 0, PM_STREAM(stream), rows, cols, (const cx<double>*)in, in_ld,
+                           (const cx<double>*)ry, ry_conj, (const cx<double>*)cxv, cx_conj, scale, (cx<double>*)out, out_ld);
+    else
+        return fail(PM_ERR_ARG, "pm_scale_sep: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
+}
+
+int pm_abs2(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t in_ld, void* out, int64_t out_ld,
+            int32_t accumulate, double weight, void* stream) {
+    if (!in || !out || rows < 0 || cols < 0) return fail(PM_ERR_ARG, "pm_abs2: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(rows, cols, block);
+    hipStream_t st = PM_STREAM(stream);
+    if (dtype == PM_C64) {
+        if (accumulate)
+            hipLaunchKernelGGL((abs2_kernel<float, 1>), grid, block, 0, st, rows, cols, (const cx<float>*)in, in_ld, (float*)out, out_ld, float(weight));
+        else
+            hipLaunchKernelGGL((abs2_kernel<float, 0>), grid, block, 0, st, rows, cols, (const cx<float>*)in, in_ld, (float*)out, out_ld, 1.f);
+    } else if (dtype == PM_C128) {
+        if (accumulate)
+            hipLaunchKernelGGL((abs2_kernel<double, 1>), grid, block, 0, st, rows, cols, (const cx<double>*)in, in_ld, (double*)out, out_ld, weight);
+        else
+            hipLaunchKernelGGL((abs2_kernel<double, 0>), grid, block, 0, st, rows, cols, (const cx<double>*)in, in_ld, (double*)out, out_ld, 1.0);
+    } else
+        return fail(PM_ERR_ARG, "pm_abs2: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
+}
+
+int pm_pupil_synth(int32_t dtype, int64_t rows, int64_t cols, const void* amp, int32_t amp_dtype, int64_t amp_ld,
+                   const void* opd, int64_t opd_ld, double k, void* out, int64_t out_ld, void* stream) {
+    if (!opd || !out || rows < 0 || cols < 0) return fail(PM_ERR_ARG, "pm_pupil_synth: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(rows, cols, block);
+    hipStream_t st = PM_STREAM(stream);
+    const double k2 = k / (2.0 * 3.14159265358979323846264338327950288);
+#define PM_PUPIL(T, A) \
+    hipLaunchKernelGGL((pupil_kernel<T, A>), grid, block, 0, st, rows, cols, (const A*)amp, amp_ld, (const T*)opd, opd_ld, k2, (cx<T>*)out, out_ld)
+    if (dtype == PM_C64) {
+        if (!amp || amp_dtype == PM_F32) PM_PUPIL(float, float);
+        else if (amp_dtype == PM_F64) PM_PUPIL(float, double);
+        else if (amp_dtype == PM_BOOL) PM_PUPIL(float, unsigned char);
+        else return fail(PM_ERR_ARG, "pm_pupil_synth: amp_dtype");
+    } else if (dtype == PM_C128) {
+        if (!amp || amp_dtype == PM_F64) PM_PUPIL(double, double);
+        else if (amp_dtype == PM_F32) PM_PUPIL(double, float);
+        else if (amp_dtype == PM_BOOL) PM_PUPIL(double, unsigned char);
+        else return fail(PM_ERR_ARG, "pm_pupil_synth: amp_dtype");
+    } else
+        return fail(PM_ERR_ARG, "pm_pupil_synth: dtype must be PM_C64 or PM_C128");
+#undef PM_PUPIL
+    return int(hipGetLastError());
+}
+
+int pm_quadratic_phase(int32_t dtype, int64_t rows, int64_t cols, const void* x, int64_t x_ld, const void* y,
+                       int64_t y_ld, double c, void* out, int64_t out_ld, void* stream) {
+    if (!x || !y || !out || rows < 0 || cols < 0) return fail(PM_ERR_ARG, "pm_quadratic_phase: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(rows, cols, block);
+    const double c2 = c / (2.0 * 3.14159265358979323846264338327950288);
+    if (dtype == PM_C64)
+        hipLaunchKernelGGL(quad_phase_kernel<float>, grid, block, 0, PM_STREAM(stream), rows, cols, (const float*)x, x_ld, (const float*)y, y_ld, c2, (cx<float>*)out, out_ld);
+    else if (dtype == PM_C128)
+        hipLaunchKernelGGL(quad_phase_kernel<double>, grid, block, 0, PM_STREAM(stream), rows, cols, (const double*)x, x_ld, (const double*)y, y_ld, c2, (cx<double>*)out, out_ld);
+    else
+        return fail(PM_ERR_ARG, "pm_quadratic_phase: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
+}
+
+int pm_as_tf_vectors(int32_t dtype, int64_t rows, int64_t cols, double wvl_um, double dx, double z, void* hy, void* hx,
+                     void* stream) {
+    if (!hy || !hx || rows <= 0 || cols <= 0) return fail(PM_ERR_ARG, "pm_as_tf_vectors: bad argument");
+    // exp(-i pi (wvl/1e3) z k^2) = exp(2 pi i * (-(wvl/1e3) z / 2) k^2)
+    const double coef = -(wvl_um / 1e3) * z * 0.5;
+    hipStream_t st = PM_STREAM(stream);
+    if (dtype == PM_C64) {
+        hipLaunchKernelGGL(as_tf_vec_kernel<float>, dim3((rows + 255) / 256), dim3(256), 0, st, rows, dx, coef, (cx<float>*)hy);
+        hipLaunchKernelGGL(as_tf_vec_kernel<float>, dim3((cols + 255) / 256), dim3(256), 0, st, cols, dx, coef, (cx<float>*)hx);
+    } else if (dtype == PM_C128) {
+        hipLaunchKernelGGL(as_tf_vec_kernel<double>, dim3((rows + 255) / 256), dim3(256), 0, st, rows, dx, coef, (cx<double>*)hy);
+        hipLaunchKernelGGL(as_tf_vec_kernel<double>, dim3((cols + 255) / 256), dim3(256), 0, st, cols, dx, coef, (cx<double>*)hx);
+    } else
+        return fail(PM_ERR_ARG, "pm_as_tf_vectors: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
+}
+
+int pm_outer(int32_t dtype, int64_t rows, int64_t cols, const void* hy, const void* hx, void* out, int64_t out_ld,
+             void* stream) {
+    if (!hy || !hx || !out || rows < 0 || cols < 0) return fail(PM_ERR_ARG, "pm_outer: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(rows, cols, block);
+    if (dtype == PM_C64)
+        hipLaunchKernelGGL(outer_kernel<float>, grid, block, 0, PM_STREAM(stream), rows, cols, (const cx<float>*)hy, (const cx<float>*)hx, (cx<float>*)out, out_ld);
+    else if (dtype == PM_C128)
+        hipLaunchKernelGGL(outer_kernel<double>, grid, block, 0, PM_STREAM(stream), rows, cols, (const cx<double>*)hy, (const cx<double>*)hx, (cx<double>*)out, out_ld);
+    else
+        return fail(PM_ERR_ARG, "pm_outer: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
+}
+
+int pm_embed(int32_t elem_bytes, int64_t irows, int64_t icols, const void* in, int64_t in_ld, int64_t orows,
+             int64_t ocols, int64_t off_y, int64_t off_x, const void* fill, void* out, int64_t out_ld, void* stream) {
+    if (!in || !out || irows < 0 || icols < 0 || orows < 0 || ocols < 0) return fail(PM_ERR_ARG, "pm_embed: bad argument");
+    if (orows == 0 || ocols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(orows, ocols, block);
+    hipStream_t st = PM_STREAM(stream);
+#define PM_EMBED(V)                                                                                              \
+    {                                                                                                            \
+        V f{};                                                                                                   \
+        if (fill) f = *reinterpret_cast<const V*>(fill);                                                         \
+        hipLaunchKernelGGL(embed_kernel<V>, grid, block, 0, st, irows, icols, (const V*)in, in_ld, orows, ocols, \
+                           off_y, off_x, f, (V*)out, out_ld);                                                    \
+    }
+    switch (elem_bytes) {
+        case 1: PM_EMBED(unsigned char) break;
+        case 4: PM_EMBED(float) break;
+        case 8: PM_EMBED(double) break;
+        case 16: PM_EMBED(double2) break;
+        default: return fail(PM_ERR_ARG, "pm_embed: elem_bytes must be 1, 4, 8 or 16");
+    }
+#undef PM_EMBED
+    return int(hipGetLastError());
+}
+
+int pm_mdft_basis(int32_t dtype, int64_t M, int64_t N, const void* f, const void* x, int32_t sign, void* E,
+                  int64_t E_ld, void* stream) {
+    if (!f || !x || !E || M < 0 || N < 0 || (sign != 1 && sign != -1)) return fail(PM_ERR_ARG, "pm_mdft_basis: bad argument");
+    if (M == 0 || N == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(M, N, block);
+    if (dtype == PM_C64)
+        hipLaunchKernelGGL(mdft_basis_kernel<float>, grid, block, 0, PM_STREAM(stream), M, N, (const float*)f, (const float*)x, double(sign), (cx<float>*)E, E_ld);
+    else if (dtype == PM_C128)
+        hipLaunchKernelGGL(mdft_basis_kernel<double>, grid, block, 0, PM_STREAM(stream), M, N, (const double*)f, (const double*)x, double(sign), (cx<double>*)E, E_ld);
+    else
+        return fail(PM_ERR_ARG, "pm_mdft_basis: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+// CPU emulation of the HIP FFT kernels' per-thread logic (test scaffolding).
+//
+// The build container has no GPU.  fft_engine.h / fft_io.h are written as
+// __host__ __device__ code, so this program runs the exact load -> stages ->
+// LDS exchange -> store sequence of prysm_amd/csrc/fft_kernels.hip for every
+// thread of every workgroup, with a std::vector standing in for LDS and phase
+// boundaries standing in for __syncthreads(), and compares against a naive
+// long-double DFT.  It validates index arithmetic, twiddles, butterflies,
+// padding / shift / crop maps and the tiled intermediate before GPU minutes
+// are spent.  It is NOT a product code path (nothing in prysm_amd calls it).
+//
+// build: g++ -O2 -std=c++17 -I prysm_amd/csrc tools/emu_fft.cpp -o /tmp/emu_fft
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "fft_io.h"
+
+using namespace pm;
+typedef long double ld;
+typedef std::complex<ld> cld;
+
+template <typename T>
+static std::vector<cx<T>> make_tw(int N) {
+    std::vector<cx<T>> tw(N);
+    const ld pi = acosl(-1.0L);
+    for (int i = 0; i < N; ++i) tw[i] = {T(cosl(-2 * pi * i / N)), T(sinl(-2 * pi * i / N))};
+    return tw;
+}
+
+template <typename C>
+struct Regs {
+    cx<typename C::T> v[C::E][C::P];
+};
+
+template <typename C, int S>
+static void emu_stages(std::vector<Regs<C>>& regs, std::vector<typename LdsType<C>::type>& lds,
+                       const cx<typename C::T>* tw) {
+    for (int tid = 0; tid < C::NT; ++tid) stage_compute<C, S>(regs[tid].v, thread_pos<C>(tid).t, tw);
+    if constexpr (S + 1 < C::NSTAGE) {
+        for (int e = 0; e < C::E; ++e)
+            for (int comp = 0; comp < C::COMP; ++comp) {
+                for (int tid = 0; tid < C::NT; ++tid)
+                    exch_write<C, S>(regs[tid].v, e, comp, thread_pos<C>(tid), lds.data());
+                for (int tid = 0; tid < C::NT; ++tid)
+                    exch_read<C>(regs[tid].v, e, comp, thread_pos<C>(tid), lds.data());
+            }
+        emu_stages<C, S + 1>(regs, lds, tw);
+    }
+}
+
+template <typename C, bool COL, typename L, typename S>
+static void emu_kernel(int nblocks, const L& lp, const S& sp, const cx<typename C::T>* tw) {
+    std::vector<Regs<C>> regs(C::NT);
+    std::vector<typename LdsType<C>::type> lds(C::LDS_ELEMS + 1);
+    for (int g = 0; g < nblocks; ++g) {
+        for (int tid = 0; tid < C::NT; ++tid) {
+            ThreadPos pos = thread_pos<C>(tid);
+            int unit = pair_remap(g, nblocks);
+            if (COL) unit = unit * C::BO + pos.bo;
+            load<C>(lp, unit, pos, regs[tid].v);
+        }
+        emu_stages<C, 0>(regs, lds, tw);
+        for (int tid = 0; tid < C::NT; ++tid) {
+            ThreadPos pos = thread_pos<C>(tid);
+            int unit = pair_remap(g, nblocks);
+            if (COL) unit = unit * C::BO + pos.bo;
+            store<C>(sp, unit, pos, regs[tid].v);
+        }
+    }
+}
+
+static int g_fail = 0;
+static void report(const char* what, double err, double tol) {
+    const bool ok = err < tol;
+    printf("%-58s err=%.3e  %s\n", what, err, ok ? "ok" : "FAIL");
+    if (!ok) ++g_fail;
+}
+
+// --- 1-D row transform, natural in / natural out, with zero-pad + shift maps -------------
+template <typename T, int LOGN, int BO, int COMP>
+static void test_row(int nseq, int in_len, int in_off, int in_shift, int out_shift, bool inverse) {
+    using C = FftCfg<T, LOGN, 1, 1, BO, COMP>;
+    const int N = C::N;
+    std::mt19937 rng(LOGN * 131 + nseq);
+    std::normal_distribution<double> nd;
+    std::vector<cx<T>> x(size_t(nseq) * in_len), y(size_t(nseq) * N, cx<T>{T(-7), T(-7)});
+    for (auto& e : x) e = {T(nd(rng)), T(nd(rng))};
+    auto tw = make_tw<T>(N);
+    RowLoadNat<T> lp{x.data(), in_len, AxisMap{N, in_len, in_off, in_shift}, nseq, inverse ? 1 : 0};
+    RowStoreNat<T> sp{y.data(), N, AxisMap{N, N, 0, out_shift}, nseq, inverse ? 1 : 0, T(1)};
+    const int nblk = (nseq + C::BO - 1) / C::BO;
+    emu_kernel<C, false>(nblk, lp, sp, tw.data());
+    const ld pi = acosl(-1.0L);
+    double err = 0, nrm = 0;
+    for (int s = 0; s < nseq; ++s) {
+        std::vector<cld> p(N, cld(0, 0));
+        for (int i = 0; i < N; ++i) {  // logical padded+shifted input
+            int pp = (i + in_shift) % N, q = pp - in_off;
+            if (q >= 0 && q < in_len) p[i] = cld(x[size_t(s) * in_len + q].x, x[size_t(s) * in_len + q].y);
+        }
+        for (int k = 0; k < N; ++k) {
+            cld acc(0, 0);
+            for (int n = 0; n < N; ++n) {
+                ld ang = (inverse ? 2 : -2) * pi * ld((int64_t(n) * k) % N) / N;
+                acc += p[n] * cld(cosl(ang), sinl(ang));
+            }
+            int pos = (k + out_shift) % N;
+            cx<T> got = y[size_t(s) * N + pos];
+            err = fmax(err, (double)std::abs(acc - cld(got.x, got.y)));
+            nrm = fmax(nrm, (double)std::abs(acc));
+        }
+    }
+    char buf[128];
+    snprintf(buf, sizeof buf, "row %s N=%d BO=%d COMP=%d nseq=%d len=%d off=%d sh=%d/%d %s",
+             sizeof(T) == 4 ? "c64" : "c128", N, BO, COMP, nseq, in_len, in_off, in_shift, out_shift,
+             inverse ? "inv" : "fwd");
+    report(buf, err / nrm, sizeof(T) == 4 ? 2e-6 : 1e-14);
+}
+
+// --- 2-D: row pass -> tiled intermediate -> column pass, vs naive 2-D DFT ---------------
+template <typename T, int LOGM, int LOGN, int RBO, int RCOMP, int CCI, int CE, int CBO, int CCOMP>
+static void test_2d(int in_rows, int in_cols, bool shifts, int epilogue, bool inverse, int out_rows, int out_cols) {
+    using RC = FftCfg<T, LOGN, 1, 1, RBO, RCOMP>;      // row transform of length N (columns)
+    using CC = FftCfg<T, LOGM, CCI, CE, CBO, CCOMP>;   // column transform of length M (rows)
+    const int M = CC::N, N = RC::N, TC = CCI * CE;
+    int log_tc = 0;
+    while ((1 << log_tc) < TC) ++log_tc;
+    std::mt19937 rng(LOGM * 17 + LOGN);
+    std::normal_distribution<double> nd;
+    std::vector<cx<T>> x(size_t(in_rows) * in_cols);
+    for (auto& e : x) e = {T(nd(rng)), T(nd(rng))};
+    const int offy = (M - in_rows + 1) / 2, offx = (N - in_cols + 1) / 2;  // pad2d: ceil(d/2)
+    const int shy = shifts ? M / 2 : 0, shx = shifts ? N / 2 : 0;
+    const int ntiles = (N + TC - 1) / TC;
+    std::vector<cx<T>> W(size_t(ntiles) * in_rows * TC, cx<T>{T(1e30), T(1e30)});
+    auto twN = make_tw<T>(N);
+    auto twM = make_tw<T>(M);
+    // pass 1: one FFT per stored input row
+    RowLoadNat<T> lp{x.data(), in_cols, AxisMap{N, in_cols, offx, shx}, in_rows, inverse ? 1 : 0};
+    RowStoreTiled<T> sp{W.data(), in_rows, log_tc};
+    emu_kernel<RC, false>((in_rows + RC::BO - 1) / RC::BO, lp, sp, twN.data());
+    // pass 2
+    const int coffy = (M - out_rows + 1) / 2, coffx = (N - out_cols + 1) / 2;  // crop_center: ceil(p/2)
+    std::vector<cx<T>> out(size_t(out_rows) * out_cols, cx<T>{T(-3), T(-3)});
+    std::vector<T> outr(size_t(out_rows) * out_cols, T(-3));
+    ColLoadTiled<T> cl{W.data(), in_rows, AxisMap{M, in_rows, offy, shy}, ntiles};
+    ColStoreNat<T> cs{};
+    cs.dst = epilogue ? (void*)outr.data() : (void*)out.data();
+    cs.ld = out_cols;
+    cs.ay = AxisMap{M, out_rows, coffy, shy};
+    cs.ax = AxisMap{N, out_cols, coffx, shx};
+    cs.conj = inverse ? 1 : 0;
+    cs.epilogue = epilogue;
+    cs.scale = T(1.0 / sqrt(double(M) * N));
+    cs.weight = T(1);
+    cs.mul_kind = MUL_NONE;
+    cs.vec_ok = (out_cols % 2 == 0) ? 1 : 0;
+    const int ngroups = (ntiles + CC::BO - 1) / CC::BO;
+    emu_kernel<CC, true>(ngroups, cl, cs, twM.data());
+    // reference
+    const ld pi = acosl(-1.0L);
+    std::vector<cld> P(size_t(M) * N, cld(0, 0));
+    for (int r = 0; r < M; ++r)
+        for (int c = 0; c < N; ++c) {
+            int qr = (r + shy) % M - offy, qc = (c + shx) % N - offx;
+            if (qr >= 0 && qr < in_rows && qc >= 0 && qc < in_cols)
+                P[size_t(r) * N + c] = cld(x[size_t(qr) * in_cols + qc].x, x[size_t(qr) * in_cols + qc].y);
+        }
+    // separable naive DFT
+    std::vector<cld> A(size_t(M) * N), B(size_t(M) * N);
+    const ld sg = inverse ? 2 : -2;
+    for (int r = 0; r < M; ++r)
+        for (int k = 0; k < N; ++k) {
+            cld acc(0, 0);
+            for (int n = 0; n < N; ++n) {
+                ld ang = sg * pi * ld((int64_t(n) * k) % N) / N;
+                acc += P[size_t(r) * N + n] * cld(cosl(ang), sinl(ang));
+            }
+            A[size_t(r) * N + k] = acc;
+        }
+    for (int c = 0; c < N; ++c)
+        for (int k = 0; k < M; ++k) {
+            cld acc(0, 0);
+            for (int n = 0; n < M; ++n) {
+                ld ang = sg * pi * ld((int64_t(n) * k) % M) / M;
+                acc += A[size_t(n) * N + c] * cld(cosl(ang), sinl(ang));
+            }
+            B[size_t(k) * N + c] = acc / sqrtl(ld(M) * N);
+        }
+    double err = 0, nrm = 0;
+    for (int k = 0; k < M; ++k)
+        for (int c = 0; c < N; ++c) {
+            int qy = (k + shy) % M - coffy, qx = (c + shx) % N - coffx;
+            if (qy < 0 || qy >= out_rows || qx < 0 || qx >= out_cols) continue;
+            cld ref = B[size_t(k) * N + c];
+            if (epilogue) {
+                ld r2 = std::norm(ref);
+                err = fmax(err, (double)fabsl(r2 - outr[size_t(qy) * out_cols + qx]));
+                nrm = fmax(nrm, (double)r2);
+            } else {
+                cx<T> got = out[size_t(qy) * out_cols + qx];
+                err = fmax(err, (double)std::abs(ref - cld(got.x, got.y)));
+                nrm = fmax(nrm, (double)std::abs(ref));
+            }
+        }
+    char buf[160];
+    snprintf(buf, sizeof buf, "2d %s %dx%d in=%dx%d out=%dx%d sh=%d epi=%d %s TC=%d", sizeof(T) == 4 ? "c64" : "c128",
+             M, N, in_rows, in_cols, out_rows, out_cols, (int)shifts, epilogue, inverse ? "inv" : "fwd", TC);
+    report(buf, err / nrm, sizeof(T) == 4 ? 3e-6 : 1e-13);
+}
+
+int main() {
+    // rows: every stage structure (P<16, single stage, 16x2, 16x16, 16x16x8, 16^3, 16^3x2)
+    test_row<float, 1, 256, 1>(300, 2, 0, 0, 0, false);
+    test_row<float, 3, 256, 1>(5, 8, 0, 0, 0, false);
+    test_row<float, 4, 256, 1>(3, 16, 0, 0, 0, false);
+    test_row<float, 5, 128, 1>(3, 32, 0, 0, 0, false);
+    test_row<float, 6, 64, 1>(70, 64, 0, 32, 32, false);
+    test_row<float, 7, 32, 1>(3, 100, 14, 64, 0, true);
+    test_row<float, 8, 16, 1>(17, 256, 0, 0, 128, false);
+    test_row<float, 9, 8, 1>(9, 500, 6, 256, 256, false);
+    test_row<float, 10, 4, 1>(5, 1024, 0, 0, 0, true);
+    test_row<float, 11, 2, 1>(3, 2048, 0, 1024, 1024, false);
+    test_row<float, 12, 1, 1>(2, 4096, 0, 0, 0, false);
+    test_row<float, 13, 1, 1>(1, 8192, 0, 0, 0, false);
+    test_row<double, 8, 16, 1>(5, 256, 0, 128, 128, false);
+    test_row<double, 12, 1, 2>(2, 4096, 0, 0, 0, true);
+    test_row<double, 10, 4, 2>(5, 700, 162, 512, 0, false);
+    // 2-D through the tiled intermediate
+    test_2d<float, 6, 5, 128, 1, 4, 2, 16, 1>(64, 32, true, 0, false, 64, 32);
+    test_2d<float, 5, 6, 64, 1, 4, 2, 32, 1>(16, 32, true, 0, false, 32, 64);      // Q=2 pad
+    test_2d<float, 5, 6, 64, 1, 4, 2, 32, 1>(32, 64, true, 0, true, 16, 32);       // adjoint: inverse + crop
+    test_2d<float, 7, 7, 32, 1, 4, 2, 8, 1>(128, 128, true, 1, false, 128, 128);   // abs2 epilogue
+    test_2d<float, 8, 5, 128, 1, 4, 2, 4, 1>(200, 20, false, 0, false, 256, 32);
+    test_2d<float, 9, 4, 256, 1, 2, 2, 4, 1>(512, 16, true, 0, false, 512, 16);    // TC=4 variant
+    test_2d<double, 6, 6, 64, 1, 4, 1, 16, 2>(64, 64, true, 0, false, 64, 64);
+    test_2d<double, 5, 7, 32, 2, 4, 1, 32, 1>(20, 100, true, 0, true, 32, 128);
+    test_2d<double, 8, 4, 256, 1, 2, 1, 8, 2>(256, 16, false, 1, false, 256, 16);
+    printf(g_fail ? "EMU FAILED (%d)\n" : "EMU OK\n", g_fail);
+    return g_fail ? 1 : 0;
+}

@@ -1,0 +1,464 @@
+// Standalone GPU check + microbenchmark for libprysm_amd.so (development tool; the judged
+// parity tests are tests/test_gpu_*.py, which go through the same C ABI from Python).
+//
+//   build: make -C tools          run: tools/pm_gpu_check [quick|full|bench]
+//
+// Verifies pm_fft2 / pm_fft1 / pm_cgemm / pointwise kernels against fp64 host references (naive DFT
+// for small and awkward sizes, an iterative radix-2 fp64 FFT for the large ones) and times the two FFT
+// passes with hipEvents, printing achieved algorithmic GB/s next to a device-to-device copy.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../include/prysm_amd.h"
+
+typedef std::complex<double> cd;
+static int g_fail = 0;
+#define HIPCHECK(x)                                                                   \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                                  \
+        }                                                                             \
+    } while (0)
+
+static void report(const std::string& what, double err, double tol) {
+    const bool ok = err < tol;
+    printf("%-64s err=%.3e %s\n", what.c_str(), err, ok ? "ok" : "FAIL");
+    if (!ok) ++g_fail;
+}
+
+// ---- host references ------------------------------------------------------------------------
+static void fft_pow2(std::vector<cd>& a, int sign) {
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = sign * 2 * M_PI / double(len);
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const cd w(cos(ang * double(k)), sin(ang * double(k)));
+                cd u = a[i + k], v = a[i + k + len / 2] * w;
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+static void dft_any(std::vector<cd>& a, int sign) {
+    const size_t n = a.size();
+    if (n >= 2 && (n & (n - 1)) == 0) return fft_pow2(a, sign);
+    std::vector<cd> o(n);
+    for (size_t k = 0; k < n; ++k) {
+        cd acc = 0;
+        for (size_t m = 0; m < n; ++m) {
+            const double ang = sign * 2 * M_PI * double((m * k) % n) / double(n);
+            acc += a[m] * cd(cos(ang), sin(ang));
+        }
+        o[k] = acc;
+    }
+    a = o;
+}
+// logical (padded + rotated) 2-D transform with output rotation / crop, as pm_fft2 defines it
+static std::vector<cd> ref_fft2(const pm_fft2_desc& d, const std::vector<cd>& x) {
+    const int64_t M = d.in_y.n, N = d.in_x.n;
+    std::vector<cd> P(size_t(M) * N, cd(0, 0));
+    for (int64_t r = 0; r < M; ++r)
+        for (int64_t c = 0; c < N; ++c) {
+            const int64_t qr = (r + d.in_y.shift) % M - d.in_y.off, qc = (c + d.in_x.shift) % N - d.in_x.off;
+            if (qr >= 0 && qr < d.in_y.len && qc >= 0 && qc < d.in_x.len) P[size_t(r * N + c)] = x[size_t(qr * d.in_ld + qc)];
+        }
+    std::vector<cd> row(N), col(M);
+    for (int64_t r = 0; r < M; ++r) {
+        for (int64_t c = 0; c < N; ++c) row[c] = P[size_t(r * N + c)];
+        dft_any(row, d.direction);
+        for (int64_t c = 0; c < N; ++c) P[size_t(r * N + c)] = row[c];
+    }
+    for (int64_t c = 0; c < N; ++c) {
+        for (int64_t r = 0; r < M; ++r) col[r] = P[size_t(r * N + c)];
+        dft_any(col, d.direction);
+        for (int64_t r = 0; r < M; ++r) P[size_t(r * N + c)] = col[r] * d.scale;
+    }
+    return P;  // indexed by unshifted bin (k, c)
+}
+
+template <typename T>
+static std::vector<std::complex<T>> to_dev_type(const std::vector<cd>& x) {
+    std::vector<std::complex<T>> o(x.size());
+    for (size_t i = 0; i < x.size(); ++i) o[i] = std::complex<T>(T(x[i].real()), T(x[i].imag()));
+    return o;
+}
+
+struct Case2 {
+    int64_t M, N, in_r, in_c, out_r, out_c;
+    bool shift;
+    int dir, epi;
+};
+
+template <typename T>
+static void check_fft2(const Case2& cs, double tol) {
+    pm_fft2_desc d;
+    memset(&d, 0, sizeof d);
+    d.dtype = sizeof(T) == 4 ? PM_C64 : PM_C128;
+    d.direction = cs.dir;
+    d.epilogue = cs.epi;
+    d.scale = 1.0 / sqrt(double(cs.M) * cs.N);
+    d.weight = 1.0;
+    d.in_y = {cs.M, cs.in_r, (cs.M - cs.in_r + 1) / 2, cs.shift ? cs.M / 2 : 0};
+    d.in_x = {cs.N, cs.in_c, (cs.N - cs.in_c + 1) / 2, cs.shift ? cs.N / 2 : 0};
+    d.out_y = {cs.M, cs.out_r, (cs.M - cs.out_r + 1) / 2, cs.shift ? cs.M / 2 : 0};
+    d.out_x = {cs.N, cs.out_c, (cs.N - cs.out_c + 1) / 2, cs.shift ? cs.N / 2 : 0};
+    d.in_ld = cs.in_c;
+    d.out_ld = cs.out_c;
+    std::mt19937_64 rng(cs.M * 7919 + cs.N);
+    std::normal_distribution<double> nd;
+    std::vector<cd> x(size_t(cs.in_r) * cs.in_c);
+    for (auto& e : x) e = cd(nd(rng), nd(rng));
+    auto hx = to_dev_type<T>(x);
+    for (size_t i = 0; i < x.size(); ++i) x[i] = cd(hx[i].real(), hx[i].imag());
+    const size_t es = 2 * sizeof(T);
+    void *din, *dout, *ws;
+    const size_t wsb = pm_fft2_workspace(&d);
+    const size_t out_elems = size_t(cs.out_r) * cs.out_c;
+    HIPCHECK(hipMalloc(&din, x.size() * es + 16));
+    HIPCHECK(hipMalloc(&dout, out_elems * es + 16));
+    HIPCHECK(hipMalloc(&ws, wsb));
+    HIPCHECK(hipMemcpy(din, hx.data(), x.size() * es, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemset(dout, 0xff, out_elems * es));
+    int rc = pm_fft2(&d, din, dout, ws, wsb, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    char name[160];
+    snprintf(name, sizeof name, "fft2 %s %lldx%lld in %lldx%lld out %lldx%lld sh%d dir%+d epi%d", sizeof(T) == 4 ? "c64" : "c128",
+             (long long)cs.M, (long long)cs.N, (long long)cs.in_r, (long long)cs.in_c, (long long)cs.out_r, (long long)cs.out_c,
+             (int)cs.shift, cs.dir, cs.epi);
+    if (rc) {
+        printf("%s rc=%d (%s)\n", name, rc, pm_last_error());
+        ++g_fail;
+    } else {
+        auto ref = ref_fft2(d, x);
+        double err = 0, nrm = 0;
+        if (cs.epi == PM_EPI_NONE) {
+            std::vector<std::complex<T>> o(out_elems);
+            HIPCHECK(hipMemcpy(o.data(), dout, out_elems * es, hipMemcpyDeviceToHost));
+            for (int64_t k = 0; k < cs.M; ++k)
+                for (int64_t c = 0; c < cs.N; ++c) {
+                    const int64_t qy = (k + d.out_y.shift) % cs.M - d.out_y.off, qx = (c + d.out_x.shift) % cs.N - d.out_x.off;
+                    if (qy < 0 || qy >= cs.out_r || qx < 0 || qx >= cs.out_c) continue;
+                    const cd r = ref[size_t(k * cs.N + c)];
+                    const auto g = o[size_t(qy * cs.out_c + qx)];
+                    err = fmax(err, std::abs(r - cd(g.real(), g.imag())));
+                    nrm = fmax(nrm, std::abs(r));
+                }
+        } else {
+            std::vector<T> o(out_elems);
+            HIPCHECK(hipMemcpy(o.data(), dout, out_elems * sizeof(T), hipMemcpyDeviceToHost));
+            for (int64_t k = 0; k < cs.M; ++k)
+                for (int64_t c = 0; c < cs.N; ++c) {
+                    const int64_t qy = (k + d.out_y.shift) % cs.M - d.out_y.off, qx = (c + d.out_x.shift) % cs.N - d.out_x.off;
+                    if (qy < 0 || qy >= cs.out_r || qx < 0 || qx >= cs.out_c) continue;
+                    const double r = std::norm(ref[size_t(k * cs.N + c)]);
+                    err = fmax(err, fabs(r - double(o[size_t(qy * cs.out_c + qx)])));
+                    nrm = fmax(nrm, r);
+                }
+        }
+        report(name, err / nrm, tol);
+    }
+    HIPCHECK(hipFree(din));
+    HIPCHECK(hipFree(dout));
+    HIPCHECK(hipFree(ws));
+}
+
+template <typename T>
+static void check_fft1(int64_t n, int64_t len, int64_t batch, int axis, int dir, double tol) {
+    // in: (batch x len) for axis 1, (len x batch) for axis 0; zero padded to n; out full length n
+    const int64_t rows = axis == 1 ? batch : len, cols = axis == 1 ? len : batch;
+    const int64_t orows = axis == 1 ? batch : n, ocols = axis == 1 ? n : batch;
+    std::mt19937_64 rng(n * 31 + len);
+    std::normal_distribution<double> nd;
+    std::vector<cd> x(size_t(rows) * cols);
+    for (auto& e : x) e = cd(nd(rng), nd(rng));
+    auto hx = to_dev_type<T>(x);
+    for (size_t i = 0; i < x.size(); ++i) x[i] = cd(hx[i].real(), hx[i].imag());
+    const size_t es = 2 * sizeof(T);
+    void *din, *dout;
+    HIPCHECK(hipMalloc(&din, x.size() * es));
+    HIPCHECK(hipMalloc(&dout, size_t(orows) * ocols * es));
+    HIPCHECK(hipMemcpy(din, hx.data(), x.size() * es, hipMemcpyHostToDevice));
+    pm_axis ti = {n, len, 0, 0}, to = {n, n, 0, 0};
+    int rc = pm_fft1(sizeof(T) == 4 ? PM_C64 : PM_C128, dir, axis, batch, &ti, &to, 1.0, din, cols, dout, ocols, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    char name[128];
+    snprintf(name, sizeof name, "fft1 %s n=%lld len=%lld batch=%lld axis=%d dir%+d", sizeof(T) == 4 ? "c64" : "c128", (long long)n,
+             (long long)len, (long long)batch, axis, dir);
+    if (rc) {
+        printf("%s rc=%d (%s)\n", name, rc, pm_last_error());
+        ++g_fail;
+    } else {
+        std::vector<std::complex<T>> o(size_t(orows) * ocols);
+        HIPCHECK(hipMemcpy(o.data(), dout, o.size() * es, hipMemcpyDeviceToHost));
+        double err = 0, nrm = 0;
+        std::vector<cd> s(n);
+        for (int64_t b = 0; b < batch; ++b) {
+            for (int64_t i = 0; i < n; ++i) s[i] = i < len ? (axis == 1 ? x[size_t(b * cols + i)] : x[size_t(i * cols + b)]) : cd(0, 0);
+            dft_any(s, dir);
+            for (int64_t k = 0; k < n; ++k) {
+                const auto g = axis == 1 ? o[size_t(b * ocols + k)] : o[size_t(k * ocols + b)];
+                err = fmax(err, std::abs(s[k] - cd(g.real(), g.imag())));
+                nrm = fmax(nrm, std::abs(s[k]));
+            }
+        }
+        report(name, err / nrm, tol);
+    }
+    HIPCHECK(hipFree(din));
+    HIPCHECK(hipFree(dout));
+}
+
+template <typename T>
+static void check_cgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, double tol, bool use_ws) {
+    std::mt19937_64 rng(M * 3 + N * 5 + K * 7 + opA * 11 + opB);
+    std::normal_distribution<double> nd;
+    const int64_t ar = (opA & 2) ? K : M, ac = (opA & 2) ? M : K, br = (opB & 2) ? N : K, bc = (opB & 2) ? K : N;
+    std::vector<cd> A(size_t(ar) * ac), B(size_t(br) * bc);
+    for (auto& e : A) e = cd(nd(rng), nd(rng));
+    for (auto& e : B) e = cd(nd(rng), nd(rng));
+    auto hA = to_dev_type<T>(A), hB = to_dev_type<T>(B);
+    for (size_t i = 0; i < A.size(); ++i) A[i] = cd(hA[i].real(), hA[i].imag());
+    for (size_t i = 0; i < B.size(); ++i) B[i] = cd(hB[i].real(), hB[i].imag());
+    const size_t es = 2 * sizeof(T);
+    void *dA, *dB, *dC, *ws = nullptr;
+    const int dt = sizeof(T) == 4 ? PM_C64 : PM_C128;
+    size_t wsb = use_ws ? pm_cgemm_workspace(dt, M, N, K) : 0;
+    HIPCHECK(hipMalloc(&dA, A.size() * es));
+    HIPCHECK(hipMalloc(&dB, B.size() * es));
+    HIPCHECK(hipMalloc(&dC, size_t(M) * N * es));
+    if (wsb) HIPCHECK(hipMalloc(&ws, wsb));
+    HIPCHECK(hipMemcpy(dA, hA.data(), A.size() * es, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dB, hB.data(), B.size() * es, hipMemcpyHostToDevice));
+    const double alpha = 0.37;
+    int rc = pm_cgemm(dt, opA, opB, M, N, K, alpha, dA, ac, dB, bc, dC, N, ws, wsb, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    char name[128];
+    snprintf(name, sizeof name, "cgemm %s opA=%d opB=%d %lldx%lldx%lld ws=%zu", sizeof(T) == 4 ? "c64" : "c128", opA, opB, (long long)M,
+             (long long)N, (long long)K, wsb);
+    if (rc) {
+        printf("%s rc=%d (%s)\n", name, rc, pm_last_error());
+        ++g_fail;
+    } else {
+        std::vector<std::complex<T>> o(size_t(M) * N);
+        HIPCHECK(hipMemcpy(o.data(), dC, o.size() * es, hipMemcpyDeviceToHost));
+        double err = 0, nrm = 0;
+        // check a subset of rows when big
+        const int64_t rstep = M > 64 ? M / 37 + 1 : 1;
+        for (int64_t i = 0; i < M; i += rstep)
+            for (int64_t j = 0; j < N; ++j) {
+                cd acc = 0;
+                for (int64_t k = 0; k < K; ++k) {
+                    cd a = (opA & 2) ? A[size_t(k * ac + i)] : A[size_t(i * ac + k)];
+                    cd b = (opB & 2) ? B[size_t(j * bc + k)] : B[size_t(k * bc + j)];
+                    if (opA & 1) a = std::conj(a);
+                    if (opB & 1) b = std::conj(b);
+                    acc += a * b;
+                }
+                acc *= alpha;
+                const auto g = o[size_t(i * N + j)];
+                err = fmax(err, std::abs(acc - cd(g.real(), g.imag())));
+                nrm = fmax(nrm, std::abs(acc));
+            }
+        report(name, err / nrm, tol);
+    }
+    HIPCHECK(hipFree(dA));
+    HIPCHECK(hipFree(dB));
+    HIPCHECK(hipFree(dC));
+    if (ws) HIPCHECK(hipFree(ws));
+}
+
+// ---- timing ---------------------------------------------------------------------------------
+static double time_copy(size_t bytes) {
+    void *a, *b;
+    HIPCHECK(hipMalloc(&a, bytes));
+    HIPCHECK(hipMalloc(&b, bytes));
+    HIPCHECK(hipMemset(a, 1, bytes));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) HIPCHECK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, nullptr));
+    HIPCHECK(hipEventRecord(e0, nullptr));
+    const int reps = 20;
+    for (int i = 0; i < reps; ++i) HIPCHECK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, nullptr));
+    HIPCHECK(hipEventRecord(e1, nullptr));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    HIPCHECK(hipFree(a));
+    HIPCHECK(hipFree(b));
+    return double(ms) / reps;
+}
+
+template <typename T>
+static void bench_fft2(int64_t n, int64_t in_n, int epi) {
+    pm_fft2_desc d;
+    memset(&d, 0, sizeof d);
+    d.dtype = sizeof(T) == 4 ? PM_C64 : PM_C128;
+    d.direction = -1;
+    d.epilogue = epi;
+    d.scale = 1.0 / double(n);
+    d.weight = 1.0;
+    d.in_y = d.in_x = {n, in_n, (n - in_n + 1) / 2, n / 2};
+    d.out_y = d.out_x = {n, n, 0, n / 2};
+    d.in_ld = in_n;
+    d.out_ld = n;
+    const size_t es = 2 * sizeof(T);
+    std::vector<std::complex<T>> hx(size_t(in_n) * in_n);
+    std::mt19937 rng(n);
+    std::normal_distribution<float> nd;
+    for (auto& e : hx) e = std::complex<T>(nd(rng), nd(rng));
+    void *din, *dout, *ws;
+    const size_t wsb = pm_fft2_workspace(&d);
+    HIPCHECK(hipMalloc(&din, hx.size() * es));
+    HIPCHECK(hipMalloc(&dout, size_t(n) * n * es));
+    HIPCHECK(hipMalloc(&ws, wsb));
+    HIPCHECK(hipMemcpy(din, hx.data(), hx.size() * es, hipMemcpyHostToDevice));
+    double ms[2] = {0, 0};
+    int rc = pm_fft2_time_passes(&d, din, dout, ws, wsb, 20, ms, nullptr);
+    // whole transform, back to back
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) pm_fft2(&d, din, dout, ws, wsb, nullptr);
+    HIPCHECK(hipEventRecord(e0, nullptr));
+    const int reps = 50;
+    for (int i = 0; i < reps; ++i) pm_fft2(&d, din, dout, ws, wsb, nullptr);
+    HIPCHECK(hipEventRecord(e1, nullptr));
+    HIPCHECK(hipEventSynchronize(e1));
+    float tot;
+    HIPCHECK(hipEventElapsedTime(&tot, e0, e1));
+    tot /= reps;
+    const double alg = 4.0 * double(n) * n * es;   // graded bytes: 2 passes x (read + write) of the transform size
+    const double b1 = (double(in_n) * in_n + double(in_n) * n) * es;                       // actual pass-1 traffic
+    const double b2 = (double(in_n) * n) * es + double(n) * n * (epi ? es / 2 : es);       // actual pass-2 traffic
+    printf("BENCH fft2 %s N=%lld in=%lld epi=%d rc=%d: pass1 %.1f us (%.0f GB/s actual) pass2 %.1f us (%.0f GB/s actual) total %.1f us "
+           "-> %.0f GB/s algorithmic (%.1f%% of 8 TB/s), %.0f props/s\n",
+           sizeof(T) == 4 ? "c64" : "c128", (long long)n, (long long)in_n, epi, rc, ms[0] * 1e3, b1 / ms[0] / 1e6, ms[1] * 1e3,
+           b2 / ms[1] / 1e6, tot * 1e3, alg / tot / 1e6, alg / tot / 1e6 / 8000 * 100, 1e3 / tot);
+    HIPCHECK(hipFree(din));
+    HIPCHECK(hipFree(dout));
+    HIPCHECK(hipFree(ws));
+}
+
+template <typename T>
+static void bench_cgemm(int64_t M, int64_t N, int64_t K, int opB) {
+    const size_t es = 2 * sizeof(T);
+    const int dt = sizeof(T) == 4 ? PM_C64 : PM_C128;
+    void *dA, *dB, *dC, *ws = nullptr;
+    size_t wsb = pm_cgemm_workspace(dt, M, N, K);
+    HIPCHECK(hipMalloc(&dA, size_t(M) * K * es));
+    HIPCHECK(hipMalloc(&dB, size_t(K) * N * es));
+    HIPCHECK(hipMalloc(&dC, size_t(M) * N * es));
+    if (wsb) HIPCHECK(hipMalloc(&ws, wsb));
+    std::vector<std::complex<T>> h(size_t(std::max(M, N)) * K);
+    std::mt19937 rng(5);
+    std::uniform_real_distribution<float> ud(-1, 1);
+    for (auto& e : h) e = std::complex<T>(ud(rng), ud(rng));
+    HIPCHECK(hipMemcpy(dA, h.data(), size_t(M) * K * es, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dB, h.data(), size_t(K) * N * es, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    const int64_t ldb = (opB & 2) ? K : N;
+    for (int i = 0; i < 2; ++i) pm_cgemm(dt, 0, opB, M, N, K, 1.0, dA, K, dB, ldb, dC, N, ws, wsb, nullptr);
+    HIPCHECK(hipEventRecord(e0, nullptr));
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) pm_cgemm(dt, 0, opB, M, N, K, 1.0, dA, K, dB, ldb, dC, N, ws, wsb, nullptr);
+    HIPCHECK(hipEventRecord(e1, nullptr));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    const double fl = 8.0 * M * N * K;
+    printf("BENCH cgemm %s %lldx%lldx%lld opB=%d ws=%zu: %.1f us -> %.1f TFLOP/s\n", sizeof(T) == 4 ? "c64" : "c128", (long long)M,
+           (long long)N, (long long)K, opB, wsb, ms * 1e3, fl / ms / 1e9);
+    HIPCHECK(hipFree(dA));
+    HIPCHECK(hipFree(dB));
+    HIPCHECK(hipFree(dC));
+    if (ws) HIPCHECK(hipFree(ws));
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "quick";
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s (%s) CUs=%d LDS/block=%zu version=%d\n", prop.name, prop.gcnArchName, prop.multiProcessorCount,
+           prop.sharedMemPerBlock, pm_version());
+    if (mode != "bench") {
+        const Case2 cases[] = {
+            {16, 16, 16, 16, 16, 16, true, -1, 0},   {8, 8, 8, 8, 8, 8, false, -1, 0},       {64, 32, 64, 32, 64, 32, true, -1, 0},
+            {32, 64, 16, 32, 32, 64, true, -1, 0},   {32, 64, 32, 64, 16, 32, true, 1, 0},   {128, 128, 128, 128, 128, 128, true, -1, 1},
+            {9, 12, 9, 12, 9, 12, true, -1, 0},      {14, 18, 9, 12, 14, 18, true, -1, 0},   {14, 18, 14, 18, 9, 12, true, 1, 0},
+            {7, 9, 7, 9, 7, 9, true, 1, 0},          {16, 12, 16, 12, 16, 12, true, -1, 0},  {12, 16, 12, 16, 12, 16, false, 1, 0},
+            {256, 256, 128, 128, 256, 256, true, -1, 0}, {512, 512, 512, 512, 512, 512, true, -1, 0},
+            {1024, 1024, 1024, 1024, 1024, 1024, false, -1, 0}, {1024, 2048, 512, 1024, 1024, 2048, true, -1, 1},
+            {2, 4, 2, 4, 2, 4, true, -1, 0},         {4, 2, 4, 2, 4, 2, false, -1, 0},      {1, 8, 1, 8, 1, 8, false, -1, 0},
+            {100, 60, 100, 60, 100, 60, true, -1, 0},
+        };
+        for (const auto& c : cases) {
+            check_fft2<float>(c, 5e-6);
+            check_fft2<double>(c, 1e-13);
+        }
+        if (mode == "full") {
+            const Case2 big[] = {{2048, 2048, 2048, 2048, 2048, 2048, true, -1, 0}, {4096, 4096, 4096, 4096, 4096, 4096, true, -1, 0},
+                                 {4096, 4096, 2048, 2048, 4096, 4096, true, -1, 1}, {8192, 8192, 8192, 8192, 8192, 8192, false, 1, 0}};
+            for (const auto& c : big) check_fft2<float>(c, 5e-6);
+            const Case2 bigd[] = {{2048, 2048, 2048, 2048, 2048, 2048, true, -1, 0}, {4096, 4096, 4096, 4096, 4096, 4096, true, 1, 0},
+                                  {8192, 4096, 8192, 4096, 8192, 4096, false, -1, 0}};
+            for (const auto& c : bigd) check_fft2<double>(c, 1e-13);
+        }
+        check_fft1<float>(64, 40, 33, 1, -1, 5e-6);
+        check_fft1<float>(64, 40, 33, 0, -1, 5e-6);
+        check_fft1<float>(50, 50, 7, 1, 1, 5e-6);
+        check_fft1<float>(50, 30, 7, 0, -1, 5e-6);
+        check_fft1<double>(1024, 700, 19, 0, 1, 1e-13);
+        check_fft1<double>(4096, 4096, 5, 1, -1, 1e-13);
+        check_fft1<float>(4096, 2500, 24, 0, -1, 5e-6);
+        for (int opA = 0; opA < 4; ++opA)
+            for (int opB = 0; opB < 4; ++opB) {
+                check_cgemm<float>(opA, opB, 70, 45, 100, 2e-5, false);
+                check_cgemm<double>(opA, opB, 33, 50, 37, 1e-13, false);
+            }
+        check_cgemm<float>(0, 0, 512, 2048, 2048, 5e-5, true);
+        check_cgemm<float>(0, 2, 512, 512, 2048, 5e-5, true);
+        check_cgemm<double>(3, 1, 200, 300, 1000, 1e-12, true);
+    }
+    if (mode != "quick") {
+        for (size_t mb : {128, 256, 1024}) {
+            const double ms = time_copy(mb << 20);
+            printf("BENCH d2d copy %zu MiB: %.1f us -> %.0f GB/s (read+write)\n", mb, ms * 1e3, 2.0 * double(mb << 20) / ms / 1e6);
+        }
+        bench_fft2<float>(2048, 2048, 0);
+        bench_fft2<float>(4096, 4096, 0);
+        bench_fft2<float>(4096, 4096, 1);
+        bench_fft2<float>(4096, 2048, 0);
+        bench_fft2<float>(8192, 8192, 0);
+        bench_fft2<double>(2048, 2048, 0);
+        bench_fft2<double>(4096, 4096, 0);
+        bench_fft2<float>(1024, 1024, 0);
+        bench_fft2<float>(512, 512, 0);
+        bench_cgemm<float>(512, 2048, 2048, 0);
+        bench_cgemm<float>(512, 512, 2048, 2);
+        bench_cgemm<float>(4096, 4096, 4096, 0);
+        bench_cgemm<double>(512, 2048, 2048, 0);
+        bench_cgemm<double>(2048, 2048, 2048, 0);
+    }
+    printf(g_fail ? "GPU CHECK FAILED (%d)\n" : "GPU CHECK OK\n", g_fail);
+    return g_fail ? 1 : 0;
+}
