@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Headline benchmark: pupil -> focus FFT propagations per second at 4096^2 complex64.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is ONE propagation ``focus(x, Q=1)`` = fftshift(fft2(ifftshift(x), norm='ortho')) of a
+synthetic 4096 x 4096 complex64 field already resident in HBM (BASELINE.json metric; config
+"4096^2 pupil->focus").  Each rank (one process per GPU) propagates its own field: the path
+shards over wavelengths / fields with no data-path collective (weak scaling); at N > 1 the timed
+region ends with the one real exchange of the polychromatic recipe -- |E|^2 of the last field and a
+sum all-reduce of that 67 MB fp32 image over RCCL -- reported separately as ``reduce_ms``.
+
+Rank 0 prints ONE JSON line.  ``roofline``: the dominant kernel (the slower of the two FFT passes),
+its duration measured with HIP events recorded between the kernels on the launch stream, in
+sequence; achieved = 2 N^2 s algorithmic bytes (read + write of one pass) / duration, peak 8 TB/s.
+``cpu_baseline``: the CPU oracle (a numpy/scipy restatement of prysm's focus, scipy.fft
+single-threaded exactly as prysm ships it) timed on this box's host cores on the same workload.
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_EDGE = 4096
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--n', type=int, default=N_EDGE, help='transform edge (default 4096, the headline)')
+    ap.add_argument('--dtype', default='c64', choices=['c64', 'c128'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget for the CPU baseline sample')
+    return ap.parse_args()
+
+
+def make_field(n, cdtype, seed):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))).astype(cdtype)
+    return x
+
+
+def kernel_pass_times(x, n, reps=20):
+    """Average duration (ms) of the row pass and of the column pass, HIP events on the launch stream."""
+    from prysm_amd import _lib as L
+    from prysm_amd import _ops
+    lib = L.load()
+    d = L.pm_fft2_desc()
+    d.dtype = L.code(x)
+    d.direction = -1
+    d.scale = 1.0 / n
+    d.weight = 1.0
+    ax = _ops._axis(n, n, 0, n // 2)
+    d.in_y = d.in_x = d.out_y = d.out_x = ax
+    d.in_ld = d.out_ld = n
+    out = torch.empty_like(x)
+    nbytes = lib.pm_fft2_workspace(ctypes.byref(d))
+    ws = L.workspace(nbytes)
+    ms = (ctypes.c_double * 2)()
+    L.check(lib.pm_fft2_time_passes(ctypes.byref(d), L.ptr(x), L.ptr(out), L.ptr(ws), ws.numel(), reps, ms,
+                                    L.stream_ptr()))
+    torch.cuda.synchronize()
+    return float(ms[0]), float(ms[1])
+
+
+def cpu_baseline(n, cdtype, budget_s):
+    """The oracle (port of prysm.propagation.focus) on host cores; scipy.fft workers=1 as prysm ships."""
+    from oracle import prysm_oracle as O
+    x = make_field(n, cdtype, 4096)
+    O.focus(x, 1)   # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 25):
+        t0 = time.perf_counter()
+        O.focus(x, 1)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {
+        'value': 1.0 / med, 'unit': 'propagations/s', 'cores': 1, 'kind': 'port',
+        'sample': f'{len(times)} x oracle.focus({n}x{n} {np.dtype(cdtype).name}, Q=1), median {med * 1e3:.1f} ms, '
+                  f'min {min(times) * 1e3:.1f} ms; scipy.fft workers=1 (as prysm ships), host has {os.cpu_count()} cores',
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU path)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL on ROCm
+    from prysm_amd import propagation as P
+    from prysm_amd import _ops
+
+    n = args.n
+    cdtype = np.complex64 if args.dtype == 'c64' else np.complex128
+    es = np.dtype(cdtype).itemsize
+    x = torch.from_numpy(make_field(n, cdtype, 4096 + rank)).cuda()
+    acc = None
+
+    def step():
+        return P.focus(x, 1)
+
+    for _ in range(args.warmup):
+        f = step()
+    if world > 1:
+        acc = _ops.abs2(f)
+        dist.all_reduce(acc)     # warm the communicator
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        f = step()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    reduce_ms = 0.0
+    if world > 1:
+        ev0.record()
+        acc = _ops.abs2(f, out=acc)
+        dist.all_reduce(acc)     # the incoherent sum over wavelengths / fields: one RCCL reduce over xGMI
+        ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        reduce_ms = ev0.elapsed_time(ev1)
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        p1, p2 = kernel_pass_times(x, n)
+        dom, dom_ms = ('row_pass', p1) if p1 >= p2 else ('column_pass', p2)
+        alg_bytes_kernel = 2.0 * n * n * es           # one pass reads N^2 s and writes N^2 s
+        achieved = alg_bytes_kernel / (dom_ms * 1e-3) / 1e9
+        alg_bytes_step = 4.0 * n * n * es             # 4 N^2 s per propagation
+        line = {
+            'metric': 'pupil->focus FFT propagations per second (PSFs/s), 4096^2',
+            'value': value, 'unit': 'propagations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'c64' if cdtype == np.complex64 else 'c128', 'data': 'synthetic',
+            'config': {'workload': f'focus(x, Q=1) on a {n}x{n} {np.dtype(cdtype).name} field resident in HBM '
+                                   '(fftshift(fft2(ifftshift(x), norm=ortho)), complex field out)',
+                       'fields_per_gpu_per_step': 1, 'parallelism': f'one field/wavelength per GPU x{world}',
+                       'reduce': 'none' if world == 1 else 'one RCCL all-reduce of the 4096^2 fp32 intensity per timed region'},
+            'whole_step_algorithmic_GBps_per_gpu': alg_bytes_step / (ms_step * 1e-3) / 1e9,
+            'whole_step_frac_of_hbm_peak': alg_bytes_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'reduce_ms': reduce_ms,
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'row_pass_ms': p1, 'column_pass_ms': p2,
+                         'note': '2*N^2*s algorithmic bytes per pass / HIP-event duration of that pass, in sequence'},
+        }
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(n, cdtype, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,182 @@
+"""ctypes binding of libprysm_amd.so (the C ABI in include/prysm_amd.h).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is
+visible, every compute call raises.  PyTorch is used only as the owner of
+device memory and streams; all arithmetic on the hot path happens in the HIP
+kernels behind this binding.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libprysm_amd.so')
+
+PM_C64, PM_C128, PM_F32, PM_F64, PM_BOOL = 0, 1, 2, 3, 4
+PM_EPI_NONE, PM_EPI_ABS2, PM_EPI_ABS2_ACCUM = 0, 1, 2
+PM_MUL_NONE, PM_MUL_FULL, PM_MUL_SEPARABLE = 0, 1, 2
+PM_FLAG_PASS1_ONLY, PM_FLAG_PASS2_ONLY = 1, 2
+PM_ERR_ARG, PM_ERR_UNSUPPORTED, PM_ERR_WORKSPACE = -1, -2, -3
+
+c_i32, c_i64, c_f64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+
+
+class pm_axis(ctypes.Structure):
+    _fields_ = [('n', c_i64), ('len', c_i64), ('off', c_i64), ('shift', c_i64)]
+
+
+class pm_fft2_desc(ctypes.Structure):
+    _fields_ = [
+        ('dtype', c_i32), ('direction', c_i32), ('epilogue', c_i32), ('flags', c_i32),
+        ('scale', c_f64), ('weight', c_f64),
+        ('in_y', pm_axis), ('in_x', pm_axis), ('out_y', pm_axis), ('out_x', pm_axis),
+        ('in_ld', c_i64), ('out_ld', c_i64),
+        ('mul_kind', c_i32), ('mul_conj', c_i32), ('mul', c_vp), ('mul_x', c_vp), ('mul_ld', c_i64),
+    ]
+
+
+# name -> (restype, argtypes); tests/test_capi_symbols.py checks this table against include/prysm_amd.h
+SIGNATURES = {
+    'pm_version': (c_i32, []),
+    'pm_last_error': (ctypes.c_char_p, []),
+    'pm_plan_prepare': (c_i32, [c_i32, c_i64]),
+    'pm_shutdown': (None, []),
+    'pm_fft2_workspace': (c_sz, [ctypes.POINTER(pm_fft2_desc)]),
+    'pm_fft2': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_vp, c_vp, c_vp, c_sz, c_vp]),
+    'pm_fft2_time_passes': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_vp, c_vp, c_vp, c_sz, c_i32,
+                                    ctypes.POINTER(c_f64), c_vp]),
+    'pm_fft1': (c_i32, [c_i32, c_i32, c_i32, c_i64, ctypes.POINTER(pm_axis), ctypes.POINTER(pm_axis), c_f64,
+                        c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'pm_cmul': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'pm_scale_sep': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_f64, c_vp, c_i64, c_vp]),
+    'pm_abs2': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_f64, c_vp]),
+    'pm_pupil_synth': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i32, c_i64, c_vp, c_i64, c_f64, c_vp, c_i64, c_vp]),
+    'pm_quadratic_phase': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_f64, c_vp, c_i64, c_vp]),
+    'pm_as_tf_vectors': (c_i32, [c_i32, c_i64, c_i64, c_f64, c_f64, c_f64, c_vp, c_vp, c_vp]),
+    'pm_outer': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'pm_embed': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    'pm_mdft_basis': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    'pm_cgemm': (c_i32, [c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_f64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                         c_vp, c_sz, c_vp]),
+    'pm_cgemm_workspace': (c_sz, [c_i32, c_i64, c_i64, c_i64]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libprysm_amd.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: build it with `make -C prysm_amd/csrc -j8` (or '
+            '`python -c "import __graft_entry__ as g; g.build()"`).  prysm_amd has no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class PrysmAmdError(RuntimeError):
+    """A HIP runtime error reported by libprysm_amd.so."""
+
+
+def check(rc):
+    """Translate a C return code into the exception class the reference would raise."""
+    if rc == 0:
+        return
+    lib = load()
+    if rc < 0:
+        msg = lib.pm_last_error().decode(errors='replace')
+        if rc == PM_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        raise ValueError(msg)
+    raise PrysmAmdError(f'libprysm_amd: HIP error {rc} (hipError_t); is an MI355X visible?')
+
+
+# --------------------------------------------------------------------------- tensors
+
+_COMPLEX_CODE = {torch.complex64: PM_C64, torch.complex128: PM_C128}
+_REAL_OF = {torch.complex64: torch.float32, torch.complex128: torch.float64}
+_COMPLEX_OF = {torch.float32: torch.complex64, torch.float64: torch.complex128, torch.float16: torch.complex64}
+_NP2TORCH = {
+    np.dtype('float32'): torch.float32, np.dtype('float64'): torch.float64, np.dtype('float16'): torch.float16,
+    np.dtype('complex64'): torch.complex64, np.dtype('complex128'): torch.complex128, np.dtype('bool'): torch.bool,
+    np.dtype('int32'): torch.int32, np.dtype('int64'): torch.int64, np.dtype('uint8'): torch.uint8,
+}
+
+
+def device():
+    """The MI355X this process computes on (torch's current device)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError('prysm_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm; there is no CPU path')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def torch_dtype(dt):
+    """numpy dtype-like or torch dtype -> torch dtype."""
+    if isinstance(dt, torch.dtype):
+        return dt
+    return _NP2TORCH[np.dtype(dt)]
+
+
+def as_device(x, dtype=None):
+    """numpy array / torch tensor / scalar sequence -> contiguous tensor in HBM."""
+    dev = device()
+    if isinstance(x, torch.Tensor):
+        t = x.to(dev) if x.device != dev else x
+    else:
+        a = np.ascontiguousarray(x)
+        t = torch.from_numpy(a).to(dev)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t
+
+
+def as_complex(x, at_least=None):
+    """Promote like numpy does for fft input: f32 -> c64, everything else real -> c128; keep complex.
+
+    `at_least` (a torch complex dtype) raises c64 to c128 when config.precision demands it.
+    """
+    t = as_device(x)
+    if not t.is_complex():
+        t = t.to(_COMPLEX_OF.get(t.dtype, torch.complex128))
+    if at_least is not None and at_least == torch.complex128 and t.dtype == torch.complex64:
+        t = t.to(torch.complex128)
+    return t
+
+
+def code(t):
+    return _COMPLEX_CODE[t.dtype]
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+_workspaces = {}
+
+
+def workspace(nbytes):
+    """Scratch buffer in HBM, reused per (device, stream); stream-ordered so back-to-back calls are safe."""
+    if nbytes <= 0:
+        return None
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    w = _workspaces.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(int(nbytes), dtype=torch.uint8, device=device())
+        _workspaces[key] = w
+    return w

@@ -1,0 +1,213 @@
+"""Thin Python wrappers over the C ABI: build descriptors, allocate outputs, enqueue.
+
+Everything here operates on torch tensors resident in HBM and enqueues on
+torch's current stream.  No arithmetic happens in Python.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _axis(n, length=None, off=0, shift=0):
+    return L.pm_axis(int(n), int(n if length is None else length), int(off), int(shift))
+
+
+def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
+         out_shape=None, out_off=(0, 0), out_shift=(0, 0), epilogue=L.PM_EPI_NONE,
+         mul=None, mul_x=None, mul_conj=False, out=None, weight=1.0, flags=0):
+    """Fused 2-D transform (pm_fft2).
+
+    x          : (m, n) complex tensor; it sits at `in_off` inside the logical `shape` = (M, N) array
+                 (zero elsewhere), which is then rotated by `in_shift`
+    out_shape  : stored window of the output (crop), at `out_off` of the rotated result
+    mul, mul_x : None | full (M, N) multiplier | (column vector hy (M,), row vector hx (N,))
+    """
+    lib = L.load()
+    m, n = x.shape
+    M, N = (m, n) if shape is None else shape
+    om, on = (M, N) if out_shape is None else out_shape
+    d = L.pm_fft2_desc()
+    d.dtype = L.code(x)
+    d.direction = direction
+    d.epilogue = epilogue
+    d.flags = flags
+    d.scale = float(scale)
+    d.weight = float(weight)
+    d.in_y = _axis(M, m, in_off[0], in_shift[0])
+    d.in_x = _axis(N, n, in_off[1], in_shift[1])
+    d.out_y = _axis(M, om, out_off[0], out_shift[0])
+    d.out_x = _axis(N, on, out_off[1], out_shift[1])
+    d.in_ld = x.stride(0) if m > 1 else n
+    keep = [x]
+    if mul is not None and mul_x is not None:
+        d.mul_kind = L.PM_MUL_SEPARABLE
+        d.mul = mul.data_ptr()
+        d.mul_x = mul_x.data_ptr()
+        keep += [mul, mul_x]
+    elif mul is not None:
+        d.mul_kind = L.PM_MUL_FULL
+        d.mul = mul.data_ptr()
+        d.mul_ld = mul.stride(0) if mul.shape[0] > 1 else mul.shape[1]
+        keep.append(mul)
+    d.mul_conj = 1 if mul_conj else 0
+    if out is None:
+        odt = x.dtype if epilogue == L.PM_EPI_NONE else L._REAL_OF[x.dtype]
+        out = torch.empty((om, on), dtype=odt, device=x.device)
+    d.out_ld = out.stride(0) if om > 1 else on
+    nbytes = lib.pm_fft2_workspace(ctypes.byref(d))
+    if nbytes == 0:
+        L.check(lib.pm_fft2(ctypes.byref(d), L.ptr(x), L.ptr(out), None, 0, L.stream_ptr()))  # raises with the reason
+    ws = L.workspace(nbytes)
+    L.check(lib.pm_fft2(ctypes.byref(d), L.ptr(x), L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()))
+    return out
+
+
+def fft1(x, n=None, axis=-1, direction=-1, scale=1.0, out_len=None, out_off=0, in_off=0):
+    """Batched 1-D transform along `axis` of a 2-D tensor (pm_fft1).
+
+    The input is zero padded (placed at `in_off`) or truncated to length n; the stored output is the
+    window [out_off, out_off + out_len) of the n bins.  direction -1: exp(-2 pi i ..); +1: exp(+..).
+    """
+    lib = L.load()
+    if x.dim() == 1:
+        return fft1(x[None, :], n, 1, direction, scale, out_len, out_off, in_off)[0]
+    axis = axis % 2
+    rows, cols = x.shape
+    length = rows if axis == 0 else cols
+    n = length if n is None else int(n)
+    batch = cols if axis == 0 else rows
+    olen = n if out_len is None else int(out_len)
+    t_in = _axis(n, min(length, n - in_off), in_off, 0)
+    t_out = _axis(n, olen, out_off, 0)
+    oshape = (olen, cols) if axis == 0 else (rows, olen)
+    out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    L.check(lib.pm_fft1(L.code(x), direction, axis, batch, ctypes.byref(t_in), ctypes.byref(t_out), float(scale),
+                        L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
+def cmul(a, b, conj_b=False):
+    lib = L.load()
+    out = torch.empty_like(a)
+    rows, cols = a.shape
+    L.check(lib.pm_cmul(L.code(a), 1 if conj_b else 0, rows, cols, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0),
+                        L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
+def scale_sep(x, row_vec=None, col_vec=None, row_conj=False, col_conj=False, scale=1.0):
+    """out[i, j] = x[i, j] * row_vec[i] * col_vec[j] * scale (row_vec indexes rows, col_vec columns)."""
+    lib = L.load()
+    out = torch.empty_like(x)
+    rows, cols = x.shape
+    L.check(lib.pm_scale_sep(L.code(x), rows, cols, L.ptr(x), x.stride(0), L.ptr(row_vec), 1 if row_conj else 0,
+                             L.ptr(col_vec), 1 if col_conj else 0, float(scale), L.ptr(out), out.stride(0),
+                             L.stream_ptr()))
+    return out
+
+
+def abs2(x, out=None, weight=None):
+    """|x|^2, or out += weight * |x|^2 when `out` and `weight` are given."""
+    lib = L.load()
+    rows, cols = x.shape
+    acc = 0
+    if out is None:
+        out = torch.empty((rows, cols), dtype=L._REAL_OF[x.dtype], device=x.device)
+    elif weight is not None:
+        acc = 1
+    L.check(lib.pm_abs2(L.code(x), rows, cols, L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), acc,
+                        float(1.0 if weight is None else weight), L.stream_ptr()))
+    return out
+
+
+_AMP_CODE = {torch.float32: L.PM_F32, torch.float64: L.PM_F64, torch.bool: L.PM_BOOL, torch.uint8: L.PM_BOOL}
+
+
+def pupil_synth(amp, opd, k, cdtype):
+    """amp * exp(i k opd); opd real tensor of the real dtype of `cdtype`."""
+    lib = L.load()
+    rows, cols = opd.shape
+    out = torch.empty((rows, cols), dtype=cdtype, device=opd.device)
+    a_code, a_ld = L.PM_F32, cols
+    if amp is not None:
+        if amp.dtype not in _AMP_CODE:
+            amp = amp.to(L._REAL_OF[cdtype])
+        a_code, a_ld = _AMP_CODE[amp.dtype], amp.stride(0)
+    L.check(lib.pm_pupil_synth(L._COMPLEX_CODE[cdtype], rows, cols, L.ptr(amp), a_code, a_ld, L.ptr(opd),
+                               opd.stride(0), float(k), L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
+def quadratic_phase(x, y, c, cdtype):
+    lib = L.load()
+    rows, cols = x.shape
+    out = torch.empty((rows, cols), dtype=cdtype, device=x.device)
+    L.check(lib.pm_quadratic_phase(L._COMPLEX_CODE[cdtype], rows, cols, L.ptr(x), x.stride(0), L.ptr(y), y.stride(0),
+                                   float(c), L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
+def as_tf_vectors(shape, wvl, dx, z, cdtype):
+    lib = L.load()
+    rows, cols = shape
+    hy = torch.empty(rows, dtype=cdtype, device=L.device())
+    hx = torch.empty(cols, dtype=cdtype, device=L.device())
+    L.check(lib.pm_as_tf_vectors(L._COMPLEX_CODE[cdtype], rows, cols, float(wvl), float(dx), float(z), L.ptr(hy),
+                                 L.ptr(hx), L.stream_ptr()))
+    return hy, hx
+
+
+def outer(hy, hx):
+    lib = L.load()
+    rows, cols = hy.numel(), hx.numel()
+    out = torch.empty((rows, cols), dtype=hy.dtype, device=hy.device)
+    L.check(lib.pm_outer(L.code(hy), rows, cols, L.ptr(hy), L.ptr(hx), L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
+def embed(x, out_shape, off, fill=0):
+    """out = fill; out[off_y:off_y+m, off_x:off_x+n] = x (negative offsets crop)."""
+    lib = L.load()
+    m, n = x.shape
+    om, on = out_shape
+    out = torch.empty((om, on), dtype=x.dtype, device=x.device)
+    es = x.element_size()
+    if es == 2:   # float16: no kernel for 2-byte elements; widen is not acceptable silently
+        raise NotImplementedError('pad2d of 2-byte element arrays is not supported')
+    fill_t = torch.tensor([fill], dtype=x.dtype)   # host scalar, passed by pointer
+    L.check(lib.pm_embed(es, m, n, L.ptr(x), x.stride(0) if m > 1 else n, om, on, int(off[0]), int(off[1]),
+                         ctypes.c_void_p(fill_t.data_ptr()), L.ptr(out), out.stride(0) if om > 1 else on,
+                         L.stream_ptr()))
+    return out
+
+
+def mdft_basis(f, x, sign, cdtype):
+    """E[m, n] = exp(sign 2 pi i f[m] x[n])."""
+    lib = L.load()
+    M, N = f.numel(), x.numel()
+    E = torch.empty((M, N), dtype=cdtype, device=f.device)
+    L.check(lib.pm_mdft_basis(L._COMPLEX_CODE[cdtype], M, N, L.ptr(f), L.ptr(x), int(sign), L.ptr(E), E.stride(0),
+                              L.stream_ptr()))
+    return E
+
+
+def cgemm(A, B, opA=0, opB=0, alpha=1.0):
+    """alpha * op(A) @ op(B) on the MFMA cores.  op: 0 none, 1 conj, 2 transpose, 3 conjugate transpose."""
+    lib = L.load()
+    M, K = (A.shape[1], A.shape[0]) if opA & 2 else A.shape
+    K2, N = (B.shape[1], B.shape[0]) if opB & 2 else B.shape
+    if K != K2:
+        raise ValueError(f'matmul: inner dimensions differ ({K} vs {K2})')
+    C = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    nbytes = lib.pm_cgemm_workspace(L.code(A), M, N, K)
+    ws = L.workspace(nbytes)
+    L.check(lib.pm_cgemm(L.code(A), opA, opB, M, N, K, float(alpha), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0),
+                         L.ptr(C), C.stride(0), L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr()))
+    return C
+
+
+def ceil_half(d):
+    return math.ceil(d / 2)

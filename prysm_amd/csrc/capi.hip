@@ -297,31 +297,42 @@ int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, s
 
 int pm_fft2_time_passes(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes,
                         int reps, double* ms, void* stream) {
-    if (!ms || reps < 1) return fail(PM_ERR_ARG, "pm_fft2_time_passes: bad argument");
+    // Per-kernel durations measured IN SEQUENCE (row pass, column pass, row pass, ...) with hipEvents
+    // recorded on the launch stream between the two kernels of every propagation, so cache state is the
+    // one the real back-to-back workload sees.  ms[0] = row pass, ms[1] = column pass, averages.
+    if (!ms || reps < 1 || reps > 256) return fail(PM_ERR_ARG, "pm_fft2_time_passes: reps must be in [1, 256]");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipEvent_t e0, e1;
-    hipError_t he;
-    if ((he = hipEventCreate(&e0)) != hipSuccess) return int(he);
-    if ((he = hipEventCreate(&e1)) != hipSuccess) return int(he);
-    pm_fft2_desc dd = *d;
-    int rc = 0;
-    // full transform once so both passes have valid inputs, then each pass alone
-    dd.flags = 0;
-    rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
-    for (int pass = 0; pass < 2 && !rc; ++pass) {
-        dd.flags = pass == 0 ? PM_FLAG_PASS1_ONLY : PM_FLAG_PASS2_ONLY;
-        rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);   // warm
-        if (rc) break;
-        (void)hipEventRecord(e0, st);
-        for (int i = 0; i < reps && !rc; ++i) rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
-        (void)hipEventRecord(e1, st);
-        (void)hipEventSynchronize(e1);
-        float t = 0.f;
-        (void)hipEventElapsedTime(&t, e0, e1);
-        ms[pass] = double(t) / reps;
+    std::vector<hipEvent_t> ev(size_t(reps) * 3);
+    for (auto& e : ev) {
+        hipError_t he = hipEventCreate(&e);
+        if (he != hipSuccess) return int(he);
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    pm_fft2_desc dd = *d;
+    dd.flags = 0;
+    int rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);   // warm (also builds the plan)
+    for (int i = 0; i < reps && !rc; ++i) {
+        (void)hipEventRecord(ev[size_t(i) * 3 + 0], st);
+        dd.flags = PM_FLAG_PASS1_ONLY;
+        rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
+        (void)hipEventRecord(ev[size_t(i) * 3 + 1], st);
+        dd.flags = PM_FLAG_PASS2_ONLY;
+        if (!rc) rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
+        (void)hipEventRecord(ev[size_t(i) * 3 + 2], st);
+    }
+    ms[0] = ms[1] = 0.0;
+    if (!rc) {
+        (void)hipEventSynchronize(ev.back());
+        for (int i = 0; i < reps; ++i) {
+            float a = 0.f, b = 0.f;
+            (void)hipEventElapsedTime(&a, ev[size_t(i) * 3 + 0], ev[size_t(i) * 3 + 1]);
+            (void)hipEventElapsedTime(&b, ev[size_t(i) * 3 + 1], ev[size_t(i) * 3 + 2]);
+            ms[0] += double(a);
+            ms[1] += double(b);
+        }
+        ms[0] /= reps;
+        ms[1] /= reps;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
 }
 

@@ -1,0 +1,358 @@
+"""Fourier-transform toolbox on the MI355X: the counterpart of prysm/fttools.py.
+
+Same names, arguments and conventions as the reference (everything is
+"FFT-centred": the origin sits at index n//2); arrays are torch tensors in HBM.
+"""
+import math
+
+import numpy as truenp
+import torch
+
+from . import _lib as L
+from . import _ops
+from .conf import config
+
+
+def _rdtype():
+    return L.torch_dtype(config.precision)
+
+
+def _cdtype():
+    return L.torch_dtype(config.precision_complex)
+
+
+def fftrange(n, dtype=None):
+    """FFT-aligned coordinate grid for n samples (prysm/fttools.py:13-15)."""
+    dt = torch.int64 if dtype is None else L.torch_dtype(dtype)
+    return torch.arange(-(n // 2), -(n // 2) + n, dtype=dt, device=L.device())
+
+
+def _next_power_of_2(n):
+    return 1 << math.ceil(math.log2(n))
+
+
+def next_fast_len(n):
+    """The next fast FFT size (prysm/fttools.py:23-31).
+
+    The engine's fast lengths are the powers of two (the reference's own fallback when the FFT
+    backend offers no next_fast_len).
+    """
+    return _next_power_of_2(n)
+
+
+def fftfreq(n, d=1.0):
+    """FFT frequency vector in config.precision (prysm/fttools.py:34-40)."""
+    out = truenp.fft.fftfreq(n, d).astype(config.precision)
+    return L.as_device(out)
+
+
+def pad2d(array, Q=2, value=0, mode='constant', out_shape=None):
+    """Symmetrically pad a 2-D array (prysm/fttools.py:43-100); data lands at offset ceil(d/2)."""
+    if Q == 1 and out_shape is None:
+        return array
+    array = L.as_device(array)
+    in_shape = tuple(array.shape)
+    if out_shape is None:
+        out_shape = [math.ceil(s * Q) for s in in_shape]
+    elif isinstance(out_shape, int):
+        out_shape = [out_shape] * array.dim()
+    if mode != 'constant':
+        raise NotImplementedError("pad2d: only mode='constant' runs on the device")
+    shape_diff = [o - i for o, i in zip(out_shape, in_shape)]
+    off = [math.ceil(d / 2) for d in shape_diff]
+    return _ops.embed(array, tuple(out_shape), off, fill=value)
+
+
+def crop_center(img, out_shape):
+    """Crop the central out_shape window, FFT aligned (prysm/fttools.py:103-125).
+
+    Returns a view, like the reference.
+    """
+    if isinstance(out_shape, int):
+        out_shape = (out_shape, out_shape)
+    padding = [i - o for i, o in zip(img.shape, out_shape)]
+    left = [math.ceil(p / 2) for p in padding]
+    slcs = tuple(slice(l, l + o) for l, o in zip(left, out_shape))  # NOQA
+    return img[slcs]
+
+
+def forward_ft_unit(dx, samples, shift=True):
+    """Frequency axis of an FFT (prysm/fttools.py:128-152)."""
+    unit = fftfreq(samples, dx)
+    if shift:
+        return torch.roll(unit, samples // 2)
+    return unit
+
+
+def _as_real_vec(v):
+    t = L.as_device(v)
+    if t.is_complex():
+        raise TypeError('coordinate vectors must be real')
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.to(_rdtype())
+    return t
+
+
+def _promote_input(ary, cdtype):
+    """numpy-style result type of (input array) x (operator of dtype cdtype)."""
+    t = L.as_complex(ary)
+    if cdtype == torch.complex128 and t.dtype == torch.complex64:
+        t = t.to(torch.complex128)
+    return t
+
+
+class MDFT:
+    """Matrix DFT: out = norm * Ey @ ary @ Ex.T on the MFMA matrix cores.
+
+    Mirror of prysm.fttools.MDFT (prysm/fttools.py:155-232): same constructor, ``__call__``,
+    ``adjoint``, ``nbytes`` and the same attributes (``Ex``, ``Ey``, ``norm``,
+    ``_forward_left_first``, ``_adjoint_left_first``).  The bases are generated on the device
+    (phase reduced in fp64, one rounding) and held by the instance -- holding the instance is the
+    caching mechanism, as in the reference.
+    """
+
+    def __init__(self, x, y, fx, fy, sign=-1, norm=1.0):
+        x, y, fx, fy = (_as_real_vec(v) for v in (x, y, fx, fy))
+        rd = torch.float64 if torch.float64 in (x.dtype, fx.dtype, y.dtype, fy.dtype) else torch.float32
+        x, y, fx, fy = (v.to(rd) for v in (x, y, fx, fy))
+        cd = L._COMPLEX_OF[rd]
+        self.Ex = _ops.mdft_basis(fx, x, sign, cd)   # (len(fx), len(x))
+        self.Ey = _ops.mdft_basis(fy, y, sign, cd)   # (len(fy), len(y))
+        self.norm = norm
+        Nx, Ny, Mx, My = x.numel(), y.numel(), fx.numel(), fy.numel()
+        self._forward_left_first = My * Nx * (Ny + Mx) <= Ny * Mx * (Nx + My)
+        self._adjoint_left_first = Ny * Mx * (My + Nx) <= My * Nx * (Mx + Ny)
+
+    def _cast(self, ary):
+        a = _promote_input(ary, self.Ex.dtype)
+        if a.dtype != self.Ex.dtype:   # complex128 data through float32 bases: numpy promotes the bases
+            return a, self.Ex.to(a.dtype), self.Ey.to(a.dtype)
+        return a, self.Ex, self.Ey
+
+    def __call__(self, ary):
+        """Apply the forward DFT to ary (prysm/fttools.py:201-207)."""
+        a, Ex, Ey = self._cast(ary)
+        if not self._forward_left_first:
+            out = _ops.cgemm(a, Ex, 0, 2)                      # ary @ Ex.T
+            return _ops.cgemm(Ey, out, 0, 0, alpha=self.norm)  # Ey @ .
+        out = _ops.cgemm(Ey, a, 0, 0)
+        return _ops.cgemm(out, Ex, 0, 2, alpha=self.norm)
+
+    def adjoint(self, grad):
+        """Apply the conjugate transpose (prysm/fttools.py:209-228): norm * Ey^H @ grad @ conj(Ex)."""
+        g, Ex, Ey = self._cast(grad)
+        if not self._adjoint_left_first:
+            out = _ops.cgemm(g, Ex, 0, 1)                      # grad @ conj(Ex)
+            return _ops.cgemm(Ey, out, 3, 0, alpha=self.norm)  # Ey^H @ .
+        out = _ops.cgemm(Ey, g, 3, 0)
+        return _ops.cgemm(out, Ex, 0, 1, alpha=self.norm)
+
+    def nbytes(self):
+        """Total size in memory of the basis matrices, bytes."""
+        return self.Ex.numel() * self.Ex.element_size() + self.Ey.numel() * self.Ey.element_size()
+
+
+def _cexp_turns(turns):
+    """exp(2 pi i t) for a real float64 vector t, in config.precision_complex (device kernel)."""
+    t = turns.to(torch.float64)
+    one = torch.ones(1, dtype=torch.float64, device=t.device)
+    E = _ops.mdft_basis(t, one, +1, torch.complex128)[:, 0].contiguous()
+    return E.to(_cdtype())
+
+
+class CZT:
+    """Chirp-Z transform with the same external API as MDFT (prysm/fttools.py:235-361).
+
+    Bluestein factorisation per axis: chirp multiply, zero-padded FFT of length K, multiply by the
+    transformed chirp, inverse FFT, slice, chirp multiply.  The FFTs are the library's batched 1-D
+    passes; zero padding and slicing are folded into their load / store windows.
+    """
+
+    def __init__(self, x, y, fx, fy, sign=-1, norm=1.0):
+        if sign not in (-1, 1):
+            raise ValueError(f'sign must be -1 or +1, got {sign}')
+        self.sign = sign
+        self.norm = norm
+        x, y, fx, fy = (_as_real_vec(v) for v in (x, y, fx, fy))
+        Nx, Mx, Ny, My = x.numel(), fx.numel(), y.numel(), fy.numel()
+        xs, ys, fxs, fys = (v.to(torch.float64) for v in (x, y, fx, fy))
+        dx = float(xs[1] - xs[0])
+        dfx = float(fxs[1] - fxs[0])
+        dy = float(ys[1] - ys[0])
+        dfy = float(fys[1] - fys[0])
+        alpha_x, alpha_y = dx * dfx, dy * dfy
+        shift_x = float(fxs[Mx // 2]) / dfx
+        shift_y = float(fys[My // 2]) / dfy
+        Kx = next_fast_len(Nx + Mx - 1)
+        Ky = next_fast_len(Ny + My - 1)
+        Hx, bx, ax = _prepare_czt_basis(Nx, Mx, Kx, shift_x, alpha_x, sign)
+        Hy, by, ay = _prepare_czt_basis(Ny, My, Ky, shift_y, alpha_y, sign)
+        self._brow, self._Hrow, self._arow = by, Hy, ay        # vectors along axis 0
+        self._bcol, self._Hcol, self._acol = bx, Hx, ax        # vectors along axis 1
+        self._x_phase = _cexp_turns(sign * float(xs[Nx // 2]) * fxs)
+        self._y_phase = _cexp_turns(sign * float(ys[Ny // 2]) * fys)
+        # post-slice factors a * phase, applied in one sweep
+        self._post_col = (self._acol * self._x_phase).contiguous()
+        self._post_row = (self._arow * self._y_phase).contiguous()
+        self._Nx, self._Ny, self._Mx, self._My = Nx, Ny, Mx, My
+        self._Kx, self._Ky = Kx, Ky
+        self._sx, self._sy = Nx - 1, Ny - 1
+        x_first_cost = Ny * Kx * math.log2(Kx) + Mx * Ky * math.log2(Ky)
+        y_first_cost = Nx * Ky * math.log2(Ky) + My * Kx * math.log2(Kx)
+        self._x_first = x_first_cost <= y_first_cost
+
+    def _xaxis(self, out, scale=1.0):
+        out = _ops.fft1(out, self._Kx, axis=1)
+        out = _ops.scale_sep(out, col_vec=self._Hcol)
+        out = _ops.fft1(out, axis=1, direction=+1, scale=1.0 / self._Kx, out_len=self._Mx, out_off=self._sx)
+        return _ops.scale_sep(out, col_vec=self._post_col, scale=scale)
+
+    def _yaxis(self, out, scale=1.0):
+        out = _ops.fft1(out, self._Ky, axis=0)
+        out = _ops.scale_sep(out, row_vec=self._Hrow)
+        out = _ops.fft1(out, axis=0, direction=+1, scale=1.0 / self._Ky, out_len=self._My, out_off=self._sy)
+        return _ops.scale_sep(out, row_vec=self._post_row, scale=scale)
+
+    def __call__(self, ary):
+        a = _promote_input(ary, _cdtype()).to(_cdtype())
+        out = _ops.scale_sep(a, row_vec=self._brow, col_vec=self._bcol)
+        if self._x_first:
+            return self._yaxis(self._xaxis(out), scale=self.norm)
+        return self._xaxis(self._yaxis(out), scale=self.norm)
+
+    def _xadj(self, out):
+        # zero-embed at [sx, sx+Mx) of length Kx, fft, * conj(H), ifft, keep [:Nx]
+        out = _ops.fft1(out, self._Kx, axis=1, in_off=self._sx)
+        out = _ops.scale_sep(out, col_vec=self._Hcol, col_conj=True)
+        return _ops.fft1(out, axis=1, direction=+1, scale=1.0 / self._Kx, out_len=self._Nx)
+
+    def _yadj(self, out):
+        out = _ops.fft1(out, self._Ky, axis=0, in_off=self._sy)
+        out = _ops.scale_sep(out, row_vec=self._Hrow, row_conj=True)
+        return _ops.fft1(out, axis=0, direction=+1, scale=1.0 / self._Ky, out_len=self._Ny)
+
+    def adjoint(self, grad):
+        g = _promote_input(grad, _cdtype()).to(_cdtype())
+        out = _ops.scale_sep(g, row_vec=self._post_row, col_vec=self._post_col, row_conj=True, col_conj=True)
+        if self._x_first:
+            out = self._xadj(self._yadj(out))
+        else:
+            out = self._yadj(self._xadj(out))
+        return _ops.scale_sep(out, row_vec=self._brow, col_vec=self._bcol, row_conj=True, col_conj=True,
+                              scale=self.norm)
+
+    def nbytes(self):
+        total = 0
+        for arr in (self._brow, self._bcol, self._Hrow, self._Hcol, self._arow, self._acol,
+                    self._x_phase, self._y_phase):
+            total += arr.numel() * arr.element_size()
+        return total
+
+
+def _prepare_czt_basis(N, M, K, shift, alpha, sign=-1):
+    """prysm/fttools.py:364-389; phases formed in fp64 on the device, FFT of the chirp by pm_fft1."""
+    n = fftrange(N, dtype=torch.float64)
+    m = fftrange(M, dtype=torch.float64)
+    q = m + shift
+    half = sign * alpha / 2.0           # exp(sign i pi alpha q^2) = exp(2 pi i * half * q^2)
+    a = _cexp_turns(half * q * q)
+    b = _cexp_turns(half * n * n)
+    d_min = float(m[0] - n[-1])
+    d_max = float(m[-1] - n[0])
+    d = torch.arange(d_min, d_max + 1, dtype=torch.float64, device=L.device())
+    h = torch.zeros(K, dtype=_cdtype(), device=L.device())
+    h[:d.numel()] = _cexp_turns(-half * (d + shift) * (d + shift))
+    H = _ops.fft1(h, K, axis=-1)
+    return H, b, a
+
+
+class FFTDFT:
+    """DFT accelerated by FFTs for compatible uniform grids (prysm/fttools.py:392-535).
+
+    Requires |dx * dfx| = 1/K with integer K >= max(N, M) per axis; one zero-padded FFT per axis,
+    the axis producing the smaller intermediate first.
+    """
+
+    def __init__(self, x, y, fx, fy, sign=-1, norm=1.0):
+        if sign not in (-1, 1):
+            raise ValueError(f'sign must be -1 or +1, got {sign}')
+        x, y, fx, fy = (_as_real_vec(v) for v in (x, y, fx, fy))
+        Nx, Ny, Mx, My = x.numel(), y.numel(), fx.numel(), fy.numel()
+        dx = _uniform_spacing(x, 'x')
+        dy = _uniform_spacing(y, 'y')
+        dfx = _uniform_spacing(fx, 'fx')
+        dfy = _uniform_spacing(fy, 'fy')
+        Kx = _fft_compatible_length(dx * dfx, Nx, Mx, 'x/fx')
+        Ky = _fft_compatible_length(dy * dfy, Ny, My, 'y/fy')
+        xs, ys, fxs, fys = (v.to(torch.float64) for v in (x, y, fx, fy))
+        nx = torch.arange(Nx, dtype=torch.float64, device=L.device())
+        ny = torch.arange(Ny, dtype=torch.float64, device=L.device())
+        self._pre_x = _cexp_turns(sign * nx * dx * float(fxs[0]))
+        self._pre_y = _cexp_turns(sign * ny * dy * float(fys[0]))
+        self._post_x = _cexp_turns(sign * float(xs[0]) * fxs)
+        self._post_y = _cexp_turns(sign * float(ys[0]) * fys)
+        self._Nx, self._Ny, self._Mx, self._My = Nx, Ny, Mx, My
+        self._Kx, self._Ky = Kx, Ky
+        self._x_direction = sign if dx * dfx > 0 else -sign
+        self._y_direction = sign if dy * dfy > 0 else -sign
+        self.norm = norm
+        x_first_cost = Ny * Kx * math.log2(Kx) + Mx * Ky * math.log2(Ky)
+        y_first_cost = Nx * Ky * math.log2(Ky) + My * Kx * math.log2(Kx)
+        self._x_first = x_first_cost <= y_first_cost
+
+    def __call__(self, ary):
+        a = _promote_input(ary, _cdtype()).to(_cdtype())
+        out = _ops.scale_sep(a, row_vec=self._pre_y, col_vec=self._pre_x)
+        # fft(ary, K) or ifft(ary, K) * K == the unnormalised transform of either sign
+        if self._x_first:
+            out = _ops.fft1(out, self._Kx, axis=1, direction=self._x_direction, out_len=self._Mx)
+            out = _ops.fft1(out, self._Ky, axis=0, direction=self._y_direction, out_len=self._My)
+        else:
+            out = _ops.fft1(out, self._Ky, axis=0, direction=self._y_direction, out_len=self._My)
+            out = _ops.fft1(out, self._Kx, axis=1, direction=self._x_direction, out_len=self._Mx)
+        return _ops.scale_sep(out, row_vec=self._post_y, col_vec=self._post_x, scale=self.norm)
+
+    def adjoint(self, grad):
+        g = _promote_input(grad, _cdtype()).to(_cdtype())
+        out = _ops.scale_sep(g, row_vec=self._post_y, col_vec=self._post_x, row_conj=True, col_conj=True)
+        # adjoint of a cropped unnormalised transform: zero pad to K, opposite sign, keep the first N
+        if self._x_first:
+            out = _ops.fft1(out, self._Ky, axis=0, direction=-self._y_direction, out_len=self._Ny)
+            out = _ops.fft1(out, self._Kx, axis=1, direction=-self._x_direction, out_len=self._Nx)
+        else:
+            out = _ops.fft1(out, self._Kx, axis=1, direction=-self._x_direction, out_len=self._Nx)
+            out = _ops.fft1(out, self._Ky, axis=0, direction=-self._y_direction, out_len=self._Ny)
+        return _ops.scale_sep(out, row_vec=self._pre_y, col_vec=self._pre_x, row_conj=True, col_conj=True,
+                              scale=self.norm)
+
+    def nbytes(self):
+        return sum(a.numel() * a.element_size() for a in (self._pre_x, self._pre_y, self._post_x, self._post_y))
+
+
+def _uniform_spacing(values, name):
+    """prysm/fttools.py:538-552."""
+    if values.numel() < 2:
+        raise ValueError(f'{name} must contain at least two samples')
+    v = values.to(torch.float64)
+    spacing = float(v[1] - v[0])
+    if spacing == 0:
+        raise ValueError(f'{name} must have nonzero spacing')
+    tolerance = 32 * float(truenp.finfo(config.precision).eps)
+    scale = max(1.0, abs(float(v[0])), abs(float(v[-1])), abs(spacing))
+    diffs = torch.diff(v)
+    if not bool(torch.all(torch.abs(diffs - spacing) <= tolerance * scale + tolerance * abs(spacing))):
+        raise ValueError(f'{name} must be uniformly spaced')
+    return spacing
+
+
+def _fft_compatible_length(alpha, N, M, name):
+    """prysm/fttools.py:555-571."""
+    inv_alpha = 1 / abs(alpha)
+    K = round(inv_alpha)
+    tolerance = 32 * float(truenp.finfo(config.precision).eps)
+    if not math.isclose(inv_alpha, K, rel_tol=tolerance, abs_tol=tolerance):
+        raise ValueError(f'{name} spacings are not FFT-compatible: '
+                         'abs(input spacing * output spacing) must be 1/integer')
+    if K < max(N, M):
+        raise ValueError(f'{name} requires FFT length {K}, smaller than input/output length {max(N, M)}')
+    return K

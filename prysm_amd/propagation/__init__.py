@@ -1,0 +1,45 @@
+"""Numerical optical propagation on the MI355X -- the counterpart of prysm/propagation/__init__.py.
+
+Files:
+- fft               FFT-based pupil <-> focal propagation (one fused device call per propagation)
+- dft               matrix-DFT / chirp-Z / FFT-DFT propagation with arbitrary sampling (MFMA GEMMs)
+- angular_spectrum  plane-to-plane free space propagation
+- wavefront         the Wavefront type, object oriented interface
+"""
+from .fft import (
+    focus,
+    focus_adjoint,
+    unfocus,
+    unfocus_adjoint,
+    focus_intensity,
+    Q_for_sampling,
+    pupil_sample_to_psf_sample,
+    psf_sample_to_pupil_sample,
+)
+from .dft import (
+    coordinates_for_focus,
+    prepare_executor,
+    unit_cell_focal_grid,
+    focus_dft,
+    focus_dft_adjoint,
+    unfocus_dft,
+    unfocus_dft_adjoint,
+    focus_fixed_sampling,
+)
+from .angular_spectrum import (
+    angular_spectrum,
+    angular_spectrum_adjoint,
+    angular_spectrum_transfer_function,
+    fresnel_number,
+    talbot_distance,
+)
+from .wavefront import Wavefront
+from ._kernels import phase_prefix
+
+__all__ = [
+    'focus', 'focus_adjoint', 'unfocus', 'unfocus_adjoint', 'focus_intensity', 'Q_for_sampling',
+    'pupil_sample_to_psf_sample', 'psf_sample_to_pupil_sample', 'coordinates_for_focus',
+    'prepare_executor', 'unit_cell_focal_grid', 'focus_dft', 'focus_dft_adjoint', 'unfocus_dft',
+    'unfocus_dft_adjoint', 'focus_fixed_sampling', 'angular_spectrum', 'angular_spectrum_adjoint',
+    'angular_spectrum_transfer_function', 'fresnel_number', 'talbot_distance', 'Wavefront', 'phase_prefix',
+]

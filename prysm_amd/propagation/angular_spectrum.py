@@ -1,0 +1,91 @@
+"""Angular-spectrum (plane-to-plane) free space propagation (prysm/propagation/angular_spectrum.py).
+
+ifft2(fft2(pad(field)) * H) with the separable Fresnel transfer function
+    H[i, j] = exp(-i pi (wvl/1e3) z ky[i]^2) * exp(-i pi (wvl/1e3) z kx[j]^2)
+never materialised: two length-N vectors are synthesised on the device and multiplied in on the
+store of the forward transform; the 1/(MN) of ifft2 rides on the last store of the inverse.
+"""
+import math
+
+import torch
+
+from .. import _lib as L
+from .. import _ops
+from ..conf import config
+from ._kernels import _padded_shape, _shape_before_pad
+
+
+def _cdtype():
+    return L.torch_dtype(config.precision_complex)
+
+
+def angular_spectrum_transfer_function(samples, wvl, dx, z):
+    """Precompute the transfer function of free space (angular_spectrum.py:82-114).
+
+    Returns the materialised (rows, cols) array in config.precision_complex, for API parity;
+    angular_spectrum() itself uses the two factors directly.
+    """
+    if isinstance(samples, int):
+        samples = (samples, samples)
+    hy, hx = _ops.as_tf_vectors(tuple(samples), wvl, dx, z, _cdtype())
+    return _ops.outer(hy, hx)
+
+
+def _field(field, other_dtype):
+    """numpy result type of field * transfer_function."""
+    f = L.as_complex(field)
+    if other_dtype == torch.complex128 and f.dtype == torch.complex64:
+        f = f.to(torch.complex128)
+    return f
+
+
+def angular_spectrum(field, wvl, dx, z, Q=2, tf=None):
+    """Propagate a field via the angular spectrum method (angular_spectrum.py:9-42)."""
+    if tf is not None:
+        tf = L.as_complex(tf)
+        f = _field(field, tf.dtype)
+        if tf.dtype != f.dtype:
+            tf = tf.to(f.dtype)
+        M, N = f.shape
+        F = _ops.fft2(f, direction=-1, scale=1.0, mul=tf)
+        return _ops.fft2(F, direction=+1, scale=1.0 / (M * N))
+    f = _field(field, _cdtype())
+    m, n = f.shape
+    M, N = _padded_shape((m, n), Q)
+    in_off = (math.ceil((M - m) / 2), math.ceil((N - n) / 2))
+    hy, hx = _ops.as_tf_vectors((M, N), wvl, dx, z, f.dtype)
+    F = _ops.fft2(f, direction=-1, scale=1.0, shape=(M, N), in_off=in_off, mul=hy, mul_x=hx)
+    return _ops.fft2(F, direction=+1, scale=1.0 / (M * N))
+
+
+def angular_spectrum_adjoint(field, wvl, dx, z, Q=2, tf=None):
+    """Apply the adjoint of angular_spectrum (angular_spectrum.py:45-79): conj(tf), then crop."""
+    if tf is not None:
+        tf = L.as_complex(tf)
+        f = _field(field, tf.dtype)
+        if tf.dtype != f.dtype:
+            tf = tf.to(f.dtype)
+        M, N = f.shape
+        F = _ops.fft2(f, direction=-1, scale=1.0, mul=tf, mul_conj=True)
+        return _ops.fft2(F, direction=+1, scale=1.0 / (M * N))
+    f = _field(field, _cdtype())
+    M, N = f.shape
+    out_shape = _shape_before_pad((M, N), Q)
+    hy, hx = _ops.as_tf_vectors((M, N), wvl, dx, z, f.dtype)
+    F = _ops.fft2(f, direction=-1, scale=1.0, mul=hy, mul_x=hx, mul_conj=True)
+    if out_shape == (M, N):
+        return _ops.fft2(F, direction=+1, scale=1.0 / (M * N))
+    out_off = (math.ceil((M - out_shape[0]) / 2), math.ceil((N - out_shape[1]) / 2))
+    return _ops.fft2(F, direction=+1, scale=1.0 / (M * N), out_shape=out_shape, out_off=out_off)
+
+
+def fresnel_number(a, L_, lambda_):
+    """Compute the Fresnel number (angular_spectrum.py:117-137)."""
+    return a**2 / (L_ * lambda_)
+
+
+def talbot_distance(a, lambda_):
+    """Compute the talbot distance (angular_spectrum.py:140-160)."""
+    num = lambda_
+    den = 1 - math.sqrt(1 - lambda_**2 / a**2)
+    return num / den

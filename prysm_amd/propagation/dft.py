@@ -1,0 +1,94 @@
+"""Matrix-DFT / chirp-Z / FFT-DFT pupil <-> focal propagation with arbitrary sampling
+(prysm/propagation/dft.py).  The executors live in prysm_amd.fttools; MDFT runs its two complex
+GEMMs on the MFMA matrix cores.
+"""
+import math
+from collections.abc import Iterable
+
+from ..conf import config
+from ..fttools import fftrange, MDFT, CZT, FFTDFT
+
+
+def coordinates_for_focus(pupil_dx, pupil_samples, focal_dx, focal_samples,
+                          wavelength, efl, focal_shift=(0, 0)):
+    """Coordinate / frequency vectors for an MDFT-based pupil <-> focal propagation (dft.py:12-66).
+
+    Returns x, y (pupil coordinates, mm) and fx, fy (spatial frequencies, 1/mm) as device vectors
+    in config.precision.
+    """
+    if not isinstance(pupil_samples, Iterable):
+        pupil_samples = (pupil_samples, pupil_samples)
+    if not isinstance(focal_samples, Iterable):
+        focal_samples = (focal_samples, focal_samples)
+    pny, pnx = pupil_samples
+    fny, fnx = focal_samples
+    fsx, fsy = focal_shift
+    dtype = config.precision
+    x = fftrange(pnx, dtype=dtype) * pupil_dx
+    y = fftrange(pny, dtype=dtype) * pupil_dx
+    inv_lz = 1.0 / (wavelength * efl)
+    fx = (fftrange(fnx, dtype=dtype) * focal_dx + fsx) * inv_lz
+    fy = (fftrange(fny, dtype=dtype) * focal_dx + fsy) * inv_lz
+    return x, y, fx, fy
+
+
+def prepare_executor(pupil_dx, pupil_samples, focal_dx, focal_samples,
+                     wavelength, efl, focal_shift=(0, 0), kind='mdft'):
+    """Build a reusable MDFT, CZT, or FFTDFT pupil <-> focal operator (dft.py:69-117).
+
+    norm = pupil_dx * focal_dx / (wavelength * efl) is baked into the executor; pupil_dx and
+    focal_dx are stashed on it.  executor(pupil) focuses, executor.adjoint(focal) unfocuses.
+    """
+    x, y, fx, fy = coordinates_for_focus(pupil_dx, pupil_samples, focal_dx, focal_samples,
+                                         wavelength, efl, focal_shift)
+    norm = (pupil_dx * focal_dx) / (wavelength * efl)
+    if kind == 'mdft':
+        op = MDFT(x, y, fx, fy, sign=-1, norm=norm)
+    elif kind == 'czt':
+        op = CZT(x, y, fx, fy, sign=-1, norm=norm)
+    elif kind == 'fftdft':
+        op = FFTDFT(x, y, fx, fy, sign=-1, norm=norm)
+    else:
+        raise ValueError(f"kind must be 'mdft', 'czt', or 'fftdft', got {kind!r}")
+    op.pupil_dx = pupil_dx
+    op.focal_dx = focal_dx
+    return op
+
+
+def focus_fixed_sampling(wavefunction, input_dx, prop_dist, wavelength, output_dx, output_samples,
+                         shift=(0, 0), method='mdft'):
+    """Pre-0.22 name of the fixed-sampling focus (BASELINE.json uses it; v0.22.rst:163-205).
+
+    Thin alias: builds the executor and applies it.  Prefer prepare_executor + focus_dft, which
+    reuses the bases across calls.
+    """
+    ex = prepare_executor(input_dx, tuple(wavefunction.shape), output_dx, output_samples, wavelength, prop_dist,
+                          focal_shift=shift, kind=method)
+    return ex(wavefunction)
+
+
+def unit_cell_focal_grid(pupil_dx, pupil_diameter, wavelength, efl, Q=2):
+    """Focal grid (focal_dx, focal_samples) spanning the full DFT unit cell (dft.py:120-152)."""
+    focal_samples = math.ceil(Q * pupil_diameter / pupil_dx)
+    focal_dx = wavelength * efl / pupil_dx / focal_samples
+    return focal_dx, focal_samples
+
+
+def focus_dft(wavefunction, executor):
+    """Propagate a pupil field to the PSF plane via a precomputed executor (dft.py:297-313)."""
+    return executor(wavefunction)
+
+
+def focus_dft_adjoint(wavefunction, executor):
+    """Apply the adjoint of focus_dft (dft.py:316-332)."""
+    return executor.adjoint(wavefunction)
+
+
+def unfocus_dft(wavefunction, executor):
+    """Propagate an image-plane field to the pupil (dft.py:335-351) -- the ADJOINT, not the inverse."""
+    return executor.adjoint(wavefunction)
+
+
+def unfocus_dft_adjoint(wavefunction, executor):
+    """Apply the adjoint of unfocus_dft (dft.py:354-370)."""
+    return executor(wavefunction)

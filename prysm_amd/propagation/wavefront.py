@@ -1,0 +1,320 @@
+"""Wavefront: the metadata-carrying object API (prysm/propagation/wavefront.py).
+
+Same constructor, attributes (data, wavelength, dx, space), methods, unit conventions
+(wavelength um, pupil dx mm, focal dx um, efl / z mm, OPD nm) and error behaviour as the
+reference; ``data`` is a torch tensor in MI355X HBM.
+"""
+import copy
+import math
+import numbers
+import operator
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .. import _ops
+from ..conf import config
+from .._richdata import RichData
+from ._kernels import phase_prefix
+from .fft import (
+    focus, focus_adjoint, unfocus, unfocus_adjoint, focus_intensity,
+    pupil_sample_to_psf_sample, psf_sample_to_pupil_sample,
+)
+from .dft import (
+    prepare_executor, focus_dft, focus_dft_adjoint, unfocus_dft, unfocus_dft_adjoint,
+)
+from .angular_spectrum import angular_spectrum, angular_spectrum_adjoint
+from ..fttools import pad2d, crop_center
+
+
+def _field_data(field):
+    """Return array data from a Wavefront-like field (pass through otherwise)."""
+    if isinstance(field, Wavefront):
+        return field.data
+    return field
+
+
+def _real_opd(phase):
+    """OPD array -> real device tensor (fp32 stays fp32, everything else fp64)."""
+    t = L.as_device(phase)
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.to(torch.float64)
+    return t
+
+
+class Wavefront:
+    """(Complex) representation of a wavefront (wavefront.py:35-56)."""
+
+    def __init__(self, cmplx_field, wavelength, dx, space='pupil'):
+        """cmplx_field: array (numpy is uploaded); wavelength um; dx mm (pupil) or um (psf)."""
+        self.data = L.as_device(cmplx_field) if not isinstance(cmplx_field, numbers.Number) else cmplx_field
+        self.wavelength = wavelength
+        self.dx = dx
+        self.space = space
+
+    @classmethod
+    def from_amp_and_phase(cls, amplitude, phase, wavelength, dx):
+        """P = amplitude * exp(i 2 pi / (wavelength 1e3) * phase_nm) (wavefront.py:58-79).
+
+        One fused synthesis kernel; with phase None the amplitude is returned unchanged, as in the
+        reference.
+        """
+        if phase is not None:
+            opd = _real_opd(phase)
+            amp = None if amplitude is None else L.as_device(amplitude)
+            cd = L._COMPLEX_OF[opd.dtype]
+            if amp is not None and amp.dtype == torch.float64 and cd == torch.complex64:
+                cd, opd = torch.complex128, opd.to(torch.float64)   # numpy result type
+            k = 2 * math.pi / wavelength / 1e3
+            if amp is not None and amp.is_complex():
+                P = _ops.cmul(amp.to(cd), _ops.pupil_synth(None, opd, k, cd))
+            else:
+                P = _ops.pupil_synth(amp, opd, k, cd)
+        else:
+            P = amplitude
+        return cls(P, wavelength, dx)
+
+    @classmethod
+    def phase_screen(cls, phase, wavelength, dx):
+        """exp(i 2 pi / (wavelength 1e3) * phase_nm) (wavefront.py:81-96)."""
+        opd = _real_opd(phase)
+        E = _ops.pupil_synth(None, opd, 2 * math.pi / wavelength / 1e3, L._COMPLEX_OF[opd.dtype])
+        return cls(E, wavelength, dx)
+
+    @classmethod
+    def thin_lens(cls, f, wavelength, x, y):
+        """Quadratic phase screen exp(-i 2 pi/(wavelength/1e3) r^2/(2f)) (wavefront.py:98-144)."""
+        w = wavelength / 1e3
+        xt, yt = _real_opd(x), _real_opd(y)
+        if xt.dtype != yt.dtype:
+            xt, yt = xt.to(torch.float64), yt.to(torch.float64)
+        c = -2 * math.pi / w / (2 * f)
+        screen = _ops.quadratic_phase(xt, yt, c, L._COMPLEX_OF[xt.dtype])
+        dx = float(xt[0, 1] - xt[0, 0])
+        return cls(cmplx_field=screen, wavelength=wavelength, dx=dx, space='pupil')
+
+    @property
+    def intensity(self):
+        """Intensity, abs(w)^2 (wavefront.py:146-151)."""
+        data = self.data
+        if data.is_complex():
+            out = _ops.abs2(data)
+        else:
+            d = data.to(torch.float64) if data.dtype == torch.bool else data
+            out = d * d
+        return RichData(out, self.dx, self.wavelength)
+
+    @property
+    def phase(self):
+        """Phase, angle(w)."""
+        return RichData(torch.angle(self.data), self.dx, self.wavelength)
+
+    @property
+    def real(self):
+        """re(w)."""
+        return RichData(self.data.real if self.data.is_complex() else self.data, self.dx, self.wavelength)
+
+    @property
+    def imag(self):
+        """im(w)."""
+        return RichData(self.data.imag if self.data.is_complex() else torch.zeros_like(self.data), self.dx,
+                        self.wavelength)
+
+    def copy(self):
+        """Return a (deep) copy of this instance."""
+        return copy.deepcopy(self)
+
+    def from_amp_and_phase_adjoint_phase(self, wf_bar):
+        """Adjoint of from_amp_and_phase with respect to phase (wavefront.py:172-188)."""
+        k = phase_prefix(self.wavelength)
+        return k * _ops.cmul(L.as_complex(wf_bar.data).to(self.data.dtype), self.data, conj_b=True).imag
+
+    def from_amp_and_phase_adjoint_amp(self, wf_bar, phase=None):
+        """Adjoint of from_amp_and_phase with respect to amplitude (wavefront.py:190-222)."""
+        if phase is not None:
+            opd = _real_opd(phase)
+            S = _ops.pupil_synth(None, opd, 2 * math.pi / self.wavelength / 1e3, self.data.dtype)
+            return _ops.cmul(L.as_complex(wf_bar.data).to(S.dtype), S, conj_b=True).real
+        absP = torch.abs(self.data)
+        nonzero = absP > 0
+        grad = _ops.cmul(L.as_complex(wf_bar.data).to(self.data.dtype), self.data, conj_b=True).real
+        return torch.where(nonzero, grad / torch.where(nonzero, absP, torch.ones_like(absP)), torch.zeros_like(grad))
+
+    def phase_screen_adjoint_phase(self, wf_bar):
+        """Adjoint of phase_screen with respect to phase (wavefront.py:224-240)."""
+        return self.from_amp_and_phase_adjoint_phase(wf_bar)
+
+    def intensity_adjoint(self, intensity_bar):
+        """Adjoint of intensity: 2 * Ibar * E (wavefront.py:282-298)."""
+        ibar = _field_data(intensity_bar)
+        if isinstance(ibar, RichData):
+            ibar = ibar.data
+        ibar = L.as_device(ibar)
+        Gbar = 2 * ibar * self.data
+        return Wavefront(Gbar, self.wavelength, self.dx, self.space)
+
+    def pad2d(self, Q, value=0, mode='constant', out_shape=None, inplace=True):
+        """Pad the wavefront (wavefront.py:300-332)."""
+        padded = pad2d(self.data, Q=Q, value=value, mode=mode, out_shape=out_shape)
+        if inplace:
+            self.data = padded
+            return self
+        return Wavefront(padded, self.wavelength, self.dx, self.space)
+
+    def crop(self, out_shape, inplace=True):
+        """Crop the wavefront to the centermost out_shape (wavefront.py:334-358)."""
+        cropped = crop_center(self.data, out_shape)
+        if inplace:
+            self.data = cropped
+            return self
+        return Wavefront(cropped, self.wavelength, self.dx, self.space)
+
+    def __numerical_operation__(self, other, op, reverse=False):
+        """Apply an operation to this wavefront with another piece of data (wavefront.py:360-383)."""
+        func = getattr(operator, op)
+        if isinstance(other, Wavefront):
+            criteria = [
+                abs(self.dx - other.dx) / self.dx * 100 < 0.1,
+                tuple(self.data.shape) == tuple(other.data.shape),
+                self.wavelength == other.wavelength,
+                self.space == other.space,
+            ]
+            if not all(criteria):
+                raise ValueError('all physicality criteria not met: sample spacing, shape, wavelength, or space different.')
+            a, b = self.data, other.data
+            if (op == 'mul' and a.is_complex() and b.is_complex() and a.dtype == b.dtype and a.dim() == 2
+                    and a.is_contiguous() and b.is_contiguous()):
+                data = _ops.cmul(a, b)   # the hot pointwise product runs in the HIP kernel
+            else:
+                data = func(b, a) if reverse else func(a, b)
+        elif isinstance(other, (torch.Tensor, np.ndarray)):
+            o = L.as_device(other)
+            data = func(o, self.data) if reverse else func(self.data, o)
+        elif isinstance(other, numbers.Number):
+            data = func(other, self.data) if reverse else func(self.data, other)
+        else:
+            raise TypeError(f'unsupported operand type(s) for {op}: \'Wavefront\' and {type(other)}')
+        return Wavefront(dx=self.dx, wavelength=self.wavelength, cmplx_field=data, space=self.space)
+
+    def __mul__(self, other):
+        return self.__numerical_operation__(other, 'mul')
+
+    def __rmul__(self, other):
+        return self.__numerical_operation__(other, 'mul', reverse=True)
+
+    def __truediv__(self, other):
+        return self.__numerical_operation__(other, 'truediv')
+
+    def __rtruediv__(self, other):
+        return self.__numerical_operation__(other, 'truediv', reverse=True)
+
+    def __add__(self, other):
+        return self.__numerical_operation__(other, 'add')
+
+    def __radd__(self, other):
+        return self.__numerical_operation__(other, 'add', reverse=True)
+
+    def __sub__(self, other):
+        return self.__numerical_operation__(other, 'sub')
+
+    def __rsub__(self, other):
+        return self.__numerical_operation__(other, 'sub', reverse=True)
+
+    def free_space(self, dz=np.nan, Q=1, tf=None):
+        """Plane-to-plane free space propagation by angular spectrum (wavefront.py:413-443)."""
+        if np.isnan(dz) and tf is None:
+            raise ValueError('dz must be provided if tf is None')
+        out = angular_spectrum(self.data, wvl=self.wavelength, dx=self.dx, z=dz, Q=Q, tf=tf)
+        return Wavefront(out, self.wavelength, self.dx, self.space)
+
+    def free_space_adjoint(self, dz=np.nan, Q=1, tf=None):
+        """Apply the adjoint of free_space (wavefront.py:445-476)."""
+        if np.isnan(dz) and tf is None:
+            raise ValueError('dz must be provided if tf is None')
+        out = angular_spectrum_adjoint(self.data, wvl=self.wavelength, dx=self.dx, z=dz, Q=Q, tf=tf)
+        return Wavefront(out, self.wavelength, self.dx, self.space)
+
+    def focus(self, efl, Q=2):
+        """Pupil to PSF plane propagation by FFT (wavefront.py:478-504)."""
+        if self.space != 'pupil':
+            raise ValueError('can only propagate from a pupil to psf plane')
+        data = focus(self.data, Q=Q)
+        dx = pupil_sample_to_psf_sample(self.dx, data.shape[1], self.wavelength, efl)
+        return Wavefront(data, self.wavelength, dx, space='psf')
+
+    def focus_intensity(self, efl, Q=2):
+        """``self.focus(efl, Q).intensity`` with |.|^2 fused into the transform (no complex PSF in memory)."""
+        if self.space != 'pupil':
+            raise ValueError('can only propagate from a pupil to psf plane')
+        data = focus_intensity(self.data, Q=Q)
+        dx = pupil_sample_to_psf_sample(self.dx, data.shape[1], self.wavelength, efl)
+        return RichData(data, dx, self.wavelength)
+
+    def focus_adjoint(self, efl, Q=2):
+        """Apply the adjoint of focus (wavefront.py:506-532)."""
+        if self.space != 'psf':
+            raise ValueError('can only apply adjoint from a psf to pupil plane')
+        samples = self.data.shape[1]
+        data = focus_adjoint(self.data, Q=Q)
+        dx = psf_sample_to_pupil_sample(self.dx, samples, self.wavelength, efl)
+        return Wavefront(data, self.wavelength, dx, space='pupil')
+
+    def unfocus(self, efl, Q=2):
+        """PSF to pupil plane propagation by FFT (wavefront.py:534-560)."""
+        if self.space != 'psf':
+            raise ValueError('can only propagate from a psf to pupil plane')
+        data = unfocus(self.data, Q=Q)
+        dx = psf_sample_to_pupil_sample(self.dx, data.shape[1], self.wavelength, efl)
+        return Wavefront(data, self.wavelength, dx, space='pupil')
+
+    def unfocus_adjoint(self, efl, Q=2):
+        """Apply the adjoint of unfocus (wavefront.py:562-588)."""
+        if self.space != 'pupil':
+            raise ValueError('can only apply adjoint from a pupil to psf plane')
+        samples = self.data.shape[1]
+        data = unfocus_adjoint(self.data, Q=Q)
+        dx = pupil_sample_to_psf_sample(self.dx, samples, self.wavelength, efl)
+        return Wavefront(data, self.wavelength, dx, space='psf')
+
+    def prepare_executor(self, efl, dx, samples, shift=(0, 0), kind='mdft'):
+        """Build a reusable MDFT, CZT, or FFTDFT focus executor (wavefront.py:590-641)."""
+        if isinstance(samples, int):
+            samples = (samples, samples)
+        if self.space == 'pupil':
+            return prepare_executor(pupil_dx=self.dx, pupil_samples=tuple(self.data.shape), focal_dx=dx,
+                                    focal_samples=samples, wavelength=self.wavelength, efl=efl, focal_shift=shift,
+                                    kind=kind)
+        elif self.space == 'psf':
+            return prepare_executor(pupil_dx=dx, pupil_samples=samples, focal_dx=self.dx,
+                                    focal_samples=tuple(self.data.shape), wavelength=self.wavelength, efl=efl,
+                                    focal_shift=shift, kind=kind)
+        raise ValueError(f"unknown space {self.space!r}")
+
+    def focus_dft(self, executor):
+        """Pupil -> PSF propagation via a precomputed executor (wavefront.py:679-696)."""
+        if self.space != 'pupil':
+            raise ValueError('can only propagate from a pupil to psf plane')
+        data = focus_dft(self.data, executor)
+        return Wavefront(dx=executor.focal_dx, cmplx_field=data, wavelength=self.wavelength, space='psf')
+
+    def focus_dft_adjoint(self, executor):
+        """Apply the adjoint of focus_dft (wavefront.py:698-718)."""
+        if self.space != 'psf':
+            raise ValueError('can only apply adjoint from a psf to pupil plane')
+        data = focus_dft_adjoint(self.data, executor)
+        return Wavefront(dx=executor.pupil_dx, cmplx_field=data, wavelength=self.wavelength, space='pupil')
+
+    def unfocus_dft(self, executor):
+        """PSF -> pupil propagation via a precomputed executor (wavefront.py:720-737)."""
+        if self.space != 'psf':
+            raise ValueError('can only propagate from a psf to pupil plane')
+        data = unfocus_dft(self.data, executor)
+        return Wavefront(dx=executor.pupil_dx, cmplx_field=data, wavelength=self.wavelength, space='pupil')
+
+    def unfocus_dft_adjoint(self, executor):
+        """Apply the adjoint of unfocus_dft (wavefront.py:739-757)."""
+        if self.space != 'pupil':
+            raise ValueError('can only apply adjoint from a pupil to psf plane')
+        data = unfocus_dft_adjoint(self.data, executor)
+        return Wavefront(dx=executor.focal_dx, cmplx_field=data, wavelength=self.wavelength, space='psf')

@@ -1,0 +1,358 @@
+"""GPU parity tests: the HIP path (through the C ABI, via prysm_amd) against
+  (1) the golden fixtures generated from the reference itself (tests/golden/),
+  (2) the CPU oracle on seeded inputs at sizes it finishes in seconds (up to 4096^2),
+  (3) the identities the reference's own test-suite pins.
+
+Tolerances (relative to the largest magnitude of the truth, always an fp64 numpy result):
+  complex128 path : 1e-10     (north star: rtol 1e-5)
+  complex64 path  : 5e-6 FFT family / 3e-5 matrix DFT   (north star: rtol 1e-3)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_max
+from oracle import prysm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-10
+TOL32 = 5e-6
+TOL32_MDFT = 3e-5
+
+
+@pytest.fixture(scope='module')
+def pa():
+    import prysm_amd
+    from prysm_amd import _lib
+    _lib.load()   # fails loudly when the HIP library is missing
+    assert torch.cuda.is_available()
+    return prysm_amd
+
+
+def tonp(x):
+    from prysm_amd.mathops import array_to_true_numpy
+    if hasattr(x, 'data') and not isinstance(x, (np.ndarray, torch.Tensor)):
+        x = x.data
+    return array_to_true_numpy(x)
+
+
+def crandn(rng, shape, dtype=np.complex128):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+
+
+# ----------------------------------------------------------------------------- golden fixtures
+
+def test_fft_family_golden(pa, golden):
+    P = pa.propagation
+    g = golden('fft_family')
+    for i in range(int(g['ncases'])):
+        x, Q, gg = g[f'c{i}_x'], float(g[f'c{i}_Q']), g[f'c{i}_g']
+        for name, arg in (('focus', x), ('unfocus', x), ('focus_adjoint', gg), ('unfocus_adjoint', gg)):
+            got = tonp(getattr(P, name)(arg, Q))
+            ref = g[f'c{i}_{name}']
+            assert got.shape == ref.shape, (name, i)
+            assert got.dtype == ref.dtype
+            assert rel_max(got, ref) < TOL64, (name, i, x.shape, Q)
+            got32 = tonp(getattr(P, name)(arg.astype(np.complex64), Q))
+            assert got32.dtype == np.complex64
+            assert rel_max(got32, ref) < TOL32, (name, i, x.shape, Q)
+
+
+def test_padcrop_golden(pa, golden):
+    F = pa.fttools
+    g = golden('padcrop')
+    cases = [((8, 8), 2, None), ((9, 9), 2, None), ((12, 12), 1.5, None), ((9, 12), 1.5, None),
+             ((9, 12), None, (14, 18)), ((5, 8), None, (16, 16)), ((8, 5), 3, None)]
+    for i, (shape, Q, oshape) in enumerate(cases):
+        x = g[f'c{i}_x']
+        p = F.pad2d(x, Q) if oshape is None else F.pad2d(x, out_shape=oshape)
+        assert np.array_equal(tonp(p), g[f'c{i}_pad'])
+        assert np.array_equal(tonp(F.crop_center(p, shape)), x)
+    assert np.array_equal(tonp(F.pad2d(g['fill_x'], Q=2, value=1.5)), g['fill_pad'])
+    assert F.pad2d(x, 1) is x
+
+
+def test_angular_spectrum_golden(pa, golden):
+    P = pa.propagation
+    g = golden('angular_spectrum')
+    for i in range(int(g['ncases'])):
+        x = g[f'c{i}_x']
+        Q, wvl, dx, z = (float(v) for v in g[f'c{i}_par'])
+        y = tonp(P.angular_spectrum(x, wvl, dx, z, Q=Q))
+        assert y.shape == g[f'c{i}_y'].shape
+        assert rel_max(y, g[f'c{i}_y']) < TOL64
+        tf = tonp(P.angular_spectrum_transfer_function(y.shape, wvl, dx, z))
+        assert rel_max(tf, g[f'c{i}_tf']) < TOL64
+        adj = tonp(P.angular_spectrum_adjoint(g[f'c{i}_g'], wvl, dx, z, Q=Q))
+        assert adj.shape == g[f'c{i}_adj'].shape
+        assert rel_max(adj, g[f'c{i}_adj']) < TOL64
+        utf = g[f'c{i}_usertf']
+        assert rel_max(tonp(P.angular_spectrum(x, wvl, dx, z, Q=Q, tf=utf)), g[f'c{i}_y_usertf']) < TOL64
+        assert rel_max(tonp(P.angular_spectrum_adjoint(x, wvl, dx, z, Q=Q, tf=utf)), g[f'c{i}_adj_usertf']) < TOL64
+
+
+def test_executors_golden(pa, golden):
+    P = pa.propagation
+    g = golden('executors')
+    for i in range(int(g['ncases'])):
+        x, gg = g[f'c{i}_x'], g[f'c{i}_g']
+        ps, fs = tuple(int(v) for v in g[f'c{i}_ps']), tuple(int(v) for v in g[f'c{i}_fs'])
+        pdx, fdx, wvl, efl, sx, sy = (float(v) for v in g[f'c{i}_par'])
+        cx, cy, cfx, cfy = P.coordinates_for_focus(pdx, ps, fdx, fs, wvl, efl, (sx, sy))
+        for a, b in ((cx, 'cx'), (cy, 'cy'), (cfx, 'cfx'), (cfy, 'cfy')):
+            assert rel_max(tonp(a), g[f'c{i}_{b}']) < 1e-15
+        for kind in ('mdft', 'czt'):
+            ex = P.prepare_executor(pdx, ps, fdx, fs, wvl, efl, focal_shift=(sx, sy), kind=kind)
+            assert ex.pupil_dx == pdx and ex.focal_dx == fdx
+            assert rel_max(tonp(P.focus_dft(x, ex)), g[f'c{i}_{kind}_fwd']) < TOL64, (kind, i)
+            assert rel_max(tonp(P.unfocus_dft(gg, ex)), g[f'c{i}_{kind}_adj']) < TOL64, (kind, i)
+    x = g['fftdft_x']
+    pdx, fdx, wvl, efl = (float(v) for v in g['fftdft_par'])
+    samples = tuple(int(v) for v in g['fftdft_samples'])
+    f = g['fftdft_fftfocus']
+    for kind in ('mdft', 'czt', 'fftdft'):
+        ex = P.prepare_executor(pdx, x.shape, fdx, samples, wvl, efl, kind=kind)
+        assert rel_max(tonp(ex(x)), g[f'fftdft_{kind}_fwd']) < TOL64, kind
+        assert rel_max(tonp(ex(x)), f) < 1e-9, kind              # FFT == MDFT == CZT == FFTDFT
+        assert rel_max(tonp(ex.adjoint(f)), g[f'fftdft_{kind}_adj']) < TOL64, kind
+    ex = P.prepare_executor(pdx, x.shape, fdx, (24, 40), wvl, efl, kind='fftdft')
+    assert rel_max(tonp(ex(x)), g['fftdft_crop_fwd']) < TOL64
+    assert rel_max(tonp(ex.adjoint(g['fftdft_crop_g'])), g['fftdft_crop_adj']) < TOL64
+
+
+def test_wavefront_golden(pa, golden):
+    P = pa.propagation
+    W = P.Wavefront
+    g = golden('wavefront')
+    A, dx = g['cfg1_amp'], float(g['cfg1_dx'])
+    # config 1 (plumbing): circular pupil, HeNe, focus(Q=2).intensity
+    wf = W.from_amp_and_phase(A, None, O.HeNe, dx)
+    psf = wf.focus(100, Q=2)
+    assert psf.space == 'psf'
+    assert psf.dx == float(g['cfg1_psf_dx'])
+    assert rel_max(tonp(psf.intensity), g['cfg1_intensity']) < TOL64
+    assert rel_max(tonp(wf.focus_intensity(100, Q=2)), g['cfg1_intensity']) < TOL64   # fused |.|^2 epilogue
+    # synthesis kernels
+    wf2 = W.from_amp_and_phase(A, g['opd'], 0.55, dx)
+    assert rel_max(tonp(wf2.data), g['fap_field']) < TOL64
+    assert rel_max(tonp(W.phase_screen(g['opd'], 0.55, dx).data), g['phase_screen']) < TOL64
+    tl = W.thin_lens(250.0, 0.55, g['xgrid'], g['ygrid'])
+    assert rel_max(tonp(tl.data), g['thin_lens']) < TOL64
+    assert tl.dx == pytest.approx(dx)
+    f2 = wf2.focus(100, Q=2)
+    assert rel_max(tonp(f2.intensity), g['fap_psf_intensity']) < TOL64
+    assert rel_max(tonp(f2.intensity_adjoint(g['ibar']).data), g['intensity_adjoint']) < TOL64
+    wfbar = W(g['wfbar'], 0.55, dx)
+    assert rel_max(tonp(wf2.from_amp_and_phase_adjoint_phase(wfbar)), g['fap_adjoint_phase']) < TOL64
+    assert rel_max(tonp(wf2.free_space(dz=5.0, Q=1).data), g['free_space']) < TOL64
+    # polychromatic recipe (docs how-to): per-wavelength MDFT + |.|^2 + weighted sum
+    acc = None
+    for w, wt in zip(g['poly_wvls'], g['poly_weights']):
+        wfl = W.from_amp_and_phase(A, g['opd'], float(w), dx)
+        ex = wfl.prepare_executor(100, float(g['poly_fdx']), 32)
+        I = wfl.focus_dft(ex).intensity.data
+        acc = I * float(wt) if acc is None else acc + I * float(wt)
+    assert rel_max(tonp(acc), g['poly_sum']) < TOL64
+
+
+def test_precision32_golden(pa, golden):
+    """dtype propagation with config.precision = 32; truth is the fp64 oracle."""
+    P = pa.propagation
+    g = golden('precision32')
+    x = g['x']
+    x64 = x.astype(np.complex128)
+    pa.config.precision = 32
+    try:
+        f = tonp(P.focus(x, 2))
+        assert f.dtype == np.complex64
+        assert rel_max(f, O.focus(x64, 2)) < TOL32
+        y = tonp(P.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1))
+        assert y.dtype == np.complex64
+        assert rel_max(y, O.angular_spectrum(x64, O.HeNe, 0.01, 10.0, Q=1)) < TOL32
+        ex = P.prepare_executor(0.1, (32, 32), 1.0, (16, 16), O.HeNe, 50.0)
+        m = tonp(P.focus_dft(x, ex))
+        assert m.dtype == np.complex64
+        ref = O.prepare_executor(0.1, (32, 32), 1.0, (16, 16), O.HeNe, 50.0)(x64)
+        assert rel_max(m, ref) < TOL32_MDFT
+    finally:
+        pa.config.precision = 64
+    # with the default precision (64) a complex64 field is promoted, as in the reference
+    assert tonp(P.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1)).dtype == np.complex128
+
+
+# ----------------------------------------------------------------------------- oracle, seeded, larger sizes
+
+@pytest.mark.parametrize('n,Q,dtype', [(512, 1, np.complex64), (512, 2, np.complex128), (1024, 1, np.complex128),
+                                       (2048, 1, np.complex64), (1024, 2, np.complex64), (4096, 1, np.complex64),
+                                       (4096, 1, np.complex128), (256, 1.5, np.complex128), (1000, 1, np.complex64)])
+def test_focus_vs_oracle(pa, n, Q, dtype):
+    """BASELINE configs 2 and the 4096^2 north-star path, plus padded / non power-of-two sizes."""
+    rng = np.random.default_rng(n)
+    x = crandn(rng, (n, n), dtype)
+    ref = O.focus(x.astype(np.complex128), Q)
+    got = tonp(pa.propagation.focus(x, Q))
+    assert got.dtype == dtype and got.shape == ref.shape
+    assert rel_max(got, ref) < (TOL32 if dtype == np.complex64 else TOL64)
+    # fused intensity epilogue == |focus|^2
+    I = tonp(pa.propagation.focus_intensity(x, Q))
+    assert rel_max(I, O.intensity(ref)) < (2 * TOL32 if dtype == np.complex64 else TOL64)
+
+
+@pytest.mark.parametrize('shape', [(512, 2048), (2048, 512), (64, 4096), (300, 512), (512, 300)])
+def test_rectangular_unfocus_vs_oracle(pa, shape):
+    rng = np.random.default_rng(sum(shape))
+    x = crandn(rng, shape)
+    assert rel_max(tonp(pa.propagation.unfocus(x, 1)), O.unfocus(x, 1)) < TOL64
+    g = crandn(rng, shape)
+    assert rel_max(tonp(pa.propagation.unfocus_adjoint(g, 1)), O.unfocus_adjoint(g, 1)) < TOL64
+
+
+def test_angular_spectrum_config3(pa):
+    """BASELINE config 3 geometry: 4096^2 complex128, HeNe, dx = 0.01 mm, z = 10 mm, Q = 1."""
+    rng = np.random.default_rng(4096)
+    x = crandn(rng, (4096, 4096))
+    ref = O.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1)
+    got = tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1))
+    assert rel_max(got, ref) < TOL64
+    x2 = crandn(rng, (1024, 1024))
+    assert rel_max(tonp(pa.propagation.angular_spectrum(x2, 0.5, 0.005, 3.0, Q=2)),
+                   O.angular_spectrum(x2, 0.5, 0.005, 3.0, Q=2)) < TOL64
+
+
+def test_mdft_config4(pa):
+    """BASELINE config 4: 2048^2 -> 512^2 fine-sampled PSF, complex64, vs the fp64 oracle."""
+    P = pa.propagation
+    rng = np.random.default_rng(2048)
+    x = crandn(rng, (2048, 2048), np.complex64)
+    pdx, efl, wvl = 10 / 2048, 100.0, O.HeNe
+    fdx = wvl * 10 / 8
+    ref_ex = O.prepare_executor(pdx, (2048, 2048), fdx, (512, 512), wvl, efl)
+    ref = ref_ex(x.astype(np.complex128))
+    pa.config.precision = 32
+    try:
+        ex = P.prepare_executor(pdx, (2048, 2048), fdx, (512, 512), wvl, efl)
+        got = tonp(P.focus_dft(x, ex))
+        assert got.dtype == np.complex64
+        assert rel_max(got, ref) < TOL32_MDFT
+        g = crandn(rng, (512, 512), np.complex64)
+        adj = tonp(P.unfocus_dft(g, ex))
+        assert rel_max(adj, ref_ex.adjoint(g.astype(np.complex128))) < TOL32_MDFT
+        assert ex.nbytes() == 2 * 512 * 2048 * 8
+    finally:
+        pa.config.precision = 64
+    ex64 = P.prepare_executor(pdx, (2048, 2048), fdx, (512, 512), wvl, efl)
+    assert rel_max(tonp(ex64(x.astype(np.complex128))), ref) < TOL64
+    # rectangular multiply-order rule (reference tests/test_fttools.py:55-85)
+    xr = crandn(rng, (96, 40))
+    for fs in ((20, 200), (200, 20)):
+        a = P.prepare_executor(0.1, xr.shape, 1.0, fs, 0.6, 40.0, (0.2, -0.1))
+        b = O.prepare_executor(0.1, xr.shape, 1.0, fs, 0.6, 40.0, (0.2, -0.1))
+        assert a._forward_left_first == b._forward_left_first
+        assert a._adjoint_left_first == b._adjoint_left_first
+        assert rel_max(tonp(a(xr)), b(xr)) < TOL64
+        gg = crandn(rng, fs)
+        assert rel_max(tonp(a.adjoint(gg)), b.adjoint(gg)) < TOL64
+
+
+def test_czt_fftdft_larger(pa):
+    P = pa.propagation
+    rng = np.random.default_rng(5)
+    x = crandn(rng, (256, 200))
+    for kind in ('czt',):
+        a = P.prepare_executor(0.05, x.shape, 0.7, (120, 90), 0.6, 80.0, (1.0, -2.0), kind=kind)
+        b = O.prepare_executor(0.05, x.shape, 0.7, (120, 90), 0.6, 80.0, (1.0, -2.0), kind='mdft')
+        assert rel_max(tonp(a(x)), b(x)) < 1e-9
+        g = crandn(rng, (120, 90))
+        assert rel_max(tonp(a.adjoint(g)), b.adjoint(g)) < 1e-9
+
+
+# ----------------------------------------------------------------------------- identities of the reference's tests
+
+@pytest.mark.parametrize('Q', [1, 1.5, 2])
+def test_adjoint_dot_products(pa, Q):
+    """reference tests/test_propagation.py:32-55, 221-243."""
+    P = pa.propagation
+    rng = np.random.default_rng(789)
+    x = crandn(rng, (9, 12))
+    for fwd, adj in ((P.focus, P.focus_adjoint), (P.unfocus, P.unfocus_adjoint)):
+        fx = tonp(fwd(x, Q))
+        y = crandn(rng, fx.shape)
+        np.testing.assert_allclose(np.vdot(fx, y), np.vdot(x, tonp(adj(y, Q))), atol=1e-11)
+    fx = tonp(P.angular_spectrum(x, 0.55, 0.02, 3.0, Q=Q))
+    y = crandn(rng, fx.shape)
+    np.testing.assert_allclose(np.vdot(fx, y), np.vdot(x, tonp(P.angular_spectrum_adjoint(y, 0.55, 0.02, 3.0, Q=Q))),
+                               atol=1e-11)
+
+
+def test_roundtrip_unitarity_identity(pa):
+    """reference tests/test_propagation.py:24-29, 210-218."""
+    P = pa.propagation
+    rng = np.random.default_rng(1)
+    z = rng.random((128, 128))
+    wf = P.Wavefront(dx=1, cmplx_field=z, wavelength=O.HeNe)
+    wf2 = wf.focus(1, 1).unfocus(1, 1)
+    assert np.allclose(tonp(wf2.data), z)
+    x = crandn(rng, (4096, 4096), np.complex64)
+    xd = pa.mathops.to_device(x)
+    f = P.focus(xd, 1)
+    e_in = float(torch.sum(pa.propagation.Wavefront(xd, 1, 1).intensity.data.double()))
+    e_out = float(torch.sum(pa.propagation.Wavefront(f, 1, 1).intensity.data.double()))
+    assert abs(e_out / e_in - 1) < 1e-5            # unitary at the full north-star size
+    back = P.unfocus(f, 1)
+    assert rel_max(tonp(back), x) < 2 * TOL32      # focus o unfocus = identity at 4096^2
+    xs = crandn(rng, (16, 16))
+    assert np.allclose(tonp(P.angular_spectrum(xs, 0.5, 0.01, 0.0, Q=1)), xs)
+
+
+def test_fft_mdft_equivalent_wavefront(pa):
+    """reference tests/test_propagation.py:98-117."""
+    P = pa.propagation
+    rng = np.random.default_rng(2)
+    z = rng.random((32, 32))
+    wf = P.Wavefront(dx=1, cmplx_field=z, wavelength=O.HeNe, space='pupil')
+    focus_fft = wf.focus(Q=2, efl=1)
+    mdft = wf.prepare_executor(efl=1, dx=focus_fft.dx, samples=tuple(focus_fft.data.shape))
+    assert np.allclose(tonp(focus_fft.data), tonp(wf.focus_dft(mdft).data))
+    wfp = P.Wavefront(dx=1, cmplx_field=rng.random((128, 128)), wavelength=O.HeNe, space='psf')
+    unfocus_fft = wfp.unfocus(Q=2, efl=1)
+    m2 = wfp.prepare_executor(efl=1, dx=unfocus_fft.dx, samples=tuple(unfocus_fft.data.shape))
+    assert np.allclose(tonp(unfocus_fft.data), tonp(wfp.unfocus_dft(m2).data))
+
+
+def test_airy_known_answer(pa):
+    """reference tests/test_physics.py:20-34: FFT PSF slice == analytic Airy disk to 1e-3-class."""
+    P = pa.propagation
+    for efl, epd, wvl in ((10, 5, 0.55), (20, 10, 0.8), (100, 10, O.HeNe)):
+        n = 256
+        x, y = O.make_xy_grid(n, diameter=4 * epd)
+        r, _ = O.cart_to_polar(x, y)
+        amp = O.circle(epd / 2, r)
+        wf = P.Wavefront.from_amp_and_phase(amp, None, wvl, float(x[0, 1] - x[0, 0]))
+        psf = wf.focus(efl, Q=3)
+        I = tonp(psf.intensity)
+        I = I / I.max()
+        xx, yy = O.make_xy_grid(I.shape, dx=psf.dx)
+        rr, _ = O.cart_to_polar(xx, yy)
+        airy = O.airydisk(rr, efl / epd, wvl)
+        c = I.shape[0] // 2
+        assert np.allclose(I[c, c:c + 40], airy[c, c:c + 40], atol=2e-3)
+
+
+def test_errors_match_reference(pa):
+    P = pa.propagation
+    z = np.ones((8, 8), dtype=np.complex128)
+    with pytest.raises(ValueError):
+        P.Wavefront(z, 0.5, 1, space='psf').focus(1)
+    with pytest.raises(ValueError):
+        P.Wavefront(z, 0.5, 1, space='pupil').unfocus(1)
+    with pytest.raises(ValueError):
+        P.prepare_executor(0.1, 8, 1.0, 8, 0.5, 10, kind='nope')
+    with pytest.raises(ValueError):
+        P.Wavefront(z, 0.5, 1).free_space()
+    with pytest.raises(TypeError):
+        P.Wavefront(z, 0.5, 1) * 'a'
+    with pytest.raises(ValueError):
+        P.Wavefront(z, 0.5, 1) * P.Wavefront(z, 0.6, 1)
+    with pytest.raises(ValueError):
+        pa.fttools.CZT(np.arange(4.), np.arange(4.), np.arange(4.), np.arange(4.), sign=2)
