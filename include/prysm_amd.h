@@ -188,6 +188,10 @@ int pm_version(void);
 const char* pm_last_error(void);   /* thread-local message for the last negative return */
 int pm_plan_prepare(int32_t dtype, int64_t n);   /* build + cache the twiddle table for length n now */
 void pm_shutdown(void);            /* free cached tables */
+/* performance knobs (never change results): "col_var", "row_var" in {0,1} pick kernel tilings,
+ * "nt_in" / "nt_out" in {0,1} make the input loads / output stores non-temporal.  Also read once from
+ * the environment: PM_TUNE="col_var=1,nt_in=1". */
+int pm_set_tuning(const char* key, int32_t value);
 /* time `reps` launches of each pass of the transform with hipEvents on `stream`; ms[0] = row pass,
  * ms[1] = column pass (average per launch).  Used by bench.py for the roofline object. */
 int pm_fft2_time_passes(const pm_fft2_desc* d, const void* in, void* out, void* workspace,

@@ -43,6 +43,7 @@ SIGNATURES = {
     'pm_last_error': (ctypes.c_char_p, []),
     'pm_plan_prepare': (c_i32, [c_i32, c_i64]),
     'pm_shutdown': (None, []),
+    'pm_set_tuning': (c_i32, [ctypes.c_char_p, c_i32]),
     'pm_fft2_workspace': (c_sz, [ctypes.POINTER(pm_fft2_desc)]),
     'pm_fft2': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_vp, c_vp, c_vp, c_sz, c_vp]),
     'pm_fft2_time_passes': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_vp, c_vp, c_vp, c_sz, c_i32,

@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -68,6 +69,32 @@ template <> const cx<float>* twiddles<float>(int64_t n, int* err) { return table
 template <> const cx<double>* twiddles<double>(int64_t n, int* err) { return table_get<double>(n, err); }
 const cx<double>* twiddles_f64(int64_t n, int* err) { return table_get<double>(n, err); }
 
+static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
+    auto is = [&](const char* k) { return strlen(k) == klen && !strncmp(key, k, klen); };
+    if (is("col_var")) t.col_var = v;
+    else if (is("log_k")) t.log_k = v < 0 ? 0 : (v > 3 ? 3 : v);
+    else if (is("row_log_g")) t.row_log_g = v < 0 ? 0 : (v > 3 ? 3 : v);
+    else if (is("row_var")) t.row_var = v;
+    else if (is("nt_in")) t.nt_in = v;
+    else if (is("nt_out")) t.nt_out = v;
+}
+
+Tuning& tuning() {
+    static Tuning t = [] {
+        Tuning x;
+        const char* e = getenv("PM_TUNE");   // e.g. PM_TUNE="col_var=1,nt_in=1"
+        while (e && *e) {
+            const char* eq = strchr(e, '=');
+            if (!eq) break;
+            tune_set(x, e, size_t(eq - e), atoi(eq + 1));
+            const char* c = strchr(eq, ',');
+            e = c ? c + 1 : nullptr;
+        }
+        return x;
+    }();
+    return t;
+}
+
 static AxisMap to_map(const pm_axis& a) { return AxisMap{int(a.n), int(a.len), int(a.off), int(a.shift)}; }
 
 static int check_axis(const pm_axis& a, const char* name) {
@@ -81,7 +108,8 @@ static int check_axis(const pm_axis& a, const char* name) {
 // ---------------------------------------------------------------- 2-D transform
 struct Fft2Plan {
     int logn, logm;       // engine log2 sizes or -1 (direct)
-    int tc;               // tile width when both passes run on the engine, else 0 (natural intermediate)
+    int tc;               // column-pass tile width when both passes run on the engine, else 0 (natural intermediate)
+    int log_k;            // layout tile width TL = tc << log_k
     size_t ws_bytes;
 };
 
@@ -93,11 +121,15 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     const size_t es = d->dtype == PM_C64 ? 8 : 16;
     const int64_t rows = d->in_y.len;   // only stored input rows are transformed in pass 1
     if (p.logn >= 0 && p.logm >= 0) {
-        p.tc = col_tile_width_for(d->dtype, p.logm);
-        const int64_t ntiles = (N + p.tc - 1) / p.tc;
-        p.ws_bytes = size_t(ntiles) * size_t(rows) * size_t(p.tc) * es;
+        p.tc = col_tile_width_for(d->dtype, p.logm, tuning().col_var);
+        p.log_k = tuning().log_k;
+        while (p.log_k > 0 && (N % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
+        const int64_t tl = int64_t(p.tc) << p.log_k;
+        const int64_t ntl = (N + tl - 1) / tl;
+        p.ws_bytes = size_t(ntl) * size_t(rows) * size_t(tl) * es;
     } else {
         p.tc = 0;
+        p.log_k = 0;
         p.ws_bytes = size_t(rows) * size_t(N) * es;
     }
     if (p.ws_bytes == 0) p.ws_bytes = es;
@@ -124,6 +156,8 @@ static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out) {
     if (d->epilogue == PM_EPI_NONE && sizeof(T) == 4)
         vec = (d->out_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     cs.vec_ok = vec ? 1 : 0;
+    const size_t out_bytes = size_t(d->out_y.len) * size_t(d->out_x.len) * (d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T));
+    cs.nt = tuning().nt_out >= 0 ? tuning().nt_out : (out_bytes >= (size_t(192) << 20) ? 1 : 0);
     return cs;
 }
 
@@ -141,16 +175,18 @@ static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, vo
         if (p.logn >= 0) {
             const cx<T>* tw = twiddles<T>(N, &err);
             if (!tw) return err;
-            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, conj};
+            const size_t in_bytes = size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
+            const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
+            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, conj, nt_in};
             int rc;
             if (p.tc) {
                 int ltc = 0;
-                while ((1 << ltc) < p.tc) ++ltc;
+                while ((1 << ltc) < (p.tc << p.log_k)) ++ltc;
                 RowStoreTiled<T> sp{W, rows, ltc};
-                rc = launch_row_tiled<T>(p.logn, lp, sp, tw, rows, st);
+                rc = launch_row_tiled<T>(p.logn, tuning().row_var, lp, sp, tw, rows, tuning().row_log_g, st);
             } else {
                 RowStoreNat<T> sp{W, N, AxisMap{int(N), int(N), 0, 0}, rows, 0, T(1)};
-                rc = launch_row_nat<T>(p.logn, lp, sp, tw, rows, st);
+                rc = launch_row_nat<T>(p.logn, tuning().row_var, lp, sp, tw, rows, 0, st);
             }
             if (rc) return rc;
         } else {
@@ -170,13 +206,13 @@ static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, vo
         if (!tw) return err;
         if (p.tc) {
             const int ntiles = int((N + p.tc - 1) / p.tc);
-            ColLoadTiled<T> cl{W, rows, to_map(d->in_y), ntiles};
-            return launch_col_tiled<T>(p.logm, cl, cs, tw, ntiles, st);
+            ColLoadTiled<T> cl{W, rows, to_map(d->in_y), ntiles, p.log_k};
+            return launch_col_tiled<T>(p.logm, tuning().col_var, cl, cs, tw, ntiles, p.log_k > 1 ? p.log_k : 1, st);
         }
-        const int tc = col_tile_width_for(d->dtype, p.logm);
+        const int tc = col_tile_width_for(d->dtype, p.logm, tuning().col_var);
         const int ntiles = int((N + tc - 1) / tc);
         ColLoadNat<T> cl{W, N, to_map(d->in_y), int(N), 0, (N % 2 == 0) ? 1 : 0};
-        return launch_col_nat<T>(p.logm, cl, cs, tw, ntiles, st);
+        return launch_col_nat<T>(p.logm, tuning().col_var, cl, cs, tw, ntiles, 1, st);
     }
     const cx<double>* tw = twiddles_f64(M, &err);
     if (!tw) return err;
@@ -219,8 +255,8 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
         if (lg >= 0) {
             const cx<T>* tw = twiddles<T>(n, &err);
             if (!tw) return err;
-            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), in_ld, to_map(*ti), int(batch), conj};
-            return launch_row_nat<T>(lg, lp, sp, tw, int(batch), st);
+            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), in_ld, to_map(*ti), int(batch), conj, 0};
+            return launch_row_nat<T>(lg, tuning().row_var, lp, sp, tw, int(batch), 0, st);
         }
         const cx<double>* tw = twiddles_f64(n, &err);
         if (!tw) return err;
@@ -242,11 +278,11 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
     if (lg >= 0) {
         const cx<T>* tw = twiddles<T>(n, &err);
         if (!tw) return err;
-        const int tc = col_tile_width_for(sizeof(T) == 4 ? PM_C64 : PM_C128, lg);
+        const int tc = col_tile_width_for(sizeof(T) == 4 ? PM_C64 : PM_C128, lg, tuning().col_var);
         const int ntiles = int((batch + tc - 1) / tc);
         const int vec = (sizeof(T) != 4 || ((in_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0))) ? 1 : 0;
         ColLoadNat<T> cl{reinterpret_cast<const cx<T>*>(in), in_ld, to_map(*ti), int(batch), conj, vec};
-        return launch_col_nat<T>(lg, cl, cs, tw, ntiles, st);
+        return launch_col_nat<T>(lg, tuning().col_var, cl, cs, tw, ntiles, 1, st);
     }
     const cx<double>* tw = twiddles_f64(n, &err);
     if (!tw) return err;
@@ -261,6 +297,12 @@ using namespace pm;
 extern "C" {
 
 int pm_version(void) { return PM_VERSION; }
+
+int pm_set_tuning(const char* key, int32_t value) {
+    if (!key) return fail(PM_ERR_ARG, "pm_set_tuning: null key");
+    tune_set(tuning(), key, strlen(key), value);
+    return 0;
+}
 const char* pm_last_error(void) { return g_err; }
 
 int pm_plan_prepare(int32_t dtype, int64_t n) {

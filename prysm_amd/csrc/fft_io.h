@@ -34,13 +34,14 @@ struct RowLoadNat {
     AxisMap ax;     // along the transform axis
     int nseq;       // number of sequences (memory rows)
     int conj;
+    int nt;         // non-temporal loads (input is read exactly once)
 };
 
 template <typename T>
 struct RowStoreTiled {
     cx<T>* dst;
     int nseq;       // rows of the intermediate
-    int log_tc;     // log2(tile width)
+    int log_tc;     // log2(LAYOUT tile width TL): one row of a layout tile is TL*sizeof(complex) contiguous bytes
 };
 
 template <typename T>
@@ -58,7 +59,8 @@ struct ColLoadTiled {
     const cx<T>* src;
     int nrows;      // rows stored in the intermediate (memory rows)
     AxisMap ay;     // logical row -> stored row
-    int ntiles;
+    int ntiles;     // number of TC-wide tiles (workgroup units)
+    int log_k;      // layout tile = 2^log_k workgroup tiles wide (TL = TC << log_k)
 };
 
 template <typename T>
@@ -87,6 +89,7 @@ struct ColStoreNat {
     const cx<T>* mul_x;   // MUL_SEPARABLE: column factor hx[c]
     int64_t mul_ld;
     int vec_ok;
+    int nt;         // non-temporal stores on the fast path (output is written exactly once)
 };
 
 // slot rotation helper: memory index (before the window offset) of register slot m.
@@ -116,6 +119,40 @@ struct alignas(16) Vec4 {
     T a, b, c, d;
 };
 
+// non-temporal (streaming) accesses: data touched exactly once should not displace the intermediate of
+// the 2-D transform from L2 / Infinity Cache.  The builtins need scalar or ext-vector types.
+#if defined(__HIPCC__)
+template <typename T, int NW> struct NtVec { typedef T type __attribute__((ext_vector_type(NW))); };
+template <typename T>
+__device__ __forceinline__ cx<T> nt_load_cx(const cx<T>* p) {
+    typedef typename NtVec<T, 2>::type V;
+    const V w = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+    return {w[0], w[1]};
+}
+template <typename T>
+__device__ __forceinline__ void nt_store_cx(cx<T>* p, cx<T> v) {
+    typedef typename NtVec<T, 2>::type V;
+    V w;
+    w[0] = v.x;
+    w[1] = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<V*>(p));
+}
+template <typename T>
+__device__ __forceinline__ void nt_store_v4(Vec4<T>* p, Vec4<T> v) {
+    typedef typename NtVec<T, 4>::type V;
+    V w;
+    w[0] = v.a; w[1] = v.b; w[2] = v.c; w[3] = v.d;
+    __builtin_nontemporal_store(w, reinterpret_cast<V*>(p));
+}
+template <typename T>
+__device__ __forceinline__ void nt_store_s(T* p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+template <typename T> inline cx<T> nt_load_cx(const cx<T>* p) { return *p; }
+template <typename T> inline void nt_store_cx(cx<T>* p, cx<T> v) { *p = v; }
+template <typename T> inline void nt_store_v4(Vec4<T>* p, Vec4<T> v) { *p = v; }
+template <typename T> inline void nt_store_s(T* p, T v) { *p = v; }
+#endif
+
 // ------------------------------------------------------------------ row mode
 template <typename C, int ROT>
 PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
@@ -130,7 +167,7 @@ PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
     for (int m = 0; m < C::P; ++m) {
         const int pp = slot_pos<C, ROT>(pos.t, m, p.ax.shift);
         cx<T> val = {T(0), T(0)};
-        if (pp >= lo && pp < hi) val = row[pp];
+        if (pp >= lo && pp < hi) val = p.nt ? nt_load_cx(row + pp) : row[pp];
         v[0][m] = val;
     }
     if (p.conj) {
@@ -204,13 +241,17 @@ PM_HD void store(const RowStoreNat<typename C::T>& p, int blk, ThreadPos pos,
 }
 
 // ------------------------------------------------------------------ col mode
-// tile handled by (blk, bo): XCD-aware pairing so that workgroups g and g+8 (same XCD,
-// dispatched back to back) own the two 64 B halves of the same 128 B lines.
-PM_HD int pair_remap(int g, int total) {
-    if ((total & 15) != 0) return g;
+// unit handled by workgroup g: XCD-aware sibling grouping.  Workgroups g, g+8, ..., g+8(G-1) run on the
+// same XCD (block b -> XCD b % 8) back to back; they get G ADJACENT units, so the pieces of one cache line
+// (or of one layout-tile row) that different workgroups touch meet in that XCD's L2.  Speed only: any
+// placement gives the same results.
+PM_HD int group_remap(int g, int total, int log_g) {
+    const int G = 1 << log_g;
+    if (log_g == 0 || (total % (8 * G)) != 0) return g;
     const int xcd = g & 7, idx = g >> 3;
-    return (((idx >> 1) << 3) + xcd) * 2 + (idx & 1);
+    return (((idx >> log_g) << 3) + xcd) * G + (idx & (G - 1));
 }
+PM_HD int pair_remap(int g, int total) { return group_remap(g, total, 1); }
 
 template <typename C, int ROT>
 PM_HD void load_rot(const ColLoadTiled<typename C::T>& p, int tile, ThreadPos pos,
@@ -218,14 +259,17 @@ PM_HD void load_rot(const ColLoadTiled<typename C::T>& p, int tile, ThreadPos po
     using T = typename C::T;
     constexpr int TC = C::CI * C::E;
     const bool ok = tile < p.ntiles;
-    // element (row q, col) of the tile at base[(q)*TC + col]; q = p - off
-    const cx<T>* base = p.src + (int64_t(ok ? tile : 0) * p.nrows - p.ay.off) * TC + pos.cl * C::E;
+    // element (row q, col) of workgroup tile `tile` lives in layout tile (tile >> log_k) at
+    // [(q)*TL + (tile & (k-1))*TC + col]; q = p - off
+    const int TL = TC << p.log_k;
+    const int tl = (ok ? tile : 0) >> p.log_k, sub = (ok ? tile : 0) & ((1 << p.log_k) - 1);
+    const cx<T>* base = p.src + (int64_t(tl) * p.nrows - p.ay.off) * TL + sub * TC + pos.cl * C::E;
     const int lo = p.ay.off, hi = ok ? p.ay.off + p.ay.len : -1;
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
         const int pp = slot_pos<C, ROT>(pos.t, m, p.ay.shift);
         if (pp >= lo && pp < hi) {
-            const cx<T>* a = base + int64_t(pp) * TC;
+            const cx<T>* a = base + int64_t(pp) * TL;
             if constexpr (C::E == 2 && sizeof(T) == 4) {
                 const Vec4<T> w = *reinterpret_cast<const Vec4<T>*>(a);  // two adjacent complex64 columns
                 v[0][m] = {w.a, w.b};
@@ -341,10 +385,19 @@ PM_HD void store_fast(const ColStoreNat<typename C::T>& p, int tile, ThreadPos p
                 if (p.conj) val[e].y = -val[e].y;
             }
             if constexpr (C::E == 2 && sizeof(T) == 4) {
-                *reinterpret_cast<Vec4<T>*>(a) = Vec4<T>{val[0].x, val[0].y, val[1].x, val[1].y};
+                const Vec4<T> w{val[0].x, val[0].y, val[1].x, val[1].y};
+                if (p.nt)
+                    nt_store_v4(reinterpret_cast<Vec4<T>*>(a), w);
+                else
+                    *reinterpret_cast<Vec4<T>*>(a) = w;
             } else {
 #pragma unroll
-                for (int e = 0; e < C::E; ++e) a[e] = val[e];
+                for (int e = 0; e < C::E; ++e) {
+                    if (p.nt)
+                        nt_store_cx(a + e, val[e]);
+                    else
+                        a[e] = val[e];
+                }
             }
         }
     } else {
@@ -358,10 +411,14 @@ PM_HD void store_fast(const ColStoreNat<typename C::T>& p, int tile, ThreadPos p
 #pragma unroll
             for (int e = 0; e < C::E; ++e) {
                 const T i2 = (v[e][m].x * v[e][m].x + v[e][m].y * v[e][m].y) * s2;
-                if (p.epilogue == EPI_ABS2)
-                    a[e] = i2;
-                else
+                if (p.epilogue == EPI_ABS2) {
+                    if (p.nt)
+                        nt_store_s(a + e, i2);
+                    else
+                        a[e] = i2;
+                } else {
                     a[e] += p.weight * i2;
+                }
             }
         }
     }

@@ -14,38 +14,36 @@ constexpr int kMaxLogN = 13;  // 8192: the largest length one workgroup holds on
 // ---- per-length configurations -------------------------------------------------------------
 // Row pass: one sequence per N/16 threads, 256 threads per workgroup (512 at N = 8192); LDS is
 // 8.5 B per point (complex64) so 4 workgroups / CU stay resident at N = 4096.
-template <typename T, int LOGN>
+// VAR (tuning variant, PM_TUNE / pm_set_tuning): row pass VAR = 1 doubles the rows per workgroup (each
+// workgroup then writes whole 128 B lines of the tiled intermediate); column pass VAR = 1 halves the tile
+// width (two workgroups per CU instead of one: memory phases of one overlap compute phases of the other).
+template <typename T, int LOGN, int VAR>
 struct RowCfgSel {
     static constexpr int N = 1 << LOGN, P = N >= 16 ? 16 : N, TPS = N / P;
-    static constexpr int BO = TPS >= 256 ? 1 : 256 / TPS;
+    static constexpr int BO = (TPS >= 256 ? 1 : 256 / TPS) << VAR;
     static constexpr int COMP = (sizeof(T) == 8 && LOGN >= 12) ? 2 : 1;
     using type = FftCfg<T, LOGN, 1, 1, BO, COMP>;
 };
 // Column pass: a tile of 64 B rows (8 complex64 / 4 complex128 columns) per workgroup; at
 // M = 4096 that is 256 KiB of field in the registers of 1024 threads, exchanged through LDS in
 // two 136 KiB chunks (complex64: the thread's two columns; complex128: real then imaginary).
-template <typename T, int LOGN>
+template <typename T, int LOGN, int VAR>
 struct ColCfgSel {
     static constexpr int N = 1 << LOGN, P = N >= 16 ? 16 : N, TPS = N / P;
     static constexpr int E = sizeof(T) == 4 ? 2 : 1;
-    static constexpr int CI = LOGN <= 12 ? 4 : 2;
+    static constexpr int CI0 = LOGN <= 12 ? 4 : 2;
+    static constexpr int CI = (CI0 >> VAR) >= 1 ? (CI0 >> VAR) : 1;
     static constexpr int BO = (CI * TPS >= 256) ? 1 : 256 / (CI * TPS);
     static constexpr int COMP = (sizeof(T) == 8 && LOGN >= 11) ? 2 : 1;
     using type = FftCfg<T, LOGN, CI, E, BO, COMP>;
 };
 
-template <typename T>
-inline int col_tile_width(int logm) {
-    const int e = sizeof(T) == 4 ? 2 : 1;
-    return (logm <= 12 ? 4 : 2) * e;
-}
-
 template <typename C, bool COL, typename L, typename S>
 __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
-                                                    const cx<typename C::T>* __restrict__ tw) {
+                                                    const cx<typename C::T>* __restrict__ tw, const int log_g) {
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
-    int unit = pair_remap(blockIdx.x, gridDim.x);
+    int unit = group_remap(blockIdx.x, gridDim.x, log_g);
     if (COL) unit = unit * C::BO + pos.bo;
     cx<typename C::T> v[C::E][C::P];
     load<C>(lp, unit, pos, v);
@@ -53,9 +51,9 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
     store<C>(sp, unit, pos, v);
 }
 
-template <typename T, bool COL, int LOGN, typename L, typename S>
-int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, hipStream_t st) {
-    using Sel = typename std::conditional<COL, ColCfgSel<T, LOGN>, RowCfgSel<T, LOGN>>::type;
+template <typename T, bool COL, int LOGN, int VAR, typename L, typename S>
+int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st) {
+    using Sel = typename std::conditional<COL, ColCfgSel<T, LOGN, VAR>, RowCfgSel<T, LOGN, VAR>>::type;
     using C = typename Sel::type;
     auto kern = fft_kernel<C, COL, L, S>;
     if (C::LDS_BYTES > 48 * 1024) {
@@ -65,28 +63,33 @@ int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, hipStream_t
     }
     const int grid = (units + C::BO - 1) / C::BO;
     if (grid <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, lp, sp, tw);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, lp, sp, tw, log_g);
     return int(hipGetLastError());
 }
 
 template <typename T, bool COL, typename L, typename S>
-int launch_fft(int logn, const L& lp, const S& sp, const cx<T>* tw, int units, hipStream_t st) {
+int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st) {
     switch (logn) {
 #define PM_CASE(k) \
     case k:        \
-        return launch_one<T, COL, k, L, S>(lp, sp, tw, units, st);
+        return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st);
+#define PM_CASEV(k)                                                       \
+    case k:                                                               \
+        if (var == 1) return launch_one<T, COL, k, 1, L, S>(lp, sp, tw, units, log_g, st); \
+        return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st);
         PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
-        PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASE(11) PM_CASE(12) PM_CASE(13)
+        PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASEV(11) PM_CASEV(12) PM_CASEV(13)
 #undef PM_CASE
+#undef PM_CASEV
         default:
             return -2;
     }
 }
 
 // entry points, one explicit instantiation per .hip file
-template <typename T> int launch_row_tiled(int logn, const RowLoadNat<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, hipStream_t);
-template <typename T> int launch_row_nat(int logn, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t);
-template <typename T> int launch_col_tiled(int logm, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, hipStream_t);
-template <typename T> int launch_col_nat(int logm, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, hipStream_t);
+template <typename T> int launch_row_tiled(int logn, int var, const RowLoadNat<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t);
+template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t);
+template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
+template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
 
 }  // namespace pm

@@ -35,13 +35,29 @@ int direct_rows_out(const DirectIn<T>& in, const RowStoreNat<T>& out, const cx<d
 template <typename T>
 int direct_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, const cx<double>* tw, hipStream_t st);
 
-// engine launchers (fft_row_*.hip / fft_col_*.hip)
-template <typename T> int launch_row_tiled(int logn, const RowLoadNat<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, hipStream_t);
-template <typename T> int launch_row_nat(int logn, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t);
-template <typename T> int launch_col_tiled(int logm, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, hipStream_t);
-template <typename T> int launch_col_nat(int logm, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, hipStream_t);
+// engine launchers (fft_row_*.hip / fft_col_*.hip); `var` = tuning variant (see fft_kernels.h)
+template <typename T> int launch_row_tiled(int logn, int var, const RowLoadNat<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t);
+template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t);
+template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
+template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
 // tile width of the column pass; MUST match ColCfgSel in fft_kernels.h (CI * E)
-inline int col_tile_width_for(int dtype, int logm) { return (logm <= 12 ? 4 : 2) * (dtype == PM_C64 ? 2 : 1); }
+inline int col_tile_width_for(int dtype, int logm, int var) {
+    int ci = logm <= 12 ? 4 : 2;
+    if (var == 1 && logm >= 11) ci = ci >> 1 ? ci >> 1 : 1;
+    return ci * (dtype == PM_C64 ? 2 : 1);
+}
+
+// runtime tuning knobs (capi.hip): PM_TUNE="col_var=1,row_var=0,nt_in=1,nt_out=1" or pm_set_tuning()
+struct Tuning {
+    int col_var = 0, row_var = 0;
+    // non-temporal input loads / output stores: 0 off, 1 on, -1 auto (by array size vs the 256 MiB
+    // Infinity Cache: measured on MI355X, streaming hints pay once the arrays no longer fit beside the
+    // intermediate -- input from ~128 MiB, output from ~256 MiB; they cost a few % below that)
+    int nt_in = -1, nt_out = -1;
+    int log_k = 2;      // layout tiles of the intermediate are 2^log_k column-pass tiles wide (256 B rows)
+    int row_log_g = 1;  // sibling group of row-pass workgroups (rows q .. q+2^g-1 on one XCD)
+};
+Tuning& tuning();
 
 constexpr int kEngineMaxLog = 13;
 inline int engine_log2(int64_t n) {  // log2(n) if n is a power of two the engine handles, else -1

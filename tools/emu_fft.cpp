@@ -90,7 +90,7 @@ static void test_row(int nseq, int in_len, int in_off, int in_shift, int out_shi
     std::vector<cx<T>> x(size_t(nseq) * in_len), y(size_t(nseq) * N, cx<T>{T(-7), T(-7)});
     for (auto& e : x) e = {T(nd(rng)), T(nd(rng))};
     auto tw = make_tw<T>(N);
-    RowLoadNat<T> lp{x.data(), in_len, AxisMap{N, in_len, in_off, in_shift}, nseq, inverse ? 1 : 0};
+    RowLoadNat<T> lp{x.data(), in_len, AxisMap{N, in_len, in_off, in_shift}, nseq, inverse ? 1 : 0, 0};
     RowStoreNat<T> sp{y.data(), N, AxisMap{N, N, 0, out_shift}, nseq, inverse ? 1 : 0, T(1)};
     const int nblk = (nseq + C::BO - 1) / C::BO;
     emu_kernel<C, false>(nblk, lp, sp, tw.data());
@@ -123,12 +123,13 @@ static void test_row(int nseq, int in_len, int in_off, int in_shift, int out_shi
 
 // --- 2-D: row pass -> tiled intermediate -> column pass, vs naive 2-D DFT ---------------
 template <typename T, int LOGM, int LOGN, int RBO, int RCOMP, int CCI, int CE, int CBO, int CCOMP>
-static void test_2d(int in_rows, int in_cols, bool shifts, int epilogue, bool inverse, int out_rows, int out_cols) {
+static void test_2d(int in_rows, int in_cols, bool shifts, int epilogue, bool inverse, int out_rows, int out_cols, int log_k = 0) {
     using RC = FftCfg<T, LOGN, 1, 1, RBO, RCOMP>;      // row transform of length N (columns)
     using CC = FftCfg<T, LOGM, CCI, CE, CBO, CCOMP>;   // column transform of length M (rows)
     const int M = CC::N, N = RC::N, TC = CCI * CE;
+    const int TL = TC << log_k;
     int log_tc = 0;
-    while ((1 << log_tc) < TC) ++log_tc;
+    while ((1 << log_tc) < TL) ++log_tc;
     std::mt19937 rng(LOGM * 17 + LOGN);
     std::normal_distribution<double> nd;
     std::vector<cx<T>> x(size_t(in_rows) * in_cols);
@@ -136,18 +137,18 @@ static void test_2d(int in_rows, int in_cols, bool shifts, int epilogue, bool in
     const int offy = (M - in_rows + 1) / 2, offx = (N - in_cols + 1) / 2;  // pad2d: ceil(d/2)
     const int shy = shifts ? M / 2 : 0, shx = shifts ? N / 2 : 0;
     const int ntiles = (N + TC - 1) / TC;
-    std::vector<cx<T>> W(size_t(ntiles) * in_rows * TC, cx<T>{T(1e30), T(1e30)});
+    std::vector<cx<T>> W(size_t((N + TL - 1) / TL) * in_rows * TL, cx<T>{T(1e30), T(1e30)});
     auto twN = make_tw<T>(N);
     auto twM = make_tw<T>(M);
     // pass 1: one FFT per stored input row
-    RowLoadNat<T> lp{x.data(), in_cols, AxisMap{N, in_cols, offx, shx}, in_rows, inverse ? 1 : 0};
+    RowLoadNat<T> lp{x.data(), in_cols, AxisMap{N, in_cols, offx, shx}, in_rows, inverse ? 1 : 0, 0};
     RowStoreTiled<T> sp{W.data(), in_rows, log_tc};
     emu_kernel<RC, false>((in_rows + RC::BO - 1) / RC::BO, lp, sp, twN.data());
     // pass 2
     const int coffy = (M - out_rows + 1) / 2, coffx = (N - out_cols + 1) / 2;  // crop_center: ceil(p/2)
     std::vector<cx<T>> out(size_t(out_rows) * out_cols, cx<T>{T(-3), T(-3)});
     std::vector<T> outr(size_t(out_rows) * out_cols, T(-3));
-    ColLoadTiled<T> cl{W.data(), in_rows, AxisMap{M, in_rows, offy, shy}, ntiles};
+    ColLoadTiled<T> cl{W.data(), in_rows, AxisMap{M, in_rows, offy, shy}, ntiles, log_k};
     ColStoreNat<T> cs{};
     cs.dst = epilogue ? (void*)outr.data() : (void*)out.data();
     cs.ld = out_cols;
@@ -208,8 +209,8 @@ static void test_2d(int in_rows, int in_cols, bool shifts, int epilogue, bool in
             }
         }
     char buf[160];
-    snprintf(buf, sizeof buf, "2d %s %dx%d in=%dx%d out=%dx%d sh=%d epi=%d %s TC=%d", sizeof(T) == 4 ? "c64" : "c128",
-             M, N, in_rows, in_cols, out_rows, out_cols, (int)shifts, epilogue, inverse ? "inv" : "fwd", TC);
+    snprintf(buf, sizeof buf, "2d %s %dx%d in=%dx%d out=%dx%d sh=%d epi=%d %s TC=%d TL=%d", sizeof(T) == 4 ? "c64" : "c128",
+             M, N, in_rows, in_cols, out_rows, out_cols, (int)shifts, epilogue, inverse ? "inv" : "fwd", TC, TL);
     report(buf, err / nrm, sizeof(T) == 4 ? 3e-6 : 1e-13);
 }
 
@@ -237,6 +238,9 @@ int main() {
     test_2d<float, 7, 7, 32, 1, 4, 2, 8, 1>(128, 128, true, 1, false, 128, 128);   // abs2 epilogue
     test_2d<float, 8, 5, 128, 1, 4, 2, 4, 1>(200, 20, false, 0, false, 256, 32);
     test_2d<float, 9, 4, 256, 1, 2, 2, 4, 1>(512, 16, true, 0, false, 512, 16);    // TC=4 variant
+    test_2d<float, 6, 6, 64, 1, 4, 2, 16, 1>(64, 64, true, 0, false, 64, 64, 1);   // layout tile 16 wide
+    test_2d<float, 5, 7, 32, 1, 4, 2, 32, 1>(16, 100, true, 0, false, 32, 128, 2);  // layout tile 32 wide + pad
+    test_2d<double, 6, 6, 64, 1, 4, 1, 16, 2>(64, 64, true, 0, true, 40, 64, 2);
     test_2d<double, 6, 6, 64, 1, 4, 1, 16, 2>(64, 64, true, 0, false, 64, 64);
     test_2d<double, 5, 7, 32, 2, 4, 1, 32, 1>(20, 100, true, 0, true, 32, 128);
     test_2d<double, 8, 4, 256, 1, 2, 1, 8, 2>(256, 16, false, 1, false, 256, 16);

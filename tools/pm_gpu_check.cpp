@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <random>
 #include <string>
 #include <vector>
@@ -283,6 +284,81 @@ static void check_cgemm(int opA, int opB, int64_t M, int64_t N, int64_t K, doubl
     if (ws) HIPCHECK(hipFree(ws));
 }
 
+// ---- calibration kernels: what a perfect streaming pass achieves on this box --------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int NTL, int NTS>
+__global__ void copy_kernel(const f4* __restrict__ a, f4* __restrict__ b, size_t n) {
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        f4 v = NTL ? __builtin_nontemporal_load(a + i) : a[i];
+        if (NTS)
+            __builtin_nontemporal_store(v, b + i);
+        else
+            b[i] = v;
+    }
+}
+static void launch_copy(int ntl, int nts, const void* a, void* b, size_t bytes) {
+    const size_t n = bytes / 16;
+    dim3 g(2048), blk(256);
+    if (!ntl && !nts) hipLaunchKernelGGL((copy_kernel<0, 0>), g, blk, 0, nullptr, (const f4*)a, (f4*)b, n);
+    if (ntl && !nts) hipLaunchKernelGGL((copy_kernel<1, 0>), g, blk, 0, nullptr, (const f4*)a, (f4*)b, n);
+    if (!ntl && nts) hipLaunchKernelGGL((copy_kernel<0, 1>), g, blk, 0, nullptr, (const f4*)a, (f4*)b, n);
+    if (ntl && nts) hipLaunchKernelGGL((copy_kernel<1, 1>), g, blk, 0, nullptr, (const f4*)a, (f4*)b, n);
+}
+static void calibrate() {
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    for (size_t mb : {128, 512, 2048}) {
+        void *a, *b;
+        HIPCHECK(hipMalloc(&a, mb << 20));
+        HIPCHECK(hipMalloc(&b, mb << 20));
+        HIPCHECK(hipMemset(a, 1, mb << 20));
+        for (int v = 0; v < 4; ++v) {
+            for (int i = 0; i < 3; ++i) launch_copy(v & 1, v >> 1, a, b, mb << 20);
+            HIPCHECK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < 20; ++i) launch_copy(v & 1, v >> 1, a, b, mb << 20);
+            HIPCHECK(hipEventRecord(e1, nullptr));
+            HIPCHECK(hipEventSynchronize(e1));
+            float ms;
+            HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+            printf("CALIB copy kernel %zu MiB ntload=%d ntstore=%d: %.1f us -> %.0f GB/s (read+write)\n", mb, v & 1, v >> 1,
+                   ms / 20 * 1e3, 2.0 * double(mb << 20) / (ms / 20) / 1e6);
+        }
+        HIPCHECK(hipFree(a));
+        HIPCHECK(hipFree(b));
+    }
+    // the three-buffer cycle of one propagation (in -> ws -> out, 128 MiB each) done by plain copies: the
+    // time two PERFECT streaming passes would take in the same cache regime as the real transform
+    for (size_t mb : {128, 256}) {
+        void *in, *ws, *out;
+        HIPCHECK(hipMalloc(&in, mb << 20));
+        HIPCHECK(hipMalloc(&ws, mb << 20));
+        HIPCHECK(hipMalloc(&out, mb << 20));
+        HIPCHECK(hipMemset(in, 1, mb << 20));
+        for (int v = 0; v < 4; ++v) {
+            const int nti = v & 1, nto = v >> 1;
+            for (int i = 0; i < 3; ++i) {
+                launch_copy(nti, 0, in, ws, mb << 20);
+                launch_copy(0, nto, ws, out, mb << 20);
+            }
+            HIPCHECK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < 20; ++i) {
+                launch_copy(nti, 0, in, ws, mb << 20);
+                launch_copy(0, nto, ws, out, mb << 20);
+            }
+            HIPCHECK(hipEventRecord(e1, nullptr));
+            HIPCHECK(hipEventSynchronize(e1));
+            float ms;
+            HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+            printf("CALIB in->ws->out copies, %zu MiB arrays, nt_in=%d nt_out=%d: %.1f us per pair -> %.0f GB/s algorithmic\n", mb, nti,
+                   nto, ms / 20 * 1e3, 4.0 * double(mb << 20) / (ms / 20) / 1e6);
+        }
+        HIPCHECK(hipFree(in));
+        HIPCHECK(hipFree(ws));
+        HIPCHECK(hipFree(out));
+    }
+}
+
 // ---- timing ---------------------------------------------------------------------------------
 static double time_copy(size_t bytes) {
     void *a, *b;
@@ -356,6 +432,80 @@ static void bench_fft2(int64_t n, int64_t in_n, int epi) {
     HIPCHECK(hipFree(ws));
 }
 
+// sweep of the tuning knobs on one transform size: configurations are timed round-robin for several
+// rounds in ONE process (interleaved A/B, cdna guide rule 24); min and median of the whole-transform time
+struct Knobs {
+    int row_var, col_var, nt_in, nt_out, log_k, row_log_g;
+};
+static void apply(const Knobs& k) {
+    pm_set_tuning("row_var", k.row_var);
+    pm_set_tuning("col_var", k.col_var);
+    pm_set_tuning("nt_in", k.nt_in);
+    pm_set_tuning("nt_out", k.nt_out);
+    pm_set_tuning("log_k", k.log_k);
+    pm_set_tuning("row_log_g", k.row_log_g);
+}
+template <typename T>
+static void sweep_fft2(int64_t n, const std::vector<Knobs>& cfgs, int rounds) {
+    pm_fft2_desc d;
+    memset(&d, 0, sizeof d);
+    d.dtype = sizeof(T) == 4 ? PM_C64 : PM_C128;
+    d.direction = -1;
+    d.scale = 1.0 / double(n);
+    d.weight = 1.0;
+    d.in_y = d.in_x = d.out_y = d.out_x = {n, n, 0, n / 2};
+    d.in_ld = d.out_ld = n;
+    const size_t es = 2 * sizeof(T);
+    std::vector<std::complex<T>> hx(size_t(n) * n);
+    std::mt19937 rng(n);
+    std::normal_distribution<float> nd;
+    for (auto& e : hx) e = std::complex<T>(nd(rng), nd(rng));
+    void *din, *dout, *ws;
+    const size_t wsb = size_t(n) * n * es;
+    HIPCHECK(hipMalloc(&din, hx.size() * es));
+    HIPCHECK(hipMalloc(&dout, size_t(n) * n * es));
+    HIPCHECK(hipMalloc(&ws, wsb));
+    HIPCHECK(hipMemcpy(din, hx.data(), hx.size() * es, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    std::vector<std::vector<double>> t(cfgs.size());
+    std::vector<double> p1(cfgs.size()), p2(cfgs.size());
+    const int reps = 40;
+    for (int r = 0; r < rounds; ++r)
+        for (size_t c = 0; c < cfgs.size(); ++c) {
+            apply(cfgs[c]);
+            for (int i = 0; i < 5; ++i) pm_fft2(&d, din, dout, ws, wsb, nullptr);
+            HIPCHECK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < reps; ++i) pm_fft2(&d, din, dout, ws, wsb, nullptr);
+            HIPCHECK(hipEventRecord(e1, nullptr));
+            HIPCHECK(hipEventSynchronize(e1));
+            float ms;
+            HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+            t[c].push_back(double(ms) / reps * 1e3);
+            if (r == rounds - 1) {
+                double pm[2];
+                pm_fft2_time_passes(&d, din, dout, ws, wsb, 20, pm, nullptr);
+                p1[c] = pm[0] * 1e3;
+                p2[c] = pm[1] * 1e3;
+            }
+        }
+    const double alg = 4.0 * double(n) * n * es;
+    for (size_t c = 0; c < cfgs.size(); ++c) {
+        std::sort(t[c].begin(), t[c].end());
+        const double mn = t[c].front(), med = t[c][t[c].size() / 2];
+        const Knobs& k = cfgs[c];
+        printf("SWEEP %s N=%lld row_var=%d col_var=%d nt_in=%d nt_out=%d log_k=%d row_log_g=%d : total min %.1f med %.1f us "
+               "(%.1f%% of 8TB/s at min) ; passes %.1f + %.1f us\n",
+               sizeof(T) == 4 ? "c64" : "c128", (long long)n, k.row_var, k.col_var, k.nt_in, k.nt_out, k.log_k, k.row_log_g, mn, med,
+               alg / mn / 1e6 / 8000 * 100, p1[c], p2[c]);
+    }
+    apply(Knobs{0, 0, -1, -1, 2, 1});
+    HIPCHECK(hipFree(din));
+    HIPCHECK(hipFree(dout));
+    HIPCHECK(hipFree(ws));
+}
+
 template <typename T>
 static void bench_cgemm(int64_t M, int64_t N, int64_t K, int opB) {
     const size_t es = 2 * sizeof(T);
@@ -400,6 +550,34 @@ int main(int argc, char** argv) {
     HIPCHECK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s (%s) CUs=%d LDS/block=%zu version=%d\n", prop.name, prop.gcnArchName, prop.multiProcessorCount,
            prop.sharedMemPerBlock, pm_version());
+    if (mode == "calib") {
+        calibrate();
+        return 0;
+    }
+    if (mode == "prof") {   // short, fixed workload for rocprofv3 (kernel trace / PMC passes)
+        bench_fft2<float>(4096, 4096, 0);
+        bench_fft2<double>(4096, 4096, 0);
+        bench_cgemm<float>(512, 2048, 2048, 0);
+        bench_cgemm<float>(512, 512, 2048, 2);
+        return 0;
+    }
+    if (mode == "sweep") {
+        const std::vector<Knobs> c64 = {
+            {0, 0, 0, 0, 0, 1}, {0, 0, 1, 0, 0, 1}, {1, 0, 0, 0, 0, 1}, {1, 0, 1, 0, 0, 1}, {0, 0, 0, 0, 1, 1}, {0, 0, 1, 0, 1, 1},
+            {0, 0, 0, 0, 2, 1}, {0, 0, 1, 0, 2, 1}, {1, 0, 1, 0, 1, 1}, {1, 0, 1, 0, 2, 1}, {0, 0, 1, 1, 2, 1}, {0, 0, 1, 0, 2, 0},
+            {0, 0, 1, 0, 2, 2}, {0, 0, 1, 0, 0, 0}, {0, 0, 1, 0, 0, 2}, {0, 0, 1, 0, 3, 1},
+        };
+        sweep_fft2<float>(4096, c64, 3);
+        const std::vector<Knobs> c128 = {
+            {0, 0, 0, 0, 0, 1}, {0, 0, 1, 1, 0, 1}, {0, 0, 1, 1, 1, 1}, {0, 0, 1, 1, 2, 1}, {1, 0, 1, 1, 1, 1}, {0, 0, 1, 0, 1, 1},
+            {0, 0, 0, 1, 1, 1}, {0, 0, 1, 1, 2, 0},
+        };
+        sweep_fft2<double>(4096, c128, 3);
+        const std::vector<Knobs> small = {{0, 0, 0, 0, 0, 1}, {0, 0, 1, 0, 0, 1}, {0, 0, 0, 0, 1, 1}, {0, 0, 0, 0, 2, 1}, {0, 0, 1, 0, 2, 1}};
+        sweep_fft2<float>(2048, small, 3);
+        sweep_fft2<double>(2048, small, 3);
+        return 0;
+    }
     if (mode != "bench") {
         const Case2 cases[] = {
             {16, 16, 16, 16, 16, 16, true, -1, 0},   {8, 8, 8, 8, 8, 8, false, -1, 0},       {64, 32, 64, 32, 64, 32, true, -1, 0},
