@@ -183,10 +183,10 @@ static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, vo
                 int ltc = 0;
                 while ((1 << ltc) < (p.tc << p.log_k)) ++ltc;
                 RowStoreTiled<T> sp{W, rows, ltc};
-                rc = launch_row_tiled<T>(p.logn, tuning().row_var, lp, sp, tw, rows, tuning().row_log_g, st);
+                rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, tuning().row_log_g, st);
             } else {
                 RowStoreNat<T> sp{W, N, AxisMap{int(N), int(N), 0, 0}, rows, 0, T(1)};
-                rc = launch_row_nat<T>(p.logn, tuning().row_var, lp, sp, tw, rows, 0, st);
+                rc = launch_row_nat<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, 0, st);
             }
             if (rc) return rc;
         } else {
@@ -256,7 +256,7 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
             const cx<T>* tw = twiddles<T>(n, &err);
             if (!tw) return err;
             RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), in_ld, to_map(*ti), int(batch), conj, 0};
-            return launch_row_nat<T>(lg, tuning().row_var, lp, sp, tw, int(batch), 0, st);
+            return launch_row_nat<T>(lg, row_variant(sizeof(T) == 4 ? PM_C64 : PM_C128, lg), lp, sp, tw, int(batch), 0, st);
         }
         const cx<double>* tw = twiddles_f64(n, &err);
         if (!tw) return err;

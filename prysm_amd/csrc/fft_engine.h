@@ -148,39 +148,64 @@ struct Dft<T, 16> {
 };
 
 // ---------------------------------------------------------------------------
+// twiddles of one stage for one thread: W^(4a b0) (a < R/4) and W^(b b0) (b < 4) per butterfly q; the
+// remaining W^((4a+b) b0) are products (one extra rounding).  They depend on the thread slot only, not on
+// the sequence, so a persistent kernel loads them once and keeps them in registers.
+// ---------------------------------------------------------------------------
+template <typename C, int S>
+struct StageTw {
+    static constexpr int R = C::radix(S), Q = C::P / R;
+    static constexpr int NA = (R / 4 > 1) ? R / 4 : 1;
+    cx<typename C::T> wa[Q][NA], wb[Q][4];
+};
+
+template <typename C, int S>
+PM_HD void load_stage_tw(StageTw<C, S>& w, int t, const cx<typename C::T>* __restrict__ tw) {
+    constexpr int R = C::radix(S), NS = C::ns(S), Q = C::P / R, NP = C::TPS;
+    if constexpr (S > 0 && R > 1) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int j = t + q * NP;
+            const int base = (j & (NS - 1)) * (C::N / (NS * R));
+            if constexpr (R == 2) {
+                w.wb[q][1] = tw[base];
+            } else {
+#pragma unroll
+                for (int a = 1; a < R / 4; ++a) w.wa[q][a] = tw[4 * a * base];
+#pragma unroll
+                for (int b = 1; b < 4; ++b) w.wb[q][b] = tw[b * base];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // one radix-R stage on the registers of a thread (all E sequences share the
 // twiddles: in column mode they are adjacent columns with the same row index)
 // ---------------------------------------------------------------------------
 template <typename C, int S>
-PM_HD void stage_compute(cx<typename C::T> (&v)[C::E][C::P], int t, const cx<typename C::T>* __restrict__ tw) {
+PM_HD void stage_compute(cx<typename C::T> (&v)[C::E][C::P], const StageTw<C, S>& w) {
     using T = typename C::T;
-    constexpr int R = C::radix(S), NS = C::ns(S), Q = C::P / R, NP = C::TPS;
+    constexpr int R = C::radix(S), Q = C::P / R;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         if constexpr (S > 0 && R > 1) {
-            const int j = t + q * NP;
-            const int base = (j & (NS - 1)) * (C::N / (NS * R));
             if constexpr (R == 2) {
-                const cx<T> w1 = tw[base];
 #pragma unroll
-                for (int e = 0; e < C::E; ++e) v[e][Q + q] = cmul(v[e][Q + q], w1);
+                for (int e = 0; e < C::E; ++e) v[e][Q + q] = cmul(v[e][Q + q], w.wb[q][1]);
             } else {
-                // R in {4, 8, 16}: W^(4a+b) = W^(4a) W^b, a < R/4, b < 4 -> R/4 - 1 + 3 table loads
-                cx<T> wa[(R / 4 > 1) ? R / 4 : 1];
 #pragma unroll
                 for (int a = 1; a < R / 4; ++a) {
-                    wa[a] = tw[4 * a * base];
 #pragma unroll
-                    for (int e = 0; e < C::E; ++e) v[e][(4 * a) * Q + q] = cmul(v[e][(4 * a) * Q + q], wa[a]);
+                    for (int e = 0; e < C::E; ++e) v[e][(4 * a) * Q + q] = cmul(v[e][(4 * a) * Q + q], w.wa[q][a]);
                 }
 #pragma unroll
                 for (int b = 1; b < 4; ++b) {
-                    const cx<T> wb = tw[b * base];
 #pragma unroll
-                    for (int e = 0; e < C::E; ++e) v[e][b * Q + q] = cmul(v[e][b * Q + q], wb);
+                    for (int e = 0; e < C::E; ++e) v[e][b * Q + q] = cmul(v[e][b * Q + q], w.wb[q][b]);
 #pragma unroll
                     for (int a = 1; a < R / 4; ++a) {
-                        const cx<T> wab = cmul(wa[a], wb);
+                        const cx<T> wab = cmul(w.wa[q][a], w.wb[q][b]);
 #pragma unroll
                         for (int e = 0; e < C::E; ++e)
                             v[e][(4 * a + b) * Q + q] = cmul(v[e][(4 * a + b) * Q + q], wab);
@@ -198,6 +223,14 @@ PM_HD void stage_compute(cx<typename C::T> (&v)[C::E][C::P], int t, const cx<typ
             for (int k = 0; k < R; ++k) v[e][k * Q + q] = a[k];
         }
     }
+}
+
+// convenience: load the stage twiddles, then compute (non-persistent kernels, CPU emulation)
+template <typename C, int S>
+PM_HD void stage_compute(cx<typename C::T> (&v)[C::E][C::P], int t, const cx<typename C::T>* __restrict__ tw) {
+    StageTw<C, S> w;
+    load_stage_tw<C, S>(w, t, tw);
+    stage_compute<C, S>(v, w);
 }
 
 template <typename C>
@@ -258,7 +291,54 @@ struct LdsType<FftCfg<T, L, CI, E, BO, 2>> {
     using type = T;
 };
 
+// twiddles of every stage of a transform (stage 0 has none)
+template <typename C, int S = 1, bool END = (S >= C::NSTAGE)>
+struct TwSet {
+    StageTw<C, S> w;
+    TwSet<C, S + 1> rest;
+};
+template <typename C, int S>
+struct TwSet<C, S, true> {};
+
+template <typename C, int S = 1>
+PM_HD void load_tw_set(TwSet<C, S>& ts, int t, const cx<typename C::T>* __restrict__ tw) {
+    if constexpr (S < C::NSTAGE) {
+        load_stage_tw<C, S>(ts.w, t, tw);
+        load_tw_set<C, S + 1>(ts.rest, t, tw);
+    }
+}
+
 #if defined(__HIPCC__)
+// transform with preloaded twiddles (persistent kernels): no global loads inside, so the only vmcnt waits in
+// the loop body belong to the data loads of the NEXT sequence, which stay in flight under this transform
+template <typename C, int S = 0, typename TS>
+__device__ __forceinline__ void fft_run_tw(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw, const TS& ts) {
+    using LT = typename LdsType<C>::type;
+    LT* lds = reinterpret_cast<LT*>(lds_raw);
+    if constexpr (S == 0) {
+        StageTw<C, 0> none;
+        stage_compute<C, 0>(v, none);
+    } else {
+        stage_compute<C, S>(v, ts.w);
+    }
+    if constexpr (S + 1 < C::NSTAGE) {
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) {
+#pragma unroll
+            for (int comp = 0; comp < C::COMP; ++comp) {
+                exch_write<C, S>(v, e, comp, pos, lds);
+                __syncthreads();
+                exch_read<C>(v, e, comp, pos, lds);
+                __syncthreads();
+            }
+        }
+        if constexpr (S == 0)
+            fft_run_tw<C, 1>(v, pos, lds_raw, ts);
+        else
+            fft_run_tw<C, S + 1>(v, pos, lds_raw, ts.rest);
+    }
+}
+
 // full transform of the registers of this thread; all threads of the workgroup must call it
 template <typename C, int S = 0>
 __device__ __forceinline__ void fft_run(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw,

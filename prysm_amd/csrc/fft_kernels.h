@@ -20,8 +20,10 @@ constexpr int kMaxLogN = 13;  // 8192: the largest length one workgroup holds on
 template <typename T, int LOGN, int VAR>
 struct RowCfgSel {
     static constexpr int N = 1 << LOGN, P = N >= 16 ? 16 : N, TPS = N / P;
-    static constexpr int BO = (TPS >= 256 ? 1 : 256 / TPS) << VAR;
-    static constexpr int COMP = (sizeof(T) == 8 && LOGN >= 12) ? 2 : 1;
+    static constexpr int BO = (TPS >= 256 ? 1 : 256 / TPS);
+    // VAR = 1: exchange real and imaginary parts separately -> half the LDS per workgroup, so the 72-VGPR
+    // complex64 kernel fits 7 workgroups per CU instead of 4 (the row pass is latency / concurrency bound)
+    static constexpr int COMP = ((sizeof(T) == 8 && LOGN >= 12) || VAR == 1) ? 2 : 1;   // VAR = 2: persistent kernel
     using type = FftCfg<T, LOGN, 1, 1, BO, COMP>;
 };
 // Column pass: a tile of 64 B rows (8 complex64 / 4 complex128 columns) per workgroup; at
@@ -51,6 +53,44 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
     store<C>(sp, unit, pos, v);
 }
 
+// Persistent row pass: each workgroup walks units g, g + G, g + 2G, ... and keeps TWO register sets: the loads
+// of the next unit are issued before the current one is transformed and stay in flight under its three
+// radix-16 stages (the wave only waits for them at the top of the next half-iteration); stores are fire and
+// forget.  Twiddles are row-invariant and live in registers for the whole kernel.  This turns the
+// load -> compute -> store chain of one workgroup into a pipeline without needing more resident workgroups.
+template <typename C, typename L, typename S>
+__global__ void __launch_bounds__(C::NT, (C::NT <= 256 ? 4 : 2)) fft_row_persistent_kernel(const L lp, const S sp,
+                                                                   const cx<typename C::T>* __restrict__ tw,
+                                                                   const int nunits, const int log_g) {
+    extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+    const ThreadPos pos = thread_pos<C>(threadIdx.x);
+    const int stride = gridDim.x;
+    cx<typename C::T> va[C::E][C::P], vb[C::E][C::P];
+    int u = blockIdx.x;
+    if (u < nunits) load<C>(lp, group_remap(u, nunits, log_g), pos, va);
+    while (u < nunits) {
+        // An opaque copy of the thread slot per iteration: without it LICM hoists every loop-invariant
+        // address, twiddle and twiddle product out of the loop (> 300 live registers, spills).
+        ThreadPos p = pos;
+        asm volatile("" : "+v"(p.t));
+        // order matters for the in-order vmcnt: twiddles of THIS unit first, then the prefetch of the next
+        // unit, so waiting for the twiddles never waits for the prefetch
+        TwSet<C> ts;
+        load_tw_set<C>(ts, p.t, tw);
+        const int u1 = u + stride;
+        if (u1 < nunits) load<C>(lp, group_remap(u1, nunits, log_g), p, vb);
+        fft_run_tw<C>(va, p, pm_smem, ts);
+        store<C>(sp, group_remap(u, nunits, log_g), p, va);
+        // rotate the register sets (32 moves); the wait for the prefetched loads lands here, after the
+        // stores of this unit were issued (those loads are older than the stores)
+#pragma unroll
+        for (int e = 0; e < C::E; ++e)
+#pragma unroll
+            for (int m = 0; m < C::P; ++m) va[e][m] = vb[e][m];
+        u = u1;
+    }
+}
+
 template <typename T, bool COL, int LOGN, int VAR, typename L, typename S>
 int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st) {
     using Sel = typename std::conditional<COL, ColCfgSel<T, LOGN, VAR>, RowCfgSel<T, LOGN, VAR>>::type;
@@ -63,6 +103,22 @@ int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, 
     }
     const int grid = (units + C::BO - 1) / C::BO;
     if (grid <= 0) return 0;
+    if constexpr (!COL && VAR == 2) {
+        // persistent, double-buffered (row pass, tuning row_var = 2)
+        auto pk = fft_row_persistent_kernel<C, L, S>;
+        if (C::LDS_BYTES > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               int(C::LDS_BYTES));
+            if (e != hipSuccess) return int(e);
+        }
+        const int lds_wg = C::LDS_BYTES ? int(160 * 1024 / C::LDS_BYTES) : 8;
+        int per_cu = lds_wg < 4 ? lds_wg : 4;
+        if (per_cu < 1) per_cu = 1;
+        int pgrid = 256 * per_cu;
+        if (pgrid > grid) pgrid = grid;
+        hipLaunchKernelGGL(pk, dim3(pgrid), dim3(C::NT), C::LDS_BYTES, st, lp, sp, tw, grid, log_g);
+        return int(hipGetLastError());
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, lp, sp, tw, log_g);
     return int(hipGetLastError());
 }
@@ -76,6 +132,7 @@ int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int
 #define PM_CASEV(k)                                                       \
     case k:                                                               \
         if (var == 1) return launch_one<T, COL, k, 1, L, S>(lp, sp, tw, units, log_g, st); \
+        if (var == 2 && !COL) return launch_one<T, COL, k, (COL ? 0 : 2), L, S>(lp, sp, tw, units, log_g, st); \
         return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st);
         PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
         PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASEV(11) PM_CASEV(12) PM_CASEV(13)

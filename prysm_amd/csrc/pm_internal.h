@@ -49,7 +49,8 @@ inline int col_tile_width_for(int dtype, int logm, int var) {
 
 // runtime tuning knobs (capi.hip): PM_TUNE="col_var=1,row_var=0,nt_in=1,nt_out=1" or pm_set_tuning()
 struct Tuning {
-    int col_var = 0, row_var = 0;
+    int col_var = 0;
+    int row_var = -1;   // row-pass variant: 0 plain, 1 half-LDS (re/im exchanged separately), 2 persistent double-buffered, -1 auto
     // non-temporal input loads / output stores: 0 off, 1 on, -1 auto (by array size vs the 256 MiB
     // Infinity Cache: measured on MI355X, streaming hints pay once the arrays no longer fit beside the
     // intermediate -- input from ~128 MiB, output from ~256 MiB; they cost a few % below that)
@@ -58,6 +59,14 @@ struct Tuning {
     int row_log_g = 1;  // sibling group of row-pass workgroups (rows q .. q+2^g-1 on one XCD)
 };
 Tuning& tuning();
+// measured on MI355X (profiles/r01): the persistent kernel wins for complex64 rows of >= 4096 points (+11 % on
+// the whole 4096^2 transform), the half-LDS variant for 2048-point rows; complex128 >= 4096 already exchanges halves
+inline int row_variant(int dtype, int logn) {
+    const int v = tuning().row_var;
+    if (v >= 0) return v;
+    if (dtype == PM_C64) return logn >= 12 ? 2 : (logn == 11 ? 1 : 0);
+    return logn == 11 ? 1 : 0;
+}
 
 constexpr int kEngineMaxLog = 13;
 inline int engine_log2(int64_t n) {  // log2(n) if n is a power of two the engine handles, else -1
