@@ -8,7 +8,7 @@ brandondube/prysm, behind prysm's own Wavefront / propagation / fttools interfac
 Arrays are torch tensors in HBM; all hot-path arithmetic runs in hand-written HIP kernels
 (libprysm_amd.so, C ABI in include/prysm_amd.h).  There is no CPU fallback.
 """
-from . import conf, mathops, fttools, propagation   # noqa: F401
+from . import conf, mathops, fttools, propagation, otf, convolution   # noqa: F401
 from .conf import config   # noqa: F401
 from .propagation import Wavefront   # noqa: F401
 

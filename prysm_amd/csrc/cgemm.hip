@@ -56,38 +56,76 @@ struct MfmaTraits<double> {
     static __device__ __forceinline__ int op_k(int lane) { return lane >> 4; }
 };
 
-// logical element (r, k) of op(X) where X is stored with leading dimension ld
-//   op 0: X[r][k]   op 1: conj X[r][k]   op 2: X[k][r]   op 3: conj X[k][r]
-template <typename T>
-__device__ __forceinline__ cx<T> fetch(const cx<T>* X, int64_t ld, int op, int64_t r, int64_t k, int64_t R, int64_t K) {
-    cx<T> v = {T(0), T(0)};
-    if (r < R && k < K) {
-        v = (op & 2) ? X[k * ld + r] : X[r * ld + k];
-        if (op & 1) v.y = -v.y;
+// Staging of one operand tile (ROWS x BK complex elements, 256 threads, E = ROWS*BK/256 per thread).
+// KFAST: the k index is contiguous in memory (A stored M x K, or B stored N x K) -> lanes run along k.
+// Loads are UNCONDITIONAL (out-of-range coordinates are clamped to element 0 and zeroed by a select after the
+// load): bounds-checked branches made the compiler wait for every load separately (vmcnt(0) x 8 per K-tile,
+// i.e. the kernel ran at L2 latency); now the loads of a K-tile issue back to back and are first waited for
+// when they are written to LDS, after the MFMAs of the current tile.
+template <typename T, int ROWS, int BK, bool KFAST>
+struct Stager {
+    static constexpr int E = ROWS * BK / 256;
+    const cx<T>* p[E];      // address of this thread's element of the current K-tile
+    bool rok[E];            // row (m or n index) in range
+    int kk[E], rr[E];       // coordinates inside the tile
+    int64_t kstep;          // pointer advance per K-tile
+    __device__ __forceinline__ void init(const cx<T>* X, int64_t ld, int64_t r0, int64_t R, int64_t k0, int tid) {
+#pragma unroll
+        for (int s = 0; s < E; ++s) {
+            const int e = tid + s * 256;
+            kk[s] = KFAST ? e % BK : e / ROWS;
+            rr[s] = KFAST ? e / BK : e % ROWS;
+            const int64_t r = r0 + rr[s];
+            rok[s] = r < R;
+            const int64_t rc = rok[s] ? r : 0;
+            p[s] = KFAST ? X + rc * ld + (k0 + kk[s]) : X + (k0 + kk[s]) * ld + rc;
+        }
+        kstep = KFAST ? BK : int64_t(BK) * ld;
     }
-    return v;
-}
+    // k0: first k of the tile being fetched; kend: one past the last valid k; X: base (for clamping)
+    // issue the loads only; `ok` remembers which of them were real.  The zeroing / conjugation happens in
+    // finish(), called when the registers are written to LDS AFTER the MFMAs of the current tile, so the first
+    // use of the loaded data (and the vmcnt wait the compiler puts in front of it) sits behind the matrix work.
+    __device__ __forceinline__ void fetch(cx<T> (&reg)[E], unsigned& okmask, const cx<T>* X, int64_t k0, int64_t kend) {
+        okmask = 0;
+#pragma unroll
+        for (int s = 0; s < E; ++s) {
+            const bool ok = rok[s] && (k0 + kk[s] < kend);
+            okmask |= ok ? (1u << s) : 0u;
+            reg[s] = *(ok ? p[s] : X);
+            p[s] += kstep;
+        }
+    }
+    __device__ __forceinline__ cx<T> finish(const cx<T> (&reg)[E], unsigned okmask, int s, T conj_sign) const {
+        const bool ok = (okmask >> s) & 1u;
+        return {ok ? reg[s].x : T(0), ok ? reg[s].y * conj_sign : T(0)};
+    }
+};
 
-template <typename T, int BM, int BN, int BK>
-__global__ void __launch_bounds__(256) cgemm_kernel(int opA, int opB, int64_t M, int64_t N, int64_t K, int64_t ksplit,
-                                                    T alpha, const cx<T>* __restrict__ A, int64_t lda,
-                                                    const cx<T>* __restrict__ B, int64_t ldb, cx<T>* __restrict__ C,
-                                                    int64_t ldc, int64_t slab_stride) {
+template <typename T, int BM, int BN, int BK, bool AKF, bool BKF>
+__global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int64_t M, int64_t N, int64_t K, int64_t ksplit,
+                                                       T alpha, const cx<T>* __restrict__ A, int64_t lda,
+                                                       const cx<T>* __restrict__ B, int64_t ldb, cx<T>* __restrict__ C,
+                                                       int64_t ldc, int64_t slab_stride) {
     using MT = MfmaTraits<T>;
     constexpr int TM = MT::TM, KS = MT::KS, NR = MT::NR;
     constexpr int WM = BM / 2, WN = BN / 2;      // 2 x 2 waves
     constexpr int TI = WM / TM, TJ = WN / TM;    // MFMA tiles per wave
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
-    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;   // complex elements staged per thread per K-tile
-    static_assert(EA >= 1 && EB >= 1, "tile too small for 256 threads");
+    using SA = Stager<T, BM, BK, AKF>;
+    using SB = Stager<T, BN, BK, BKF>;
 
-    __shared__ T As_r[2][BK][LDA_S], As_i[2][BK][LDA_S], Bs_r[2][BK][LDB_S], Bs_i[2][BK][LDB_S];
+    // LDS holds the operand tiles k-major and INTERLEAVED (re, im): one ds_read_b64 (b128 for fp64) per operand
+    // per k-step delivers both MFMA inputs of a lane; rows padded by one element so the k-fast staging writes
+    // of a 16-lane group fall on distinct banks.
+    __shared__ cx<T> As[2][BK][LDA_S], Bs[2][BK][LDB_S];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int64_t m0 = int64_t(blockIdx.y) * BM, n0 = int64_t(blockIdx.x) * BN;
     const int64_t kbeg = int64_t(blockIdx.z) * ksplit;
     const int64_t kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
+    const T sa = conjA ? T(-1) : T(1), sb = conjB ? T(-1) : T(1);
 
     typename MT::acc_t acc_r[TI][TJ], acc_i[TI][TJ];
 #pragma unroll
@@ -100,82 +138,49 @@ __global__ void __launch_bounds__(256) cgemm_kernel(int opA, int opB, int64_t M,
                 acc_i[i][j][r] = T(0);
             }
 
-    // staging map: the memory-contiguous index varies fastest across lanes
-    const bool a_kfast = !(opA & 2), b_kfast = (opB & 2) != 0;
-    cx<T> ra[EA], rb[EB];
+    SA stA;
+    SB stB;
+    stA.init(A, lda, m0, M, kbeg, tid);
+    stB.init(B, ldb, n0, N, kbeg, tid);
+    cx<T> ra[SA::E], rb[SB::E];
+    unsigned oka = 0, okb = 0;
 
-    auto g_load = [&](int64_t k0) {
-#pragma unroll
-        for (int s = 0; s < EA; ++s) {
-            const int e = tid + s * 256;
-            const int kk = a_kfast ? e % BK : e / BM, ii = a_kfast ? e / BK : e % BM;
-            ra[s] = fetch(A, lda, opA, m0 + ii, k0 + kk, M, kend);
-        }
-#pragma unroll
-        for (int s = 0; s < EB; ++s) {
-            const int e = tid + s * 256;
-            const int kk = b_kfast ? e % BK : e / BN, jj = b_kfast ? e / BK : e % BN;
-            // op(B) logical (k, j): stored B[k][j] (op 0/1) or B[j][k] (op 2/3)
-            cx<T> v = {T(0), T(0)};
-            const int64_t k = k0 + kk, j = n0 + jj;
-            if (k < kend && j < N) {
-                v = (opB & 2) ? B[j * ldb + k] : B[k * ldb + j];
-                if (opB & 1) v.y = -v.y;
-            }
-            rb[s] = v;
-        }
-    };
     auto s_store = [&](int buf) {
 #pragma unroll
-        for (int s = 0; s < EA; ++s) {
-            const int e = tid + s * 256;
-            const int kk = a_kfast ? e % BK : e / BM, ii = a_kfast ? e / BK : e % BM;
-            As_r[buf][kk][ii] = ra[s].x;
-            As_i[buf][kk][ii] = ra[s].y;
-        }
+        for (int s = 0; s < SA::E; ++s) As[buf][stA.kk[s]][stA.rr[s]] = stA.finish(ra, oka, s, sa);
 #pragma unroll
-        for (int s = 0; s < EB; ++s) {
-            const int e = tid + s * 256;
-            const int kk = b_kfast ? e % BK : e / BN, jj = b_kfast ? e / BK : e % BN;
-            Bs_r[buf][kk][jj] = rb[s].x;
-            Bs_i[buf][kk][jj] = rb[s].y;
-        }
+        for (int s = 0; s < SB::E; ++s) Bs[buf][stB.kk[s]][stB.rr[s]] = stB.finish(rb, okb, s, sb);
     };
 
     int buf = 0;
     if (kbeg < kend) {
-        g_load(kbeg);
+        stA.fetch(ra, oka, A, kbeg, kend);
+        stB.fetch(rb, okb, B, kbeg, kend);
         s_store(0);
     }
     __syncthreads();
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
-        if (more) g_load(k0 + BK);   // prefetch the next K-tile into registers (in flight under the MFMAs)
+        if (more) {   // prefetch the next K-tile into registers: in flight under the MFMAs of this tile
+            stA.fetch(ra, oka, A, k0 + BK, kend);
+            stB.fetch(rb, okb, B, k0 + BK, kend);
+        }
 #pragma unroll
         for (int ks = 0; ks < BK; ks += KS) {
             const int kk = ks + MT::op_k(lane);
-            T ar[TI], ai[TI], nai[TI], br[TJ], bi[TJ];
+            cx<T> a[TI], b[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int row = wr * WM + i * TM + MT::op_row(lane);
-                ar[i] = As_r[buf][kk][row];
-                ai[i] = As_i[buf][kk][row];
-                nai[i] = -ai[i];
-            }
+            for (int i = 0; i < TI; ++i) a[i] = As[buf][kk][wr * WM + i * TM + MT::op_row(lane)];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int col = wc * WN + j * TM + MT::op_row(lane);
-                br[j] = Bs_r[buf][kk][col];
-                bi[j] = Bs_i[buf][kk][col];
-            }
+            for (int j = 0; j < TJ; ++j) b[j] = Bs[buf][kk][wc * WN + j * TM + MT::op_row(lane)];
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
-                    acc_r[i][j] = MT::mfma(ar[i], br[j], acc_r[i][j]);
-                    acc_i[i][j] = MT::mfma(ar[i], bi[j], acc_i[i][j]);
-                    acc_r[i][j] = MT::mfma(nai[i], bi[j], acc_r[i][j]);
-                    acc_i[i][j] = MT::mfma(ai[i], br[j], acc_i[i][j]);
+                    acc_r[i][j] = MT::mfma(a[i].x, b[j].x, acc_r[i][j]);
+                    acc_i[i][j] = MT::mfma(a[i].x, b[j].y, acc_i[i][j]);
+                    acc_r[i][j] = MT::mfma(-a[i].y, b[j].y, acc_r[i][j]);
+                    acc_i[i][j] = MT::mfma(a[i].y, b[j].x, acc_i[i][j]);
                 }
         }
         if (more) s_store(buf ^ 1);
@@ -217,7 +222,7 @@ size_t cgemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int* S_
     const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int S = 1;
     // aim for >= 2 workgroups per CU (512) while keeping >= 8 K-tiles per slab
-    while (tiles * S < 512 && (K / (S * 2)) >= 8 * BK && S < 32) S *= 2;
+    while (tiles * S < tuning().gemm_min_wgs && (K / (S * 2)) >= 4 * BK && S < 32) S *= 2;
     if (S_out) *S_out = S;
     if (S == 1) return 0;
     return size_t(S) * size_t(M) * size_t(N) * (dtype == PM_C64 ? 8 : 16);
@@ -236,14 +241,25 @@ int cgemm_ws(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, co
     S = int((K + ksplit - 1) / ksplit);
     if (S < 1) S = 1;
     dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)S);
+    // op 0/1: A stored M x K (k contiguous), B stored K x N (n contiguous); op 2/3: transposed storage
+    const bool akf = !(opA & 2), bkf = (opB & 2) != 0;
+    const int cA = opA & 1, cB = opB & 1;
+    auto launch = [&](T al, cx<T>* out, int64_t ldo, int64_t slab) {
+#define PM_GEMM(AK, BK_)                                                                                                     \
+    hipLaunchKernelGGL((cgemm_kernel<T, BM, BN, BK, AK, BK_>), grid, dim3(256), 0, st, cA, cB, M, N, K, ksplit, al, A, lda, B, \
+                       ldb, out, ldo, slab)
+        if (akf && bkf) PM_GEMM(true, true);
+        else if (akf) PM_GEMM(true, false);
+        else if (bkf) PM_GEMM(false, true);
+        else PM_GEMM(false, false);
+#undef PM_GEMM
+    };
     if (S == 1) {
-        hipLaunchKernelGGL((cgemm_kernel<T, BM, BN, BK>), grid, dim3(256), 0, st, opA, opB, M, N, K, ksplit, T(alpha), A, lda, B,
-                           ldb, C, ldc, int64_t(0));
+        launch(T(alpha), C, ldc, int64_t(0));
         return int(hipGetLastError());
     }
     cx<T>* slabs = reinterpret_cast<cx<T>*>(ws);
-    hipLaunchKernelGGL((cgemm_kernel<T, BM, BN, BK>), grid, dim3(256), 0, st, opA, opB, M, N, K, ksplit, T(1), A, lda, B, ldb,
-                       slabs, N, M * N);
+    launch(T(1), slabs, N, M * N);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return int(e);
     const int64_t total = M * N;

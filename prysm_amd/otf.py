@@ -1,0 +1,94 @@
+"""MTF / PTF / OTF from a PSF (prysm/otf.py) -- SURVEY 8(f) rank 1, a "next" row of the hot path.
+
+The forward transform fftshift(fft2(ifftshift(psf))) is the same fused pm_fft2 call as `focus`
+(unnormalised, shifts folded into the index maps).  The centre normalisation and abs / angle are
+elementwise device ops.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from . import _ops
+from ._richdata import RichData
+
+
+def _center(shape):
+    """Pixel index of the (floor) center of a 2D array (prysm/otf.py:11-13)."""
+    return tuple(int(math.floor(s / 2)) for s in shape)
+
+
+def _unwrap_psf(psf, dx):
+    """Resolve a PSF container-or-array to a bare array and its sample spacing (otf.py:16-25)."""
+    if isinstance(psf, RichData) or (hasattr(psf, 'data') and hasattr(psf, 'dx') and not isinstance(psf, torch.Tensor)):
+        if dx is None:
+            dx = psf.dx
+        psf = psf.data
+    if dx is None:
+        raise ValueError('dx is None: dx must be provided if psf is an array')
+    return psf, dx
+
+
+def transform_psf(psf, dx=None):
+    """Transform a PSF to k-space without further modification (otf.py:28-33)."""
+    psf, dx = _unwrap_psf(psf, dx)
+    x = L.as_complex(psf)
+    M, N = x.shape
+    shift = (M // 2, N // 2)
+    data = _ops.fft2(x, direction=-1, scale=1.0, in_shift=shift, out_shift=shift)
+    df = 1000 / (data.shape[0] * dx)  # cy/um to cy/mm
+    return data, df
+
+
+def transform_psf_adjoint(data_bar):
+    """Adjoint of transform_psf (otf.py:36-59): fftshift(ifft2(ifftshift(.), norm='forward'))."""
+    x = L.as_complex(data_bar)
+    M, N = x.shape
+    shift = (M // 2, N // 2)
+    return _ops.fft2(x, direction=+1, scale=1.0, in_shift=shift, out_shift=shift)
+
+
+def _normalized_transform(psf, dx):
+    """Forward-transform a PSF and divide by its central value (otf.py:62-74)."""
+    data, df = transform_psf(psf, dx)
+    cy, cx = _center(data.shape)
+    normalized = data / data[cy, cx]
+    return normalized, data, df
+
+
+def mtf_from_psf(psf, dx=None, return_more=False):
+    """Compute the MTF from a given PSF (otf.py:77-103)."""
+    normalized, data, df = _normalized_transform(psf, dx)
+    rd = RichData(data=torch.abs(normalized), dx=df, wavelength=None)
+    if return_more:
+        return rd, data
+    return rd
+
+
+def ptf_from_psf(psf, dx=None, return_more=False):
+    """Compute the PTF from a given PSF (otf.py:106-135)."""
+    normalized, data, df = _normalized_transform(psf, dx)
+    rd = RichData(data=torch.angle(normalized), dx=df, wavelength=None)
+    if return_more:
+        return rd, data
+    return rd
+
+
+def otf_from_psf(psf, dx=None, return_more=False):
+    """Compute the OTF from a given PSF (otf.py:138-164)."""
+    normalized, data, df = _normalized_transform(psf, dx)
+    rd = RichData(data=normalized, dx=df, wavelength=None)
+    if return_more:
+        return rd, data
+    return rd
+
+
+def mtf_ptf_otf_from_psf(psf, dx=None, return_more=False):
+    """MTF, PTF and OTF with a single forward transform (otf.py:167-203)."""
+    normalized, data, df = _normalized_transform(psf, dx)
+    mtf = RichData(data=torch.abs(normalized), dx=df, wavelength=None)
+    ptf = RichData(data=torch.angle(normalized), dx=df, wavelength=None)
+    otf = RichData(data=normalized, dx=df, wavelength=None)
+    if return_more:
+        return mtf, ptf, otf, data
+    return mtf, ptf, otf

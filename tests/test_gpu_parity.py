@@ -339,6 +339,28 @@ def test_airy_known_answer(pa):
         assert np.allclose(I[c, c:c + 40], airy[c, c:c + 40], atol=2e-3)
 
 
+def test_otf_and_convolution_golden(pa, golden):
+    """transform_psf / MTF / conv against the reference's outputs."""
+    g = golden('wavefront')
+    psf = g['cfg1_intensity']
+    data, df = pa.otf.transform_psf(psf, float(g['cfg1_psf_dx']))
+    assert rel_max(tonp(data), g['otf_transform']) < TOL64
+    assert df == 1000 / (psf.shape[0] * float(g['cfg1_psf_dx']))
+    mtf = pa.otf.mtf_from_psf(psf, float(g['cfg1_psf_dx']))
+    assert rel_max(tonp(mtf), g['otf_mtf']) < TOL64
+    mtf2, ptf2, otf2 = pa.otf.mtf_ptf_otf_from_psf(psf, float(g['cfg1_psf_dx']))
+    assert rel_max(tonp(mtf2), g['otf_mtf']) < TOL64
+    # adjoint dot-product test of the linear transform (reference tests/test_otf.py:56-100)
+    rng = np.random.default_rng(3)
+    y = crandn(rng, psf.shape)
+    lhs = np.vdot(tonp(data), y)
+    rhs = np.vdot(psf.astype(np.complex128), tonp(pa.otf.transform_psf_adjoint(y)))
+    np.testing.assert_allclose(lhs, rhs, rtol=1e-11)
+    out = pa.convolution.conv(g['conv_obj'], g['conv_psf'])
+    assert not out.is_complex()
+    assert rel_max(tonp(out), g['conv_out']) < TOL64
+
+
 def test_errors_match_reference(pa):
     P = pa.propagation
     z = np.ones((8, 8), dtype=np.complex128)

@@ -550,6 +550,31 @@ int main(int argc, char** argv) {
     HIPCHECK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s (%s) CUs=%d LDS/block=%zu version=%d\n", prop.name, prop.gcnArchName, prop.multiProcessorCount,
            prop.sharedMemPerBlock, pm_version());
+    if (mode == "gemm") {
+        for (int opA = 0; opA < 4; ++opA)
+            for (int opB = 0; opB < 4; ++opB) {
+                check_cgemm<float>(opA, opB, 70, 45, 100, 2e-5, false);
+                check_cgemm<double>(opA, opB, 33, 50, 37, 1e-13, false);
+            }
+        check_cgemm<float>(0, 0, 512, 2048, 2048, 5e-5, true);
+        check_cgemm<float>(0, 2, 512, 512, 2048, 5e-5, true);
+        check_cgemm<float>(3, 0, 2048, 512, 512, 5e-5, true);
+        check_cgemm<float>(0, 1, 2048, 2048, 512, 5e-5, true);
+        check_cgemm<double>(3, 1, 200, 300, 1000, 1e-12, true);
+        for (int wgs : {512, 768, 1024}) {
+            pm_set_tuning("gemm_min_wgs", wgs);
+            printf("gemm_min_wgs=%d\n", wgs);
+            bench_cgemm<float>(512, 2048, 2048, 0);
+            bench_cgemm<float>(512, 512, 2048, 2);
+            bench_cgemm<float>(2048, 512, 512, 0);
+            bench_cgemm<double>(512, 2048, 2048, 0);
+        }
+        pm_set_tuning("gemm_min_wgs", 1024);
+        bench_cgemm<float>(4096, 4096, 4096, 0);
+        bench_cgemm<double>(2048, 2048, 2048, 0);
+        printf(g_fail ? "GPU CHECK FAILED (%d)\n" : "GPU CHECK OK\n", g_fail);
+        return g_fail ? 1 : 0;
+    }
     if (mode == "calib") {
         calibrate();
         return 0;
