@@ -77,6 +77,25 @@ def kernel_pass_times(x, n, reps=20):
     return float(ms[0]), float(ms[1])
 
 
+def pmc_traffic(kernel, n, dtype_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of THIS command
+    (profiles/pmc_bench_summary.json: separate --pmc FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled per
+    the gfx950 correction in MI355X_MICROARCH.md).  Counters cannot be read from inside the process."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_bench_summary.json')
+    if not os.path.exists(path):
+        return None, None
+    try:
+        tab = json.load(open(path))
+    except Exception:
+        return None, None
+    want = f"fft_{kernel}"
+    real = 'float' if dtype_name == 'c64' else 'double'
+    for k, v in tab.items():
+        if k.startswith(want) and k.endswith(f'_{real}_N{n}'):
+            return v['hbm_traffic_bytes'], f'profiles/pmc_bench_summary.json:{k}'
+    return None, None
+
+
 def cpu_baseline(n, cdtype, budget_s):
     """The oracle (port of prysm.propagation.focus) on host cores; scipy.fft workers=1 as prysm ships."""
     from oracle import prysm_oracle as O
@@ -157,6 +176,7 @@ def main():
         alg_bytes_kernel = 2.0 * n * n * es           # one pass reads N^2 s and writes N^2 s
         achieved = alg_bytes_kernel / (dom_ms * 1e-3) / 1e9
         alg_bytes_step = 4.0 * n * n * es             # 4 N^2 s per propagation
+        traffic, traffic_src = pmc_traffic(dom, n, args.dtype)
         line = {
             'metric': 'pupil->focus FFT propagations per second (PSFs/s), 4096^2',
             'value': value, 'unit': 'propagations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -170,7 +190,8 @@ def main():
             'whole_step_frac_of_hbm_peak': alg_bytes_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'reduce_ms': reduce_ms,
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
+                         'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes_kernel,
                          'row_pass_ms': p1, 'column_pass_ms': p2,
                          'note': '2*N^2*s algorithmic bytes per pass / HIP-event duration of that pass, in sequence'},
         }

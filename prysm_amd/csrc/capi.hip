@@ -72,7 +72,7 @@ const cx<double>* twiddles_f64(int64_t n, int* err) { return table_get<double>(n
 static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     auto is = [&](const char* k) { return strlen(k) == klen && !strncmp(key, k, klen); };
     if (is("col_var")) t.col_var = v;
-    else if (is("log_k")) t.log_k = v < 0 ? 0 : (v > 3 ? 3 : v);
+    else if (is("log_k")) t.log_k = v > 3 ? 3 : v;   // < 0: auto
     else if (is("row_log_g")) t.row_log_g = v < 0 ? 0 : (v > 3 ? 3 : v);
     else if (is("row_var")) t.row_var = v;
     else if (is("gemm_min_wgs")) t.gemm_min_wgs = v < 1 ? 1 : v;
@@ -123,7 +123,7 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     const int64_t rows = d->in_y.len;   // only stored input rows are transformed in pass 1
     if (p.logn >= 0 && p.logm >= 0) {
         p.tc = col_tile_width_for(d->dtype, p.logm, tuning().col_var);
-        p.log_k = tuning().log_k;
+        p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 4096 ? 2 : 1);   // auto: 256 B pieces from 4096 columns
         while (p.log_k > 0 && (N % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
         const int64_t tl = int64_t(p.tc) << p.log_k;
         const int64_t ntl = (N + tl - 1) / tl;

@@ -291,6 +291,66 @@ struct LdsType<FftCfg<T, L, CI, E, BO, 2>> {
     using type = T;
 };
 
+// ---- per-workgroup LDS twiddle table (column pass, complex64) -----------------------------------------
+// Stage S needs NT(S) = 3 + R/4 - 1 table values per distinct (j mod Ns); Ns of them per stage.  For
+// N = 4096 that is (16 + 256) * 6 entries = 13 KiB, placed behind the exchange chunk.  Reading them with
+// ds_read (lgkmcnt) instead of global gathers (vmcnt, L2 latency) matters in the column pass, where one
+// workgroup per CU has nobody to hide a 1 us round trip behind, twice per tile.
+template <typename C, int S>
+struct TwLds {
+    static constexpr int R = C::radix(S), NS = C::ns(S);
+    static constexpr int NT = (S > 0 && R > 1) ? (R == 2 ? 1 : 3 + (R / 4 - 1)) : 0;
+    static constexpr int ENTRIES = (S > 0 && R > 1) ? NS * NT : 0;
+};
+template <typename C, int S = 1>
+constexpr int tw_lds_entries() {
+    if constexpr (S >= C::NSTAGE) return 0;
+    else return TwLds<C, S>::ENTRIES + tw_lds_entries<C, S + 1>();
+}
+template <typename C, int S = 1>
+constexpr int tw_lds_offset(int stage) {   // first entry of `stage` inside the table
+    if constexpr (S >= C::NSTAGE) return 0;
+    else return stage <= S ? 0 : TwLds<C, S>::ENTRIES + tw_lds_offset<C, S + 1>(stage);
+}
+
+// fill: entry (jm, slot) of stage S = W^(mult(slot) * jm * N/(Ns R)); mult = 1,2,3 then 4,8,12,...
+template <typename C, int S = 1>
+PM_HD void fill_tw_lds(cx<typename C::T>* tab, int tid, int nthreads, const cx<typename C::T>* __restrict__ tw) {
+    if constexpr (S < C::NSTAGE) {
+        using TL = TwLds<C, S>;
+        constexpr int R = TL::R, NS = TL::NS, NT = TL::NT;
+        constexpr int off = tw_lds_offset<C>(S);
+        for (int e = tid; e < TL::ENTRIES; e += nthreads) {
+            const int jm = e / NT, slot = e % NT;
+            const int mult = (R == 2) ? 1 : (slot < 3 ? slot + 1 : 4 * (slot - 2));
+            tab[off + e] = tw[mult * jm * (C::N / (NS * R))];
+        }
+        fill_tw_lds<C, S + 1>(tab, tid, nthreads, tw);
+    }
+}
+
+template <typename C, int S>
+PM_HD void load_stage_tw_lds(StageTw<C, S>& w, int t, const cx<typename C::T>* tab) {
+    using TL = TwLds<C, S>;
+    constexpr int R = TL::R, NS = TL::NS, NT = TL::NT, Q = C::P / R, NP = C::TPS;
+    constexpr int off = tw_lds_offset<C>(S);
+    if constexpr (S > 0 && R > 1) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int jm = (t + q * NP) & (NS - 1);
+            const cx<typename C::T>* e = tab + off + jm * NT;
+            if constexpr (R == 2) {
+                w.wb[q][1] = e[0];
+            } else {
+#pragma unroll
+                for (int b = 1; b < 4; ++b) w.wb[q][b] = e[b - 1];
+#pragma unroll
+                for (int a = 1; a < R / 4; ++a) w.wa[q][a] = e[2 + a];
+            }
+        }
+    }
+}
+
 // twiddles of every stage of a transform (stage 0 has none)
 template <typename C, int S = 1, bool END = (S >= C::NSTAGE)>
 struct TwSet {
@@ -336,6 +396,30 @@ __device__ __forceinline__ void fft_run_tw(cx<typename C::T> (&v)[C::E][C::P], T
             fft_run_tw<C, 1>(v, pos, lds_raw, ts);
         else
             fft_run_tw<C, S + 1>(v, pos, lds_raw, ts.rest);
+    }
+}
+
+// transform whose stage twiddles come from the workgroup's LDS table (filled by fill_tw_lds + barrier)
+template <typename C, int S = 0>
+__device__ __forceinline__ void fft_run_twlds(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw,
+                                              const cx<typename C::T>* tab) {
+    using LT = typename LdsType<C>::type;
+    LT* lds = reinterpret_cast<LT*>(lds_raw);
+    StageTw<C, S> w;
+    if constexpr (S > 0) load_stage_tw_lds<C, S>(w, pos.t, tab);
+    stage_compute<C, S>(v, w);
+    if constexpr (S + 1 < C::NSTAGE) {
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) {
+#pragma unroll
+            for (int comp = 0; comp < C::COMP; ++comp) {
+                exch_write<C, S>(v, e, comp, pos, lds);
+                __syncthreads();
+                exch_read<C>(v, e, comp, pos, lds);
+                __syncthreads();
+            }
+        }
+        fft_run_twlds<C, S + 1>(v, pos, lds_raw, tab);
     }
 }
 

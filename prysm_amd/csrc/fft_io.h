@@ -154,7 +154,8 @@ template <typename T> inline void nt_store_s(T* p, T v) { *p = v; }
 #endif
 
 // ------------------------------------------------------------------ row mode
-template <typename C, int ROT>
+// FULL: the window covers the whole axis and the sequence exists -> no per-element predicates at all
+template <typename C, int ROT, bool FULL = false>
 PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
                     cx<typename C::T> (&v)[C::E][C::P]) {
     using T = typename C::T;
@@ -167,7 +168,7 @@ PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
     for (int m = 0; m < C::P; ++m) {
         const int pp = slot_pos<C, ROT>(pos.t, m, p.ax.shift);
         cx<T> val = {T(0), T(0)};
-        if (pp >= lo && pp < hi) val = p.nt ? nt_load_cx(row + pp) : row[pp];
+        if (FULL || (pp >= lo && pp < hi)) val = p.nt ? nt_load_cx(row + pp) : row[pp];
         v[0][m] = val;
     }
     if (p.conj) {
@@ -179,12 +180,16 @@ PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
 template <typename C>
 PM_HD void load(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
     const int rot = rot_of<C>(p.ax.shift);
-    if (rot == 0)
-        load_rot<C, 0>(p, blk, pos, v);
-    else if (rot > 0)
-        load_rot<C, (C::P >= 2 ? C::P / 2 : 0)>(p, blk, pos, v);
-    else
+    const bool full = p.ax.off == 0 && p.ax.len == C::N && (blk * C::BO + pos.bo) < p.nseq;
+    if (rot == 0) {
+        if (full) load_rot<C, 0, true>(p, blk, pos, v);
+        else load_rot<C, 0>(p, blk, pos, v);
+    } else if (rot > 0) {
+        if (full) load_rot<C, (C::P >= 2 ? C::P / 2 : 0), true>(p, blk, pos, v);
+        else load_rot<C, (C::P >= 2 ? C::P / 2 : 0)>(p, blk, pos, v);
+    } else {
         load_rot<C, -1>(p, blk, pos, v);
+    }
 }
 
 template <typename C>
@@ -253,7 +258,7 @@ PM_HD int group_remap(int g, int total, int log_g) {
 }
 PM_HD int pair_remap(int g, int total) { return group_remap(g, total, 1); }
 
-template <typename C, int ROT>
+template <typename C, int ROT, bool FULL = false>
 PM_HD void load_rot(const ColLoadTiled<typename C::T>& p, int tile, ThreadPos pos,
                     cx<typename C::T> (&v)[C::E][C::P]) {
     using T = typename C::T;
@@ -268,7 +273,7 @@ PM_HD void load_rot(const ColLoadTiled<typename C::T>& p, int tile, ThreadPos po
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
         const int pp = slot_pos<C, ROT>(pos.t, m, p.ay.shift);
-        if (pp >= lo && pp < hi) {
+        if (FULL || (pp >= lo && pp < hi)) {
             const cx<T>* a = base + int64_t(pp) * TL;
             if constexpr (C::E == 2 && sizeof(T) == 4) {
                 const Vec4<T> w = *reinterpret_cast<const Vec4<T>*>(a);  // two adjacent complex64 columns
@@ -289,12 +294,16 @@ template <typename C>
 PM_HD void load(const ColLoadTiled<typename C::T>& p, int tile, ThreadPos pos,
                 cx<typename C::T> (&v)[C::E][C::P]) {
     const int rot = rot_of<C>(p.ay.shift);
-    if (rot == 0)
-        load_rot<C, 0>(p, tile, pos, v);
-    else if (rot > 0)
-        load_rot<C, (C::P >= 2 ? C::P / 2 : 0)>(p, tile, pos, v);
-    else
+    const bool full = p.ay.off == 0 && p.ay.len == C::N && tile < p.ntiles;
+    if (rot == 0) {
+        if (full) load_rot<C, 0, true>(p, tile, pos, v);
+        else load_rot<C, 0>(p, tile, pos, v);
+    } else if (rot > 0) {
+        if (full) load_rot<C, (C::P >= 2 ? C::P / 2 : 0), true>(p, tile, pos, v);
+        else load_rot<C, (C::P >= 2 ? C::P / 2 : 0)>(p, tile, pos, v);
+    } else {
         load_rot<C, -1>(p, tile, pos, v);
+    }
 }
 
 template <typename C>
@@ -361,7 +370,7 @@ PM_HD void store_one(const ColStoreNat<T>& p, int k, int c, cx<T> x) {
 
 // fast path: no multiplier, full-width aligned columns (no crop along x, even rotation), complex or
 // |.|^2 output.  Row window handled by a compare; addresses affine in the slot index.
-template <typename C, int ROT>
+template <typename C, int ROT, bool FULL = false>
 PM_HD void store_fast(const ColStoreNat<typename C::T>& p, int tile, ThreadPos pos,
                       const cx<typename C::T> (&v)[C::E][C::P]) {
     using T = typename C::T;
@@ -376,7 +385,7 @@ PM_HD void store_fast(const ColStoreNat<typename C::T>& p, int tile, ThreadPos p
 #pragma unroll
         for (int m = 0; m < C::P; ++m) {
             const int pp = slot_pos<C, ROT>(pos.t, m, p.ay.shift);
-            if (pp < lo || pp >= hi) continue;
+            if (!FULL && (pp < lo || pp >= hi)) continue;
             cx<T>* a = base + int64_t(pp) * p.ld;
             cx<T> val[C::E];
 #pragma unroll
@@ -406,7 +415,7 @@ PM_HD void store_fast(const ColStoreNat<typename C::T>& p, int tile, ThreadPos p
 #pragma unroll
         for (int m = 0; m < C::P; ++m) {
             const int pp = slot_pos<C, ROT>(pos.t, m, p.ay.shift);
-            if (pp < lo || pp >= hi) continue;
+            if (!FULL && (pp < lo || pp >= hi)) continue;
             T* a = base + int64_t(pp) * p.ld;
 #pragma unroll
             for (int e = 0; e < C::E; ++e) {
@@ -432,10 +441,14 @@ PM_HD void store(const ColStoreNat<typename C::T>& p, int tile, ThreadPos pos,
     const bool fast = p.mul_kind == MUL_NONE && p.vec_ok && p.ax.off == 0 && p.ax.len == p.ax.n &&
                       (p.ax.n % TC) == 0 && (p.ax.shift % TC) == 0 && rot >= 0;
     if (fast) {
-        if (rot == 0)
-            store_fast<C, 0>(p, tile, pos, v);
-        else
-            store_fast<C, (C::P >= 2 ? C::P / 2 : 0)>(p, tile, pos, v);
+        const bool full = p.ay.off == 0 && p.ay.len == C::N;
+        if (rot == 0) {
+            if (full) store_fast<C, 0, true>(p, tile, pos, v);
+            else store_fast<C, 0>(p, tile, pos, v);
+        } else {
+            if (full) store_fast<C, (C::P >= 2 ? C::P / 2 : 0), true>(p, tile, pos, v);
+            else store_fast<C, (C::P >= 2 ? C::P / 2 : 0)>(p, tile, pos, v);
+        }
         return;
     }
     const int col0 = tile * TC + pos.cl * C::E;

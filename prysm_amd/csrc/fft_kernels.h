@@ -15,8 +15,9 @@ constexpr int kMaxLogN = 13;  // 8192: the largest length one workgroup holds on
 // Row pass: one sequence per N/16 threads, 256 threads per workgroup (512 at N = 8192); LDS is
 // 8.5 B per point (complex64) so 4 workgroups / CU stay resident at N = 4096.
 // VAR (tuning variant, PM_TUNE / pm_set_tuning): row pass VAR = 1 doubles the rows per workgroup (each
-// workgroup then writes whole 128 B lines of the tiled intermediate); column pass VAR = 1 halves the tile
-// width (two workgroups per CU instead of one: memory phases of one overlap compute phases of the other).
+// workgroup then writes whole 128 B lines of the tiled intermediate); column pass VAR = 1 takes the stage
+// twiddles from a per-workgroup LDS table instead of global gathers (measured 6 % slower at 4096^2: the
+// extra registers spill under the 128-VGPR cap of the 1024-thread workgroup; kept as an A/B knob).
 template <typename T, int LOGN, int VAR>
 struct RowCfgSel {
     static constexpr int N = 1 << LOGN, P = N >= 16 ? 16 : N, TPS = N / P;
@@ -33,14 +34,24 @@ template <typename T, int LOGN, int VAR>
 struct ColCfgSel {
     static constexpr int N = 1 << LOGN, P = N >= 16 ? 16 : N, TPS = N / P;
     static constexpr int E = sizeof(T) == 4 ? 2 : 1;
-    static constexpr int CI0 = LOGN <= 12 ? 4 : 2;
-    static constexpr int CI = (CI0 >> VAR) >= 1 ? (CI0 >> VAR) : 1;
+    static constexpr int CI = LOGN <= 12 ? 4 : 2;   // VAR = 1: stage twiddles from an LDS table (A/B knob; measured slower)
     static constexpr int BO = (CI * TPS >= 256) ? 1 : 256 / (CI * TPS);
     static constexpr int COMP = (sizeof(T) == 8 && LOGN >= 11) ? 2 : 1;
     using type = FftCfg<T, LOGN, CI, E, BO, COMP>;
 };
 
-template <typename C, bool COL, typename L, typename S>
+// stage twiddles from an LDS table: column pass, complex64, when the table fits behind the exchange chunk
+template <typename C, bool COL, int VAR = 0>
+constexpr bool use_tw_lds() {
+    return COL && VAR == 1 && sizeof(typename C::T) == 4 && C::NSTAGE > 1 &&
+           (C::LDS_BYTES + size_t(tw_lds_entries<C>()) * sizeof(cx<typename C::T>) <= 160 * 1024);
+}
+template <typename C, bool COL, int VAR = 0>
+constexpr size_t kernel_lds_bytes() {
+    return C::LDS_BYTES + (use_tw_lds<C, COL, VAR>() ? size_t(tw_lds_entries<C>()) * sizeof(cx<typename C::T>) : 0);
+}
+
+template <typename C, bool COL, int VAR, typename L, typename S>
 __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
                                                     const cx<typename C::T>* __restrict__ tw, const int log_g) {
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
@@ -48,8 +59,18 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
     int unit = group_remap(blockIdx.x, gridDim.x, log_g);
     if (COL) unit = unit * C::BO + pos.bo;
     cx<typename C::T> v[C::E][C::P];
-    load<C>(lp, unit, pos, v);
-    fft_run<C>(v, pos, pm_smem, tw);
+    if constexpr (use_tw_lds<C, COL, VAR>()) {
+        // table first (two gathers + two ds_write per thread), then the tile loads; the barrier that publishes
+        // the table is passed while the tile loads are still in flight
+        cx<typename C::T>* tab = reinterpret_cast<cx<typename C::T>*>(pm_smem + C::LDS_BYTES);
+        fill_tw_lds<C>(tab, threadIdx.x, C::NT, tw);
+        load<C>(lp, unit, pos, v);
+        __syncthreads();
+        fft_run_twlds<C>(v, pos, pm_smem, tab);
+    } else {
+        load<C>(lp, unit, pos, v);
+        fft_run<C>(v, pos, pm_smem, tw);
+    }
     store<C>(sp, unit, pos, v);
 }
 
@@ -79,6 +100,10 @@ __global__ void __launch_bounds__(C::NT, (C::NT <= 256 ? 4 : 2)) fft_row_persist
         load_tw_set<C>(ts, p.t, tw);
         const int u1 = u + stride;
         if (u1 < nunits) load<C>(lp, group_remap(u1, nunits, log_g), p, vb);
+        // pin the issue point: with predicate-free (full-window) loads nothing else stops the machine
+        // scheduler from sinking the prefetch next to its first use to save registers, which would serialise
+        // the row pipeline again
+        __builtin_amdgcn_sched_barrier(0);
         fft_run_tw<C>(va, p, pm_smem, ts);
         store<C>(sp, group_remap(u, nunits, log_g), p, va);
         // rotate the register sets (32 moves); the wait for the prefetched loads lands here, after the
@@ -95,10 +120,11 @@ template <typename T, bool COL, int LOGN, int VAR, typename L, typename S>
 int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st) {
     using Sel = typename std::conditional<COL, ColCfgSel<T, LOGN, VAR>, RowCfgSel<T, LOGN, VAR>>::type;
     using C = typename Sel::type;
-    auto kern = fft_kernel<C, COL, L, S>;
-    if (C::LDS_BYTES > 48 * 1024) {
+    auto kern = fft_kernel<C, COL, (COL ? VAR : 0), L, S>;
+    constexpr size_t LDSB = kernel_lds_bytes<C, COL, (COL ? VAR : 0)>();
+    if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(C::LDS_BYTES));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
         if (e != hipSuccess) return int(e);
     }
     const int grid = (units + C::BO - 1) / C::BO;
@@ -119,7 +145,7 @@ int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, 
         hipLaunchKernelGGL(pk, dim3(pgrid), dim3(C::NT), C::LDS_BYTES, st, lp, sp, tw, grid, log_g);
         return int(hipGetLastError());
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, lp, sp, tw, log_g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
     return int(hipGetLastError());
 }
 

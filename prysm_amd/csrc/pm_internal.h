@@ -42,8 +42,8 @@ template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled
 template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
 // tile width of the column pass; MUST match ColCfgSel in fft_kernels.h (CI * E)
 inline int col_tile_width_for(int dtype, int logm, int var) {
-    int ci = logm <= 12 ? 4 : 2;
-    if (var == 1 && logm >= 11) ci = ci >> 1 ? ci >> 1 : 1;
+    (void)var;
+    const int ci = logm <= 12 ? 4 : 2;
     return ci * (dtype == PM_C64 ? 2 : 1);
 }
 
@@ -55,17 +55,18 @@ struct Tuning {
     // Infinity Cache: measured on MI355X, streaming hints pay once the arrays no longer fit beside the
     // intermediate -- input from ~128 MiB, output from ~256 MiB; they cost a few % below that)
     int nt_in = -1, nt_out = -1;
-    int log_k = 2;      // layout tiles of the intermediate are 2^log_k column-pass tiles wide (256 B rows)
+    int log_k = -1;     // layout tiles of the intermediate are 2^log_k column-pass tiles wide; -1 auto
     int gemm_min_wgs = 1024;   // split K until the GEMM launch has at least this many workgroups
     int row_log_g = 1;  // sibling group of row-pass workgroups (rows q .. q+2^g-1 on one XCD)
 };
 Tuning& tuning();
-// measured on MI355X (profiles/r01): the persistent kernel wins for complex64 rows of >= 4096 points (+11 % on
-// the whole 4096^2 transform), the half-LDS variant for 2048-point rows; complex128 >= 4096 already exchanges halves
+// measured on MI355X (profiles/r01/sweep*.log): with predicate-free full-window loads the plain row kernel is
+// the fastest at 4096 points (58 us vs 65-70 us persistent); the half-LDS variant wins for 2048-point rows
+// (complex128: 24.6 vs 30.5 us).  The persistent double-buffered kernel stays available as row_var = 2.
 inline int row_variant(int dtype, int logn) {
     const int v = tuning().row_var;
     if (v >= 0) return v;
-    if (dtype == PM_C64) return logn >= 12 ? 2 : (logn == 11 ? 1 : 0);
+    (void)dtype;
     return logn == 11 ? 1 : 0;
 }
 

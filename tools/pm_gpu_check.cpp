@@ -500,7 +500,7 @@ static void sweep_fft2(int64_t n, const std::vector<Knobs>& cfgs, int rounds) {
                sizeof(T) == 4 ? "c64" : "c128", (long long)n, k.row_var, k.col_var, k.nt_in, k.nt_out, k.log_k, k.row_log_g, mn, med,
                alg / mn / 1e6 / 8000 * 100, p1[c], p2[c]);
     }
-    apply(Knobs{-1, 0, -1, -1, 2, 1});
+    apply(Knobs{-1, 0, -1, -1, -1, 1});
     HIPCHECK(hipFree(din));
     HIPCHECK(hipFree(dout));
     HIPCHECK(hipFree(ws));
@@ -588,14 +588,14 @@ int main(int argc, char** argv) {
     }
     if (mode == "sweep") {
         const std::vector<Knobs> c64 = {
-            {0, 0, -1, -1, 2, 1}, {1, 0, -1, -1, 2, 1}, {2, 0, -1, -1, 2, 1}, {2, 0, 0, 0, 2, 1}, {2, 0, -1, -1, 1, 1}, {2, 0, -1, -1, 2, 0},
+            {2, 0, -1, -1, -1, 1}, {0, 0, -1, -1, -1, 1}, {1, 0, -1, -1, -1, 1},
         };
-        sweep_fft2<float>(4096, c64, 3);
+        sweep_fft2<float>(4096, c64, 4);
         const std::vector<Knobs> c128 = {
-            {0, 0, -1, -1, 2, 1}, {2, 0, -1, -1, 2, 1},
+            {-1, 0, -1, -1, -1, 1},
         };
-        sweep_fft2<double>(4096, c128, 3);
-        const std::vector<Knobs> small = {{0, 0, -1, -1, 2, 1}, {1, 0, -1, -1, 2, 1}, {2, 0, -1, -1, 2, 1}, {2, 0, -1, -1, 1, 1}};
+        sweep_fft2<double>(4096, c128, 2);
+        const std::vector<Knobs> small = {{0, 0, -1, -1, -1, 1}, {1, 0, -1, -1, -1, 1}, {2, 0, -1, -1, -1, 1}};
         sweep_fft2<float>(2048, small, 3);
         sweep_fft2<double>(2048, small, 3);
         return 0;
