@@ -148,7 +148,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        f = step()
+        f = None       # release the previous focal field first: the caching allocator then hands the same block
+        f = step()     # back, so the steady state touches in + workspace + out (not two alternating outputs)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     reduce_ms = 0.0

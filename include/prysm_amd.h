@@ -112,6 +112,17 @@ size_t pm_fft2_workspace(const pm_fft2_desc* d);
 int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes,
             void* stream);
 
+/* Fused  out = window( ifft2( fft2( pad(in) ) * H ) )  in THREE passes (row FFT, column FFT x H x column IFFT
+ * in registers, row IFFT): 6 N^2 s bytes of HBM traffic instead of the 8 N^2 s of two pm_fft2 calls.
+ * Replaces fft.ifft2(fft.fft2(field) * tf) of angular_spectrum / angular_spectrum_adjoint
+ * (prysm/propagation/angular_spectrum.py:35,41-42,76) and the fft2 * fft2 -> ifft2 core of convolution.conv
+ * (prysm/convolution.py:27-30).  Both transform lengths must be powers of two <= 8192 (PM_ERR_UNSUPPORTED
+ * otherwise: the caller composes two pm_fft2 calls).  Uses the fields of pm_fft2_desc: dtype, scale (applied
+ * once, at the end), in_* / out_* views, mul_* (required); direction / epilogue / weight are ignored. */
+size_t pm_fft2_mul_ifft2_workspace(const pm_fft2_desc* d);
+int pm_fft2_mul_ifft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
 /* Batched 1-D complex transform along one axis of a 2-D array, zero padded or
  * truncated to n on input (numpy `fft.fft(x, n, axis=)` semantics).
  * Replaces fft.fft / fft.ifft at prysm/fttools.py:301-321,335-355,387,519-533 (CZT, FFTDFT).

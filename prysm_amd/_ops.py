@@ -65,6 +65,54 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
     return out
 
 
+def _is_pow2_engine(n):
+    return 2 <= n <= 8192 and (n & (n - 1)) == 0
+
+
+def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_off=(0, 0), in_shift=(0, 0),
+                   out_shape=None, out_off=(0, 0), out_shift=(0, 0)):
+    """window(ifft2(fft2(pad(x)) * H)) * scale.
+
+    Power-of-two transform sizes run the fused three-pass kernel chain (pm_fft2_mul_ifft2: the multiply and
+    both column transforms happen in registers); other sizes compose two pm_fft2 calls.
+    """
+    lib = L.load()
+    m, n = x.shape
+    M, N = (m, n) if shape is None else shape
+    # the in-register forward/inverse column kernel pays up to 2048-point columns (see fft_kernels.h); beyond
+    # that, and for non power-of-two sizes, two fused transforms are faster
+    if not (_is_pow2_engine(M) and _is_pow2_engine(N) and M <= 2048):
+        F = fft2(x, direction=-1, scale=1.0, shape=shape, in_off=in_off, in_shift=in_shift, mul=mul, mul_x=mul_x,
+                 mul_conj=mul_conj)
+        return fft2(F, direction=+1, scale=scale, out_shape=out_shape, out_off=out_off, out_shift=out_shift)
+    om, on = (M, N) if out_shape is None else out_shape
+    d = L.pm_fft2_desc()
+    d.dtype = L.code(x)
+    d.direction = -1
+    d.scale = float(scale)
+    d.weight = 1.0
+    d.in_y = _axis(M, m, in_off[0], in_shift[0])
+    d.in_x = _axis(N, n, in_off[1], in_shift[1])
+    d.out_y = _axis(M, om, out_off[0], out_shift[0])
+    d.out_x = _axis(N, on, out_off[1], out_shift[1])
+    d.in_ld = x.stride(0) if m > 1 else n
+    if mul_x is not None:
+        d.mul_kind = L.PM_MUL_SEPARABLE
+        d.mul = mul.data_ptr()
+        d.mul_x = mul_x.data_ptr()
+    else:
+        d.mul_kind = L.PM_MUL_FULL
+        d.mul = mul.data_ptr()
+        d.mul_ld = mul.stride(0) if mul.shape[0] > 1 else mul.shape[1]
+    d.mul_conj = 1 if mul_conj else 0
+    out = torch.empty((om, on), dtype=x.dtype, device=x.device)
+    d.out_ld = out.stride(0) if om > 1 else on
+    nbytes = lib.pm_fft2_mul_ifft2_workspace(ctypes.byref(d))
+    ws = L.workspace(max(int(nbytes), 16))
+    L.check(lib.pm_fft2_mul_ifft2(ctypes.byref(d), L.ptr(x), L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()))
+    return out
+
+
 def fft1(x, n=None, axis=-1, direction=-1, scale=1.0, out_len=None, out_off=0, in_off=0):
     """Batched 1-D transform along `axis` of a 2-D tensor (pm_fft1).
 

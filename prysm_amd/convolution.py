@@ -20,6 +20,5 @@ def conv(obj, psf):
     M, N = o.shape
     shift = (M // 2, N // 2)
     H = _ops.fft2(h, direction=-1, scale=1.0, in_shift=shift)
-    OH = _ops.fft2(o, direction=-1, scale=1.0, in_shift=shift, mul=H)
-    i = _ops.fft2(OH, direction=+1, scale=1.0 / (M * N), out_shift=shift)
+    i = _ops.fft2_mul_ifft2(o, scale=1.0 / (M * N), mul=H, in_shift=shift, out_shift=shift)
     return i.real if real else i

@@ -186,7 +186,7 @@ static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, vo
                 RowStoreTiled<T> sp{W, rows, ltc};
                 rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, tuning().row_log_g, st);
             } else {
-                RowStoreNat<T> sp{W, N, AxisMap{int(N), int(N), 0, 0}, rows, 0, T(1)};
+                RowStoreNat<T> sp{W, N, AxisMap{int(N), int(N), 0, 0}, rows, 0, T(1), 0, AxisMap{1, 1, 0, 0}};
                 rc = launch_row_nat<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, 0, st);
             }
             if (rc) return rc;
@@ -221,6 +221,67 @@ static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, vo
     return direct_cols<T>(di, cs, tw, st);
 }
 
+// ---------------------------------------------------------------- fused fft2 -> multiply -> ifft2
+struct FusedPlan {
+    int logn, logm, tc, log_k;
+    size_t w1_bytes, w2_bytes;   // tiled buffers: stored input rows x N, and M x N (shared when rows == M)
+    bool inplace;
+};
+
+static bool plan_fused(const pm_fft2_desc* d, FusedPlan& p) {
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    p.logn = engine_log2(N);
+    p.logm = engine_log2(M);
+    if (p.logn < 0 || p.logm < 0) return false;
+    const size_t es = d->dtype == PM_C64 ? 8 : 16;
+    p.tc = col_tile_width_for(d->dtype, p.logm, 0);
+    p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 4096 ? 2 : 1);
+    while (p.log_k > 0 && (N % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
+    const int64_t tl = int64_t(p.tc) << p.log_k, ntl = (N + tl - 1) / tl;
+    p.inplace = d->in_y.len == M;
+    p.w1_bytes = size_t(ntl) * size_t(d->in_y.len > 0 ? d->in_y.len : 1) * size_t(tl) * es;
+    p.w2_bytes = p.inplace ? 0 : size_t(ntl) * size_t(M) * size_t(tl) * es;
+    return true;
+}
+
+template <typename T>
+static int fused_run(const pm_fft2_desc* d, const FusedPlan& p, const void* in, void* out, void* ws, hipStream_t st) {
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    const int rows = int(d->in_y.len);
+    int err = 0;
+    cx<T>* W1 = reinterpret_cast<cx<T>*>(ws);
+    cx<T>* W2 = p.inplace ? W1 : reinterpret_cast<cx<T>*>(reinterpret_cast<char*>(ws) + ((p.w1_bytes + 255) & ~size_t(255)));
+    const cx<T>* twN = twiddles<T>(N, &err);
+    if (!twN) return err;
+    const cx<T>* twM = twiddles<T>(M, &err);
+    if (!twM) return err;
+    const int tl = p.tc << p.log_k;
+    int ltl = 0;
+    while ((1 << ltl) < tl) ++ltl;
+    // pass A: forward row transforms of the stored input rows -> tiled W1
+    if (rows > 0) {
+        const size_t in_bytes = size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
+        const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
+        RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, 0, nt_in};
+        RowStoreTiled<T> sp{W1, rows, ltl};
+        int rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, twN, rows, tuning().row_log_g, st);
+        if (rc) return rc;
+    }
+    // pass B: column FFT, x H, column IFFT (unnormalised) -> tiled W2 (all M rows)
+    const int ntiles = int((N + p.tc - 1) / p.tc);
+    ColLoadTiled<T> cl{W1, rows, to_map(d->in_y), ntiles, p.log_k};
+    MidMul<T> mm{d->mul_kind, d->mul_conj, reinterpret_cast<const cx<T>*>(d->mul), reinterpret_cast<const cx<T>*>(d->mul_x),
+                 d->mul_ld, int(N)};
+    ColStoreTiled<T> cst{W2, int(M), ntiles, p.log_k};
+    int rc = launch_col_mul<T>(p.logm, cl, mm, cst, twM, ntiles, p.log_k > 1 ? p.log_k : 1, st);
+    if (rc) return rc;
+    // pass C: inverse row transforms of the rows inside the output window -> natural output, scale applied here.
+    // Sequence s is stored row s of W2 (= logical row s); the output row map rotates / crops it.
+    RowLoadTiled<T> rl{W2, int(M), ltl, 0, int(M), 1};
+    RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), int(M), 1, T(d->scale), 1, to_map(d->out_y)};
+    return launch_row_from_tiled<T>(p.logn, row_variant(d->dtype, p.logn), rl, rs, twN, int(M), st);
+}
+
 static int check_fft2(const pm_fft2_desc* d) {
     if (!d) return fail(PM_ERR_ARG, "pm_fft2: null descriptor");
     if (d->dtype != PM_C64 && d->dtype != PM_C128) return fail(PM_ERR_ARG, "pm_fft2: dtype must be PM_C64 or PM_C128");
@@ -252,7 +313,7 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
     const int conj = direction > 0 ? 1 : 0;
     int err = 0;
     if (axis == 1) {
-        RowStoreNat<T> sp{reinterpret_cast<cx<T>*>(out), out_ld, to_map(*to), int(batch), conj, T(scale)};
+        RowStoreNat<T> sp{reinterpret_cast<cx<T>*>(out), out_ld, to_map(*to), int(batch), conj, T(scale), 0, AxisMap{1, 1, 0, 0}};
         if (lg >= 0) {
             const cx<T>* tw = twiddles<T>(n, &err);
             if (!tw) return err;
@@ -336,6 +397,30 @@ int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, s
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == PM_C64) return fft2_run<float>(d, p, in, out, workspace, st);
     return fft2_run<double>(d, p, in, out, workspace, st);
+}
+
+size_t pm_fft2_mul_ifft2_workspace(const pm_fft2_desc* d) {
+    if (check_fft2(d)) return 0;
+    FusedPlan p;
+    if (!plan_fused(d, p)) return 0;
+    return ((p.w1_bytes + 255) & ~size_t(255)) + p.w2_bytes;
+}
+
+int pm_fft2_mul_ifft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_fft2(d);
+    if (rc) return rc;
+    if (!in || !out) return fail(PM_ERR_ARG, "pm_fft2_mul_ifft2: null buffer");
+    if (d->mul_kind == PM_MUL_NONE) return fail(PM_ERR_ARG, "pm_fft2_mul_ifft2: a multiplier is required");
+    FusedPlan p;
+    if (!plan_fused(d, p))
+        return fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: both lengths must be powers of two <= 8192 (got %lld x %lld); "
+                    "compose two pm_fft2 calls instead", (long long)d->in_y.n, (long long)d->in_x.n);
+    const size_t need = ((p.w1_bytes + 255) & ~size_t(255)) + p.w2_bytes;
+    if (!workspace || workspace_bytes < need)
+        return fail(PM_ERR_WORKSPACE, "pm_fft2_mul_ifft2: workspace of %zu bytes required, %zu given", need, workspace_bytes);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == PM_C64) return fused_run<float>(d, p, in, out, workspace, st);
+    return fused_run<double>(d, p, in, out, workspace, st);
 }
 
 int pm_fft2_time_passes(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes,

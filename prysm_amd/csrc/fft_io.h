@@ -52,6 +52,40 @@ struct RowStoreNat {
     int nseq;
     int conj;
     T scale;
+    int use_ay;     // 0: sequence s is written to memory row s; 1: to row ay.map(s) (rotation / crop of rows)
+    AxisMap ay;
+};
+
+// row pass reading the tiled intermediate (third pass of the fused fft2 -> multiply -> ifft2)
+template <typename T>
+struct RowLoadTiled {
+    const cx<T>* src;
+    int nrows;      // rows stored in the tiled buffer
+    int log_tl;     // log2(layout tile width)
+    int row0;       // first stored row to transform (sequence s reads stored row row0 + s)
+    int nseq;
+    int conj;
+};
+
+// column pass writing back into the tiled layout (second pass of the fused operation)
+template <typename T>
+struct ColStoreTiled {
+    cx<T>* dst;
+    int nrows;      // rows of the destination (the full transform length)
+    int ntiles;
+    int log_k;
+};
+
+// spectral multiplier applied between the forward and inverse column transforms, indexed by the
+// unshifted bin (row k, column c)
+template <typename T>
+struct MidMul {
+    int kind;       // MUL_FULL / MUL_SEPARABLE
+    int conj;
+    const cx<T>* mul;     // FULL: mul[k*ld + c]; SEPARABLE: hy[k]
+    const cx<T>* mul_x;   // SEPARABLE: hx[c]
+    int64_t ld;
+    int ncols;
 };
 
 template <typename T>
@@ -221,7 +255,12 @@ PM_HD void store_rot(const RowStoreNat<typename C::T>& p, int blk, ThreadPos pos
     using T = typename C::T;
     const int seq = blk * C::BO + pos.bo;
     if (seq >= p.nseq) return;
-    cx<T>* row = p.dst + int64_t(seq) * p.ld - p.ax.off;
+    int mrow = seq;
+    if (p.use_ay) {
+        mrow = p.ay.map(seq);
+        if (mrow < 0) return;
+    }
+    cx<T>* row = p.dst + int64_t(mrow) * p.ld - p.ax.off;
     const int lo = p.ax.off, hi = p.ax.off + p.ax.len;
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
@@ -243,6 +282,25 @@ PM_HD void store(const RowStoreNat<typename C::T>& p, int blk, ThreadPos pos,
         store_rot<C, (C::P >= 2 ? C::P / 2 : 0)>(p, blk, pos, v);
     else
         store_rot<C, -1>(p, blk, pos, v);
+}
+
+template <typename C>
+PM_HD void load(const RowLoadTiled<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    static_assert(C::CI == 1 && C::E == 1, "row mode");
+    const int seq = blk * C::BO + pos.bo;
+    const bool ok = seq < p.nseq;
+    const int q = p.row0 + (ok ? seq : 0);
+    const int tlm = (1 << p.log_tl) - 1;
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const int c = pos.t + m * C::TPS;
+        const int64_t a = ((int64_t(c >> p.log_tl) * p.nrows + q) << p.log_tl) + (c & tlm);
+        cx<T> val = {T(0), T(0)};
+        if (ok) val = p.src[a];
+        if (p.conj) val.y = -val.y;
+        v[0][m] = val;
+    }
 }
 
 // ------------------------------------------------------------------ col mode
@@ -336,6 +394,58 @@ PM_HD void load(const ColLoadNat<typename C::T>& p, int tile, ThreadPos pos,
         if (p.conj) {
 #pragma unroll
             for (int e = 0; e < C::E; ++e) v[e][m].y = -v[e][m].y;
+        }
+    }
+}
+
+template <typename C>
+PM_HD void store(const ColStoreTiled<typename C::T>& p, int tile, ThreadPos pos,
+                 const cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    constexpr int TC = C::CI * C::E;
+    if (tile >= p.ntiles) return;
+    const int TL = TC << p.log_k;
+    const int tl = tile >> p.log_k, sub = tile & ((1 << p.log_k) - 1);
+    cx<T>* base = p.dst + int64_t(tl) * p.nrows * TL + sub * TC + pos.cl * C::E;
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        cx<T>* a = base + int64_t(pos.t + m * C::TPS) * TL;
+        if constexpr (C::E == 2 && sizeof(T) == 4) {
+            *reinterpret_cast<Vec4<T>*>(a) = Vec4<T>{v[0][m].x, v[0][m].y, v[1][m].x, v[1][m].y};
+        } else {
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) a[e] = v[e][m];
+        }
+    }
+}
+
+// v[e][m] *= H[k = t + m*TPS][col], then conjugate (the inverse transform that follows is conj(FFT(conj .)))
+template <typename C>
+PM_HD void mid_multiply_conj(const MidMul<typename C::T>& p, int tile, ThreadPos pos,
+                             cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    constexpr int TC = C::CI * C::E;
+    const int col0 = tile * TC + pos.cl * C::E;
+    cx<T> hx[C::E];
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) {
+        hx[e] = {T(1), T(0)};
+        if (p.kind == MUL_SEPARABLE && col0 + e < p.ncols) hx[e] = p.mul_x[col0 + e];
+    }
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const int k = pos.t + m * C::TPS;
+        cx<T> hy = {T(1), T(0)};
+        if (p.kind == MUL_SEPARABLE) hy = p.mul[k];
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) {
+            cx<T> h;
+            if (p.kind == MUL_FULL)
+                h = (col0 + e < p.ncols) ? p.mul[int64_t(k) * p.ld + col0 + e] : cx<T>{T(1), T(0)};
+            else
+                h = cmul(hy, hx[e]);
+            const cx<T> x = p.conj ? cmulc(v[e][m], h) : cmul(v[e][m], h);
+            v[e][m] = {x.x, -x.y};
         }
     }
 }

@@ -74,6 +74,68 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
     store<C>(sp, unit, pos, v);
 }
 
+// Fused spectral-multiply column pass: forward transform, multiply by H, inverse transform -- all on the
+// registers of the workgroup (the engine returns natural order, so the inverse starts where the forward ended);
+// reads the tiled intermediate of the row pass and writes a tiled buffer for the inverse row pass.  This is the
+// middle pass of ifft2(fft2(x) * H) in 3 passes / 6 N^2 s bytes instead of 4 passes / 8 N^2 s.
+// Measured (profiles/r01/fused_as.log): a win up to 2048-point columns (512-thread workgroups, 256-VGPR budget);
+// at 4096 points the two transforms in one 1024-thread kernel spill > 150 VGPRs under the 128-register cap and the
+// host side uses two fused pm_fft2 calls instead.
+template <typename C>
+__global__ void __launch_bounds__(C::NT) fft_col_mul_kernel(const ColLoadTiled<typename C::T> lp, const MidMul<typename C::T> mp,
+                                                            const ColStoreTiled<typename C::T> sp,
+                                                            const cx<typename C::T>* __restrict__ tw, const int log_g) {
+    extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+    const ThreadPos pos = thread_pos<C>(threadIdx.x);
+    const int unit = group_remap(blockIdx.x, gridDim.x, log_g) * C::BO + pos.bo;
+    cx<typename C::T> v[C::E][C::P];
+    load<C>(lp, unit, pos, v);
+    fft_run<C>(v, pos, pm_smem, tw);
+    mid_multiply_conj<C>(mp, unit, pos, v);
+    __syncthreads();   // LDS of the forward exchange is reused by the inverse
+    // opaque copy of the slot: otherwise the twiddles (and their products) of the first transform are CSE'd
+    // with the second and kept live across it -- hundreds of spilled registers at 1024 threads
+    ThreadPos pos2 = pos;
+    asm volatile("" : "+v"(pos2.t), "+v"(pos2.cl), "+v"(pos2.bo));
+    fft_run<C>(v, pos2, pm_smem, tw);
+#pragma unroll
+    for (int e = 0; e < C::E; ++e)
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) v[e][m].y = -v[e][m].y;
+    store<C>(sp, unit, pos, v);
+}
+
+template <typename T, int LOGN>
+int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const ColStoreTiled<T>& sp, const cx<T>* tw, int ntiles,
+                       int log_g, hipStream_t st) {
+    using C = typename ColCfgSel<T, LOGN, 0>::type;
+    auto kern = fft_col_mul_kernel<C>;
+    if (C::LDS_BYTES > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           int(C::LDS_BYTES));
+        if (e != hipSuccess) return int(e);
+    }
+    const int grid = (ntiles + C::BO - 1) / C::BO;
+    if (grid <= 0) return 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, lp, mp, sp, tw, log_g);
+    return int(hipGetLastError());
+}
+
+template <typename T>
+int launch_col_mul_impl(int logm, const ColLoadTiled<T>& lp, const MidMul<T>& mp, const ColStoreTiled<T>& sp, const cx<T>* tw,
+                        int ntiles, int log_g, hipStream_t st) {
+    switch (logm) {
+#define PM_CASE(k) \
+    case k:        \
+        return launch_col_mul_one<T, k>(lp, mp, sp, tw, ntiles, log_g, st);
+        PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
+        PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASE(11) PM_CASE(12) PM_CASE(13)
+#undef PM_CASE
+        default:
+            return -2;
+    }
+}
+
 // Persistent row pass: each workgroup walks units g, g + G, g + 2G, ... and keeps TWO register sets: the loads
 // of the next unit are issued before the current one is transformed and stay in flight under its three
 // radix-16 stages (the wave only waits for them at the top of the next half-iteration); stores are fire and
@@ -174,5 +236,7 @@ template <typename T> int launch_row_tiled(int logn, int var, const RowLoadNat<T
 template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t);
 template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
 template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
+template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
+template <typename T> int launch_row_from_tiled(int logn, int var, const RowLoadTiled<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t);
 
 }  // namespace pm

@@ -7,4 +7,7 @@ template <> int launch_row_tiled<float>(int logn, int var, const RowLoadNat<floa
 template <> int launch_row_nat<float>(int logn, int var, const RowLoadNat<float>& l, const RowStoreNat<float>& s, const cx<float>* tw, int nseq, int log_g, hipStream_t st) {
     return launch_fft<float, false>(logn, var, l, s, tw, nseq, log_g, st);
 }
+template <> int launch_row_from_tiled<float>(int logn, int var, const RowLoadTiled<float>& l, const RowStoreNat<float>& s, const cx<float>* tw, int nseq, hipStream_t st) {
+    return launch_fft<float, false>(logn, var == 2 ? 0 : var, l, s, tw, nseq, 0, st);
+}
 }  // namespace pm

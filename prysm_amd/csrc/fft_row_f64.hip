@@ -7,4 +7,7 @@ template <> int launch_row_tiled<double>(int logn, int var, const RowLoadNat<dou
 template <> int launch_row_nat<double>(int logn, int var, const RowLoadNat<double>& l, const RowStoreNat<double>& s, const cx<double>* tw, int nseq, int log_g, hipStream_t st) {
     return launch_fft<double, false>(logn, var, l, s, tw, nseq, log_g, st);
 }
+template <> int launch_row_from_tiled<double>(int logn, int var, const RowLoadTiled<double>& l, const RowStoreNat<double>& s, const cx<double>* tw, int nseq, hipStream_t st) {
+    return launch_fft<double, false>(logn, var == 2 ? 0 : var, l, s, tw, nseq, 0, st);
+}
 }  // namespace pm

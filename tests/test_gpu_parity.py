@@ -361,6 +361,31 @@ def test_otf_and_convolution_golden(pa, golden):
     assert rel_max(tonp(out), g['conv_out']) < TOL64
 
 
+def test_polychromatic_driver_single_gpu(pa):
+    """BASELINE config 5 recipe at a small size on one GPU (world size 1: no process group, no reduce);
+    the N > 1 sharding / reduce logic is covered on CPU by tests/test_distributed_cpu.py."""
+    from prysm_amd.polychromatic import polychromatic_psf
+    n = 128
+    x, y = O.make_xy_grid(n, diameter=10)
+    r, _ = O.cart_to_polar(x, y)
+    amp = O.circle(5, r)
+    opd = O.hopkins_w040(r / 5, 500.0)
+    dx = float(x[0, 1] - x[0, 0])
+    wvls = np.linspace(0.5, 0.7, 6)
+    wts = np.array([0.5, 1.0, 1.5, 1.5, 1.0, 0.5])
+    # variant M (the how-to): fixed focal grid, MDFT per wavelength
+    got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, focal_dx=0.55 * 10 / 4, samples=64, kind='mdft'))
+    comps = []
+    for w in wvls:
+        P = O.from_amp_and_phase(amp, opd, float(w))
+        comps.append(O.intensity(O.prepare_executor(dx, P.shape, 0.55 * 10 / 4, (64, 64), float(w), 100.0)(P)))
+    assert rel_max(got, O.sum_of_2d_modes(np.asarray(comps), wts)) < TOL64
+    # variant F (throughput): FFT focus per wavelength with the fused |.|^2 accumulate epilogue
+    got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2))
+    comps = [O.intensity(O.focus(O.from_amp_and_phase(amp, opd, float(w)), 2)) for w in wvls]
+    assert rel_max(got, O.sum_of_2d_modes(np.asarray(comps), wts)) < TOL64
+
+
 def test_errors_match_reference(pa):
     P = pa.propagation
     z = np.ones((8, 8), dtype=np.complex128)

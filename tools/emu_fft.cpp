@@ -91,7 +91,7 @@ static void test_row(int nseq, int in_len, int in_off, int in_shift, int out_shi
     for (auto& e : x) e = {T(nd(rng)), T(nd(rng))};
     auto tw = make_tw<T>(N);
     RowLoadNat<T> lp{x.data(), in_len, AxisMap{N, in_len, in_off, in_shift}, nseq, inverse ? 1 : 0, 0};
-    RowStoreNat<T> sp{y.data(), N, AxisMap{N, N, 0, out_shift}, nseq, inverse ? 1 : 0, T(1)};
+    RowStoreNat<T> sp{y.data(), N, AxisMap{N, N, 0, out_shift}, nseq, inverse ? 1 : 0, T(1), 0, AxisMap{1, 1, 0, 0}};
     const int nblk = (nseq + C::BO - 1) / C::BO;
     emu_kernel<C, false>(nblk, lp, sp, tw.data());
     const ld pi = acosl(-1.0L);
@@ -214,6 +214,112 @@ static void test_2d(int in_rows, int in_cols, bool shifts, int epilogue, bool in
     report(buf, err / nrm, sizeof(T) == 4 ? 3e-6 : 1e-13);
 }
 
+// --- fused fft2 -> x H -> ifft2 (3 passes), vs naive ---------------------------------------------------------
+template <typename T, int LOGM, int LOGN, int RBO, int CCI, int CE, int CBO, int CCOMP>
+static void test_fused(int in_rows, int in_cols, int out_rows, int out_cols, int log_k, bool separable, bool mconj, bool shifts) {
+    using RC = FftCfg<T, LOGN, 1, 1, RBO, 1>;
+    using CC = FftCfg<T, LOGM, CCI, CE, CBO, CCOMP>;
+    const int M = CC::N, N = RC::N, TC = CCI * CE, TL = TC << log_k;
+    int ltl = 0;
+    while ((1 << ltl) < TL) ++ltl;
+    std::mt19937 rng(LOGM * 19 + LOGN + log_k);
+    std::normal_distribution<double> nd;
+    std::vector<cx<T>> x(size_t(in_rows) * in_cols), H(size_t(M) * N), hy(M), hx(N);
+    for (auto& e : x) e = {T(nd(rng)), T(nd(rng))};
+    for (auto& e : H) e = {T(nd(rng)), T(nd(rng))};
+    for (auto& e : hy) e = {T(nd(rng)), T(nd(rng))};
+    for (auto& e : hx) e = {T(nd(rng)), T(nd(rng))};
+    const int offy = (M - in_rows + 1) / 2, offx = (N - in_cols + 1) / 2;
+    const int shy = shifts ? M / 2 : 0, shx = shifts ? N / 2 : 0;
+    const int coffy = (M - out_rows + 1) / 2, coffx = (N - out_cols + 1) / 2;
+    const int ntl = (N + TL - 1) / TL, ntiles = (N + TC - 1) / TC;
+    std::vector<cx<T>> W1(size_t(ntl) * in_rows * TL, cx<T>{T(1e30), T(1e30)}), W2(size_t(ntl) * M * TL, cx<T>{T(1e30), T(1e30)});
+    auto twN = make_tw<T>(N);
+    auto twM = make_tw<T>(M);
+    RowLoadNat<T> lp{x.data(), in_cols, AxisMap{N, in_cols, offx, shx}, in_rows, 0, 0};
+    RowStoreTiled<T> sp{W1.data(), in_rows, ltl};
+    emu_kernel<RC, false>((in_rows + RC::BO - 1) / RC::BO, lp, sp, twN.data());
+    // pass B
+    ColLoadTiled<T> cl{W1.data(), in_rows, AxisMap{M, in_rows, offy, shy}, ntiles, log_k};
+    MidMul<T> mm{separable ? MUL_SEPARABLE : MUL_FULL, mconj ? 1 : 0, separable ? hy.data() : H.data(), hx.data(), N, N};
+    ColStoreTiled<T> cst{W2.data(), M, ntiles, log_k};
+    {
+        std::vector<Regs<CC>> regs(CC::NT);
+        std::vector<typename LdsType<CC>::type> lds(CC::LDS_ELEMS + 1);
+        const int ngroups = (ntiles + CC::BO - 1) / CC::BO;
+        for (int g = 0; g < ngroups; ++g) {
+            for (int tid = 0; tid < CC::NT; ++tid) {
+                ThreadPos pos = thread_pos<CC>(tid);
+                load<CC>(cl, g * CC::BO + pos.bo, pos, regs[tid].v);
+            }
+            emu_stages<CC, 0>(regs, lds, twM.data());
+            for (int tid = 0; tid < CC::NT; ++tid) {
+                ThreadPos pos = thread_pos<CC>(tid);
+                mid_multiply_conj<CC>(mm, g * CC::BO + pos.bo, pos, regs[tid].v);
+            }
+            emu_stages<CC, 0>(regs, lds, twM.data());
+            for (int tid = 0; tid < CC::NT; ++tid) {
+                ThreadPos pos = thread_pos<CC>(tid);
+                for (int e = 0; e < CC::E; ++e)
+                    for (int m = 0; m < CC::P; ++m) regs[tid].v[e][m].y = -regs[tid].v[e][m].y;
+                store<CC>(cst, g * CC::BO + pos.bo, pos, regs[tid].v);
+            }
+        }
+    }
+    // pass C
+    std::vector<cx<T>> out(size_t(out_rows) * out_cols, cx<T>{T(-3), T(-3)});
+    RowLoadTiled<T> rl{W2.data(), M, ltl, 0, M, 1};
+    RowStoreNat<T> rs{out.data(), out_cols, AxisMap{N, out_cols, coffx, shx}, M, 1, T(1.0 / (double(M) * N)), 1,
+                      AxisMap{M, out_rows, coffy, shy}};
+    emu_kernel<RC, false>((M + RC::BO - 1) / RC::BO, rl, rs, twN.data());
+    // reference
+    const ld pi = acosl(-1.0L);
+    std::vector<cld> P(size_t(M) * N, cld(0, 0)), A(size_t(M) * N), B(size_t(M) * N);
+    for (int r = 0; r < M; ++r)
+        for (int c = 0; c < N; ++c) {
+            int qr = (r + shy) % M - offy, qc = (c + shx) % N - offx;
+            if (qr >= 0 && qr < in_rows && qc >= 0 && qc < in_cols)
+                P[size_t(r) * N + c] = cld(x[size_t(qr) * in_cols + qc].x, x[size_t(qr) * in_cols + qc].y);
+        }
+    auto dft2 = [&](std::vector<cld>& Z, ld sg) {
+        for (int r = 0; r < M; ++r)
+            for (int k = 0; k < N; ++k) {
+                cld acc(0, 0);
+                for (int n = 0; n < N; ++n) acc += Z[size_t(r) * N + n] * std::polar<ld>(1.0L, sg * pi * ld((int64_t(n) * k) % N) / N);
+                A[size_t(r) * N + k] = acc;
+            }
+        for (int c = 0; c < N; ++c)
+            for (int k = 0; k < M; ++k) {
+                cld acc(0, 0);
+                for (int n = 0; n < M; ++n) acc += A[size_t(n) * N + c] * std::polar<ld>(1.0L, sg * pi * ld((int64_t(n) * k) % M) / M);
+                B[size_t(k) * N + c] = acc;
+            }
+        Z = B;
+    };
+    dft2(P, -2);
+    for (int k = 0; k < M; ++k)
+        for (int c = 0; c < N; ++c) {
+            cld h = separable ? cld(hy[k].x, hy[k].y) * cld(hx[c].x, hx[c].y) : cld(H[size_t(k) * N + c].x, H[size_t(k) * N + c].y);
+            if (mconj) h = std::conj(h);
+            P[size_t(k) * N + c] *= h;
+        }
+    dft2(P, +2);
+    double err = 0, nrm = 0;
+    for (int r = 0; r < M; ++r)
+        for (int c = 0; c < N; ++c) {
+            int qy = (r + shy) % M - coffy, qx = (c + shx) % N - coffx;
+            if (qy < 0 || qy >= out_rows || qx < 0 || qx >= out_cols) continue;
+            cld ref = P[size_t(r) * N + c] / (ld(M) * N);
+            cx<T> got = out[size_t(qy) * out_cols + qx];
+            err = fmax(err, (double)std::abs(ref - cld(got.x, got.y)));
+            nrm = fmax(nrm, (double)std::abs(ref));
+        }
+    char buf[160];
+    snprintf(buf, sizeof buf, "fused %s %dx%d in=%dx%d out=%dx%d TL=%d sep=%d conj=%d sh=%d", sizeof(T) == 4 ? "c64" : "c128", M, N,
+             in_rows, in_cols, out_rows, out_cols, TL, (int)separable, (int)mconj, (int)shifts);
+    report(buf, err / nrm, sizeof(T) == 4 ? 5e-6 : 1e-13);
+}
+
 // --- LDS twiddle table of the column kernel == the global-table twiddles, every stage, every thread slot ----
 template <typename C, int S>
 static int cmp_tw_stage(const cx<typename C::T>* tab, const cx<typename C::T>* tw) {
@@ -283,6 +389,11 @@ int main() {
     test_2d<double, 6, 6, 64, 1, 4, 1, 16, 2>(64, 64, true, 0, false, 64, 64);
     test_2d<double, 5, 7, 32, 2, 4, 1, 32, 1>(20, 100, true, 0, true, 32, 128);
     test_2d<double, 8, 4, 256, 1, 2, 1, 8, 2>(256, 16, false, 1, false, 256, 16);
+    test_fused<float, 5, 6, 64, 4, 2, 32, 1>(32, 64, 32, 64, 1, true, false, false);
+    test_fused<float, 6, 5, 128, 4, 2, 16, 1>(40, 20, 64, 32, 2, false, false, false);   // padded input
+    test_fused<float, 5, 6, 64, 4, 2, 32, 1>(32, 64, 16, 32, 0, true, true, false);      // adjoint: conj(H) + crop
+    test_fused<double, 6, 6, 64, 4, 1, 16, 2>(64, 64, 64, 64, 2, true, false, true);      // with rotations (conv)
+    test_fused<double, 5, 7, 32, 4, 1, 32, 1>(20, 100, 32, 128, 1, false, true, false);
     printf(g_fail ? "EMU FAILED (%d)\n" : "EMU OK\n", g_fail);
     return g_fail ? 1 : 0;
 }

@@ -506,6 +506,89 @@ static void sweep_fft2(int64_t n, const std::vector<Knobs>& cfgs, int rounds) {
     HIPCHECK(hipFree(ws));
 }
 
+// fused fft2 -> x H -> ifft2 (separable H) against the two-call composition: same result, fewer passes
+template <typename T>
+static void check_bench_fused(int64_t n, int64_t in_n, bool timeit) {
+    pm_fft2_desc d;
+    memset(&d, 0, sizeof d);
+    d.dtype = sizeof(T) == 4 ? PM_C64 : PM_C128;
+    d.direction = -1;
+    d.scale = 1.0 / (double(n) * n);
+    d.weight = 1.0;
+    d.in_y = d.in_x = {n, in_n, (n - in_n + 1) / 2, 0};
+    d.out_y = d.out_x = {n, n, 0, 0};
+    d.in_ld = in_n;
+    d.out_ld = n;
+    d.mul_kind = PM_MUL_SEPARABLE;
+    const size_t es = 2 * sizeof(T);
+    std::vector<std::complex<T>> hx(size_t(in_n) * in_n);
+    std::mt19937 rng(n + 1);
+    std::normal_distribution<float> nd;
+    for (auto& e : hx) e = std::complex<T>(nd(rng), nd(rng));
+    void *din, *dout, *dout2, *dtmp, *ws, *hy, *hxv;
+    HIPCHECK(hipMalloc(&din, hx.size() * es));
+    HIPCHECK(hipMalloc(&dout, size_t(n) * n * es));
+    HIPCHECK(hipMalloc(&dout2, size_t(n) * n * es));
+    HIPCHECK(hipMalloc(&dtmp, size_t(n) * n * es));
+    HIPCHECK(hipMalloc(&hy, size_t(n) * es));
+    HIPCHECK(hipMalloc(&hxv, size_t(n) * es));
+    HIPCHECK(hipMemcpy(din, hx.data(), hx.size() * es, hipMemcpyHostToDevice));
+    pm_as_tf_vectors(d.dtype, n, n, 0.6328, 0.01, 10.0, hy, hxv, nullptr);
+    d.mul = hy;
+    d.mul_x = hxv;
+    const size_t wsb = std::max(pm_fft2_mul_ifft2_workspace(&d), size_t(n) * n * es);
+    HIPCHECK(hipMalloc(&ws, wsb));
+    int rc = pm_fft2_mul_ifft2(&d, din, dout, ws, wsb, nullptr);
+    // composition: forward with multiplier on the store, then inverse
+    pm_fft2_desc a = d, b = d;
+    a.scale = 1.0;
+    b.direction = +1;
+    b.mul_kind = PM_MUL_NONE;
+    b.in_y = b.in_x = {n, n, 0, 0};
+    b.in_ld = n;
+    int rc2 = pm_fft2(&a, din, dtmp, ws, wsb, nullptr);
+    int rc3 = pm_fft2(&b, dtmp, dout2, ws, wsb, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    std::vector<std::complex<T>> o1(size_t(n) * n), o2(size_t(n) * n);
+    HIPCHECK(hipMemcpy(o1.data(), dout, o1.size() * es, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(o2.data(), dout2, o2.size() * es, hipMemcpyDeviceToHost));
+    double err = 0, nrm = 0;
+    for (size_t i = 0; i < o1.size(); ++i) {
+        err = fmax(err, std::abs(std::complex<double>(o1[i]) - std::complex<double>(o2[i])));
+        nrm = fmax(nrm, std::abs(std::complex<double>(o2[i])));
+    }
+    char name[128];
+    snprintf(name, sizeof name, "fused fft2*H ifft2 %s N=%lld in=%lld rc=%d/%d/%d (vs two-call composition)", sizeof(T) == 4 ? "c64" : "c128",
+             (long long)n, (long long)in_n, rc, rc2, rc3);
+    report(name, (rc || rc2 || rc3) ? 1.0 : err / nrm, sizeof(T) == 4 ? 3e-6 : 1e-13);
+    if (timeit) {
+        hipEvent_t e0, e1;
+        HIPCHECK(hipEventCreate(&e0));
+        HIPCHECK(hipEventCreate(&e1));
+        float t3, t4;
+        for (int i = 0; i < 3; ++i) pm_fft2_mul_ifft2(&d, din, dout, ws, wsb, nullptr);
+        HIPCHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < 20; ++i) pm_fft2_mul_ifft2(&d, din, dout, ws, wsb, nullptr);
+        HIPCHECK(hipEventRecord(e1, nullptr));
+        HIPCHECK(hipEventSynchronize(e1));
+        HIPCHECK(hipEventElapsedTime(&t3, e0, e1));
+        HIPCHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < 20; ++i) {
+            pm_fft2(&a, din, dtmp, ws, wsb, nullptr);
+            pm_fft2(&b, dtmp, dout2, ws, wsb, nullptr);
+        }
+        HIPCHECK(hipEventRecord(e1, nullptr));
+        HIPCHECK(hipEventSynchronize(e1));
+        HIPCHECK(hipEventElapsedTime(&t4, e0, e1));
+        const double alg = 8.0 * double(n) * n * es;
+        printf("BENCH angular-spectrum step %s N=%lld in=%lld: fused 3-pass %.1f us (%.0f GB/s on 8N^2s = %.1f%% of 8 TB/s; %.0f GB/s on 6N^2s), "
+               "two-call 4-pass %.1f us (%.1f%%)\n",
+               sizeof(T) == 4 ? "c64" : "c128", (long long)n, (long long)in_n, t3 / 20 * 1e3, alg / (t3 / 20) / 1e6, alg / (t3 / 20) / 1e6 / 80,
+               0.75 * alg / (t3 / 20) / 1e6, t4 / 20 * 1e3, alg / (t4 / 20) / 1e6 / 80);
+    }
+    for (void* p : {din, dout, dout2, dtmp, ws, hy, hxv}) HIPCHECK(hipFree(p));
+}
+
 template <typename T>
 static void bench_cgemm(int64_t M, int64_t N, int64_t K, int opB) {
     const size_t es = 2 * sizeof(T);
@@ -550,6 +633,18 @@ int main(int argc, char** argv) {
     HIPCHECK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s (%s) CUs=%d LDS/block=%zu version=%d\n", prop.name, prop.gcnArchName, prop.multiProcessorCount,
            prop.sharedMemPerBlock, pm_version());
+    if (mode == "fused") {
+        check_bench_fused<float>(64, 64, false);
+        check_bench_fused<float>(256, 128, false);
+        check_bench_fused<double>(128, 100, false);
+        check_bench_fused<float>(2048, 2048, true);
+        check_bench_fused<float>(4096, 4096, true);
+        check_bench_fused<double>(2048, 2048, true);
+        check_bench_fused<double>(4096, 4096, true);
+        check_bench_fused<double>(4096, 2048, true);
+        printf(g_fail ? "GPU CHECK FAILED (%d)\n" : "GPU CHECK OK\n", g_fail);
+        return g_fail ? 1 : 0;
+    }
     if (mode == "gemm") {
         for (int opA = 0; opA < 4; ++opA)
             for (int opB = 0; opB < 4; ++opB) {
