@@ -79,9 +79,9 @@ def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_
     lib = L.load()
     m, n = x.shape
     M, N = (m, n) if shape is None else shape
-    # the in-register forward/inverse column kernel pays up to 2048-point columns (see fft_kernels.h); beyond
-    # that, and for non power-of-two sizes, two fused transforms are faster
-    if not (_is_pow2_engine(M) and _is_pow2_engine(N) and M <= 2048):
+    # non power-of-two sizes compose two fused transforms (measured, profiles/r01/fused_as.log: the 3-pass chain
+    # wins at every engine size, e.g. 4096^2 complex128 448 vs 473 us, 2048^2 complex64 55 vs 75 us)
+    if not (_is_pow2_engine(M) and _is_pow2_engine(N)):
         F = fft2(x, direction=-1, scale=1.0, shape=shape, in_off=in_off, in_shift=in_shift, mul=mul, mul_x=mul_x,
                  mul_conj=mul_conj)
         return fft2(F, direction=+1, scale=scale, out_shape=out_shape, out_off=out_off, out_shift=out_shift)

@@ -419,10 +419,12 @@ PM_HD void store(const ColStoreTiled<typename C::T>& p, int tile, ThreadPos pos,
     }
 }
 
-// v[e][m] *= H[k = t + m*TPS][col], then conjugate (the inverse transform that follows is conj(FFT(conj .)))
-template <typename C>
-PM_HD void mid_multiply_conj(const MidMul<typename C::T>& p, int tile, ThreadPos pos,
-                             cx<typename C::T> (&v)[C::E][C::P]) {
+// v[e][m] *= H[k = t + m*TPS][col], then conjugate (the inverse transform that follows is conj(FFT(conj .))).
+// The multiplier kind is resolved OUTSIDE the unrolled loops (template argument): a runtime test inside them made
+// the compiler issue the loads of both kinds for all 32 elements and spill.
+template <typename C, int KIND>
+PM_HD void mid_multiply_conj_kind(const MidMul<typename C::T>& p, int tile, ThreadPos pos,
+                                  cx<typename C::T> (&v)[C::E][C::P]) {
     using T = typename C::T;
     constexpr int TC = C::CI * C::E;
     const int col0 = tile * TC + pos.cl * C::E;
@@ -430,17 +432,17 @@ PM_HD void mid_multiply_conj(const MidMul<typename C::T>& p, int tile, ThreadPos
 #pragma unroll
     for (int e = 0; e < C::E; ++e) {
         hx[e] = {T(1), T(0)};
-        if (p.kind == MUL_SEPARABLE && col0 + e < p.ncols) hx[e] = p.mul_x[col0 + e];
+        if (KIND == MUL_SEPARABLE && col0 + e < p.ncols) hx[e] = p.mul_x[col0 + e];
     }
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
         const int k = pos.t + m * C::TPS;
         cx<T> hy = {T(1), T(0)};
-        if (p.kind == MUL_SEPARABLE) hy = p.mul[k];
+        if (KIND == MUL_SEPARABLE) hy = p.mul[k];
 #pragma unroll
         for (int e = 0; e < C::E; ++e) {
             cx<T> h;
-            if (p.kind == MUL_FULL)
+            if (KIND == MUL_FULL)
                 h = (col0 + e < p.ncols) ? p.mul[int64_t(k) * p.ld + col0 + e] : cx<T>{T(1), T(0)};
             else
                 h = cmul(hy, hx[e]);
@@ -448,6 +450,15 @@ PM_HD void mid_multiply_conj(const MidMul<typename C::T>& p, int tile, ThreadPos
             v[e][m] = {x.x, -x.y};
         }
     }
+}
+
+template <typename C>
+PM_HD void mid_multiply_conj(const MidMul<typename C::T>& p, int tile, ThreadPos pos,
+                             cx<typename C::T> (&v)[C::E][C::P]) {
+    if (p.kind == MUL_FULL)
+        mid_multiply_conj_kind<C, MUL_FULL>(p, tile, pos, v);
+    else
+        mid_multiply_conj_kind<C, MUL_SEPARABLE>(p, tile, pos, v);
 }
 
 // one output element (row bin k, column bin c) through the full epilogue -- shared by the

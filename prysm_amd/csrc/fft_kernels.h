@@ -78,9 +78,9 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
 // registers of the workgroup (the engine returns natural order, so the inverse starts where the forward ended);
 // reads the tiled intermediate of the row pass and writes a tiled buffer for the inverse row pass.  This is the
 // middle pass of ifft2(fft2(x) * H) in 3 passes / 6 N^2 s bytes instead of 4 passes / 8 N^2 s.
-// Measured (profiles/r01/fused_as.log): a win up to 2048-point columns (512-thread workgroups, 256-VGPR budget);
-// at 4096 points the two transforms in one 1024-thread kernel spill > 150 VGPRs under the 128-register cap and the
-// host side uses two fused pm_fft2 calls instead.
+// Measured (profiles/r01/fused_as.log): 4096^2 complex128 448 vs 473 us, complex64 210 vs 239 us, 2048^2 complex64
+// 55 vs 75 us against two pm_fft2 calls.  (Built without the SLP vectorizer -- with it this kernel spilled > 150
+// VGPRs under the 128-register cap of the 1024-thread workgroup and lost.)
 template <typename C>
 __global__ void __launch_bounds__(C::NT) fft_col_mul_kernel(const ColLoadTiled<typename C::T> lp, const MidMul<typename C::T> mp,
                                                             const ColStoreTiled<typename C::T> sp,

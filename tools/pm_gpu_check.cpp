@@ -683,14 +683,14 @@ int main(int argc, char** argv) {
     }
     if (mode == "sweep") {
         const std::vector<Knobs> c64 = {
-            {2, 0, -1, -1, -1, 1}, {0, 0, -1, -1, -1, 1}, {1, 0, -1, -1, -1, 1},
+            {0, 0, -1, -1, -1, 1}, {1, 0, -1, -1, -1, 1}, {2, 0, -1, -1, -1, 1},
         };
-        sweep_fft2<float>(4096, c64, 4);
+        sweep_fft2<float>(4096, c64, 3);
         const std::vector<Knobs> c128 = {
             {-1, 0, -1, -1, -1, 1},
         };
         sweep_fft2<double>(4096, c128, 2);
-        const std::vector<Knobs> small = {{0, 0, -1, -1, -1, 1}, {1, 0, -1, -1, -1, 1}, {2, 0, -1, -1, -1, 1}};
+        const std::vector<Knobs> small = {{0, 0, -1, -1, -1, 1}, {1, 0, -1, -1, -1, 1}};
         sweep_fft2<float>(2048, small, 3);
         sweep_fft2<double>(2048, small, 3);
         return 0;
