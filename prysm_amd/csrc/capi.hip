@@ -123,7 +123,7 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     const int64_t rows = d->in_y.len;   // only stored input rows are transformed in pass 1
     if (p.logn >= 0 && p.logm >= 0) {
         p.tc = col_tile_width_for(d->dtype, p.logm, tuning().col_var);
-        p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 4096 ? 2 : 1);   // auto: 256 B pieces from 4096 columns
+        p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 8192 ? 3 : (N >= 4096 ? 2 : 1));   // auto: >= 256 B pieces from 4096 columns
         while (p.log_k > 0 && (N % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
         const int64_t tl = int64_t(p.tc) << p.log_k;
         const int64_t ntl = (N + tl - 1) / tl;
@@ -158,7 +158,11 @@ static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out) {
         vec = (d->out_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     cs.vec_ok = vec ? 1 : 0;
     const size_t out_bytes = size_t(d->out_y.len) * size_t(d->out_x.len) * (d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T));
-    cs.nt = tuning().nt_out >= 0 ? tuning().nt_out : (out_bytes >= (size_t(192) << 20) ? 1 : 0);
+    // streaming stores only help when a workgroup writes whole 64 B pieces; on the 32 B pieces of 8192-point
+    // columns they defeat the L2 write combining of sibling workgroups (measured: 977 -> 428 us without)
+    const size_t piece = size_t(col_tile_width_for(d->dtype, engine_log2(d->out_y.n) >= 0 ? engine_log2(d->out_y.n) : 12, 0)) *
+                         (d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T));
+    cs.nt = tuning().nt_out >= 0 ? tuning().nt_out : ((out_bytes >= (size_t(192) << 20) && piece >= 64) ? 1 : 0);
     return cs;
 }
 
@@ -235,7 +239,7 @@ static bool plan_fused(const pm_fft2_desc* d, FusedPlan& p) {
     if (p.logn < 0 || p.logm < 0) return false;
     const size_t es = d->dtype == PM_C64 ? 8 : 16;
     p.tc = col_tile_width_for(d->dtype, p.logm, 0);
-    p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 4096 ? 2 : 1);
+    p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 8192 ? 3 : (N >= 4096 ? 2 : 1));
     while (p.log_k > 0 && (N % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
     const int64_t tl = int64_t(p.tc) << p.log_k, ntl = (N + tl - 1) / tl;
     p.inplace = d->in_y.len == M;

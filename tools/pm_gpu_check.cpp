@@ -633,6 +633,11 @@ int main(int argc, char** argv) {
     HIPCHECK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s (%s) CUs=%d LDS/block=%zu version=%d\n", prop.name, prop.gcnArchName, prop.multiProcessorCount,
            prop.sharedMemPerBlock, pm_version());
+    if (mode == "big") {
+        const std::vector<Knobs> cfg = {{-1, 0, -1, -1, -1, 1}, {-1, 0, -1, 0, -1, 1}, {-1, 0, 0, 0, -1, 1}, {-1, 0, -1, 0, 3, 1}, {-1, 0, -1, 0, 1, 1}};
+        sweep_fft2<float>(8192, cfg, 2);
+        return 0;
+    }
     if (mode == "fused") {
         check_bench_fused<float>(64, 64, false);
         check_bench_fused<float>(256, 128, false);
