@@ -199,7 +199,7 @@ def test_focus_vs_oracle(pa, n, Q, dtype):
     assert rel_max(I, O.intensity(ref)) < (2 * TOL32 if dtype == np.complex64 else TOL64)
 
 
-@pytest.mark.parametrize('shape', [(512, 2048), (2048, 512), (64, 4096), (300, 512), (512, 300)])
+@pytest.mark.parametrize('shape', [(512, 2048), (2048, 512), (64, 4096), (300, 512), (512, 300), (8192, 128), (64, 8192)])
 def test_rectangular_unfocus_vs_oracle(pa, shape):
     rng = np.random.default_rng(sum(shape))
     x = crandn(rng, shape)
