@@ -75,6 +75,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("log_k")) t.log_k = v > 3 ? 3 : v;   // < 0: auto
     else if (is("row_log_g")) t.row_log_g = v < 0 ? 0 : (v > 3 ? 3 : v);
     else if (is("row_var")) t.row_var = v;
+    else if (is("gemm_bk")) t.gemm_bk = v;
     else if (is("gemm_min_wgs")) t.gemm_min_wgs = v < 1 ? 1 : v;
     else if (is("nt_in")) t.nt_in = v;
     else if (is("nt_out")) t.nt_out = v;

@@ -118,7 +118,11 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
     // LDS holds the operand tiles k-major and INTERLEAVED (re, im): one ds_read_b64 (b128 for fp64) per operand
     // per k-step delivers both MFMA inputs of a lane; rows padded by one element so the k-fast staging writes
     // of a 16-lane group fall on distinct banks.
-    __shared__ cx<T> As[2][BK][LDA_S], Bs[2][BK][LDB_S];
+    extern __shared__ __attribute__((aligned(16))) char pm_gemm_smem[];
+    typedef cx<T> (*ATile)[BK][LDA_S];
+    typedef cx<T> (*BTile)[BK][LDB_S];
+    ATile As = reinterpret_cast<ATile>(pm_gemm_smem);
+    BTile Bs = reinterpret_cast<BTile>(pm_gemm_smem + sizeof(cx<T>) * 2 * BK * LDA_S);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -218,7 +222,7 @@ __global__ void splitk_reduce_kernel(int64_t M, int64_t N, int S, T alpha, const
 }
 
 size_t cgemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int* S_out) {
-    const int BM = 64, BN = 64, BK = 16;
+    const int BM = 64, BN = 64, BK = 32;   // slab depth multiple of the deepest K-tile
     const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int S = 1;
     // aim for >= 2 workgroups per CU (512) while keeping >= 8 K-tiles per slab
@@ -228,10 +232,10 @@ size_t cgemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int* S_
     return size_t(S) * size_t(M) * size_t(N) * (dtype == PM_C64 ? 8 : 16);
 }
 
-template <typename T>
-int cgemm_ws(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, const cx<T>* A, int64_t lda,
-             const cx<T>* B, int64_t ldb, cx<T>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
-    constexpr int BM = 64, BN = 64, BK = sizeof(T) == 4 ? 16 : 8;   // 33 KiB of LDS either way
+template <typename T, int BK>
+int cgemm_ws_bk(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, const cx<T>* A, int64_t lda,
+                const cx<T>* B, int64_t ldb, cx<T>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int BM = 64, BN = 64;
     int S = 1;
     const size_t need = cgemm_workspace_bytes(sizeof(T) == 4 ? PM_C64 : PM_C128, M, N, K, &S);
     if (S > 1 && (!ws || ws_bytes < need)) S = 1;   // no workspace: fall back to unsplit (still correct)
@@ -245,13 +249,23 @@ int cgemm_ws(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, co
     const bool akf = !(opA & 2), bkf = (opB & 2) != 0;
     const int cA = opA & 1, cB = opB & 1;
     auto launch = [&](T al, cx<T>* out, int64_t ldo, int64_t slab) {
-#define PM_GEMM(AK, BK_)                                                                                                     \
-    hipLaunchKernelGGL((cgemm_kernel<T, BM, BN, BK, AK, BK_>), grid, dim3(256), 0, st, cA, cB, M, N, K, ksplit, al, A, lda, B, \
-                       ldb, out, ldo, slab)
-        if (akf && bkf) PM_GEMM(true, true);
-        else if (akf) PM_GEMM(true, false);
-        else if (bkf) PM_GEMM(false, true);
-        else PM_GEMM(false, false);
+        constexpr size_t LDSB = sizeof(cx<T>) * 2 * BK * ((BM + 1) + (BN + 1));
+#define PM_GEMM(AK, BK_)                                                                                                   \
+    {                                                                                                                      \
+        auto kern = cgemm_kernel<T, BM, BN, BK, AK, BK_>;                                                                  \
+        if (LDSB > 48 * 1024)                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB)); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDSB, st, cA, cB, M, N, K, ksplit, al, A, lda, B, ldb, out, ldo, slab);  \
+    }
+        if (akf && bkf) {
+            PM_GEMM(true, true)
+        } else if (akf) {
+            PM_GEMM(true, false)
+        } else if (bkf) {
+            PM_GEMM(false, true)
+        } else {
+            PM_GEMM(false, false)
+        }
 #undef PM_GEMM
     };
     if (S == 1) {
@@ -266,6 +280,20 @@ int cgemm_ws(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, co
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, S, T(alpha),
                        slabs, M * N, C, ldc);
     return int(hipGetLastError());
+}
+
+template <typename T>
+int cgemm_ws(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, const cx<T>* A, int64_t lda,
+             const cx<T>* B, int64_t ldb, cx<T>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    // K-tile depth: 16 (fp32) / 8 (fp64) = 33 KiB of LDS, 4 workgroups per CU; tuning gemm_bk = 32 / 16 doubles it
+    // (66.5 KiB, 2 per CU, half the barriers per flop)
+    const int bk = tuning().gemm_bk;
+    if (sizeof(T) == 4) {
+        if (bk == 32) return cgemm_ws_bk<T, 32>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
+        return cgemm_ws_bk<T, 16>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
+    }
+    if (bk == 32) return cgemm_ws_bk<T, 16>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
+    return cgemm_ws_bk<T, 8>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
 }
 
 }  // namespace pm

@@ -33,6 +33,14 @@ from .angular_spectrum import (
     fresnel_number,
     talbot_distance,
 )
+from .coronagraph import (
+    to_fpm_and_back,
+    to_fpm_and_back_adjoint,
+    to_fpm_and_back_multiresolution,
+    vortex_phase_mask,
+    babinet,
+    babinet_adjoint,
+)
 from .wavefront import Wavefront
 from ._kernels import phase_prefix
 
@@ -42,4 +50,6 @@ __all__ = [
     'prepare_executor', 'unit_cell_focal_grid', 'focus_dft', 'focus_dft_adjoint', 'unfocus_dft',
     'unfocus_dft_adjoint', 'focus_fixed_sampling', 'angular_spectrum', 'angular_spectrum_adjoint',
     'angular_spectrum_transfer_function', 'fresnel_number', 'talbot_distance', 'Wavefront', 'phase_prefix',
+    'to_fpm_and_back', 'to_fpm_and_back_adjoint', 'to_fpm_and_back_multiresolution', 'vortex_phase_mask',
+    'babinet', 'babinet_adjoint',
 ]

@@ -1,0 +1,135 @@
+"""Propagation through Lyot-family / vortex coronagraphs (prysm/propagation/coronagraph.py) -- SURVEY 8(f) rank 2.
+
+Pure compositions of the fixed-sampling executors (MFMA GEMM pairs), pointwise complex multiplies and sums:
+the workloads behind prysm's published speed figures.  Same signatures and return conventions as the reference.
+"""
+import numbers
+
+import torch
+
+from .. import _lib as L
+from .. import _ops
+from ._kernels import _adjoint_multiply
+from .dft import focus_dft, focus_dft_adjoint, unfocus_dft, unfocus_dft_adjoint
+
+
+def _mul(a, b):
+    """a * b with the complex x complex 2-D case on the HIP kernel, numpy-style promotion otherwise."""
+    if isinstance(b, numbers.Number):
+        return a * b
+    b = L.as_device(b)
+    if (a.is_complex() and b.is_complex() and a.dtype == b.dtype and a.dim() == 2 and a.shape == b.shape
+            and a.is_contiguous() and b.is_contiguous()):
+        return _ops.cmul(a, b)
+    return a * b
+
+
+def to_fpm_and_back(wavefunction, fpm, executor, return_more=False):
+    """Propagate to a focal plane mask, apply it, and return (coronagraph.py:12-43)."""
+    field_at_fpm = focus_dft(wavefunction, executor)
+    field_after_fpm = _mul(field_at_fpm, fpm)
+    field_at_next_pupil = unfocus_dft(field_after_fpm, executor)
+    if return_more:
+        return field_at_next_pupil, field_at_fpm, field_after_fpm
+    return field_at_next_pupil
+
+
+def to_fpm_and_back_adjoint(wavefunction, fpm, executor, return_more=False,
+                            return_fpm_grad=False, field_at_fpm=None):
+    """Apply the adjoint of to_fpm_and_back (coronagraph.py:46-94)."""
+    if return_fpm_grad and field_at_fpm is None:
+        raise ValueError('return_fpm_grad=True requires field_at_fpm from the forward propagation')
+    fpm_t = fpm if isinstance(fpm, numbers.Number) else L.as_device(fpm)
+    fpm_is_complex = isinstance(fpm_t, complex) or (isinstance(fpm_t, torch.Tensor) and fpm_t.is_complex())
+    Ebbar = unfocus_dft_adjoint(wavefunction, executor)
+    if isinstance(fpm_t, numbers.Number):
+        intermediate = Ebbar * (fpm_t.conjugate() if isinstance(fpm_t, complex) else fpm_t)
+    else:
+        intermediate = _adjoint_multiply(Ebbar, fpm_t)
+    Eabar = focus_dft_adjoint(intermediate, executor)
+    if return_fpm_grad:
+        fpm_bar = _adjoint_multiply(Ebbar, field_at_fpm, real=not fpm_is_complex)
+    if return_more:
+        if return_fpm_grad:
+            return Eabar, Ebbar, intermediate, fpm_bar
+        return Eabar, Ebbar, intermediate
+    elif return_fpm_grad:
+        return Eabar, fpm_bar
+    return Eabar
+
+
+def vortex_phase_mask(charge):
+    """Focal-plane-mask callable exp(i charge theta) of a vortex coronagraph (coronagraph.py:97-125)."""
+    if not isinstance(charge, numbers.Integral):
+        raise TypeError(f'charge must be an integer, got {charge!r}; non-integer charge has a branch cut at theta=pi')
+
+    def fpm(xf, yf):
+        xf, yf = L.as_device(xf), L.as_device(yf)
+        return torch.exp((1j * charge) * torch.atan2(yf, xf))
+    return fpm
+
+
+def to_fpm_and_back_multiresolution(wavefunction, fpm, executor, return_more=False):
+    """Propagate to a focal plane mask and back at multiple resolutions (coronagraph.py:203-225)."""
+    out = None
+    fields_at_fpm, fields_after_fpm = [], []
+    for ex, win, xf, yf in zip(executor.executors, executor.windows, executor.xf, executor.yf):
+        field_at_fpm = focus_dft(wavefunction, ex)
+        field_after_fpm = field_at_fpm * fpm(xf, yf) * win
+        contribution = unfocus_dft(field_after_fpm, ex)
+        out = contribution if out is None else out + contribution
+        if return_more:
+            fields_at_fpm.append(field_at_fpm)
+            fields_after_fpm.append(field_after_fpm)
+    if return_more:
+        return out, fields_at_fpm, fields_after_fpm
+    return out
+
+
+def babinet(wavefunction, lyot, fpm, executor, return_more=False):
+    """Propagate through a Lyot-style coronagraph using Babinet's principle (coronagraph.py:308-360)."""
+    wavefunction = L.as_complex(wavefunction)
+    fpm = 1 - (fpm if isinstance(fpm, numbers.Number) else L.as_device(fpm))
+    result = to_fpm_and_back(wavefunction, fpm=fpm, executor=executor, return_more=return_more)
+    if return_more:
+        field, field_at_fpm, field_after_fpm = result
+    else:
+        field = result
+    if field.dtype != wavefunction.dtype:
+        wavefunction = wavefunction.to(field.dtype)
+    field_at_lyot = wavefunction - field
+    if lyot is not None:
+        field_after_lyot = L.as_device(lyot) * field_at_lyot
+    else:
+        field_after_lyot = field_at_lyot
+    if return_more:
+        return field_after_lyot, field_at_fpm, field_after_fpm, field_at_lyot
+    return field_after_lyot
+
+
+def babinet_adjoint(wavefunction, lyot, fpm, executor, field_at_fpm=None,
+                    field_at_lyot=None, return_fpm_grad=False, return_lyot_grad=False):
+    """Apply the adjoint of babinet (coronagraph.py:363-431)."""
+    if return_lyot_grad and field_at_lyot is None:
+        raise ValueError('return_lyot_grad=True requires field_at_lyot from the forward propagation')
+    lyot_t = None if lyot is None else L.as_device(lyot)
+    lyot_is_complex = True if lyot_t is None else lyot_t.is_complex()
+    fpm = 1 - (fpm if isinstance(fpm, numbers.Number) else L.as_device(fpm))
+    dbar = L.as_complex(wavefunction)
+    cbar = _adjoint_multiply(dbar, lyot_t) if lyot_t is not None else dbar
+    if return_fpm_grad:
+        abar, fpm_bar = to_fpm_and_back_adjoint(cbar, fpm=fpm, executor=executor, return_fpm_grad=True,
+                                                field_at_fpm=field_at_fpm)
+    else:
+        abar = to_fpm_and_back_adjoint(cbar, fpm=fpm, executor=executor)
+    if cbar.dtype != abar.dtype:
+        cbar = cbar.to(abar.dtype)
+    abar = cbar - abar
+    if not (return_fpm_grad or return_lyot_grad):
+        return abar
+    out = [abar]
+    if return_fpm_grad:
+        out.append(fpm_bar)
+    if return_lyot_grad:
+        out.append(_adjoint_multiply(dbar, field_at_lyot, real=not lyot_is_complex))
+    return tuple(out)

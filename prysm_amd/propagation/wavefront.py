@@ -25,6 +25,7 @@ from .dft import (
     prepare_executor, focus_dft, focus_dft_adjoint, unfocus_dft, unfocus_dft_adjoint,
 )
 from .angular_spectrum import angular_spectrum, angular_spectrum_adjoint
+from .coronagraph import to_fpm_and_back, to_fpm_and_back_adjoint, babinet, babinet_adjoint
 from ..fttools import pad2d, crop_center
 
 
@@ -318,3 +319,38 @@ class Wavefront:
             raise ValueError('can only apply adjoint from a pupil to psf plane')
         data = unfocus_dft_adjoint(self.data, executor)
         return Wavefront(dx=executor.focal_dx, cmplx_field=data, wavelength=self.wavelength, space='psf')
+
+    def to_fpm_and_back(self, fpm, executor, return_more=False):
+        """Propagate to a focal plane mask, apply it, and return (wavefront.py:759-789)."""
+        fpm = _field_data(fpm)
+        pak = to_fpm_and_back(self.data, fpm=fpm, executor=executor, return_more=return_more)
+        if return_more:
+            at_next_pupil, at_fpm, after_fpm = pak
+            return (Wavefront(at_next_pupil, self.wavelength, self.dx, self.space),
+                    Wavefront(at_fpm, self.wavelength, executor.focal_dx, 'psf'),
+                    Wavefront(after_fpm, self.wavelength, executor.focal_dx, 'psf'))
+        return Wavefront(pak, self.wavelength, self.dx, self.space)
+
+    def to_fpm_and_back_adjoint(self, fpm, executor):
+        """Apply the adjoint of to_fpm_and_back (wavefront.py:791-850, gradient at the input pupil)."""
+        fpm = _field_data(fpm)
+        return Wavefront(to_fpm_and_back_adjoint(self.data, fpm=fpm, executor=executor), self.wavelength, self.dx,
+                         self.space)
+
+    def babinet(self, lyot, fpm, executor, return_more=False):
+        """Propagate through a Lyot-style coronagraph using Babinet's principle (wavefront.py:952-1000)."""
+        fpm, lyot = _field_data(fpm), _field_data(lyot)
+        pak = babinet(self.data, lyot=lyot, fpm=fpm, executor=executor, return_more=return_more)
+        if return_more:
+            after_lyot, at_fpm, after_fpm, at_lyot = pak
+            return (Wavefront(after_lyot, self.wavelength, self.dx, self.space),
+                    Wavefront(at_fpm, self.wavelength, executor.focal_dx, 'psf'),
+                    Wavefront(after_fpm, self.wavelength, executor.focal_dx, 'psf'),
+                    Wavefront(at_lyot, self.wavelength, self.dx, self.space))
+        return Wavefront(pak, self.wavelength, self.dx, self.space)
+
+    def babinet_adjoint(self, lyot, fpm, executor):
+        """Apply the adjoint of babinet (wavefront.py:1002-1038, gradient at the input pupil)."""
+        fpm, lyot = _field_data(fpm), _field_data(lyot)
+        return Wavefront(babinet_adjoint(self.data, lyot=lyot, fpm=fpm, executor=executor), self.wavelength, self.dx,
+                         self.space)

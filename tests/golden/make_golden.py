@@ -213,6 +213,31 @@ def wavefront_and_physics():
     np.savez_compressed(os.path.join(HERE, 'wavefront.npz'), **out)
 
 
+def coronagraph():
+    """to_fpm_and_back / babinet and their adjoints through the reference."""
+    out = {}
+    rng = np.random.default_rng(29)
+    n, m = 48, 40
+    x = crandn(rng, (n, n))
+    ex = propagation.prepare_executor(0.1, (n, n), 1.2, (m, m), HeNe, 60.0)
+    fpm = crandn(rng, (m, m))
+    fpm_real = rng.random((m, m))
+    lyot = (rng.random((n, n)) > 0.3).astype(float)
+    g = crandn(rng, (n, n))
+    out['x'], out['fpm'], out['fpm_real'], out['lyot'], out['g'] = x, fpm, fpm_real, lyot, g
+    out['par'] = np.array([0.1, 1.2, HeNe, 60.0], dtype=np.float64)
+    nxt, at_fpm, after = propagation.to_fpm_and_back(x, fpm, ex, return_more=True)
+    out['tfab'], out['tfab_at'], out['tfab_after'] = nxt, at_fpm, after
+    Ea, fbar = propagation.to_fpm_and_back_adjoint(g, fpm, ex, return_fpm_grad=True, field_at_fpm=at_fpm)
+    out['tfab_adj'], out['tfab_fpmbar'] = Ea, fbar
+    out['babinet'] = propagation.babinet(x, lyot, fpm_real, ex)
+    out['babinet_adj'] = propagation.babinet_adjoint(g, lyot, fpm_real, ex)
+    vm = propagation.vortex_phase_mask(2)
+    xf, yf = np.meshgrid(np.linspace(-3, 3.1, 16), np.linspace(-2, 2.2, 12))
+    out['vortex_xf'], out['vortex_yf'], out['vortex'] = xf, yf, vm(xf, yf)
+    np.savez_compressed(os.path.join(HERE, 'coronagraph.npz'), **out)
+
+
 def precision32():
     """fp32 path semantics (dtype propagation) on one case each."""
     out = {}
@@ -238,6 +263,7 @@ if __name__ == '__main__':
     angular()
     executors()
     wavefront_and_physics()
+    coronagraph()
     precision32()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):

@@ -361,6 +361,31 @@ def test_otf_and_convolution_golden(pa, golden):
     assert rel_max(tonp(out), g['conv_out']) < TOL64
 
 
+def test_coronagraph_golden(pa, golden):
+    """to_fpm_and_back / babinet (+ adjoints), compositions of the MFMA executors."""
+    P = pa.propagation
+    g = golden('coronagraph')
+    pdx, fdx, wvl, efl = (float(v) for v in g['par'])
+    x, fpm = g['x'], g['fpm']
+    ex = P.prepare_executor(pdx, x.shape, fdx, fpm.shape, wvl, efl)
+    nxt, at_fpm, after = P.to_fpm_and_back(x, fpm, ex, return_more=True)
+    assert rel_max(tonp(nxt), g['tfab']) < TOL64
+    assert rel_max(tonp(at_fpm), g['tfab_at']) < TOL64
+    assert rel_max(tonp(after), g['tfab_after']) < TOL64
+    Ea, fbar = P.to_fpm_and_back_adjoint(g['g'], fpm, ex, return_fpm_grad=True, field_at_fpm=at_fpm)
+    assert rel_max(tonp(Ea), g['tfab_adj']) < TOL64
+    assert rel_max(tonp(fbar), g['tfab_fpmbar']) < TOL64
+    assert rel_max(tonp(P.babinet(x, g['lyot'], g['fpm_real'], ex)), g['babinet']) < TOL64
+    assert rel_max(tonp(P.babinet_adjoint(g['g'], g['lyot'], g['fpm_real'], ex)), g['babinet_adj']) < TOL64
+    assert rel_max(tonp(P.vortex_phase_mask(2)(g['vortex_xf'], g['vortex_yf'])), g['vortex']) < 1e-12
+    wf = P.Wavefront(x, wvl, pdx)
+    assert rel_max(tonp(wf.babinet(g['lyot'], g['fpm_real'], ex).data), g['babinet']) < TOL64
+    with pytest.raises(TypeError):
+        P.vortex_phase_mask(1.5)
+    with pytest.raises(ValueError):
+        P.to_fpm_and_back_adjoint(g['g'], fpm, ex, return_fpm_grad=True)
+
+
 def test_polychromatic_driver_single_gpu(pa):
     """BASELINE config 5 recipe at a small size on one GPU (world size 1: no process group, no reduce);
     the N > 1 sharding / reduce logic is covered on CPU by tests/test_distributed_cpu.py."""

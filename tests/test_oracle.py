@@ -138,6 +138,19 @@ def test_wavefront_golden(golden):
     assert rel_max(O.conv(g['conv_obj'], g['conv_psf']), g['conv_out']) < 1e-11
 
 
+def test_coronagraph_golden(golden):
+    g = golden('coronagraph')
+    pdx, fdx, wvl, efl = (float(v) for v in g['par'])
+    x, fpm = g['x'], g['fpm']
+    ex = O.prepare_executor(pdx, x.shape, fdx, fpm.shape, wvl, efl)
+    nxt, at_fpm, after = O.to_fpm_and_back(x, fpm, ex, return_more=True)
+    assert rel_max(nxt, g['tfab']) < 1e-11 and rel_max(at_fpm, g['tfab_at']) < 1e-11 and rel_max(after, g['tfab_after']) < 1e-11
+    assert rel_max(O.to_fpm_and_back_adjoint(g['g'], fpm, ex), g['tfab_adj']) < 1e-11
+    assert rel_max(O._adjoint_multiply(ex(g['g']), at_fpm), g['tfab_fpmbar']) < 1e-11
+    assert rel_max(O.babinet(x, g['lyot'], g['fpm_real'], ex), g['babinet']) < 1e-11
+    assert rel_max(O.babinet_adjoint(g['g'], g['lyot'], g['fpm_real'], ex), g['babinet_adj']) < 1e-11
+
+
 def test_precision32_golden(golden):
     g = golden('precision32')
     x = g['x']

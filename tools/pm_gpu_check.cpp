@@ -661,15 +661,20 @@ int main(int argc, char** argv) {
         check_cgemm<float>(3, 0, 2048, 512, 512, 5e-5, true);
         check_cgemm<float>(0, 1, 2048, 2048, 512, 5e-5, true);
         check_cgemm<double>(3, 1, 200, 300, 1000, 1e-12, true);
-        for (int wgs : {512, 768, 1024}) {
-            pm_set_tuning("gemm_min_wgs", wgs);
-            printf("gemm_min_wgs=%d\n", wgs);
+        for (int wgs : {1024, 1032, 512, 520}) {   // odd values: gemm_bk = 32 variant
+            pm_set_tuning("gemm_min_wgs", wgs & ~15);
+            pm_set_tuning("gemm_bk", (wgs & 8) ? 32 : 0);
+            printf("gemm_min_wgs=%d gemm_bk=%d\n", wgs & ~15, (wgs & 8) ? 32 : 0);
             bench_cgemm<float>(512, 2048, 2048, 0);
             bench_cgemm<float>(512, 512, 2048, 2);
             bench_cgemm<float>(2048, 512, 512, 0);
             bench_cgemm<double>(512, 2048, 2048, 0);
         }
         pm_set_tuning("gemm_min_wgs", 1024);
+        pm_set_tuning("gemm_bk", 32);
+        bench_cgemm<float>(4096, 4096, 4096, 0);
+        bench_cgemm<double>(2048, 2048, 2048, 0);
+        pm_set_tuning("gemm_bk", 0);
         bench_cgemm<float>(4096, 4096, 4096, 0);
         bench_cgemm<double>(2048, 2048, 2048, 0);
         printf(g_fail ? "GPU CHECK FAILED (%d)\n" : "GPU CHECK OK\n", g_fail);
