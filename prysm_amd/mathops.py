@@ -49,3 +49,60 @@ def is_power_of_2(value):
     if value == 1:
         return False
     return bool(value and not value & (value - 1))
+
+
+# --------------------------------------------------------------------------------------------------------
+# Installing the engine into an existing prysm (the reference's own plug mechanism: rebinding names on its
+# modules at run time, as prysm/x/polarization.py:541-553 does for Jones propagation).
+# --------------------------------------------------------------------------------------------------------
+_PROPAGATION_NAMES = (
+    'focus', 'focus_adjoint', 'unfocus', 'unfocus_adjoint',
+    'angular_spectrum', 'angular_spectrum_adjoint', 'angular_spectrum_transfer_function',
+    'coordinates_for_focus', 'prepare_executor', 'focus_dft', 'focus_dft_adjoint', 'unfocus_dft',
+    'unfocus_dft_adjoint', 'to_fpm_and_back', 'to_fpm_and_back_adjoint', 'babinet', 'babinet_adjoint',
+)
+_FTTOOLS_NAMES = ('pad2d', 'crop_center', 'fftrange', 'MDFT', 'CZT', 'FFTDFT')
+_saved = {}
+
+
+def set_backend_to_mi355x(prysm=None):
+    """Route prysm's pupil<->focus / free-space / matrix-DFT hot path to libprysm_amd.so.
+
+    Rebinds the array-level functions and executor classes on ``prysm.propagation`` (and on the submodules and
+    ``prysm.propagation.wavefront``, which bind them by name at import, prysm/propagation/wavefront.py:11-25),
+    ``prysm.fttools`` and ``prysm.propagation.Wavefront``.  Arrays handed to these functions may be numpy (they are
+    uploaded) or torch tensors in HBM; results are device tensors (use ``array_to_true_numpy``).  Undo with
+    ``restore_prysm_backend()``.  ``config.precision`` of prysm is mirrored into ``prysm_amd.conf.config``.
+    """
+    import importlib
+    if prysm is None:
+        prysm = importlib.import_module('prysm')
+    from . import propagation as pa_prop, fttools as pa_ft
+    from .conf import config as pa_config
+    P = importlib.import_module(prysm.__name__ + '.propagation')
+    F = importlib.import_module(prysm.__name__ + '.fttools')
+    mods = [P] + [importlib.import_module(f'{prysm.__name__}.propagation.{m}')
+                  for m in ('fft', 'angular_spectrum', 'dft', 'coronagraph', 'wavefront')]
+    for name in _PROPAGATION_NAMES:
+        fn = getattr(pa_prop, name)
+        for mod in mods:
+            if hasattr(mod, name):
+                _saved.setdefault((mod, name), getattr(mod, name))
+                setattr(mod, name, fn)
+    for name in _FTTOOLS_NAMES:
+        _saved.setdefault((F, name), getattr(F, name))
+        setattr(F, name, getattr(pa_ft, name))
+    for mod in (P, mods[-1]):
+        _saved.setdefault((mod, 'Wavefront'), mod.Wavefront)
+        mod.Wavefront = pa_prop.Wavefront
+    try:
+        pa_config.precision = importlib.import_module(prysm.__name__ + '.conf').config.precision
+    except Exception:   # pragma: no cover
+        pass
+
+
+def restore_prysm_backend():
+    """Undo set_backend_to_mi355x()."""
+    for (mod, name), obj in _saved.items():
+        setattr(mod, name, obj)
+    _saved.clear()

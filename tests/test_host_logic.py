@@ -62,3 +62,34 @@ def test_fft_engine_emulation():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:]
     assert 'EMU OK' in out.stdout
+
+
+REF = '/root/reference'
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'prysm')), reason='reference not present on this box')
+def test_install_into_prysm_rebinds_and_restores():
+    """The plug mechanism of INTEGRATION.md: names on prysm's modules are rebound to the MI355X engine and
+    restored afterwards (no compute here -- there is no GPU in this container)."""
+    import sys
+    sys.path.insert(0, REF)
+    try:
+        import prysm
+        import prysm.propagation as P
+        import prysm.propagation.wavefront as W
+        import prysm.fttools as F
+    finally:
+        sys.path.remove(REF)
+    import prysm_amd
+    from prysm_amd import mathops
+    orig_focus, orig_mdft, orig_wf = P.focus, F.MDFT, P.Wavefront
+    mathops.set_backend_to_mi355x(prysm)
+    try:
+        assert P.focus is prysm_amd.propagation.focus
+        assert W.focus is prysm_amd.propagation.focus          # bound by name in wavefront.py
+        assert P.prepare_executor is prysm_amd.propagation.prepare_executor
+        assert F.MDFT is prysm_amd.fttools.MDFT
+        assert P.Wavefront is prysm_amd.propagation.Wavefront
+    finally:
+        mathops.restore_prysm_backend()
+    assert P.focus is orig_focus and F.MDFT is orig_mdft and P.Wavefront is orig_wf
