@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PM_VERSION 100 /* 0.1.0 */
+#define PM_VERSION 101 /* 0.1.0 */
 
 /* dtype codes */
 enum { PM_C64 = 0, PM_C128 = 1, PM_F32 = 2, PM_F64 = 3, PM_BOOL = 4 };
@@ -104,6 +104,15 @@ typedef struct pm_fft2_desc {
     const void* mul;    /* FULL: (M x N) complex array; SEPARABLE: length-M complex vector (rows) */
     const void* mul_x;  /* SEPARABLE: length-N complex vector (columns) */
     int64_t mul_ld;
+    /* Batch of independent fields in ONE launch pair (wavelengths / field points of a polychromatic or
+     * multi-field model -- the per-wavelength loop of docs/source/how-tos/Polychromatic Propagation.ipynb).
+     * Field b reads in + b*in_bstride and writes out + b*out_bstride (elements of the respective array; for the
+     * |.|^2 epilogues out elements are real).  batch = 0 means 1.  mul_bstride / mul_x_bstride: elements between
+     * per-field multipliers (FULL: arrays; SEPARABLE: the row-factor and column-factor vectors), 0 = shared.
+     * The workspace grows by the batch factor.  PM_EPI_ABS2_ACCUM needs distinct outputs per field. */
+    int64_t batch;
+    int64_t in_bstride, out_bstride;
+    int64_t mul_bstride, mul_x_bstride;
 } pm_fft2_desc;
 
 /* bytes of workspace pm_fft2 needs for this descriptor (the tiled intermediate) */
@@ -150,6 +159,13 @@ int pm_scale_sep(int32_t dtype, int64_t rows, int64_t cols, const void* in, int6
  * polynomials.sum_of_2d_modes (prysm/polynomials/fitting.py:7-37) as a running weighted sum. */
 int pm_abs2(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t in_ld, void* out, int64_t out_ld,
             int32_t accumulate, double weight, void* stream);
+
+/* out = sum_b weights[b] * modes[b] (accumulate = 0) or out += ...; REAL images of the precision that goes with
+ * dtype (PM_C64: float, PM_C128: double), modes[b] at modes + b*mode_stride elements; weights is a HOST array.
+ * polynomials.sum_of_2d_modes = tensordot(weights, modes, axes=(0, 0)) (prysm/polynomials/fitting.py:7-37), the
+ * incoherent sum of the polychromatic recipe over a batch of intensities. */
+int pm_sum_modes(int32_t dtype, int64_t nmodes, int64_t rows, int64_t cols, const void* modes, int64_t mode_stride,
+                 int64_t modes_ld, const double* weights, int32_t accumulate, void* out, int64_t out_ld, void* stream);
 
 /* P = amp * exp(i * k * opd), k = 2 pi / (wavelength_um * 1e3) for opd in nm.
  * amp may be NULL (unit amplitude: phase_screen).  amp_dtype in {PM_F32, PM_F64, PM_BOOL}.

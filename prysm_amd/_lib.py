@@ -34,6 +34,7 @@ class pm_fft2_desc(ctypes.Structure):
         ('in_y', pm_axis), ('in_x', pm_axis), ('out_y', pm_axis), ('out_x', pm_axis),
         ('in_ld', c_i64), ('out_ld', c_i64),
         ('mul_kind', c_i32), ('mul_conj', c_i32), ('mul', c_vp), ('mul_x', c_vp), ('mul_ld', c_i64),
+        ('batch', c_i64), ('in_bstride', c_i64), ('out_bstride', c_i64), ('mul_bstride', c_i64), ('mul_x_bstride', c_i64),
     ]
 
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     'pm_cmul': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'pm_scale_sep': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_f64, c_vp, c_i64, c_vp]),
     'pm_abs2': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_f64, c_vp]),
+    'pm_sum_modes': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, ctypes.POINTER(c_f64), c_i32, c_vp, c_i64, c_vp]),
     'pm_pupil_synth': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i32, c_i64, c_vp, c_i64, c_f64, c_vp, c_i64, c_vp]),
     'pm_quadratic_phase': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_f64, c_vp, c_i64, c_vp]),
     'pm_as_tf_vectors': (c_i32, [c_i32, c_i64, c_i64, c_f64, c_f64, c_f64, c_vp, c_vp, c_vp]),

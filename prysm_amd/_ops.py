@@ -15,48 +15,77 @@ def _axis(n, length=None, off=0, shift=0):
     return L.pm_axis(int(n), int(n if length is None else length), int(off), int(shift))
 
 
-def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
-         out_shape=None, out_off=(0, 0), out_shift=(0, 0), epilogue=L.PM_EPI_NONE,
-         mul=None, mul_x=None, mul_conj=False, out=None, weight=1.0, flags=0):
-    """Fused 2-D transform (pm_fft2).
-
-    x          : (m, n) complex tensor; it sits at `in_off` inside the logical `shape` = (M, N) array
-                 (zero elsewhere), which is then rotated by `in_shift`
-    out_shape  : stored window of the output (crop), at `out_off` of the rotated result
-    mul, mul_x : None | full (M, N) multiplier | (column vector hy (M,), row vector hx (N,))
-    """
-    lib = L.load()
-    m, n = x.shape
+def _fill_views(d, x, shape, in_off, in_shift, out_shape, out_off, out_shift):
+    """Common part of the 2-D descriptors: views, leading dimensions and the batch (leading axis of a 3-D x)."""
+    if x.dim() not in (2, 3):
+        raise ValueError('2-D transforms take a 2-D array or a (batch, rows, cols) stack of them')
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    m, n = x.shape[-2:]
     M, N = (m, n) if shape is None else shape
     om, on = (M, N) if out_shape is None else out_shape
-    d = L.pm_fft2_desc()
     d.dtype = L.code(x)
-    d.direction = direction
-    d.epilogue = epilogue
-    d.flags = flags
-    d.scale = float(scale)
-    d.weight = float(weight)
     d.in_y = _axis(M, m, in_off[0], in_shift[0])
     d.in_x = _axis(N, n, in_off[1], in_shift[1])
     d.out_y = _axis(M, om, out_off[0], out_shift[0])
     d.out_x = _axis(N, on, out_off[1], out_shift[1])
-    d.in_ld = x.stride(0) if m > 1 else n
-    keep = [x]
+    d.in_ld = x.stride(-2) if m > 1 else n
+    if x.dim() == 3:
+        d.batch = x.shape[0]
+        d.in_bstride = x.stride(0) if x.shape[0] > 1 else m * n
+    return x, (M, N), (om, on)
+
+
+def _fill_mul(d, x, mul, mul_x, mul_conj, keep):
+    """Multiplier: full (M, N) array or the (hy, hx) vector pair; with a batch, optionally one per field."""
+    batched = x.dim() == 3
     if mul is not None and mul_x is not None:
         d.mul_kind = L.PM_MUL_SEPARABLE
+        if batched and mul.dim() == 2:
+            mul, mul_x = mul.contiguous(), mul_x.contiguous()
+            d.mul_bstride, d.mul_x_bstride = mul.stride(0), mul_x.stride(0)
         d.mul = mul.data_ptr()
         d.mul_x = mul_x.data_ptr()
         keep += [mul, mul_x]
     elif mul is not None:
         d.mul_kind = L.PM_MUL_FULL
+        if batched and mul.dim() == 3:
+            d.mul_bstride = mul.stride(0)
         d.mul = mul.data_ptr()
-        d.mul_ld = mul.stride(0) if mul.shape[0] > 1 else mul.shape[1]
+        d.mul_ld = mul.stride(-2) if mul.shape[-2] > 1 else mul.shape[-1]
         keep.append(mul)
     d.mul_conj = 1 if mul_conj else 0
+
+
+def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
+         out_shape=None, out_off=(0, 0), out_shift=(0, 0), epilogue=L.PM_EPI_NONE,
+         mul=None, mul_x=None, mul_conj=False, out=None, weight=1.0, flags=0):
+    """Fused 2-D transform (pm_fft2).
+
+    x          : (m, n) complex tensor, or a (B, m, n) stack transformed in one launch pair; each field sits at
+                 `in_off` inside the logical `shape` = (M, N) array (zero elsewhere), which is then rotated by
+                 `in_shift`
+    out_shape  : stored window of the output (crop), at `out_off` of the rotated result
+    mul, mul_x : None | full (M, N) multiplier | (column vector hy (M,), row vector hx (N,)); with a stack,
+                 (B, M, N) / ((B, M), (B, N)) give one multiplier per field
+    """
+    lib = L.load()
+    d = L.pm_fft2_desc()
+    x, (M, N), (om, on) = _fill_views(d, x, shape, in_off, in_shift, out_shape, out_off, out_shift)
+    d.direction = direction
+    d.epilogue = epilogue
+    d.flags = flags
+    d.scale = float(scale)
+    d.weight = float(weight)
+    keep = [x]
+    _fill_mul(d, x, mul, mul_x, mul_conj, keep)
     if out is None:
         odt = x.dtype if epilogue == L.PM_EPI_NONE else L._REAL_OF[x.dtype]
-        out = torch.empty((om, on), dtype=odt, device=x.device)
-    d.out_ld = out.stride(0) if om > 1 else on
+        oshape = (om, on) if x.dim() == 2 else (x.shape[0], om, on)
+        out = torch.empty(oshape, dtype=odt, device=x.device)
+    d.out_ld = out.stride(-2) if om > 1 else on
+    if x.dim() == 3:
+        d.out_bstride = out.stride(0) if out.shape[0] > 1 else om * d.out_ld
     nbytes = lib.pm_fft2_workspace(ctypes.byref(d))
     if nbytes == 0:
         L.check(lib.pm_fft2(ctypes.byref(d), L.ptr(x), L.ptr(out), None, 0, L.stream_ptr()))  # raises with the reason
@@ -77,7 +106,7 @@ def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_
     both column transforms happen in registers); other sizes compose two pm_fft2 calls.
     """
     lib = L.load()
-    m, n = x.shape
+    m, n = x.shape[-2:]
     M, N = (m, n) if shape is None else shape
     # non power-of-two sizes compose two fused transforms (measured, profiles/r01/fused_as.log: the 3-pass chain
     # wins at every engine size, e.g. 4096^2 complex128 448 vs 473 us, 2048^2 complex64 55 vs 75 us)
@@ -85,28 +114,18 @@ def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_
         F = fft2(x, direction=-1, scale=1.0, shape=shape, in_off=in_off, in_shift=in_shift, mul=mul, mul_x=mul_x,
                  mul_conj=mul_conj)
         return fft2(F, direction=+1, scale=scale, out_shape=out_shape, out_off=out_off, out_shift=out_shift)
-    om, on = (M, N) if out_shape is None else out_shape
     d = L.pm_fft2_desc()
-    d.dtype = L.code(x)
+    x, (M, N), (om, on) = _fill_views(d, x, shape, in_off, in_shift, out_shape, out_off, out_shift)
     d.direction = -1
     d.scale = float(scale)
     d.weight = 1.0
-    d.in_y = _axis(M, m, in_off[0], in_shift[0])
-    d.in_x = _axis(N, n, in_off[1], in_shift[1])
-    d.out_y = _axis(M, om, out_off[0], out_shift[0])
-    d.out_x = _axis(N, on, out_off[1], out_shift[1])
-    d.in_ld = x.stride(0) if m > 1 else n
-    if mul_x is not None:
-        d.mul_kind = L.PM_MUL_SEPARABLE
-        d.mul = mul.data_ptr()
-        d.mul_x = mul_x.data_ptr()
-    else:
-        d.mul_kind = L.PM_MUL_FULL
-        d.mul = mul.data_ptr()
-        d.mul_ld = mul.stride(0) if mul.shape[0] > 1 else mul.shape[1]
-    d.mul_conj = 1 if mul_conj else 0
-    out = torch.empty((om, on), dtype=x.dtype, device=x.device)
-    d.out_ld = out.stride(0) if om > 1 else on
+    keep = [x]
+    _fill_mul(d, x, mul, mul_x, mul_conj, keep)
+    oshape = (om, on) if x.dim() == 2 else (x.shape[0], om, on)
+    out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    d.out_ld = out.stride(-2) if om > 1 else on
+    if x.dim() == 3:
+        d.out_bstride = out.stride(0) if out.shape[0] > 1 else om * d.out_ld
     nbytes = lib.pm_fft2_mul_ifft2_workspace(ctypes.byref(d))
     ws = L.workspace(max(int(nbytes), 16))
     L.check(lib.pm_fft2_mul_ifft2(ctypes.byref(d), L.ptr(x), L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()))
@@ -171,14 +190,39 @@ def abs2(x, out=None, weight=None):
     return out
 
 
+def sum_modes(modes, weights, out=None, accumulate=False):
+    """sum_b weights[b] * modes[b] over a (B, rows, cols) stack of real images (pm_sum_modes);
+    with `out` and accumulate=True adds into `out`."""
+    lib = L.load()
+    if modes.dim() != 3 or modes.is_complex():
+        raise ValueError('sum_modes takes a (B, rows, cols) stack of real images')
+    if modes.stride(-1) != 1:
+        modes = modes.contiguous()
+    B, rows, cols = modes.shape
+    w = [float(v) for v in weights]
+    if len(w) != B:
+        raise ValueError('one weight per mode is required')
+    if out is None:
+        out = torch.empty((rows, cols), dtype=modes.dtype, device=modes.device)
+        accumulate = False
+    code = L.PM_C64 if modes.dtype == torch.float32 else L.PM_C128
+    if modes.dtype not in (torch.float32, torch.float64):
+        raise TypeError('sum_modes: float32 or float64 images')
+    arr = (ctypes.c_double * max(B, 1))(*w)
+    L.check(lib.pm_sum_modes(code, B, rows, cols, L.ptr(modes), modes.stride(0) if B > 1 else rows * cols, modes.stride(1),
+                             arr, 1 if accumulate else 0, L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
 _AMP_CODE = {torch.float32: L.PM_F32, torch.float64: L.PM_F64, torch.bool: L.PM_BOOL, torch.uint8: L.PM_BOOL}
 
 
-def pupil_synth(amp, opd, k, cdtype):
-    """amp * exp(i k opd); opd real tensor of the real dtype of `cdtype`."""
+def pupil_synth(amp, opd, k, cdtype, out=None):
+    """amp * exp(i k opd); opd real tensor of the real dtype of `cdtype`; `out`: e.g. one field of a stack."""
     lib = L.load()
     rows, cols = opd.shape
-    out = torch.empty((rows, cols), dtype=cdtype, device=opd.device)
+    if out is None:
+        out = torch.empty((rows, cols), dtype=cdtype, device=opd.device)
     a_code, a_ld = L.PM_F32, cols
     if amp is not None:
         if amp.dtype not in _AMP_CODE:

@@ -79,6 +79,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("gemm_min_wgs")) t.gemm_min_wgs = v < 1 ? 1 : v;
     else if (is("nt_in")) t.nt_in = v;
     else if (is("nt_out")) t.nt_out = v;
+    else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
 }
 
 Tuning& tuning() {
@@ -112,8 +113,19 @@ struct Fft2Plan {
     int logn, logm;       // engine log2 sizes or -1 (direct)
     int tc;               // column-pass tile width when both passes run on the engine, else 0 (natural intermediate)
     int log_k;            // layout tile width TL = tc << log_k
-    size_t ws_bytes;
+    size_t ws_bytes;      // total
+    size_t ws_field;      // bytes of intermediate per field (256 B aligned)
+    int64_t nbatch;       // fields
+    int64_t chunk;        // fields per launch pair: the intermediates of one chunk stay resident in the 256 MiB
+                          // Infinity Cache between the two passes, consecutive chunks reuse the same workspace
 };
+
+static int64_t batch_chunk(int64_t nb, size_t ws_field) {
+    const size_t budget = size_t(tuning().batch_ws_mib) << 20;
+    int64_t c = int64_t(budget / (ws_field ? ws_field : 1));
+    if (c < 1) c = 1;
+    return c < nb ? c : nb;
+}
 
 static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     Fft2Plan p;
@@ -135,6 +147,10 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
         p.ws_bytes = size_t(rows) * size_t(N) * es;
     }
     if (p.ws_bytes == 0) p.ws_bytes = es;
+    p.nbatch = d->batch > 1 ? d->batch : 1;
+    p.ws_field = (p.ws_bytes + 255) & ~size_t(255);
+    p.chunk = batch_chunk(p.nbatch, p.ws_field);
+    if (p.nbatch > 1) p.ws_bytes = p.ws_field * size_t(p.chunk);
     return p;
 }
 
@@ -154,11 +170,15 @@ static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out) {
     cs.mul = reinterpret_cast<const cx<T>*>(d->mul);
     cs.mul_x = reinterpret_cast<const cx<T>*>(d->mul_x);
     cs.mul_ld = d->mul_ld;
+    cs.bstride = d->out_bstride;
+    cs.mul_bstride = d->mul_bstride;
+    cs.mul_bstride_x = d->mul_x_bstride;
     bool vec = true;
     if (d->epilogue == PM_EPI_NONE && sizeof(T) == 4)
-        vec = (d->out_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+        vec = (d->out_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (d->out_bstride % 2 == 0);
     cs.vec_ok = vec ? 1 : 0;
-    const size_t out_bytes = size_t(d->out_y.len) * size_t(d->out_x.len) * (d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T));
+    const size_t out_bytes = size_t(d->batch > 1 ? d->batch : 1) * size_t(d->out_y.len) * size_t(d->out_x.len) *
+                             (d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T));
     // streaming stores only help when a workgroup writes whole 64 B pieces; on the 32 B pieces of 8192-point
     // columns they defeat the L2 write combining of sibling workgroups (measured: 977 -> 428 us without)
     const size_t piece = size_t(col_tile_width_for(d->dtype, engine_log2(d->out_y.n) >= 0 ? engine_log2(d->out_y.n) : 12, 0)) *
@@ -167,9 +187,11 @@ static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out) {
     return cs;
 }
 
+// one launch pair over `nb` fields (nb > 1 only when both passes run on the engine)
 template <typename T>
-static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st) {
+static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st, int nb) {
     const int64_t M = d->in_y.n, N = d->in_x.n;
+    const int64_t wstride = int64_t(p.ws_field / sizeof(cx<T>));
     const int rows = int(d->in_y.len);
     const int conj = d->direction > 0 ? 1 : 0;
     int err = 0;
@@ -181,15 +203,15 @@ static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, vo
         if (p.logn >= 0) {
             const cx<T>* tw = twiddles<T>(N, &err);
             if (!tw) return err;
-            const size_t in_bytes = size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
+            const size_t in_bytes = size_t(p.nbatch) * size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
             const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
-            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, conj, nt_in};
+            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, conj, nt_in, d->in_bstride};
             int rc;
             if (p.tc) {
                 int ltc = 0;
                 while ((1 << ltc) < (p.tc << p.log_k)) ++ltc;
-                RowStoreTiled<T> sp{W, rows, ltc};
-                rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, tuning().row_log_g, st);
+                RowStoreTiled<T> sp{W, rows, ltc, wstride};
+                rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, tuning().row_log_g, st, nb);
             } else {
                 RowStoreNat<T> sp{W, N, AxisMap{int(N), int(N), 0, 0}, rows, 0, T(1), 0, AxisMap{1, 1, 0, 0}};
                 rc = launch_row_nat<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, 0, st);
@@ -212,8 +234,8 @@ static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, vo
         if (!tw) return err;
         if (p.tc) {
             const int ntiles = int((N + p.tc - 1) / p.tc);
-            ColLoadTiled<T> cl{W, rows, to_map(d->in_y), ntiles, p.log_k};
-            return launch_col_tiled<T>(p.logm, tuning().col_var, cl, cs, tw, ntiles, p.log_k > 1 ? p.log_k : 1, st);
+            ColLoadTiled<T> cl{W, rows, to_map(d->in_y), ntiles, p.log_k, wstride};
+            return launch_col_tiled<T>(p.logm, tuning().col_var, cl, cs, tw, ntiles, p.log_k > 1 ? p.log_k : 1, st, nb);
         }
         const int tc = col_tile_width_for(d->dtype, p.logm, tuning().col_var);
         const int ntiles = int((N + tc - 1) / tc);
@@ -226,11 +248,38 @@ static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, vo
     return direct_cols<T>(di, cs, tw, st);
 }
 
+static const void* offset_elems(const void* p, int64_t elems, size_t es) {
+    return p ? static_cast<const void*>(static_cast<const char*>(p) + elems * int64_t(es)) : nullptr;
+}
+
+// Batch driver: chunks of fields whose intermediates fit the Infinity Cache go out as one launch pair each
+// (grid.y = fields); sizes that need the direct-DFT kernels run field by field.
+template <typename T>
+static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st) {
+    if (p.nbatch <= 1) return fft2_run_chunk<T>(d, p, in, out, ws, st, 1);
+    const bool engine = p.tc != 0;
+    const int64_t step = engine ? p.chunk : 1;
+    const size_t oes = d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T);
+    for (int64_t b0 = 0; b0 < p.nbatch; b0 += step) {
+        const int nb = int(p.nbatch - b0 < step ? p.nbatch - b0 : step);
+        pm_fft2_desc dd = *d;
+        dd.mul = offset_elems(d->mul, b0 * d->mul_bstride, sizeof(cx<T>));
+        dd.mul_x = offset_elems(d->mul_x, b0 * d->mul_x_bstride, sizeof(cx<T>));
+        const void* inb = offset_elems(in, b0 * d->in_bstride, sizeof(cx<T>));
+        void* outb = const_cast<void*>(offset_elems(out, b0 * d->out_bstride, oes));
+        int rc = fft2_run_chunk<T>(&dd, p, inb, outb, ws, st, nb);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------- fused fft2 -> multiply -> ifft2
 struct FusedPlan {
     int logn, logm, tc, log_k;
-    size_t w1_bytes, w2_bytes;   // tiled buffers: stored input rows x N, and M x N (shared when rows == M)
+    size_t w1_bytes, w2_bytes;   // tiled buffers PER FIELD: stored input rows x N, and M x N (shared when rows == M)
     bool inplace;
+    int64_t nbatch, chunk;       // fields, fields per launch triple
+    size_t ws_bytes;             // total workspace
 };
 
 static bool plan_fused(const pm_fft2_desc* d, FusedPlan& p) {
@@ -246,16 +295,23 @@ static bool plan_fused(const pm_fft2_desc* d, FusedPlan& p) {
     p.inplace = d->in_y.len == M;
     p.w1_bytes = size_t(ntl) * size_t(d->in_y.len > 0 ? d->in_y.len : 1) * size_t(tl) * es;
     p.w2_bytes = p.inplace ? 0 : size_t(ntl) * size_t(M) * size_t(tl) * es;
+    p.w1_bytes = (p.w1_bytes + 255) & ~size_t(255);
+    p.w2_bytes = (p.w2_bytes + 255) & ~size_t(255);
+    p.nbatch = d->batch > 1 ? d->batch : 1;
+    p.chunk = batch_chunk(p.nbatch, p.w1_bytes + p.w2_bytes);
+    p.ws_bytes = (p.w1_bytes + p.w2_bytes) * size_t(p.chunk);
     return true;
 }
 
 template <typename T>
-static int fused_run(const pm_fft2_desc* d, const FusedPlan& p, const void* in, void* out, void* ws, hipStream_t st) {
+static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void* in, void* out, void* ws, hipStream_t st, int nb) {
     const int64_t M = d->in_y.n, N = d->in_x.n;
     const int rows = int(d->in_y.len);
     int err = 0;
+    // per field: W1 at ws + b*(w1 + w2), W2 right behind it (or the same block when the transform is in place)
+    const int64_t wstride = int64_t((p.w1_bytes + p.w2_bytes) / sizeof(cx<T>));
     cx<T>* W1 = reinterpret_cast<cx<T>*>(ws);
-    cx<T>* W2 = p.inplace ? W1 : reinterpret_cast<cx<T>*>(reinterpret_cast<char*>(ws) + ((p.w1_bytes + 255) & ~size_t(255)));
+    cx<T>* W2 = p.inplace ? W1 : reinterpret_cast<cx<T>*>(reinterpret_cast<char*>(ws) + p.w1_bytes);
     const cx<T>* twN = twiddles<T>(N, &err);
     if (!twN) return err;
     const cx<T>* twM = twiddles<T>(M, &err);
@@ -265,26 +321,41 @@ static int fused_run(const pm_fft2_desc* d, const FusedPlan& p, const void* in, 
     while ((1 << ltl) < tl) ++ltl;
     // pass A: forward row transforms of the stored input rows -> tiled W1
     if (rows > 0) {
-        const size_t in_bytes = size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
+        const size_t in_bytes = size_t(p.nbatch) * size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
         const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
-        RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, 0, nt_in};
-        RowStoreTiled<T> sp{W1, rows, ltl};
-        int rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, twN, rows, tuning().row_log_g, st);
+        RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, 0, nt_in, d->in_bstride};
+        RowStoreTiled<T> sp{W1, rows, ltl, wstride};
+        int rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, twN, rows, tuning().row_log_g, st, nb);
         if (rc) return rc;
     }
     // pass B: column FFT, x H, column IFFT (unnormalised) -> tiled W2 (all M rows)
     const int ntiles = int((N + p.tc - 1) / p.tc);
-    ColLoadTiled<T> cl{W1, rows, to_map(d->in_y), ntiles, p.log_k};
+    ColLoadTiled<T> cl{W1, rows, to_map(d->in_y), ntiles, p.log_k, wstride};
     MidMul<T> mm{d->mul_kind, d->mul_conj, reinterpret_cast<const cx<T>*>(d->mul), reinterpret_cast<const cx<T>*>(d->mul_x),
-                 d->mul_ld, int(N)};
-    ColStoreTiled<T> cst{W2, int(M), ntiles, p.log_k};
-    int rc = launch_col_mul<T>(p.logm, cl, mm, cst, twM, ntiles, p.log_k > 1 ? p.log_k : 1, st);
+                 d->mul_ld, int(N), d->mul_bstride, d->mul_x_bstride};
+    ColStoreTiled<T> cst{W2, int(M), ntiles, p.log_k, wstride};
+    int rc = launch_col_mul<T>(p.logm, cl, mm, cst, twM, ntiles, p.log_k > 1 ? p.log_k : 1, st, nb);
     if (rc) return rc;
     // pass C: inverse row transforms of the rows inside the output window -> natural output, scale applied here.
     // Sequence s is stored row s of W2 (= logical row s); the output row map rotates / crops it.
-    RowLoadTiled<T> rl{W2, int(M), ltl, 0, int(M), 1};
-    RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), int(M), 1, T(d->scale), 1, to_map(d->out_y)};
-    return launch_row_from_tiled<T>(p.logn, row_variant(d->dtype, p.logn), rl, rs, twN, int(M), st);
+    RowLoadTiled<T> rl{W2, int(M), ltl, 0, int(M), 1, wstride};
+    RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), int(M), 1, T(d->scale), 1, to_map(d->out_y),
+                      d->out_bstride};
+    return launch_row_from_tiled<T>(p.logn, row_variant(d->dtype, p.logn), rl, rs, twN, int(M), st, nb);
+}
+
+template <typename T>
+static int fused_run(const pm_fft2_desc* d, const FusedPlan& p, const void* in, void* out, void* ws, hipStream_t st) {
+    for (int64_t b0 = 0; b0 < p.nbatch; b0 += p.chunk) {
+        const int nb = int(p.nbatch - b0 < p.chunk ? p.nbatch - b0 : p.chunk);
+        pm_fft2_desc dd = *d;
+        dd.mul = offset_elems(d->mul, b0 * d->mul_bstride, sizeof(cx<T>));
+        dd.mul_x = offset_elems(d->mul_x, b0 * d->mul_x_bstride, sizeof(cx<T>));
+        int rc = fused_run_chunk<T>(&dd, p, offset_elems(in, b0 * d->in_bstride, sizeof(cx<T>)),
+                                    const_cast<void*>(offset_elems(out, b0 * d->out_bstride, sizeof(cx<T>))), ws, st, nb);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 static int check_fft2(const pm_fft2_desc* d) {
@@ -302,6 +373,13 @@ static int check_fft2(const pm_fft2_desc* d) {
     if (d->in_y.n != d->out_y.n || d->in_x.n != d->out_x.n)
         return fail(PM_ERR_ARG, "pm_fft2: input and output views must share the transform size");
     if (d->in_ld < d->in_x.len || d->out_ld < d->out_x.len) return fail(PM_ERR_ARG, "pm_fft2: leading dimension < row length");
+    if (d->batch < 0 || d->batch > 65535) return fail(PM_ERR_ARG, "pm_fft2: batch = %lld must be in [0, 65535]", (long long)d->batch);
+    if (d->batch > 1) {
+        if (d->in_bstride < 0 || d->out_bstride < 0 || d->mul_bstride < 0 || d->mul_x_bstride < 0)
+            return fail(PM_ERR_ARG, "pm_fft2: batch strides must be >= 0");
+        if (d->out_bstride < (d->out_y.len > 0 ? (d->out_y.len - 1) * d->out_ld + d->out_x.len : 0))
+            return fail(PM_ERR_ARG, "pm_fft2: out_bstride = %lld makes the outputs of a batch overlap", (long long)d->out_bstride);
+    }
     const int64_t lim = int64_t(1) << 15;
     if ((engine_log2(d->in_x.n) < 0 && d->in_x.n > lim) || (engine_log2(d->in_y.n) < 0 && d->in_y.n > lim))
         return fail(PM_ERR_UNSUPPORTED, "pm_fft2: length %lld x %lld: powers of two up to 8192 run on the FFT engine, other "
@@ -408,7 +486,7 @@ size_t pm_fft2_mul_ifft2_workspace(const pm_fft2_desc* d) {
     if (check_fft2(d)) return 0;
     FusedPlan p;
     if (!plan_fused(d, p)) return 0;
-    return ((p.w1_bytes + 255) & ~size_t(255)) + p.w2_bytes;
+    return p.ws_bytes;
 }
 
 int pm_fft2_mul_ifft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes, void* stream) {
@@ -420,7 +498,7 @@ int pm_fft2_mul_ifft2(const pm_fft2_desc* d, const void* in, void* out, void* wo
     if (!plan_fused(d, p))
         return fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: both lengths must be powers of two <= 8192 (got %lld x %lld); "
                     "compose two pm_fft2 calls instead", (long long)d->in_y.n, (long long)d->in_x.n);
-    const size_t need = ((p.w1_bytes + 255) & ~size_t(255)) + p.w2_bytes;
+    const size_t need = p.ws_bytes;
     if (!workspace || workspace_bytes < need)
         return fail(PM_ERR_WORKSPACE, "pm_fft2_mul_ifft2: workspace of %zu bytes required, %zu given", need, workspace_bytes);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

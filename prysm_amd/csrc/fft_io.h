@@ -35,6 +35,7 @@ struct RowLoadNat {
     int nseq;       // number of sequences (memory rows)
     int conj;
     int nt;         // non-temporal loads (input is read exactly once)
+    int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
 };
 
 template <typename T>
@@ -42,6 +43,7 @@ struct RowStoreTiled {
     cx<T>* dst;
     int nseq;       // rows of the intermediate
     int log_tc;     // log2(LAYOUT tile width TL): one row of a layout tile is TL*sizeof(complex) contiguous bytes
+    int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
 };
 
 template <typename T>
@@ -54,6 +56,7 @@ struct RowStoreNat {
     T scale;
     int use_ay;     // 0: sequence s is written to memory row s; 1: to row ay.map(s) (rotation / crop of rows)
     AxisMap ay;
+    int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
 };
 
 // row pass reading the tiled intermediate (third pass of the fused fft2 -> multiply -> ifft2)
@@ -65,6 +68,7 @@ struct RowLoadTiled {
     int row0;       // first stored row to transform (sequence s reads stored row row0 + s)
     int nseq;
     int conj;
+    int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
 };
 
 // column pass writing back into the tiled layout (second pass of the fused operation)
@@ -74,6 +78,7 @@ struct ColStoreTiled {
     int nrows;      // rows of the destination (the full transform length)
     int ntiles;
     int log_k;
+    int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
 };
 
 // spectral multiplier applied between the forward and inverse column transforms, indexed by the
@@ -86,6 +91,8 @@ struct MidMul {
     const cx<T>* mul_x;   // SEPARABLE: hx[c]
     int64_t ld;
     int ncols;
+    int64_t bstride;   // elements between the multipliers (FULL) / the hy vectors (SEPARABLE) of consecutive fields;
+    int64_t bstride_x; // ... between the hx vectors.  0: one multiplier for the whole batch
 };
 
 template <typename T>
@@ -95,6 +102,7 @@ struct ColLoadTiled {
     AxisMap ay;     // logical row -> stored row
     int ntiles;     // number of TC-wide tiles (workgroup units)
     int log_k;      // layout tile = 2^log_k workgroup tiles wide (TL = TC << log_k)
+    int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
 };
 
 template <typename T>
@@ -105,6 +113,7 @@ struct ColLoadNat {
     int ncols;      // number of columns in memory
     int conj;
     int vec_ok;     // base and ld allow 16-byte loads of column pairs
+    int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
 };
 
 template <typename T>
@@ -124,6 +133,9 @@ struct ColStoreNat {
     int64_t mul_ld;
     int vec_ok;
     int nt;         // non-temporal stores on the fast path (output is written exactly once)
+    int64_t bstride;       // OUTPUT elements (complex, or real for the |.|^2 epilogues) between fields of a batch
+    int64_t mul_bstride;   // elements between per-field multipliers (FULL) / hy vectors (SEPARABLE); 0: shared
+    int64_t mul_bstride_x; // elements between per-field hx vectors
 };
 
 // slot rotation helper: memory index (before the window offset) of register slot m.
@@ -186,6 +198,31 @@ template <typename T> inline void nt_store_cx(cx<T>* p, cx<T> v) { *p = v; }
 template <typename T> inline void nt_store_v4(Vec4<T>* p, Vec4<T> v) { *p = v; }
 template <typename T> inline void nt_store_s(T* p, T v) { *p = v; }
 #endif
+
+// ------------------------------------------------------------------ batches
+// Field b of a batch (blockIdx.y) is the same problem at an offset: a copy of the parameter block with
+// the base pointers advanced.  The parameter blocks live in SGPRs, so this is a handful of scalar ops.
+template <typename T> PM_HD RowLoadNat<T> at_batch(RowLoadNat<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD RowStoreTiled<T> at_batch(RowStoreTiled<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD RowStoreNat<T> at_batch(RowStoreNat<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD RowLoadTiled<T> at_batch(RowLoadTiled<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD ColStoreTiled<T> at_batch(ColStoreTiled<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD ColLoadTiled<T> at_batch(ColLoadTiled<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD ColLoadNat<T> at_batch(ColLoadNat<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD MidMul<T> at_batch(MidMul<T> p, int b) {
+    p.mul += int64_t(b) * p.bstride;
+    if (p.mul_x) p.mul_x += int64_t(b) * p.bstride_x;
+    return p;
+}
+template <typename T> PM_HD ColStoreNat<T> at_batch(ColStoreNat<T> p, int b) {
+    if (p.epilogue == EPI_NONE)
+        p.dst = reinterpret_cast<cx<T>*>(p.dst) + int64_t(b) * p.bstride;
+    else
+        p.dst = reinterpret_cast<T*>(p.dst) + int64_t(b) * p.bstride;
+    if (p.mul) p.mul += int64_t(b) * p.mul_bstride;
+    if (p.mul_x) p.mul_x += int64_t(b) * p.mul_bstride_x;
+    return p;
+}
 
 // ------------------------------------------------------------------ row mode
 // FULL: the window covers the whole axis and the sequence exists -> no per-element predicates at all

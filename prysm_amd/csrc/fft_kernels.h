@@ -59,19 +59,21 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
     int unit = group_remap(blockIdx.x, gridDim.x, log_g);
     if (COL) unit = unit * C::BO + pos.bo;
     cx<typename C::T> v[C::E][C::P];
+    const L lpb = at_batch(lp, blockIdx.y);   // blockIdx.y: field of a batch
+    const S spb = at_batch(sp, blockIdx.y);
     if constexpr (use_tw_lds<C, COL, VAR>()) {
         // table first (two gathers + two ds_write per thread), then the tile loads; the barrier that publishes
         // the table is passed while the tile loads are still in flight
         cx<typename C::T>* tab = reinterpret_cast<cx<typename C::T>*>(pm_smem + C::LDS_BYTES);
         fill_tw_lds<C>(tab, threadIdx.x, C::NT, tw);
-        load<C>(lp, unit, pos, v);
+        load<C>(lpb, unit, pos, v);
         __syncthreads();
         fft_run_twlds<C>(v, pos, pm_smem, tab);
     } else {
-        load<C>(lp, unit, pos, v);
+        load<C>(lpb, unit, pos, v);
         fft_run<C>(v, pos, pm_smem, tw);
     }
-    store<C>(sp, unit, pos, v);
+    store<C>(spb, unit, pos, v);
 }
 
 // Fused spectral-multiply column pass: forward transform, multiply by H, inverse transform -- all on the
@@ -82,12 +84,15 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
 // 55 vs 75 us against two pm_fft2 calls.  (Built without the SLP vectorizer -- with it this kernel spilled > 150
 // VGPRs under the 128-register cap of the 1024-thread workgroup and lost.)
 template <typename C>
-__global__ void __launch_bounds__(C::NT) fft_col_mul_kernel(const ColLoadTiled<typename C::T> lp, const MidMul<typename C::T> mp,
-                                                            const ColStoreTiled<typename C::T> sp,
+__global__ void __launch_bounds__(C::NT) fft_col_mul_kernel(const ColLoadTiled<typename C::T> lp0, const MidMul<typename C::T> mp0,
+                                                            const ColStoreTiled<typename C::T> sp0,
                                                             const cx<typename C::T>* __restrict__ tw, const int log_g) {
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
     const int unit = group_remap(blockIdx.x, gridDim.x, log_g) * C::BO + pos.bo;
+    const auto lp = at_batch(lp0, blockIdx.y);
+    const auto mp = at_batch(mp0, blockIdx.y);
+    const auto sp = at_batch(sp0, blockIdx.y);
     cx<typename C::T> v[C::E][C::P];
     load<C>(lp, unit, pos, v);
     fft_run<C>(v, pos, pm_smem, tw);
@@ -107,7 +112,7 @@ __global__ void __launch_bounds__(C::NT) fft_col_mul_kernel(const ColLoadTiled<t
 
 template <typename T, int LOGN>
 int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const ColStoreTiled<T>& sp, const cx<T>* tw, int ntiles,
-                       int log_g, hipStream_t st) {
+                       int log_g, hipStream_t st, int nbatch) {
     using C = typename ColCfgSel<T, LOGN, 0>::type;
     auto kern = fft_col_mul_kernel<C>;
     if (C::LDS_BYTES > 48 * 1024) {
@@ -117,17 +122,17 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const Col
     }
     const int grid = (ntiles + C::BO - 1) / C::BO;
     if (grid <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, st, lp, mp, sp, tw, log_g);
+    hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), C::LDS_BYTES, st, lp, mp, sp, tw, log_g);
     return int(hipGetLastError());
 }
 
 template <typename T>
 int launch_col_mul_impl(int logm, const ColLoadTiled<T>& lp, const MidMul<T>& mp, const ColStoreTiled<T>& sp, const cx<T>* tw,
-                        int ntiles, int log_g, hipStream_t st) {
+                        int ntiles, int log_g, hipStream_t st, int nbatch) {
     switch (logm) {
 #define PM_CASE(k) \
     case k:        \
-        return launch_col_mul_one<T, k>(lp, mp, sp, tw, ntiles, log_g, st);
+        return launch_col_mul_one<T, k>(lp, mp, sp, tw, ntiles, log_g, st, nbatch);
         PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
         PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASE(11) PM_CASE(12) PM_CASE(13)
 #undef PM_CASE
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(C::NT, (C::NT <= 256 ? 4 : 2)) fft_row_persist
 }
 
 template <typename T, bool COL, int LOGN, int VAR, typename L, typename S>
-int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st) {
+int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st, int nbatch) {
     using Sel = typename std::conditional<COL, ColCfgSel<T, LOGN, VAR>, RowCfgSel<T, LOGN, VAR>>::type;
     using C = typename Sel::type;
     auto kern = fft_kernel<C, COL, (COL ? VAR : 0), L, S>;
@@ -191,7 +196,9 @@ int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, 
     }
     const int grid = (units + C::BO - 1) / C::BO;
     if (grid <= 0) return 0;
+    if (nbatch <= 0) return 0;
     if constexpr (!COL && VAR == 2) {
+        if (nbatch == 1) {
         // persistent, double-buffered (row pass, tuning row_var = 2)
         auto pk = fft_row_persistent_kernel<C, L, S>;
         if (C::LDS_BYTES > 48 * 1024) {
@@ -206,22 +213,23 @@ int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, 
         if (pgrid > grid) pgrid = grid;
         hipLaunchKernelGGL(pk, dim3(pgrid), dim3(C::NT), C::LDS_BYTES, st, lp, sp, tw, grid, log_g);
         return int(hipGetLastError());
+        }   // batches take the plain kernel (the grid already holds many workgroups per CU)
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
+    hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
     return int(hipGetLastError());
 }
 
 template <typename T, bool COL, typename L, typename S>
-int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st) {
+int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st, int nbatch) {
     switch (logn) {
 #define PM_CASE(k) \
     case k:        \
-        return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st);
+        return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st, nbatch);
 #define PM_CASEV(k)                                                       \
     case k:                                                               \
-        if (var == 1) return launch_one<T, COL, k, 1, L, S>(lp, sp, tw, units, log_g, st); \
-        if (var == 2 && !COL) return launch_one<T, COL, k, (COL ? 0 : 2), L, S>(lp, sp, tw, units, log_g, st); \
-        return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st);
+        if (var == 1) return launch_one<T, COL, k, 1, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        if (var == 2 && !COL) return launch_one<T, COL, k, (COL ? 0 : 2), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st, nbatch);
         PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
         PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASEV(11) PM_CASEV(12) PM_CASEV(13)
 #undef PM_CASE
@@ -232,11 +240,11 @@ int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int
 }
 
 // entry points, one explicit instantiation per .hip file
-template <typename T> int launch_row_tiled(int logn, int var, const RowLoadNat<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t);
-template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t);
-template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
-template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
-template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
-template <typename T> int launch_row_from_tiled(int logn, int var, const RowLoadTiled<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t);
+template <typename T> int launch_row_tiled(int logn, int var, const RowLoadNat<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_row_from_tiled(int logn, int var, const RowLoadTiled<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t, int nbatch = 1);
 
 }  // namespace pm

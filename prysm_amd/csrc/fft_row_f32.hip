@@ -1,13 +1,13 @@
 // Row-pass FFT kernels, float precision (explicit instantiation; see fft_kernels.h).
 #include "fft_kernels.h"
 namespace pm {
-template <> int launch_row_tiled<float>(int logn, int var, const RowLoadNat<float>& l, const RowStoreTiled<float>& s, const cx<float>* tw, int nseq, int log_g, hipStream_t st) {
-    return launch_fft<float, false>(logn, var, l, s, tw, nseq, log_g, st);
+template <> int launch_row_tiled<float>(int logn, int var, const RowLoadNat<float>& l, const RowStoreTiled<float>& s, const cx<float>* tw, int nseq, int log_g, hipStream_t st, int nbatch) {
+    return launch_fft<float, false>(logn, var, l, s, tw, nseq, log_g, st, nbatch);
 }
-template <> int launch_row_nat<float>(int logn, int var, const RowLoadNat<float>& l, const RowStoreNat<float>& s, const cx<float>* tw, int nseq, int log_g, hipStream_t st) {
-    return launch_fft<float, false>(logn, var, l, s, tw, nseq, log_g, st);
+template <> int launch_row_nat<float>(int logn, int var, const RowLoadNat<float>& l, const RowStoreNat<float>& s, const cx<float>* tw, int nseq, int log_g, hipStream_t st, int nbatch) {
+    return launch_fft<float, false>(logn, var, l, s, tw, nseq, log_g, st, nbatch);
 }
-template <> int launch_row_from_tiled<float>(int logn, int var, const RowLoadTiled<float>& l, const RowStoreNat<float>& s, const cx<float>* tw, int nseq, hipStream_t st) {
-    return launch_fft<float, false>(logn, var == 2 ? 0 : var, l, s, tw, nseq, 0, st);
+template <> int launch_row_from_tiled<float>(int logn, int var, const RowLoadTiled<float>& l, const RowStoreNat<float>& s, const cx<float>* tw, int nseq, hipStream_t st, int nbatch) {
+    return launch_fft<float, false>(logn, var == 2 ? 0 : var, l, s, tw, nseq, 0, st, nbatch);
 }
 }  // namespace pm

@@ -1,13 +1,13 @@
 // Row-pass FFT kernels, double precision (explicit instantiation; see fft_kernels.h).
 #include "fft_kernels.h"
 namespace pm {
-template <> int launch_row_tiled<double>(int logn, int var, const RowLoadNat<double>& l, const RowStoreTiled<double>& s, const cx<double>* tw, int nseq, int log_g, hipStream_t st) {
-    return launch_fft<double, false>(logn, var, l, s, tw, nseq, log_g, st);
+template <> int launch_row_tiled<double>(int logn, int var, const RowLoadNat<double>& l, const RowStoreTiled<double>& s, const cx<double>* tw, int nseq, int log_g, hipStream_t st, int nbatch) {
+    return launch_fft<double, false>(logn, var, l, s, tw, nseq, log_g, st, nbatch);
 }
-template <> int launch_row_nat<double>(int logn, int var, const RowLoadNat<double>& l, const RowStoreNat<double>& s, const cx<double>* tw, int nseq, int log_g, hipStream_t st) {
-    return launch_fft<double, false>(logn, var, l, s, tw, nseq, log_g, st);
+template <> int launch_row_nat<double>(int logn, int var, const RowLoadNat<double>& l, const RowStoreNat<double>& s, const cx<double>* tw, int nseq, int log_g, hipStream_t st, int nbatch) {
+    return launch_fft<double, false>(logn, var, l, s, tw, nseq, log_g, st, nbatch);
 }
-template <> int launch_row_from_tiled<double>(int logn, int var, const RowLoadTiled<double>& l, const RowStoreNat<double>& s, const cx<double>* tw, int nseq, hipStream_t st) {
-    return launch_fft<double, false>(logn, var == 2 ? 0 : var, l, s, tw, nseq, 0, st);
+template <> int launch_row_from_tiled<double>(int logn, int var, const RowLoadTiled<double>& l, const RowStoreNat<double>& s, const cx<double>* tw, int nseq, hipStream_t st, int nbatch) {
+    return launch_fft<double, false>(logn, var == 2 ? 0 : var, l, s, tw, nseq, 0, st, nbatch);
 }
 }  // namespace pm

@@ -36,12 +36,12 @@ template <typename T>
 int direct_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, const cx<double>* tw, hipStream_t st);
 
 // engine launchers (fft_row_*.hip / fft_col_*.hip); `var` = tuning variant (see fft_kernels.h)
-template <typename T> int launch_row_tiled(int logn, int var, const RowLoadNat<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t);
-template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t);
-template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
-template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
-template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
-template <typename T> int launch_row_from_tiled(int logn, int var, const RowLoadTiled<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t);
+template <typename T> int launch_row_tiled(int logn, int var, const RowLoadNat<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_row_from_tiled(int logn, int var, const RowLoadTiled<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t, int nbatch = 1);
 // tile width of the column pass; MUST match ColCfgSel in fft_kernels.h (CI * E)
 inline int col_tile_width_for(int dtype, int logm, int var) {
     (void)var;
@@ -61,6 +61,8 @@ struct Tuning {
     int gemm_bk = 0;          // 0 default K-tile depth, 32 doubles it
     int gemm_min_wgs = 1024;   // split K until the GEMM launch has at least this many workgroups
     int row_log_g = 1;  // sibling group of row-pass workgroups (rows q .. q+2^g-1 on one XCD)
+    int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
+                             // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)
 };
 Tuning& tuning();
 // measured on MI355X (profiles/r01/sweep*.log): with predicate-free full-window loads the plain row kernel is

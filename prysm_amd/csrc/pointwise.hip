@@ -85,6 +85,25 @@ __global__ void abs2_kernel(int64_t rows, int64_t cols, const cx<T>* in, int64_t
     }
 }
 
+// ---------------------------------------------------------------- weighted sum of modes
+// out (+)= sum_b w[b] * modes[b]; the weights ride in the kernel arguments (SGPRs), 32 modes per launch
+template <typename T>
+struct ModeWeights {
+    T w[32];
+};
+template <typename T>
+__global__ void sum_modes_kernel(int64_t rows, int64_t cols, const T* __restrict__ modes, int64_t mstride, int64_t ldm,
+                                 const ModeWeights<T> mw, int nb, int acc, T* o, int64_t ldo) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < rows; r += int64_t(gridDim.y) * blockDim.y) {
+        const T* m = modes + r * ldm + c;
+        T a = acc ? o[r * ldo + c] : T(0);
+        for (int b = 0; b < nb; ++b) a += mw.w[b] * m[int64_t(b) * mstride];
+        o[r * ldo + c] = a;
+    }
+}
+
 // ---------------------------------------------------------------- pupil synthesis
 template <typename T, typename A>
 __global__ void pupil_kernel(int64_t rows, int64_t cols, const A* amp, int64_t lda, const T* opd, int64_t ldp,
@@ -221,6 +240,36 @@ int pm_abs2(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t i
             hipLaunchKernelGGL((abs2_kernel<double, 0>), grid, block, 0, st, rows, cols, (const cx<double>*)in, in_ld, (double*)out, out_ld, 1.0);
     } else
         return fail(PM_ERR_ARG, "pm_abs2: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
+}
+
+int pm_sum_modes(int32_t dtype, int64_t nmodes, int64_t rows, int64_t cols, const void* modes, int64_t mode_stride,
+                 int64_t modes_ld, const double* weights, int32_t accumulate, void* out, int64_t out_ld, void* stream) {
+    if (!modes || !out || (!weights && nmodes > 0) || rows < 0 || cols < 0 || nmodes < 0) return fail(PM_ERR_ARG, "pm_sum_modes: bad argument");
+    if (dtype != PM_C64 && dtype != PM_C128) return fail(PM_ERR_ARG, "pm_sum_modes: dtype must be PM_C64 (float images) or PM_C128 (double)");
+    if (rows == 0 || cols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(rows, cols, block);
+    hipStream_t st = PM_STREAM(stream);
+    int acc = accumulate ? 1 : 0;
+    if (nmodes == 0 && acc) return 0;
+    int64_t b0 = 0;
+    do {   // 32 modes per launch; an empty sum still writes zeros
+        const int nb = int(nmodes - b0 < 32 ? nmodes - b0 : 32);
+        if (dtype == PM_C64) {
+            ModeWeights<float> mw;
+            for (int i = 0; i < 32; ++i) mw.w[i] = i < nb ? float(weights[b0 + i]) : 0.f;
+            hipLaunchKernelGGL(sum_modes_kernel<float>, grid, block, 0, st, rows, cols, (const float*)modes + b0 * mode_stride, mode_stride,
+                               modes_ld, mw, nb, acc, (float*)out, out_ld);
+        } else {
+            ModeWeights<double> mw;
+            for (int i = 0; i < 32; ++i) mw.w[i] = i < nb ? weights[b0 + i] : 0.0;
+            hipLaunchKernelGGL(sum_modes_kernel<double>, grid, block, 0, st, rows, cols, (const double*)modes + b0 * mode_stride,
+                               mode_stride, modes_ld, mw, nb, acc, (double*)out, out_ld);
+        }
+        acc = 1;
+        b0 += 32;
+    } while (b0 < nmodes);
     return int(hipGetLastError());
 }
 

@@ -10,6 +10,8 @@ rank accumulates ``sum_k w_k |E_k|^2`` for its contiguous block of wavelengths i
 sum-reduce of the real image (RCCL over xGMI; `backend="nccl"` is RCCL on ROCm) produces the
 incoherent sum.  One process per GPU; world size 1 needs no process group.
 """
+import math
+
 import torch
 import torch.distributed as dist
 
@@ -51,21 +53,63 @@ def incoherent_sum(propagate, wavelengths, weights, *, group=None, reduce_to_all
     return acc
 
 
+def _fields_per_launch(shape, cdtype_bytes, Q, limit_bytes=1 << 30):
+    """How many wavelengths go into one batched launch: bounded by ~1 GiB of stack (pupils + intensities)."""
+    m, n = shape
+    M, N = math.ceil(m * Q), math.ceil(n * Q)
+    per_field = m * n * cdtype_bytes + M * N * cdtype_bytes // 2
+    return max(1, min(64, limit_bytes // per_field))
+
+
 def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, focal_dx=None, samples=None,
-                      kind='mdft', group=None, reduce_to_all=True):
+                      kind='mdft', group=None, reduce_to_all=True, batched=True):
     """Polychromatic PSF of a pupil (amplitude, OPD in nm) -- the how-to's recipe on N GPUs.
 
-    Q given            : per-wavelength FFT focus with fused |.|^2 accumulate (multi-field throughput
-                         variant; focal sampling is chromatic, as the reference docs note).
+    Q given            : FFT focus per wavelength with the |.|^2 fused into the transform (multi-field throughput
+                         variant; focal sampling is chromatic, as the reference docs note).  With `batched`
+                         (default) the wavelengths of a rank are propagated as stacks -- one launch pair per stack,
+                         then one weighted sum (sum_of_2d_modes) -- which is what makes <= 1024^2 pupils
+                         bandwidth-bound instead of launch-bound; batched=False is the field-by-field loop with
+                         the accumulate epilogue.
     focal_dx + samples : per-wavelength fixed-sampling focus (prepare_executor + focus_dft, `kind`),
                          all wavelengths on one focal grid -- the variant of the how-to.
     """
     from . import _lib as L
     from . import _ops
     from .propagation import Wavefront, focus_intensity
+    from .propagation.wavefront import _synth_args
 
     amp = L.as_device(amplitude)
     phs = L.as_device(opd)
+
+    if Q is not None and batched:
+        if len(wavelengths) != len(weights):
+            raise ValueError('wavelengths and weights must have the same length')
+        use_dist = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if use_dist else 0
+        world = dist.get_world_size(group) if use_dist else 1
+        lo, hi = shard_bounds(len(wavelengths), rank, world)
+        a, o, cd = _synth_args(amp, phs)
+        m, n = o.shape
+        M, N = math.ceil(m * Q), math.ceil(n * Q)
+        acc = torch.zeros((M, N), dtype=L._REAL_OF[cd], device=o.device)
+        step = _fields_per_launch((m, n), torch.empty((), dtype=cd).element_size(), Q)
+        for b0 in range(lo, hi, step):
+            b1 = min(hi, b0 + step)
+            stack = torch.empty((b1 - b0, m, n), dtype=cd, device=o.device)
+            for i, k in enumerate(range(b0, b1)):
+                kk = 2 * math.pi / float(wavelengths[k]) / 1e3
+                if a is not None and a.is_complex():
+                    stack[i] = Wavefront.from_amp_and_phase(a, o, float(wavelengths[k]), dx).data
+                else:
+                    _ops.pupil_synth(a, o, kk, cd, out=stack[i])     # synthesised straight into the stack
+            _ops.sum_modes(focus_intensity(stack, Q), [float(w) for w in weights[b0:b1]], out=acc, accumulate=True)
+        if world > 1:
+            if reduce_to_all:
+                dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+            else:
+                dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM, group=group)
+        return acc
 
     def propagate(wvl, w, acc):
         wf = Wavefront.from_amp_and_phase(amp, phs, wvl, dx)

@@ -40,20 +40,35 @@ def _field(field, other_dtype):
     return f
 
 
+def _tf_vectors(shape, wvl, dx, z, dtype, batch):
+    """(hy, hx) of the separable transfer function; one pair per field when wvl / z are sequences (stack input)."""
+    multi = [v for v in (wvl, z) if hasattr(v, '__len__')]
+    if not multi:
+        return _ops.as_tf_vectors(shape, wvl, dx, z, dtype)
+    if batch is None or any(len(v) != batch for v in multi):
+        raise ValueError('per-field wvl / z need a (batch, rows, cols) stack with one entry per field')
+    wv = list(wvl) if hasattr(wvl, '__len__') else [wvl] * batch
+    zz = list(z) if hasattr(z, '__len__') else [z] * batch
+    pairs = [_ops.as_tf_vectors(shape, float(w), dx, float(zi), dtype) for w, zi in zip(wv, zz)]
+    return torch.stack([p[0] for p in pairs]), torch.stack([p[1] for p in pairs])
+
+
 def angular_spectrum(field, wvl, dx, z, Q=2, tf=None):
-    """Propagate a field via the angular spectrum method (angular_spectrum.py:9-42)."""
+    """Propagate a field via the angular spectrum method (angular_spectrum.py:9-42).
+
+    Extension: `field` may be a (batch, rows, cols) stack, with `wvl` / `z` scalars or one value per field."""
     if tf is not None:
         tf = L.as_complex(tf)
         f = _field(field, tf.dtype)
         if tf.dtype != f.dtype:
             tf = tf.to(f.dtype)
-        M, N = f.shape
+        M, N = f.shape[-2:]
         return _ops.fft2_mul_ifft2(f, scale=1.0 / (M * N), mul=tf.contiguous())
     f = _field(field, _cdtype())
-    m, n = f.shape
+    m, n = f.shape[-2:]
     M, N = _padded_shape((m, n), Q)
     in_off = (math.ceil((M - m) / 2), math.ceil((N - n) / 2))
-    hy, hx = _ops.as_tf_vectors((M, N), wvl, dx, z, f.dtype)
+    hy, hx = _tf_vectors((M, N), wvl, dx, z, f.dtype, f.shape[0] if f.dim() == 3 else None)
     return _ops.fft2_mul_ifft2(f, scale=1.0 / (M * N), mul=hy, mul_x=hx, shape=(M, N), in_off=in_off)
 
 
@@ -64,12 +79,12 @@ def angular_spectrum_adjoint(field, wvl, dx, z, Q=2, tf=None):
         f = _field(field, tf.dtype)
         if tf.dtype != f.dtype:
             tf = tf.to(f.dtype)
-        M, N = f.shape
+        M, N = f.shape[-2:]
         return _ops.fft2_mul_ifft2(f, scale=1.0 / (M * N), mul=tf.contiguous(), mul_conj=True)
     f = _field(field, _cdtype())
-    M, N = f.shape
+    M, N = f.shape[-2:]
     out_shape = _shape_before_pad((M, N), Q)
-    hy, hx = _ops.as_tf_vectors((M, N), wvl, dx, z, f.dtype)
+    hy, hx = _tf_vectors((M, N), wvl, dx, z, f.dtype, f.shape[0] if f.dim() == 3 else None)
     if out_shape == (M, N):
         return _ops.fft2_mul_ifft2(f, scale=1.0 / (M * N), mul=hy, mul_x=hx, mul_conj=True)
     out_off = (math.ceil((M - out_shape[0]) / 2), math.ceil((N - out_shape[1]) / 2))

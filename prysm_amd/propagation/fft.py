@@ -1,5 +1,9 @@
 """FFT-based pupil <-> focal propagation (prysm/propagation/fft.py) as ONE fused device call each.
 
+Extension over the reference: every routine here also takes a (batch, rows, cols) stack of fields
+(wavelengths / field points of one model) and propagates the whole stack in one launch pair --
+small fields (<= 1024^2) are launch- and latency-bound one at a time.
+
 The reference composes pad2d -> ifftshift -> fft2 -> fftshift (five full-array sweeps around the
 transform).  Here the zero padding is a load-side window, both shifts are index rotations, the
 'ortho' scale rides on the last store and the crop of the adjoints is a store-side window: the
@@ -15,9 +19,9 @@ from ._kernels import _padded_shape, _shape_before_pad
 def _centered_fft2(x, Q, direction, crop_to=None):
     """fftshift(fft2 | ifft2(ifftshift(pad2d(x, Q)), norm='ortho')) [+ crop_center]."""
     x = L.as_complex(x)
-    if x.dim() != 2:
-        raise ValueError('propagation routines operate on 2-D arrays')
-    m, n = x.shape
+    if x.dim() not in (2, 3):
+        raise ValueError('propagation routines operate on 2-D arrays (or a (batch, rows, cols) stack of them)')
+    m, n = x.shape[-2:]
     M, N = _padded_shape((m, n), Q)
     in_off = (math.ceil((M - m) / 2), math.ceil((N - n) / 2))       # pad2d: prysm/fttools.py:88-89
     shift = (M // 2, N // 2)   # ifftshift on the way in, fftshift on the way out (fft.py:24)
@@ -36,7 +40,7 @@ def focus(wavefunction, Q):
 
 def focus_adjoint(wavefunction, Q):
     """Adjoint of focus (fft.py:28-45): inverse transform of the gradient, then crop to int(s//Q)."""
-    shape = tuple(wavefunction.shape)
+    shape = tuple(wavefunction.shape[-2:])
     return _centered_fft2(wavefunction, 1, +1, crop_to=_shape_before_pad(shape, Q))
 
 
@@ -47,7 +51,7 @@ def unfocus(wavefunction, Q):
 
 def unfocus_adjoint(wavefunction, Q):
     """Adjoint of unfocus (fft.py:68-85)."""
-    shape = tuple(wavefunction.shape)
+    shape = tuple(wavefunction.shape[-2:])
     return _centered_fft2(wavefunction, 1, -1, crop_to=_shape_before_pad(shape, Q))
 
 
@@ -60,7 +64,7 @@ def focus_intensity(wavefunction, Q, out=None, weight=None):
     polychromatic recipe).
     """
     x = L.as_complex(wavefunction)
-    m, n = x.shape
+    m, n = x.shape[-2:]
     M, N = _padded_shape((m, n), Q)
     in_off = (math.ceil((M - m) / 2), math.ceil((N - n) / 2))
     shift = (M // 2, N // 2)

@@ -44,6 +44,16 @@ def _real_opd(phase):
     return t
 
 
+def _synth_args(amplitude, phase):
+    """(amplitude, OPD, complex dtype) of from_amp_and_phase with numpy's result-type rules applied."""
+    opd = _real_opd(phase)
+    amp = None if amplitude is None else L.as_device(amplitude)
+    cd = L._COMPLEX_OF[opd.dtype]
+    if amp is not None and amp.dtype == torch.float64 and cd == torch.complex64:
+        cd, opd = torch.complex128, opd.to(torch.float64)
+    return amp, opd, cd
+
+
 class Wavefront:
     """(Complex) representation of a wavefront (wavefront.py:35-56)."""
 
@@ -62,11 +72,7 @@ class Wavefront:
         reference.
         """
         if phase is not None:
-            opd = _real_opd(phase)
-            amp = None if amplitude is None else L.as_device(amplitude)
-            cd = L._COMPLEX_OF[opd.dtype]
-            if amp is not None and amp.dtype == torch.float64 and cd == torch.complex64:
-                cd, opd = torch.complex128, opd.to(torch.float64)   # numpy result type
+            amp, opd, cd = _synth_args(amplitude, phase)
             k = 2 * math.pi / wavelength / 1e3
             if amp is not None and amp.is_complex():
                 P = _ops.cmul(amp.to(cd), _ops.pupil_synth(None, opd, k, cd))

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     for s in declared_symbols():
         assert hasattr(lib, s), f'{s} declared in prysm_amd.h but not exported'
         assert s in _lib.SIGNATURES, f'{s} has no ctypes signature in prysm_amd/_lib.py'
-    assert lib.pm_version() == 100
+    assert lib.pm_version() == 101
 
 
 def test_argument_errors_are_reported_without_a_gpu(lib):
@@ -61,6 +61,22 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     d.in_y = d.in_x = L.pm_axis(4096, 2048, 1024, 2048)
     d.in_ld = 2048
     assert lib.pm_fft2_workspace(ctypes.byref(d)) == 2048 * 4096 * 8
+    # batches: the workspace holds one chunk of fields (<= 128 MiB of intermediates per launch pair), not the batch
+    d.in_y = d.in_x = d.out_y = d.out_x = L.pm_axis(1024, 1024, 0, 512)
+    d.in_ld = d.out_ld = 1024
+    d.batch, d.in_bstride, d.out_bstride = 4, 1024 * 1024, 1024 * 1024
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 4 * 1024 * 1024 * 8
+    d.batch = 100
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 16 * 1024 * 1024 * 8
+    d.out_bstride = 1000          # outputs of consecutive fields would overlap
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 0
+    assert lib.pm_fft2(ctypes.byref(d), ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0, None) == L.PM_ERR_ARG
+    assert b'out_bstride' in lib.pm_last_error()
+    d.batch = d.in_bstride = d.out_bstride = 0
+    d.in_ld = 2048
+    d.in_y = d.in_x = L.pm_axis(4096, 2048, 1024, 2048)
+    d.out_y = d.out_x = ax
+    d.out_ld = 4096
     # lengths beyond both the engine and the direct DFT are refused loudly
     d.in_y = d.out_y = L.pm_axis(40000, 40000, 0, 0)
     assert lib.pm_fft2_workspace(ctypes.byref(d)) == 0

@@ -406,9 +406,27 @@ def test_polychromatic_driver_single_gpu(pa):
         comps.append(O.intensity(O.prepare_executor(dx, P.shape, 0.55 * 10 / 4, (64, 64), float(w), 100.0)(P)))
     assert rel_max(got, O.sum_of_2d_modes(np.asarray(comps), wts)) < TOL64
     # variant F (throughput): FFT focus per wavelength with the fused |.|^2 accumulate epilogue
-    got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2))
     comps = [O.intensity(O.focus(O.from_amp_and_phase(amp, opd, float(w)), 2)) for w in wvls]
-    assert rel_max(got, O.sum_of_2d_modes(np.asarray(comps), wts)) < TOL64
+    want = O.sum_of_2d_modes(np.asarray(comps), wts)
+    got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2))                   # stacks + one weighted sum
+    assert rel_max(got, want) < TOL64
+    got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2, batched=False))    # field by field, accumulate epilogue
+    assert rel_max(got, want) < TOL64
+
+
+def test_sum_modes_vs_oracle(pa):
+    """pm_sum_modes = polynomials.sum_of_2d_modes (tensordot of weights and modes), incl. > 32 modes and accumulate."""
+    from prysm_amd import _ops
+    rng = np.random.default_rng(9)
+    for B, dt in ((3, np.float64), (40, np.float32), (1, np.float64)):
+        modes = rng.standard_normal((B, 37, 53)).astype(dt)
+        w = rng.standard_normal(B)
+        got = tonp(_ops.sum_modes(torch.from_numpy(modes).cuda(), w))
+        want = O.sum_of_2d_modes(modes.astype(np.float64), w)
+        assert rel_max(got, want) < (1e-13 if dt == np.float64 else 2e-6)
+        acc = torch.ones((37, 53), dtype=torch.from_numpy(modes).dtype, device='cuda')
+        got = tonp(_ops.sum_modes(torch.from_numpy(modes).cuda(), w, out=acc, accumulate=True))
+        assert rel_max(got, want + 1.0) < (1e-13 if dt == np.float64 else 2e-6)
 
 
 def test_errors_match_reference(pa):
@@ -428,3 +446,66 @@ def test_errors_match_reference(pa):
         P.Wavefront(z, 0.5, 1) * P.Wavefront(z, 0.6, 1)
     with pytest.raises(ValueError):
         pa.fttools.CZT(np.arange(4.), np.arange(4.), np.arange(4.), np.arange(4.), sign=2)
+
+
+# ---------------------------------------------------------------- batches of fields (one launch pair)
+@pytest.mark.parametrize('n,Q,dtype,B', [(256, 1, np.complex128, 5), (512, 2, np.complex64, 3), (96, 1.5, np.complex128, 4),
+                                        (1024, 1, np.complex64, 9)])
+def test_batched_focus_family_vs_oracle(pa, n, Q, dtype, B):
+    """A (B, n, n) stack through focus / unfocus / their adjoints / focus_intensity equals the oracle field by field
+    (power-of-two sizes run grid.y = B; 96 * 1.5 = 144 goes through the direct-DFT kernels field by field)."""
+    P = pa.propagation
+    rng = np.random.default_rng(n + B)
+    x = crandn(rng, (B, n, n), dtype)
+    tol = TOL64 if dtype == np.complex128 else TOL32
+    for name in ('focus', 'unfocus'):
+        got = tonp(getattr(P, name)(x, Q))
+        assert got.shape[0] == B and got.dtype == dtype
+        for b in range(B):
+            assert rel_max(got[b], getattr(O, name)(x[b], Q)) < tol, (name, b)
+    M = got.shape[-1]
+    g = crandn(rng, (B, M, M), dtype)
+    got = tonp(P.focus_adjoint(g, Q))
+    for b in range(B):
+        assert rel_max(got[b], O.focus_adjoint(g[b], Q)) < tol
+    got = tonp(P.focus_intensity(x, Q))
+    for b in range(B):
+        assert rel_max(got[b], O.intensity(O.focus(x[b], Q))) < 4 * tol
+
+
+def test_batched_equals_single_bitwise_and_chunking(pa):
+    """The batch is the same arithmetic as B single calls: results are bit-identical, whatever the chunking of
+    the batch over the workspace budget."""
+    from prysm_amd import _lib
+    P = pa.propagation
+    rng = np.random.default_rng(77)
+    x = torch.from_numpy(crandn(rng, (7, 512, 512), np.complex64)).cuda()
+    single = torch.stack([P.focus(x[b], 1) for b in range(7)])
+    lib = _lib.load()
+    try:
+        for mib in (1, 4, 64):
+            lib.pm_set_tuning(b'batch_ws_mib', mib)
+            assert torch.equal(P.focus(x, 1), single), mib
+    finally:
+        lib.pm_set_tuning(b'batch_ws_mib', 128)
+    # strided views of a bigger stack (every other field)
+    assert torch.equal(P.focus(x[::2], 1), single[::2])
+
+
+def test_batched_angular_spectrum_per_field_wavelengths(pa):
+    """Stack of fields with one wavelength each (per-field separable transfer functions) -- the polychromatic
+    free-space step -- equals the oracle's angular_spectrum wavelength by wavelength; fused 3-pass path and the
+    two-call path (non power-of-two)."""
+    P = pa.propagation
+    rng = np.random.default_rng(5)
+    wvls = [0.5, 0.6, 0.7]
+    for n, Q in ((256, 1), (128, 2), (100, 1)):
+        x = crandn(rng, (3, n, n))
+        got = tonp(P.angular_spectrum(x, wvls, 0.01, 50.0, Q=Q))
+        for b, w in enumerate(wvls):
+            assert rel_max(got[b], O.angular_spectrum(x[b], w, 0.01, 50.0, Q=Q)) < TOL64
+        got = tonp(P.angular_spectrum(x, 0.55, 0.01, [10.0, 20.0, 30.0], Q=Q))
+        for b, z in enumerate([10.0, 20.0, 30.0]):
+            assert rel_max(got[b], O.angular_spectrum(x[b], 0.55, 0.01, z, Q=Q)) < TOL64
+    with pytest.raises(ValueError):
+        P.angular_spectrum(x, [0.5, 0.6], 0.01, 50.0)

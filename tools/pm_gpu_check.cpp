@@ -627,6 +627,81 @@ static void bench_cgemm(int64_t M, int64_t N, int64_t K, int opB) {
     if (ws) HIPCHECK(hipFree(ws));
 }
 
+// Batched transforms: (1) a batch must reproduce the field-by-field results bit for bit, (2) time per field
+// against the batch size (small fields are launch / latency bound one at a time).
+template <typename T>
+static void check_bench_batch(int64_t n, int64_t in_n, int batch, int epi, bool timeit) {
+    pm_fft2_desc d;
+    memset(&d, 0, sizeof d);
+    d.dtype = sizeof(T) == 4 ? PM_C64 : PM_C128;
+    d.direction = -1;
+    d.epilogue = epi;
+    d.scale = 1.0 / double(n);
+    d.weight = 1.0;
+    d.in_y = d.in_x = {n, in_n, (n - in_n + 1) / 2, n / 2};
+    d.out_y = d.out_x = {n, n, 0, n / 2};
+    d.in_ld = in_n;
+    d.out_ld = n;
+    pm_fft2_desc db = d;
+    db.batch = batch;
+    db.in_bstride = in_n * in_n;
+    db.out_bstride = n * n;
+    const size_t es = 2 * sizeof(T), oes = epi ? sizeof(T) : es;
+    std::vector<std::complex<T>> hx(size_t(batch) * in_n * in_n);
+    std::mt19937 rng(n + batch);
+    std::normal_distribution<float> nd;
+    for (auto& e : hx) e = std::complex<T>(nd(rng), nd(rng));
+    void *din, *dout, *dref, *ws;
+    const size_t wsb = std::max(pm_fft2_workspace(&db), pm_fft2_workspace(&d));
+    const size_t out_bytes = size_t(batch) * n * n * oes;
+    HIPCHECK(hipMalloc(&din, hx.size() * es));
+    HIPCHECK(hipMalloc(&dout, out_bytes));
+    HIPCHECK(hipMalloc(&dref, out_bytes));
+    HIPCHECK(hipMalloc(&ws, wsb));
+    HIPCHECK(hipMemcpy(din, hx.data(), hx.size() * es, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemset(dout, 0xff, out_bytes));
+    int rc = pm_fft2(&db, din, dout, ws, wsb, nullptr);
+    for (int b = 0; b < batch && !rc; ++b)
+        rc = pm_fft2(&d, (char*)din + size_t(b) * in_n * in_n * es, (char*)dref + size_t(b) * n * n * oes, ws, wsb, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    std::vector<char> a(out_bytes), r(out_bytes);
+    HIPCHECK(hipMemcpy(a.data(), dout, out_bytes, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(r.data(), dref, out_bytes, hipMemcpyDeviceToHost));
+    char name[160];
+    snprintf(name, sizeof name, "batch %s N=%lld in=%lld B=%d epi=%d (bitwise vs field-by-field) rc=%d", sizeof(T) == 4 ? "c64" : "c128",
+             (long long)n, (long long)in_n, batch, epi, rc);
+    report(name, (rc || memcmp(a.data(), r.data(), out_bytes)) ? 1.0 : 0.0, 0.5);
+    if (timeit) {
+        hipEvent_t e0, e1;
+        HIPCHECK(hipEventCreate(&e0));
+        HIPCHECK(hipEventCreate(&e1));
+        float tb = 0, t1 = 0;
+        const int reps = 20;
+        for (int i = 0; i < 3; ++i) pm_fft2(&db, din, dout, ws, wsb, nullptr);
+        HIPCHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < reps; ++i) pm_fft2(&db, din, dout, ws, wsb, nullptr);
+        HIPCHECK(hipEventRecord(e1, nullptr));
+        HIPCHECK(hipEventSynchronize(e1));
+        HIPCHECK(hipEventElapsedTime(&tb, e0, e1));
+        HIPCHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < reps; ++i)
+            for (int b = 0; b < batch; ++b)
+                pm_fft2(&d, (char*)din + size_t(b) * in_n * in_n * es, (char*)dref + size_t(b) * n * n * oes, ws, wsb, nullptr);
+        HIPCHECK(hipEventRecord(e1, nullptr));
+        HIPCHECK(hipEventSynchronize(e1));
+        HIPCHECK(hipEventElapsedTime(&t1, e0, e1));
+        const double alg = 4.0 * double(n) * n * es;
+        const double usb = tb / reps / batch * 1e3, us1 = t1 / reps / batch * 1e3;
+        printf("BENCH batch %s N=%lld in=%lld B=%d epi=%d: %.2f us/field batched (%.0f GB/s algorithmic, %.1f%% of 8 TB/s) vs %.2f us/field "
+               "one at a time (%.1f%%)\n", sizeof(T) == 4 ? "c64" : "c128", (long long)n, (long long)in_n, batch, epi, usb, alg / usb / 1e3,
+               alg / usb / 1e3 / 8000 * 100, us1, alg / us1 / 1e3 / 8000 * 100);
+    }
+    HIPCHECK(hipFree(din));
+    HIPCHECK(hipFree(dout));
+    HIPCHECK(hipFree(dref));
+    HIPCHECK(hipFree(ws));
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "quick";
     hipDeviceProp_t prop;
@@ -637,6 +712,30 @@ int main(int argc, char** argv) {
         const std::vector<Knobs> cfg = {{-1, 0, -1, -1, -1, 1}, {-1, 0, -1, 0, -1, 1}, {-1, 0, 0, 0, -1, 1}, {-1, 0, -1, 0, 3, 1}, {-1, 0, -1, 0, 1, 1}};
         sweep_fft2<float>(8192, cfg, 2);
         return 0;
+    }
+    if (mode == "batch") {
+        check_bench_batch<float>(64, 40, 5, 0, false);
+        check_bench_batch<double>(128, 128, 3, 1, false);
+        check_bench_batch<float>(100, 60, 3, 0, false);    // direct-DFT sizes: field by field inside the library
+        pm_set_tuning("batch_ws_mib", 1);                  // force several chunks
+        check_bench_batch<float>(512, 256, 7, 0, false);
+        pm_set_tuning("batch_ws_mib", 128);
+        for (int64_t n : {256, 512, 1024, 2048})
+            for (int b : {1, 4, 16, 64}) {
+                if (n * n * 8 * b > (int64_t(1) << 30)) continue;
+                check_bench_batch<float>(n, n, b, 0, true);
+            }
+        for (int mib : {16, 32, 128, 1024}) {
+            pm_set_tuning("batch_ws_mib", mib);
+            printf("batch_ws_mib = %d\n", mib);
+            check_bench_batch<float>(1024, 1024, 64, 0, true);
+            check_bench_batch<float>(512, 512, 64, 0, true);
+        }
+        pm_set_tuning("batch_ws_mib", 128);
+        check_bench_batch<float>(1024, 512, 16, 1, true);   // Q = 2 PSFs, fused |.|^2
+        check_bench_batch<double>(1024, 1024, 16, 0, true);
+        printf(g_fail ? "GPU CHECK FAILED (%d)\n" : "GPU CHECK OK\n", g_fail);
+        return g_fail ? 1 : 0;
     }
     if (mode == "fused") {
         check_bench_fused<float>(64, 64, false);
