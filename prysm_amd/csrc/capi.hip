@@ -79,6 +79,8 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("gemm_min_wgs")) t.gemm_min_wgs = v < 1 ? 1 : v;
     else if (is("nt_in")) t.nt_in = v;
     else if (is("nt_out")) t.nt_out = v;
+    else if (is("col_spread")) t.col_spread = v < 0 ? 0 : (v > 12 ? 12 : v);
+    else if (is("col_skew")) t.col_skew = v < 0 ? 0 : (v > 64 ? 64 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
 }
 
@@ -235,7 +237,8 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         if (p.tc) {
             const int ntiles = int((N + p.tc - 1) / p.tc);
             ColLoadTiled<T> cl{W, rows, to_map(d->in_y), ntiles, p.log_k, wstride};
-            return launch_col_tiled<T>(p.logm, tuning().col_var, cl, cs, tw, ntiles, p.log_k > 1 ? p.log_k : 1, st, nb);
+            return launch_col_tiled<T>(p.logm, tuning().col_var, cl, cs, tw, ntiles, (p.log_k > 1 ? p.log_k : 1) | (tuning().col_skew << 8) | (tuning().col_spread << 16),
+                                       st, nb);
         }
         const int tc = col_tile_width_for(d->dtype, p.logm, tuning().col_var);
         const int ntiles = int((N + tc - 1) / tc);

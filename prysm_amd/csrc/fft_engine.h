@@ -183,7 +183,7 @@ PM_HD void load_stage_tw(StageTw<C, S>& w, int t, const cx<typename C::T>* __res
 // one radix-R stage on the registers of a thread (all E sequences share the
 // twiddles: in column mode they are adjacent columns with the same row index)
 // ---------------------------------------------------------------------------
-template <typename C, int S>
+template <typename C, int S, int E0 = 0, int E1 = C::E>
 PM_HD void stage_compute(cx<typename C::T> (&v)[C::E][C::P], const StageTw<C, S>& w) {
     using T = typename C::T;
     constexpr int R = C::radix(S), Q = C::P / R;
@@ -192,29 +192,29 @@ PM_HD void stage_compute(cx<typename C::T> (&v)[C::E][C::P], const StageTw<C, S>
         if constexpr (S > 0 && R > 1) {
             if constexpr (R == 2) {
 #pragma unroll
-                for (int e = 0; e < C::E; ++e) v[e][Q + q] = cmul(v[e][Q + q], w.wb[q][1]);
+                for (int e = E0; e < E1; ++e) v[e][Q + q] = cmul(v[e][Q + q], w.wb[q][1]);
             } else {
 #pragma unroll
                 for (int a = 1; a < R / 4; ++a) {
 #pragma unroll
-                    for (int e = 0; e < C::E; ++e) v[e][(4 * a) * Q + q] = cmul(v[e][(4 * a) * Q + q], w.wa[q][a]);
+                    for (int e = E0; e < E1; ++e) v[e][(4 * a) * Q + q] = cmul(v[e][(4 * a) * Q + q], w.wa[q][a]);
                 }
 #pragma unroll
                 for (int b = 1; b < 4; ++b) {
 #pragma unroll
-                    for (int e = 0; e < C::E; ++e) v[e][b * Q + q] = cmul(v[e][b * Q + q], w.wb[q][b]);
+                    for (int e = E0; e < E1; ++e) v[e][b * Q + q] = cmul(v[e][b * Q + q], w.wb[q][b]);
 #pragma unroll
                     for (int a = 1; a < R / 4; ++a) {
                         const cx<T> wab = cmul(w.wa[q][a], w.wb[q][b]);
 #pragma unroll
-                        for (int e = 0; e < C::E; ++e)
+                        for (int e = E0; e < E1; ++e)
                             v[e][(4 * a + b) * Q + q] = cmul(v[e][(4 * a + b) * Q + q], wab);
                     }
                 }
             }
         }
 #pragma unroll
-        for (int e = 0; e < C::E; ++e) {
+        for (int e = E0; e < E1; ++e) {
             cx<T> a[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) a[k] = v[e][k * Q + q];
@@ -442,6 +442,50 @@ __device__ __forceinline__ void fft_run(cx<typename C::T> (&v)[C::E][C::P], Thre
             }
         }
         fft_run<C, S + 1>(v, pos, lds_raw, tw);
+    }
+}
+
+// Software-pipelined transform for two sequences per thread (complex64 column pass): the LDS exchange of one
+// sequence is issued right before the butterflies of the other, so ds_write traffic drains under VALU work
+// instead of in front of a barrier.  Same arithmetic and the same number of barriers as fft_run.
+//   invariant on entry to stage S > 0: v[0] is exchanged and ready for stage S; v[1] holds the un-exchanged
+//   output of stage S - 1.
+template <typename C, int S = 0>
+__device__ __forceinline__ void fft_run_pipe2(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw,
+                                              const cx<typename C::T>* __restrict__ tw) {
+    static_assert(C::E == 2 && C::COMP == 1, "two sequences per thread, complex exchange");
+    using LT = typename LdsType<C>::type;
+    LT* lds = reinterpret_cast<LT*>(lds_raw);
+    StageTw<C, S> w;
+    load_stage_tw<C, S>(w, pos.t, tw);
+    if constexpr (S == 0) {
+        stage_compute<C, 0, 0, 1>(v, w);
+        if constexpr (C::NSTAGE == 1) {
+            stage_compute<C, 0, 1, 2>(v, w);
+        } else {
+            exch_write<C, 0>(v, 0, 0, pos, lds);
+            stage_compute<C, 0, 1, 2>(v, w);
+            __syncthreads();
+            exch_read<C>(v, 0, 0, pos, lds);
+            __syncthreads();
+            fft_run_pipe2<C, 1>(v, pos, lds_raw, tw);
+        }
+    } else {
+        exch_write<C, S - 1>(v, 1, 0, pos, lds);
+        stage_compute<C, S, 0, 1>(v, w);
+        __syncthreads();
+        exch_read<C>(v, 1, 0, pos, lds);
+        if constexpr (S + 1 < C::NSTAGE) {
+            __syncthreads();
+            exch_write<C, S>(v, 0, 0, pos, lds);
+            stage_compute<C, S, 1, 2>(v, w);
+            __syncthreads();
+            exch_read<C>(v, 0, 0, pos, lds);
+            __syncthreads();
+            fft_run_pipe2<C, S + 1>(v, pos, lds_raw, tw);
+        } else {
+            stage_compute<C, S, 1, 2>(v, w);   // no trailing barrier: callers that reuse the LDS synchronise themselves
+        }
     }
 }
 #endif

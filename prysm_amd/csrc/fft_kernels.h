@@ -53,10 +53,27 @@ constexpr size_t kernel_lds_bytes() {
 
 template <typename C, bool COL, int VAR, typename L, typename S>
 __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
-                                                    const cx<typename C::T>* __restrict__ tw, const int log_g) {
+                                                    const cx<typename C::T>* __restrict__ tw, const int log_g_skew) {
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
+    // log_g_skew: bits 0-7 sibling-group size, bits 8+ start skew (column pass, experiment): every other workgroup
+    // of the first wave sleeps skew x ~0.85 us so the CUs do not run their load / compute / store phases in lockstep
+    const int log_g = log_g_skew & 0xff;
+    if (COL && ((log_g_skew >> 8) & 0xff) && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+        for (int i = 0; i < ((log_g_skew >> 8) & 0xff); ++i) __builtin_amdgcn_s_sleep(32);
+    }
     int unit = group_remap(blockIdx.x, gridDim.x, log_g);
+    if (COL && (log_g_skew >> 16)) {
+        // experiment: spread the sibling groups that run at the same time across the whole row (stride permutation
+        // of the group index) instead of one contiguous span
+        const int ls = log_g_skew >> 16, G = 1 << log_g;
+        const int ngroups = int(gridDim.x) >> log_g, SP = 1 << ls;
+        if ((int(gridDim.x) & (G - 1)) == 0 && (ngroups & (SP - 1)) == 0) {
+            const int gi = unit >> log_g, within = unit & (G - 1);
+            const int g2 = (gi & (SP - 1)) * (ngroups >> ls) + (gi >> ls);
+            unit = (g2 << log_g) | within;
+        }
+    }
     if (COL) unit = unit * C::BO + pos.bo;
     cx<typename C::T> v[C::E][C::P];
     const L lpb = at_batch(lp, blockIdx.y);   // blockIdx.y: field of a batch
@@ -71,7 +88,13 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
         fft_run_twlds<C>(v, pos, pm_smem, tab);
     } else {
         load<C>(lpb, unit, pos, v);
-        fft_run<C>(v, pos, pm_smem, tw);
+        // two sequences per thread (complex64 columns): exchanges pipelined against the butterflies of the other
+        // sequence (measured: 4096^2 column pass 57.2 -> 56.1 us, 8192^2 419 -> 358 us); VAR = 5 keeps the plain order
+        // for A/B runs, VAR = 3 skips the transform (memory phases only: timing experiments, wrong results)
+        if constexpr (VAR != 5 && VAR != 3 && COL && C::E == 2 && C::COMP == 1 && C::NSTAGE > 1)
+            fft_run_pipe2<C>(v, pos, pm_smem, tw);
+        else if constexpr (VAR != 3)
+            fft_run<C>(v, pos, pm_smem, tw);
     }
     store<C>(spb, unit, pos, v);
 }
@@ -95,14 +118,16 @@ __global__ void __launch_bounds__(C::NT) fft_col_mul_kernel(const ColLoadTiled<t
     const auto sp = at_batch(sp0, blockIdx.y);
     cx<typename C::T> v[C::E][C::P];
     load<C>(lp, unit, pos, v);
-    fft_run<C>(v, pos, pm_smem, tw);
+    if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
+    else fft_run<C>(v, pos, pm_smem, tw);
     mid_multiply_conj<C>(mp, unit, pos, v);
     __syncthreads();   // LDS of the forward exchange is reused by the inverse
     // opaque copy of the slot: otherwise the twiddles (and their products) of the first transform are CSE'd
     // with the second and kept live across it -- hundreds of spilled registers at 1024 threads
     ThreadPos pos2 = pos;
     asm volatile("" : "+v"(pos2.t), "+v"(pos2.cl), "+v"(pos2.bo));
-    fft_run<C>(v, pos2, pm_smem, tw);
+    if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos2, pm_smem, tw);
+    else fft_run<C>(v, pos2, pm_smem, tw);
 #pragma unroll
     for (int e = 0; e < C::E; ++e)
 #pragma unroll
@@ -187,7 +212,7 @@ template <typename T, bool COL, int LOGN, int VAR, typename L, typename S>
 int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st, int nbatch) {
     using Sel = typename std::conditional<COL, ColCfgSel<T, LOGN, VAR>, RowCfgSel<T, LOGN, VAR>>::type;
     using C = typename Sel::type;
-    auto kern = fft_kernel<C, COL, (COL ? VAR : 0), L, S>;
+    auto kern = fft_kernel<C, COL, (COL || VAR == 3 ? VAR : 0), L, S>;
     constexpr size_t LDSB = kernel_lds_bytes<C, COL, (COL ? VAR : 0)>();
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -229,6 +254,8 @@ int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int
     case k:                                                               \
         if (var == 1) return launch_one<T, COL, k, 1, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         if (var == 2 && !COL) return launch_one<T, COL, k, (COL ? 0 : 2), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        if (var == 3) return launch_one<T, COL, k, 3, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        if (var == 5 && COL) return launch_one<T, COL, k, (COL ? 5 : 0), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st, nbatch);
         PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
         PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASEV(11) PM_CASEV(12) PM_CASEV(13)

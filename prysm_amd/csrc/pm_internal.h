@@ -61,6 +61,8 @@ struct Tuning {
     int gemm_bk = 0;          // 0 default K-tile depth, 32 doubles it
     int gemm_min_wgs = 1024;   // split K until the GEMM launch has at least this many workgroups
     int row_log_g = 1;  // sibling group of row-pass workgroups (rows q .. q+2^g-1 on one XCD)
+    int col_spread = 0;      // experiment: log2 of the stride permutation of column-pass sibling groups
+    int col_skew = 0;        // experiment: start skew of every other column-pass workgroup, units of ~0.85 us
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)
 };

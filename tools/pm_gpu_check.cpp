@@ -506,6 +506,81 @@ static void sweep_fft2(int64_t n, const std::vector<Knobs>& cfgs, int rounds) {
     HIPCHECK(hipFree(ws));
 }
 
+// generic interleaved A/B: "tune N c64|c128 rounds cfg cfg ..." with cfg = "key=val,key=val" (pm_set_tuning keys; keys not
+// named in a cfg are reset to their defaults first)
+static void set_cfg(const std::string& cfg) {
+    static const char* defaults = "row_var=-1,col_var=0,nt_in=-1,nt_out=-1,log_k=-1,row_log_g=1,col_skew=0,col_spread=0";
+    for (const std::string& src : {std::string(defaults), cfg}) {
+        size_t i = 0;
+        while (i < src.size()) {
+            size_t c = src.find(',', i);
+            if (c == std::string::npos) c = src.size();
+            const std::string kv = src.substr(i, c - i);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos) pm_set_tuning(kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1));
+            i = c + 1;
+        }
+    }
+}
+template <typename T>
+static void tune_fft2(int64_t n, int rounds, const std::vector<std::string>& cfgs) {
+    pm_fft2_desc d;
+    memset(&d, 0, sizeof d);
+    d.dtype = sizeof(T) == 4 ? PM_C64 : PM_C128;
+    d.direction = -1;
+    d.scale = 1.0 / double(n);
+    d.weight = 1.0;
+    d.in_y = d.in_x = d.out_y = d.out_x = {n, n, 0, n / 2};
+    // PM_LD_PAD=k: leading dimensions n + k (experiment: power-of-two row strides vs the HBM channel mapping)
+    const int64_t pad = getenv("PM_LD_PAD") ? atoll(getenv("PM_LD_PAD")) : 0;
+    d.in_ld = d.out_ld = n + pad;
+    const size_t es = 2 * sizeof(T);
+    std::vector<std::complex<T>> hx(size_t(n) * (n + pad));
+    std::mt19937 rng(n);
+    std::normal_distribution<float> nd;
+    for (auto& e : hx) e = std::complex<T>(nd(rng), nd(rng));
+    void *din, *dout, *ws;
+    const size_t wsb = size_t(n) * n * es;
+    HIPCHECK(hipMalloc(&din, hx.size() * es));
+    HIPCHECK(hipMalloc(&dout, size_t(n) * (n + pad) * es));
+    HIPCHECK(hipMalloc(&ws, wsb));
+    HIPCHECK(hipMemcpy(din, hx.data(), hx.size() * es, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    std::vector<std::vector<double>> t(cfgs.size()), p1(cfgs.size()), p2(cfgs.size());
+    const int reps = 40;
+    for (int r = 0; r < rounds; ++r)
+        for (size_t c = 0; c < cfgs.size(); ++c) {
+            set_cfg(cfgs[c]);
+            for (int i = 0; i < 5; ++i) pm_fft2(&d, din, dout, ws, wsb, nullptr);
+            HIPCHECK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < reps; ++i) pm_fft2(&d, din, dout, ws, wsb, nullptr);
+            HIPCHECK(hipEventRecord(e1, nullptr));
+            HIPCHECK(hipEventSynchronize(e1));
+            float ms;
+            HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+            t[c].push_back(double(ms) / reps * 1e3);
+            double pm[2];
+            pm_fft2_time_passes(&d, din, dout, ws, wsb, 20, pm, nullptr);
+            p1[c].push_back(pm[0] * 1e3);
+            p2[c].push_back(pm[1] * 1e3);
+        }
+    const double alg = 4.0 * double(n) * n * es;
+    for (size_t c = 0; c < cfgs.size(); ++c) {
+        std::sort(t[c].begin(), t[c].end());
+        std::sort(p1[c].begin(), p1[c].end());
+        std::sort(p2[c].begin(), p2[c].end());
+        printf("TUNE %s N=%lld [%s]: total min %.1f med %.1f us (%.1f%% of 8TB/s at min); row pass min %.1f med %.1f; column pass min %.1f med %.1f\n",
+               sizeof(T) == 4 ? "c64" : "c128", (long long)n, cfgs[c].c_str(), t[c].front(), t[c][t[c].size() / 2],
+               alg / t[c].front() / 1e3 / 8000 * 100, p1[c].front(), p1[c][p1[c].size() / 2], p2[c].front(), p2[c][p2[c].size() / 2]);
+    }
+    set_cfg("");
+    HIPCHECK(hipFree(din));
+    HIPCHECK(hipFree(dout));
+    HIPCHECK(hipFree(ws));
+}
+
 // fused fft2 -> x H -> ifft2 (separable H) against the two-call composition: same result, fewer passes
 template <typename T>
 static void check_bench_fused(int64_t n, int64_t in_n, bool timeit) {
@@ -711,6 +786,15 @@ int main(int argc, char** argv) {
     if (mode == "big") {
         const std::vector<Knobs> cfg = {{-1, 0, -1, -1, -1, 1}, {-1, 0, -1, 0, -1, 1}, {-1, 0, 0, 0, -1, 1}, {-1, 0, -1, 0, 3, 1}, {-1, 0, -1, 0, 1, 1}};
         sweep_fft2<float>(8192, cfg, 2);
+        return 0;
+    }
+    if (mode == "tune" && argc >= 6) {
+        const int64_t n = atoll(argv[2]);
+        const int rounds = atoi(argv[4]);
+        std::vector<std::string> cfgs;
+        for (int i = 5; i < argc; ++i) cfgs.push_back(argv[i]);
+        if (!strcmp(argv[3], "c128")) tune_fft2<double>(n, rounds, cfgs);
+        else tune_fft2<float>(n, rounds, cfgs);
         return 0;
     }
     if (mode == "batch") {
