@@ -61,7 +61,11 @@ enum { PM_MUL_NONE = 0, PM_MUL_FULL = 1, PM_MUL_SEPARABLE = 2 };
 /* flags */
 enum {
     PM_FLAG_PASS1_ONLY = 1, /* profiling: run only the row pass    */
-    PM_FLAG_PASS2_ONLY = 2  /* profiling: run only the column pass */
+    PM_FLAG_PASS2_ONLY = 2, /* profiling: run only the column pass */
+    PM_FLAG_REAL_INPUT = 4  /* `in` is a REAL array of the precision that goes with dtype (float / double); in_ld and
+                             * in_bstride count real elements.  fft2 of a real PSF / object / actuator map
+                             * (prysm/otf.py:31, prysm/convolution.py:27-28,82-85) without a complex copy: pass 1 reads
+                             * half the bytes */
 };
 
 /* One axis of a windowed, rotated view.  A logical (transform-sized) axis of

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libprysm_amd.so')
 PM_C64, PM_C128, PM_F32, PM_F64, PM_BOOL = 0, 1, 2, 3, 4
 PM_EPI_NONE, PM_EPI_ABS2, PM_EPI_ABS2_ACCUM = 0, 1, 2
 PM_MUL_NONE, PM_MUL_FULL, PM_MUL_SEPARABLE = 0, 1, 2
-PM_FLAG_PASS1_ONLY, PM_FLAG_PASS2_ONLY = 1, 2
+PM_FLAG_PASS1_ONLY, PM_FLAG_PASS2_ONLY, PM_FLAG_REAL_INPUT = 1, 2, 4
 PM_ERR_ARG, PM_ERR_UNSUPPORTED, PM_ERR_WORKSPACE = -1, -2, -3
 
 c_i32, c_i64, c_f64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
@@ -160,8 +160,22 @@ def as_complex(x, at_least=None):
     return t
 
 
+def as_field(x):
+    """Like as_complex, but float32 / float64 arrays stay REAL: the 2-D transforms read them directly
+    (PM_FLAG_REAL_INPUT), which halves the bytes of the first pass and avoids a complex copy."""
+    t = as_device(x)
+    if t.is_complex() or t.dtype in (torch.float32, torch.float64):
+        return t
+    return as_complex(t)
+
+
+def cdtype_of(t):
+    """Complex dtype a transform of `t` produces."""
+    return t.dtype if t.is_complex() else _COMPLEX_OF[t.dtype]
+
+
 def code(t):
-    return _COMPLEX_CODE[t.dtype]
+    return _COMPLEX_CODE[cdtype_of(t)]
 
 
 def stream_ptr():

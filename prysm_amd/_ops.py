@@ -30,6 +30,8 @@ def _fill_views(d, x, shape, in_off, in_shift, out_shape, out_off, out_shift):
     d.out_y = _axis(M, om, out_off[0], out_shift[0])
     d.out_x = _axis(N, on, out_off[1], out_shift[1])
     d.in_ld = x.stride(-2) if m > 1 else n
+    if not x.is_complex():
+        d.flags |= L.PM_FLAG_REAL_INPUT      # float32 / float64 field read as it is
     if x.dim() == 3:
         d.batch = x.shape[0]
         d.in_bstride = x.stride(0) if x.shape[0] > 1 else m * n
@@ -71,16 +73,16 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
     """
     lib = L.load()
     d = L.pm_fft2_desc()
+    d.flags = flags
     x, (M, N), (om, on) = _fill_views(d, x, shape, in_off, in_shift, out_shape, out_off, out_shift)
     d.direction = direction
     d.epilogue = epilogue
-    d.flags = flags
     d.scale = float(scale)
     d.weight = float(weight)
     keep = [x]
     _fill_mul(d, x, mul, mul_x, mul_conj, keep)
     if out is None:
-        odt = x.dtype if epilogue == L.PM_EPI_NONE else L._REAL_OF[x.dtype]
+        odt = L.cdtype_of(x) if epilogue == L.PM_EPI_NONE else L._REAL_OF[L.cdtype_of(x)]
         oshape = (om, on) if x.dim() == 2 else (x.shape[0], om, on)
         out = torch.empty(oshape, dtype=odt, device=x.device)
     d.out_ld = out.stride(-2) if om > 1 else on
@@ -122,7 +124,7 @@ def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_
     keep = [x]
     _fill_mul(d, x, mul, mul_x, mul_conj, keep)
     oshape = (om, on) if x.dim() == 2 else (x.shape[0], om, on)
-    out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    out = torch.empty(oshape, dtype=L.cdtype_of(x), device=x.device)
     d.out_ld = out.stride(-2) if om > 1 else on
     if x.dim() == 3:
         d.out_bstride = out.stride(0) if out.shape[0] > 1 else om * d.out_ld

@@ -207,7 +207,8 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
             if (!tw) return err;
             const size_t in_bytes = size_t(p.nbatch) * size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
             const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
-            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, conj, nt_in, d->in_bstride};
+            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, conj, nt_in, d->in_bstride,
+                             (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
             int rc;
             if (p.tc) {
                 int ltc = 0;
@@ -222,7 +223,8 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         } else {
             const cx<double>* tw = twiddles_f64(N, &err);
             if (!tw) return err;
-            DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), d->in_ld, 1, to_map(d->in_x), rows, conj};
+            DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), d->in_ld, 1, to_map(d->in_x), rows, conj,
+                           (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
             int rc = direct_rows<T>(di, W, N, tw, st);
             if (rc) return rc;
         }
@@ -268,7 +270,7 @@ static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, vo
         pm_fft2_desc dd = *d;
         dd.mul = offset_elems(d->mul, b0 * d->mul_bstride, sizeof(cx<T>));
         dd.mul_x = offset_elems(d->mul_x, b0 * d->mul_x_bstride, sizeof(cx<T>));
-        const void* inb = offset_elems(in, b0 * d->in_bstride, sizeof(cx<T>));
+        const void* inb = offset_elems(in, b0 * d->in_bstride, (d->flags & PM_FLAG_REAL_INPUT) ? sizeof(T) : sizeof(cx<T>));
         void* outb = const_cast<void*>(offset_elems(out, b0 * d->out_bstride, oes));
         int rc = fft2_run_chunk<T>(&dd, p, inb, outb, ws, st, nb);
         if (rc) return rc;
@@ -326,7 +328,8 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
     if (rows > 0) {
         const size_t in_bytes = size_t(p.nbatch) * size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
         const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
-        RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, 0, nt_in, d->in_bstride};
+        RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, 0, nt_in, d->in_bstride,
+                         (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
         RowStoreTiled<T> sp{W1, rows, ltl, wstride};
         int rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, twN, rows, tuning().row_log_g, st, nb);
         if (rc) return rc;
@@ -354,7 +357,7 @@ static int fused_run(const pm_fft2_desc* d, const FusedPlan& p, const void* in, 
         pm_fft2_desc dd = *d;
         dd.mul = offset_elems(d->mul, b0 * d->mul_bstride, sizeof(cx<T>));
         dd.mul_x = offset_elems(d->mul_x, b0 * d->mul_x_bstride, sizeof(cx<T>));
-        int rc = fused_run_chunk<T>(&dd, p, offset_elems(in, b0 * d->in_bstride, sizeof(cx<T>)),
+        int rc = fused_run_chunk<T>(&dd, p, offset_elems(in, b0 * d->in_bstride, (d->flags & PM_FLAG_REAL_INPUT) ? sizeof(T) : sizeof(cx<T>)),
                                     const_cast<void*>(offset_elems(out, b0 * d->out_bstride, sizeof(cx<T>))), ws, st, nb);
         if (rc) return rc;
     }
@@ -522,14 +525,15 @@ int pm_fft2_time_passes(const pm_fft2_desc* d, const void* in, void* out, void* 
         if (he != hipSuccess) return int(he);
     }
     pm_fft2_desc dd = *d;
-    dd.flags = 0;
+    const int32_t keep = d->flags & PM_FLAG_REAL_INPUT;
+    dd.flags = keep;
     int rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);   // warm (also builds the plan)
     for (int i = 0; i < reps && !rc; ++i) {
         (void)hipEventRecord(ev[size_t(i) * 3 + 0], st);
-        dd.flags = PM_FLAG_PASS1_ONLY;
+        dd.flags = keep | PM_FLAG_PASS1_ONLY;
         rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
         (void)hipEventRecord(ev[size_t(i) * 3 + 1], st);
-        dd.flags = PM_FLAG_PASS2_ONLY;
+        dd.flags = keep | PM_FLAG_PASS2_ONLY;
         if (!rc) rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
         (void)hipEventRecord(ev[size_t(i) * 3 + 2], st);
     }

@@ -11,12 +11,17 @@ template <typename T>
 __device__ __forceinline__ cx<double> direct_sum(const DirectIn<T>& in, int seq, int k, const cx<double>* tw) {
     const int n = in.ax.n;
     const cx<T>* base = in.src + int64_t(seq) * in.s_seq;
+    const T* rbase = reinterpret_cast<const T*>(in.src) + int64_t(seq) * in.s_seq;
     double ar = 0.0, ai = 0.0;
     // walk the stored window; logical index i of stored element q
     int i = in.ax.unmap(0);
     int64_t idx = (int64_t(i) * k) % n;
     for (int q = 0; q < in.ax.len; ++q) {
-        cx<T> x = base[int64_t(q) * in.s_i];
+        cx<T> x;
+        if (in.real)
+            x = {rbase[int64_t(q) * in.s_i], T(0)};
+        else
+            x = base[int64_t(q) * in.s_i];
         double xr = double(x.x), xi = in.conj ? -double(x.y) : double(x.y);
         const cx<double> w = tw[idx];
         ar += xr * w.x - xi * w.y;

@@ -36,6 +36,7 @@ struct RowLoadNat {
     int conj;
     int nt;         // non-temporal loads (input is read exactly once)
     int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
+    int real;       // the array is REAL (T, not cx<T>): src points at T, ld / bstride count real elements, imag = 0
 };
 
 template <typename T>
@@ -192,7 +193,10 @@ __device__ __forceinline__ void nt_store_v4(Vec4<T>* p, Vec4<T> v) {
 }
 template <typename T>
 __device__ __forceinline__ void nt_store_s(T* p, T v) { __builtin_nontemporal_store(v, p); }
+template <typename T>
+__device__ __forceinline__ T nt_load_s(const T* p) { return __builtin_nontemporal_load(p); }
 #else
+template <typename T> inline T nt_load_s(const T* p) { return *p; }
 template <typename T> inline cx<T> nt_load_cx(const cx<T>* p) { return *p; }
 template <typename T> inline void nt_store_cx(cx<T>* p, cx<T> v) { *p = v; }
 template <typename T> inline void nt_store_v4(Vec4<T>* p, Vec4<T> v) { *p = v; }
@@ -202,7 +206,13 @@ template <typename T> inline void nt_store_s(T* p, T v) { *p = v; }
 // ------------------------------------------------------------------ batches
 // Field b of a batch (blockIdx.y) is the same problem at an offset: a copy of the parameter block with
 // the base pointers advanced.  The parameter blocks live in SGPRs, so this is a handful of scalar ops.
-template <typename T> PM_HD RowLoadNat<T> at_batch(RowLoadNat<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD RowLoadNat<T> at_batch(RowLoadNat<T> p, int b) {
+    if (p.real)
+        p.src = reinterpret_cast<const cx<T>*>(reinterpret_cast<const T*>(p.src) + int64_t(b) * p.bstride);
+    else
+        p.src += int64_t(b) * p.bstride;
+    return p;
+}
 template <typename T> PM_HD RowStoreTiled<T> at_batch(RowStoreTiled<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD RowStoreNat<T> at_batch(RowStoreNat<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD RowLoadTiled<T> at_batch(RowLoadTiled<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
@@ -226,7 +236,7 @@ template <typename T> PM_HD ColStoreNat<T> at_batch(ColStoreNat<T> p, int b) {
 
 // ------------------------------------------------------------------ row mode
 // FULL: the window covers the whole axis and the sequence exists -> no per-element predicates at all
-template <typename C, int ROT, bool FULL = false>
+template <typename C, int ROT, bool FULL = false, bool REAL = false>
 PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
                     cx<typename C::T> (&v)[C::E][C::P]) {
     using T = typename C::T;
@@ -234,33 +244,45 @@ PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
     const int seq = blk * C::BO + pos.bo;
     const bool ok = seq < p.nseq;
     const cx<T>* row = p.src + int64_t(ok ? seq : 0) * p.ld - p.ax.off;
+    const T* rrow = reinterpret_cast<const T*>(p.src) + int64_t(ok ? seq : 0) * p.ld - p.ax.off;   // REAL input
     const int lo = p.ax.off, hi = ok ? p.ax.off + p.ax.len : -1;
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
         const int pp = slot_pos<C, ROT>(pos.t, m, p.ax.shift);
         cx<T> val = {T(0), T(0)};
-        if (FULL || (pp >= lo && pp < hi)) val = p.nt ? nt_load_cx(row + pp) : row[pp];
+        if (FULL || (pp >= lo && pp < hi)) {
+            if constexpr (REAL)
+                val.x = p.nt ? nt_load_s(rrow + pp) : rrow[pp];
+            else
+                val = p.nt ? nt_load_cx(row + pp) : row[pp];
+        }
         v[0][m] = val;
     }
-    if (p.conj) {
+    if (!REAL && p.conj) {
 #pragma unroll
         for (int m = 0; m < C::P; ++m) v[0][m].y = -v[0][m].y;
     }
 }
 
-template <typename C>
-PM_HD void load(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
+template <typename C, bool REAL>
+PM_HD void load_sel(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
     const int rot = rot_of<C>(p.ax.shift);
     const bool full = p.ax.off == 0 && p.ax.len == C::N && (blk * C::BO + pos.bo) < p.nseq;
     if (rot == 0) {
-        if (full) load_rot<C, 0, true>(p, blk, pos, v);
-        else load_rot<C, 0>(p, blk, pos, v);
+        if (full) load_rot<C, 0, true, REAL>(p, blk, pos, v);
+        else load_rot<C, 0, false, REAL>(p, blk, pos, v);
     } else if (rot > 0) {
-        if (full) load_rot<C, (C::P >= 2 ? C::P / 2 : 0), true>(p, blk, pos, v);
-        else load_rot<C, (C::P >= 2 ? C::P / 2 : 0)>(p, blk, pos, v);
+        if (full) load_rot<C, (C::P >= 2 ? C::P / 2 : 0), true, REAL>(p, blk, pos, v);
+        else load_rot<C, (C::P >= 2 ? C::P / 2 : 0), false, REAL>(p, blk, pos, v);
     } else {
-        load_rot<C, -1>(p, blk, pos, v);
+        load_rot<C, -1, false, REAL>(p, blk, pos, v);
     }
+}
+
+template <typename C>
+PM_HD void load(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
+    if (p.real) load_sel<C, true>(p, blk, pos, v);
+    else load_sel<C, false>(p, blk, pos, v);
 }
 
 template <typename C>

@@ -24,6 +24,7 @@ struct DirectIn {
     AxisMap ax;
     int nseq;
     int conj;
+    int real;   // src is a REAL array (T): strides count real elements
 };
 // rows: out[seq*ld + k] (natural complex intermediate, k in [0,n))
 template <typename T>

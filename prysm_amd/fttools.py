@@ -356,3 +356,33 @@ def _fft_compatible_length(alpha, N, M, name):
     if K < max(N, M):
         raise ValueError(f'{name} requires FFT length {K}, smaller than input/output length {max(N, M)}')
     return K
+
+
+def fourier_resample(f, zoom):
+    """Resample f via Fourier methods (truncated sinc interpolation) (prysm/fttools.py:538-593).
+
+    One fused centred fft2 (real input read as it is) and one matrix-DFT GEMM pair onto the zoomed grid.
+    """
+    if zoom == 1:
+        return f
+    if isinstance(zoom, (float, int)):
+        zoom = (zoom, zoom)
+    elif not isinstance(zoom, tuple):
+        zoom = tuple(float(z) for z in zoom)
+    if len(zoom) != 2 or any(z <= 0 for z in zoom):
+        raise ValueError('zoom must contain two positive values')
+    x = L.as_field(f)
+    real = not x.is_complex()
+    m, n = x.shape
+    M = int(m * zoom[0])
+    N = int(n * zoom[1])
+    if M < 1 or N < 1:
+        raise ValueError('zoom produces an empty output')
+    sh = (m // 2, n // 2)
+    F = _ops.fft2(x, direction=-1, scale=1.0, in_shift=sh, out_shift=sh)
+    xx = fftrange(n, dtype=config.precision)
+    yy = fftrange(m, dtype=config.precision)
+    fx = fftrange(N, dtype=config.precision) * (1.0 / zoom[1] / n)
+    fy = fftrange(M, dtype=config.precision) * (1.0 / zoom[0] / m)
+    fprime = MDFT(xx, yy, fx, fy, sign=+1, norm=1.0 / (m * n))(F)
+    return fprime.real if real else fprime

@@ -34,9 +34,9 @@ def angular_spectrum_transfer_function(samples, wvl, dx, z):
 
 def _field(field, other_dtype):
     """numpy result type of field * transfer_function."""
-    f = L.as_complex(field)
-    if other_dtype == torch.complex128 and f.dtype == torch.complex64:
-        f = f.to(torch.complex128)
+    f = L.as_field(field)
+    if other_dtype == torch.complex128 and L.cdtype_of(f) == torch.complex64:
+        f = f.to(torch.complex128 if f.is_complex() else torch.float64)
     return f
 
 
@@ -60,15 +60,15 @@ def angular_spectrum(field, wvl, dx, z, Q=2, tf=None):
     if tf is not None:
         tf = L.as_complex(tf)
         f = _field(field, tf.dtype)
-        if tf.dtype != f.dtype:
-            tf = tf.to(f.dtype)
+        if tf.dtype != L.cdtype_of(f):
+            tf = tf.to(L.cdtype_of(f))
         M, N = f.shape[-2:]
         return _ops.fft2_mul_ifft2(f, scale=1.0 / (M * N), mul=tf.contiguous())
     f = _field(field, _cdtype())
     m, n = f.shape[-2:]
     M, N = _padded_shape((m, n), Q)
     in_off = (math.ceil((M - m) / 2), math.ceil((N - n) / 2))
-    hy, hx = _tf_vectors((M, N), wvl, dx, z, f.dtype, f.shape[0] if f.dim() == 3 else None)
+    hy, hx = _tf_vectors((M, N), wvl, dx, z, L.cdtype_of(f), f.shape[0] if f.dim() == 3 else None)
     return _ops.fft2_mul_ifft2(f, scale=1.0 / (M * N), mul=hy, mul_x=hx, shape=(M, N), in_off=in_off)
 
 
@@ -77,14 +77,14 @@ def angular_spectrum_adjoint(field, wvl, dx, z, Q=2, tf=None):
     if tf is not None:
         tf = L.as_complex(tf)
         f = _field(field, tf.dtype)
-        if tf.dtype != f.dtype:
-            tf = tf.to(f.dtype)
+        if tf.dtype != L.cdtype_of(f):
+            tf = tf.to(L.cdtype_of(f))
         M, N = f.shape[-2:]
         return _ops.fft2_mul_ifft2(f, scale=1.0 / (M * N), mul=tf.contiguous(), mul_conj=True)
     f = _field(field, _cdtype())
     M, N = f.shape[-2:]
     out_shape = _shape_before_pad((M, N), Q)
-    hy, hx = _tf_vectors((M, N), wvl, dx, z, f.dtype, f.shape[0] if f.dim() == 3 else None)
+    hy, hx = _tf_vectors((M, N), wvl, dx, z, L.cdtype_of(f), f.shape[0] if f.dim() == 3 else None)
     if out_shape == (M, N):
         return _ops.fft2_mul_ifft2(f, scale=1.0 / (M * N), mul=hy, mul_x=hx, mul_conj=True)
     out_off = (math.ceil((M - out_shape[0]) / 2), math.ceil((N - out_shape[1]) / 2))

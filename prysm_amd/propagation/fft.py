@@ -18,7 +18,7 @@ from ._kernels import _padded_shape, _shape_before_pad
 
 def _centered_fft2(x, Q, direction, crop_to=None):
     """fftshift(fft2 | ifft2(ifftshift(pad2d(x, Q)), norm='ortho')) [+ crop_center]."""
-    x = L.as_complex(x)
+    x = L.as_field(x)
     if x.dim() not in (2, 3):
         raise ValueError('propagation routines operate on 2-D arrays (or a (batch, rows, cols) stack of them)')
     m, n = x.shape[-2:]
@@ -63,7 +63,7 @@ def focus_intensity(wavefunction, Q, out=None, weight=None):
     and ``weight`` the result is accumulated, ``out += weight * |.|^2`` (the incoherent sum of the
     polychromatic recipe).
     """
-    x = L.as_complex(wavefunction)
+    x = L.as_field(wavefunction)
     m, n = x.shape[-2:]
     M, N = _padded_shape((m, n), Q)
     in_off = (math.ceil((M - m) / 2), math.ceil((N - n) / 2))

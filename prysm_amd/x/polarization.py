@@ -1,0 +1,49 @@
+"""Polarized (Jones) field propagation (prysm/x/polarization.py:478-553) -- SURVEY 8(f) rank 3.
+
+The reference's jones_adapter calls the wrapped propagation function four times, once per element of the
+(..., 2, 2) Jones field.  The four elements are independent fields of one shape, i.e. a batch: here they go
+through the FFT routines as ONE (4, m, n) stack (one launch pair), and through the matrix-DFT executors
+element by element.
+"""
+import functools
+
+import torch
+
+from .. import _lib as L
+from .. import propagation
+
+supported_propagation_funcs = ['focus', 'unfocus', 'focus_dft', 'unfocus_dft', 'angular_spectrum']
+
+# routines that take a (batch, rows, cols) stack
+_STACKABLE = {'focus', 'unfocus', 'focus_adjoint', 'unfocus_adjoint', 'angular_spectrum', 'angular_spectrum_adjoint'}
+
+
+def jones_adapter(prop_func):
+    """Wrap a prysm_amd.propagation function to support polarized field propagation (polarization.py:478-537)."""
+    @functools.wraps(prop_func)
+    def wrapper(*args, **kwargs):
+        wavefunction = args[0]
+        other_args = args[1:]
+        ndim = wavefunction.ndim if hasattr(wavefunction, 'ndim') else L.as_device(wavefunction).dim()
+        if ndim == 2:
+            return prop_func(*args, **kwargs)      # pass through the non-Jones case
+        w = L.as_device(wavefunction)
+        m, n = w.shape[0], w.shape[1]
+        if getattr(prop_func, '__name__', '') in _STACKABLE:
+            stack = w.permute(2, 3, 0, 1).reshape(4, m, n).contiguous()
+            ret = prop_func(stack, *other_args, **kwargs)
+            M, N = ret.shape[-2:]
+            return ret.reshape(2, 2, M, N).permute(2, 3, 0, 1).contiguous()
+        tmp = [prop_func(w[..., i, j].contiguous(), *other_args, **kwargs) for i in (0, 1) for j in (0, 1)]
+        tmp = [t.data if hasattr(t, 'data') and not isinstance(t, torch.Tensor) else t for t in tmp]
+        return torch.stack(tmp, dim=-1).reshape(*tmp[0].shape, 2, 2)
+    return wrapper
+
+
+def add_jones_propagation(funcs_to_change=supported_propagation_funcs):
+    """Apply the decorator to the supported propagation functions of prysm_amd.propagation (polarization.py:540-553)."""
+    for name, func in list(vars(propagation).items()):
+        if name in funcs_to_change and callable(func) and not getattr(func, '_jones', False):
+            wrapped = jones_adapter(func)
+            wrapped._jones = True
+            setattr(propagation, name, wrapped)

@@ -238,6 +238,49 @@ def coronagraph():
     np.savez_compressed(os.path.join(HERE, 'coronagraph.npz'), **out)
 
 
+def next_rows():
+    """apply_transfer_functions, fourier_resample, jones_adapter."""
+    from prysm.x import polarization as ppol
+    out = {}
+    rng = np.random.default_rng(8604)
+    # apply_transfer_functions: array tfs (the DM render path, x/dm.py:254) and callable tfs, both shift modes
+    obj = rng.standard_normal((24, 32))
+    tf1 = crandn(rng, (24, 32))
+    tf2 = rng.standard_normal((24, 32))
+    out['atf_obj'] = obj
+    out['atf_tf1'] = tf1
+    out['atf_tf2'] = tf2
+    out['atf_arrays_noshift'] = pconv.apply_transfer_functions(obj, None, [tf1, tf2], shift=False)
+    out['atf_arrays_shift'] = pconv.apply_transfer_functions(obj, None, [tf1, tf2], shift=True)
+    cobj = crandn(rng, (17, 20))
+    out['atf_cobj'] = cobj
+
+    def gauss(fr):
+        return np.exp(-(fr / 3.0) ** 2)
+
+    def ramp(fx, fy):
+        return np.exp(-2j * np.pi * (0.01 * fx + 0.02 * fy))
+
+    out['atf_callable_noshift'] = pconv.apply_transfer_functions(cobj, 0.05, [gauss, ramp], shift=False)
+    out['atf_callable_shift'] = pconv.apply_transfer_functions(cobj, 0.05, [gauss, ramp], shift=True)
+    # fourier_resample: real and complex, up / down, anisotropic zoom
+    f = rng.standard_normal((16, 20))
+    out['fr_f'] = f
+    out['fr_up2'] = fttools.fourier_resample(f, 2)
+    out['fr_up15'] = fttools.fourier_resample(f, 1.5)
+    out['fr_aniso'] = fttools.fourier_resample(f, (0.75, 1.25))
+    g = crandn(rng, (12, 9))
+    out['fr_g'] = g
+    out['fr_g_up'] = fttools.fourier_resample(g, 1.7)
+    # jones_adapter on focus / angular_spectrum
+    J = crandn(rng, (12, 16, 2, 2))
+    out['jones_in'] = J
+    out['jones_focus_Q2'] = ppol.jones_adapter(propagation.focus)(J, 2)
+    out['jones_unfocus_Q1'] = ppol.jones_adapter(propagation.unfocus)(J, 1)
+    out['jones_as'] = ppol.jones_adapter(propagation.angular_spectrum)(J, 0.6328, 0.01, 25.0, Q=2)
+    np.savez_compressed(os.path.join(HERE, 'next_rows.npz'), **out)
+
+
 def precision32():
     """fp32 path semantics (dtype propagation) on one case each."""
     out = {}
@@ -265,6 +308,7 @@ if __name__ == '__main__':
     wavefront_and_physics()
     coronagraph()
     precision32()
+    next_rows()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))

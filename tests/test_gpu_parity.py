@@ -509,3 +509,64 @@ def test_batched_angular_spectrum_per_field_wavelengths(pa):
             assert rel_max(got[b], O.angular_spectrum(x[b], 0.55, 0.01, z, Q=Q)) < TOL64
     with pytest.raises(ValueError):
         P.angular_spectrum(x, [0.5, 0.6], 0.01, 50.0)
+
+
+# ---------------------------------------------------------------- SURVEY 8(f) ranks 3-4 and the real-input path
+def test_next_rows_golden(pa, golden):
+    """apply_transfer_functions, fourier_resample, jones_adapter against the reference's own outputs."""
+    from prysm_amd import convolution as C, fttools as F
+    from prysm_amd.x.polarization import jones_adapter
+    P = pa.propagation
+    g = golden('next_rows')
+    obj, tf1, tf2 = g['atf_obj'], g['atf_tf1'], g['atf_tf2']
+    got = tonp(C.apply_transfer_functions(obj, None, [tf1, tf2], shift=False))
+    assert not np.iscomplexobj(got) and rel_max(got, g['atf_arrays_noshift']) < TOL64
+    assert rel_max(tonp(C.apply_transfer_functions(obj, None, [tf1, tf2], shift=True)), g['atf_arrays_shift']) < TOL64
+
+    def gauss(fr):
+        return torch.exp(-(fr / 3.0) ** 2)
+
+    def ramp(fx, fy):
+        return torch.exp(-2j * np.pi * (0.01 * fx + 0.02 * fy))
+
+    cobj = g['atf_cobj']
+    assert rel_max(tonp(C.apply_transfer_functions(cobj, 0.05, [gauss, ramp], shift=False)), g['atf_callable_noshift']) < TOL64
+    assert rel_max(tonp(C.apply_transfer_functions(cobj, 0.05, [gauss, ramp], shift=True)), g['atf_callable_shift']) < TOL64
+    f, gg = g['fr_f'], g['fr_g']
+    for zoom, key in ((2, 'fr_up2'), (1.5, 'fr_up15'), ((0.75, 1.25), 'fr_aniso')):
+        got = tonp(F.fourier_resample(f, zoom))
+        assert got.shape == g[key].shape and not np.iscomplexobj(got)
+        assert rel_max(got, g[key]) < TOL64
+    assert rel_max(tonp(F.fourier_resample(gg, 1.7)), g['fr_g_up']) < TOL64
+    assert F.fourier_resample(f, 1) is f
+    with pytest.raises(ValueError):
+        F.fourier_resample(f, (1, -1))
+    J = g['jones_in']
+    assert rel_max(tonp(jones_adapter(P.focus)(J, 2)), g['jones_focus_Q2']) < TOL64
+    assert rel_max(tonp(jones_adapter(P.unfocus)(J, 1)), g['jones_unfocus_Q1']) < TOL64
+    assert rel_max(tonp(jones_adapter(P.angular_spectrum)(J, 0.6328, 0.01, 25.0, Q=2)), g['jones_as']) < TOL64
+    assert rel_max(tonp(jones_adapter(P.focus)(J[..., 0, 1], 2)), g['jones_focus_Q2'][..., 0, 1]) < TOL64   # 2-D passes through
+
+
+@pytest.mark.parametrize('shape,dtype', [((512, 512), np.float32), ((256, 1024), np.float64), ((90, 120), np.float64),
+                                         ((2048, 2048), np.float32)])
+def test_real_input_paths_vs_oracle(pa, shape, dtype):
+    """float32 / float64 fields are read as they are (PM_FLAG_REAL_INPUT): focus, transform_psf, conv and the batch form
+    equal the oracle on the same real arrays (engine sizes and the direct-DFT sizes)."""
+    from prysm_amd import otf, convolution as C
+    P = pa.propagation
+    rng = np.random.default_rng(shape[0] + shape[1])
+    a = rng.standard_normal(shape).astype(dtype)
+    b = rng.standard_normal(shape).astype(dtype)
+    tol = TOL64 if dtype == np.float64 else TOL32
+    cdt = np.complex128 if dtype == np.float64 else np.complex64
+    got = tonp(P.focus(a, 1))
+    assert got.dtype == cdt and rel_max(got, O.focus(a, 1)) < tol
+    if shape[0] <= 512:
+        assert rel_max(tonp(P.focus(a, 2)), O.focus(a, 2)) < tol
+        assert rel_max(tonp(P.focus(np.stack([a, b]), 1)[1]), O.focus(b, 1)) < tol
+    data, df = otf.transform_psf(a, 1.0)
+    assert rel_max(tonp(data), O.transform_psf(a)) < tol
+    got = tonp(C.conv(a, b))
+    assert got.dtype == dtype and rel_max(got, O.conv(a.astype(np.float64), b.astype(np.float64))) < 4 * tol
+    assert rel_max(tonp(P.angular_spectrum(a, 0.6, 0.01, 20.0, Q=1)), O.angular_spectrum(a.astype(np.float64), 0.6, 0.01, 20.0, Q=1)) < 4 * tol

@@ -230,3 +230,31 @@ def test_oracle_matches_live_reference():
             g = rng.normal(size=(20, 28)) + 1j * rng.normal(size=(20, 28))
             assert rel_max(a.adjoint(g), b.adjoint(g)) < 1e-11
     assert np.array_equal(O.pad2d(x, 1.7), F.pad2d(x, 1.7))
+
+
+def test_next_rows_oracle_vs_golden(golden):
+    """apply_transfer_functions, fourier_resample, jones_adapter restatements against the reference's outputs."""
+    g = golden('next_rows')
+    obj, tf1, tf2 = g['atf_obj'], g['atf_tf1'], g['atf_tf2']
+    assert rel_max(O.apply_transfer_functions(obj, None, [tf1, tf2], shift=False), g['atf_arrays_noshift']) < 1e-13
+    assert rel_max(O.apply_transfer_functions(obj, None, [tf1, tf2], shift=True), g['atf_arrays_shift']) < 1e-13
+
+    def gauss(fr):
+        return np.exp(-(fr / 3.0) ** 2)
+
+    def ramp(fx, fy):
+        return np.exp(-2j * np.pi * (0.01 * fx + 0.02 * fy))
+
+    cobj = g['atf_cobj']
+    assert rel_max(O.apply_transfer_functions(cobj, 0.05, [gauss, ramp], shift=False), g['atf_callable_noshift']) < 1e-13
+    assert rel_max(O.apply_transfer_functions(cobj, 0.05, [gauss, ramp], shift=True), g['atf_callable_shift']) < 1e-13
+    f, gg = g['fr_f'], g['fr_g']
+    assert rel_max(O.fourier_resample(f, 2), g['fr_up2']) < 1e-12
+    assert rel_max(O.fourier_resample(f, 1.5), g['fr_up15']) < 1e-12
+    assert rel_max(O.fourier_resample(f, (0.75, 1.25)), g['fr_aniso']) < 1e-12
+    assert rel_max(O.fourier_resample(gg, 1.7), g['fr_g_up']) < 1e-12
+    assert O.fourier_resample(f, 2).dtype == np.float64 and np.iscomplexobj(O.fourier_resample(gg, 1.7))
+    J = g['jones_in']
+    assert rel_max(O.jones_adapter(O.focus)(J, 2), g['jones_focus_Q2']) < 1e-13
+    assert rel_max(O.jones_adapter(O.unfocus)(J, 1), g['jones_unfocus_Q1']) < 1e-13
+    assert rel_max(O.jones_adapter(O.angular_spectrum)(J, 0.6328, 0.01, 25.0, Q=2), g['jones_as']) < 1e-13
