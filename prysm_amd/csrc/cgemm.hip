@@ -102,7 +102,7 @@ struct Stager {
     }
 };
 
-template <typename T, int BM, int BN, int BK, bool AKF, bool BKF>
+template <typename T, int BM, int BN, int BK, bool AKF, bool BKF, bool M3>
 __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int64_t M, int64_t N, int64_t K, int64_t ksplit,
                                                        T alpha, const cx<T>* __restrict__ A, int64_t lda,
                                                        const cx<T>* __restrict__ B, int64_t ldb, cx<T>* __restrict__ C,
@@ -131,7 +131,10 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
     const int64_t kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
     const T sa = conjA ? T(-1) : T(1), sb = conjB ? T(-1) : T(1);
 
-    typename MT::acc_t acc_r[TI][TJ], acc_i[TI][TJ];
+    // M3 (three-multiplication complex product, "3M"): P1 = Ar Br, P2 = Ai Bi, P3 = (Ar + Ai)(Br + Bi);
+    // Cr = P1 - P2, Ci = P3 - P1 - P2 -- three MFMA chains instead of four for two extra VALU adds per operand
+    // fragment; acc_r = P1, acc_i = P2 (M3) and acc_3 = P3.
+    typename MT::acc_t acc_r[TI][TJ], acc_i[TI][TJ], acc_3[M3 ? TI : 1][M3 ? TJ : 1];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -140,6 +143,7 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
             for (int r = 0; r < NR; ++r) {
                 acc_r[i][j][r] = T(0);
                 acc_i[i][j][r] = T(0);
+                if constexpr (M3) acc_3[i][j][r] = T(0);
             }
 
     SA stA;
@@ -177,15 +181,31 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
             for (int i = 0; i < TI; ++i) a[i] = As[buf][kk][wr * WM + i * TM + MT::op_row(lane)];
 #pragma unroll
             for (int j = 0; j < TJ; ++j) b[j] = Bs[buf][kk][wc * WN + j * TM + MT::op_row(lane)];
+            if constexpr (M3) {
+                T as[TI], bs[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+                for (int i = 0; i < TI; ++i) as[i] = a[i].x + a[i].y;
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    acc_r[i][j] = MT::mfma(a[i].x, b[j].x, acc_r[i][j]);
-                    acc_i[i][j] = MT::mfma(a[i].x, b[j].y, acc_i[i][j]);
-                    acc_r[i][j] = MT::mfma(-a[i].y, b[j].y, acc_r[i][j]);
-                    acc_i[i][j] = MT::mfma(a[i].y, b[j].x, acc_i[i][j]);
-                }
+                for (int j = 0; j < TJ; ++j) bs[j] = b[j].x + b[j].y;
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        acc_r[i][j] = MT::mfma(a[i].x, b[j].x, acc_r[i][j]);
+                        acc_i[i][j] = MT::mfma(a[i].y, b[j].y, acc_i[i][j]);
+                        acc_3[i][j] = MT::mfma(as[i], bs[j], acc_3[i][j]);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        acc_r[i][j] = MT::mfma(a[i].x, b[j].x, acc_r[i][j]);
+                        acc_i[i][j] = MT::mfma(a[i].x, b[j].y, acc_i[i][j]);
+                        acc_r[i][j] = MT::mfma(-a[i].y, b[j].y, acc_r[i][j]);
+                        acc_i[i][j] = MT::mfma(a[i].y, b[j].x, acc_i[i][j]);
+                    }
+            }
         }
         if (more) s_store(buf ^ 1);
         __syncthreads();
@@ -202,7 +222,13 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
             for (int r = 0; r < NR; ++r) {
                 const int64_t row = m0 + wr * WM + i * TM + MT::row_of(r, lane);
                 const int64_t col = n0 + wc * WN + j * TM + MT::col_of(lane);
-                if (row < M && col < N) Cout[row * ldc + col] = {acc_r[i][j][r] * alpha, acc_i[i][j][r] * alpha};
+                T cr = acc_r[i][j][r], ci = acc_i[i][j][r];
+                if constexpr (M3) {
+                    const T p1 = cr, p2 = ci;
+                    cr = p1 - p2;
+                    ci = acc_3[i][j][r] - p1 - p2;
+                }
+                if (row < M && col < N) Cout[row * ldc + col] = {cr * alpha, ci * alpha};
             }
 }
 
@@ -250,12 +276,20 @@ int cgemm_ws_bk(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha,
     const int cA = opA & 1, cB = opB & 1;
     auto launch = [&](T al, cx<T>* out, int64_t ldo, int64_t slab) {
         constexpr size_t LDSB = sizeof(cx<T>) * 2 * BK * ((BM + 1) + (BN + 1));
-#define PM_GEMM(AK, BK_)                                                                                                   \
+#define PM_GEMM_(AK, BK_, M3_)                                                                                             \
     {                                                                                                                      \
-        auto kern = cgemm_kernel<T, BM, BN, BK, AK, BK_>;                                                                  \
+        auto kern = cgemm_kernel<T, BM, BN, BK, AK, BK_, M3_>;                                                             \
         if (LDSB > 48 * 1024)                                                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB)); \
         hipLaunchKernelGGL(kern, grid, dim3(256), LDSB, st, cA, cB, M, N, K, ksplit, al, A, lda, B, ldb, out, ldo, slab);  \
+    }
+#define PM_GEMM(AK, BK_)                     \
+    {                                        \
+        if (tuning().gemm_3m) {              \
+            PM_GEMM_(AK, BK_, true)          \
+        } else {                             \
+            PM_GEMM_(AK, BK_, false)         \
+        }                                    \
     }
         if (akf && bkf) {
             PM_GEMM(true, true)
@@ -267,6 +301,7 @@ int cgemm_ws_bk(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha,
             PM_GEMM(false, false)
         }
 #undef PM_GEMM
+#undef PM_GEMM_
     };
     if (S == 1) {
         launch(T(alpha), C, ldc, int64_t(0));
