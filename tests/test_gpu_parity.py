@@ -570,3 +570,30 @@ def test_real_input_paths_vs_oracle(pa, shape, dtype):
     got = tonp(C.conv(a, b))
     assert got.dtype == dtype and rel_max(got, O.conv(a.astype(np.float64), b.astype(np.float64))) < 4 * tol
     assert rel_max(tonp(P.angular_spectrum(a, 0.6, 0.01, 20.0, Q=1)), O.angular_spectrum(a.astype(np.float64), 0.6, 0.01, 20.0, Q=1)) < 4 * tol
+
+
+def test_hipgraph_capture_of_a_model(pa):
+    """A chain (pupil synthesis -> focus Q=2 -> |.|^2 -> OTF) captured into a hipGraph replays to the same bits as
+    the eager calls, on new inputs, and the library issues nothing that breaks capture (no sync, no allocation)."""
+    from prysm_amd import graph, otf
+    P = pa.propagation
+    rng = np.random.default_rng(31)
+    amp = (rng.random((256, 256)) > 0.3).astype(np.float64)
+
+    def model(a, opd):
+        wf = P.Wavefront.from_amp_and_phase(a, opd, 0.6328, 0.04)
+        psf = wf.focus(100.0, Q=2).intensity
+        mtf = otf.mtf_from_psf(psf)
+        return psf.data, mtf.data
+
+    opd0 = rng.standard_normal((256, 256)) * 50
+    m = graph.capture(model, amp, opd0)
+    for seed in (1, 2):
+        opd = np.random.default_rng(seed).standard_normal((256, 256)) * 80
+        psf_g, mtf_g = [t.clone() for t in m(amp, opd)]
+        psf_e, mtf_e = model(torch.from_numpy(amp).cuda(), torch.from_numpy(opd).cuda())
+        assert torch.equal(psf_g, psf_e) and torch.equal(mtf_g, mtf_e)
+        want = O.intensity(O.focus(O.from_amp_and_phase(amp, opd, 0.6328), 2))
+        assert rel_max(tonp(psf_g), want) < TOL64
+    with pytest.raises(ValueError):
+        m(amp)
