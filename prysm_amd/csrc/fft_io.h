@@ -240,34 +240,38 @@ template <typename C, int ROT, bool FULL = false, bool REAL = false>
 PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
                     cx<typename C::T> (&v)[C::E][C::P]) {
     using T = typename C::T;
-    static_assert(C::CI == 1 && C::E == 1, "row mode");
-    const int seq = blk * C::BO + pos.bo;
-    const bool ok = seq < p.nseq;
-    const cx<T>* row = p.src + int64_t(ok ? seq : 0) * p.ld - p.ax.off;
-    const T* rrow = reinterpret_cast<const T*>(p.src) + int64_t(ok ? seq : 0) * p.ld - p.ax.off;   // REAL input
-    const int lo = p.ax.off, hi = ok ? p.ax.off + p.ax.len : -1;
+    static_assert(C::CI == 1, "row mode");
+    // a thread owns E consecutive sequences (rows): (blk*BO + bo)*E + e; they share twiddles and addressing
 #pragma unroll
-    for (int m = 0; m < C::P; ++m) {
-        const int pp = slot_pos<C, ROT>(pos.t, m, p.ax.shift);
-        cx<T> val = {T(0), T(0)};
-        if (FULL || (pp >= lo && pp < hi)) {
-            if constexpr (REAL)
-                val.x = p.nt ? nt_load_s(rrow + pp) : rrow[pp];
-            else
-                val = p.nt ? nt_load_cx(row + pp) : row[pp];
+    for (int e = 0; e < C::E; ++e) {
+        const int seq = (blk * C::BO + pos.bo) * C::E + e;
+        const bool ok = seq < p.nseq;
+        const cx<T>* row = p.src + int64_t(ok ? seq : 0) * p.ld - p.ax.off;
+        const T* rrow = reinterpret_cast<const T*>(p.src) + int64_t(ok ? seq : 0) * p.ld - p.ax.off;   // REAL input
+        const int lo = p.ax.off, hi = ok ? p.ax.off + p.ax.len : -1;
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) {
+            const int pp = slot_pos<C, ROT>(pos.t, m, p.ax.shift);
+            cx<T> val = {T(0), T(0)};
+            if (FULL || (pp >= lo && pp < hi)) {
+                if constexpr (REAL)
+                    val.x = p.nt ? nt_load_s(rrow + pp) : rrow[pp];
+                else
+                    val = p.nt ? nt_load_cx(row + pp) : row[pp];
+            }
+            v[e][m] = val;
         }
-        v[0][m] = val;
-    }
-    if (!REAL && p.conj) {
+        if (!REAL && p.conj) {
 #pragma unroll
-        for (int m = 0; m < C::P; ++m) v[0][m].y = -v[0][m].y;
+            for (int m = 0; m < C::P; ++m) v[e][m].y = -v[e][m].y;
+        }
     }
 }
 
 template <typename C, bool REAL>
 PM_HD void load_sel(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
     const int rot = rot_of<C>(p.ax.shift);
-    const bool full = p.ax.off == 0 && p.ax.len == C::N && (blk * C::BO + pos.bo) < p.nseq;
+    const bool full = p.ax.off == 0 && p.ax.len == C::N && ((blk * C::BO + pos.bo) * C::E + C::E - 1) < p.nseq;
     if (rot == 0) {
         if (full) load_rot<C, 0, true, REAL>(p, blk, pos, v);
         else load_rot<C, 0, false, REAL>(p, blk, pos, v);
@@ -288,22 +292,25 @@ PM_HD void load(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<t
 template <typename C>
 PM_HD void store(const RowStoreTiled<typename C::T>& p, int blk, ThreadPos pos,
                  const cx<typename C::T> (&v)[C::E][C::P]) {
-    const int seq = blk * C::BO + pos.bo;
-    if (seq >= p.nseq) return;
     const int tcm = (1 << p.log_tc) - 1;
-    // element (seq, c) -> ((c >> ltc) * nseq + seq) << ltc  +  (c & tcm); c = t + m*TPS
-    if (C::TPS > tcm) {
-        // TPS is a multiple of the tile width: tile index and in-tile column separate cleanly
-        const int64_t base = ((int64_t(pos.t >> p.log_tc) * p.nseq + seq) << p.log_tc) + (pos.t & tcm);
-        const int64_t step = int64_t(C::TPS >> p.log_tc) * p.nseq << p.log_tc;
 #pragma unroll
-        for (int m = 0; m < C::P; ++m) p.dst[base + m * step] = v[0][m];
-    } else {
+    for (int e = 0; e < C::E; ++e) {
+        const int seq = (blk * C::BO + pos.bo) * C::E + e;
+        if (seq >= p.nseq) continue;
+        // element (seq, c) -> ((c >> ltc) * nseq + seq) << ltc  +  (c & tcm); c = t + m*TPS
+        if (C::TPS > tcm) {
+            // TPS is a multiple of the tile width: tile index and in-tile column separate cleanly
+            const int64_t base = ((int64_t(pos.t >> p.log_tc) * p.nseq + seq) << p.log_tc) + (pos.t & tcm);
+            const int64_t step = int64_t(C::TPS >> p.log_tc) * p.nseq << p.log_tc;
 #pragma unroll
-        for (int m = 0; m < C::P; ++m) {
-            const int c = pos.t + m * C::TPS;
-            const int64_t a = ((int64_t(c >> p.log_tc) * p.nseq + seq) << p.log_tc) + (c & tcm);
-            p.dst[a] = v[0][m];
+            for (int m = 0; m < C::P; ++m) p.dst[base + m * step] = v[e][m];
+        } else {
+#pragma unroll
+            for (int m = 0; m < C::P; ++m) {
+                const int c = pos.t + m * C::TPS;
+                const int64_t a = ((int64_t(c >> p.log_tc) * p.nseq + seq) << p.log_tc) + (c & tcm);
+                p.dst[a] = v[e][m];
+            }
         }
     }
 }
@@ -312,22 +319,25 @@ template <typename C, int ROT>
 PM_HD void store_rot(const RowStoreNat<typename C::T>& p, int blk, ThreadPos pos,
                      const cx<typename C::T> (&v)[C::E][C::P]) {
     using T = typename C::T;
-    const int seq = blk * C::BO + pos.bo;
-    if (seq >= p.nseq) return;
-    int mrow = seq;
-    if (p.use_ay) {
-        mrow = p.ay.map(seq);
-        if (mrow < 0) return;
-    }
-    cx<T>* row = p.dst + int64_t(mrow) * p.ld - p.ax.off;
-    const int lo = p.ax.off, hi = p.ax.off + p.ax.len;
 #pragma unroll
-    for (int m = 0; m < C::P; ++m) {
-        const int pp = slot_pos<C, ROT>(pos.t, m, p.ax.shift);
-        if (pp < lo || pp >= hi) continue;
-        cx<T> val = cscale(v[0][m], p.scale);
-        if (p.conj) val.y = -val.y;
-        row[pp] = val;
+    for (int e = 0; e < C::E; ++e) {
+        const int seq = (blk * C::BO + pos.bo) * C::E + e;
+        if (seq >= p.nseq) continue;
+        int mrow = seq;
+        if (p.use_ay) {
+            mrow = p.ay.map(seq);
+            if (mrow < 0) continue;
+        }
+        cx<T>* row = p.dst + int64_t(mrow) * p.ld - p.ax.off;
+        const int lo = p.ax.off, hi = p.ax.off + p.ax.len;
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) {
+            const int pp = slot_pos<C, ROT>(pos.t, m, p.ax.shift);
+            if (pp < lo || pp >= hi) continue;
+            cx<T> val = cscale(v[e][m], p.scale);
+            if (p.conj) val.y = -val.y;
+            row[pp] = val;
+        }
     }
 }
 
@@ -346,19 +356,22 @@ PM_HD void store(const RowStoreNat<typename C::T>& p, int blk, ThreadPos pos,
 template <typename C>
 PM_HD void load(const RowLoadTiled<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
     using T = typename C::T;
-    static_assert(C::CI == 1 && C::E == 1, "row mode");
-    const int seq = blk * C::BO + pos.bo;
-    const bool ok = seq < p.nseq;
-    const int q = p.row0 + (ok ? seq : 0);
+    static_assert(C::CI == 1, "row mode");
     const int tlm = (1 << p.log_tl) - 1;
 #pragma unroll
-    for (int m = 0; m < C::P; ++m) {
-        const int c = pos.t + m * C::TPS;
-        const int64_t a = ((int64_t(c >> p.log_tl) * p.nrows + q) << p.log_tl) + (c & tlm);
-        cx<T> val = {T(0), T(0)};
-        if (ok) val = p.src[a];
-        if (p.conj) val.y = -val.y;
-        v[0][m] = val;
+    for (int e = 0; e < C::E; ++e) {
+        const int seq = (blk * C::BO + pos.bo) * C::E + e;
+        const bool ok = seq < p.nseq;
+        const int q = p.row0 + (ok ? seq : 0);
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) {
+            const int c = pos.t + m * C::TPS;
+            const int64_t a = ((int64_t(c >> p.log_tl) * p.nrows + q) << p.log_tl) + (c & tlm);
+            cx<T> val = {T(0), T(0)};
+            if (ok) val = p.src[a];
+            if (p.conj) val.y = -val.y;
+            v[e][m] = val;
+        }
     }
 }
 

@@ -25,7 +25,10 @@ struct RowCfgSel {
     // VAR = 1: exchange real and imaginary parts separately -> half the LDS per workgroup, so the 72-VGPR
     // complex64 kernel fits 7 workgroups per CU instead of 4 (the row pass is latency / concurrency bound)
     static constexpr int COMP = ((sizeof(T) == 8 && LOGN >= 12) || VAR == 1) ? 2 : 1;   // VAR = 2: persistent kernel
-    using type = FftCfg<T, LOGN, 1, 1, BO, COMP>;
+    // VAR = 4: two consecutive rows per thread -- stage twiddles, their products and the LDS addressing are shared by
+    // the pair (the row pass spends more VALU time per point than the column pass, which already works this way)
+    static constexpr int E = (VAR == 4) ? 2 : 1;
+    using type = FftCfg<T, LOGN, 1, E, BO, COMP>;
 };
 // Column pass: a tile of 64 B rows (8 complex64 / 4 complex128 columns) per workgroup; at
 // M = 4096 that is 256 KiB of field in the registers of 1024 threads, exchanged through LDS in
@@ -87,14 +90,31 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
         __syncthreads();
         fft_run_twlds<C>(v, pos, pm_smem, tab);
     } else {
-        load<C>(lpb, unit, pos, v);
+        if constexpr (VAR == 6 || VAR == 7) {
+            // compute only (timing experiments): registers filled from the thread index, results stored only under a
+            // condition that never holds
+#pragma unroll
+            for (int e = 0; e < C::E; ++e)
+#pragma unroll
+                for (int m = 0; m < C::P; ++m) v[e][m] = {typename C::T(threadIdx.x + m), typename C::T(unit + e)};
+        } else {
+            load<C>(lpb, unit, pos, v);
+        }
         // two sequences per thread (complex64 columns): exchanges pipelined against the butterflies of the other
         // sequence (measured: 4096^2 column pass 57.2 -> 56.1 us, 8192^2 419 -> 358 us); VAR = 5 keeps the plain order
         // for A/B runs, VAR = 3 skips the transform (memory phases only: timing experiments, wrong results)
-        if constexpr (VAR != 5 && VAR != 3 && COL && C::E == 2 && C::COMP == 1 && C::NSTAGE > 1)
+        if constexpr (VAR == 7) {   // butterflies only, no exchange (timing experiments; wrong results)
+            stage_compute<C, 0>(v, pos.t, tw);
+            if constexpr (C::NSTAGE > 1) stage_compute<C, 1>(v, pos.t, tw);
+            if constexpr (C::NSTAGE > 2) stage_compute<C, 2>(v, pos.t, tw);
+            if constexpr (C::NSTAGE > 3) stage_compute<C, 3>(v, pos.t, tw);
+        } else if constexpr (VAR != 5 && VAR != 3 && C::E == 2 && C::COMP == 1 && C::NSTAGE > 1)
             fft_run_pipe2<C>(v, pos, pm_smem, tw);
         else if constexpr (VAR != 3)
             fft_run<C>(v, pos, pm_smem, tw);
+    }
+    if constexpr (VAR == 6 || VAR == 7) {
+        if (v[0][0].x != typename C::T(-12345.5)) return;
     }
     store<C>(spb, unit, pos, v);
 }
@@ -212,14 +232,15 @@ template <typename T, bool COL, int LOGN, int VAR, typename L, typename S>
 int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st, int nbatch) {
     using Sel = typename std::conditional<COL, ColCfgSel<T, LOGN, VAR>, RowCfgSel<T, LOGN, VAR>>::type;
     using C = typename Sel::type;
-    auto kern = fft_kernel<C, COL, (COL || VAR == 3 ? VAR : 0), L, S>;
+    auto kern = fft_kernel<C, COL, (COL || VAR == 3 || VAR == 4 || VAR == 6 || VAR == 7 ? VAR : 0), L, S>;
     constexpr size_t LDSB = kernel_lds_bytes<C, COL, (COL ? VAR : 0)>();
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
         if (e != hipSuccess) return int(e);
     }
-    const int grid = (units + C::BO - 1) / C::BO;
+    const int per_wg = C::BO * (COL ? 1 : C::E);     // row mode: a thread owns E consecutive rows
+    const int grid = (units + per_wg - 1) / per_wg;
     if (grid <= 0) return 0;
     if (nbatch <= 0) return 0;
     if constexpr (!COL && VAR == 2) {
@@ -255,7 +276,10 @@ int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int
         if (var == 1) return launch_one<T, COL, k, 1, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         if (var == 2 && !COL) return launch_one<T, COL, k, (COL ? 0 : 2), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         if (var == 3) return launch_one<T, COL, k, 3, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        if (var == 6) return launch_one<T, COL, k, 6, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        if (var == 7) return launch_one<T, COL, k, 7, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         if (var == 5 && COL) return launch_one<T, COL, k, (COL ? 5 : 0), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        if (var == 4 && !COL) return launch_one<T, COL, k, (COL ? 0 : 4), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st, nbatch);
         PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
         PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASEV(11) PM_CASEV(12) PM_CASEV(13)

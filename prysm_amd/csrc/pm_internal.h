@@ -75,7 +75,9 @@ Tuning& tuning();
 inline int row_variant(int dtype, int logn) {
     const int v = tuning().row_var;
     if (v >= 0) return v;
-    (void)dtype;
+    // two rows per thread (variant 4) for complex64 from 4096 points: 53.5 -> 51.4 us at 4096^2, 226 -> 207 us at 8192^2;
+    // it loses for complex128 (register pressure) and makes no difference at 2048
+    if (dtype == PM_C64 && logn >= 12) return 4;
     return logn == 11 ? 1 : 0;
 }
 
