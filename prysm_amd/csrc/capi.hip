@@ -80,6 +80,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("gemm_min_wgs")) t.gemm_min_wgs = v < 1 ? 1 : v;
     else if (is("nt_in")) t.nt_in = v;
     else if (is("nt_out")) t.nt_out = v;
+    else if (is("fold")) t.fold = v;
     else if (is("col_spread")) t.col_spread = v < 0 ? 0 : (v > 12 ? 12 : v);
     else if (is("col_skew")) t.col_skew = v < 0 ? 0 : (v > 64 ? 64 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
@@ -121,7 +122,21 @@ struct Fft2Plan {
     int64_t nbatch;       // fields
     int64_t chunk;        // fields per launch pair: the intermediates of one chunk stay resident in the 256 MiB
                           // Infinity Cache between the two passes, consecutive chunks reuse the same workspace
+    bool fold;            // one radix-2 step of the column transform is taken in the row pass (RowStoreFold): the column
+                          // pass then runs two planes of M/2-point tiles
 };
+
+// The fold needs every input row stored (pairs (i, i + M/2) are combined), rotations by 0 or M/2 and an even output
+// window.  It pays from 4096-point columns: the M/2-point column tiles leave room for two workgroups per CU (their
+// load / butterfly / store phases overlap), twice the register budget per thread (complex128) and 64 B instead of 32 B
+// pieces at 8192.  Measured (profiles/r01/tune_fold.log): 4096^2 complex64 101.9 -> 98.1 us, complex128 229 -> 216 us,
+// 8192^2 complex64 557 -> 497 us, complex128 1143 -> 1047 us; 2048-point columns gain nothing (complex128 loses).
+static bool fold_legal(const pm_fft2_desc* d, int logn, int logm) {
+    const int64_t M = d->in_y.n;
+    return logn >= 11 && logm >= 3 && d->in_y.off == 0 && d->in_y.len == M && (d->in_y.shift == 0 || d->in_y.shift == M / 2) &&
+           (d->out_y.off % 2) == 0 && (d->out_y.len % 2) == 0 && (d->out_y.shift % 2) == 0 && d->mul_kind == PM_MUL_NONE &&
+           d->batch <= 1 && (d->out_ld % 2) == 0;
+}
 
 static int64_t batch_chunk(int64_t nb, size_t ws_field) {
     const size_t budget = size_t(tuning().batch_ws_mib) << 20;
@@ -137,8 +152,13 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     p.logm = engine_log2(M);
     const size_t es = d->dtype == PM_C64 ? 8 : 16;
     const int64_t rows = d->in_y.len;   // only stored input rows are transformed in pass 1
+    p.fold = false;
     if (p.logn >= 0 && p.logm >= 0) {
-        p.tc = col_tile_width_for(d->dtype, p.logm, tuning().col_var);
+        if (fold_legal(d, p.logn, p.logm)) {
+            const int f = tuning().fold;
+            p.fold = f > 0 || (f < 0 && p.logm >= 12);
+        }
+        p.tc = col_tile_width_for(d->dtype, p.fold ? p.logm - 1 : p.logm, tuning().col_var);
         p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 8192 ? 3 : (N >= 4096 ? 2 : 1));   // auto: >= 256 B pieces from 4096 columns
         while (p.log_k > 0 && (N % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
         const int64_t tl = int64_t(p.tc) << p.log_k;
@@ -158,7 +178,7 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
 }
 
 template <typename T>
-static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out) {
+static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out, int logm_tile = -1) {
     ColStoreNat<T> cs{};
     cs.dst = out;
     cs.ld = d->out_ld;
@@ -184,9 +204,13 @@ static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out) {
                              (d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T));
     // streaming stores only help when a workgroup writes whole 64 B pieces; on the 32 B pieces of 8192-point
     // columns they defeat the L2 write combining of sibling workgroups (measured: 977 -> 428 us without)
-    const size_t piece = size_t(col_tile_width_for(d->dtype, engine_log2(d->out_y.n) >= 0 ? engine_log2(d->out_y.n) : 12, 0)) *
+    if (logm_tile < 0) logm_tile = engine_log2(d->out_y.n) >= 0 ? engine_log2(d->out_y.n) : 12;
+    const size_t piece = size_t(col_tile_width_for(d->dtype, logm_tile, 0)) *
                          (d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T));
-    cs.nt = tuning().nt_out >= 0 ? tuning().nt_out : ((out_bytes >= (size_t(192) << 20) && piece >= 64) ? 1 : 0);
+    // ... and only while the output is about the size of the 256 MiB Infinity Cache: measured +25 % at 256 MiB (4096^2
+    // complex128), -10 % at 512 MiB and 1 GiB (8192^2), -8 % at 128 MiB
+    cs.nt = tuning().nt_out >= 0 ? tuning().nt_out
+                                 : ((out_bytes >= (size_t(192) << 20) && out_bytes < (size_t(384) << 20) && piece >= 64) ? 1 : 0);
     return cs;
 }
 
@@ -211,7 +235,16 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
             RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, conj, nt_in, d->in_bstride,
                              (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
             int rc;
-            if (p.tc) {
+            if (p.fold) {
+                int ltc = 0;
+                while ((1 << ltc) < (p.tc << p.log_k)) ++ltc;
+                const cx<T>* twm = twiddles<T>(M, &err);
+                if (!twm) return err;
+                lp.eoff = int(M / 2);
+                const int64_t tl = int64_t(1) << ltc, ntl = (N + tl - 1) / tl;
+                RowStoreFold<T> sp{W, ntl * (M / 2) * tl, int(M / 2), ltc, twm, d->in_y.shift == M / 2 ? 1 : 0, 0};
+                rc = launch_row_fold<T>(p.logn, lp, sp, tw, int(M / 2), 0, st, 1);   // pairs are not siblings: no XCD grouping
+            } else if (p.tc) {
                 int ltc = 0;
                 while ((1 << ltc) < (p.tc << p.log_k)) ++ltc;
                 RowStoreTiled<T> sp{W, rows, ltc, wstride};
@@ -233,7 +266,21 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
     if (!run2) return 0;
 
     // ---- pass 2: transforms of length M down the columns, epilogue fused into the store
-    ColStoreNat<T> cs = make_colstore<T>(d, out);
+    ColStoreNat<T> cs = make_colstore<T>(d, out, p.fold ? p.logm - 1 : -1);
+    if (p.fold) {
+        // two planes of M/2-point column transforms: plane b holds output rows 2k + b -> output view with doubled
+        // leading dimension, plane b offset by one row (the batch stride of the store)
+        const cx<T>* tw = twiddles<T>(M / 2, &err);
+        if (!tw) return err;
+        const int ntiles = int((N + p.tc - 1) / p.tc);
+        const int64_t tl = int64_t(p.tc) << p.log_k, ntl = (N + tl - 1) / tl;
+        const int H = int(M / 2);
+        ColLoadTiled<T> cl{W, H, AxisMap{H, H, 0, 0}, ntiles, p.log_k, ntl * H * tl};
+        cs.ay = AxisMap{H, int(d->out_y.len / 2), int(d->out_y.off / 2), int(d->out_y.shift / 2)};
+        cs.bstride = d->out_ld;
+        cs.ld = 2 * d->out_ld;
+        return launch_col_tiled<T>(p.logm - 1, tuning().col_var, cl, cs, tw, ntiles, (p.log_k > 1 ? p.log_k : 1), st, 2);
+    }
     if (p.logm >= 0) {
         const cx<T>* tw = twiddles<T>(M, &err);
         if (!tw) return err;

@@ -37,6 +37,8 @@ struct RowLoadNat {
     int nt;         // non-temporal loads (input is read exactly once)
     int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
     int real;       // the array is REAL (T, not cx<T>): src points at T, ld / bstride count real elements, imag = 0
+    int eoff;       // E > 1: sequence of slot e is unit*E + e (eoff == 0, consecutive rows) or unit + e*eoff (rows eoff apart:
+                    // the pair (i, i + M/2) of a folded column transform)
 };
 
 template <typename T>
@@ -45,6 +47,23 @@ struct RowStoreTiled {
     int nseq;       // rows of the intermediate
     int log_tc;     // log2(LAYOUT tile width TL): one row of a layout tile is TL*sizeof(complex) contiguous bytes
     int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
+};
+
+// Row pass of a FOLDED 2-D transform: the thread's two rows are the pair (i, i + M/2) of the column axis; one radix-2
+// decimation-in-frequency step of the length-M column transform is taken here,
+//     plane 0 row i = y[i] + y[i + M/2]          (-> even output rows, an M/2-point column transform)
+//     plane 1 row i = (y[i] - y[i + M/2]) W_M^i  (-> odd output rows)
+// so the column pass runs M/2-point tiles: 64 B pieces instead of 32 B at M = 8192, twice the register budget per
+// thread at M = 4096 complex128.  Both planes are stored tiled like RowStoreTiled.
+template <typename T>
+struct RowStoreFold {
+    cx<T>* dst;             // plane 0; plane 1 at dst + plane_stride
+    int64_t plane_stride;   // elements
+    int npairs;             // M / 2 = rows per plane
+    int log_tc;
+    const cx<T>* twm;       // twiddle table of length M (W_M^k)
+    int swap;               // input rows were rotated by M/2 (ifftshift): slot 0 holds logical row i + M/2
+    int64_t bstride;
 };
 
 template <typename T>
@@ -214,6 +233,7 @@ template <typename T> PM_HD RowLoadNat<T> at_batch(RowLoadNat<T> p, int b) {
     return p;
 }
 template <typename T> PM_HD RowStoreTiled<T> at_batch(RowStoreTiled<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD RowStoreFold<T> at_batch(RowStoreFold<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD RowStoreNat<T> at_batch(RowStoreNat<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD RowLoadTiled<T> at_batch(RowLoadTiled<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD ColStoreTiled<T> at_batch(ColStoreTiled<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
@@ -244,8 +264,9 @@ PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
     // a thread owns E consecutive sequences (rows): (blk*BO + bo)*E + e; they share twiddles and addressing
 #pragma unroll
     for (int e = 0; e < C::E; ++e) {
-        const int seq = (blk * C::BO + pos.bo) * C::E + e;
-        const bool ok = seq < p.nseq;
+        const int unit = blk * C::BO + pos.bo;
+        const int seq = p.eoff ? unit + e * p.eoff : unit * C::E + e;
+        const bool ok = seq < p.nseq && (!p.eoff || unit < p.eoff);
         const cx<T>* row = p.src + int64_t(ok ? seq : 0) * p.ld - p.ax.off;
         const T* rrow = reinterpret_cast<const T*>(p.src) + int64_t(ok ? seq : 0) * p.ld - p.ax.off;   // REAL input
         const int lo = p.ax.off, hi = ok ? p.ax.off + p.ax.len : -1;
@@ -271,7 +292,9 @@ PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
 template <typename C, bool REAL>
 PM_HD void load_sel(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
     const int rot = rot_of<C>(p.ax.shift);
-    const bool full = p.ax.off == 0 && p.ax.len == C::N && ((blk * C::BO + pos.bo) * C::E + C::E - 1) < p.nseq;
+    const int unit_ = blk * C::BO + pos.bo;
+    const bool full = p.ax.off == 0 && p.ax.len == C::N &&
+                      (p.eoff ? (unit_ < p.eoff && unit_ + (C::E - 1) * p.eoff < p.nseq) : (unit_ * C::E + C::E - 1) < p.nseq);
     if (rot == 0) {
         if (full) load_rot<C, 0, true, REAL>(p, blk, pos, v);
         else load_rot<C, 0, false, REAL>(p, blk, pos, v);
@@ -312,6 +335,27 @@ PM_HD void store(const RowStoreTiled<typename C::T>& p, int blk, ThreadPos pos,
                 p.dst[a] = v[e][m];
             }
         }
+    }
+}
+
+template <typename C>
+PM_HD void store(const RowStoreFold<typename C::T>& p, int blk, ThreadPos pos,
+                 const cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    static_assert(C::E == 2, "the fold pairs the two rows of a thread");
+    const int i = blk * C::BO + pos.bo;       // pair index = logical row of the lower half
+    if (i >= p.npairs) return;
+    const cx<T> w = p.twm[i];
+    const int tcm = (1 << p.log_tc) - 1;
+    const int lo = p.swap ? 1 : 0, hi = lo ^ 1;
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const int c = pos.t + m * C::TPS;
+        const int64_t a = ((int64_t(c >> p.log_tc) * p.npairs + i) << p.log_tc) + (c & tcm);
+        const cx<T> s = {v[lo][m].x + v[hi][m].x, v[lo][m].y + v[hi][m].y};
+        const cx<T> d = {v[lo][m].x - v[hi][m].x, v[lo][m].y - v[hi][m].y};
+        p.dst[a] = s;
+        p.dst[a + p.plane_stride] = cmul(d, w);
     }
 }
 

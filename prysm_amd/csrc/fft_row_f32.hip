@@ -10,4 +10,7 @@ template <> int launch_row_nat<float>(int logn, int var, const RowLoadNat<float>
 template <> int launch_row_from_tiled<float>(int logn, int var, const RowLoadTiled<float>& l, const RowStoreNat<float>& s, const cx<float>* tw, int nseq, hipStream_t st, int nbatch) {
     return launch_fft<float, false>(logn, var == 2 ? 0 : var, l, s, tw, nseq, 0, st, nbatch);
 }
+template <> int launch_row_fold<float>(int logn, const RowLoadNat<float>& l, const RowStoreFold<float>& s, const cx<float>* tw, int npairs, int log_g, hipStream_t st, int nbatch) {
+    return launch_fold_impl<float>(logn, l, s, tw, npairs, log_g, st, nbatch);
+}
 }  // namespace pm

@@ -10,4 +10,7 @@ template <> int launch_row_nat<double>(int logn, int var, const RowLoadNat<doubl
 template <> int launch_row_from_tiled<double>(int logn, int var, const RowLoadTiled<double>& l, const RowStoreNat<double>& s, const cx<double>* tw, int nseq, hipStream_t st, int nbatch) {
     return launch_fft<double, false>(logn, var == 2 ? 0 : var, l, s, tw, nseq, 0, st, nbatch);
 }
+template <> int launch_row_fold<double>(int logn, const RowLoadNat<double>& l, const RowStoreFold<double>& s, const cx<double>* tw, int npairs, int log_g, hipStream_t st, int nbatch) {
+    return launch_fold_impl<double>(logn, l, s, tw, npairs, log_g, st, nbatch);
+}
 }  // namespace pm

@@ -43,6 +43,7 @@ template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled
 template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_row_from_tiled(int logn, int var, const RowLoadTiled<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t, int nbatch = 1);
+template <typename T> int launch_row_fold(int logn, const RowLoadNat<T>&, const RowStoreFold<T>&, const cx<T>* tw, int npairs, int log_g, hipStream_t, int nbatch = 1);
 // tile width of the column pass; MUST match ColCfgSel in fft_kernels.h (CI * E)
 inline int col_tile_width_for(int dtype, int logm, int var) {
     (void)var;
@@ -63,6 +64,7 @@ struct Tuning {
     int gemm_bk = 0;          // 0 default K-tile depth, 32 doubles it
     int gemm_min_wgs = 1024;   // split K until the GEMM launch has at least this many workgroups
     int row_log_g = 1;  // sibling group of row-pass workgroups (rows q .. q+2^g-1 on one XCD)
+    int fold = -1;           // radix-2 step of the column transform folded into the row pass: -1 auto, 0 never, 1 wherever legal
     int col_spread = 0;      // experiment: log2 of the stride permutation of column-pass sibling groups
     int col_skew = 0;        // experiment: start skew of every other column-pass workgroup, units of ~0.85 us
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take

@@ -597,3 +597,30 @@ def test_hipgraph_capture_of_a_model(pa):
         assert rel_max(tonp(psf_g), want) < TOL64
     with pytest.raises(ValueError):
         m(amp)
+
+
+@pytest.mark.parametrize('shape,dtype,forced', [((8192, 2048), np.complex64, False), ((4096, 2048), np.complex128, False),
+                                                ((64, 2048), np.complex64, True), ((256, 4096), np.complex128, True)])
+def test_folded_column_transform_vs_oracle(pa, shape, dtype, forced):
+    """The radix-2 step of the column transform folded into the row pass (8192-point columns; 4096-point complex128
+    columns; forced by the tuning knob elsewhere): focus / unfocus / |.|^2 / even crops equal the oracle, and the
+    folded and unfolded paths agree."""
+    from prysm_amd import _lib
+    P = pa.propagation
+    lib = _lib.load()
+    rng = np.random.default_rng(shape[0] * 3 + shape[1])
+    x = crandn(rng, shape, dtype)
+    tol = TOL64 if dtype == np.complex128 else TOL32
+    try:
+        if forced:
+            lib.pm_set_tuning(b'fold', 1)
+        got = tonp(P.focus(x, 1))
+        assert rel_max(got, O.focus(x, 1)) < tol
+        assert rel_max(tonp(P.unfocus(x, 1)), O.unfocus(x, 1)) < tol
+        assert rel_max(tonp(P.focus_intensity(x, 1)), O.intensity(O.focus(x, 1))) < 4 * tol
+        assert rel_max(tonp(P.focus_adjoint(x, 2)), O.focus_adjoint(x, 2)) < tol      # even crop of the output
+        lib.pm_set_tuning(b'fold', 0)
+        unfolded = tonp(P.focus(x, 1))
+        assert rel_max(got, unfolded) < 4 * tol
+    finally:
+        lib.pm_set_tuning(b'fold', -1)

@@ -121,6 +121,41 @@ static void test_row(int nseq, int in_len, int in_off, int in_shift, int out_shi
     report(buf, err / nrm, sizeof(T) == 4 ? 2e-6 : 1e-14);
 }
 
+// naive separable 2-D DFT of the padded / rotated input, scaled 1/sqrt(MN): B[k][c]
+template <typename T>
+static std::vector<cld> naive_2d(const std::vector<cx<T>>& x, int in_rows, int in_cols, int M, int N, int offy, int offx, int shy,
+                                 int shx, bool inverse) {
+    const ld pi = acosl(-1.0L);
+    std::vector<cld> P(size_t(M) * N, cld(0, 0));
+    for (int r = 0; r < M; ++r)
+        for (int c = 0; c < N; ++c) {
+            int qr = (r + shy) % M - offy, qc = (c + shx) % N - offx;
+            if (qr >= 0 && qr < in_rows && qc >= 0 && qc < in_cols)
+                P[size_t(r) * N + c] = cld(x[size_t(qr) * in_cols + qc].x, x[size_t(qr) * in_cols + qc].y);
+        }
+    std::vector<cld> A(size_t(M) * N), B(size_t(M) * N);
+    const ld sg = inverse ? 2 : -2;
+    for (int r = 0; r < M; ++r)
+        for (int k = 0; k < N; ++k) {
+            cld acc(0, 0);
+            for (int n = 0; n < N; ++n) {
+                ld ang = sg * pi * ld((int64_t(n) * k) % N) / N;
+                acc += P[size_t(r) * N + n] * cld(cosl(ang), sinl(ang));
+            }
+            A[size_t(r) * N + k] = acc;
+        }
+    for (int c = 0; c < N; ++c)
+        for (int k = 0; k < M; ++k) {
+            cld acc(0, 0);
+            for (int n = 0; n < M; ++n) {
+                ld ang = sg * pi * ld((int64_t(n) * k) % M) / M;
+                acc += A[size_t(n) * N + c] * cld(cosl(ang), sinl(ang));
+            }
+            B[size_t(k) * N + c] = acc / sqrtl(ld(M) * N);
+        }
+    return B;
+}
+
 // --- 2-D: row pass -> tiled intermediate -> column pass, vs naive 2-D DFT ---------------
 template <typename T, int LOGM, int LOGN, int RBO, int RCOMP, int CCI, int CE, int CBO, int CCOMP>
 static void test_2d(int in_rows, int in_cols, bool shifts, int epilogue, bool inverse, int out_rows, int out_cols, int log_k = 0) {
@@ -162,36 +197,7 @@ static void test_2d(int in_rows, int in_cols, bool shifts, int epilogue, bool in
     cs.vec_ok = (out_cols % 2 == 0) ? 1 : 0;
     const int ngroups = (ntiles + CC::BO - 1) / CC::BO;
     emu_kernel<CC, true>(ngroups, cl, cs, twM.data());
-    // reference
-    const ld pi = acosl(-1.0L);
-    std::vector<cld> P(size_t(M) * N, cld(0, 0));
-    for (int r = 0; r < M; ++r)
-        for (int c = 0; c < N; ++c) {
-            int qr = (r + shy) % M - offy, qc = (c + shx) % N - offx;
-            if (qr >= 0 && qr < in_rows && qc >= 0 && qc < in_cols)
-                P[size_t(r) * N + c] = cld(x[size_t(qr) * in_cols + qc].x, x[size_t(qr) * in_cols + qc].y);
-        }
-    // separable naive DFT
-    std::vector<cld> A(size_t(M) * N), B(size_t(M) * N);
-    const ld sg = inverse ? 2 : -2;
-    for (int r = 0; r < M; ++r)
-        for (int k = 0; k < N; ++k) {
-            cld acc(0, 0);
-            for (int n = 0; n < N; ++n) {
-                ld ang = sg * pi * ld((int64_t(n) * k) % N) / N;
-                acc += P[size_t(r) * N + n] * cld(cosl(ang), sinl(ang));
-            }
-            A[size_t(r) * N + k] = acc;
-        }
-    for (int c = 0; c < N; ++c)
-        for (int k = 0; k < M; ++k) {
-            cld acc(0, 0);
-            for (int n = 0; n < M; ++n) {
-                ld ang = sg * pi * ld((int64_t(n) * k) % M) / M;
-                acc += A[size_t(n) * N + c] * cld(cosl(ang), sinl(ang));
-            }
-            B[size_t(k) * N + c] = acc / sqrtl(ld(M) * N);
-        }
+    const std::vector<cld> B = naive_2d<T>(x, in_rows, in_cols, M, N, offy, offx, shy, shx, inverse);
     double err = 0, nrm = 0;
     for (int k = 0; k < M; ++k)
         for (int c = 0; c < N; ++c) {
@@ -211,6 +217,72 @@ static void test_2d(int in_rows, int in_cols, bool shifts, int epilogue, bool in
     char buf[160];
     snprintf(buf, sizeof buf, "2d %s %dx%d in=%dx%d out=%dx%d sh=%d epi=%d %s TC=%d TL=%d", sizeof(T) == 4 ? "c64" : "c128",
              M, N, in_rows, in_cols, out_rows, out_cols, (int)shifts, epilogue, inverse ? "inv" : "fwd", TC, TL);
+    report(buf, err / nrm, sizeof(T) == 4 ? 3e-6 : 1e-13);
+}
+
+// --- folded 2-D: the row pass (two rows (i, i + M/2) per thread) takes one radix-2 step of the column transform, the
+// column pass runs two planes of M/2-point tiles that write the even / odd output rows -----------------------------
+template <typename T, int LOGM, int LOGN, int RBO, int RCOMP, int CCI, int CE, int CBO, int CCOMP>
+static void test_2d_fold(int in_cols, bool shifts, int epilogue, bool inverse, int out_rows, int out_cols, int log_k = 0) {
+    using RC = FftCfg<T, LOGN, 1, 2, RBO, RCOMP>;
+    using CC = FftCfg<T, LOGM - 1, CCI, CE, CBO, CCOMP>;
+    const int M = 1 << LOGM, H = M / 2, N = RC::N, TC = CCI * CE, TL = TC << log_k;
+    int log_tc = 0;
+    while ((1 << log_tc) < TL) ++log_tc;
+    std::mt19937 rng(LOGM * 19 + LOGN);
+    std::normal_distribution<double> nd;
+    std::vector<cx<T>> x(size_t(M) * in_cols);
+    for (auto& e : x) e = {T(nd(rng)), T(nd(rng))};
+    const int offx = (N - in_cols + 1) / 2;
+    const int shy = shifts ? M / 2 : 0, shx = shifts ? N / 2 : 0;
+    const int ntiles = (N + TC - 1) / TC, ntl = (N + TL - 1) / TL;
+    const int64_t plane = int64_t(ntl) * H * TL;
+    std::vector<cx<T>> W(size_t(2 * plane), cx<T>{T(1e30), T(1e30)});
+    auto twN = make_tw<T>(N);
+    auto twM = make_tw<T>(M);
+    auto twH = make_tw<T>(H);
+    RowLoadNat<T> lp{x.data(), in_cols, AxisMap{N, in_cols, offx, shx}, M, inverse ? 1 : 0, 0, 0, 0, H};
+    RowStoreFold<T> sp{W.data(), plane, H, log_tc, twM.data(), shifts ? 1 : 0, 0};
+    emu_kernel<RC, false>((H + RC::BO - 1) / RC::BO, lp, sp, twN.data());
+    const int coffy = (M - out_rows + 1) / 2, coffx = (N - out_cols + 1) / 2;
+    std::vector<cx<T>> out(size_t(out_rows) * out_cols, cx<T>{T(-3), T(-3)});
+    std::vector<T> outr(size_t(out_rows) * out_cols, T(-3));
+    ColLoadTiled<T> cl{W.data(), H, AxisMap{H, H, 0, 0}, ntiles, log_k, plane};
+    ColStoreNat<T> cs{};
+    cs.dst = epilogue ? (void*)outr.data() : (void*)out.data();
+    cs.ld = 2 * out_cols;
+    cs.ay = AxisMap{H, out_rows / 2, coffy / 2, shy / 2};
+    cs.ax = AxisMap{N, out_cols, coffx, shx};
+    cs.conj = inverse ? 1 : 0;
+    cs.epilogue = epilogue;
+    cs.scale = T(1.0 / sqrt(double(M) * N));
+    cs.weight = T(1);
+    cs.mul_kind = MUL_NONE;
+    cs.vec_ok = (out_cols % 2 == 0) ? 1 : 0;
+    cs.bstride = out_cols;
+    const int ngroups = (ntiles + CC::BO - 1) / CC::BO;
+    for (int plane_id = 0; plane_id < 2; ++plane_id)
+        emu_kernel<CC, true>(ngroups, at_batch(cl, plane_id), at_batch(cs, plane_id), twH.data());
+    const std::vector<cld> B = naive_2d<T>(x, M, in_cols, M, N, 0, offx, shy, shx, inverse);
+    double err = 0, nrm = 0;
+    for (int k = 0; k < M; ++k)
+        for (int c = 0; c < N; ++c) {
+            int qy = (k + shy) % M - coffy, qx = (c + shx) % N - coffx;
+            if (qy < 0 || qy >= out_rows || qx < 0 || qx >= out_cols) continue;
+            cld ref = B[size_t(k) * N + c];
+            if (epilogue) {
+                ld r2 = std::norm(ref);
+                err = fmax(err, (double)fabsl(r2 - outr[size_t(qy) * out_cols + qx]));
+                nrm = fmax(nrm, (double)r2);
+            } else {
+                cx<T> got = out[size_t(qy) * out_cols + qx];
+                err = fmax(err, (double)std::abs(ref - cld(got.x, got.y)));
+                nrm = fmax(nrm, (double)std::abs(ref));
+            }
+        }
+    char buf[160];
+    snprintf(buf, sizeof buf, "2d FOLD %s %dx%d in=%dx%d out=%dx%d sh=%d epi=%d %s TC=%d TL=%d", sizeof(T) == 4 ? "c64" : "c128",
+             M, N, M, in_cols, out_rows, out_cols, (int)shifts, epilogue, inverse ? "inv" : "fwd", TC, TL);
     report(buf, err / nrm, sizeof(T) == 4 ? 3e-6 : 1e-13);
 }
 
@@ -394,6 +466,12 @@ int main() {
     test_2d<double, 6, 6, 64, 1, 4, 1, 16, 2>(64, 64, true, 0, false, 64, 64);
     test_2d<double, 5, 7, 32, 2, 4, 1, 32, 1>(20, 100, true, 0, true, 32, 128);
     test_2d<double, 8, 4, 256, 1, 2, 1, 8, 2>(256, 16, false, 1, false, 256, 16);
+    test_2d_fold<float, 6, 5, 128, 1, 4, 2, 32, 1>(32, true, 0, false, 64, 32, 1);
+    test_2d_fold<float, 5, 6, 64, 1, 4, 2, 64, 1>(50, false, 0, false, 32, 64);             // padded columns, no rotation
+    test_2d_fold<float, 6, 6, 64, 1, 4, 2, 32, 1>(64, true, 1, false, 64, 64, 2);            // |.|^2 epilogue
+    test_2d_fold<float, 6, 5, 128, 1, 4, 2, 32, 1>(32, true, 0, true, 32, 16);               // inverse + even crop
+    test_2d_fold<double, 6, 6, 64, 1, 4, 1, 32, 2>(64, true, 0, false, 64, 64, 2);
+    test_2d_fold<double, 7, 5, 128, 2, 4, 1, 16, 2>(20, true, 0, true, 128, 32, 1);
     test_fused<float, 5, 6, 64, 4, 2, 32, 1>(32, 64, 32, 64, 1, true, false, false);
     test_fused<float, 6, 5, 128, 4, 2, 16, 1>(40, 20, 64, 32, 2, false, false, false);   // padded input
     test_fused<float, 5, 6, 64, 4, 2, 32, 1>(32, 64, 16, 32, 0, true, true, false);      // adjoint: conj(H) + crop
