@@ -92,9 +92,11 @@ def pmc_traffic(kernel, n, dtype_name):
         return None, None
     want = f"fft_{kernel}"
     real = 'float' if dtype_name == 'c64' else 'double'
-    for k, v in tab.items():
-        if k.startswith(want) and k.endswith(f'_{real}_N{n}'):
-            return v['hbm_traffic_bytes'], f'profiles/pmc_bench_summary.json:{k}'
+    # the folded column pass runs kernels of n/2 points (two planes per launch), the row pass kernels of n points
+    for nn in (n, n // 2):
+        for k, v in tab.items():
+            if k.startswith(want) and k.endswith(f'_{real}_N{nn}'):
+                return v['hbm_traffic_bytes'], f'profiles/pmc_bench_summary.json:{k}'
     return None, None
 
 

@@ -333,6 +333,7 @@ struct FusedPlan {
     bool inplace;
     int64_t nbatch, chunk;       // fields, fields per launch triple
     size_t ws_bytes;             // total workspace
+    bool fold;                   // radix-2 step of the column transforms folded into the first / last row pass
 };
 
 static bool plan_fused(const pm_fft2_desc* d, FusedPlan& p) {
@@ -341,7 +342,14 @@ static bool plan_fused(const pm_fft2_desc* d, FusedPlan& p) {
     p.logm = engine_log2(M);
     if (p.logn < 0 || p.logm < 0) return false;
     const size_t es = d->dtype == PM_C64 ? 8 : 16;
-    p.tc = col_tile_width_for(d->dtype, p.logm, 0);
+    // fold (see fold_legal): here the output window is unconstrained -- the last row pass rebuilds whole rows
+    p.fold = false;
+    if (p.logn >= 11 && p.logm >= 3 && d->in_y.off == 0 && d->in_y.len == M && (d->in_y.shift == 0 || d->in_y.shift == M / 2) &&
+        d->batch <= 1) {
+        const int f = tuning().fold;
+        p.fold = f > 0 || (f < 0 && p.logm >= 12);
+    }
+    p.tc = col_tile_width_for(d->dtype, p.fold ? p.logm - 1 : p.logm, 0);
     p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 8192 ? 3 : (N >= 4096 ? 2 : 1));
     while (p.log_k > 0 && (N % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
     const int64_t tl = int64_t(p.tc) << p.log_k, ntl = (N + tl - 1) / tl;
@@ -372,6 +380,31 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
     const int tl = p.tc << p.log_k;
     int ltl = 0;
     while ((1 << ltl) < tl) ++ltl;
+    if (p.fold) {
+        // folded chain: row FFT + radix-2 DIF step -> two planes of M/2 rows; column FFT x H x IFFT per plane on M/2
+        // points (in place); radix-2 DIT step + inverse row FFT -> natural output
+        const int H = int(M / 2);
+        const int64_t ntl = (N + tl - 1) / tl, plane = ntl * H * tl;
+        const cx<T>* twH = twiddles<T>(H, &err);
+        if (!twH) return err;
+        const size_t in_bytes = size_t(M) * size_t(d->in_x.len) * sizeof(cx<T>);
+        const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
+        RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), int(M), 0, nt_in, 0,
+                         (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0, H};
+        RowStoreFold<T> sp{W1, plane, H, ltl, twM, d->in_y.shift == M / 2 ? 1 : 0, 0};
+        int rc = launch_row_fold<T>(p.logn, lp, sp, twN, H, 0, st, 1);
+        if (rc) return rc;
+        const int ntiles = int((N + p.tc - 1) / p.tc);
+        ColLoadTiled<T> cl{W1, H, AxisMap{H, H, 0, 0}, ntiles, p.log_k, plane};
+        MidMul<T> mm{d->mul_kind, d->mul_conj, reinterpret_cast<const cx<T>*>(d->mul), reinterpret_cast<const cx<T>*>(d->mul_x),
+                     2 * d->mul_ld, int(N), d->mul_kind == PM_MUL_FULL ? d->mul_ld : 1, 0, 2};
+        ColStoreTiled<T> cst{W1, H, ntiles, p.log_k, plane};
+        rc = launch_col_mul<T>(p.logm - 1, cl, mm, cst, twH, ntiles, p.log_k > 1 ? p.log_k : 1, st, 2);
+        if (rc) return rc;
+        RowLoadFold<T> rl{W1, plane, H, ltl, twM, 1, 0};
+        RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), int(M), 1, T(d->scale), 1, to_map(d->out_y), 0, H};
+        return launch_row_unfold<T>(p.logn, rl, rs, twN, H, st, 1);
+    }
     // pass A: forward row transforms of the stored input rows -> tiled W1
     if (rows > 0) {
         const size_t in_bytes = size_t(p.nbatch) * size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);

@@ -77,6 +77,7 @@ struct RowStoreNat {
     int use_ay;     // 0: sequence s is written to memory row s; 1: to row ay.map(s) (rotation / crop of rows)
     AxisMap ay;
     int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
+    int eoff;          // E > 1: sequence of slot e is unit*E + e (0) or unit + e*eoff (the pair (n, n + M/2) of an unfolded transform)
 };
 
 // row pass reading the tiled intermediate (third pass of the fused fft2 -> multiply -> ifft2)
@@ -89,6 +90,21 @@ struct RowLoadTiled {
     int nseq;
     int conj;
     int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
+};
+
+// Row pass UNDOING a fold (last pass of the folded fused operation): the two planes hold the M/2-point inverse column
+// transforms A0[n], A1[n] of the even / odd bins; one radix-2 decimation-in-time step rebuilds the two rows
+//     z[n] = A0[n] + conj(W_M^n) A1[n],     z[n + M/2] = A0[n] - conj(W_M^n) A1[n]
+// in the registers of the thread that then transforms both along the row.
+template <typename T>
+struct RowLoadFold {
+    const cx<T>* src;       // plane 0; plane 1 at src + plane_stride
+    int64_t plane_stride;
+    int npairs;             // M / 2 = rows per plane
+    int log_tl;
+    const cx<T>* twm;       // W_M^k
+    int conj;               // conjugate the rebuilt rows (inverse row transform = conj-in / conj-out)
+    int64_t bstride;
 };
 
 // column pass writing back into the tiled layout (second pass of the fused operation)
@@ -113,6 +129,7 @@ struct MidMul {
     int ncols;
     int64_t bstride;   // elements between the multipliers (FULL) / the hy vectors (SEPARABLE) of consecutive fields;
     int64_t bstride_x; // ... between the hx vectors.  0: one multiplier for the whole batch
+    int ystep;         // SEPARABLE: row factor of bin k is mul[k * ystep] (0 means 1); 2 for the planes of a folded transform
 };
 
 template <typename T>
@@ -235,6 +252,7 @@ template <typename T> PM_HD RowLoadNat<T> at_batch(RowLoadNat<T> p, int b) {
 template <typename T> PM_HD RowStoreTiled<T> at_batch(RowStoreTiled<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD RowStoreFold<T> at_batch(RowStoreFold<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD RowStoreNat<T> at_batch(RowStoreNat<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD RowLoadFold<T> at_batch(RowLoadFold<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD RowLoadTiled<T> at_batch(RowLoadTiled<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD ColStoreTiled<T> at_batch(ColStoreTiled<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD ColLoadTiled<T> at_batch(ColLoadTiled<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
@@ -365,8 +383,9 @@ PM_HD void store_rot(const RowStoreNat<typename C::T>& p, int blk, ThreadPos pos
     using T = typename C::T;
 #pragma unroll
     for (int e = 0; e < C::E; ++e) {
-        const int seq = (blk * C::BO + pos.bo) * C::E + e;
-        if (seq >= p.nseq) continue;
+        const int unit = blk * C::BO + pos.bo;
+        const int seq = p.eoff ? unit + e * p.eoff : unit * C::E + e;
+        if (seq >= p.nseq || (p.eoff && unit >= p.eoff)) continue;
         int mrow = seq;
         if (p.use_ay) {
             mrow = p.ay.map(seq);
@@ -416,6 +435,34 @@ PM_HD void load(const RowLoadTiled<typename C::T>& p, int blk, ThreadPos pos, cx
             if (p.conj) val.y = -val.y;
             v[e][m] = val;
         }
+    }
+}
+
+template <typename C>
+PM_HD void load(const RowLoadFold<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    static_assert(C::CI == 1 && C::E == 2, "the unfold rebuilds the two rows of a thread");
+    const int n = blk * C::BO + pos.bo;
+    const bool ok = n < p.npairs;
+    const int tlm = (1 << p.log_tl) - 1;
+    const cx<T> w = p.twm[ok ? n : 0];
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const int c = pos.t + m * C::TPS;
+        const int64_t a = ((int64_t(c >> p.log_tl) * p.npairs + (ok ? n : 0)) << p.log_tl) + (c & tlm);
+        cx<T> a0 = {T(0), T(0)}, a1 = {T(0), T(0)};
+        if (ok) {
+            a0 = p.src[a];
+            a1 = p.src[a + p.plane_stride];
+        }
+        const cx<T> b = cmulc(a1, w);      // conj(W_M^n) A1[n]
+        cx<T> lo = {a0.x + b.x, a0.y + b.y}, hi = {a0.x - b.x, a0.y - b.y};
+        if (p.conj) {
+            lo.y = -lo.y;
+            hi.y = -hi.y;
+        }
+        v[0][m] = lo;
+        v[1][m] = hi;
     }
 }
 
@@ -554,7 +601,7 @@ PM_HD void mid_multiply_conj_kind(const MidMul<typename C::T>& p, int tile, Thre
     for (int m = 0; m < C::P; ++m) {
         const int k = pos.t + m * C::TPS;
         cx<T> hy = {T(1), T(0)};
-        if (KIND == MUL_SEPARABLE) hy = p.mul[k];
+        if (KIND == MUL_SEPARABLE) hy = p.mul[p.ystep > 1 ? k * p.ystep : k];
 #pragma unroll
         for (int e = 0; e < C::E; ++e) {
             cx<T> h;

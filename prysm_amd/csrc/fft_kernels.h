@@ -292,6 +292,32 @@ int launch_fold_impl(int logn, const RowLoadNat<T>& lp, const RowStoreFold<T>& s
     }
 }
 
+// last pass of the folded fused operation: rows rebuilt from the two planes (RowLoadFold), natural output
+template <typename T, int LOGN>
+int launch_unfold_one(const RowLoadFold<T>& lp, const RowStoreNat<T>& sp, const cx<T>* tw, int npairs, hipStream_t st, int nbatch) {
+    using C = typename RowCfgSel<T, LOGN, 4>::type;
+    auto kern = fft_kernel<C, false, 4, RowLoadFold<T>, RowStoreNat<T>>;
+    constexpr size_t LDSB = kernel_lds_bytes<C, false, 0>();
+    if (LDSB > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
+        if (e != hipSuccess) return int(e);
+    }
+    const int grid = (npairs + C::BO - 1) / C::BO;
+    if (grid <= 0 || nbatch <= 0) return 0;
+    hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), LDSB, st, lp, sp, tw, 0);
+    return int(hipGetLastError());
+}
+template <typename T>
+int launch_unfold_impl(int logn, const RowLoadFold<T>& lp, const RowStoreNat<T>& sp, const cx<T>* tw, int npairs, hipStream_t st,
+                       int nbatch) {
+    switch (logn) {
+        case 11: return launch_unfold_one<T, 11>(lp, sp, tw, npairs, st, nbatch);
+        case 12: return launch_unfold_one<T, 12>(lp, sp, tw, npairs, st, nbatch);
+        case 13: return launch_unfold_one<T, 13>(lp, sp, tw, npairs, st, nbatch);
+        default: return -2;
+    }
+}
+
 template <typename T, bool COL, typename L, typename S>
 int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st, int nbatch) {
     switch (logn) {
@@ -325,5 +351,6 @@ template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&
 template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_row_from_tiled(int logn, int var, const RowLoadTiled<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t, int nbatch = 1);
 template <typename T> int launch_row_fold(int logn, const RowLoadNat<T>&, const RowStoreFold<T>&, const cx<T>* tw, int npairs, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_row_unfold(int logn, const RowLoadFold<T>&, const RowStoreNat<T>&, const cx<T>* tw, int npairs, hipStream_t, int nbatch = 1);
 
 }  // namespace pm

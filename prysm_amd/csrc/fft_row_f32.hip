@@ -13,4 +13,7 @@ template <> int launch_row_from_tiled<float>(int logn, int var, const RowLoadTil
 template <> int launch_row_fold<float>(int logn, const RowLoadNat<float>& l, const RowStoreFold<float>& s, const cx<float>* tw, int npairs, int log_g, hipStream_t st, int nbatch) {
     return launch_fold_impl<float>(logn, l, s, tw, npairs, log_g, st, nbatch);
 }
+template <> int launch_row_unfold<float>(int logn, const RowLoadFold<float>& l, const RowStoreNat<float>& s, const cx<float>* tw, int npairs, hipStream_t st, int nbatch) {
+    return launch_unfold_impl<float>(logn, l, s, tw, npairs, st, nbatch);
+}
 }  // namespace pm

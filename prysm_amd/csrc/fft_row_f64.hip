@@ -13,4 +13,7 @@ template <> int launch_row_from_tiled<double>(int logn, int var, const RowLoadTi
 template <> int launch_row_fold<double>(int logn, const RowLoadNat<double>& l, const RowStoreFold<double>& s, const cx<double>* tw, int npairs, int log_g, hipStream_t st, int nbatch) {
     return launch_fold_impl<double>(logn, l, s, tw, npairs, log_g, st, nbatch);
 }
+template <> int launch_row_unfold<double>(int logn, const RowLoadFold<double>& l, const RowStoreNat<double>& s, const cx<double>* tw, int npairs, hipStream_t st, int nbatch) {
+    return launch_unfold_impl<double>(logn, l, s, tw, npairs, st, nbatch);
+}
 }  // namespace pm

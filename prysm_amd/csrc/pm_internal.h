@@ -44,6 +44,7 @@ template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&
 template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_row_from_tiled(int logn, int var, const RowLoadTiled<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t, int nbatch = 1);
 template <typename T> int launch_row_fold(int logn, const RowLoadNat<T>&, const RowStoreFold<T>&, const cx<T>* tw, int npairs, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_row_unfold(int logn, const RowLoadFold<T>&, const RowStoreNat<T>&, const cx<T>* tw, int npairs, hipStream_t, int nbatch = 1);
 // tile width of the column pass; MUST match ColCfgSel in fft_kernels.h (CI * E)
 inline int col_tile_width_for(int dtype, int logm, int var) {
     (void)var;

@@ -624,3 +624,33 @@ def test_folded_column_transform_vs_oracle(pa, shape, dtype, forced):
         assert rel_max(got, unfolded) < 4 * tol
     finally:
         lib.pm_set_tuning(b'fold', -1)
+
+
+@pytest.mark.parametrize('shape,dtype', [((64, 2048), np.complex128), ((128, 4096), np.complex64), ((4096, 2048), np.complex128)])
+def test_folded_fused_angular_spectrum_vs_oracle(pa, shape, dtype):
+    """The folded 3-pass chain (fold in the first row pass, M/2-point column FFT x H x IFFT per plane, unfold in the
+    last row pass): angular spectrum (separable H), its adjoint (conj H), a full tf= array and conv (rotations)."""
+    from prysm_amd import _lib, convolution as C
+    from prysm_amd.conf import config
+    P = pa.propagation
+    lib = _lib.load()
+    rng = np.random.default_rng(shape[0] + 7 * shape[1])
+    x = crandn(rng, shape, dtype)
+    tol = TOL64 if dtype == np.complex128 else 4 * TOL32
+    prec = config.precision
+    try:
+        config.precision = 64 if dtype == np.complex128 else 32
+        lib.pm_set_tuning(b'fold', 1)
+        xo = x.astype(np.complex128)
+        assert rel_max(tonp(P.angular_spectrum(x, 0.6, 0.01, 30.0, Q=1)), O.angular_spectrum(xo, 0.6, 0.01, 30.0, Q=1)) < tol
+        assert rel_max(tonp(P.angular_spectrum_adjoint(x, 0.6, 0.01, 30.0, Q=1)),
+                       O.angular_spectrum_adjoint(xo, 0.6, 0.01, 30.0, Q=1)) < tol
+        if shape[0] <= 128:
+            tf = crandn(rng, shape, dtype)
+            assert rel_max(tonp(P.angular_spectrum(x, 0.6, 0.01, 30.0, Q=1, tf=tf)),
+                           O.angular_spectrum(xo, 0.6, 0.01, 30.0, Q=1, tf=tf.astype(np.complex128))) < tol
+            h = crandn(rng, shape, dtype)
+            assert rel_max(tonp(C.conv(x, h)), O.conv(xo, h.astype(np.complex128))) < 4 * tol
+    finally:
+        lib.pm_set_tuning(b'fold', -1)
+        config.precision = prec

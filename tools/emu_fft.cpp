@@ -286,6 +286,45 @@ static void test_2d_fold(int in_cols, bool shifts, int epilogue, bool inverse, i
     report(buf, err / nrm, sizeof(T) == 4 ? 3e-6 : 1e-13);
 }
 
+// naive ifft2(fft2(pad(x)) * H) without the 1/(MN): the reference of the fused chain
+template <typename T>
+static std::vector<cld> naive_fused(const std::vector<cx<T>>& x, int in_rows, int in_cols, int M, int N, int offy, int offx, int shy,
+                                    int shx, const std::vector<cx<T>>& H, const std::vector<cx<T>>& hy, const std::vector<cx<T>>& hx,
+                                    bool separable, bool mconj) {
+    const ld pi = acosl(-1.0L);
+    std::vector<cld> P(size_t(M) * N, cld(0, 0)), A(size_t(M) * N), B(size_t(M) * N);
+    for (int r = 0; r < M; ++r)
+        for (int c = 0; c < N; ++c) {
+            int qr = (r + shy) % M - offy, qc = (c + shx) % N - offx;
+            if (qr >= 0 && qr < in_rows && qc >= 0 && qc < in_cols)
+                P[size_t(r) * N + c] = cld(x[size_t(qr) * in_cols + qc].x, x[size_t(qr) * in_cols + qc].y);
+        }
+    auto dft2 = [&](std::vector<cld>& Z, ld sg) {
+        for (int r = 0; r < M; ++r)
+            for (int k = 0; k < N; ++k) {
+                cld acc(0, 0);
+                for (int n = 0; n < N; ++n) acc += Z[size_t(r) * N + n] * std::polar<ld>(1.0L, sg * pi * ld((int64_t(n) * k) % N) / N);
+                A[size_t(r) * N + k] = acc;
+            }
+        for (int c = 0; c < N; ++c)
+            for (int k = 0; k < M; ++k) {
+                cld acc(0, 0);
+                for (int n = 0; n < M; ++n) acc += A[size_t(n) * N + c] * std::polar<ld>(1.0L, sg * pi * ld((int64_t(n) * k) % M) / M);
+                B[size_t(k) * N + c] = acc;
+            }
+        Z = B;
+    };
+    dft2(P, -2);
+    for (int k = 0; k < M; ++k)
+        for (int c = 0; c < N; ++c) {
+            cld h = separable ? cld(hy[k].x, hy[k].y) * cld(hx[c].x, hx[c].y) : cld(H[size_t(k) * N + c].x, H[size_t(k) * N + c].y);
+            if (mconj) h = std::conj(h);
+            P[size_t(k) * N + c] *= h;
+        }
+    dft2(P, +2);
+    return P;
+}
+
 // --- fused fft2 -> x H -> ifft2 (3 passes), vs naive ---------------------------------------------------------
 template <typename T, int LOGM, int LOGN, int RBO, int CCI, int CE, int CBO, int CCOMP>
 static void test_fused(int in_rows, int in_cols, int out_rows, int out_cols, int log_k, bool separable, bool mconj, bool shifts) {
@@ -344,38 +383,7 @@ static void test_fused(int in_rows, int in_cols, int out_rows, int out_cols, int
     RowStoreNat<T> rs{out.data(), out_cols, AxisMap{N, out_cols, coffx, shx}, M, 1, T(1.0 / (double(M) * N)), 1,
                       AxisMap{M, out_rows, coffy, shy}};
     emu_kernel<RC, false>((M + RC::BO - 1) / RC::BO, rl, rs, twN.data());
-    // reference
-    const ld pi = acosl(-1.0L);
-    std::vector<cld> P(size_t(M) * N, cld(0, 0)), A(size_t(M) * N), B(size_t(M) * N);
-    for (int r = 0; r < M; ++r)
-        for (int c = 0; c < N; ++c) {
-            int qr = (r + shy) % M - offy, qc = (c + shx) % N - offx;
-            if (qr >= 0 && qr < in_rows && qc >= 0 && qc < in_cols)
-                P[size_t(r) * N + c] = cld(x[size_t(qr) * in_cols + qc].x, x[size_t(qr) * in_cols + qc].y);
-        }
-    auto dft2 = [&](std::vector<cld>& Z, ld sg) {
-        for (int r = 0; r < M; ++r)
-            for (int k = 0; k < N; ++k) {
-                cld acc(0, 0);
-                for (int n = 0; n < N; ++n) acc += Z[size_t(r) * N + n] * std::polar<ld>(1.0L, sg * pi * ld((int64_t(n) * k) % N) / N);
-                A[size_t(r) * N + k] = acc;
-            }
-        for (int c = 0; c < N; ++c)
-            for (int k = 0; k < M; ++k) {
-                cld acc(0, 0);
-                for (int n = 0; n < M; ++n) acc += A[size_t(n) * N + c] * std::polar<ld>(1.0L, sg * pi * ld((int64_t(n) * k) % M) / M);
-                B[size_t(k) * N + c] = acc;
-            }
-        Z = B;
-    };
-    dft2(P, -2);
-    for (int k = 0; k < M; ++k)
-        for (int c = 0; c < N; ++c) {
-            cld h = separable ? cld(hy[k].x, hy[k].y) * cld(hx[c].x, hx[c].y) : cld(H[size_t(k) * N + c].x, H[size_t(k) * N + c].y);
-            if (mconj) h = std::conj(h);
-            P[size_t(k) * N + c] *= h;
-        }
-    dft2(P, +2);
+    std::vector<cld> P = naive_fused<T>(x, in_rows, in_cols, M, N, offy, offx, shy, shx, H, hy, hx, separable, mconj);
     double err = 0, nrm = 0;
     for (int r = 0; r < M; ++r)
         for (int c = 0; c < N; ++c) {
@@ -389,6 +397,85 @@ static void test_fused(int in_rows, int in_cols, int out_rows, int out_cols, int
     char buf[160];
     snprintf(buf, sizeof buf, "fused %s %dx%d in=%dx%d out=%dx%d TL=%d sep=%d conj=%d sh=%d", sizeof(T) == 4 ? "c64" : "c128", M, N,
              in_rows, in_cols, out_rows, out_cols, TL, (int)separable, (int)mconj, (int)shifts);
+    report(buf, err / nrm, sizeof(T) == 4 ? 5e-6 : 1e-13);
+}
+
+// --- folded fused chain: fold in the first row pass, M/2-point column FFT x H x IFFT per plane, unfold in the last ----
+template <typename T, int LOGM, int LOGN, int RBO, int RCOMP, int CCI, int CE, int CBO, int CCOMP>
+static void test_fused_fold(int in_cols, int out_rows, int out_cols, int log_k, bool separable, bool mconj, bool shifts) {
+    using RC = FftCfg<T, LOGN, 1, 2, RBO, RCOMP>;
+    using CC = FftCfg<T, LOGM - 1, CCI, CE, CBO, CCOMP>;
+    const int M = 1 << LOGM, Hh = M / 2, N = RC::N, TC = CCI * CE, TL = TC << log_k;
+    int ltl = 0;
+    while ((1 << ltl) < TL) ++ltl;
+    std::mt19937 rng(LOGM * 23 + LOGN + log_k);
+    std::normal_distribution<double> nd;
+    std::vector<cx<T>> x(size_t(M) * in_cols), H(size_t(M) * N), hy(M), hx(N);
+    for (auto& e : x) e = {T(nd(rng)), T(nd(rng))};
+    for (auto& e : H) e = {T(nd(rng)), T(nd(rng))};
+    for (auto& e : hy) e = {T(nd(rng)), T(nd(rng))};
+    for (auto& e : hx) e = {T(nd(rng)), T(nd(rng))};
+    const int offx = (N - in_cols + 1) / 2;
+    const int shy = shifts ? M / 2 : 0, shx = shifts ? N / 2 : 0;
+    const int coffy = (M - out_rows + 1) / 2, coffx = (N - out_cols + 1) / 2;
+    const int ntl = (N + TL - 1) / TL, ntiles = (N + TC - 1) / TC;
+    const int64_t plane = int64_t(ntl) * Hh * TL;
+    std::vector<cx<T>> W(size_t(2 * plane), cx<T>{T(1e30), T(1e30)});
+    auto twN = make_tw<T>(N);
+    auto twM = make_tw<T>(M);
+    auto twH = make_tw<T>(Hh);
+    RowLoadNat<T> lp{x.data(), in_cols, AxisMap{N, in_cols, offx, shx}, M, 0, 0, 0, 0, Hh};
+    RowStoreFold<T> sp{W.data(), plane, Hh, ltl, twM.data(), shifts ? 1 : 0, 0};
+    emu_kernel<RC, false>((Hh + RC::BO - 1) / RC::BO, lp, sp, twN.data());
+    ColLoadTiled<T> cl0{W.data(), Hh, AxisMap{Hh, Hh, 0, 0}, ntiles, log_k, plane};
+    MidMul<T> mm0{separable ? MUL_SEPARABLE : MUL_FULL, mconj ? 1 : 0, separable ? hy.data() : H.data(), hx.data(), 2 * N, N,
+                  separable ? 1 : N, 0, 2};
+    ColStoreTiled<T> cst0{W.data(), Hh, ntiles, log_k, plane};
+    for (int b = 0; b < 2; ++b) {
+        const auto cl = at_batch(cl0, b);
+        const auto mm = at_batch(mm0, b);
+        const auto cst = at_batch(cst0, b);
+        std::vector<Regs<CC>> regs(CC::NT);
+        std::vector<typename LdsType<CC>::type> lds(CC::LDS_ELEMS + 1);
+        const int ngroups = (ntiles + CC::BO - 1) / CC::BO;
+        for (int g = 0; g < ngroups; ++g) {
+            for (int tid = 0; tid < CC::NT; ++tid) {
+                ThreadPos pos = thread_pos<CC>(tid);
+                load<CC>(cl, g * CC::BO + pos.bo, pos, regs[tid].v);
+            }
+            emu_stages<CC, 0>(regs, lds, twH.data());
+            for (int tid = 0; tid < CC::NT; ++tid) {
+                ThreadPos pos = thread_pos<CC>(tid);
+                mid_multiply_conj<CC>(mm, g * CC::BO + pos.bo, pos, regs[tid].v);
+            }
+            emu_stages<CC, 0>(regs, lds, twH.data());
+            for (int tid = 0; tid < CC::NT; ++tid) {
+                ThreadPos pos = thread_pos<CC>(tid);
+                for (int e = 0; e < CC::E; ++e)
+                    for (int m = 0; m < CC::P; ++m) regs[tid].v[e][m].y = -regs[tid].v[e][m].y;
+                store<CC>(cst, g * CC::BO + pos.bo, pos, regs[tid].v);
+            }
+        }
+    }
+    std::vector<cx<T>> out(size_t(out_rows) * out_cols, cx<T>{T(-3), T(-3)});
+    RowLoadFold<T> rl{W.data(), plane, Hh, ltl, twM.data(), 1, 0};
+    RowStoreNat<T> rs{out.data(), out_cols, AxisMap{N, out_cols, coffx, shx}, M, 1, T(1.0 / (double(M) * N)), 1,
+                      AxisMap{M, out_rows, coffy, shy}, 0, Hh};
+    emu_kernel<RC, false>((Hh + RC::BO - 1) / RC::BO, rl, rs, twN.data());
+    std::vector<cld> P = naive_fused<T>(x, M, in_cols, M, N, 0, offx, shy, shx, H, hy, hx, separable, mconj);
+    double err = 0, nrm = 0;
+    for (int r = 0; r < M; ++r)
+        for (int c = 0; c < N; ++c) {
+            int qy = (r + shy) % M - coffy, qx = (c + shx) % N - coffx;
+            if (qy < 0 || qy >= out_rows || qx < 0 || qx >= out_cols) continue;
+            cld ref = P[size_t(r) * N + c] / (ld(M) * N);
+            cx<T> got = out[size_t(qy) * out_cols + qx];
+            err = fmax(err, (double)std::abs(ref - cld(got.x, got.y)));
+            nrm = fmax(nrm, (double)std::abs(ref));
+        }
+    char buf[160];
+    snprintf(buf, sizeof buf, "fused FOLD %s %dx%d in=%dx%d out=%dx%d TL=%d sep=%d conj=%d sh=%d", sizeof(T) == 4 ? "c64" : "c128", M, N,
+             M, in_cols, out_rows, out_cols, TL, (int)separable, (int)mconj, (int)shifts);
     report(buf, err / nrm, sizeof(T) == 4 ? 5e-6 : 1e-13);
 }
 
@@ -477,6 +564,11 @@ int main() {
     test_fused<float, 5, 6, 64, 4, 2, 32, 1>(32, 64, 16, 32, 0, true, true, false);      // adjoint: conj(H) + crop
     test_fused<double, 6, 6, 64, 4, 1, 16, 2>(64, 64, 64, 64, 2, true, false, true);      // with rotations (conv)
     test_fused<double, 5, 7, 32, 4, 1, 32, 1>(20, 100, 32, 128, 1, false, true, false);
+    test_fused_fold<float, 6, 5, 128, 1, 4, 2, 32, 1>(32, 64, 32, 1, true, false, false);
+    test_fused_fold<float, 5, 6, 64, 1, 4, 2, 64, 1>(40, 32, 64, 0, false, false, true);       // full H, rotations (conv), padded columns
+    test_fused_fold<float, 6, 5, 128, 1, 4, 2, 32, 1>(32, 31, 16, 2, true, true, false);        // conj(H) + odd crop of the rows
+    test_fused_fold<double, 6, 6, 64, 1, 4, 1, 32, 2>(64, 64, 64, 2, true, false, true);
+    test_fused_fold<double, 7, 5, 128, 2, 4, 1, 16, 2>(20, 128, 32, 1, false, true, false);
     printf(g_fail ? "EMU FAILED (%d)\n" : "EMU OK\n", g_fail);
     return g_fail ? 1 : 0;
 }
