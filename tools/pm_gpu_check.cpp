@@ -867,6 +867,10 @@ int main(int argc, char** argv) {
         calibrate();
         return 0;
     }
+    if (mode == "gemmprof") {   // the large config-4 GEMM only (PMC passes)
+        bench_cgemm<float>(512, 2048, 2048, 0);
+        return 0;
+    }
     if (mode == "prof") {   // short, fixed workload for rocprofv3 (kernel trace / PMC passes)
         bench_fft2<float>(4096, 4096, 0);
         bench_fft2<double>(4096, 4096, 0);
