@@ -21,7 +21,8 @@ constexpr int kMaxLogN = 13;  // 8192: the largest length one workgroup holds on
 template <typename T, int LOGN, int VAR>
 struct RowCfgSel {
     static constexpr int N = 1 << LOGN, P = N >= 16 ? 16 : N, TPS = N / P;
-    static constexpr int BO = (TPS >= 256 ? 1 : 256 / TPS);
+    // VAR = 5: one sequence per (small) workgroup -- twice the workgroups at 2048 points, finer overlap of their phases
+    static constexpr int BO = (TPS >= 256 || VAR == 5) ? 1 : 256 / TPS;
     // VAR = 1: exchange real and imaginary parts separately -> half the LDS per workgroup, so the 72-VGPR
     // complex64 kernel fits 7 workgroups per CU instead of 4 (the row pass is latency / concurrency bound)
     static constexpr int COMP = ((sizeof(T) == 8 && LOGN >= 12) || VAR == 1) ? 2 : 1;   // VAR = 2: persistent kernel
@@ -232,7 +233,7 @@ template <typename T, bool COL, int LOGN, int VAR, typename L, typename S>
 int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st, int nbatch) {
     using Sel = typename std::conditional<COL, ColCfgSel<T, LOGN, VAR>, RowCfgSel<T, LOGN, VAR>>::type;
     using C = typename Sel::type;
-    auto kern = fft_kernel<C, COL, (COL || VAR == 3 || VAR == 4 || VAR == 6 || VAR == 7 ? VAR : 0), L, S>;
+    auto kern = fft_kernel<C, COL, (COL || VAR == 3 || VAR == 4 || VAR == 5 || VAR == 6 || VAR == 7 ? VAR : 0), L, S>;
     constexpr size_t LDSB = kernel_lds_bytes<C, COL, (COL ? VAR : 0)>();
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -333,6 +334,7 @@ int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int
         if (var == 7) return launch_one<T, COL, k, 7, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         if (var == 5 && COL) return launch_one<T, COL, k, (COL ? 5 : 0), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         if (var == 4 && !COL) return launch_one<T, COL, k, (COL ? 0 : 4), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        if (var == 5 && !COL) return launch_one<T, COL, k, (COL ? 0 : 5), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st, nbatch);
         PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
         PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASEV(11) PM_CASEV(12) PM_CASEV(13)

@@ -81,7 +81,10 @@ inline int row_variant(int dtype, int logn) {
     // two rows per thread (variant 4) for complex64 from 4096 points: 53.5 -> 51.4 us at 4096^2, 226 -> 207 us at 8192^2;
     // it loses for complex128 (register pressure) and makes no difference at 2048
     if (dtype == PM_C64 && logn >= 12) return 4;
-    return logn == 11 ? 1 : 0;
+    // 2048 points: complex64 one row per 128-thread workgroup (twice the workgroups: 17.9 -> 16.5 us at 2048^2), complex128 the
+    // half-LDS exchange (24.3 vs 28.3 us)
+    if (logn == 11) return dtype == PM_C64 ? 5 : 1;
+    return 0;
 }
 
 constexpr int kEngineMaxLog = 13;
