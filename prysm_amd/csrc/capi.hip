@@ -76,6 +76,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("row_log_g")) t.row_log_g = v < 0 ? 0 : (v > 3 ? 3 : v);
     else if (is("row_var")) t.row_var = v;
     else if (is("gemm_bk")) t.gemm_bk = v;
+    else if (is("gemm_bm")) t.gemm_bm = v;
     else if (is("gemm_3m")) t.gemm_3m = v ? 1 : 0;
     else if (is("gemm_min_wgs")) t.gemm_min_wgs = v < 1 ? 1 : v;
     else if (is("nt_in")) t.nt_in = v;

@@ -247,8 +247,15 @@ __global__ void splitk_reduce_kernel(int64_t M, int64_t N, int S, T alpha, const
     C[r * ldc + c] = {sr * alpha, si * alpha};
 }
 
+static int gemm_bm(int64_t M, int dtype = PM_C64) {
+    if (dtype != PM_C64) return 64;   // rows per workgroup tile: 128 (two MFMA tiles per wave along M) when M allows it
+    const int t = tuning().gemm_bm;
+    if (t == 64 || t == 128) return (t == 128 && M >= 128) ? 128 : 64;
+    return 64;
+}
+
 size_t cgemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int* S_out) {
-    const int BM = 64, BN = 64, BK = 32;   // slab depth multiple of the deepest K-tile
+    const int BM = gemm_bm(M, dtype), BN = 64, BK = 32;   // slab depth multiple of the deepest K-tile
     const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int S = 1;
     // aim for >= 2 workgroups per CU (512) while keeping >= 8 K-tiles per slab
@@ -258,10 +265,10 @@ size_t cgemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int* S_
     return size_t(S) * size_t(M) * size_t(N) * (dtype == PM_C64 ? 8 : 16);
 }
 
-template <typename T, int BK>
-int cgemm_ws_bk(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, const cx<T>* A, int64_t lda,
+template <typename T, int BK, int BM>
+int cgemm_ws_bm(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, const cx<T>* A, int64_t lda,
                 const cx<T>* B, int64_t ldb, cx<T>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
-    constexpr int BM = 64, BN = 64;
+    constexpr int BN = 64;
     int S = 1;
     const size_t need = cgemm_workspace_bytes(sizeof(T) == 4 ? PM_C64 : PM_C128, M, N, K, &S);
     if (S > 1 && (!ws || ws_bytes < need)) S = 1;   // no workspace: fall back to unsplit (still correct)
@@ -315,6 +322,15 @@ int cgemm_ws_bk(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha,
     hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, S, T(alpha),
                        slabs, M * N, C, ldc);
     return int(hipGetLastError());
+}
+
+template <typename T, int BK>
+int cgemm_ws_bk(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, const cx<T>* A, int64_t lda,
+                const cx<T>* B, int64_t ldb, cx<T>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    if constexpr (sizeof(T) == 4) {   // fp64: 16x16 MFMA tiles, four per wave along M would spill
+        if (gemm_bm(M) == 128) return cgemm_ws_bm<T, BK, 128>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
+    }
+    return cgemm_ws_bm<T, BK, 64>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
 }
 
 template <typename T>

@@ -325,13 +325,21 @@ int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int
 #define PM_CASE(k) \
     case k:        \
         return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st, nbatch);
+// timing variants (memory phases only / arithmetic only / butterflies only; WRONG results, used for the "where the time
+// goes" analysis in DESIGN.md) exist only in builds with -DPM_TIMING_VARIANTS (make EXTRA=-DPM_TIMING_VARIANTS)
+#ifdef PM_TIMING_VARIANTS
+#define PM_TIMING_CASES(k)                                                                      \
+    if (var == 3) return launch_one<T, COL, k, 3, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+    if (var == 6) return launch_one<T, COL, k, 6, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+    if (var == 7) return launch_one<T, COL, k, 7, L, S>(lp, sp, tw, units, log_g, st, nbatch);
+#else
+#define PM_TIMING_CASES(k)
+#endif
 #define PM_CASEV(k)                                                       \
     case k:                                                               \
         if (var == 1) return launch_one<T, COL, k, 1, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         if (var == 2 && !COL) return launch_one<T, COL, k, (COL ? 0 : 2), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
-        if (var == 3) return launch_one<T, COL, k, 3, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
-        if (var == 6) return launch_one<T, COL, k, 6, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
-        if (var == 7) return launch_one<T, COL, k, 7, L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        PM_TIMING_CASES(k) \
         if (var == 5 && COL) return launch_one<T, COL, k, (COL ? 5 : 0), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         if (var == 4 && !COL) return launch_one<T, COL, k, (COL ? 0 : 4), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         if (var == 5 && !COL) return launch_one<T, COL, k, (COL ? 0 : 5), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
@@ -340,6 +348,7 @@ int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int
         PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASEV(11) PM_CASEV(12) PM_CASEV(13)
 #undef PM_CASE
 #undef PM_CASEV
+#undef PM_TIMING_CASES
         default:
             return -2;
     }

@@ -62,6 +62,7 @@ struct Tuning {
     int nt_in = -1, nt_out = -1;
     int log_k = -1;     // layout tiles of the intermediate are 2^log_k column-pass tiles wide; -1 auto
     int gemm_3m = 1;          // complex products as three real MFMA chains (3M) instead of four
+    int gemm_bm = 64;         // rows of the GEMM workgroup tile (64 or 128)
     int gemm_bk = 0;          // 0 default K-tile depth, 32 doubles it
     int gemm_min_wgs = 1024;   // split K until the GEMM launch has at least this many workgroups
     int row_log_g = 1;  // sibling group of row-pass workgroups (rows q .. q+2^g-1 on one XCD)
