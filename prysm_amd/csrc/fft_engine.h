@@ -450,14 +450,21 @@ __device__ __forceinline__ void fft_run(cx<typename C::T> (&v)[C::E][C::P], Thre
 // instead of in front of a barrier.  Same arithmetic and the same number of barriers as fft_run.
 //   invariant on entry to stage S > 0: v[0] is exchanged and ready for stage S; v[1] holds the un-exchanged
 //   output of stage S - 1.
-template <typename C, int S = 0>
-__device__ __forceinline__ void fft_run_pipe2(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw,
-                                              const cx<typename C::T>* __restrict__ tw) {
-    static_assert(C::E == 2 && C::COMP == 1, "two sequences per thread, complex exchange");
+// With PM_TW_PREFETCH the twiddles of stage S + 1 are requested at the START of stage S (one stage ahead), so their L2
+// round trip runs under the butterflies and the exchange of stage S.
+template <typename C, int S>
+__device__ __forceinline__ void fft_run_pipe2_stage(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw,
+                                                    const cx<typename C::T>* __restrict__ tw, const StageTw<C, S>& w) {
     using LT = typename LdsType<C>::type;
     LT* lds = reinterpret_cast<LT*>(lds_raw);
-    StageTw<C, S> w;
-    load_stage_tw<C, S>(w, pos.t, tw);
+    constexpr int SN = (S + 1 < C::NSTAGE) ? S + 1 : S;
+    StageTw<C, SN> wn;
+#ifdef PM_TW_PREFETCH
+    constexpr bool kAhead = true;    // A/B builds (make EXTRA=-DPM_TW_PREFETCH): request the twiddles one stage ahead.
+#else                                // Measured equal within noise at 2048^2 / 4096^2 / 8192^2 and it costs ~12 VGPRs
+    constexpr bool kAhead = false;   // (8192-point rows drop to 3 waves / SIMD), so the default requests them in-stage.
+#endif
+    if constexpr (kAhead && S + 1 < C::NSTAGE) load_stage_tw<C, SN>(wn, pos.t, tw);
     if constexpr (S == 0) {
         stage_compute<C, 0, 0, 1>(v, w);
         if constexpr (C::NSTAGE == 1) {
@@ -468,7 +475,8 @@ __device__ __forceinline__ void fft_run_pipe2(cx<typename C::T> (&v)[C::E][C::P]
             __syncthreads();
             exch_read<C>(v, 0, 0, pos, lds);
             __syncthreads();
-            fft_run_pipe2<C, 1>(v, pos, lds_raw, tw);
+            if constexpr (!kAhead) load_stage_tw<C, SN>(wn, pos.t, tw);
+            fft_run_pipe2_stage<C, 1>(v, pos, lds_raw, tw, wn);
         }
     } else {
         exch_write<C, S - 1>(v, 1, 0, pos, lds);
@@ -482,11 +490,20 @@ __device__ __forceinline__ void fft_run_pipe2(cx<typename C::T> (&v)[C::E][C::P]
             __syncthreads();
             exch_read<C>(v, 0, 0, pos, lds);
             __syncthreads();
-            fft_run_pipe2<C, S + 1>(v, pos, lds_raw, tw);
+            if constexpr (!kAhead) load_stage_tw<C, SN>(wn, pos.t, tw);
+            fft_run_pipe2_stage<C, S + 1>(v, pos, lds_raw, tw, wn);
         } else {
             stage_compute<C, S, 1, 2>(v, w);   // no trailing barrier: callers that reuse the LDS synchronise themselves
         }
     }
+}
+
+template <typename C>
+__device__ __forceinline__ void fft_run_pipe2(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw,
+                                              const cx<typename C::T>* __restrict__ tw) {
+    static_assert(C::E == 2 && C::COMP == 1, "two sequences per thread, complex exchange");
+    StageTw<C, 0> none;
+    fft_run_pipe2_stage<C, 0>(v, pos, lds_raw, tw, none);
 }
 #endif
 
