@@ -127,8 +127,12 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
 // Measured (profiles/r01/fused_as.log): 4096^2 complex128 448 vs 473 us, complex64 210 vs 239 us, 2048^2 complex64
 // 55 vs 75 us against two pm_fft2 calls.  (Built without the SLP vectorizer -- with it this kernel spilled > 150
 // VGPRs under the 128-register cap of the 1024-thread workgroup and lost.)
+#ifndef PM_COLMUL_MINWG
+#define PM_COLMUL_MINWG 1
+#endif
 template <typename C>
-__global__ void __launch_bounds__(C::NT) fft_col_mul_kernel(const ColLoadTiled<typename C::T> lp0, const MidMul<typename C::T> mp0,
+__global__ void __launch_bounds__(C::NT, (C::NT == 512 ? PM_COLMUL_MINWG : 1))   // 2nd argument: min waves per SIMD
+    fft_col_mul_kernel(const ColLoadTiled<typename C::T> lp0, const MidMul<typename C::T> mp0,
                                                             const ColStoreTiled<typename C::T> sp0,
                                                             const cx<typename C::T>* __restrict__ tw, const int log_g) {
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];

@@ -24,6 +24,16 @@ def shard_bounds(n_items, rank, world_size):
     return lo, hi
 
 
+def _reduce_image(acc, world, group, reduce_to_all):
+    """The one data-path collective: sum-reduce of the real image over the ranks (RCCL; gloo in the CPU tests)."""
+    if world > 1:
+        if reduce_to_all:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM, group=group)
+    return acc
+
+
 def incoherent_sum(propagate, wavelengths, weights, *, group=None, reduce_to_all=True, out=None):
     """Weighted incoherent sum over wavelengths (or fields), sharded over the ranks of `group`.
 
@@ -45,12 +55,7 @@ def incoherent_sum(propagate, wavelengths, weights, *, group=None, reduce_to_all
         acc = propagate(float(wavelengths[k]), float(weights[k]), acc)
     if acc is None:
         raise ValueError('a rank received no wavelengths and no `out` buffer to define the image shape')
-    if world > 1:
-        if reduce_to_all:
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
-        else:
-            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM, group=group)
-    return acc
+    return _reduce_image(acc, world, group, reduce_to_all)
 
 
 def _fields_per_launch(shape, cdtype_bytes, Q, limit_bytes=1 << 30):
@@ -104,12 +109,7 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
                 else:
                     _ops.pupil_synth(a, o, kk, cd, out=stack[i])     # synthesised straight into the stack
             _ops.sum_modes(focus_intensity(stack, Q), [float(w) for w in weights[b0:b1]], out=acc, accumulate=True)
-        if world > 1:
-            if reduce_to_all:
-                dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
-            else:
-                dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM, group=group)
-        return acc
+        return _reduce_image(acc, world, group, reduce_to_all)
 
     def propagate(wvl, w, acc):
         wf = Wavefront.from_amp_and_phase(amp, phs, wvl, dx)

@@ -1,0 +1,38 @@
+"""2 ranks on ONE GPU (gloo): the polychromatic driver's sharded paths (stacks and field-by-field, FFT and matrix-DFT
+variants) against the oracle's single-process sum.  Launch with torch.distributed.run --nproc-per-node 2."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, torch.distributed as dist
+from oracle import prysm_oracle as O
+
+rank = int(os.environ['RANK'])
+torch.cuda.set_device(0)
+dist.init_process_group('gloo')
+from prysm_amd.polychromatic import polychromatic_psf
+from prysm_amd.mathops import array_to_true_numpy as tonp
+
+n = 128
+x, y = O.make_xy_grid(n, diameter=10)
+r, _ = O.cart_to_polar(x, y)
+amp = O.circle(5, r)
+opd = O.hopkins_w040(r / 5, 300.0)
+dx = float(x[0, 1] - x[0, 0])
+wvls = np.linspace(0.5, 0.7, 7)      # uneven shards: 4 + 3
+wts = np.linspace(1.0, 2.0, 7)
+comps = [O.intensity(O.focus(O.from_amp_and_phase(amp, opd, float(w)), 2)) for w in wvls]
+want = O.sum_of_2d_modes(np.asarray(comps), wts)
+worst = 0.0
+for batched in (True, False):
+    got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2, batched=batched))
+    worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))
+comps = []
+for w in wvls:
+    P = O.from_amp_and_phase(amp, opd, float(w))
+    comps.append(O.intensity(O.prepare_executor(dx, P.shape, 0.55 * 10 / 4, (64, 64), float(w), 100.0)(P)))
+want_m = O.sum_of_2d_modes(np.asarray(comps), wts)
+got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, focal_dx=0.55 * 10 / 4, samples=64, kind='mdft'))
+worst = max(worst, float(np.abs(got - want_m).max() / np.abs(want_m).max()))
+print(f'rank {rank}: polychromatic 2-rank sum vs oracle, worst relative error {worst:.2e}', 'OK' if worst < 1e-10 else 'FAIL', flush=True)
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if worst < 1e-10 else 1)
