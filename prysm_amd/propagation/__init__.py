@@ -19,6 +19,8 @@ from .fft import (
 from .dft import (
     coordinates_for_focus,
     prepare_executor,
+    prepare_multiresolution,
+    MultiResolutionExecutor,
     unit_cell_focal_grid,
     focus_dft,
     focus_dft_adjoint,
@@ -37,6 +39,7 @@ from .coronagraph import (
     to_fpm_and_back,
     to_fpm_and_back_adjoint,
     to_fpm_and_back_multiresolution,
+    to_fpm_and_back_multiresolution_adjoint,
     vortex_phase_mask,
     babinet,
     babinet_adjoint,

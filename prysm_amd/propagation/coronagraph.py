@@ -86,6 +86,34 @@ def to_fpm_and_back_multiresolution(wavefunction, fpm, executor, return_more=Fal
     return out
 
 
+def to_fpm_and_back_multiresolution_adjoint(wavefunction, fpm, executor, return_more=False,
+                                            return_fpm_grad=False, field_at_fpm=None):
+    """Apply the adjoint of to_fpm_and_back_multiresolution (coronagraph.py:228-305)."""
+    if return_fpm_grad and field_at_fpm is None:
+        raise ValueError('return_fpm_grad=True requires field_at_fpm from the forward propagation')
+    out = None
+    Ebbars, intermediates, fpm_bars = [], [], []
+    levels = zip(executor.executors, executor.windows, executor.xf, executor.yf)
+    for k, (ex, win, xf, yf) in enumerate(levels):
+        m = L.as_device(fpm(xf, yf))
+        Ebbar = unfocus_dft_adjoint(wavefunction, ex)
+        intermediate = _adjoint_multiply(Ebbar, m * win)
+        contribution = focus_dft_adjoint(intermediate, ex)
+        out = contribution if out is None else out + contribution
+        if return_more:
+            Ebbars.append(Ebbar)
+            intermediates.append(intermediate)
+        if return_fpm_grad:
+            fpm_bars.append(_adjoint_multiply(Ebbar, L.as_device(field_at_fpm[k]) * win, real=not m.is_complex()))
+    if return_more:
+        if return_fpm_grad:
+            return out, Ebbars, intermediates, fpm_bars
+        return out, Ebbars, intermediates
+    elif return_fpm_grad:
+        return out, fpm_bars
+    return out
+
+
 def babinet(wavefunction, lyot, fpm, executor, return_more=False):
     """Propagate through a Lyot-style coronagraph using Babinet's principle (coronagraph.py:308-360)."""
     wavefunction = L.as_complex(wavefunction)

@@ -5,6 +5,9 @@ GEMMs on the MFMA matrix cores.
 import math
 from collections.abc import Iterable
 
+import torch
+
+from .. import _lib as L
 from ..conf import config
 from ..fttools import fftrange, MDFT, CZT, FFTDFT
 
@@ -72,6 +75,77 @@ def unit_cell_focal_grid(pupil_dx, pupil_diameter, wavelength, efl, Q=2):
     focal_samples = math.ceil(Q * pupil_diameter / pupil_dx)
     focal_dx = wavelength * efl / pupil_dx / focal_samples
     return focal_dx, focal_samples
+
+
+def _smootherstep(t):
+    """C2 smoothstep 6t^5 - 15t^4 + 10t^3, clipped to [0, 1] (dft.py:155-158)."""
+    t = torch.clamp(t, 0, 1)
+    return t * t * t * (t * (t * 6 - 15) + 10)
+
+
+def _cumulative_window(r, a, b):
+    """Radial taper that is 1 for r < a and 0 for r > b, with a C2 transition (dft.py:161-168)."""
+    return 1 - _smootherstep((r - a) / (b - a))
+
+
+class MultiResolutionExecutor:
+    """A stack of arbitrary-sampling executors plus partition-of-unity windows (dft.py:171-212).
+
+    Attributes: executors (coarsest first), windows (real, summing to one over the focal plane), xf, yf (per-level focal
+    coordinate meshgrids, microns) -- device tensors.
+    """
+
+    __slots__ = ('executors', 'windows', 'xf', 'yf')
+
+    def __init__(self, executors, windows, xf, yf):
+        self.executors = executors
+        self.windows = windows
+        self.xf = xf
+        self.yf = yf
+
+    def __len__(self):
+        return len(self.executors)
+
+
+def prepare_multiresolution(pupil_dx, pupil_samples, focal_dx, focal_samples,
+                            wavelength, efl, num_levels, scaling=4.0,
+                            fine_samples=None, window=(0.2, 0.7), kind='mdft'):
+    """Build a MultiResolutionExecutor for focal-plane-mask propagation (dft.py:215-294).
+
+    Level k samples the focal plane at focal_dx / scaling**k over a field of view that shrinks by the same factor; every
+    level's grid is shifted by half a sample so a mask singularity at the origin is never sampled; the windows telescope
+    to a partition of unity.
+    """
+    if fine_samples is None:
+        fine_samples = focal_samples
+    inner, outer = window
+    executors, xfs, yfs, radii, halves = [], [], [], [], []
+    for k in range(num_levels):
+        nf = focal_samples if k == 0 else fine_samples
+        if not isinstance(nf, Iterable):
+            nf = (nf, nf)
+        nfy, nfx = nf
+        fdx = focal_dx / scaling**k
+        shift = fdx / 2.0
+        ex = prepare_executor(pupil_dx, pupil_samples, fdx, nf, wavelength, efl, focal_shift=(shift, shift), kind=kind)
+        xline = fftrange(nfx, dtype=config.precision) * fdx + shift
+        yline = fftrange(nfy, dtype=config.precision) * fdx + shift
+        yf, xf = torch.meshgrid(yline, xline, indexing='ij')
+        executors.append(ex)
+        xfs.append(xf)
+        yfs.append(yf)
+        radii.append(torch.hypot(xf, yf))
+        halves.append(min(nfy, nfx) / 2.0 * fdx)
+    windows = []
+    for k in range(num_levels):
+        r = radii[k]
+        here = 1.0 if k == 0 else _cumulative_window(r, inner * halves[k], outer * halves[k])
+        nxt = 0.0 if k == num_levels - 1 else _cumulative_window(r, inner * halves[k + 1], outer * halves[k + 1])
+        win = here - nxt
+        if not isinstance(win, torch.Tensor):
+            win = torch.full_like(r, float(win))
+        windows.append(win)
+    return MultiResolutionExecutor(executors, windows, xfs, yfs)
 
 
 def focus_dft(wavefunction, executor):

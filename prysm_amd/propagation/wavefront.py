@@ -22,10 +22,11 @@ from .fft import (
     pupil_sample_to_psf_sample, psf_sample_to_pupil_sample,
 )
 from .dft import (
-    prepare_executor, focus_dft, focus_dft_adjoint, unfocus_dft, unfocus_dft_adjoint,
+    prepare_executor, prepare_multiresolution, focus_dft, focus_dft_adjoint, unfocus_dft, unfocus_dft_adjoint,
 )
 from .angular_spectrum import angular_spectrum, angular_spectrum_adjoint
-from .coronagraph import to_fpm_and_back, to_fpm_and_back_adjoint, babinet, babinet_adjoint
+from .coronagraph import (to_fpm_and_back, to_fpm_and_back_adjoint, to_fpm_and_back_multiresolution,
+                          to_fpm_and_back_multiresolution_adjoint, babinet, babinet_adjoint)
 from ..fttools import pad2d, crop_center
 
 
@@ -100,6 +101,20 @@ class Wavefront:
         screen = _ops.quadratic_phase(xt, yt, c, L._COMPLEX_OF[xt.dtype])
         dx = float(xt[0, 1] - xt[0, 0])
         return cls(cmplx_field=screen, wavelength=wavelength, dx=dx, space='pupil')
+
+    @classmethod
+    def thin_lens_adjoint(cls, f, wavelength, x, y, wf_bar):
+        """Adjoint of thin_lens with respect to the focal length f (wavefront.py:244-279): a scalar."""
+        L_bar = L.as_complex(_field_data(wf_bar))
+        screen = cls.thin_lens(f, wavelength, x, y).data
+        if L_bar.dtype != screen.dtype:
+            L_bar = L_bar.to(torch.complex128)
+            screen = screen.to(torch.complex128)
+        w = wavelength / 1e3
+        xt, yt = _real_opd(x), _real_opd(y)
+        rsq = xt * xt + yt * yt
+        coeff = math.pi / (w * f * f)
+        return coeff * torch.sum(rsq * _ops.cmul(L_bar, screen, conj_b=True).imag)
 
     @property
     def intensity(self):
@@ -298,6 +313,16 @@ class Wavefront:
                                     focal_shift=shift, kind=kind)
         raise ValueError(f"unknown space {self.space!r}")
 
+    def prepare_multiresolution(self, efl, focal_dx, focal_samples, num_levels, scaling=4.0, fine_samples=None,
+                                window=(0.2, 0.7), kind='mdft'):
+        """Build a MultiResolutionExecutor for this pupil-plane wavefront (wavefront.py:643-677)."""
+        if self.space != 'pupil':
+            raise ValueError('multiresolution propagation begins at a pupil plane')
+        return prepare_multiresolution(pupil_dx=self.dx, pupil_samples=tuple(self.data.shape), focal_dx=focal_dx,
+                                       focal_samples=focal_samples, wavelength=self.wavelength, efl=efl,
+                                       num_levels=num_levels, scaling=scaling, fine_samples=fine_samples, window=window,
+                                       kind=kind)
+
     def focus_dft(self, executor):
         """Pupil -> PSF propagation via a precomputed executor (wavefront.py:679-696)."""
         if self.space != 'pupil':
@@ -342,6 +367,46 @@ class Wavefront:
         fpm = _field_data(fpm)
         return Wavefront(to_fpm_and_back_adjoint(self.data, fpm=fpm, executor=executor), self.wavelength, self.dx,
                          self.space)
+
+    def to_fpm_and_back_multiresolution(self, fpm, executor, return_more=False):
+        """Propagate to a focal plane mask and back at multiple resolutions (wavefront.py:852-885)."""
+        if self.space != 'pupil':
+            raise ValueError('can only propagate from a pupil to psf plane')
+        pak = to_fpm_and_back_multiresolution(self.data, fpm, executor, return_more=return_more)
+        if not return_more:
+            return Wavefront(pak, self.wavelength, self.dx, self.space)
+        out, at_fpm, after_fpm = pak
+        out = Wavefront(out, self.wavelength, self.dx, self.space)
+        at_fpm = [Wavefront(f, self.wavelength, ex.focal_dx, 'psf') for f, ex in zip(at_fpm, executor.executors)]
+        after_fpm = [Wavefront(f, self.wavelength, ex.focal_dx, 'psf') for f, ex in zip(after_fpm, executor.executors)]
+        return out, at_fpm, after_fpm
+
+    def to_fpm_and_back_multiresolution_adjoint(self, fpm, executor, return_more=False, return_fpm_grad=False,
+                                                field_at_fpm=None):
+        """Apply the adjoint of to_fpm_and_back_multiresolution (wavefront.py:887-944)."""
+        if field_at_fpm is not None:
+            field_at_fpm = [_field_data(f) for f in field_at_fpm]
+        pak = to_fpm_and_back_multiresolution_adjoint(self.data, fpm, executor, return_more=return_more,
+                                                      return_fpm_grad=return_fpm_grad, field_at_fpm=field_at_fpm)
+
+        def _psf_wrap(fields):
+            return [Wavefront(f, self.wavelength, ex.focal_dx, 'psf') for f, ex in zip(fields, executor.executors)]
+
+        if return_more:
+            if return_fpm_grad:
+                Eabar, Ebbars, intermediates, fpm_bars = pak
+            else:
+                Eabar, Ebbars, intermediates = pak
+            Eabar = Wavefront(Eabar, self.wavelength, self.dx, self.space)
+            Ebbars = _psf_wrap(Ebbars)
+            intermediates = _psf_wrap(intermediates)
+            if return_fpm_grad:
+                return Eabar, Ebbars, intermediates, _psf_wrap(fpm_bars)
+            return Eabar, Ebbars, intermediates
+        elif return_fpm_grad:
+            Eabar, fpm_bars = pak
+            return Wavefront(Eabar, self.wavelength, self.dx, self.space), _psf_wrap(fpm_bars)
+        return Wavefront(pak, self.wavelength, self.dx, self.space)
 
     def babinet(self, lyot, fpm, executor, return_more=False):
         """Propagate through a Lyot-style coronagraph using Babinet's principle (wavefront.py:952-1000)."""

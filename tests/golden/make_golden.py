@@ -281,6 +281,33 @@ def next_rows():
     np.savez_compressed(os.path.join(HERE, 'next_rows.npz'), **out)
 
 
+def multires():
+    """SURVEY 8(f) rank 2, second half: prepare_multiresolution + to_fpm_and_back_multiresolution(+adjoint), thin_lens_adjoint."""
+    out = {}
+    rng = np.random.default_rng(405)
+    n = 40
+    x = crandn(rng, (n, n))
+    g = crandn(rng, (n, n))
+    par = dict(pupil_dx=0.25, pupil_samples=(n, n), focal_dx=3.0, focal_samples=(24, 20), wavelength=HeNe, efl=80.0,
+               num_levels=3, scaling=3.0, fine_samples=16, window=(0.25, 0.65))
+    for kind in ('mdft', 'czt'):
+        ex = propagation.prepare_multiresolution(kind=kind, **par)
+        fpm = propagation.vortex_phase_mask(2)
+        out[f'{kind}_fwd'] = propagation.to_fpm_and_back_multiresolution(x, fpm, ex)
+        out[f'{kind}_adj'] = propagation.to_fpm_and_back_multiresolution_adjoint(g, fpm, ex)
+    for k, w in enumerate(ex.windows):
+        out[f'window{k}'] = np.asarray(w)
+        out[f'xf{k}'] = ex.xf[k]
+    out['x'], out['g'] = x, g
+    out['par'] = np.array([0.25, 3.0, HeNe, 80.0, 3, 3.0, 16, 0.25, 0.65])
+    # thin_lens_adjoint
+    xx, yy = coordinates.make_xy_grid(32, diameter=8.0)
+    Lbar = crandn(rng, (32, 32))
+    out['tl_x'], out['tl_y'], out['tl_Lbar'] = xx, yy, Lbar
+    out['tl_grad'] = np.asarray(propagation.Wavefront.thin_lens_adjoint(250.0, HeNe, xx, yy, Lbar))
+    np.savez_compressed(os.path.join(HERE, 'multires.npz'), **out)
+
+
 def precision32():
     """fp32 path semantics (dtype propagation) on one case each."""
     out = {}
@@ -309,6 +336,7 @@ if __name__ == '__main__':
     coronagraph()
     precision32()
     next_rows()
+    multires()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -654,3 +654,40 @@ def test_folded_fused_angular_spectrum_vs_oracle(pa, shape, dtype):
     finally:
         lib.pm_set_tuning(b'fold', -1)
         config.precision = prec
+
+
+def test_multiresolution_golden(pa, golden):
+    """prepare_multiresolution + to_fpm_and_back_multiresolution(+adjoint) (mdft and czt levels), Wavefront wrappers,
+    the adjoint dot-product identity and thin_lens_adjoint against the reference's outputs."""
+    P = pa.propagation
+    g = golden('multires')
+    x, gg = g['x'], g['g']
+    n = x.shape[0]
+    wvl = float(g['par'][2])
+    for kind in ('mdft', 'czt'):
+        ex = P.prepare_multiresolution(0.25, (n, n), 3.0, (24, 20), wvl, 80.0, 3, scaling=3.0, fine_samples=16,
+                                       window=(0.25, 0.65), kind=kind)
+        assert len(ex) == 3
+        fpm = P.vortex_phase_mask(2)
+        fwd = P.to_fpm_and_back_multiresolution(x, fpm, ex)
+        adj = P.to_fpm_and_back_multiresolution_adjoint(gg, fpm, ex)
+        assert rel_max(tonp(fwd), g[f'{kind}_fwd']) < TOL64
+        assert rel_max(tonp(adj), g[f'{kind}_adj']) < TOL64
+        lhs = np.vdot(tonp(fwd), gg)
+        rhs = np.vdot(x, tonp(adj))
+        assert abs(lhs - rhs) < 1e-10 * abs(lhs)
+    for k in range(3):
+        assert rel_max(tonp(ex.windows[k]), g[f'window{k}']) < 1e-13
+        assert rel_max(tonp(ex.xf[k]), g[f'xf{k}']) < 1e-13
+    wf = P.Wavefront(x, wvl, 0.25)
+    ex = wf.prepare_multiresolution(efl=80.0, focal_dx=3.0, focal_samples=(24, 20), num_levels=3, scaling=3.0, fine_samples=16,
+                                    window=(0.25, 0.65))
+    out, at_fpm, after_fpm = wf.to_fpm_and_back_multiresolution(P.vortex_phase_mask(2), ex, return_more=True)
+    assert rel_max(tonp(out), g['mdft_fwd']) < TOL64 and len(at_fpm) == 3 and at_fpm[1].space == 'psf'
+    Ea, fbars = P.Wavefront(gg, wvl, 0.25).to_fpm_and_back_multiresolution_adjoint(
+        P.vortex_phase_mask(2), ex, return_fpm_grad=True, field_at_fpm=at_fpm)
+    assert rel_max(tonp(Ea), g['mdft_adj']) < TOL64 and len(fbars) == 3
+    with pytest.raises(ValueError):
+        P.to_fpm_and_back_multiresolution_adjoint(gg, P.vortex_phase_mask(2), ex, return_fpm_grad=True)
+    got = float(P.Wavefront.thin_lens_adjoint(250.0, wvl, g['tl_x'], g['tl_y'], g['tl_Lbar']))
+    assert abs(got - float(g['tl_grad'])) < 1e-10 * abs(float(g['tl_grad']))

@@ -258,3 +258,21 @@ def test_next_rows_oracle_vs_golden(golden):
     assert rel_max(O.jones_adapter(O.focus)(J, 2), g['jones_focus_Q2']) < 1e-13
     assert rel_max(O.jones_adapter(O.unfocus)(J, 1), g['jones_unfocus_Q1']) < 1e-13
     assert rel_max(O.jones_adapter(O.angular_spectrum)(J, 0.6328, 0.01, 25.0, Q=2), g['jones_as']) < 1e-13
+
+
+def test_multiresolution_oracle_vs_golden(golden):
+    """prepare_multiresolution (windows, grids), the multi-level FPM round trip and its adjoint, thin_lens_adjoint."""
+    g = golden('multires')
+    x, gg = g['x'], g['g']
+    n = x.shape[0]
+    for kind in ('mdft', 'czt'):
+        ex = O.prepare_multiresolution(0.25, (n, n), 3.0, (24, 20), float(g['par'][2]), 80.0, 3, scaling=3.0, fine_samples=16,
+                                       window=(0.25, 0.65), kind=kind)
+        fpm = O.vortex_phase_mask(2)
+        assert rel_max(O.to_fpm_and_back_multiresolution(x, fpm, ex), g[f'{kind}_fwd']) < 1e-12
+        assert rel_max(O.to_fpm_and_back_multiresolution_adjoint(gg, fpm, ex), g[f'{kind}_adj']) < 1e-12
+    for k in range(3):
+        assert rel_max(ex.windows[k], g[f'window{k}']) < 1e-14
+        assert rel_max(ex.xf[k], g[f'xf{k}']) < 1e-14
+    got = O.thin_lens_adjoint(250.0, float(g['par'][2]), g['tl_x'], g['tl_y'], g['tl_Lbar'])
+    assert abs(got - float(g['tl_grad'])) < 1e-12 * abs(float(g['tl_grad']))
