@@ -92,3 +92,44 @@ def mtf_ptf_otf_from_psf(psf, dx=None, return_more=False):
     if return_more:
         return mtf, ptf, otf, data
     return mtf, ptf, otf
+
+
+def _forward_data(psf, dx, data):
+    if data is None:
+        data, _ = transform_psf(psf, dx)
+    return L.as_complex(data)
+
+
+def mtf_from_psf_adjoint(mtf_bar, psf=None, dx=None, data=None):
+    """Apply the adjoint of mtf_from_psf (otf.py:205-242): gradient on the centre-normalised MTF -> real PSF."""
+    data = _forward_data(psf, dx, data)
+    mtf_bar = L.as_device(mtf_bar).to(L._REAL_OF[data.dtype])
+    cy, cx = _center(data.shape)
+    mag = torch.abs(data)
+    a = mag[cy, cx]
+    data_bar = mtf_bar * data / mag / a
+    S = torch.sum(mtf_bar * mag)
+    data_bar[cy, cx] -= S * data[cy, cx] / a ** 3
+    return transform_psf_adjoint(data_bar).real
+
+
+def ptf_from_psf_adjoint(ptf_bar, psf=None, dx=None, data=None):
+    """Apply the adjoint of ptf_from_psf (otf.py:245-279)."""
+    data = _forward_data(psf, dx, data)
+    ptf_bar = L.as_device(ptf_bar).to(L._REAL_OF[data.dtype])
+    cy, cx = _center(data.shape)
+    msq = data.real * data.real + data.imag * data.imag
+    data_bar = ptf_bar * 1j * data / msq
+    data_bar[cy, cx] -= torch.sum(ptf_bar) * 1j * data[cy, cx] / msq[cy, cx]
+    return transform_psf_adjoint(data_bar).real
+
+
+def otf_from_psf_adjoint(otf_bar, psf=None, dx=None, data=None):
+    """Apply the adjoint of otf_from_psf (otf.py:282-316)."""
+    data = _forward_data(psf, dx, data)
+    otf_bar = L.as_complex(otf_bar).to(data.dtype)
+    cy, cx = _center(data.shape)
+    cc = torch.conj(data[cy, cx])
+    data_bar = otf_bar / cc
+    data_bar[cy, cx] -= torch.sum(torch.conj(data) * otf_bar) / cc ** 2
+    return transform_psf_adjoint(data_bar).real

@@ -305,6 +305,15 @@ def multires():
     Lbar = crandn(rng, (32, 32))
     out['tl_x'], out['tl_y'], out['tl_Lbar'] = xx, yy, Lbar
     out['tl_grad'] = np.asarray(propagation.Wavefront.thin_lens_adjoint(250.0, HeNe, xx, yy, Lbar))
+    # otf adjoints (otf.py:205-316)
+    psf = rng.random((20, 24)) + 0.1
+    out['otf_psf'] = psf
+    out['otf_mtf_bar'] = rng.standard_normal((20, 24))
+    out['otf_ptf_bar'] = rng.standard_normal((20, 24))
+    out['otf_otf_bar'] = crandn(rng, (20, 24))
+    out['otf_mtf_adj'] = potf.mtf_from_psf_adjoint(out['otf_mtf_bar'], psf, 1.0)
+    out['otf_ptf_adj'] = potf.ptf_from_psf_adjoint(out['otf_ptf_bar'], psf, 1.0)
+    out['otf_otf_adj'] = potf.otf_from_psf_adjoint(out['otf_otf_bar'], psf, 1.0)
     np.savez_compressed(os.path.join(HERE, 'multires.npz'), **out)
 
 

@@ -691,3 +691,15 @@ def test_multiresolution_golden(pa, golden):
         P.to_fpm_and_back_multiresolution_adjoint(gg, P.vortex_phase_mask(2), ex, return_fpm_grad=True)
     got = float(P.Wavefront.thin_lens_adjoint(250.0, wvl, g['tl_x'], g['tl_y'], g['tl_Lbar']))
     assert abs(got - float(g['tl_grad'])) < 1e-10 * abs(float(g['tl_grad']))
+
+
+def test_otf_adjoints_golden(pa, golden):
+    """mtf / ptf / otf_from_psf_adjoint (otf.py:205-316) against the reference, with and without the reused transform."""
+    from prysm_amd import otf
+    g = golden('multires')
+    psf = g['otf_psf']
+    assert rel_max(tonp(otf.mtf_from_psf_adjoint(g['otf_mtf_bar'], psf, 1.0)), g['otf_mtf_adj']) < TOL64
+    assert rel_max(tonp(otf.ptf_from_psf_adjoint(g['otf_ptf_bar'], psf, 1.0)), g['otf_ptf_adj']) < TOL64
+    assert rel_max(tonp(otf.otf_from_psf_adjoint(g['otf_otf_bar'], psf, 1.0)), g['otf_otf_adj']) < TOL64
+    _, data = otf.mtf_from_psf(psf, 1.0, return_more=True)
+    assert rel_max(tonp(otf.mtf_from_psf_adjoint(g['otf_mtf_bar'], data=data)), g['otf_mtf_adj']) < TOL64

@@ -276,3 +276,11 @@ def test_multiresolution_oracle_vs_golden(golden):
         assert rel_max(ex.xf[k], g[f'xf{k}']) < 1e-14
     got = O.thin_lens_adjoint(250.0, float(g['par'][2]), g['tl_x'], g['tl_y'], g['tl_Lbar'])
     assert abs(got - float(g['tl_grad'])) < 1e-12 * abs(float(g['tl_grad']))
+
+
+def test_otf_adjoints_oracle_vs_golden(golden):
+    g = golden('multires')
+    psf = g['otf_psf']
+    assert rel_max(O.mtf_from_psf_adjoint(g['otf_mtf_bar'], psf), g['otf_mtf_adj']) < 1e-12
+    assert rel_max(O.ptf_from_psf_adjoint(g['otf_ptf_bar'], psf), g['otf_ptf_adj']) < 1e-12
+    assert rel_max(O.otf_from_psf_adjoint(g['otf_otf_bar'], psf), g['otf_otf_adj']) < 1e-12
