@@ -55,6 +55,75 @@ def is_power_of_2(value):
 # Installing the engine into an existing prysm (the reference's own plug mechanism: rebinding names on its
 # modules at run time, as prysm/x/polarization.py:541-553 does for Jones propagation).
 # --------------------------------------------------------------------------------------------------------
+class FFTFacade:
+    """Module-like ``fft`` object for prysm's BackendShim (``prysm.mathops.fft._srcmodule = FFTFacade()``).
+
+    Exactly the surface the hot path touches: fft2 / ifft2 (norm None | 'backward' | 'ortho' | 'forward'),
+    fft / ifft (n, axis), fftshift / ifftshift, fftfreq, next_fast_len -- numpy semantics on torch tensors in HBM,
+    the transforms on libprysm_amd.so.  This is the UNFUSED level: prysm's own ``fftshift(fft2(ifftshift(x)))`` then
+    runs as three device operations; the fused level is the function rebinding of set_backend_to_mi355x().
+    """
+
+    @staticmethod
+    def _scale(norm, count, inverse):
+        if norm in (None, 'backward'):
+            return 1.0 / count if inverse else 1.0
+        if norm == 'ortho':
+            return 1.0 / count ** 0.5
+        if norm == 'forward':
+            return 1.0 if inverse else 1.0 / count
+        raise ValueError(f'invalid norm {norm!r}')
+
+    def fft2(self, x, s=None, axes=(-2, -1), norm=None):
+        from . import _ops
+        x = L.as_field(x)
+        if s is not None or tuple(a % x.dim() for a in axes) != (x.dim() - 2, x.dim() - 1):
+            raise NotImplementedError('fft2 facade: last two axes, no resizing')
+        M, N = x.shape[-2:]
+        return _ops.fft2(x, direction=-1, scale=self._scale(norm, M * N, False))
+
+    def ifft2(self, x, s=None, axes=(-2, -1), norm=None):
+        from . import _ops
+        x = L.as_field(x)
+        if s is not None or tuple(a % x.dim() for a in axes) != (x.dim() - 2, x.dim() - 1):
+            raise NotImplementedError('ifft2 facade: last two axes, no resizing')
+        M, N = x.shape[-2:]
+        return _ops.fft2(x, direction=+1, scale=self._scale(norm, M * N, True))
+
+    def fft(self, x, n=None, axis=-1, norm=None):
+        from . import _ops
+        x = L.as_complex(x)
+        length = n if n is not None else x.shape[axis]
+        return _ops.fft1(x, n, axis, -1, self._scale(norm, length, False))
+
+    def ifft(self, x, n=None, axis=-1, norm=None):
+        from . import _ops
+        x = L.as_complex(x)
+        length = n if n is not None else x.shape[axis]
+        return _ops.fft1(x, n, axis, +1, self._scale(norm, length, True))
+
+    @staticmethod
+    def fftshift(x, axes=None):
+        x = L.as_device(x)
+        axes = tuple(range(x.dim())) if axes is None else ((axes,) if isinstance(axes, int) else tuple(axes))
+        return torch.roll(x, [x.shape[a] // 2 for a in axes], axes)
+
+    @staticmethod
+    def ifftshift(x, axes=None):
+        x = L.as_device(x)
+        axes = tuple(range(x.dim())) if axes is None else ((axes,) if isinstance(axes, int) else tuple(axes))
+        return torch.roll(x, [-(x.shape[a] // 2) for a in axes], axes)
+
+    @staticmethod
+    def fftfreq(n, d=1.0):
+        return torch.fft.fftfreq(n, d, dtype=torch.float64, device=L.device())
+
+    @staticmethod
+    def next_fast_len(n):
+        from .fttools import next_fast_len
+        return next_fast_len(n)
+
+
 _PROPAGATION_NAMES = (
     'focus', 'focus_adjoint', 'unfocus', 'unfocus_adjoint',
     'angular_spectrum', 'angular_spectrum_adjoint', 'angular_spectrum_transfer_function',
@@ -97,6 +166,13 @@ def set_backend_to_mi355x(prysm=None):
         mod.Wavefront = pa_prop.Wavefront
     try:
         pa_config.precision = importlib.import_module(prysm.__name__ + '.conf').config.precision
+    except Exception:   # pragma: no cover
+        pass
+    # unfused level: prysm's own fft shim (anything that still calls fft.fft2 / fft.fftshift directly, e.g. otf.py)
+    try:
+        shim = importlib.import_module(prysm.__name__ + '.mathops').fft
+        _saved.setdefault((shim, '_srcmodule'), shim._srcmodule)
+        shim._srcmodule = FFTFacade()
     except Exception:   # pragma: no cover
         pass
 

@@ -703,3 +703,24 @@ def test_otf_adjoints_golden(pa, golden):
     assert rel_max(tonp(otf.otf_from_psf_adjoint(g['otf_otf_bar'], psf, 1.0)), g['otf_otf_adj']) < TOL64
     _, data = otf.mtf_from_psf(psf, 1.0, return_more=True)
     assert rel_max(tonp(otf.mtf_from_psf_adjoint(g['otf_mtf_bar'], data=data)), g['otf_mtf_adj']) < TOL64
+
+
+def test_fft_facade_numpy_semantics(pa):
+    """The module-like fft object handed to prysm's BackendShim: numpy semantics (norm modes, n / axis, odd-length shifts)."""
+    from prysm_amd.mathops import FFTFacade
+    fft = FFTFacade()
+    rng = np.random.default_rng(8)
+    x = crandn(rng, (9, 12))
+    for norm in (None, 'ortho', 'forward'):
+        assert rel_max(tonp(fft.fft2(x, norm=norm)), np.fft.fft2(x, norm=norm)) < TOL64
+        assert rel_max(tonp(fft.ifft2(x, norm=norm)), np.fft.ifft2(x, norm=norm)) < TOL64
+    assert rel_max(tonp(fft.fft(x, 16, axis=0)), np.fft.fft(x, 16, axis=0)) < TOL64
+    assert rel_max(tonp(fft.ifft(x, 8, axis=1)), np.fft.ifft(x, 8, axis=1)) < TOL64
+    assert np.array_equal(tonp(fft.fftshift(x)), np.fft.fftshift(x)) and np.array_equal(tonp(fft.ifftshift(x)), np.fft.ifftshift(x))
+    assert np.array_equal(tonp(fft.fftshift(x, axes=1)), np.fft.fftshift(x, axes=1))
+    assert np.allclose(tonp(fft.fftfreq(9, 0.5)), np.fft.fftfreq(9, 0.5))
+    # prysm's focus written against the shim: fftshift(fft2(ifftshift(x), norm='ortho'))
+    got = tonp(fft.fftshift(fft.fft2(fft.ifftshift(x), norm='ortho')))
+    assert rel_max(got, O.focus(x, 1)) < TOL64
+    real = rng.standard_normal((16, 16))
+    assert rel_max(tonp(fft.fft2(real)), np.fft.fft2(real)) < TOL64

@@ -90,6 +90,11 @@ def test_install_into_prysm_rebinds_and_restores():
         assert P.prepare_executor is prysm_amd.propagation.prepare_executor
         assert F.MDFT is prysm_amd.fttools.MDFT
         assert P.Wavefront is prysm_amd.propagation.Wavefront
+        import prysm.mathops as PM
+        assert isinstance(PM.fft._srcmodule, mathops.FFTFacade)    # the unfused fft shim level
+        assert PM.fft.fft2.__self__ is PM.fft._srcmodule
     finally:
         mathops.restore_prysm_backend()
     assert P.focus is orig_focus and F.MDFT is orig_mdft and P.Wavefront is orig_wf
+    import prysm.mathops as PM
+    assert not isinstance(PM.fft._srcmodule, mathops.FFTFacade)
