@@ -67,15 +67,16 @@ def _fields_per_launch(shape, cdtype_bytes, Q, limit_bytes=1 << 30):
 
 
 def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, focal_dx=None, samples=None,
-                      kind='mdft', group=None, reduce_to_all=True, batched=True):
+                      kind='mdft', group=None, reduce_to_all=True, batched=None):
     """Polychromatic PSF of a pupil (amplitude, OPD in nm) -- the how-to's recipe on N GPUs.
 
     Q given            : FFT focus per wavelength with the |.|^2 fused into the transform (multi-field throughput
-                         variant; focal sampling is chromatic, as the reference docs note).  With `batched`
-                         (default) the wavelengths of a rank are propagated as stacks -- one launch pair per stack,
-                         then one weighted sum (sum_of_2d_modes) -- which is what makes <= 1024^2 pupils
-                         bandwidth-bound instead of launch-bound; batched=False is the field-by-field loop with
-                         the accumulate epilogue.
+                         variant; focal sampling is chromatic, as the reference docs note).  With `batched` the
+                         wavelengths of a rank are propagated as stacks -- one launch pair per stack, then one
+                         weighted sum (sum_of_2d_modes) -- which is what makes <= 2048^2 transforms bandwidth-bound
+                         instead of launch-bound; batched=False is the field-by-field loop with the accumulate
+                         epilogue, the faster form from 4096^2 transforms (single fields take the folded kernels).
+                         Default (None): stacks below 4096^2 transforms.
     focal_dx + samples : per-wavelength fixed-sampling focus (prepare_executor + focus_dft, `kind`),
                          all wavelengths on one focal grid -- the variant of the how-to.
     """
@@ -87,6 +88,8 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
     amp = L.as_device(amplitude)
     phs = L.as_device(opd)
 
+    if Q is not None and batched is None:
+        batched = math.ceil(amp.shape[-2] * Q) * math.ceil(amp.shape[-1] * Q) < 4096 * 4096
     if Q is not None and batched:
         if len(wavelengths) != len(weights):
             raise ValueError('wavelengths and weights must have the same length')

@@ -408,7 +408,7 @@ def test_polychromatic_driver_single_gpu(pa):
     # variant F (throughput): FFT focus per wavelength with the fused |.|^2 accumulate epilogue
     comps = [O.intensity(O.focus(O.from_amp_and_phase(amp, opd, float(w)), 2)) for w in wvls]
     want = O.sum_of_2d_modes(np.asarray(comps), wts)
-    got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2))                   # stacks + one weighted sum
+    got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2, batched=True))     # stacks + one weighted sum
     assert rel_max(got, want) < TOL64
     got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2, batched=False))    # field by field, accumulate epilogue
     assert rel_max(got, want) < TOL64
