@@ -11,7 +11,8 @@ shards over wavelengths / fields with no data-path collective (weak scaling), so
 is exactly K propagations per rank.  The one real exchange of the polychromatic recipe -- |E|^2 and a
 sum all-reduce of the 67 MB fp32 image over RCCL -- happens once per polychromatic PSF, not per
 propagation; it is run and timed AFTER the timed region (``reduce_ms``, median of 3) and folded into
-``polychromatic_64wvl_ms``, the time of BASELINE config 5 (64 wavelengths over the N ranks + one reduce).
+``polychromatic.psf_64wvl_ms``, the time of BASELINE config 5 (64 wavelengths over the N ranks, each = pupil
+synthesis + focus with the fused |.|^2 accumulate, measured on rank 0, + one reduce).
 
 Rank 0 prints ONE JSON line.  ``roofline``: the dominant kernel (the slower of the two FFT passes),
 its duration measured with HIP events recorded between the kernels on the launch stream, in
@@ -100,6 +101,33 @@ def pmc_traffic(kernel, n, dtype_name):
             if k.startswith(want) and k.endswith(f'_{real}_N{nn}'):
                 return v['hbm_traffic_bytes'], f'profiles/pmc_bench_summary.json:{k}'
     return None, None
+
+
+def polychromatic_per_wavelength_ms(n, cdtype, reps=8):
+    """One wavelength of BASELINE config 5, variant F, as the driver runs it per GPU: pupil synthesis
+    (from_amp_and_phase of a circular amplitude and a W040 OPD map) + FFT focus with the fused |.|^2 accumulate."""
+    from prysm_amd import propagation as P
+    rdt = torch.float32 if cdtype == np.complex64 else torch.float64
+    ax = (torch.arange(n, device='cuda', dtype=torch.float64) - n // 2) * (10.0 / n)
+    r = torch.hypot(ax[None, :], ax[:, None])
+    amp = (r <= 5).to(rdt)
+    opd = (500.0 * (r / 5) ** 4).to(rdt)
+    acc = torch.zeros((n, n), dtype=rdt, device='cuda')
+
+    def one(wvl):
+        wf = P.Wavefront.from_amp_and_phase(amp, opd, wvl, 10.0 / n)
+        P.focus_intensity(wf.data, 1, out=acc, weight=1.0)
+
+    for k in range(2):
+        one(0.5 + 0.01 * k)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(reps):
+        one(0.5 + 0.2 * k / 63)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def cpu_baseline(n, cdtype, budget_s):
@@ -202,6 +230,7 @@ def main():
         dist.all_reduce(r, op=dist.ReduceOp.MAX)
         reduce_ms = float(r.item())
 
+    poly_ms = polychromatic_per_wavelength_ms(n, cdtype) if rank == 0 else 0.0
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
@@ -223,7 +252,10 @@ def main():
             'whole_step_algorithmic_GBps_per_gpu': alg_bytes_step / (ms_step * 1e-3) / 1e9,
             'whole_step_frac_of_hbm_peak': alg_bytes_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'reduce_ms': reduce_ms,
-            'polychromatic_64wvl_ms': math.ceil(64 / world) * ms_step + reduce_ms,
+            'polychromatic': {'per_wavelength_ms': poly_ms, 'wavelengths_per_gpu': math.ceil(64 / world),
+                              'psf_64wvl_ms': math.ceil(64 / world) * poly_ms + reduce_ms,
+                              'note': 'BASELINE config 5 variant F: per wavelength = pupil synthesis + FFT focus with fused '
+                                      '|.|^2 accumulate (measured on rank 0 after the timed region), plus one sum-reduce'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
                          'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes_kernel,
