@@ -116,7 +116,11 @@ def polychromatic_per_wavelength_ms(n, cdtype, reps=8):
 
     def one(wvl):
         wf = P.Wavefront.from_amp_and_phase(amp, opd, wvl, 10.0 / n)
-        P.focus_intensity(wf.data, 1, out=acc, weight=1.0)
+        fus = wf._fusable(1)     # complex64: the pupil is synthesised inside the row pass, never written
+        if fus is not None:
+            P.focus_intensity(fus[1], 1, out=acc, weight=1.0, synth=(fus[0], fus[2]))
+        else:
+            P.focus_intensity(wf.data, 1, out=acc, weight=1.0)
 
     for k in range(2):
         one(0.5 + 0.01 * k)

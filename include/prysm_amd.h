@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PM_VERSION 101 /* 0.1.0 */
+#define PM_VERSION 102 /* 0.1.0 */
 
 /* dtype codes */
 enum { PM_C64 = 0, PM_C128 = 1, PM_F32 = 2, PM_F64 = 3, PM_BOOL = 4 };
@@ -62,6 +62,10 @@ enum { PM_MUL_NONE = 0, PM_MUL_FULL = 1, PM_MUL_SEPARABLE = 2 };
 enum {
     PM_FLAG_PASS1_ONLY = 1, /* profiling: run only the row pass    */
     PM_FLAG_PASS2_ONLY = 2, /* profiling: run only the column pass */
+    PM_FLAG_SYNTH_INPUT = 8, /* `in` is the real OPD map (float); the transformed field is synth_amp * exp(i synth_k opd),
+                             * synthesised while the row pass loads it -- Wavefront.from_amp_and_phase
+                             * (prysm/propagation/wavefront.py:58-79) fused into focus: the complex pupil never exists in
+                             * memory.  PM_C64 with power-of-two row lengths only (PM_ERR_UNSUPPORTED otherwise). */
     PM_FLAG_REAL_INPUT = 4  /* `in` is a REAL array of the precision that goes with dtype (float / double); in_ld and
                              * in_bstride count real elements.  fft2 of a real PSF / object / actuator map
                              * (prysm/otf.py:31, prysm/convolution.py:27-28,82-85) without a complex copy: pass 1 reads
@@ -117,6 +121,13 @@ typedef struct pm_fft2_desc {
     int64_t batch;
     int64_t in_bstride, out_bstride;
     int64_t mul_bstride, mul_x_bstride;
+    /* PM_FLAG_SYNTH_INPUT: amplitude array of the in window's shape (NULL: unit amplitude), its type (PM_F32, PM_F64,
+     * PM_BOOL), leading dimension, and k = 2 pi / (wavelength_um * 1e3) for an OPD in nm */
+    const void* synth_amp;
+    int32_t synth_amp_dtype;
+    int32_t synth_reserved;
+    int64_t synth_amp_ld;
+    double synth_k;
 } pm_fft2_desc;
 
 /* bytes of workspace pm_fft2 needs for this descriptor (the tiled intermediate) */

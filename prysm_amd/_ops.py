@@ -59,9 +59,17 @@ def _fill_mul(d, x, mul, mul_x, mul_conj, keep):
     d.mul_conj = 1 if mul_conj else 0
 
 
+def synth_supported(opd, amp, N):
+    """Whether pm_fft2 can synthesise amp * exp(i k opd) while loading (PM_FLAG_SYNTH_INPUT): complex64 path, 2-D,
+    power-of-two row length, real / bool amplitude."""
+    if opd.dim() != 2 or opd.dtype != torch.float32 or not _is_pow2_engine(N):
+        return False
+    return amp is None or (amp.dtype in _AMP_CODE and amp.dim() == 2 and amp.shape == opd.shape and amp.stride(-1) == 1)
+
+
 def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
          out_shape=None, out_off=(0, 0), out_shift=(0, 0), epilogue=L.PM_EPI_NONE,
-         mul=None, mul_x=None, mul_conj=False, out=None, weight=1.0, flags=0):
+         mul=None, mul_x=None, mul_conj=False, out=None, weight=1.0, flags=0, synth=None):
     """Fused 2-D transform (pm_fft2).
 
     x          : (m, n) complex tensor, or a (B, m, n) stack transformed in one launch pair; each field sits at
@@ -70,6 +78,8 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
     out_shape  : stored window of the output (crop), at `out_off` of the rotated result
     mul, mul_x : None | full (M, N) multiplier | (column vector hy (M,), row vector hx (N,)); with a stack,
                  (B, M, N) / ((B, M), (B, N)) give one multiplier per field
+    synth      : (amp | None, k): x is the real float32 OPD map and the transformed field is amp * exp(i k x),
+                 synthesised while the row pass loads it (see synth_supported)
     """
     lib = L.load()
     d = L.pm_fft2_desc()
@@ -80,6 +90,15 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
     d.scale = float(scale)
     d.weight = float(weight)
     keep = [x]
+    if synth is not None:
+        amp, k = synth
+        d.flags = (d.flags & ~L.PM_FLAG_REAL_INPUT) | L.PM_FLAG_SYNTH_INPUT
+        d.synth_k = float(k)
+        if amp is not None:
+            d.synth_amp = amp.data_ptr()
+            d.synth_amp_dtype = _AMP_CODE[amp.dtype]
+            d.synth_amp_ld = amp.stride(0) if amp.shape[0] > 1 else amp.shape[1]
+            keep.append(amp)
     _fill_mul(d, x, mul, mul_x, mul_conj, keep)
     if out is None:
         odt = L.cdtype_of(x) if epilogue == L.PM_EPI_NONE else L._REAL_OF[L.cdtype_of(x)]

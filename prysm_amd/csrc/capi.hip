@@ -113,6 +113,19 @@ static int check_axis(const pm_axis& a, const char* name) {
     return 0;
 }
 
+// input mode of the row loader from the descriptor flags: complex, real, or pupil synthesis
+template <typename T>
+static void set_input_mode(RowLoadNat<T>& lp, const pm_fft2_desc* d) {
+    lp.real = (d->flags & PM_FLAG_SYNTH_INPUT) ? 2 : ((d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0);
+    if (lp.real == 2) {
+        lp.amp = d->synth_amp;
+        lp.amp_kind = !d->synth_amp ? 0 : (d->synth_amp_dtype == PM_F32 ? 1 : (d->synth_amp_dtype == PM_F64 ? 2 : 3));
+        lp.amp_ld = d->synth_amp_ld;
+        lp.k2 = d->synth_k / (2.0 * 3.14159265358979323846264338327950288);
+        lp.conj = 0;   // the inverse transform's conj-in is folded into the sign of k by the caller; synthesis is forward only
+    }
+}
+
 // ---------------------------------------------------------------- 2-D transform
 struct Fft2Plan {
     int logn, logm;       // engine log2 sizes or -1 (direct)
@@ -233,8 +246,8 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
             if (!tw) return err;
             const size_t in_bytes = size_t(p.nbatch) * size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
             const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
-            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, conj, nt_in, d->in_bstride,
-                             (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
+            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, conj, nt_in, d->in_bstride};
+            set_input_mode(lp, d);
             int rc;
             if (p.fold) {
                 int ltc = 0;
@@ -390,8 +403,8 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
         if (!twH) return err;
         const size_t in_bytes = size_t(M) * size_t(d->in_x.len) * sizeof(cx<T>);
         const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
-        RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), int(M), 0, nt_in, 0,
-                         (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0, H};
+        RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), int(M), 0, nt_in, 0, 0, H};
+        set_input_mode(lp, d);
         RowStoreFold<T> sp{W1, plane, H, ltl, twM, d->in_y.shift == M / 2 ? 1 : 0, 0};
         int rc = launch_row_fold<T>(p.logn, lp, sp, twN, H, 0, st, 1);
         if (rc) return rc;
@@ -410,8 +423,8 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
     if (rows > 0) {
         const size_t in_bytes = size_t(p.nbatch) * size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
         const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
-        RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, 0, nt_in, d->in_bstride,
-                         (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
+        RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, 0, nt_in, d->in_bstride};
+        set_input_mode(lp, d);
         RowStoreTiled<T> sp{W1, rows, ltl, wstride};
         int rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, twN, rows, tuning().row_log_g, st, nb);
         if (rc) return rc;
@@ -461,6 +474,14 @@ static int check_fft2(const pm_fft2_desc* d) {
     if (d->in_y.n != d->out_y.n || d->in_x.n != d->out_x.n)
         return fail(PM_ERR_ARG, "pm_fft2: input and output views must share the transform size");
     if (d->in_ld < d->in_x.len || d->out_ld < d->out_x.len) return fail(PM_ERR_ARG, "pm_fft2: leading dimension < row length");
+    if (d->flags & PM_FLAG_SYNTH_INPUT) {
+        if (d->direction != -1) return fail(PM_ERR_ARG, "pm_fft2: PM_FLAG_SYNTH_INPUT is a forward transform");
+        if (d->dtype != PM_C64 || engine_log2(d->in_x.n) < 0 || d->batch > 1)
+            return fail(PM_ERR_UNSUPPORTED, "pm_fft2: PM_FLAG_SYNTH_INPUT needs PM_C64, a power-of-two row length and no batch");
+        if (d->synth_amp && d->synth_amp_dtype != PM_F32 && d->synth_amp_dtype != PM_F64 && d->synth_amp_dtype != PM_BOOL)
+            return fail(PM_ERR_ARG, "pm_fft2: synth_amp_dtype");
+        if (d->synth_amp && d->synth_amp_ld < d->in_x.len) return fail(PM_ERR_ARG, "pm_fft2: synth_amp_ld < row length");
+    }
     if (d->batch < 0 || d->batch > 65535) return fail(PM_ERR_ARG, "pm_fft2: batch = %lld must be in [0, 65535]", (long long)d->batch);
     if (d->batch > 1) {
         if (d->in_bstride < 0 || d->out_bstride < 0 || d->mul_bstride < 0 || d->mul_x_bstride < 0)
@@ -607,7 +628,7 @@ int pm_fft2_time_passes(const pm_fft2_desc* d, const void* in, void* out, void* 
         if (he != hipSuccess) return int(he);
     }
     pm_fft2_desc dd = *d;
-    const int32_t keep = d->flags & PM_FLAG_REAL_INPUT;
+    const int32_t keep = d->flags & (PM_FLAG_REAL_INPUT | PM_FLAG_SYNTH_INPUT);
     dd.flags = keep;
     int rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);   // warm (also builds the plan)
     for (int i = 0; i < reps && !rc; ++i) {

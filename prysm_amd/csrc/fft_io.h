@@ -39,6 +39,13 @@ struct RowLoadNat {
     int real;       // the array is REAL (T, not cx<T>): src points at T, ld / bstride count real elements, imag = 0
     int eoff;       // E > 1: sequence of slot e is unit*E + e (eoff == 0, consecutive rows) or unit + e*eoff (rows eoff apart:
                     // the pair (i, i + M/2) of a folded column transform)
+    // real == 2: PUPIL SYNTHESIS on the fly -- src is the real OPD map and the element is amp * exp(2 pi i * k2 * opd)
+    // (Wavefront.from_amp_and_phase, prysm/propagation/wavefront.py:58-79, fused into the load: the complex pupil is
+    // never written to memory).  amp_kind: 0 unit amplitude, 1 float, 2 double, 3 bool / uint8.
+    const void* amp;
+    int amp_kind;
+    int64_t amp_ld;
+    double k2;      // phase in turns per OPD unit: k / (2 pi)
 };
 
 template <typename T>
@@ -239,6 +246,35 @@ template <typename T> inline void nt_store_v4(Vec4<T>* p, Vec4<T> v) { *p = v; }
 template <typename T> inline void nt_store_s(T* p, T v) { *p = v; }
 #endif
 
+// amp * exp(2 pi i * turns): the phase is reduced to [-0.5, 0.5] turns in fp64 (OPD * k reaches thousands of radians),
+// then the hardware sine / cosine (argument in revolutions; measured max abs error 1.3e-7 on that interval,
+// tools/exp_hwsin.cpp) for float, sincospi for double.
+template <typename T>
+PM_HD cx<T> synth_value(T opd, T a, double k2) {
+    const double turns = double(opd) * k2;
+    const double r = turns - rint(turns);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (sizeof(T) == 4) {
+        const float rf = float(r);
+        return {a * __builtin_amdgcn_cosf(rf), a * __builtin_amdgcn_sinf(rf)};
+    } else {
+        double sn, cs;
+        sincospi(2.0 * r, &sn, &cs);
+        return {T(a * cs), T(a * sn)};
+    }
+#else
+    const double ang = 6.283185307179586476925286766559 * r;
+    return {T(double(a) * cos(ang)), T(double(a) * sin(ang))};
+#endif
+}
+template <typename T>
+PM_HD T synth_amp(const void* amp, int kind, int64_t idx) {
+    if (kind == 1) return T(reinterpret_cast<const float*>(amp)[idx]);
+    if (kind == 2) return T(reinterpret_cast<const double*>(amp)[idx]);
+    if (kind == 3) return T(reinterpret_cast<const unsigned char*>(amp)[idx] ? 1 : 0);
+    return T(1);
+}
+
 // ------------------------------------------------------------------ batches
 // Field b of a batch (blockIdx.y) is the same problem at an offset: a copy of the parameter block with
 // the base pointers advanced.  The parameter blocks live in SGPRs, so this is a handful of scalar ops.
@@ -274,60 +310,70 @@ template <typename T> PM_HD ColStoreNat<T> at_batch(ColStoreNat<T> p, int b) {
 
 // ------------------------------------------------------------------ row mode
 // FULL: the window covers the whole axis and the sequence exists -> no per-element predicates at all
-template <typename C, int ROT, bool FULL = false, bool REAL = false>
+// MODE: 0 complex input, 1 real input, 2 pupil synthesis (real OPD + amplitude)
+template <typename C, int ROT, bool FULL = false, int MODE = 0>
 PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
                     cx<typename C::T> (&v)[C::E][C::P]) {
     using T = typename C::T;
     static_assert(C::CI == 1, "row mode");
-    // a thread owns E consecutive sequences (rows): (blk*BO + bo)*E + e; they share twiddles and addressing
+    // a thread owns E sequences (rows): consecutive ones, or the pair (i, i + eoff) of a folded transform
 #pragma unroll
     for (int e = 0; e < C::E; ++e) {
         const int unit = blk * C::BO + pos.bo;
         const int seq = p.eoff ? unit + e * p.eoff : unit * C::E + e;
         const bool ok = seq < p.nseq && (!p.eoff || unit < p.eoff);
         const cx<T>* row = p.src + int64_t(ok ? seq : 0) * p.ld - p.ax.off;
-        const T* rrow = reinterpret_cast<const T*>(p.src) + int64_t(ok ? seq : 0) * p.ld - p.ax.off;   // REAL input
+        const T* rrow = reinterpret_cast<const T*>(p.src) + int64_t(ok ? seq : 0) * p.ld - p.ax.off;   // real input / OPD
+        const int64_t arow = int64_t(ok ? seq : 0) * p.amp_ld - p.ax.off;                               // amplitude row
         const int lo = p.ax.off, hi = ok ? p.ax.off + p.ax.len : -1;
 #pragma unroll
         for (int m = 0; m < C::P; ++m) {
             const int pp = slot_pos<C, ROT>(pos.t, m, p.ax.shift);
             cx<T> val = {T(0), T(0)};
             if (FULL || (pp >= lo && pp < hi)) {
-                if constexpr (REAL)
+                if constexpr (MODE == 2)
+                    val = synth_value<T>(rrow[pp], synth_amp<T>(p.amp, p.amp_kind, arow + pp), p.k2);
+                else if constexpr (MODE == 1)
                     val.x = p.nt ? nt_load_s(rrow + pp) : rrow[pp];
                 else
                     val = p.nt ? nt_load_cx(row + pp) : row[pp];
             }
             v[e][m] = val;
         }
-        if (!REAL && p.conj) {
+        if (MODE != 1 && p.conj) {
 #pragma unroll
             for (int m = 0; m < C::P; ++m) v[e][m].y = -v[e][m].y;
         }
     }
 }
 
-template <typename C, bool REAL>
+template <typename C, int MODE>
 PM_HD void load_sel(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
     const int rot = rot_of<C>(p.ax.shift);
     const int unit_ = blk * C::BO + pos.bo;
     const bool full = p.ax.off == 0 && p.ax.len == C::N &&
                       (p.eoff ? (unit_ < p.eoff && unit_ + (C::E - 1) * p.eoff < p.nseq) : (unit_ * C::E + C::E - 1) < p.nseq);
     if (rot == 0) {
-        if (full) load_rot<C, 0, true, REAL>(p, blk, pos, v);
-        else load_rot<C, 0, false, REAL>(p, blk, pos, v);
+        if (full) load_rot<C, 0, true, MODE>(p, blk, pos, v);
+        else load_rot<C, 0, false, MODE>(p, blk, pos, v);
     } else if (rot > 0) {
-        if (full) load_rot<C, (C::P >= 2 ? C::P / 2 : 0), true, REAL>(p, blk, pos, v);
-        else load_rot<C, (C::P >= 2 ? C::P / 2 : 0), false, REAL>(p, blk, pos, v);
+        if (full) load_rot<C, (C::P >= 2 ? C::P / 2 : 0), true, MODE>(p, blk, pos, v);
+        else load_rot<C, (C::P >= 2 ? C::P / 2 : 0), false, MODE>(p, blk, pos, v);
     } else {
-        load_rot<C, -1, false, REAL>(p, blk, pos, v);
+        load_rot<C, -1, false, MODE>(p, blk, pos, v);
     }
 }
 
 template <typename C>
 PM_HD void load(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
-    if (p.real) load_sel<C, true>(p, blk, pos, v);
-    else load_sel<C, false>(p, blk, pos, v);
+    if constexpr (sizeof(typename C::T) == 4) {   // synthesis only on the complex64 path (fp64 sincospi would dominate the pass)
+        if (p.real == 2) {
+            load_sel<C, 2>(p, blk, pos, v);
+            return;
+        }
+    }
+    if (p.real) load_sel<C, 1>(p, blk, pos, v);
+    else load_sel<C, 0>(p, blk, pos, v);
 }
 
 template <typename C>

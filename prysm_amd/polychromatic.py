@@ -117,9 +117,12 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
     def propagate(wvl, w, acc):
         wf = Wavefront.from_amp_and_phase(amp, phs, wvl, dx)
         if Q is not None:
+            fus = wf._fusable(Q)      # float32 maps, power-of-two width: the pupil is synthesised inside the transform
+            src, syn = (fus[1], (fus[0], fus[2])) if fus is not None else (wf.data, None)
             if acc is None:
-                return focus_intensity(wf.data, Q) * w if w != 1.0 else focus_intensity(wf.data, Q)
-            return focus_intensity(wf.data, Q, out=acc, weight=w)
+                first = focus_intensity(src, Q, synth=syn)
+                return first * w if w != 1.0 else first
+            return focus_intensity(src, Q, out=acc, weight=w, synth=syn)
         ex = wf.prepare_executor(efl, focal_dx, samples, kind=kind)
         E = wf.focus_dft(ex).data
         if acc is None:

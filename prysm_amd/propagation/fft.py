@@ -16,7 +16,7 @@ from .. import _ops
 from ._kernels import _padded_shape, _shape_before_pad
 
 
-def _centered_fft2(x, Q, direction, crop_to=None):
+def _centered_fft2(x, Q, direction, crop_to=None, synth=None):
     """fftshift(fft2 | ifft2(ifftshift(pad2d(x, Q)), norm='ortho')) [+ crop_center]."""
     x = L.as_field(x)
     if x.dim() not in (2, 3):
@@ -30,7 +30,13 @@ def _centered_fft2(x, Q, direction, crop_to=None):
         out_shape = tuple(crop_to)
         out_off = (math.ceil((M - crop_to[0]) / 2), math.ceil((N - crop_to[1]) / 2))  # crop_center: fttools.py:122-124
     return _ops.fft2(x, direction=direction, scale=1.0 / math.sqrt(M * N), shape=(M, N), in_off=in_off,
-                     in_shift=shift, out_shape=out_shape, out_off=out_off, out_shift=shift)
+                     in_shift=shift, out_shape=out_shape, out_off=out_off, out_shift=shift, synth=synth)
+
+
+def focus_from_amp_and_phase(amplitude, opd, k, Q):
+    """focus(amplitude * exp(i k opd), Q) with the pupil synthesised inside the transform (no complex pupil in memory);
+    the caller checks _ops.synth_supported."""
+    return _centered_fft2(opd, Q, -1, synth=(amplitude, k))
 
 
 def focus(wavefunction, Q):
@@ -55,7 +61,7 @@ def unfocus_adjoint(wavefunction, Q):
     return _centered_fft2(wavefunction, 1, -1, crop_to=_shape_before_pad(shape, Q))
 
 
-def focus_intensity(wavefunction, Q, out=None, weight=None):
+def focus_intensity(wavefunction, Q, out=None, weight=None, synth=None):
     """|focus(wavefunction, Q)|^2 with the modulus fused into the last FFT pass.
 
     Equivalent to ``Wavefront.focus(...).intensity.data`` (wavefront.py:146-151, 478-504) but the
@@ -70,7 +76,7 @@ def focus_intensity(wavefunction, Q, out=None, weight=None):
     shift = (M // 2, N // 2)
     epi = L.PM_EPI_ABS2 if (out is None or weight is None) else L.PM_EPI_ABS2_ACCUM
     return _ops.fft2(x, direction=-1, scale=1.0 / math.sqrt(M * N), shape=(M, N), in_off=in_off, in_shift=shift,
-                     out_shift=shift, epilogue=epi, out=out, weight=1.0 if weight is None else weight)
+                     out_shift=shift, epilogue=epi, out=out, weight=1.0 if weight is None else weight, synth=synth)
 
 
 def Q_for_sampling(input_diameter, prop_dist, wavelength, output_dx):

@@ -18,7 +18,7 @@ from ..conf import config
 from .._richdata import RichData
 from ._kernels import phase_prefix
 from .fft import (
-    focus, focus_adjoint, unfocus, unfocus_adjoint, focus_intensity,
+    focus, focus_adjoint, unfocus, unfocus_adjoint, focus_intensity, focus_from_amp_and_phase,
     pupil_sample_to_psf_sample, psf_sample_to_pupil_sample,
 )
 from .dft import (
@@ -60,10 +60,39 @@ class Wavefront:
 
     def __init__(self, cmplx_field, wavelength, dx, space='pupil'):
         """cmplx_field: array (numpy is uploaded); wavelength um; dx mm (pupil) or um (psf)."""
-        self.data = L.as_device(cmplx_field) if not isinstance(cmplx_field, numbers.Number) else cmplx_field
+        self._synth = None
+        if cmplx_field is None or isinstance(cmplx_field, numbers.Number):
+            self.data = cmplx_field
+        else:
+            self.data = L.as_device(cmplx_field)
         self.wavelength = wavelength
         self.dx = dx
         self.space = space
+
+    # `data` of a wavefront made by from_amp_and_phase is materialised on first use: focus / focus_intensity of such a
+    # wavefront synthesise amp * exp(i k opd) inside the transform instead (PM_FLAG_SYNTH_INPUT) and never touch it.
+    @property
+    def data(self):
+        if self._data is None and self._synth is not None:
+            amp, opd, k, cd = self._synth
+            self._data = _ops.pupil_synth(amp, opd, k, cd)
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = value
+        self._synth = None
+
+    def _fusable(self, Q):
+        """(amp, opd, k) when the pupil can be synthesised inside the FFT (not yet materialised, complex64, power-of-two
+        padded width), else None."""
+        if self._data is not None or self._synth is None:
+            return None
+        amp, opd, k, cd = self._synth
+        N = math.ceil(opd.shape[1] * Q)
+        if cd == torch.complex64 and _ops.synth_supported(opd, amp, N):
+            return amp, opd, k
+        return None
 
     @classmethod
     def from_amp_and_phase(cls, amplitude, phase, wavelength, dx):
@@ -78,7 +107,9 @@ class Wavefront:
             if amp is not None and amp.is_complex():
                 P = _ops.cmul(amp.to(cd), _ops.pupil_synth(None, opd, k, cd))
             else:
-                P = _ops.pupil_synth(amp, opd, k, cd)
+                wf = cls(None, wavelength, dx)       # lazy: see the `data` property
+                wf._synth = (amp, opd, k, cd)
+                return wf
         else:
             P = amplitude
         return cls(P, wavelength, dx)
@@ -261,7 +292,11 @@ class Wavefront:
         """Pupil to PSF plane propagation by FFT (wavefront.py:478-504)."""
         if self.space != 'pupil':
             raise ValueError('can only propagate from a pupil to psf plane')
-        data = focus(self.data, Q=Q)
+        fus = self._fusable(Q)
+        if fus is not None:
+            data = focus_from_amp_and_phase(fus[0], fus[1], fus[2], Q)
+        else:
+            data = focus(self.data, Q=Q)
         dx = pupil_sample_to_psf_sample(self.dx, data.shape[1], self.wavelength, efl)
         return Wavefront(data, self.wavelength, dx, space='psf')
 
@@ -269,7 +304,11 @@ class Wavefront:
         """``self.focus(efl, Q).intensity`` with |.|^2 fused into the transform (no complex PSF in memory)."""
         if self.space != 'pupil':
             raise ValueError('can only propagate from a pupil to psf plane')
-        data = focus_intensity(self.data, Q=Q)
+        fus = self._fusable(Q)
+        if fus is not None:
+            data = focus_intensity(fus[1], Q=Q, synth=(fus[0], fus[2]))
+        else:
+            data = focus_intensity(self.data, Q=Q)
         dx = pupil_sample_to_psf_sample(self.dx, data.shape[1], self.wavelength, efl)
         return RichData(data, dx, self.wavelength)
 

@@ -724,3 +724,37 @@ def test_fft_facade_numpy_semantics(pa):
     assert rel_max(got, O.focus(x, 1)) < TOL64
     real = rng.standard_normal((16, 16))
     assert rel_max(tonp(fft.fft2(real)), np.fft.fft2(real)) < TOL64
+
+
+def test_fused_pupil_synthesis(pa):
+    """Wavefront.from_amp_and_phase(...).focus / focus_intensity with the pupil synthesised inside the row pass
+    (PM_FLAG_SYNTH_INPUT, complex64): equals the oracle's from_amp_and_phase -> focus, for bool / float / no amplitude,
+    Q = 1 and 2, the folded (4096-row) and unfolded paths; materialising .data afterwards gives the same field as the
+    separate synthesis kernel; the lazy wavefront still behaves like an array holder."""
+    from prysm_amd.conf import config
+    P = pa.propagation
+    prec = config.precision
+    try:
+        config.precision = 32
+        rng = np.random.default_rng(12)
+        for n, Q in ((512, 1), (256, 2), (4096, 1)):
+            x, y = O.make_xy_grid(n, diameter=10)
+            r, _ = O.cart_to_polar(x, y)
+            opd = (O.hopkins_w040(r / 5, 800.0) + 30 * rng.standard_normal((n, n))).astype(np.float32)
+            for amp in (O.circle(5, r), rng.random((n, n)).astype(np.float32), None):
+                wf = P.Wavefront.from_amp_and_phase(amp, opd, 0.55, 10.0 / n)
+                if amp is not None:
+                    assert wf._fusable(Q) is not None
+                want = O.focus(O.from_amp_and_phase(np.ones((n, n)) if amp is None else amp, opd.astype(np.float64), 0.55), Q)
+                got = wf.focus(100.0, Q)
+                assert got.data.dtype == torch.complex64
+                assert rel_max(tonp(got), want) < 2 * TOL32
+                assert rel_max(tonp(wf.focus_intensity(100.0, Q)), O.intensity(want)) < 6 * TOL32
+                assert wf._data is None                      # nothing materialised so far
+                if n <= 512:
+                    field = tonp(wf.data)                    # now it is
+                    assert rel_max(field, O.from_amp_and_phase(np.ones((n, n)) if amp is None else amp, opd.astype(np.float64), 0.55)) < TOL32
+                    assert rel_max(tonp(wf.focus(100.0, Q)), want) < 2 * TOL32      # unfused path on the materialised data
+                    assert (wf * 2.0).data.shape == (n, n)
+    finally:
+        config.precision = prec
