@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--n', type=int, default=N_EDGE, help='transform edge (default 4096, the headline)')
     ap.add_argument('--dtype', default='c64', choices=['c64', 'c128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-poly', action='store_true', help='skip the polychromatic per-wavelength measurement (profiling runs)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget for the CPU baseline sample')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on one GPU)')
@@ -234,7 +235,7 @@ def main():
         dist.all_reduce(r, op=dist.ReduceOp.MAX)
         reduce_ms = float(r.item())
 
-    poly_ms = polychromatic_per_wavelength_ms(n, cdtype) if rank == 0 else 0.0
+    poly_ms = polychromatic_per_wavelength_ms(n, cdtype) if (rank == 0 and not args.no_poly) else 0.0
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
