@@ -267,7 +267,7 @@ def main():
                          'row_pass_ms': p1, 'column_pass_ms': p2,
                          'note': '2*N^2*s algorithmic bytes per pass / HIP-event duration of that pass, in sequence'},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only (the other ranks would just wait)
             line['cpu_baseline'] = cpu_baseline(n, cdtype, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
