@@ -103,6 +103,8 @@ Tuning& tuning() {
     return t;
 }
 
+int tuning_row_var_for_timing() { return tuning().row_var; }
+
 static AxisMap to_map(const pm_axis& a) { return AxisMap{int(a.n), int(a.len), int(a.off), int(a.shift)}; }
 
 static int check_axis(const pm_axis& a, const char* name) {

@@ -270,12 +270,14 @@ int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, 
     return int(hipGetLastError());
 }
 
+int tuning_row_var_for_timing();   // capi.hip: the row_var knob (timing builds only)
+
 // folded row pass (RowStoreFold): units are row PAIRS (i, i + M/2); complex64 / complex128 rows of 2048 .. 8192 points
-template <typename T, int LOGN>
+template <typename T, int LOGN, int KVAR = 4>
 int launch_fold_one(const RowLoadNat<T>& lp, const RowStoreFold<T>& sp, const cx<T>* tw, int npairs, int log_g, hipStream_t st,
                     int nbatch) {
     using C = typename RowCfgSel<T, LOGN, 4>::type;
-    auto kern = fft_kernel<C, false, 4, RowLoadNat<T>, RowStoreFold<T>>;
+    auto kern = fft_kernel<C, false, KVAR, RowLoadNat<T>, RowStoreFold<T>>;
     constexpr size_t LDSB = kernel_lds_bytes<C, false, 0>();
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
@@ -289,6 +291,14 @@ int launch_fold_one(const RowLoadNat<T>& lp, const RowStoreFold<T>& sp, const cx
 template <typename T>
 int launch_fold_impl(int logn, const RowLoadNat<T>& lp, const RowStoreFold<T>& sp, const cx<T>* tw, int npairs, int log_g,
                      hipStream_t st, int nbatch) {
+#ifdef PM_TIMING_VARIANTS   // row_var = 3 / 6 / 7 on the folded row pass (4096 points): memory only / arithmetic only / butterflies only
+    if (logn == 12 && (tuning_row_var_for_timing() == 3 || tuning_row_var_for_timing() == 6 || tuning_row_var_for_timing() == 7)) {
+        const int v = tuning_row_var_for_timing();
+        if (v == 3) return launch_fold_one<T, 12, 3>(lp, sp, tw, npairs, log_g, st, nbatch);
+        if (v == 6) return launch_fold_one<T, 12, 6>(lp, sp, tw, npairs, log_g, st, nbatch);
+        return launch_fold_one<T, 12, 7>(lp, sp, tw, npairs, log_g, st, nbatch);
+    }
+#endif
     switch (logn) {
         case 11: return launch_fold_one<T, 11>(lp, sp, tw, npairs, log_g, st, nbatch);
         case 12: return launch_fold_one<T, 12>(lp, sp, tw, npairs, log_g, st, nbatch);
