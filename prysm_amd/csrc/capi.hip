@@ -72,7 +72,7 @@ const cx<double>* twiddles_f64(int64_t n, int* err) { return table_get<double>(n
 static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     auto is = [&](const char* k) { return strlen(k) == klen && !strncmp(key, k, klen); };
     if (is("col_var")) t.col_var = v;
-    else if (is("log_k")) t.log_k = v > 3 ? 3 : v;   // < 0: auto
+    else if (is("log_k")) t.log_k = v > 12 ? 12 : v;   // < 0: auto; log2(N / tile width) makes the intermediate natural (row-major)
     else if (is("row_log_g")) t.row_log_g = v < 0 ? 0 : (v > 3 ? 3 : v);
     else if (is("row_var")) t.row_var = v;
     else if (is("gemm_bk")) t.gemm_bk = v;
@@ -104,6 +104,9 @@ Tuning& tuning() {
 }
 
 int tuning_row_var_for_timing() { return tuning().row_var; }
+
+// sibling group of column-pass workgroups: the tiles of one layout-tile row, at most 8
+static int sibling_log_g(int log_k) { return log_k < 1 ? 1 : (log_k > 3 ? 3 : log_k); }
 
 static AxisMap to_map(const pm_axis& a) { return AxisMap{int(a.n), int(a.len), int(a.off), int(a.shift)}; }
 
@@ -176,6 +179,9 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
         }
         p.tc = col_tile_width_for(d->dtype, p.fold ? p.logm - 1 : p.logm, tuning().col_var);
         p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 8192 ? 3 : (N >= 4096 ? 2 : 1));   // auto: >= 256 B pieces from 4096 columns
+        // folded 4096^2 complex64 (intermediate = 128 MiB, inside the Infinity Cache): 8 KiB row pieces measured 95.0 vs 97.8 us
+        // (profiles/r01/tune_log_k.log); every other size / precision measured best with the narrow tiles above
+        if (tuning().log_k < 0 && p.fold && d->dtype == PM_C64 && N == 4096 && M == 4096) p.log_k = 7;
         while (p.log_k > 0 && (N % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
         const int64_t tl = int64_t(p.tc) << p.log_k;
         const int64_t ntl = (N + tl - 1) / tl;
@@ -295,7 +301,7 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         cs.ay = AxisMap{H, int(d->out_y.len / 2), int(d->out_y.off / 2), int(d->out_y.shift / 2)};
         cs.bstride = d->out_ld;
         cs.ld = 2 * d->out_ld;
-        return launch_col_tiled<T>(p.logm - 1, tuning().col_var, cl, cs, tw, ntiles, (p.log_k > 1 ? p.log_k : 1), st, 2);
+        return launch_col_tiled<T>(p.logm - 1, tuning().col_var, cl, cs, tw, ntiles, sibling_log_g(p.log_k), st, 2);
     }
     if (p.logm >= 0) {
         const cx<T>* tw = twiddles<T>(M, &err);
@@ -303,7 +309,7 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         if (p.tc) {
             const int ntiles = int((N + p.tc - 1) / p.tc);
             ColLoadTiled<T> cl{W, rows, to_map(d->in_y), ntiles, p.log_k, wstride};
-            return launch_col_tiled<T>(p.logm, tuning().col_var, cl, cs, tw, ntiles, (p.log_k > 1 ? p.log_k : 1) | (tuning().col_skew << 8) | (tuning().col_spread << 16),
+            return launch_col_tiled<T>(p.logm, tuning().col_var, cl, cs, tw, ntiles, sibling_log_g(p.log_k) | (tuning().col_skew << 8) | (tuning().col_spread << 16),
                                        st, nb);
         }
         const int tc = col_tile_width_for(d->dtype, p.logm, tuning().col_var);
@@ -367,6 +373,8 @@ static bool plan_fused(const pm_fft2_desc* d, FusedPlan& p) {
     }
     p.tc = col_tile_width_for(d->dtype, p.fold ? p.logm - 1 : p.logm, 0);
     p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 8192 ? 3 : (N >= 4096 ? 2 : 1));
+    // folded 4096^2 complex64: 16 KiB row pieces measured 182.7 vs 188.7 us for the chain (see plan_fft2)
+    if (tuning().log_k < 0 && p.fold && d->dtype == PM_C64 && N == 4096 && M == 4096) p.log_k = 8;
     while (p.log_k > 0 && (N % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
     const int64_t tl = int64_t(p.tc) << p.log_k, ntl = (N + tl - 1) / tl;
     p.inplace = d->in_y.len == M;
@@ -415,7 +423,7 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
         MidMul<T> mm{d->mul_kind, d->mul_conj, reinterpret_cast<const cx<T>*>(d->mul), reinterpret_cast<const cx<T>*>(d->mul_x),
                      2 * d->mul_ld, int(N), d->mul_kind == PM_MUL_FULL ? d->mul_ld : 1, 0, 2};
         ColStoreTiled<T> cst{W1, H, ntiles, p.log_k, plane};
-        rc = launch_col_mul<T>(p.logm - 1, cl, mm, cst, twH, ntiles, p.log_k > 1 ? p.log_k : 1, st, 2);
+        rc = launch_col_mul<T>(p.logm - 1, cl, mm, cst, twH, ntiles, sibling_log_g(p.log_k), st, 2);
         if (rc) return rc;
         RowLoadFold<T> rl{W1, plane, H, ltl, twM, 1, 0};
         RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), int(M), 1, T(d->scale), 1, to_map(d->out_y), 0, H};
@@ -437,7 +445,7 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
     MidMul<T> mm{d->mul_kind, d->mul_conj, reinterpret_cast<const cx<T>*>(d->mul), reinterpret_cast<const cx<T>*>(d->mul_x),
                  d->mul_ld, int(N), d->mul_bstride, d->mul_x_bstride};
     ColStoreTiled<T> cst{W2, int(M), ntiles, p.log_k, wstride};
-    int rc = launch_col_mul<T>(p.logm, cl, mm, cst, twM, ntiles, p.log_k > 1 ? p.log_k : 1, st, nb);
+    int rc = launch_col_mul<T>(p.logm, cl, mm, cst, twM, ntiles, sibling_log_g(p.log_k), st, nb);
     if (rc) return rc;
     // pass C: inverse row transforms of the rows inside the output window -> natural output, scale applied here.
     // Sequence s is stored row s of W2 (= logical row s); the output row map rotates / crops it.
