@@ -98,3 +98,19 @@ def test_install_into_prysm_rebinds_and_restores():
     assert P.focus is orig_focus and F.MDFT is orig_mdft and P.Wavefront is orig_wf
     import prysm.mathops as PM
     assert not isinstance(PM.fft._srcmodule, mathops.FFTFacade)
+
+
+def test_small_host_helpers():
+    """Pure host arithmetic of the newer host code: norm scales of the fft facade, stack sizing of the polychromatic
+    driver, the auto choice between stacks and field-by-field."""
+    from prysm_amd.mathops import FFTFacade
+    from prysm_amd import polychromatic as pc
+    sc = FFTFacade._scale
+    assert sc(None, 64, False) == 1.0 and sc(None, 64, True) == 1 / 64
+    assert sc('ortho', 64, False) == sc('ortho', 64, True) == 0.125
+    assert sc('forward', 64, False) == 1 / 64 and sc('forward', 64, True) == 1.0
+    with pytest.raises(ValueError):
+        sc('nope', 4, False)
+    assert pc._fields_per_launch((512, 512), 8, 2) == 64                 # capped
+    assert pc._fields_per_launch((4096, 4096), 16, 1) == 2               # 1 GiB of stack / (256 MiB + 128 MiB)
+    assert pc.shard_bounds(64, 3, 8) == (24, 32) and pc.shard_bounds(7, 1, 2) == (4, 7)
