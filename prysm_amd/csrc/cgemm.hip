@@ -58,49 +58,68 @@ struct MfmaTraits<double> {
 
 // Staging of one operand tile (ROWS x BK complex elements, 256 threads, E = ROWS*BK/256 per thread).
 // KFAST: the k index is contiguous in memory (A stored M x K, or B stored N x K) -> lanes run along k.
-// Loads are UNCONDITIONAL (out-of-range coordinates are clamped to element 0 and zeroed by a select after the
-// load): bounds-checked branches made the compiler wait for every load separately (vmcnt(0) x 8 per K-tile,
-// i.e. the kernel ran at L2 latency); now the loads of a K-tile issue back to back and are first waited for
-// when they are written to LDS, after the MFMAs of the current tile.
+//
+// Everything per-thread is computed ONCE: the byte offset of each element from the (workgroup-uniform) base of the
+// current K-tile, and its LDS slot.  Per K-tile the base advances by a scalar add and the loads are
+// `global_load ... v_off, s[base]`; on interior tiles the registers go to LDS as they are.  (Measured with the
+// timing builds -DPM_GEMM_DBG: the MFMA loop alone runs the 512 x 2048 x 2048 product in 110 us; the previous staging
+// -- 64-bit pointer bumps, validity masks, select / conj multiplies, LDS address arithmetic, ~120 VALU instructions per
+// K-tile and thread -- cost another 46 us because VALU work beside MFMAs steals their issue slots.)
+// Conjugations are NOT applied here: they are folded into the sign of the imaginary parts at the MFMA operands and
+// in the epilogue.  Out-of-range rows are clamped to the last valid row and zeroed when stored (edge tiles only);
+// the K tail (last tile of a slab) takes the masked path too.
 template <typename T, int ROWS, int BK, bool KFAST>
 struct Stager {
     static constexpr int E = ROWS * BK / 256;
-    const cx<T>* p[E];      // address of this thread's element of the current K-tile
-    bool rok[E];            // row (m or n index) in range
-    int kk[E], rr[E];       // coordinates inside the tile
-    int64_t kstep;          // pointer advance per K-tile
-    __device__ __forceinline__ void init(const cx<T>* X, int64_t ld, int64_t r0, int64_t R, int64_t k0, int tid) {
+    unsigned boff[E];       // byte offset from the base of the K-tile (row block r0, first k of the tile)
+    int lds[E];             // element slot inside one LDS buffer: kk * LD_S + rr
+    int kk[E];              // k inside the tile (K-tail masking)
+    unsigned rowmask;       // bit s: the row of element s exists
+    __device__ __forceinline__ void init(int64_t ld, int64_t r0, int64_t R, int tid, int ld_s) {
+        rowmask = 0;
 #pragma unroll
         for (int s = 0; s < E; ++s) {
             const int e = tid + s * 256;
             kk[s] = KFAST ? e % BK : e / ROWS;
-            rr[s] = KFAST ? e / BK : e % ROWS;
-            const int64_t r = r0 + rr[s];
-            rok[s] = r < R;
-            const int64_t rc = rok[s] ? r : 0;
-            p[s] = KFAST ? X + rc * ld + (k0 + kk[s]) : X + (k0 + kk[s]) * ld + rc;
+            const int rr = KFAST ? e / BK : e % ROWS;
+            const bool ok = r0 + rr < R;
+            rowmask |= ok ? (1u << s) : 0u;
+            const int64_t rc = ok ? rr : (R - 1 - r0);        // clamp into the matrix (R > r0 always)
+            const int64_t off = KFAST ? rc * ld + kk[s] : int64_t(kk[s]) * ld + rc;
+            boff[s] = unsigned(off * int64_t(sizeof(cx<T>)));
+            lds[s] = kk[s] * ld_s + rr;
         }
-        kstep = KFAST ? BK : int64_t(BK) * ld;
     }
-    // k0: first k of the tile being fetched; kend: one past the last valid k; X: base (for clamping)
-    // issue the loads only; `ok` remembers which of them were real.  The zeroing / conjugation happens in
-    // finish(), called when the registers are written to LDS AFTER the MFMAs of the current tile, so the first
-    // use of the loaded data (and the vmcnt wait the compiler puts in front of it) sits behind the matrix work.
-    __device__ __forceinline__ void fetch(cx<T> (&reg)[E], unsigned& okmask, const cx<T>* X, int64_t k0, int64_t kend) {
-        okmask = 0;
+    // base of a K-tile: first element of row block r0 at k = k0 (uniform over the workgroup)
+    static __device__ __forceinline__ const char* tile_base(const cx<T>* X, int64_t ld, int64_t r0, int64_t k0) {
+        return reinterpret_cast<const char*>(KFAST ? X + r0 * ld + k0 : X + k0 * ld + r0);
+    }
+    // interior tile: E unconditional loads from uniform base + per-thread offset
+    __device__ __forceinline__ void fetch(cx<T> (&reg)[E], const char* base) const {
+#pragma unroll
+        for (int s = 0; s < E; ++s) reg[s] = *reinterpret_cast<const cx<T>*>(base + boff[s]);
+    }
+    // K tail: elements past kend read the tile's first k instead (always inside the matrix) and are zeroed at the store
+    __device__ __forceinline__ void fetch_tail(cx<T> (&reg)[E], const char* base, int64_t ld, int krem) const {
 #pragma unroll
         for (int s = 0; s < E; ++s) {
-            const bool ok = rok[s] && (k0 + kk[s] < kend);
-            okmask |= ok ? (1u << s) : 0u;
-            reg[s] = *(ok ? p[s] : X);
-            p[s] += kstep;
+            const unsigned back = unsigned((KFAST ? int64_t(kk[s]) : int64_t(kk[s]) * ld) * int64_t(sizeof(cx<T>)));
+            reg[s] = *reinterpret_cast<const cx<T>*>(base + (kk[s] < krem ? boff[s] : boff[s] - back));
         }
     }
-    __device__ __forceinline__ cx<T> finish(const cx<T> (&reg)[E], unsigned okmask, int s, T conj_sign) const {
-        const bool ok = (okmask >> s) & 1u;
-        return {ok ? reg[s].x : T(0), ok ? reg[s].y * conj_sign : T(0)};
+    __device__ __forceinline__ void store(cx<T>* tile, const cx<T> (&reg)[E]) const {
+#pragma unroll
+        for (int s = 0; s < E; ++s) tile[lds[s]] = reg[s];
+    }
+    __device__ __forceinline__ void store_masked(cx<T>* tile, const cx<T> (&reg)[E], int krem) const {
+#pragma unroll
+        for (int s = 0; s < E; ++s) {
+            const bool ok = ((rowmask >> s) & 1u) && kk[s] < krem;
+            tile[lds[s]] = ok ? reg[s] : cx<T>{T(0), T(0)};
+        }
     }
 };
+
 
 template <typename T, int BM, int BN, int BK, bool AKF, bool BKF, bool M3>
 __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int64_t M, int64_t N, int64_t K, int64_t ksplit,
@@ -148,66 +167,112 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
 
     SA stA;
     SB stB;
-    stA.init(A, lda, m0, M, kbeg, tid);
-    stB.init(B, ldb, n0, N, kbeg, tid);
+    stA.init(lda, m0, M, tid, LDA_S);
+    stB.init(ldb, n0, N, tid, LDB_S);
     cx<T> ra[SA::E], rb[SB::E];
-    unsigned oka = 0, okb = 0;
+    const bool rows_full = (m0 + BM <= M) && (n0 + BN <= N);     // uniform: no row / column of the tile is out of range
+    cx<T>* const As0 = &As[0][0][0];
+    cx<T>* const Bs0 = &Bs[0][0][0];
+    constexpr int ABUF = BK * LDA_S, BBUF = BK * LDB_S;
 
-    auto s_store = [&](int buf) {
-#pragma unroll
-        for (int s = 0; s < SA::E; ++s) As[buf][stA.kk[s]][stA.rr[s]] = stA.finish(ra, oka, s, sa);
-#pragma unroll
-        for (int s = 0; s < SB::E; ++s) Bs[buf][stB.kk[s]][stB.rr[s]] = stB.finish(rb, okb, s, sb);
+    // fetch the K-tile starting at k (uniform) into registers; store the registers into LDS buffer `buf`
+    auto fetch_tile = [&](int64_t k) {
+        const char* ba = SA::tile_base(A, lda, m0, k);
+        const char* bb = SB::tile_base(B, ldb, n0, k);
+        if (k + BK <= kend) {
+            stA.fetch(ra, ba);
+            stB.fetch(rb, bb);
+        } else {
+            stA.fetch_tail(ra, ba, lda, int(kend - k));
+            stB.fetch_tail(rb, bb, ldb, int(kend - k));
+        }
+    };
+    auto store_tile = [&](int buf, int64_t k) {
+        if (rows_full && k + BK <= kend) {
+            stA.store(As0 + buf * ABUF, ra);
+            stB.store(Bs0 + buf * BBUF, rb);
+        } else {
+            const int krem = int(kend - k < BK ? kend - k : BK);
+            stA.store_masked(As0 + buf * ABUF, ra, krem);
+            stB.store_masked(Bs0 + buf * BBUF, rb, krem);
+        }
     };
 
     int buf = 0;
     if (kbeg < kend) {
-        stA.fetch(ra, oka, A, kbeg, kend);
-        stB.fetch(rb, okb, B, kbeg, kend);
-        s_store(0);
+        fetch_tile(kbeg);
+        store_tile(0, kbeg);
     }
     __syncthreads();
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
-        if (more) {   // prefetch the next K-tile into registers: in flight under the MFMAs of this tile
-            stA.fetch(ra, oka, A, k0 + BK, kend);
-            stB.fetch(rb, okb, B, k0 + BK, kend);
-        }
+#ifndef PM_GEMM_DBG
+#define PM_GEMM_DBG 0   // timing builds (wrong results): 1 = no global loads / LDS staging in the loop, 2 = also no LDS operand
+                        // reads, 3 = global loads but no LDS stores, 4 = LDS stores but no global loads
+#endif
+        if (more && (PM_GEMM_DBG == 0 || PM_GEMM_DBG == 3)) fetch_tile(k0 + BK);   // next K-tile into registers: in flight under the MFMAs of this one
+        // operand fragments of k-step n + 1 are read from LDS BEFORE the MFMAs of k-step n are issued (register double
+        // buffer), so the LDS latency -- longer while other workgroups stage their tiles -- hides under matrix work
+        cx<T> a[2][TI], b[2][TJ];
+        auto read_frags = [&](int slot, int ks) {
+            const int kk = ks + MT::op_k(lane);
+            if (PM_GEMM_DBG == 2) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) a[slot][i] = {T(lane + ks), T(i + 1)};
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) b[slot][j] = {T(ks + 1), T(lane + j)};
+            } else {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) a[slot][i] = As[buf][kk][wr * WM + i * TM + MT::op_row(lane)];
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) b[slot][j] = Bs[buf][kk][wc * WN + j * TM + MT::op_row(lane)];
+            }
+        };
+        read_frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < BK; ks += KS) {
-            const int kk = ks + MT::op_k(lane);
-            cx<T> a[TI], b[TJ];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) a[i] = As[buf][kk][wr * WM + i * TM + MT::op_row(lane)];
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) b[j] = Bs[buf][kk][wc * WN + j * TM + MT::op_row(lane)];
+            const int cur = (ks / KS) & 1;
+            if (ks + KS < BK) read_frags(cur ^ 1, ks + KS);
+            // conjugations: op(A) = Ar + i sa Ai, op(B) = Br + i sb Bi with sa, sb = +-1 (uniform)
             if constexpr (M3) {
+                // P1 = Ar Br, P2 = Ai Bi (raw), P3 = (Ar + sa Ai)(Br + sb Bi); Cr = P1 - sa sb P2, Ci = P3 - P1 - sa sb P2
                 T as[TI], bs[TJ];
 #pragma unroll
-                for (int i = 0; i < TI; ++i) as[i] = a[i].x + a[i].y;
+                for (int i = 0; i < TI; ++i) as[i] = a[cur][i].x + sa * a[cur][i].y;
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) bs[j] = b[j].x + b[j].y;
+                for (int j = 0; j < TJ; ++j) bs[j] = b[cur][j].x + sb * b[cur][j].y;
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) {
-                        acc_r[i][j] = MT::mfma(a[i].x, b[j].x, acc_r[i][j]);
-                        acc_i[i][j] = MT::mfma(a[i].y, b[j].y, acc_i[i][j]);
+                        acc_r[i][j] = MT::mfma(a[cur][i].x, b[cur][j].x, acc_r[i][j]);
+                        acc_i[i][j] = MT::mfma(a[cur][i].y, b[cur][j].y, acc_i[i][j]);
                         acc_3[i][j] = MT::mfma(as[i], bs[j], acc_3[i][j]);
                     }
             } else {
+                T ay[TI], by[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) ay[i] = sa * a[cur][i].y;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) by[j] = sb * b[cur][j].y;
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) {
-                        acc_r[i][j] = MT::mfma(a[i].x, b[j].x, acc_r[i][j]);
-                        acc_i[i][j] = MT::mfma(a[i].x, b[j].y, acc_i[i][j]);
-                        acc_r[i][j] = MT::mfma(-a[i].y, b[j].y, acc_r[i][j]);
-                        acc_i[i][j] = MT::mfma(a[i].y, b[j].x, acc_i[i][j]);
+                        acc_r[i][j] = MT::mfma(a[cur][i].x, b[cur][j].x, acc_r[i][j]);
+                        acc_i[i][j] = MT::mfma(a[cur][i].x, by[j], acc_i[i][j]);
+                        acc_r[i][j] = MT::mfma(-ay[i], by[j], acc_r[i][j]);
+                        acc_i[i][j] = MT::mfma(ay[i], b[cur][j].x, acc_i[i][j]);
                     }
             }
         }
-        if (more) s_store(buf ^ 1);
+        if (more && (PM_GEMM_DBG == 0 || PM_GEMM_DBG == 4)) store_tile(buf ^ 1, k0 + BK);
+        if (PM_GEMM_DBG == 3 && more) {   // keep the loads alive without the LDS stores
+            T sum = T(0);
+#pragma unroll
+            for (int s_ = 0; s_ < SA::E; ++s_) sum += ra[s_].x + rb[s_].y;
+            if (sum == T(-12345.5)) As0[tid] = {sum, sum};
+        }
         __syncthreads();
         buf ^= 1;
     }
@@ -224,7 +289,7 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
                 const int64_t col = n0 + wc * WN + j * TM + MT::col_of(lane);
                 T cr = acc_r[i][j][r], ci = acc_i[i][j][r];
                 if constexpr (M3) {
-                    const T p1 = cr, p2 = ci;
+                    const T p1 = cr, p2 = sa * sb * ci;
                     cr = p1 - p2;
                     ci = acc_3[i][j][r] - p1 - p2;
                 }
@@ -363,6 +428,8 @@ int pm_cgemm(int32_t dtype, int32_t opA, int32_t opB, int64_t M, int64_t N, int6
     if (!A || !B || !C) return fail(PM_ERR_ARG, "pm_cgemm: null buffer");
     if (M < 0 || N < 0 || K < 0 || opA < 0 || opA > 3 || opB < 0 || opB > 3) return fail(PM_ERR_ARG, "pm_cgemm: bad argument");
     if (M == 0 || N == 0) return 0;
+    if (lda >= (int64_t(1) << 22) || ldb >= (int64_t(1) << 22))   // per-thread 32-bit byte offsets inside a K-tile
+        return fail(PM_ERR_UNSUPPORTED, "pm_cgemm: leading dimensions of 2^22 elements or more are not supported");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == PM_C64)
         return cgemm_ws<float>(opA, opB, M, N, K, alpha, (const cx<float>*)A, lda, (const cx<float>*)B, ldb, (cx<float>*)C, ldc,

@@ -867,6 +867,12 @@ int main(int argc, char** argv) {
         calibrate();
         return 0;
     }
+    if (mode == "gemmk") {   // time against K: per-iteration cost and fixed overhead of the config-4 GEMM
+        for (int64_t K : {256, 512, 1024, 2048, 4096, 8192}) bench_cgemm<float>(512, 2048, K, 0);
+        pm_set_tuning("gemm_min_wgs", 1);   // no split-K
+        for (int64_t K : {512, 2048, 8192}) bench_cgemm<float>(512, 2048, K, 0);
+        return 0;
+    }
     if (mode == "gemmprof") {   // the large config-4 GEMM only (PMC passes)
         bench_cgemm<float>(512, 2048, 2048, 0);
         return 0;
