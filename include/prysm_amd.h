@@ -218,7 +218,8 @@ int pm_mdft_basis(int32_t dtype, int64_t M, int64_t N, const void* f, const void
 /* C (M x N) = alpha * opA(A) (M x K) @ opB(B) (K x N), complex, on the MFMA matrix cores.
  *   opA: 0 = A, 1 = conj(A), 2 = A^T, 3 = A^H     (A stored M x K for 0/1, K x M for 2/3)
  *   opB: likewise                                   (B stored K x N for 0/1, N x K for 2/3)
- * The two GEMMs of fttools.MDFT.__call__ / .adjoint (prysm/fttools.py:201-228). */
+ * The two GEMMs of fttools.MDFT.__call__ / .adjoint (prysm/fttools.py:201-228).
+ * Leading dimensions must be below 2^22 elements (PM_ERR_UNSUPPORTED otherwise). */
 int pm_cgemm(int32_t dtype, int32_t opA, int32_t opB, int64_t M, int64_t N, int64_t K, double alpha,
              const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, void* workspace,
              size_t workspace_bytes, void* stream);
