@@ -39,8 +39,14 @@ def array_to_true_numpy(*args):
             out.append(arg.detach().cpu().numpy())
         elif hasattr(arg, 'get'):
             out.append(arg.get())
-        else:
+        elif isinstance(getattr(arg, 'data', None), (torch.Tensor, _np.ndarray)):
+            # a Wavefront / RichData: convert its array.  (numpy would otherwise wrap the object in a 0-d object array
+            # and every later arithmetic op would call the object's operators once per element of the other operand.)
+            out.append(array_to_true_numpy(arg.data))
+        elif isinstance(arg, (list, tuple)):
             out.append(_np.array(arg))
+        else:
+            raise TypeError(f'cannot convert {type(arg).__name__} to a numpy array')
     return out[0] if len(out) == 1 else out
 
 

@@ -83,6 +83,11 @@ class Wavefront:
         self._data = value
         self._synth = None
 
+    def __array__(self, dtype=None, copy=None):
+        """numpy conversion = the field (keeps np.asarray(wavefront) from building an object array)."""
+        a = self.data.detach().cpu().numpy() if isinstance(self.data, torch.Tensor) else np.asarray(self.data)
+        return a.astype(dtype) if dtype is not None else a
+
     def _fusable(self, Q):
         """(amp, opd, k) when the pupil can be synthesised inside the FFT (not yet materialised, complex64, power-of-two
         padded width), else None."""

@@ -114,3 +114,17 @@ def test_small_host_helpers():
     assert pc._fields_per_launch((512, 512), 8, 2) == 64                 # capped
     assert pc._fields_per_launch((4096, 4096), 16, 1) == 2               # 1 GiB of stack / (256 MiB + 128 MiB)
     assert pc.shard_bounds(64, 3, 8) == (24, 32) and pc.shard_bounds(7, 1, 2) == (4, 7)
+
+
+def test_array_to_true_numpy_unwraps_containers():
+    """Wavefront / RichData convert through their array (never as a 0-d object array); unknown objects are refused."""
+    import torch
+    from prysm_amd.mathops import array_to_true_numpy
+    from prysm_amd._richdata import RichData
+    t = torch.arange(6, dtype=torch.float64).reshape(2, 3)
+    rd = RichData(t, 1.0, 0.5)
+    out = array_to_true_numpy(rd)
+    assert isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == (2, 3)
+    assert array_to_true_numpy(3.0) == 3.0 and array_to_true_numpy([1, 2]).tolist() == [1, 2]
+    with pytest.raises(TypeError):
+        array_to_true_numpy(object())
