@@ -58,6 +58,8 @@ def _synth_args(amplitude, phase):
 class Wavefront:
     """(Complex) representation of a wavefront (wavefront.py:35-56)."""
 
+    __array_ufunc__ = None   # numpy_array <op> wavefront defers to the reflected operators below (one device op, not one per element)
+
     def __init__(self, cmplx_field, wavelength, dx, space='pupil'):
         """cmplx_field: array (numpy is uploaded); wavelength um; dx mm (pupil) or um (psf)."""
         self._synth = None
