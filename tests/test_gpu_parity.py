@@ -758,3 +758,19 @@ def test_fused_pupil_synthesis(pa):
                     assert (wf * 2.0).data.shape == (n, n)
     finally:
         config.precision = prec
+
+
+def test_numpy_operand_defers_to_wavefront_operators(pa):
+    """numpy_array <op> Wavefront must be ONE device operation through the reflected operator (and np.asarray(wf) the
+    field itself), never numpy's elementwise object loop."""
+    P = pa.propagation
+    rng = np.random.default_rng(3)
+    x = crandn(rng, (32, 32))
+    m = rng.standard_normal((32, 32))
+    wf = P.Wavefront(x, 0.5, 1.0)
+    assert rel_max(tonp((m * wf).data), m * x) < TOL64
+    assert rel_max(tonp((wf * m).data), m * x) < TOL64
+    assert rel_max(tonp((m + wf).data), m + x) < TOL64
+    assert rel_max(np.asarray(wf), x) < TOL64
+    from prysm_amd.mathops import array_to_true_numpy
+    assert rel_max(array_to_true_numpy(wf), x) < TOL64
