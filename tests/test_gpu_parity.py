@@ -774,3 +774,21 @@ def test_numpy_operand_defers_to_wavefront_operators(pa):
     assert rel_max(np.asarray(wf), x) < TOL64
     from prysm_amd.mathops import array_to_true_numpy
     assert rel_max(array_to_true_numpy(wf), x) < TOL64
+
+
+def test_randomised_differential_fuzz(pa):
+    """tools/fuzz_fft2.py: random sizes / windows / rotations / crops / input kinds / stacks / epilogues / multipliers /
+    precisions / fold settings of pm_fft2 and the fused chain against numpy (a fixed seed keeps it reproducible)."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_fft2.py')
+    spec = importlib.util.spec_from_file_location('fuzz_fft2', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    try:
+        sys.argv = ['fuzz_fft2.py', '60', '2026']
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv

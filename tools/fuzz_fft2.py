@@ -1,0 +1,183 @@
+"""Randomised differential test of pm_fft2 / pm_fft2_mul_ifft2 through prysm_amd._ops against numpy on the host:
+random sizes (engine and direct-DFT lengths), windows, rotations, crops, real / complex / synthesised input, stacks,
+epilogues, multipliers, precisions, with and without the fold.  Usage: python tools/fuzz_fft2.py [ncases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from prysm_amd import _ops, _lib as L
+
+def ref_fft2(x, M, N, in_off, in_shift, direction, scale):
+    P = np.zeros((M, N), dtype=np.complex128)
+    m, n = x.shape
+    # logical element i reads mem[(i + shift) mod n - off]
+    for ax, (size, ln, off, sh) in enumerate(((M, m, in_off[0], in_shift[0]), (N, n, in_off[1], in_shift[1]))):
+        pass
+    iy = (np.arange(M) + in_shift[0]) % M - in_off[0]
+    ix = (np.arange(N) + in_shift[1]) % N - in_off[1]
+    oky = (iy >= 0) & (iy < m)
+    okx = (ix >= 0) & (ix < n)
+    P[np.ix_(oky, okx)] = x[np.ix_(iy[oky], ix[okx])]
+    F = np.fft.fft2(P) if direction < 0 else np.fft.ifft2(P) * (M * N)
+    return F * scale
+
+def window(F, out_shape, out_off, out_shift):
+    M, N = F.shape
+    om, on = out_shape
+    out = np.zeros((om, on), dtype=F.dtype)
+    ky = (np.arange(M) + out_shift[0]) % M - out_off[0]
+    kx = (np.arange(N) + out_shift[1]) % N - out_off[1]
+    oky = (ky >= 0) & (ky < om)
+    okx = (kx >= 0) & (kx < on)
+    out[np.ix_(ky[oky], kx[okx])] = F[np.ix_(np.nonzero(oky)[0], np.nonzero(okx)[0])]
+    return out
+
+def fuzz_fused(ncases, rng, lib):
+    """window(ifft2(fft2(pad(x)) * H)) * scale: fused 3-pass chain (powers of two) or two-call composition."""
+    sizes = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 12, 20, 100]
+    nfail, worst = 0, 0.0
+    for case in range(ncases):
+        big = rng.random() < 0.2
+        M = int(rng.choice([2048, 4096] if big else sizes))
+        N = int(rng.choice([2048, 4096] if big else sizes))
+        if M * N > (1 << 23):
+            N = 2048
+        cdt = np.complex64 if rng.random() < 0.5 else np.complex128
+        m = M if rng.random() < 0.6 else int(rng.integers(1, M + 1))
+        n = N if rng.random() < 0.6 else int(rng.integers(1, N + 1))
+        in_off = (int(rng.integers(0, M - m + 1)), int(rng.integers(0, N - n + 1)))
+        sh = lambda s_: int(rng.choice([0, s_ // 2]))
+        in_shift = (sh(M), sh(N))
+        out_shift = (sh(M), sh(N))
+        om = M if rng.random() < 0.6 else int(rng.integers(1, M + 1))
+        on = N if rng.random() < 0.6 else int(rng.integers(1, N + 1))
+        out_off = (int(rng.integers(0, M - om + 1)), int(rng.integers(0, N - on + 1)))
+        B = int(rng.choice([0, 0, 2, 3])) if M * N <= (1 << 18) else 0
+        sep = rng.random() < 0.5
+        per_field = bool(B) and rng.random() < 0.5
+        conj = rng.random() < 0.4
+        fold = int(rng.choice([-1, 0, 1]))
+        lib.pm_set_tuning(b'fold', fold)
+        shp = (B, m, n) if B else (m, n)
+        x = (rng.standard_normal(shp) + 1j * rng.standard_normal(shp)).astype(cdt)
+        nb = B if per_field else 1
+        if sep:
+            hy = (rng.standard_normal((nb, M)) + 1j * rng.standard_normal((nb, M))).astype(cdt)
+            hx = (rng.standard_normal((nb, N)) + 1j * rng.standard_normal((nb, N))).astype(cdt)
+            H = hy[:, :, None] * hx[:, None, :]
+            mul = torch.from_numpy(hy if per_field else hy[0]).cuda()
+            mul_x = torch.from_numpy(hx if per_field else hx[0]).cuda()
+        else:
+            H = (rng.standard_normal((nb, M, N)) + 1j * rng.standard_normal((nb, M, N))).astype(cdt)
+            mul = torch.from_numpy(H if per_field else H[0]).cuda()
+            mul_x = None
+        scale = 1.0 / (M * N)
+        try:
+            got = _ops.fft2_mul_ifft2(torch.from_numpy(x).cuda(), scale=scale, mul=mul, mul_x=mul_x, mul_conj=conj, shape=(M, N),
+                                      in_off=in_off, in_shift=in_shift, out_shape=(om, on), out_off=out_off,
+                                      out_shift=out_shift).cpu().numpy()
+        except Exception as exc:
+            print('fused case', case, 'EXC', repr(exc)[:200], (M, N, m, n, cdt.__name__, B, sep, per_field, fold))
+            nfail += 1
+            continue
+        fields = x if B else x[None]
+        err = 0.0
+        for b in range(fields.shape[0]):
+            F = ref_fft2(fields[b].astype(np.complex128), M, N, in_off, in_shift, -1, 1.0)
+            h = H[b if per_field else 0].astype(np.complex128)
+            G = np.fft.ifft2(F * (np.conj(h) if conj else h)) * (M * N) * scale
+            want = window(G, (om, on), out_off, out_shift)
+            g = got[b] if B else got
+            err = max(err, float(np.abs(g - want).max() / max(np.abs(want).max(), 1e-30)))
+        tol = 1e-4 if cdt == np.complex64 else 1e-10
+        worst = max(worst, err / tol)
+        if not err < tol:
+            nfail += 1
+            print('fused case', case, 'FAIL err', err, (M, N, m, n, in_off, in_shift, (om, on), out_off, out_shift, cdt.__name__, B, sep, per_field, conj, fold))
+    lib.pm_set_tuning(b'fold', -1)
+    print(f'fuzz_fused: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
+    return nfail
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    lib = L.load()
+    sizes = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 3, 5, 9, 12, 20, 36, 100]
+    worst = 0.0
+    nfail = 0
+    for case in range(ncases):
+        big = rng.random() < 0.25
+        M = int(rng.choice([2048, 4096, 8192] if big else sizes))
+        N = int(rng.choice([2048, 4096] if big else sizes))
+        if M * N > (1 << 23):
+            N = 2048 if M == 8192 else N
+            M = min(M, 4096) if N == 4096 else M
+        cdt = np.complex64 if rng.random() < 0.5 else np.complex128
+        rdt = np.float32 if cdt == np.complex64 else np.float64
+        m = M if rng.random() < 0.6 else int(rng.integers(1, M + 1))
+        n = N if rng.random() < 0.6 else int(rng.integers(1, N + 1))
+        in_off = (int(rng.integers(0, M - m + 1)), int(rng.integers(0, N - n + 1)))
+        shift = lambda s: int(rng.choice([0, s // 2, int(rng.integers(0, s))]))
+        in_shift = (shift(M), shift(N))
+        out_shift = (shift(M), shift(N))
+        om = M if rng.random() < 0.6 else int(rng.integers(1, M + 1))
+        on = N if rng.random() < 0.6 else int(rng.integers(1, N + 1))
+        out_off = (int(rng.integers(0, M - om + 1)), int(rng.integers(0, N - on + 1)))
+        direction = -1 if rng.random() < 0.6 else +1
+        kind = rng.choice(['complex', 'real', 'synth']) if direction < 0 else 'complex'
+        B = int(rng.choice([0, 0, 0, 2, 3])) if M * N <= (1 << 20) else 0
+        epi = int(rng.choice([0, 0, 1]))
+        fold = int(rng.choice([-1, 0, 1]))
+        lib.pm_set_tuning(b'fold', fold)
+        scale = float(rng.choice([1.0, 1.0 / np.sqrt(M * N)]))
+        shp = (B, m, n) if B else (m, n)
+        amp = None
+        if kind == 'complex':
+            x = (rng.standard_normal(shp) + 1j * rng.standard_normal(shp)).astype(cdt)
+            xs = x
+        elif kind == 'real':
+            x = rng.standard_normal(shp).astype(rdt)
+            xs = x.astype(cdt)
+        else:
+            if cdt != np.complex64 or B or (N & (N - 1)) or N < 2 or N > 8192:
+                kind = 'real'
+                x = rng.standard_normal(shp).astype(rdt)
+                xs = x.astype(cdt)
+            else:
+                x = (rng.standard_normal(shp) * 300).astype(np.float32)
+                amp = rng.random(shp).astype(np.float32) if rng.random() < 0.7 else None
+                k = 2 * np.pi / 0.55 / 1e3
+                xs = ((1 if amp is None else amp.astype(np.float64)) * np.exp(1j * k * x.astype(np.float64)))
+        xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        kw = dict(direction=direction, scale=scale, shape=(M, N), in_off=in_off, in_shift=in_shift, out_shape=(om, on),
+                  out_off=out_off, out_shift=out_shift, epilogue=epi)
+        if kind == 'synth':
+            kw['synth'] = (None if amp is None else torch.from_numpy(amp).cuda(), k)
+        try:
+            got = _ops.fft2(xd, **kw).cpu().numpy()
+        except Exception as exc:
+            print('case', case, 'EXC', repr(exc)[:200], (M, N, m, n, cdt.__name__, kind, B, fold))
+            nfail += 1
+            continue
+        fields = xs if B else xs[None]
+        err = 0.0
+        for b in range(fields.shape[0]):
+            F = ref_fft2(fields[b].astype(np.complex128), M, N, in_off, in_shift, direction, scale)
+            W = window(F, (om, on), out_off, out_shift)
+            want = (W.real ** 2 + W.imag ** 2) if epi else W
+            g = got[b] if B else got
+            den = max(np.abs(want).max(), 1e-30)
+            err = max(err, float(np.abs(g - want).max() / den))
+        tol = (3e-5 if cdt == np.complex64 else 1e-10) * (4 if epi else 1)
+        ok = err < tol
+        worst = max(worst, err / tol)
+        if not ok:
+            nfail += 1
+            print('case', case, 'FAIL err', err, (M, N, m, n, in_off, in_shift, (om, on), out_off, out_shift, direction, cdt.__name__, kind, B, epi, fold))
+    lib.pm_set_tuning(b'fold', -1)
+    print(f'fuzz_fft2: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
+    nfail += fuzz_fused(max(20, ncases // 2), rng, lib)
+    return 1 if nfail else 0
+
+if __name__ == '__main__':
+    sys.exit(main())
