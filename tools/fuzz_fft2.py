@@ -98,6 +98,45 @@ def fuzz_fused(ncases, rng, lib):
     return nfail
 
 
+def fuzz_gemm(ncases, rng, lib):
+    """alpha * op(A) @ op(B) for every op combination, ragged sizes (edge tiles, K tails, split-K and unsplit), strided views."""
+    nfail, worst = 0, 0.0
+    opf = {0: lambda z: z, 1: np.conj, 2: lambda z: z.T, 3: lambda z: z.conj().T}
+    for case in range(ncases):
+        big = rng.random() < 0.2
+        M, N, K = (int(rng.choice([64, 128, 512, 1000])), int(rng.choice([64, 300, 2048])), int(rng.choice([512, 2048, 3000]))) if big else \
+                  (int(rng.integers(1, 200)), int(rng.integers(1, 200)), int(rng.integers(1, 300)))
+        cdt = np.complex64 if rng.random() < 0.5 else np.complex128
+        opA, opB = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        alpha = float(rng.choice([1.0, 0.37]))
+        lib.pm_set_tuning(b'gemm_min_wgs', int(rng.choice([1, 1024])))
+        lib.pm_set_tuning(b'gemm_3m', int(rng.choice([0, 1])))
+        pad = int(rng.choice([0, 0, 3]))       # leading dimension larger than the row
+        sa = (K, M) if opA & 2 else (M, K)
+        sb = (N, K) if opB & 2 else (K, N)
+        A = (rng.standard_normal((sa[0], sa[1] + pad)) + 1j * rng.standard_normal((sa[0], sa[1] + pad))).astype(cdt)
+        B = (rng.standard_normal((sb[0], sb[1] + pad)) + 1j * rng.standard_normal((sb[0], sb[1] + pad))).astype(cdt)
+        Ad = torch.from_numpy(A).cuda()[:, :sa[1]]
+        Bd = torch.from_numpy(B).cuda()[:, :sb[1]]
+        try:
+            got = _ops.cgemm(Ad, Bd, opA, opB, alpha).cpu().numpy()
+        except Exception as exc:
+            print('gemm case', case, 'EXC', repr(exc)[:200], (M, N, K, opA, opB, cdt.__name__))
+            nfail += 1
+            continue
+        want = alpha * (opf[opA](A[:, :sa[1]].astype(np.complex128)) @ opf[opB](B[:, :sb[1]].astype(np.complex128)))
+        err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+        tol = 5e-5 if cdt == np.complex64 else 1e-12
+        worst = max(worst, err / tol)
+        if not err < tol:
+            nfail += 1
+            print('gemm case', case, 'FAIL err', err, (M, N, K, opA, opB, cdt.__name__, pad))
+    lib.pm_set_tuning(b'gemm_min_wgs', 1024)
+    lib.pm_set_tuning(b'gemm_3m', 1)
+    print(f'fuzz_gemm: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
+    return nfail
+
+
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -177,6 +216,7 @@ def main():
     lib.pm_set_tuning(b'fold', -1)
     print(f'fuzz_fft2: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
     nfail += fuzz_fused(max(20, ncases // 2), rng, lib)
+    nfail += fuzz_gemm(max(20, ncases // 2), rng, lib)
     return 1 if nfail else 0
 
 if __name__ == '__main__':
