@@ -222,6 +222,10 @@ static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out, int logm_t
     if (d->epilogue == PM_EPI_NONE && sizeof(T) == 4)
         vec = (d->out_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (d->out_bstride % 2 == 0);
     cs.vec_ok = vec ? 1 : 0;
+    // bit 1: pairs of REAL outputs (the |.|^2 epilogues of the two-column complex64 threads) may go out as 8-byte accesses
+    if (d->epilogue != PM_EPI_NONE && (d->out_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % (2 * sizeof(T)) == 0) &&
+        (d->out_bstride % 2 == 0))
+        cs.vec_ok |= 2;
     const size_t out_bytes = size_t(d->batch > 1 ? d->batch : 1) * size_t(d->out_y.len) * size_t(d->out_x.len) *
                              (d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T));
     // streaming stores only help when a workgroup writes whole 64 B pieces; on the 32 B pieces of 8192-point

@@ -742,21 +742,41 @@ PM_HD void store_fast(const ColStoreNat<typename C::T>& p, int tile, ThreadPos p
     } else {
         T* base = reinterpret_cast<T*>(p.dst) - int64_t(p.ay.off) * p.ld + qx;
         const T s2 = p.scale * p.scale;
+        // the thread's E = 2 adjacent columns go out as ONE 8-byte access when the output allows it (vec_ok bit 1): two
+        // 4-byte stores per row doubled the store instructions of the |.|^2 epilogues (measured 65 -> 5x us at 4096^2)
+        const bool pair = C::E == 2 && (p.vec_ok & 2);
 #pragma unroll
         for (int m = 0; m < C::P; ++m) {
             const int pp = slot_pos<C, ROT>(pos.t, m, p.ay.shift);
             if (!FULL && (pp < lo || pp >= hi)) continue;
             T* a = base + int64_t(pp) * p.ld;
+            T i2[C::E];
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) i2[e] = (v[e][m].x * v[e][m].x + v[e][m].y * v[e][m].y) * s2;
+            if constexpr (C::E == 2) {
+                if (pair) {
+                    cx<T>* a2 = reinterpret_cast<cx<T>*>(a);       // a pair of reals, same size and alignment as one complex
+                    if (p.epilogue == EPI_ABS2) {
+                        if (p.nt)
+                            nt_store_cx(a2, cx<T>{i2[0], i2[1]});
+                        else
+                            *a2 = cx<T>{i2[0], i2[1]};
+                    } else {
+                        const cx<T> old = *a2;
+                        *a2 = cx<T>{old.x + p.weight * i2[0], old.y + p.weight * i2[1]};
+                    }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < C::E; ++e) {
-                const T i2 = (v[e][m].x * v[e][m].x + v[e][m].y * v[e][m].y) * s2;
                 if (p.epilogue == EPI_ABS2) {
                     if (p.nt)
-                        nt_store_s(a + e, i2);
+                        nt_store_s(a + e, i2[e]);
                     else
-                        a[e] = i2;
+                        a[e] = i2[e];
                 } else {
-                    a[e] += p.weight * i2;
+                    a[e] += p.weight * i2[e];
                 }
             }
         }
