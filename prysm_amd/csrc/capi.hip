@@ -425,7 +425,9 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
         const int ntiles = int((N + p.tc - 1) / p.tc);
         ColLoadTiled<T> cl{W1, H, AxisMap{H, H, 0, 0}, ntiles, p.log_k, plane};
         MidMul<T> mm{d->mul_kind, d->mul_conj, reinterpret_cast<const cx<T>*>(d->mul), reinterpret_cast<const cx<T>*>(d->mul_x),
-                     2 * d->mul_ld, int(N), d->mul_kind == PM_MUL_FULL ? d->mul_ld : 1, 0, 2};
+                     2 * d->mul_ld, int(N), d->mul_kind == PM_MUL_FULL ? d->mul_ld : 1, 0, 2, 0};
+        mm.vec_ok = (d->mul_kind == PM_MUL_FULL && sizeof(T) == 4 && d->mul_ld % 2 == 0 &&
+                     reinterpret_cast<uintptr_t>(d->mul) % 16 == 0) ? 1 : 0;
         ColStoreTiled<T> cst{W1, H, ntiles, p.log_k, plane};
         rc = launch_col_mul<T>(p.logm - 1, cl, mm, cst, twH, ntiles, sibling_log_g(p.log_k), st, 2);
         if (rc) return rc;
@@ -447,7 +449,9 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
     const int ntiles = int((N + p.tc - 1) / p.tc);
     ColLoadTiled<T> cl{W1, rows, to_map(d->in_y), ntiles, p.log_k, wstride};
     MidMul<T> mm{d->mul_kind, d->mul_conj, reinterpret_cast<const cx<T>*>(d->mul), reinterpret_cast<const cx<T>*>(d->mul_x),
-                 d->mul_ld, int(N), d->mul_bstride, d->mul_x_bstride};
+                 d->mul_ld, int(N), d->mul_bstride, d->mul_x_bstride, 0,
+                 (d->mul_kind == PM_MUL_FULL && sizeof(T) == 4 && d->mul_ld % 2 == 0 && d->mul_bstride % 2 == 0 &&
+                  reinterpret_cast<uintptr_t>(d->mul) % 16 == 0) ? 1 : 0};
     ColStoreTiled<T> cst{W2, int(M), ntiles, p.log_k, wstride};
     int rc = launch_col_mul<T>(p.logm, cl, mm, cst, twM, ntiles, sibling_log_g(p.log_k), st, nb);
     if (rc) return rc;

@@ -137,6 +137,7 @@ struct MidMul {
     int64_t bstride;   // elements between the multipliers (FULL) / the hy vectors (SEPARABLE) of consecutive fields;
     int64_t bstride_x; // ... between the hx vectors.  0: one multiplier for the whole batch
     int ystep;         // SEPARABLE: row factor of bin k is mul[k * ystep] (0 means 1); 2 for the planes of a folded transform
+    int vec_ok;        // FULL, complex64: the multipliers of a thread's two columns may be read as one 16-byte access
 };
 
 template <typename T>
@@ -648,13 +649,26 @@ PM_HD void mid_multiply_conj_kind(const MidMul<typename C::T>& p, int tile, Thre
         const int k = pos.t + m * C::TPS;
         cx<T> hy = {T(1), T(0)};
         if (KIND == MUL_SEPARABLE) hy = p.mul[p.ystep > 1 ? k * p.ystep : k];
+        cx<T> hf[C::E];
+        if constexpr (KIND == MUL_FULL) {
+            bool done = false;
+            if constexpr (C::E == 2 && sizeof(T) == 4) {
+                if (p.vec_ok && col0 + 1 < p.ncols) {
+                    const Vec4<T> w = *reinterpret_cast<const Vec4<T>*>(p.mul + int64_t(k) * p.ld + col0);
+                    hf[0] = {w.a, w.b};
+                    hf[1] = {w.c, w.d};
+                    done = true;
+                }
+            }
+            if (!done) {
+#pragma unroll
+                for (int e = 0; e < C::E; ++e)
+                    hf[e] = (col0 + e < p.ncols) ? p.mul[int64_t(k) * p.ld + col0 + e] : cx<T>{T(1), T(0)};
+            }
+        }
 #pragma unroll
         for (int e = 0; e < C::E; ++e) {
-            cx<T> h;
-            if (KIND == MUL_FULL)
-                h = (col0 + e < p.ncols) ? p.mul[int64_t(k) * p.ld + col0 + e] : cx<T>{T(1), T(0)};
-            else
-                h = cmul(hy, hx[e]);
+            const cx<T> h = (KIND == MUL_FULL) ? hf[e] : cmul(hy, hx[e]);
             const cx<T> x = p.conj ? cmulc(v[e][m], h) : cmul(v[e][m], h);
             v[e][m] = {x.x, -x.y};
         }
