@@ -237,6 +237,18 @@ def main():
         reduce_ms = float(r.item())
 
     poly_ms = polychromatic_per_wavelength_ms(n, cdtype) if (rank == 0 and not args.no_poly) else 0.0
+    psf_ms = 0.0
+    if rank == 0 and not args.no_poly:
+        # the intensity form of the same step: |focus(x)|^2 with the modulus fused into the column pass (no complex PSF in memory)
+        acc_i = P.focus_intensity(x, 1)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            P.focus_intensity(x, 1, out=acc_i)
+        e1.record()
+        torch.cuda.synchronize()
+        psf_ms = e0.elapsed_time(e1) / 50
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
@@ -258,6 +270,8 @@ def main():
             'whole_step_algorithmic_GBps_per_gpu': alg_bytes_step / (ms_step * 1e-3) / 1e9,
             'whole_step_frac_of_hbm_peak': alg_bytes_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'whole_step_frac_of_measured_copy_ceiling': alg_bytes_step / (ms_step * 1e-3) / 1e9 / HBM_COPY_CEILING_GBS,
+            'psf_variant': {'ms_per_psf': psf_ms, 'psfs_per_s_per_gpu': (1e3 / psf_ms) if psf_ms else None,
+                            'note': 'focus_intensity(x, 1): the same propagation storing |.|^2 (fp32 image) instead of the complex field'},
             'reduce_ms': reduce_ms,
             'polychromatic': {'per_wavelength_ms': poly_ms, 'wavelengths_per_gpu': math.ceil(64 / world),
                               'psf_64wvl_ms': math.ceil(64 / world) * poly_ms + reduce_ms,
