@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
         const bool more = k0 + BK < kend;
 #ifndef PM_GEMM_DBG
 #define PM_GEMM_DBG 0   // timing builds (wrong results): 1 = no global loads / LDS staging in the loop, 2 = also no LDS operand
-                        // reads, 3 = global loads but no LDS stores, 4 = LDS stores but no global loads
+                        // reads, 3 = global loads but no LDS stores, 4 = LDS stores but no global loads, 5 = everything but the barrier
 #endif
         if (more && (PM_GEMM_DBG == 0 || PM_GEMM_DBG == 3)) fetch_tile(k0 + BK);   // next K-tile into registers: in flight under the MFMAs of this one
         // operand fragments of k-step n + 1 are read from LDS BEFORE the MFMAs of k-step n are issued (register double
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
             for (int s_ = 0; s_ < SA::E; ++s_) sum += ra[s_].x + rb[s_].y;
             if (sum == T(-12345.5)) As0[tid] = {sum, sum};
         }
-        __syncthreads();
+        if (PM_GEMM_DBG != 5) __syncthreads();   // timing build 5: no barrier in the loop (wrong results)
         buf ^= 1;
     }
 
