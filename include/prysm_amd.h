@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PM_VERSION 102 /* 0.1.0 */
+#define PM_VERSION 103 /* 0.1.0 */
 
 /* dtype codes */
 enum { PM_C64 = 0, PM_C128 = 1, PM_F32 = 2, PM_F64 = 3, PM_BOOL = 4 };
@@ -181,6 +181,17 @@ int pm_abs2(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t i
  * incoherent sum of the polychromatic recipe over a batch of intensities. */
 int pm_sum_modes(int32_t dtype, int64_t nmodes, int64_t rows, int64_t cols, const void* modes, int64_t mode_stride,
                  int64_t modes_ld, const double* weights, int32_t accumulate, void* out, int64_t out_ld, void* stream);
+
+/* Resample a measured complex focal-plane-mask map at focal coordinates: scipy.ndimage.map_coordinates(order 0 | 1,
+ * mode='nearest') of the real and imaginary parts at row = (yf - center_y)/dx + map_rows/2, col = (xf - center_x)/dx +
+ * map_cols/2; points outside [0, n-1] on either axis take fill (a rows x cols complex array) or, with fill NULL, the
+ * constant fill_re + i fill_im.  xf / yf are REAL arrays of the precision that goes with dtype, addressed as
+ * xf[r*xf_sy + c*xf_sx] (a stride of 0 broadcasts a coordinate vector).  prepare_measured_fpm
+ * (prysm/propagation/coronagraph.py:128-200).  Other spline orders: PM_ERR_UNSUPPORTED. */
+int pm_sample_map(int32_t dtype, int32_t order, int64_t map_rows, int64_t map_cols, const void* map, int64_t map_ld, double dx,
+                  double center_x, double center_y, int64_t rows, int64_t cols, const void* xf, int64_t xf_sy, int64_t xf_sx,
+                  const void* yf, int64_t yf_sy, int64_t yf_sx, const void* fill, int64_t fill_ld, double fill_re, double fill_im,
+                  void* out, int64_t out_ld, void* stream);
 
 /* P = amp * exp(i * k * opd), k = 2 pi / (wavelength_um * 1e3) for opd in nm.
  * amp may be NULL (unit amplitude: phase_screen).  amp_dtype in {PM_F32, PM_F64, PM_BOOL}.

@@ -58,6 +58,8 @@ SIGNATURES = {
     'pm_scale_sep': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_f64, c_vp, c_i64, c_vp]),
     'pm_abs2': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_f64, c_vp]),
     'pm_sum_modes': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, ctypes.POINTER(c_f64), c_i32, c_vp, c_i64, c_vp]),
+    'pm_sample_map': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_vp, c_i64, c_f64, c_f64, c_f64, c_i64, c_i64, c_vp, c_i64, c_i64,
+                              c_vp, c_i64, c_i64, c_vp, c_i64, c_f64, c_f64, c_vp, c_i64, c_vp]),
     'pm_pupil_synth': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i32, c_i64, c_vp, c_i64, c_f64, c_vp, c_i64, c_vp]),
     'pm_quadratic_phase': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_f64, c_vp, c_i64, c_vp]),
     'pm_as_tf_vectors': (c_i32, [c_i32, c_i64, c_i64, c_f64, c_f64, c_f64, c_vp, c_vp, c_vp]),

@@ -235,6 +235,35 @@ def sum_modes(modes, weights, out=None, accumulate=False):
     return out
 
 
+def sample_map(measurement, dx, center, xf, yf, fill=1.0, order=1):
+    """Complex map resampled at focal coordinates (pm_sample_map): map_coordinates(order 0 | 1, mode='nearest') inside the
+    measured extent, `fill` (scalar or array of the shape of xf) outside.  xf / yf broadcast against each other."""
+    lib = L.load()
+    m = L.as_field(measurement)
+    if not m.is_complex():
+        m = m.to(L.cdtype_of(m))
+    m = m.contiguous()
+    rdt = torch.float32 if m.dtype == torch.complex64 else torch.float64
+    xf, yf = L.as_device(xf).to(rdt), L.as_device(yf).to(rdt)
+    shape = torch.broadcast_shapes(xf.shape, yf.shape)
+    if len(shape) != 2:
+        raise ValueError('sample_map: focal coordinates must broadcast to a 2-D grid')
+    xb, yb = xf.expand(shape), yf.expand(shape)
+    rows, cols = shape
+    out = torch.empty(shape, dtype=m.dtype, device=m.device)
+    fill_t, fre, fim = None, 0.0, 0.0
+    if isinstance(fill, (int, float, complex)):
+        fre, fim = float(complex(fill).real), float(complex(fill).imag)
+    else:
+        fill_t = torch.broadcast_to(L.as_device(fill).to(m.dtype), shape).contiguous()
+    cxo, cyo = center
+    L.check(lib.pm_sample_map(L.code(m.dtype), int(order), m.shape[0], m.shape[1], L.ptr(m), m.stride(0), float(dx), float(cxo),
+                              float(cyo), rows, cols, L.ptr(xb), xb.stride(0), xb.stride(1), L.ptr(yb), yb.stride(0),
+                              yb.stride(1), L.ptr(fill_t) if fill_t is not None else None,
+                              fill_t.stride(0) if fill_t is not None else 0, fre, fim, L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
 _AMP_CODE = {torch.float32: L.PM_F32, torch.float64: L.PM_F64, torch.bool: L.PM_BOOL, torch.uint8: L.PM_BOOL}
 
 

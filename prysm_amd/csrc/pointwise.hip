@@ -104,6 +104,42 @@ __global__ void sum_modes_kernel(int64_t rows, int64_t cols, const T* __restrict
     }
 }
 
+// ---------------------------------------------------------------- measured focal-plane mask
+// map_coordinates(order 0 | 1, mode='nearest') of a complex map at (row, col) = ((yf-cy)/dx + ny/2, (xf-cx)/dx + nx/2);
+// coordinates are formed in the precision of xf / yf as numpy does, the interpolation itself in fp64 as scipy does.
+template <typename T>
+__global__ void sample_map_kernel(int order, int64_t ny, int64_t nx, const cx<T>* __restrict__ map, int64_t ldm, T dx, T cxo, T cyo,
+                                  int64_t rows, int64_t cols, const T* xf, int64_t xsy, int64_t xsx, const T* yf, int64_t ysy,
+                                  int64_t ysx, const cx<T>* fill, int64_t ldf, cx<T> fillv, cx<T>* o, int64_t ldo) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < rows; r += int64_t(gridDim.y) * blockDim.y) {
+        const T col = (xf[r * xsy + c * xsx] - cxo) / dx + T(nx / 2);
+        const T row = (yf[r * ysy + c * ysx] - cyo) / dx + T(ny / 2);
+        const bool inside = row >= T(0) && row <= T(ny - 1) && col >= T(0) && col <= T(nx - 1);
+        cx<T> v;
+        if (!inside) {
+            v = fill ? fill[r * ldf + c] : fillv;
+        } else {
+            const double rr = double(row), cc = double(col);
+            if (order == 0) {
+                int64_t ir = int64_t(floor(rr + 0.5)), ic = int64_t(floor(cc + 0.5));
+                ir = ir > ny - 1 ? ny - 1 : ir;
+                ic = ic > nx - 1 ? nx - 1 : ic;
+                v = map[ir * ldm + ic];
+            } else {
+                const int64_t r0 = int64_t(floor(rr)), c0 = int64_t(floor(cc));
+                const int64_t r1 = r0 + 1 > ny - 1 ? ny - 1 : r0 + 1, c1 = c0 + 1 > nx - 1 ? nx - 1 : c0 + 1;
+                const double tr = rr - double(r0), tc = cc - double(c0);
+                const cx<T> a = map[r0 * ldm + c0], b = map[r0 * ldm + c1], d = map[r1 * ldm + c0], e = map[r1 * ldm + c1];
+                const double w00 = (1 - tr) * (1 - tc), w01 = (1 - tr) * tc, w10 = tr * (1 - tc), w11 = tr * tc;
+                v = {T(w00 * a.x + w01 * b.x + w10 * d.x + w11 * e.x), T(w00 * a.y + w01 * b.y + w10 * d.y + w11 * e.y)};
+            }
+        }
+        o[r * ldo + c] = v;
+    }
+}
+
 // ---------------------------------------------------------------- pupil synthesis
 template <typename T, typename A>
 __global__ void pupil_kernel(int64_t rows, int64_t cols, const A* amp, int64_t lda, const T* opd, int64_t ldp,
@@ -270,6 +306,30 @@ int pm_sum_modes(int32_t dtype, int64_t nmodes, int64_t rows, int64_t cols, cons
         acc = 1;
         b0 += 32;
     } while (b0 < nmodes);
+    return int(hipGetLastError());
+}
+
+int pm_sample_map(int32_t dtype, int32_t order, int64_t map_rows, int64_t map_cols, const void* map, int64_t map_ld, double dx,
+                  double center_x, double center_y, int64_t rows, int64_t cols, const void* xf, int64_t xf_sy, int64_t xf_sx,
+                  const void* yf, int64_t yf_sy, int64_t yf_sx, const void* fill, int64_t fill_ld, double fill_re, double fill_im,
+                  void* out, int64_t out_ld, void* stream) {
+    if (!map || !xf || !yf || !out || rows < 0 || cols < 0 || map_rows < 1 || map_cols < 1 || !(dx != 0.0))
+        return fail(PM_ERR_ARG, "pm_sample_map: bad argument");
+    if (order != 0 && order != 1) return fail(PM_ERR_UNSUPPORTED, "pm_sample_map: spline order must be 0 or 1");
+    if (rows == 0 || cols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(rows, cols, block);
+    hipStream_t st = PM_STREAM(stream);
+    if (dtype == PM_C64)
+        hipLaunchKernelGGL(sample_map_kernel<float>, grid, block, 0, st, order, map_rows, map_cols, (const cx<float>*)map, map_ld, float(dx),
+                           float(center_x), float(center_y), rows, cols, (const float*)xf, xf_sy, xf_sx, (const float*)yf, yf_sy, yf_sx,
+                           (const cx<float>*)fill, fill_ld, cx<float>{float(fill_re), float(fill_im)}, (cx<float>*)out, out_ld);
+    else if (dtype == PM_C128)
+        hipLaunchKernelGGL(sample_map_kernel<double>, grid, block, 0, st, order, map_rows, map_cols, (const cx<double>*)map, map_ld, dx,
+                           center_x, center_y, rows, cols, (const double*)xf, xf_sy, xf_sx, (const double*)yf, yf_sy, yf_sx,
+                           (const cx<double>*)fill, fill_ld, cx<double>{fill_re, fill_im}, (cx<double>*)out, out_ld);
+    else
+        return fail(PM_ERR_ARG, "pm_sample_map: dtype must be PM_C64 or PM_C128");
     return int(hipGetLastError());
 }
 

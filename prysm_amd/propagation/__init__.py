@@ -16,7 +16,7 @@ _EXPORTS = {
            'focus_dft focus_dft_adjoint unfocus_dft unfocus_dft_adjoint focus_fixed_sampling'),
     _as: 'angular_spectrum angular_spectrum_adjoint angular_spectrum_transfer_function fresnel_number talbot_distance',
     _cor: ('to_fpm_and_back to_fpm_and_back_adjoint to_fpm_and_back_multiresolution '
-           'to_fpm_and_back_multiresolution_adjoint vortex_phase_mask babinet babinet_adjoint'),
+           'to_fpm_and_back_multiresolution_adjoint vortex_phase_mask prepare_measured_fpm babinet babinet_adjoint'),
 }
 for _mod, _names in _EXPORTS.items():
     for _n in _names.split():

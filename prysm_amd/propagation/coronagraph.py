@@ -69,6 +69,27 @@ def vortex_phase_mask(charge):
     return fpm
 
 
+def prepare_measured_fpm(measurement, dx, center=(0, 0), charge=None, fill=None, order=1):
+    """Wrap a measured complex focal-plane-mask map as an fpm(xf, yf) callable (coronagraph.py:128-200).
+
+    The map is resampled on the device at each level's focal grid (pm_sample_map: map_coordinates order 0 | 1,
+    mode='nearest'); outside the measured extent the mask continues as `fill` (scalar or callable), an ideal vortex of
+    `charge`, or 1.  Spline orders above 1 raise NotImplementedError.
+    """
+    meas = L.as_field(measurement)
+    if not meas.is_complex():
+        meas = meas.to(L.cdtype_of(meas))
+    if order not in (0, 1):
+        raise NotImplementedError('prepare_measured_fpm: spline order 0 or 1 (higher orders need the spline prefilter)')
+    if fill is None:
+        fill = vortex_phase_mask(charge) if charge is not None else 1.0
+
+    def fpm(xf, yf):
+        fillv = fill(xf, yf) if callable(fill) else fill
+        return _ops.sample_map(meas, dx, center, xf, yf, fill=fillv, order=order)
+    return fpm
+
+
 def to_fpm_and_back_multiresolution(wavefunction, fpm, executor, return_more=False):
     """Propagate to a focal plane mask and back at multiple resolutions (coronagraph.py:203-225)."""
     out = None

@@ -314,6 +314,18 @@ def multires():
     out['otf_mtf_adj'] = potf.mtf_from_psf_adjoint(out['otf_mtf_bar'], psf, 1.0)
     out['otf_ptf_adj'] = potf.ptf_from_psf_adjoint(out['otf_ptf_bar'], psf, 1.0)
     out['otf_otf_adj'] = potf.otf_from_psf_adjoint(out['otf_otf_bar'], psf, 1.0)
+    # prepare_measured_fpm (coronagraph.py:128-200): a measured map on its own grid, resampled per level
+    meas = (0.8 + 0.2 * rng.random((33, 28))) * np.exp(1j * rng.uniform(-np.pi, np.pi, (33, 28)))
+    out['meas'] = meas
+    xf, yf = np.meshgrid(np.linspace(-9.0, 9.5, 31), np.linspace(-11.0, 10.0, 26))
+    out['meas_xf'], out['meas_yf'] = xf, yf
+    for order in (0, 1):
+        out[f'meas_o{order}_vortex'] = propagation.prepare_measured_fpm(meas, 0.6, center=(0.3, -0.2), charge=2, order=order)(xf, yf)
+    out['meas_o1_one'] = propagation.prepare_measured_fpm(meas, 0.6)(xf, yf)
+    out['meas_o1_fill'] = propagation.prepare_measured_fpm(meas, 0.6, fill=0.25 - 0.5j)(xf, yf)
+    ex = propagation.prepare_multiresolution(kind='mdft', **par)
+    out['meas_fwd'] = propagation.to_fpm_and_back_multiresolution(
+        x, propagation.prepare_measured_fpm(meas, 0.6, center=(0.3, -0.2), charge=2), ex)
     np.savez_compressed(os.path.join(HERE, 'multires.npz'), **out)
 
 

@@ -28,7 +28,7 @@ def lib():
 def test_header_declares_the_expected_surface():
     syms = declared_symbols()
     for s in ('pm_fft2', 'pm_fft2_workspace', 'pm_fft1', 'pm_cmul', 'pm_abs2', 'pm_pupil_synth', 'pm_mdft_basis',
-              'pm_cgemm', 'pm_as_tf_vectors', 'pm_embed', 'pm_last_error', 'pm_version'):
+              'pm_cgemm', 'pm_sample_map', 'pm_as_tf_vectors', 'pm_embed', 'pm_last_error', 'pm_version'):
         assert s in syms
 
 
@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     for s in declared_symbols():
         assert hasattr(lib, s), f'{s} declared in prysm_amd.h but not exported'
         assert s in _lib.SIGNATURES, f'{s} has no ctypes signature in prysm_amd/_lib.py'
-    assert lib.pm_version() == 102
+    assert lib.pm_version() == 103
 
 
 def test_argument_errors_are_reported_without_a_gpu(lib):

@@ -278,6 +278,22 @@ def test_multiresolution_oracle_vs_golden(golden):
     assert abs(got - float(g['tl_grad'])) < 1e-12 * abs(float(g['tl_grad']))
 
 
+def test_measured_fpm_oracle_vs_golden(golden):
+    """prepare_measured_fpm: the restated map_coordinates (orders 0, 1, mode nearest) against scipy's through the reference."""
+    g = golden('multires')
+    meas, xf, yf = g['meas'], g['meas_xf'], g['meas_yf']
+    for order in (0, 1):
+        got = O.prepare_measured_fpm(meas, 0.6, center=(0.3, -0.2), charge=2, order=order)(xf, yf)
+        assert rel_max(got, g[f'meas_o{order}_vortex']) < 1e-13
+    assert rel_max(O.prepare_measured_fpm(meas, 0.6)(xf, yf), g['meas_o1_one']) < 1e-13
+    assert rel_max(O.prepare_measured_fpm(meas, 0.6, fill=0.25 - 0.5j)(xf, yf), g['meas_o1_fill']) < 1e-13
+    n = g['x'].shape[0]
+    ex = O.prepare_multiresolution(0.25, (n, n), 3.0, (24, 20), float(g['par'][2]), 80.0, 3, scaling=3.0, fine_samples=16,
+                                   window=(0.25, 0.65), kind='mdft')
+    fpm = O.prepare_measured_fpm(meas, 0.6, center=(0.3, -0.2), charge=2)
+    assert rel_max(O.to_fpm_and_back_multiresolution(g['x'], fpm, ex), g['meas_fwd']) < 1e-12
+
+
 def test_otf_adjoints_oracle_vs_golden(golden):
     g = golden('multires')
     psf = g['otf_psf']
