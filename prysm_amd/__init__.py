@@ -11,5 +11,6 @@ Arrays are torch tensors in HBM; all hot-path arithmetic runs in hand-written HI
 from . import conf, mathops, fttools, propagation, otf, convolution   # noqa: F401
 from .conf import config   # noqa: F401
 from .propagation import Wavefront   # noqa: F401
+from .npfacade import NumpyFacade, DeviceArray   # noqa: F401
 
 __version__ = '0.1.0'

@@ -145,6 +145,8 @@ def as_device(x, dtype=None):
         t = torch.from_numpy(a).to(dev)
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)
+    if t.is_conj() or t.is_neg():       # torch's lazy conj / neg views: the library reads the stored bytes
+        t = t.resolve_conj().resolve_neg()
     if not t.is_contiguous():
         t = t.contiguous()
     return t

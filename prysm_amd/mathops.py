@@ -13,6 +13,7 @@ import numpy as _np
 import torch
 
 from . import _lib as L
+from .npfacade import NumpyFacade, DeviceArray, _wrap
 
 _scalar_types = (Number, _np.generic)
 
@@ -70,6 +71,9 @@ class FFTFacade:
     runs as three device operations; the fused level is the function rebinding of set_backend_to_mi355x().
     """
 
+    def __init__(self, device=None):
+        self._device = device       # fftfreq only; the transforms run where the library runs
+
     @staticmethod
     def _scale(norm, count, inverse):
         if norm in (None, 'backward'):
@@ -86,7 +90,7 @@ class FFTFacade:
         if s is not None or tuple(a % x.dim() for a in axes) != (x.dim() - 2, x.dim() - 1):
             raise NotImplementedError('fft2 facade: last two axes, no resizing')
         M, N = x.shape[-2:]
-        return _ops.fft2(x, direction=-1, scale=self._scale(norm, M * N, False))
+        return _wrap(_ops.fft2(x, direction=-1, scale=self._scale(norm, M * N, False)))
 
     def ifft2(self, x, s=None, axes=(-2, -1), norm=None):
         from . import _ops
@@ -94,35 +98,35 @@ class FFTFacade:
         if s is not None or tuple(a % x.dim() for a in axes) != (x.dim() - 2, x.dim() - 1):
             raise NotImplementedError('ifft2 facade: last two axes, no resizing')
         M, N = x.shape[-2:]
-        return _ops.fft2(x, direction=+1, scale=self._scale(norm, M * N, True))
+        return _wrap(_ops.fft2(x, direction=+1, scale=self._scale(norm, M * N, True)))
 
     def fft(self, x, n=None, axis=-1, norm=None):
         from . import _ops
         x = L.as_complex(x)
         length = n if n is not None else x.shape[axis]
-        return _ops.fft1(x, n, axis, -1, self._scale(norm, length, False))
+        return _wrap(_ops.fft1(x, n, axis, -1, self._scale(norm, length, False)))
 
     def ifft(self, x, n=None, axis=-1, norm=None):
         from . import _ops
         x = L.as_complex(x)
         length = n if n is not None else x.shape[axis]
-        return _ops.fft1(x, n, axis, +1, self._scale(norm, length, True))
+        return _wrap(_ops.fft1(x, n, axis, +1, self._scale(norm, length, True)))
 
     @staticmethod
     def fftshift(x, axes=None):
         x = L.as_device(x)
         axes = tuple(range(x.dim())) if axes is None else ((axes,) if isinstance(axes, int) else tuple(axes))
-        return torch.roll(x, [x.shape[a] // 2 for a in axes], axes)
+        return _wrap(torch.roll(x, [x.shape[a] // 2 for a in axes], axes))
 
     @staticmethod
     def ifftshift(x, axes=None):
         x = L.as_device(x)
         axes = tuple(range(x.dim())) if axes is None else ((axes,) if isinstance(axes, int) else tuple(axes))
-        return torch.roll(x, [-(x.shape[a] // 2) for a in axes], axes)
+        return _wrap(torch.roll(x, [-(x.shape[a] // 2) for a in axes], axes))
 
-    @staticmethod
-    def fftfreq(n, d=1.0):
-        return torch.fft.fftfreq(n, d, dtype=torch.float64, device=L.device())
+    def fftfreq(self, n, d=1.0):
+        dev = self._device if self._device is not None else L.device()
+        return _wrap(torch.fft.fftfreq(n, d, dtype=torch.float64, device=dev))
 
     @staticmethod
     def next_fast_len(n):
@@ -140,7 +144,7 @@ _FTTOOLS_NAMES = ('pad2d', 'crop_center', 'fftrange', 'MDFT', 'CZT', 'FFTDFT')
 _saved = {}
 
 
-def set_backend_to_mi355x(prysm=None):
+def set_backend_to_mi355x(prysm=None, arrays=False):
     """Route prysm's pupil<->focus / free-space / matrix-DFT hot path to libprysm_amd.so.
 
     Rebinds the array-level functions and executor classes on ``prysm.propagation`` (and on the submodules and
@@ -148,6 +152,9 @@ def set_backend_to_mi355x(prysm=None):
     ``prysm.fttools`` and ``prysm.propagation.Wavefront``.  Arrays handed to these functions may be numpy (they are
     uploaded) or torch tensors in HBM; results are device tensors (use ``array_to_true_numpy``).  Undo with
     ``restore_prysm_backend()``.  ``config.precision`` of prysm is mirrored into ``prysm_amd.conf.config``.
+
+    ``arrays=True`` also plugs ``prysm.mathops.np`` (NumpyFacade): prysm's own array code -- coordinates, geometry, the
+    Wavefront constructors -- then builds its arrays in HBM and nothing crosses PCIe between model steps.
     """
     import importlib
     if prysm is None:
@@ -179,6 +186,10 @@ def set_backend_to_mi355x(prysm=None):
         shim = importlib.import_module(prysm.__name__ + '.mathops').fft
         _saved.setdefault((shim, '_srcmodule'), shim._srcmodule)
         shim._srcmodule = FFTFacade()
+        if arrays:
+            npshim = importlib.import_module(prysm.__name__ + '.mathops').np
+            _saved.setdefault((npshim, '_srcmodule'), npshim._srcmodule)
+            npshim._srcmodule = NumpyFacade()
     except Exception:   # pragma: no cover
         pass
 

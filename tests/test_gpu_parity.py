@@ -752,6 +752,48 @@ def test_fft_facade_numpy_semantics(pa):
     assert rel_max(tonp(fft.fft2(real)), np.fft.fft2(real)) < TOL64
 
 
+def test_array_level_plug_on_the_device(pa):
+    """The ``np`` facade with the ``fft`` facade on the MI355X: the reference's formulas written against the two shims.
+    focus as fft.py:7-25 spells it; the matrix DFT and its adjoint as fttools.py:187-228 spell them with ``@`` / ``.T`` /
+    ``.conj()`` -- complex 2-D products reach pm_cgemm with the views as operand flags; torch's lazy conj view handed to a
+    fused-level function is resolved before the library reads the bytes."""
+    from prysm_amd.mathops import FFTFacade
+    from prysm_amd.npfacade import NumpyFacade, DeviceArray
+    P = pa.propagation
+    xp, fft = NumpyFacade(), FFTFacade()
+    rng = np.random.default_rng(11)
+    a = crandn(rng, (48, 40))
+    padded = xp.pad(xp.asarray(a), ((24, 24), (20, 20)))
+    got = fft.fftshift(fft.fft2(fft.ifftshift(padded), norm='ortho'))
+    assert isinstance(got, DeviceArray) and got.is_cuda
+    assert rel_max(got.get(), O.focus(a, 2)) < TOL64
+    for cdt, rdt, tol in ((np.complex128, np.float64, TOL64), (np.complex64, np.float32, TOL32_MDFT)):
+        x = xp.arange(-20, 20, dtype=rdt) * 0.25
+        y = xp.arange(-24, 24, dtype=rdt) * 0.25
+        fx = xp.arange(-8, 8, dtype=rdt) * 0.031
+        fy = xp.arange(-6, 6, dtype=rdt) * 0.029
+        Ex = xp.exp(-2j * xp.pi * xp.outer(fx, x)).astype(cdt)
+        Ey = xp.exp(-2j * xp.pi * xp.outer(fy, y)).astype(cdt)
+        ary = xp.asarray(a.astype(cdt))
+        out = Ey @ ary @ Ex.T
+        nEx, nEy = np.asarray(Ex).astype(np.complex128), np.asarray(Ey).astype(np.complex128)
+        assert isinstance(out, DeviceArray) and tuple(out.shape) == (12, 16) and out.get().dtype == cdt
+        assert rel_max(out.get(), nEy @ a @ nEx.T) < tol
+        g = crandn(rng, (12, 16)).astype(cdt)
+        back = Ey.conj().T @ xp.asarray(g) @ Ex.conj()
+        assert rel_max(back.get(), nEy.conj().T @ g @ nEx.conj()) < tol
+        assert rel_max((ary @ xp.conj(ary).T).get(), a @ a.conj().T) < tol
+    # numpy operand on the left of a device array, intensity as wavefront.py:146-151 spells it
+    inten = xp.real(got) ** 2 + xp.imag(got) ** 2
+    assert rel_max(inten.get(), np.abs(O.focus(a, 2)) ** 2) < TOL64
+    assert rel_max((np.conj(a) * xp.asarray(a)).get(), np.abs(a) ** 2) < 1e-14
+    # lazy conj / neg views into the fused level
+    t = torch.as_tensor(a, device='cuda')
+    assert torch.conj(t).is_conj()
+    assert rel_max(tonp(P.focus(torch.conj(t), 1)), O.focus(np.conj(a), 1)) < TOL64
+    assert rel_max(tonp(P.focus(torch.conj(t).imag, 1)), O.focus(-a.imag, 1)) < TOL64
+
+
 def test_fused_pupil_synthesis(pa):
     """Wavefront.from_amp_and_phase(...).focus / focus_intensity with the pupil synthesised inside the row pass
     (PM_FLAG_SYNTH_INPUT, complex64): equals the oracle's from_amp_and_phase -> focus, for bool / float / no amplitude,

@@ -128,3 +128,94 @@ def test_array_to_true_numpy_unwraps_containers():
     assert array_to_true_numpy(3.0) == 3.0 and array_to_true_numpy([1, 2]).tolist() == [1, 2]
     with pytest.raises(TypeError):
         array_to_true_numpy(object())
+
+
+def test_numpy_facade_semantics():
+    """NumpyFacade / DeviceArray: numpy spellings and dtype rules on torch tensors (CPU tensors here: plumbing only)."""
+    import torch
+    from prysm_amd.npfacade import NumpyFacade, DeviceArray
+    xp = NumpyFacade(torch.device('cpu'))
+    a = xp.arange(-3, 4, dtype=np.float32)
+    assert isinstance(a, DeviceArray) and a.dtype == torch.float32 and a.get().dtype == np.float32
+    assert xp.arange(5).dtype == torch.int64 and xp.zeros((2, 3)).dtype == torch.float64
+    assert xp.zeros(4, dtype=np.complex64).dtype == torch.complex64
+    assert a.astype(np.float64).dtype == torch.float64 and a.astype(xp.float64).get().dtype == np.float64
+    z = xp.exp(1j * xp.pi * a.astype(np.float64))
+    np.testing.assert_allclose(z.get(), np.exp(1j * np.pi * np.arange(-3, 4.0)), atol=1e-15)
+    assert isinstance(xp.exp(1.0), float) or isinstance(xp.exp(1.0), np.floating)        # host scalars stay on the host
+    p = xp.pad(xp.ones((2, 3)), ((1, 2), (3, 0)))
+    np.testing.assert_array_equal(p.get(), np.pad(np.ones((2, 3)), ((1, 2), (3, 0))))
+    gx, gy = xp.meshgrid(xp.arange(3), xp.arange(2))
+    nx, ny = np.meshgrid(np.arange(3), np.arange(2))
+    np.testing.assert_array_equal(gx.get(), nx)
+    np.testing.assert_array_equal(gy.get(), ny)
+    w = xp.where(a > 0, 1j, 0.5)
+    np.testing.assert_array_equal(w.get(), np.where(np.arange(-3, 4.0) > 0, 1j, 0.5))
+    m = np.arange(6.0).reshape(2, 3) * xp.ones((2, 3))            # numpy operand defers to the device array
+    assert isinstance(m, DeviceArray)
+    np.testing.assert_array_equal(np.asarray(m), np.arange(6.0).reshape(2, 3))
+    assert xp.result_type(a, np.complex128) == np.complex128 and xp.finfo(a.dtype).eps == np.finfo(np.float32).eps
+    assert xp.iscomplexobj(z) and not xp.iscomplexobj(a) and xp.sum(a > 0).item() == 3
+    np.testing.assert_array_equal(xp.real(z).get(), z.get().real)
+    with pytest.raises(AttributeError):
+        xp.polyfit
+    with pytest.raises(RuntimeError):
+        NumpyFacade().zeros(3) if not torch.cuda.is_available() else (_ for _ in ()).throw(RuntimeError())
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'prysm')), reason='reference not present on this box')
+def test_numpy_facade_runs_the_references_array_code():
+    """prysm's own coordinates / geometry / Wavefront constructors / pad2d / transfer function / MDFT executor run
+    unmodified on ``np._srcmodule = NumpyFacade`` and give numpy's results, dtypes included."""
+    import sys
+    import torch
+    sys.path.insert(0, REF)
+    try:
+        from prysm import mathops, coordinates, geometry, fttools, propagation
+        from prysm.conf import config
+        from prysm.propagation import Wavefront
+    finally:
+        sys.path.remove(REF)
+    from prysm_amd.npfacade import NumpyFacade, DeviceArray
+    from prysm_amd.mathops import FFTFacade
+    field = np.random.default_rng(3).standard_normal((24, 20)) + 1j * np.random.default_rng(4).standard_normal((24, 20))
+
+    def run():
+        xp = mathops.np
+        out = {}
+        x, y = coordinates.make_xy_grid(64, diameter=10)
+        r, t = coordinates.cart_to_polar(x, y)
+        A = geometry.circle(5, r)
+        wf = Wavefront.from_amp_and_phase(A, 100 * (r / 5) ** 2 * xp.cos(t), 0.6328, x[0, 1] - x[0, 0])
+        pad = fttools.pad2d(wf.data, Q=2)
+        out.update(x=x, r=r, t=t, A=A, wf=wf.data, pad=pad, crop=fttools.crop_center(pad, (40, 30)), I=wf.intensity.data,
+                   rng=fttools.fftrange(9), lens=Wavefront.thin_lens(250.0, 0.6328, x, y).data)
+        out['xx'], _, out['fx'], _ = propagation.coordinates_for_focus(0.1, (64, 64), 2.0, (16, 16), 0.6328, 100.0)
+        for prec in (64, 32):
+            config.precision = prec
+            try:
+                a = xp.asarray(field.astype(np.complex64 if prec == 32 else np.complex128))
+                ex = propagation.prepare_executor(0.2, (24, 20), 3.0, (10, 12), 0.6328, 50.0, kind='mdft')
+                out[f'mdft{prec}'] = propagation.focus_dft(a, ex)
+                out[f'mdft_adj{prec}'] = propagation.focus_dft_adjoint(out[f'mdft{prec}'], ex)
+                out[f'H{prec}'] = propagation.angular_spectrum_transfer_function((8, 12), 0.6328, 0.01, 10.0)
+            finally:
+                config.precision = 64
+        return out
+
+    ref = run()
+    cpu = torch.device('cpu')
+    mathops.np._srcmodule, mathops.fft._srcmodule = NumpyFacade(cpu), FFTFacade(cpu)
+    try:
+        got = run()
+        with pytest.raises(RuntimeError):      # the transforms themselves have no CPU path
+            propagation.focus(got['wf'], 2)
+    finally:
+        mathops.set_backend_to_defaults()
+    for k, want in ref.items():
+        assert isinstance(got[k], DeviceArray), k
+        have = got[k].get()
+        want = np.asarray(want)
+        assert have.shape == want.shape and have.dtype == want.dtype, (k, have.dtype, want.dtype)
+        tol = 1e-6 if want.dtype in (np.complex64, np.float32) else 1e-14
+        assert np.abs(have.astype(complex) - want.astype(complex)).max() <= tol * max(np.abs(want).max(), 1), k
