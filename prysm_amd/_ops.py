@@ -257,7 +257,7 @@ def sample_map(measurement, dx, center, xf, yf, fill=1.0, order=1):
     else:
         fill_t = torch.broadcast_to(L.as_device(fill).to(m.dtype), shape).contiguous()
     cxo, cyo = center
-    L.check(lib.pm_sample_map(L.code(m.dtype), int(order), m.shape[0], m.shape[1], L.ptr(m), m.stride(0), float(dx), float(cxo),
+    L.check(lib.pm_sample_map(L.code(m), int(order), m.shape[0], m.shape[1], L.ptr(m), m.stride(0), float(dx), float(cxo),
                               float(cyo), rows, cols, L.ptr(xb), xb.stride(0), xb.stride(1), L.ptr(yb), yb.stride(0),
                               yb.stride(1), L.ptr(fill_t) if fill_t is not None else None,
                               fill_t.stride(0) if fill_t is not None else 0, fre, fim, L.ptr(out), out.stride(0), L.stream_ptr()))
