@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PM_VERSION 103 /* 0.1.0 */
+#define PM_VERSION 104 /* 0.1.0 */
 
 /* dtype codes */
 enum { PM_C64 = 0, PM_C128 = 1, PM_F32 = 2, PM_F64 = 3, PM_BOOL = 4 };
@@ -130,7 +130,13 @@ typedef struct pm_fft2_desc {
     double synth_k;
 } pm_fft2_desc;
 
-/* bytes of workspace pm_fft2 needs for this descriptor (the tiled intermediate) */
+/* Transform lengths (per axis): powers of two from 2 to 8192 run on the Stockham engine; other lengths from 96 to 4096 run on
+ * the same engine through Bluestein's identity (chirp multiply, power-of-two convolution of length >= 2n - 1, chirp multiply;
+ * when both axes are such lengths the 2-D convolution is ONE fused fft2 x B ifft2 chain); shorter lengths, and other lengths
+ * up to 32768, run on a direct O(n^2) kernel with fp64 accumulation.  Anything else is PM_ERR_UNSUPPORTED.  The reference
+ * takes any length through scipy.fft (prysm/propagation/fft.py:24).
+ *
+ * bytes of workspace pm_fft2 needs for this descriptor (the tiled intermediate, plus the Bluestein scratch) */
 size_t pm_fft2_workspace(const pm_fft2_desc* d);
 
 int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes,
@@ -156,6 +162,14 @@ int pm_fft2_mul_ifft2(const pm_fft2_desc* d, const void* in, void* out, void* wo
 int pm_fft1(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in,
             const pm_axis* t_out, double scale, const void* in, int64_t in_ld, void* out, int64_t out_ld,
             void* stream);
+/* The same with a workspace: pm_fft1_workspace() bytes (256 B aligned; 0 when none is needed) put lengths that are not
+ * powers of two (96 .. 4096) on the FFT engine through Bluestein's identity; without it (pm_fft1, or a smaller / NULL
+ * workspace) such lengths run on the direct O(n^2) kernel.  FFTDFT with K = 1 / (dx dfx) not a power of two
+ * (prysm/fttools.py:484-533) is the caller that needs it. */
+size_t pm_fft1_workspace(int32_t dtype, int32_t axis, int64_t batch, int64_t n);
+int pm_fft1_ws(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in,
+               const pm_axis* t_out, double scale, const void* in, int64_t in_ld, void* out, int64_t out_ld,
+               void* workspace, size_t workspace_bytes, void* stream);
 
 /* --- pointwise / synthesis kernels -------------------------------------------------------- */
 

@@ -172,8 +172,10 @@ def fft1(x, n=None, axis=-1, direction=-1, scale=1.0, out_len=None, out_off=0, i
     t_out = _axis(n, olen, out_off, 0)
     oshape = (olen, cols) if axis == 0 else (rows, olen)
     out = torch.empty(oshape, dtype=x.dtype, device=x.device)
-    L.check(lib.pm_fft1(L.code(x), direction, axis, batch, ctypes.byref(t_in), ctypes.byref(t_out), float(scale),
-                        L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), L.stream_ptr()))
+    nbytes = lib.pm_fft1_workspace(L.code(x), axis, batch, n)   # non-zero: a non power-of-two length on the Bluestein path
+    ws = L.workspace(nbytes) if nbytes else None
+    L.check(lib.pm_fft1_ws(L.code(x), direction, axis, batch, ctypes.byref(t_in), ctypes.byref(t_out), float(scale),
+                           L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), L.ptr(ws), nbytes, L.stream_ptr()))
     return out
 
 

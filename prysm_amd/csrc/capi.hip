@@ -9,6 +9,7 @@
 #include <tuple>
 #include <vector>
 
+#include "bluestein.h"
 #include "pm_internal.h"
 
 namespace pm {
@@ -69,6 +70,39 @@ template <> const cx<float>* twiddles<float>(int64_t n, int* err) { return table
 template <> const cx<double>* twiddles<double>(int64_t n, int* err) { return table_get<double>(n, err); }
 const cx<double>* twiddles_f64(int64_t n, int* err) { return table_get<double>(n, err); }
 
+// Bluestein tables [w (n) | B (MB)] of a non-power-of-two length n (bluestein.h), same cache, element-size key + 64
+template <typename T>
+static const cx<T>* blue_table_get(int64_t n, int* err) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        *err = int(e);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(dev, int(sizeof(T)) + 64, n);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) return reinterpret_cast<const cx<T>*>(it->second);
+    std::vector<cx<T>> h;
+    blue_make_tables<T>(int(n), blue_conv_len(n), h);
+    void* d = nullptr;
+    e = hipMalloc(&d, h.size() * sizeof(cx<T>));
+    if (e != hipSuccess) {
+        *err = int(e);
+        return nullptr;
+    }
+    e = hipMemcpy(d, h.data(), h.size() * sizeof(cx<T>), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        *err = int(e);
+        return nullptr;
+    }
+    g_tables[key] = d;
+    return reinterpret_cast<const cx<T>*>(d);
+}
+template <> const cx<float>* blue_tables<float>(int64_t n, int* err) { return blue_table_get<float>(n, err); }
+template <> const cx<double>* blue_tables<double>(int64_t n, int* err) { return blue_table_get<double>(n, err); }
+
 static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     auto is = [&](const char* k) { return strlen(k) == klen && !strncmp(key, k, klen); };
     if (is("col_var")) t.col_var = v;
@@ -85,6 +119,8 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("col_spread")) t.col_spread = v < 0 ? 0 : (v > 12 ? 12 : v);
     else if (is("col_skew")) t.col_skew = v < 0 ? 0 : (v > 64 ? 64 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
+    else if (is("blue_min")) t.blue_min = v < 0 ? 0 : v;
+    else if (is("blue_2d")) t.blue_2d = v ? 1 : 0;
 }
 
 Tuning& tuning() {
@@ -143,7 +179,12 @@ struct Fft2Plan {
                           // Infinity Cache between the two passes, consecutive chunks reuse the same workspace
     bool fold;            // one radix-2 step of the column transform is taken in the row pass (RowStoreFold): the column
                           // pass then runs two planes of M/2-point tiles
+    bool blue_n, blue_m;  // the row / column transforms take the Bluestein path (non-power-of-two lengths, bluestein.hip)
+    size_t blue_off;      // its scratch sits behind the intermediates in the workspace (shared by the two passes)
+    bool blue2d;          // both axes: chirp multiply -> ONE fused fft2 x (B1 (x) B2) ifft2 chain of size MB1 x MB2 -> chirp multiply
+                          // (blue2d_run); the workspace is then [a (M x N) | c (M x N) | workspace of the fused chain]
 };
+static size_t blue2d_fused_ws(int dtype, int64_t M, int64_t N);
 
 // The fold needs every input row stored (pairs (i, i + M/2) are combined), rotations by 0 or M/2 and an even output
 // window.  It pays from 4096-point columns: the M/2-point column tiles leave room for two workgroups per CU (their
@@ -196,6 +237,17 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     p.ws_field = (p.ws_bytes + 255) & ~size_t(255);
     p.chunk = batch_chunk(p.nbatch, p.ws_field);
     if (p.nbatch > 1) p.ws_bytes = p.ws_field * size_t(p.chunk);
+    p.blue_n = p.logn < 0 && use_blue(N);
+    p.blue_m = p.logm < 0 && use_blue(M);
+    p.blue_off = (p.ws_bytes + 255) & ~size_t(255);
+    p.blue2d = p.blue_n && p.blue_m && tuning().blue_2d && !(d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY));
+    if (p.blue2d) {
+        const size_t arr = (size_t(M) * size_t(N) * es + 255) & ~size_t(255);
+        p.ws_bytes = 2 * arr + blue2d_fused_ws(d->dtype, M, N);
+    } else if (p.blue_n || p.blue_m) {
+        const size_t a = p.blue_n ? blue_rows_scratch(es, rows, N) : 0, b = p.blue_m ? blue_cols_scratch(es, N, M) : 0;
+        p.ws_bytes = p.blue_off + (a > b ? a : b);
+    }
     return p;
 }
 
@@ -240,6 +292,9 @@ static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out, int logm_t
     return cs;
 }
 
+template <typename T>
+static int blue2d_run(const pm_fft2_desc* d, const void* in, void* out, void* ws, hipStream_t st);
+
 // one launch pair over `nb` fields (nb > 1 only when both passes run on the engine)
 template <typename T>
 static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st, int nb) {
@@ -250,6 +305,7 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
     int err = 0;
     cx<T>* W = reinterpret_cast<cx<T>*>(ws);
     const bool run1 = !(d->flags & PM_FLAG_PASS2_ONLY), run2 = !(d->flags & PM_FLAG_PASS1_ONLY);
+    if (p.blue2d) return blue2d_run<T>(d, in, out, ws, st);
 
     // ---- pass 1: one transform of length N per STORED input row (all-zero padded rows are skipped)
     if (run1 && rows > 0) {
@@ -281,11 +337,16 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
             }
             if (rc) return rc;
         } else {
-            const cx<double>* tw = twiddles_f64(N, &err);
-            if (!tw) return err;
             DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), d->in_ld, 1, to_map(d->in_x), rows, conj,
                            (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
-            int rc = direct_rows<T>(di, W, N, tw, st);
+            int rc;
+            if (p.blue_n) {
+                rc = blue_rows<T>(di, W, N, static_cast<char*>(ws) + p.blue_off, st);
+            } else {
+                const cx<double>* tw = twiddles_f64(N, &err);
+                if (!tw) return err;
+                rc = direct_rows<T>(di, W, N, tw, st);
+            }
             if (rc) return rc;
         }
     }
@@ -321,9 +382,10 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         ColLoadNat<T> cl{W, N, to_map(d->in_y), int(N), 0, (N % 2 == 0) ? 1 : 0};
         return launch_col_nat<T>(p.logm, tuning().col_var, cl, cs, tw, ntiles, 1, st);
     }
+    DirectIn<T> di{W, 1, N, to_map(d->in_y), int(N), 0};   // sequence = column c at W[c], element stride N
+    if (p.blue_m) return blue_cols<T>(di, cs, static_cast<char*>(ws) + p.blue_off, st);
     const cx<double>* tw = twiddles_f64(M, &err);
     if (!tw) return err;
-    DirectIn<T> di{W, 1, N, to_map(d->in_y), int(N), 0};   // sequence = column c at W[c], element stride N
     return direct_cols<T>(di, cs, tw, st);
 }
 
@@ -457,10 +519,66 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
     if (rc) return rc;
     // pass C: inverse row transforms of the rows inside the output window -> natural output, scale applied here.
     // Sequence s is stored row s of W2 (= logical row s); the output row map rotates / crops it.
-    RowLoadTiled<T> rl{W2, int(M), ltl, 0, int(M), 1, wstride};
-    RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), int(M), 1, T(d->scale), 1, to_map(d->out_y),
-                      d->out_bstride};
-    return launch_row_from_tiled<T>(p.logn, row_variant(d->dtype, p.logn), rl, rs, twN, int(M), st, nb);
+    // An unrotated row window (crops: adjoints, the Bluestein convolution) only transforms its own rows [off, off + len).
+    int row0 = 0, nrun = int(M);
+    AxisMap oy = to_map(d->out_y);
+    if (d->out_y.shift == 0 && d->out_y.len < M) {
+        row0 = int(d->out_y.off);
+        nrun = int(d->out_y.len);
+        oy = AxisMap{nrun, nrun, 0, 0};
+    }
+    RowLoadTiled<T> rl{W2, int(M), ltl, row0, nrun, 1, wstride};
+    RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), nrun, 1, T(d->scale), 1, oy, d->out_bstride};
+    return launch_row_from_tiled<T>(p.logn, row_variant(d->dtype, p.logn), rl, rs, twN, nrun, st, nb);
+}
+
+// ---------------------------------------------------------------- both axes not powers of two: 2-D Bluestein
+// The 2-D cyclic convolution with the separable chirp IS the fused chain: window(ifft2(fft2(pad(a)) * (B1 (x) B2))) with the
+// pad window [0, n) of MB on the way in and the same crop on the way out.
+static void blue2d_desc(pm_fft2_desc& dd, int dtype, int64_t M, int64_t N) {
+    memset(&dd, 0, sizeof dd);
+    const int64_t mb1 = blue_conv_len(M), mb2 = blue_conv_len(N);
+    dd.dtype = dtype;
+    dd.direction = -1;
+    dd.in_y = dd.out_y = pm_axis{mb1, M, 0, 0};
+    dd.in_x = dd.out_x = pm_axis{mb2, N, 0, 0};
+    dd.in_ld = dd.out_ld = N;
+    dd.scale = 1.0;   // 1 / (MB1 MB2) lives in the tables
+    dd.weight = 1.0;
+    dd.mul_kind = PM_MUL_SEPARABLE;
+}
+static size_t blue2d_fused_ws(int dtype, int64_t M, int64_t N) {
+    pm_fft2_desc dd;
+    blue2d_desc(dd, dtype, M, N);
+    FusedPlan fp;
+    return plan_fused(&dd, fp) ? fp.ws_bytes : 0;
+}
+
+template <typename T>
+static int blue2d_run(const pm_fft2_desc* d, const void* in, void* out, void* ws, hipStream_t st) {
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    int err = 0;
+    const cx<T>* t1 = blue_tables<T>(M, &err);
+    if (!t1) return err;
+    const cx<T>* t2 = blue_tables<T>(N, &err);
+    if (!t2) return err;
+    const size_t arr = (size_t(M) * size_t(N) * sizeof(cx<T>) + 255) & ~size_t(255);
+    cx<T>* a = reinterpret_cast<cx<T>*>(ws);
+    cx<T>* c = reinterpret_cast<cx<T>*>(static_cast<char*>(ws) + arr);
+    void* fws = static_cast<char*>(ws) + 2 * arr;
+    Blue2dIn<T> bi{in, d->in_ld, to_map(d->in_y), to_map(d->in_x), d->direction > 0 ? 1 : 0, (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
+    int rc = blue_pre2d<T>(bi, a, t1, t2, st);
+    if (rc) return rc;
+    pm_fft2_desc dd;
+    blue2d_desc(dd, d->dtype, M, N);
+    dd.mul = t1 + M;
+    dd.mul_x = t2 + N;
+    FusedPlan fp;
+    if (!plan_fused(&dd, fp)) return fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: no fused plan for the Bluestein convolution");
+    rc = fused_run_chunk<T>(&dd, fp, a, c, fws, st, 1);
+    if (rc) return rc;
+    const ColStoreNat<T> cs = make_colstore<T>(d, out);
+    return blue_post2d<T>(c, int(M), int(N), t1, t2, cs, st);
 }
 
 template <typename T>
@@ -517,7 +635,7 @@ static int check_fft2(const pm_fft2_desc* d) {
 
 template <typename T>
 static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, const pm_axis* to, double scale,
-                    const void* in, int64_t in_ld, void* out, int64_t out_ld, hipStream_t st) {
+                    const void* in, int64_t in_ld, void* out, int64_t out_ld, hipStream_t st, void* blue_ws = nullptr) {
     const int64_t n = ti->n;
     const int lg = engine_log2(n);
     const int conj = direction > 0 ? 1 : 0;
@@ -530,9 +648,10 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
             RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), in_ld, to_map(*ti), int(batch), conj, 0};
             return launch_row_nat<T>(lg, row_variant(sizeof(T) == 4 ? PM_C64 : PM_C128, lg), lp, sp, tw, int(batch), 0, st);
         }
+        DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), in_ld, 1, to_map(*ti), int(batch), conj};
+        if (blue_ws) return blue_rows<T>(di, nullptr, 0, blue_ws, st, &sp);
         const cx<double>* tw = twiddles_f64(n, &err);
         if (!tw) return err;
-        DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), in_ld, 1, to_map(*ti), int(batch), conj};
         return direct_rows_out<T>(di, sp, tw, st);
     }
     // axis == 0: sequences are the `batch` columns
@@ -556,9 +675,10 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
         ColLoadNat<T> cl{reinterpret_cast<const cx<T>*>(in), in_ld, to_map(*ti), int(batch), conj, vec};
         return launch_col_nat<T>(lg, tuning().col_var, cl, cs, tw, ntiles, 1, st);
     }
+    DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), 1, in_ld, to_map(*ti), int(batch), conj};
+    if (blue_ws) return blue_cols<T>(di, cs, blue_ws, st);
     const cx<double>* tw = twiddles_f64(n, &err);
     if (!tw) return err;
-    DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), 1, in_ld, to_map(*ti), int(batch), conj};
     return direct_cols<T>(di, cs, tw, st);
 }
 
@@ -675,9 +795,8 @@ int pm_fft2_time_passes(const pm_fft2_desc* d, const void* in, void* out, void* 
     return rc;
 }
 
-int pm_fft1(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in, const pm_axis* t_out,
-            double scale, const void* in, int64_t in_ld, void* out, int64_t out_ld, void* stream) {
-    if (!t_in || !t_out || !in || !out) return fail(PM_ERR_ARG, "pm_fft1: null argument");
+static int check_fft1(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in, const pm_axis* t_out) {
+    if (!t_in || !t_out) return fail(PM_ERR_ARG, "pm_fft1: null argument");
     if (dtype != PM_C64 && dtype != PM_C128) return fail(PM_ERR_ARG, "pm_fft1: dtype must be PM_C64 or PM_C128");
     if (direction != 1 && direction != -1) return fail(PM_ERR_ARG, "pm_fft1: direction must be -1 or +1");
     if (axis != 0 && axis != 1) return fail(PM_ERR_ARG, "pm_fft1: axis must be 0 or 1");
@@ -687,10 +806,34 @@ int pm_fft1(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const
     if (t_in->n != t_out->n) return fail(PM_ERR_ARG, "pm_fft1: t_in.n != t_out.n");
     if (engine_log2(t_in->n) < 0 && t_in->n > (int64_t(1) << 15))
         return fail(PM_ERR_UNSUPPORTED, "pm_fft1: length %lld not supported", (long long)t_in->n);
+    return 0;
+}
+
+int pm_fft1(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in, const pm_axis* t_out,
+            double scale, const void* in, int64_t in_ld, void* out, int64_t out_ld, void* stream) {
+    return pm_fft1_ws(dtype, direction, axis, batch, t_in, t_out, scale, in, in_ld, out, out_ld, nullptr, 0, stream);
+}
+
+size_t pm_fft1_workspace(int32_t dtype, int32_t axis, int64_t batch, int64_t n) {
+    if ((dtype != PM_C64 && dtype != PM_C128) || batch <= 0 || !use_blue(n)) return 0;
+    const size_t es = dtype == PM_C64 ? 8 : 16;
+    return axis == 1 ? blue_rows_scratch(es, batch, n) : blue_cols_scratch(es, batch, n);
+}
+
+int pm_fft1_ws(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in, const pm_axis* t_out,
+               double scale, const void* in, int64_t in_ld, void* out, int64_t out_ld, void* workspace, size_t workspace_bytes,
+               void* stream) {
+    int rc = check_fft1(dtype, direction, axis, batch, t_in, t_out);
+    if (rc) return rc;
+    if (!in || !out) return fail(PM_ERR_ARG, "pm_fft1: null argument");
     if (batch == 0) return 0;
+    // a workspace of pm_fft1_workspace() bytes puts non-power-of-two lengths on the Bluestein path; without one they run on
+    // the direct O(n^2) kernel
+    const size_t need = pm_fft1_workspace(dtype, axis, batch, t_in->n);
+    void* bws = (need && workspace && workspace_bytes >= need && reinterpret_cast<uintptr_t>(workspace) % 256 == 0) ? workspace : nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == PM_C64) return fft1_run<float>(direction, axis, batch, t_in, t_out, scale, in, in_ld, out, out_ld, st);
-    return fft1_run<double>(direction, axis, batch, t_in, t_out, scale, in, in_ld, out, out_ld, st);
+    if (dtype == PM_C64) return fft1_run<float>(direction, axis, batch, t_in, t_out, scale, in, in_ld, out, out_ld, st, bws);
+    return fft1_run<double>(direction, axis, batch, t_in, t_out, scale, in, in_ld, out, out_ld, st, bws);
 }
 
 }  // extern "C"

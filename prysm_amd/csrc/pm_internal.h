@@ -36,6 +36,31 @@ int direct_rows_out(const DirectIn<T>& in, const RowStoreNat<T>& out, const cx<d
 template <typename T>
 int direct_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, const cx<double>* tw, hipStream_t st);
 
+// Bluestein path (bluestein.hip): lengths that are not powers of two, up to 4096, as engine transforms of length
+// MB = 2^ceil(log2(2n - 1)).  Same contracts as direct_rows / direct_cols; `scratch` (256 B aligned) holds
+// blue_rows_scratch / blue_cols_scratch bytes.  blue_tables (capi.hip plan cache): [w (n) | B (MB)], see bluestein.h.
+template <typename T> const cx<T>* blue_tables(int64_t n, int* err);
+size_t blue_rows_scratch(size_t es, int64_t nseq, int64_t n);
+size_t blue_cols_scratch(size_t es, int64_t ncols, int64_t n);
+// `o` (1-D API): the result goes through that output view (window / rotation, scale, conj) instead of to out[seq*ld + k]
+template <typename T>
+int blue_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, void* scratch, hipStream_t st, const RowStoreNat<T>* o = nullptr);
+template <typename T>
+int blue_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, void* scratch, hipStream_t st);
+
+// both axes at once (capi.hip blue2d_run): the chirp multiplies around ONE fused fft2 -> x (B1 (x) B2) -> ifft2 chain of size
+// MB1 x MB2 (the 2-D cyclic convolution with the separable chirp)
+template <typename T>
+struct Blue2dIn {
+    const void* src;   // cx<T>* or T* (real)
+    int64_t ld;
+    AxisMap ay, ax;
+    int conj, real;
+};
+template <typename T> int blue_pre2d(const Blue2dIn<T>& in, cx<T>* a, const cx<T>* w1, const cx<T>* w2, hipStream_t st);
+template <typename T>
+int blue_post2d(const cx<T>* t, int n1, int n2, const cx<T>* w1, const cx<T>* w2, const ColStoreNat<T>& out, hipStream_t st);
+
 // engine launchers (fft_row_*.hip / fft_col_*.hip); `var` = tuning variant (see fft_kernels.h)
 template <typename T> int launch_row_tiled(int logn, int var, const RowLoadNat<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t, int nbatch = 1);
@@ -69,6 +94,9 @@ struct Tuning {
     int fold = -1;           // radix-2 step of the column transform folded into the row pass: -1 auto, 0 never, 1 wherever legal
     int col_spread = 0;      // experiment: log2 of the stride permutation of column-pass sibling groups
     int col_skew = 0;        // experiment: start skew of every other column-pass workgroup, units of ~0.85 us
+    int blue_min = 96;        // shortest non-power-of-two length that takes the Bluestein path (shorter ones, and lengths
+                             // above 4096, run on the direct O(n^2) kernel); 0 disables the path
+    int blue_2d = 1;          // both axes on the Bluestein path: one fused fft2 x B ifft2 chain (1) or axis by axis (0)
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)
 };
@@ -94,6 +122,12 @@ inline int engine_log2(int64_t n) {  // log2(n) if n is a power of two the engin
     int l = 0;
     while ((int64_t(1) << l) < n) ++l;
     return l <= kEngineMaxLog ? l : -1;
+}
+
+// lengths the Bluestein path takes (bluestein.h: 2n - 1 must fit the engine's longest transform)
+inline bool use_blue(int64_t n) {
+    const int lo = tuning().blue_min;
+    return lo > 0 && engine_log2(n) < 0 && n >= lo && n <= 4096;
 }
 
 }  // namespace pm

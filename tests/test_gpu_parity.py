@@ -844,6 +844,76 @@ def test_numpy_operand_defers_to_wavefront_operators(pa):
     assert rel_max(array_to_true_numpy(wf), x) < TOL64
 
 
+@pytest.mark.parametrize('shape,dtype', [((1000, 1000), np.complex64), ((300, 500), np.complex128), ((1000, 1024), np.complex64),
+                                         ((1536, 9), np.complex128), ((97, 2000), np.complex64), ((4000, 130), np.complex128)])
+def test_bluestein_lengths(pa, shape, dtype):
+    """Lengths that are not powers of two (96 .. 4096) run on the FFT engine through Bluestein's identity (csrc/bluestein.hip):
+    against numpy, against the direct O(n^2) kernel (tuning blue_min = 0), for the focus family (pad / shift / crop / inverse),
+    real input, the |.|^2 epilogue and a stack."""
+    from prysm_amd import _lib, _ops
+    lib = _lib.load()
+    rng = np.random.default_rng(sum(shape))
+    tol = TOL32 if dtype == np.complex64 else TOL64
+    x = crandn(rng, shape, dtype)
+    want = np.fft.fft2(x.astype(np.complex128))
+    xd = torch.from_numpy(x).cuda()
+    got = _ops.fft2(xd, direction=-1, scale=1.0).cpu().numpy()
+    assert got.dtype == dtype and rel_max(got, want) < tol
+    try:
+        lib.pm_set_tuning(b'blue_min', 0)
+        direct = _ops.fft2(xd, direction=-1, scale=1.0).cpu().numpy()
+    finally:
+        lib.pm_set_tuning(b'blue_min', 96)
+    assert rel_max(got, direct) < 2 * tol
+    try:   # both axes on the path: one fused convolution chain (default) or axis by axis
+        lib.pm_set_tuning(b'blue_2d', 0)
+        per_axis = _ops.fft2(xd, direction=-1, scale=1.0).cpu().numpy()
+    finally:
+        lib.pm_set_tuning(b'blue_2d', 1)
+    assert rel_max(per_axis, want) < tol
+    inv = _ops.fft2(torch.from_numpy(got).cuda(), direction=+1, scale=1.0 / (shape[0] * shape[1])).cpu().numpy()
+    assert rel_max(inv, x) < 2 * tol
+    # the focus family on these shapes: pad to Q = 2 (non power-of-two padded size), shifts, adjoint crop
+    small = x[:shape[0] // 2, :shape[1] // 2]
+    ref = O.focus(small.astype(np.complex128), 2)
+    assert rel_max(tonp(pa.propagation.focus(small, 2)), ref) < tol
+    assert rel_max(tonp(pa.propagation.focus_intensity(small, 2)), O.intensity(ref)) < 2 * tol
+    g = crandn(rng, ref.shape, dtype)
+    assert rel_max(tonp(pa.propagation.focus_adjoint(g, 2)), O.focus_adjoint(g.astype(np.complex128), 2)) < tol
+    assert rel_max(tonp(pa.propagation.unfocus(x, 1)), O.unfocus(x.astype(np.complex128), 1)) < tol
+    # real input read as it is, and a stack of fields (run field by field on this path)
+    xr = np.ascontiguousarray(x.real)
+    assert rel_max(_ops.fft2(torch.from_numpy(xr).cuda(), direction=-1, scale=1.0).cpu().numpy(), np.fft.fft2(xr.astype(np.float64))) < tol
+    st = crandn(rng, (2,) + shape, dtype)
+    gs = _ops.fft2(torch.from_numpy(st).cuda(), direction=-1, scale=1.0).cpu().numpy()
+    assert max(rel_max(gs[b], np.fft.fft2(st[b].astype(np.complex128))) for b in range(2)) < tol
+
+
+@pytest.mark.parametrize('dtype', [np.complex64, np.complex128])
+def test_bluestein_fft1(pa, dtype):
+    """pm_fft1_ws: batched 1-D transforms of non power-of-two length along either axis, zero padded to n, cropped output."""
+    from prysm_amd import _ops
+    rng = np.random.default_rng(77)
+    tol = TOL32 if dtype == np.complex64 else TOL64
+    x = crandn(rng, (300, 1000), dtype)
+    xd = torch.from_numpy(x).cuda()
+    x128 = x.astype(np.complex128)
+    assert rel_max(_ops.fft1(xd, axis=1).cpu().numpy(), np.fft.fft(x128, axis=1)) < tol
+    assert rel_max(_ops.fft1(xd, axis=0).cpu().numpy(), np.fft.fft(x128, axis=0)) < tol
+    assert rel_max(_ops.fft1(xd, n=1500, axis=1, direction=+1, scale=1 / 1500).cpu().numpy(), np.fft.ifft(x128, 1500, axis=1)) < tol
+    assert rel_max(_ops.fft1(xd, n=777, axis=0, out_len=100, out_off=30).cpu().numpy(), np.fft.fft(x128, 777, axis=0)[30:130]) < tol
+    assert rel_max(_ops.fft1(xd, n=600, axis=1).cpu().numpy(), np.fft.fft(x128, 600, axis=1)) < tol   # truncation
+
+
+def test_bluestein_angular_spectrum_non_pow2(pa):
+    """free space on a 1000^2 grid (two Bluestein transforms with the transfer function in between) against the oracle."""
+    rng = np.random.default_rng(1000)
+    x = crandn(rng, (1000, 1000))
+    ref = O.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1)
+    got = tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1))
+    assert rel_max(got, ref) < TOL64
+
+
 def test_randomised_differential_fuzz(pa):
     """tools/fuzz_fft2.py: random sizes / windows / rotations / crops / input kinds / stacks / epilogues / multipliers /
     precisions / fold settings of pm_fft2 and the fused chain against numpy (a fixed seed keeps it reproducible)."""

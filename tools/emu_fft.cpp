@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "fft_io.h"
+#include "bluestein.h"
 
 using namespace pm;
 typedef long double ld;
@@ -513,7 +514,172 @@ static void test_tw_lds() {
     report(buf, double(bad), 0.5);
 }
 
+// --- Bluestein (bluestein.h / bluestein.hip): a non-power-of-two length n through engine transforms of length MB.  Rows run
+// the emulated engine passes with exactly the load / store descriptors blue_rows builds; columns restate the natural column
+// pass by its contract (pad window on the load, crop window on the store, conj-in / conj-out inverse) --------------------
+template <typename T, int LOGMB, int BO>
+static void test_blue_rows(int n, int nseq, int in_len, int in_off, int in_shift, bool conj_in, bool real_in) {
+    using C = FftCfg<T, LOGMB, 1, 1, BO, 1>;
+    const int mb = blue_conv_len(n);
+    if (mb != C::N) { printf("blue rows: MB mismatch %d vs %d\n", mb, C::N); ++g_fail; return; }
+    std::mt19937 rng(n * 7 + nseq);
+    std::normal_distribution<double> nd;
+    std::vector<cx<T>> x(size_t(nseq) * in_len);
+    std::vector<T> xr(size_t(nseq) * in_len);
+    for (auto& e : x) e = {T(nd(rng)), T(nd(rng))};
+    for (auto& e : xr) e = T(nd(rng));
+    std::vector<cx<T>> tab;
+    blue_make_tables<T>(n, mb, tab);
+    const cx<T>*w = tab.data(), *bf = tab.data() + n;
+    BlueIn<T> in{real_in ? (const void*)xr.data() : (const void*)x.data(), in_len, 1, AxisMap{n, in_len, in_off, in_shift}, conj_in ? 1 : 0,
+                 real_in ? 1 : 0};
+    std::vector<cx<T>> a(size_t(nseq) * n), b(size_t(nseq) * mb), out(size_t(nseq) * n, cx<T>{T(-7), T(-7)});
+    for (int s = 0; s < nseq; ++s)
+        for (int j = 0; j < n; ++j) a[size_t(s) * n + j] = cmul(blue_fetch(in, s, j), w[j]);
+    auto tw = make_tw<T>(mb);
+    const int nblk = (nseq + C::BO - 1) / C::BO;
+    {
+        RowLoadNat<T> lp{a.data(), n, AxisMap{mb, n, 0, 0}, nseq, 0, 0};
+        RowStoreNat<T> sp{b.data(), mb, AxisMap{mb, mb, 0, 0}, nseq, 0, T(1), 0, AxisMap{1, 1, 0, 0}};
+        emu_kernel<C, false>(nblk, lp, sp, tw.data());
+    }
+    for (int s = 0; s < nseq; ++s)
+        for (int k = 0; k < mb; ++k) b[size_t(s) * mb + k] = cmul(b[size_t(s) * mb + k], bf[k]);
+    {
+        RowLoadNat<T> lp{b.data(), mb, AxisMap{mb, mb, 0, 0}, nseq, 1, 0};
+        RowStoreNat<T> sp{out.data(), n, AxisMap{mb, n, 0, 0}, nseq, 1, T(1), 0, AxisMap{1, 1, 0, 0}};
+        emu_kernel<C, false>(nblk, lp, sp, tw.data());
+    }
+    for (int s = 0; s < nseq; ++s)
+        for (int k = 0; k < n; ++k) out[size_t(s) * n + k] = cmul(out[size_t(s) * n + k], w[k]);
+    const ld pi = acosl(-1.0L);
+    double err = 0, nrm = 0;
+    for (int s = 0; s < nseq; ++s) {
+        std::vector<cld> p(n, cld(0, 0));
+        for (int i = 0; i < n; ++i) {
+            int pp = (i + in_shift) % n, q = pp - in_off;
+            if (q >= 0 && q < in_len) {
+                p[i] = real_in ? cld(xr[size_t(s) * in_len + q], 0) : cld(x[size_t(s) * in_len + q].x, x[size_t(s) * in_len + q].y);
+                if (conj_in) p[i] = std::conj(p[i]);
+            }
+        }
+        for (int k = 0; k < n; ++k) {
+            cld acc(0, 0);
+            for (int j = 0; j < n; ++j) {
+                ld ang = -2 * pi * ld((int64_t(j) * k) % n) / n;
+                acc += p[j] * cld(cosl(ang), sinl(ang));
+            }
+            cx<T> got = out[size_t(s) * n + k];
+            err = fmax(err, (double)std::abs(acc - cld(got.x, got.y)));
+            nrm = fmax(nrm, (double)std::abs(acc));
+        }
+    }
+    char buf[128];
+    snprintf(buf, sizeof buf, "bluestein rows %s n=%d MB=%d nseq=%d len=%d off=%d sh=%d conj=%d real=%d", sizeof(T) == 4 ? "c64" : "c128", n,
+             mb, nseq, in_len, in_off, in_shift, int(conj_in), int(real_in));
+    report(buf, err / nrm, sizeof(T) == 4 ? 3e-6 : 1e-14);
+}
+
+// natural column pass by contract: logical sequence p[i] = (ay_in.map(i) >= 0 ? src[map][c] : 0), conj-in, DFT, conj-out, scale,
+// bin k stored at row ay_out.map(k)
+template <typename T>
+static void naive_col_pass(const std::vector<cx<T>>& src, AxisMap ain, std::vector<cx<T>>& dst, AxisMap aout, int ncols, bool inv) {
+    const int N = ain.n;
+    const ld pi = acosl(-1.0L);
+    for (int c = 0; c < ncols; ++c) {
+        std::vector<cld> p(N, cld(0, 0));
+        for (int i = 0; i < N; ++i) {
+            const int q = ain.map(i);
+            if (q >= 0) p[i] = cld(src[size_t(q) * ncols + c].x, src[size_t(q) * ncols + c].y);
+        }
+        for (int k = 0; k < N; ++k) {
+            const int q = aout.map(k);
+            if (q < 0) continue;
+            cld acc(0, 0);
+            for (int j = 0; j < N; ++j) {
+                ld ang = (inv ? 2 : -2) * pi * ld((int64_t(j) * k) % N) / N;
+                acc += p[j] * cld(cosl(ang), sinl(ang));
+            }
+            dst[size_t(q) * ncols + c] = {T(acc.real()), T(acc.imag())};
+        }
+    }
+}
+
+template <typename T>
+static void test_blue_cols(int n, int ncols, int in_rows, int in_off, int in_shift, int out_len, int out_off, int out_shift, int epilogue) {
+    const int mb = blue_conv_len(n);
+    std::mt19937 rng(n * 11 + ncols);
+    std::normal_distribution<double> nd;
+    std::vector<cx<T>> W(size_t(in_rows) * ncols);
+    for (auto& e : W) e = {T(nd(rng)), T(nd(rng))};
+    std::vector<cx<T>> tab;
+    blue_make_tables<T>(n, mb, tab);
+    const cx<T>*w = tab.data(), *bf = tab.data() + n;
+    BlueIn<T> in{W.data(), 1, ncols, AxisMap{n, in_rows, in_off, in_shift}, 0, 0};
+    std::vector<cx<T>> a(size_t(n) * ncols), b(size_t(mb) * ncols);
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < ncols; ++c) a[size_t(i) * ncols + c] = cmul(blue_fetch(in, c, i), w[i]);
+    naive_col_pass<T>(a, AxisMap{mb, n, 0, 0}, b, AxisMap{mb, mb, 0, 0}, ncols, false);
+    for (int k = 0; k < mb; ++k)
+        for (int c = 0; c < ncols; ++c) b[size_t(k) * ncols + c] = cmul(b[size_t(k) * ncols + c], bf[k]);
+    naive_col_pass<T>(b, AxisMap{mb, mb, 0, 0}, a, AxisMap{mb, n, 0, 0}, ncols, true);
+    // epilogue: scale 0.5, conj, crop / rotate rows, |.|^2 optional
+    std::vector<cx<T>> oc(size_t(out_len) * ncols, cx<T>{T(-7), T(-7)});
+    std::vector<T> orl(size_t(out_len) * ncols, T(-7));
+    ColStoreNat<T> cs{};
+    cs.dst = epilogue ? (void*)orl.data() : (void*)oc.data();
+    cs.ld = ncols;
+    cs.ay = AxisMap{n, out_len, out_off, out_shift};
+    cs.ax = AxisMap{ncols, ncols, 0, 0};
+    cs.conj = 1;
+    cs.epilogue = epilogue;
+    cs.scale = T(0.5);
+    cs.weight = T(1);
+    cs.mul_kind = MUL_NONE;
+    for (int k = 0; k < n; ++k)
+        for (int c = 0; c < ncols; ++c) store_one(cs, k, c, cmul(a[size_t(k) * ncols + c], w[k]));
+    const ld pi = acosl(-1.0L);
+    double err = 0, nrm = 0;
+    for (int c = 0; c < ncols; ++c) {
+        std::vector<cld> p(n, cld(0, 0));
+        for (int i = 0; i < n; ++i) {
+            int pp = (i + in_shift) % n, q = pp - in_off;
+            if (q >= 0 && q < in_rows) p[i] = cld(W[size_t(q) * ncols + c].x, W[size_t(q) * ncols + c].y);
+        }
+        for (int k = 0; k < n; ++k) {
+            int q = (k + out_shift) % n - out_off;
+            if (q < 0 || q >= out_len) continue;
+            cld acc(0, 0);
+            for (int j = 0; j < n; ++j) {
+                ld ang = -2 * pi * ld((int64_t(j) * k) % n) / n;
+                acc += p[j] * cld(cosl(ang), sinl(ang));
+            }
+            acc = std::conj(acc * ld(0.5));
+            if (epilogue) {
+                err = fmax(err, fabs(double(std::norm(acc)) - double(orl[size_t(q) * ncols + c])));
+                nrm = fmax(nrm, double(std::norm(acc)));
+            } else {
+                cx<T> got = oc[size_t(q) * ncols + c];
+                err = fmax(err, (double)std::abs(acc - cld(got.x, got.y)));
+                nrm = fmax(nrm, (double)std::abs(acc));
+            }
+        }
+    }
+    char buf[128];
+    snprintf(buf, sizeof buf, "bluestein cols %s n=%d MB=%d ncols=%d rows=%d off=%d sh=%d out=%d/%d/%d epi=%d", sizeof(T) == 4 ? "c64" : "c128",
+             n, mb, ncols, in_rows, in_off, in_shift, out_len, out_off, out_shift, epilogue);
+    report(buf, err / nrm, sizeof(T) == 4 ? 3e-6 : 1e-13);
+}
+
 int main() {
+    test_blue_rows<float, 8, 16>(100, 5, 100, 0, 0, false, false);
+    test_blue_rows<float, 8, 16>(127, 3, 60, 34, 63, true, false);      // padded (Q ~ 2) + ifftshift rotation + inverse
+    test_blue_rows<float, 9, 8>(129, 4, 129, 0, 64, false, true);       // real input, MB = 512
+    test_blue_rows<double, 8, 16>(97, 3, 97, 0, 48, false, false);      // prime length
+    test_blue_rows<double, 11, 2>(1000, 2, 500, 250, 500, true, false);
+    test_blue_cols<float>(100, 6, 100, 0, 50, 100, 0, 50, 0);
+    test_blue_cols<float>(97, 5, 40, 29, 48, 60, 18, 48, 1);            // padded rows, crop, |.|^2
+    test_blue_cols<double>(150, 3, 150, 0, 0, 150, 0, 75, 0);
     test_tw_lds<float, 5>();
     test_tw_lds<float, 8>();
     test_tw_lds<float, 11>();

@@ -141,7 +141,7 @@ def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     lib = L.load()
-    sizes = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 3, 5, 9, 12, 20, 36, 100]
+    sizes = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 3, 5, 9, 12, 20, 36, 100, 96, 127, 200, 384, 1000]   # engine, direct and Bluestein lengths
     worst = 0.0
     nfail = 0
     for case in range(ncases):
