@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PM_VERSION 104 /* 0.1.0 */
+#define PM_VERSION 105 /* 0.1.0 */
 
 /* dtype codes */
 enum { PM_C64 = 0, PM_C128 = 1, PM_F32 = 2, PM_F64 = 3, PM_BOOL = 4 };
@@ -195,6 +195,22 @@ int pm_abs2(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t i
  * incoherent sum of the polychromatic recipe over a batch of intensities. */
 int pm_sum_modes(int32_t dtype, int64_t nmodes, int64_t rows, int64_t cols, const void* modes, int64_t mode_stride,
                  int64_t modes_ld, const double* weights, int32_t accumulate, void* out, int64_t out_ld, void* stream);
+
+/* Encircled energy of a PSF from its centre-normalised MTF (Baliga & Cohn 1988):
+ *   out[r] = radius_r * df^2 * sum_ij mtf[i][j] * J1(2 pi radius_r nu_ij) / nu_ij,
+ * nu = hypot of the FFT-centred frequency grid of spacing df (cy/mm; the zero bin is nudged to 1e-16 like the reference),
+ * radii in mm in a HOST array (the reference divides its micron radii by 1e3), `out` a DEVICE array of nradii doubles.
+ * Replaces otf._encircled_energy_geometry / _encircled_energy_core (prysm/otf.py:319-343,390-414) for every radius of
+ * otf.encircled_energy (otf.py:346-387) in ceil(nradii / 8) passes over the MTF.  mtf is REAL (PM_C64: float, PM_C128: double);
+ * J1 and the sums are fp64, reduced in a fixed order (reproducible).  workspace: pm_encircled_energy_workspace() bytes. */
+size_t pm_encircled_energy_workspace(void);
+int pm_encircled_energy(int32_t dtype, int64_t rows, int64_t cols, const void* mtf, int64_t mtf_ld, double df, int64_t nradii,
+                        const double* radii_mm, double* out, void* workspace, size_t workspace_bytes, void* stream);
+/* MTF-plane gradient of the encircled energies: mtf_bar[i][j] = sum_r ee_bar[r] * radius_r * J1(2 pi radius_r nu_ij) / nu_ij * df^2
+ * (otf.encircled_energy_adjoint, prysm/otf.py:417-472; the caller routes it through mtf_from_psf_adjoint).  radii_mm and
+ * ee_bar are HOST arrays; mtf_bar is a REAL rows x cols device array of the precision that goes with dtype. */
+int pm_encircled_energy_adjoint(int32_t dtype, int64_t rows, int64_t cols, double df, int64_t nradii, const double* radii_mm,
+                                const double* ee_bar, void* mtf_bar, int64_t mtf_bar_ld, void* stream);
 
 /* Resample a measured complex focal-plane-mask map at focal coordinates: scipy.ndimage.map_coordinates(order 0 | 1,
  * mode='nearest') of the real and imaginary parts at row = (yf - center_y)/dx + map_rows/2, col = (xf - center_x)/dx +

@@ -237,6 +237,42 @@ def sum_modes(modes, weights, out=None, accumulate=False):
     return out
 
 
+def encircled_energy(mtf, df, radii_mm):
+    """EE(r) for every r of radii_mm (host floats, mm) from the real centre-normalised MTF (pm_encircled_energy):
+    a float64 device vector."""
+    lib = L.load()
+    if mtf.dim() != 2 or mtf.dtype not in (torch.float32, torch.float64):
+        raise TypeError('encircled_energy: the MTF is a real 2-D float32 / float64 array')
+    if mtf.stride(-1) != 1:
+        mtf = mtf.contiguous()
+    rows, cols = mtf.shape
+    r = [float(v) for v in radii_mm]
+    arr = (ctypes.c_double * max(len(r), 1))(*r)
+    out = torch.empty(len(r), dtype=torch.float64, device=mtf.device)
+    nbytes = lib.pm_encircled_energy_workspace()
+    ws = L.workspace(nbytes)
+    code = L.PM_C64 if mtf.dtype == torch.float32 else L.PM_C128
+    L.check(lib.pm_encircled_energy(code, rows, cols, L.ptr(mtf), mtf.stride(0), float(df), len(r), arr, L.ptr(out), L.ptr(ws),
+                                    ws.numel(), L.stream_ptr()))
+    return out
+
+
+def encircled_energy_adjoint(shape, df, radii_mm, ee_bar, rdtype):
+    """sum_r ee_bar_r r J1(2 pi r nu) / nu df^2 on the frequency grid of `shape` (pm_encircled_energy_adjoint)."""
+    lib = L.load()
+    rows, cols = shape
+    r = [float(v) for v in radii_mm]
+    b = [float(v) for v in ee_bar]
+    if len(r) != len(b):
+        raise ValueError('one ee_bar value per radius is required')
+    ra = (ctypes.c_double * max(len(r), 1))(*r)
+    ba = (ctypes.c_double * max(len(b), 1))(*b)
+    out = torch.empty((rows, cols), dtype=rdtype, device=L.device())
+    code = L.PM_C64 if rdtype == torch.float32 else L.PM_C128
+    L.check(lib.pm_encircled_energy_adjoint(code, rows, cols, float(df), len(r), ra, ba, L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
 def sample_map(measurement, dx, center, xf, yf, fill=1.0, order=1):
     """Complex map resampled at focal coordinates (pm_sample_map): map_coordinates(order 0 | 1, mode='nearest') inside the
     measured extent, `fill` (scalar or array of the shape of xf) outside.  xf / yf broadcast against each other."""

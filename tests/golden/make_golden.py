@@ -281,6 +281,38 @@ def next_rows():
     np.savez_compressed(os.path.join(HERE, 'next_rows.npz'), **out)
 
 
+def encircled():
+    """otf.encircled_energy (+ adjoint) on an aberrated circular-pupil PSF and on a rectangular random PSF."""
+    out = {}
+    x, y = coordinates.make_xy_grid(64, diameter=10)
+    r, t = coordinates.cart_to_polar(x, y)
+    amp = geometry.circle(5, r)
+    opd = polynomials.hopkins(0, 4, 0, r / 5, t, 1) * 150
+    wf = propagation.Wavefront.from_amp_and_phase(amp, opd, HeNe, x[0, 1] - x[0, 0])
+    psf = wf.focus(100, Q=2).intensity
+    out['psf'] = psf.data
+    out['psf_dx'] = psf.dx
+    radii = np.array([1.0, 2.5, 5.0, 7.72, 10.0, 15.0, 20.0, 30.0, 40.0, 55.0])   # more than one 8-radius pass
+    out['radii'] = radii
+    out['ee_scalar'] = potf.encircled_energy(psf, psf.dx, 7.72)
+    out['ee_many'] = potf.encircled_energy(psf.data, psf.dx, radii)
+    rng = np.random.default_rng(346)
+    bar = rng.standard_normal(radii.size)
+    out['ee_bar'] = bar
+    # the adjoint divides by |FT(psf)| (otf.py:238): a noiseless FFT PSF has exact zeros beyond the cutoff (NaN in the
+    # reference), so the adjoint cases carry a small detector-like pedestal
+    noisy = psf.data + 1e-4 * psf.data.max() * rng.random(psf.data.shape)
+    out['psf_noisy'] = noisy
+    out['ee_noisy'] = potf.encircled_energy(noisy, psf.dx, radii)
+    out['ee_adj_many'] = potf.encircled_energy_adjoint(bar, psf=noisy, dx=psf.dx, radius=radii)
+    out['ee_adj_scalar'] = potf.encircled_energy_adjoint(0.7, psf=noisy, dx=psf.dx, radius=12.0)
+    rect = rng.random((40, 56))
+    out['rect'] = rect
+    out['rect_ee'] = potf.encircled_energy(rect, 0.8, radii[:3])
+    out['rect_adj'] = potf.encircled_energy_adjoint(bar[:3], psf=rect, dx=0.8, radius=radii[:3])
+    np.savez_compressed(os.path.join(HERE, 'encircled.npz'), **out)
+
+
 def multires():
     """SURVEY 8(f) rank 2, second half: prepare_multiresolution + to_fpm_and_back_multiresolution(+adjoint), thin_lens_adjoint."""
     out = {}
@@ -349,6 +381,10 @@ def precision32():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1:   # only the named groups
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     fft_family()
     padcrop()
     angular()
@@ -358,6 +394,7 @@ if __name__ == '__main__':
     precision32()
     next_rows()
     multires()
+    encircled()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)))

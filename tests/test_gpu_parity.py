@@ -731,6 +731,35 @@ def test_otf_adjoints_golden(pa, golden):
     assert rel_max(tonp(otf.mtf_from_psf_adjoint(g['otf_mtf_bar'], data=data)), g['otf_mtf_adj']) < TOL64
 
 
+def test_encircled_energy_golden_and_oracle(pa, golden):
+    """otf.encircled_energy (+ adjoint; pm_encircled_energy: Bessel-kernel reduction over the MTF, 8 radii per pass) against
+    the reference's outputs, and against the oracle on a larger PSF in both precisions."""
+    from prysm_amd import otf
+    g = golden('encircled')
+    dx, radii = float(g['psf_dx']), g['radii']
+    assert abs(float(tonp(otf.encircled_energy(g['psf'], dx, 7.72))) - float(g['ee_scalar'])) < 1e-11
+    assert rel_max(tonp(otf.encircled_energy(g['psf'], dx, radii)), g['ee_many']) < TOL64
+    ee, data = otf.encircled_energy(g['psf_noisy'], dx, radii, return_more=True)
+    assert rel_max(tonp(ee), g['ee_noisy']) < TOL64
+    assert rel_max(tonp(otf.encircled_energy_adjoint(g['ee_bar'], psf=g['psf_noisy'], dx=dx, radius=radii)), g['ee_adj_many']) < 1e-9
+    assert rel_max(tonp(otf.encircled_energy_adjoint(g['ee_bar'], dx=dx, radius=radii, data=data)), g['ee_adj_many']) < 1e-9
+    assert rel_max(tonp(otf.encircled_energy_adjoint(0.7, psf=g['psf_noisy'], dx=dx, radius=12.0)), g['ee_adj_scalar']) < 1e-9
+    assert rel_max(tonp(otf.encircled_energy(g['rect'], 0.8, radii[:3])), g['rect_ee']) < TOL64
+    assert rel_max(tonp(otf.encircled_energy_adjoint(g['ee_bar'][:3], psf=g['rect'], dx=0.8, radius=radii[:3])), g['rect_adj']) < 1e-9
+    # a 1024^2 PSF (config-1 style pupil, Q = 2), float64 and float32
+    x = np.arange(-256, 256) * (10 / 512)
+    r = np.hypot(*np.meshgrid(x, x))
+    psf = np.abs(O.focus((r <= 5).astype(np.complex128), 2)) ** 2
+    psf_dx = 100 * O.HeNe / (10 / 512 * 1024)
+    rr = [2.0, 7.72, 15.0, 40.0]
+    want = O.encircled_energy(psf, psf_dx, rr)
+    assert rel_max(tonp(otf.encircled_energy(psf, psf_dx, rr)), want) < TOL64
+    got32 = tonp(otf.encircled_energy(psf.astype(np.float32), psf_dx, rr))
+    assert rel_max(got32, want) < 1e-5
+    with pytest.raises(ValueError):
+        otf.encircled_energy_adjoint(1.0, radius=3.0, data=data)   # dx is required with data (otf.py:451-452)
+
+
 def test_fft_facade_numpy_semantics(pa):
     """The module-like fft object handed to prysm's BackendShim: numpy semantics (norm modes, n / axis, odd-length shifts)."""
     from prysm_amd.mathops import FFTFacade

@@ -300,3 +300,23 @@ def test_otf_adjoints_oracle_vs_golden(golden):
     assert rel_max(O.mtf_from_psf_adjoint(g['otf_mtf_bar'], psf), g['otf_mtf_adj']) < 1e-12
     assert rel_max(O.ptf_from_psf_adjoint(g['otf_ptf_bar'], psf), g['otf_ptf_adj']) < 1e-12
     assert rel_max(O.otf_from_psf_adjoint(g['otf_otf_bar'], psf), g['otf_otf_adj']) < 1e-12
+
+
+def test_encircled_energy_oracle_vs_golden(golden):
+    """otf.encircled_energy (+ adjoint), prysm/otf.py:319-472, against the reference's outputs."""
+    g = golden('encircled')
+    dx, radii = float(g['psf_dx']), g['radii']
+    assert abs(O.encircled_energy(g['psf'], dx, 7.72) - float(g['ee_scalar'])) < TOL
+    assert rel_max(O.encircled_energy(g['psf'], dx, radii), g['ee_many']) < TOL
+    assert rel_max(O.encircled_energy(g['psf_noisy'], dx, radii), g['ee_noisy']) < TOL
+    assert rel_max(O.encircled_energy_adjoint(g['ee_bar'], g['psf_noisy'], dx, radii), g['ee_adj_many']) < TOL
+    assert rel_max(O.encircled_energy_adjoint(0.7, g['psf_noisy'], dx, 12.0), g['ee_adj_scalar']) < TOL
+    assert rel_max(O.encircled_energy(g['rect'], 0.8, radii[:3]), g['rect_ee']) < TOL
+    assert rel_max(O.encircled_energy_adjoint(g['ee_bar'][:3], g['rect'], 0.8, radii[:3]), g['rect_adj']) < TOL
+    # known answer: a diffraction-limited circular aperture encircles ~83.8 % inside the first Airy zero (1.22 lambda N)
+    x = np.arange(-128, 128) * (10 / 256)
+    r = np.hypot(*np.meshgrid(x, x))
+    psf = np.abs(O.focus((r <= 5).astype(np.complex128), 4)) ** 2
+    psf_dx = 100 * O.HeNe / (10 / 256 * 1024)       # efl * wvl / (dx * N), microns
+    ee = O.encircled_energy(psf, psf_dx, 1.22 * O.HeNe * 10)   # F/10
+    assert abs(ee - 0.838) < 5e-3
