@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PM_VERSION 105 /* 0.1.0 */
+#define PM_VERSION 106 /* 0.1.0 */
 
 /* dtype codes */
 enum { PM_C64 = 0, PM_C128 = 1, PM_F32 = 2, PM_F64 = 3, PM_BOOL = 4 };
@@ -217,11 +217,23 @@ int pm_encircled_energy_adjoint(int32_t dtype, int64_t rows, int64_t cols, doubl
  * map_cols/2; points outside [0, n-1] on either axis take fill (a rows x cols complex array) or, with fill NULL, the
  * constant fill_re + i fill_im.  xf / yf are REAL arrays of the precision that goes with dtype, addressed as
  * xf[r*xf_sy + c*xf_sx] (a stride of 0 broadcasts a coordinate vector).  prepare_measured_fpm
- * (prysm/propagation/coronagraph.py:128-200).  Other spline orders: PM_ERR_UNSUPPORTED. */
+ * (prysm/propagation/coronagraph.py:128-200).  Other spline orders: PM_ERR_UNSUPPORTED here, see pm_sample_spline. */
 int pm_sample_map(int32_t dtype, int32_t order, int64_t map_rows, int64_t map_cols, const void* map, int64_t map_ld, double dx,
                   double center_x, double center_y, int64_t rows, int64_t cols, const void* xf, int64_t xf_sy, int64_t xf_sx,
                   const void* yf, int64_t yf_sy, int64_t yf_sx, const void* fill, int64_t fill_ld, double fill_re, double fill_im,
                   void* out, int64_t out_ld, void* stream);
+
+/* Spline orders 2 .. 5 of the same resampling (scipy.ndimage.map_coordinates(order, mode='nearest') as prepare_measured_fpm
+ * calls it, prysm/propagation/coronagraph.py:193-194): pm_spline_prefilter pads the map by 12 edge samples and runs scipy's
+ * recursive B-spline prefilter along both axes in fp64 (once per measured map) into `coeff`, a complex128
+ * (map_rows + 24) x (map_cols + 24) array; pm_sample_spline evaluates the tensor-product B-spline at the focal coordinates,
+ * arguments as pm_sample_map with `coeff` in place of the map. */
+int pm_spline_prefilter(int32_t dtype, int32_t order, int64_t map_rows, int64_t map_cols, const void* map, int64_t map_ld,
+                        void* coeff, int64_t coeff_ld, void* stream);
+int pm_sample_spline(int32_t dtype, int32_t order, int64_t map_rows, int64_t map_cols, const void* coeff, int64_t coeff_ld,
+                     double dx, double center_x, double center_y, int64_t rows, int64_t cols, const void* xf, int64_t xf_sy,
+                     int64_t xf_sx, const void* yf, int64_t yf_sy, int64_t yf_sx, const void* fill, int64_t fill_ld,
+                     double fill_re, double fill_im, void* out, int64_t out_ld, void* stream);
 
 /* P = amp * exp(i * k * opd), k = 2 pi / (wavelength_um * 1e3) for opd in nm.
  * amp may be NULL (unit amplitude: phase_screen).  amp_dtype in {PM_F32, PM_F64, PM_BOOL}.

@@ -67,6 +67,9 @@ SIGNATURES = {
                                             c_i64, c_vp]),
     'pm_sample_map': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_vp, c_i64, c_f64, c_f64, c_f64, c_i64, c_i64, c_vp, c_i64, c_i64,
                               c_vp, c_i64, c_i64, c_vp, c_i64, c_f64, c_f64, c_vp, c_i64, c_vp]),
+    'pm_spline_prefilter': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'pm_sample_spline': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_vp, c_i64, c_f64, c_f64, c_f64, c_i64, c_i64, c_vp, c_i64, c_i64,
+                                 c_vp, c_i64, c_i64, c_vp, c_i64, c_f64, c_f64, c_vp, c_i64, c_vp]),
     'pm_pupil_synth': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i32, c_i64, c_vp, c_i64, c_f64, c_vp, c_i64, c_vp]),
     'pm_quadratic_phase': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_f64, c_vp, c_i64, c_vp]),
     'pm_as_tf_vectors': (c_i32, [c_i32, c_i64, c_i64, c_f64, c_f64, c_f64, c_vp, c_vp, c_vp]),

@@ -273,9 +273,23 @@ def encircled_energy_adjoint(shape, df, radii_mm, ee_bar, rdtype):
     return out
 
 
-def sample_map(measurement, dx, center, xf, yf, fill=1.0, order=1):
-    """Complex map resampled at focal coordinates (pm_sample_map): map_coordinates(order 0 | 1, mode='nearest') inside the
-    measured extent, `fill` (scalar or array of the shape of xf) outside.  xf / yf broadcast against each other."""
+def spline_prefilter(measurement, order):
+    """B-spline coefficients of a measured complex map for orders 2 .. 5 (pm_spline_prefilter): complex128,
+    (rows + 24, cols + 24) -- scipy's edge padding by 12 included."""
+    lib = L.load()
+    m = L.as_field(measurement)
+    if not m.is_complex():
+        m = m.to(L.cdtype_of(m))
+    m = m.contiguous()
+    coeff = torch.empty((m.shape[0] + 24, m.shape[1] + 24), dtype=torch.complex128, device=m.device)
+    L.check(lib.pm_spline_prefilter(L.code(m), int(order), m.shape[0], m.shape[1], L.ptr(m), m.stride(0), L.ptr(coeff), coeff.stride(0),
+                                    L.stream_ptr()))
+    return coeff
+
+
+def sample_map(measurement, dx, center, xf, yf, fill=1.0, order=1, coeff=None):
+    """Complex map resampled at focal coordinates (pm_sample_map / pm_sample_spline): map_coordinates(order 0 .. 5, mode='nearest')
+    inside the measured extent, `fill` (scalar or array of the shape of xf) outside.  xf / yf broadcast against each other."""
     lib = L.load()
     m = L.as_field(measurement)
     if not m.is_complex():
@@ -295,6 +309,14 @@ def sample_map(measurement, dx, center, xf, yf, fill=1.0, order=1):
     else:
         fill_t = torch.broadcast_to(L.as_device(fill).to(m.dtype), shape).contiguous()
     cxo, cyo = center
+    if order >= 2:   # coeff: the prefiltered map (spline_prefilter), made once per measured map by the caller
+        if coeff is None:
+            coeff = spline_prefilter(m, order)
+        L.check(lib.pm_sample_spline(L.code(m), int(order), m.shape[0], m.shape[1], L.ptr(coeff), coeff.stride(0), float(dx), float(cxo),
+                                     float(cyo), rows, cols, L.ptr(xb), xb.stride(0), xb.stride(1), L.ptr(yb), yb.stride(0),
+                                     yb.stride(1), L.ptr(fill_t) if fill_t is not None else None,
+                                     fill_t.stride(0) if fill_t is not None else 0, fre, fim, L.ptr(out), out.stride(0), L.stream_ptr()))
+        return out
     L.check(lib.pm_sample_map(L.code(m), int(order), m.shape[0], m.shape[1], L.ptr(m), m.stride(0), float(dx), float(cxo),
                               float(cyo), rows, cols, L.ptr(xb), xb.stride(0), xb.stride(1), L.ptr(yb), yb.stride(0),
                               yb.stride(1), L.ptr(fill_t) if fill_t is not None else None,

@@ -140,6 +140,137 @@ __global__ void sample_map_kernel(int order, int64_t ny, int64_t nx, const cx<T>
     }
 }
 
+// ---------------------------------------------------------------- spline orders 2..5 of map_coordinates(mode='nearest')
+// scipy pads the map by 12 samples of edge values, runs the recursive B-spline prefilter (poles z_k, reflect initialisation, gain
+// prod (1 - z)(1 - 1/z)) along each axis in fp64, and evaluates the tensor-product B-spline at coordinate + 12
+// (scipy/ndimage/_interpolation.py map_coordinates / _prepad_for_spline_filter, src/ni_splines.c).  Restated here: one thread
+// filters one line of the padded coefficient array in place.
+struct SplinePoles {
+    int n;
+    double z[2];
+};
+static SplinePoles spline_poles(int order) {
+    switch (order) {
+        case 2: return {1, {sqrt(8.0) - 3.0, 0.0}};
+        case 3: return {1, {sqrt(3.0) - 2.0, 0.0}};
+        case 4: return {2, {sqrt(664.0 - sqrt(438976.0)) + sqrt(304.0) - 19.0, sqrt(664.0 + sqrt(438976.0)) - sqrt(304.0) - 19.0}};
+        default: return {2, {sqrt(67.5 - sqrt(4436.25)) + sqrt(26.25) - 6.5, sqrt(67.5 + sqrt(4436.25)) - sqrt(26.25) - 6.5}};
+    }
+}
+constexpr int kSplinePad = 12;
+
+__device__ __forceinline__ void spline_filter_line(cx<double>* c, int64_t stride, int64_t n, const SplinePoles& pl) {
+    for (int k = 0; k < pl.n; ++k) {
+        const double z = pl.z[k];
+        const double z_n = pow(z, double(n));
+        // causal initialisation, reflect boundary
+        const cx<double> c0 = c[0], cl = c[(n - 1) * stride];
+        double ar = c0.x + z_n * cl.x, ai = c0.y + z_n * cl.y, z_i = z;
+        for (int64_t i = 1; i < n; ++i) {
+            const cx<double> a = c[i * stride], b = c[(n - 1 - i) * stride];
+            ar += z_i * (a.x + z_n * b.x);
+            ai += z_i * (a.y + z_n * b.y);
+            z_i *= z;
+        }
+        const double f = z / (1.0 - z_n * z_n);
+        cx<double> prev = {ar * f + c0.x, ai * f + c0.y};
+        c[0] = prev;
+        for (int64_t i = 1; i < n; ++i) {
+            cx<double> v = c[i * stride];
+            v.x += z * prev.x;
+            v.y += z * prev.y;
+            c[i * stride] = v;
+            prev = v;
+        }
+        const double g = z / (z - 1.0);
+        prev = {prev.x * g, prev.y * g};
+        c[(n - 1) * stride] = prev;
+        for (int64_t i = n - 2; i >= 0; --i) {
+            const cx<double> v = c[i * stride];
+            prev = {z * (prev.x - v.x), z * (prev.y - v.y)};
+            c[i * stride] = prev;
+        }
+    }
+}
+
+// coeff[r][c] = gain^2 * map[clamp(r - 12)][clamp(c - 12)]   (edge padding; the gain of both axes applied up front)
+template <typename T>
+__global__ void spline_pad_kernel(int64_t ny, int64_t nx, const cx<T>* map, int64_t ldm, double gain2, cx<double>* coeff, int64_t ldc) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t py = ny + 2 * kSplinePad, px = nx + 2 * kSplinePad;
+    if (g >= py * px) return;
+    const int64_t r = g / px, c = g - r * px;
+    int64_t sr = r - kSplinePad, sc = c - kSplinePad;
+    sr = sr < 0 ? 0 : (sr > ny - 1 ? ny - 1 : sr);
+    sc = sc < 0 ? 0 : (sc > nx - 1 ? nx - 1 : sc);
+    const cx<T> v = map[sr * ldm + sc];
+    coeff[r * ldc + c] = {double(v.x) * gain2, double(v.y) * gain2};
+}
+// axis = 0: one thread per column (line stride ldc); axis = 1: one thread per row (line stride 1)
+__global__ void spline_filter_kernel(int axis, int64_t py, int64_t px, cx<double>* coeff, int64_t ldc, SplinePoles pl) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (axis == 0) {
+        if (g < px) spline_filter_line(coeff + g, ldc, py, pl);
+    } else {
+        if (g < py) spline_filter_line(coeff + g * ldc, 1, px, pl);
+    }
+}
+
+// centred cardinal B-spline of degree n at t: (1/n!) sum_j (-1)^j C(n+1, j) (t + (n+1)/2 - j)_+^n
+__device__ __forceinline__ double bspline_value(double t, int n) {
+    const double binom[6][7] = {{1, 1, 0, 0, 0, 0, 0}, {1, 2, 1, 0, 0, 0, 0}, {1, 3, 3, 1, 0, 0, 0}, {1, 4, 6, 4, 1, 0, 0},
+                                {1, 5, 10, 10, 5, 1, 0}, {1, 6, 15, 20, 15, 6, 1}};
+    const double fact[6] = {1, 1, 2, 6, 24, 120};
+    double s = 0.0, sign = 1.0;
+    for (int j = 0; j <= n + 1; ++j) {
+        const double u = t + 0.5 * double(n + 1) - double(j);
+        if (u > 0.0) {
+            double p = 1.0;
+            for (int e = 0; e < n; ++e) p *= u;
+            s += sign * binom[n][j] * p;
+        }
+        sign = -sign;
+    }
+    return s / fact[n];
+}
+
+template <typename T>
+__global__ void sample_spline_kernel(int order, int64_t ny, int64_t nx, const cx<double>* __restrict__ coeff, int64_t ldc, T dx, T cxo, T cyo,
+                                     int64_t rows, int64_t cols, const T* xf, int64_t xsy, int64_t xsx, const T* yf, int64_t ysy,
+                                     int64_t ysx, const cx<T>* fill, int64_t ldf, cx<T> fillv, cx<T>* o, int64_t ldo) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < rows; r += int64_t(gridDim.y) * blockDim.y) {
+        const T col = (xf[r * xsy + c * xsx] - cxo) / dx + T(nx / 2);
+        const T row = (yf[r * ysy + c * ysx] - cyo) / dx + T(ny / 2);
+        const bool inside = row >= T(0) && row <= T(ny - 1) && col >= T(0) && col <= T(nx - 1);
+        cx<T> v;
+        if (!inside) {
+            v = fill ? fill[r * ldf + c] : fillv;
+        } else {
+            const double rr = double(row) + kSplinePad, cc = double(col) + kSplinePad;
+            const int64_t r0 = int64_t(floor((order & 1) ? rr : rr + 0.5)) - order / 2;
+            const int64_t c0 = int64_t(floor((order & 1) ? cc : cc + 0.5)) - order / 2;
+            double wc[6];
+            for (int b = 0; b <= order; ++b) wc[b] = bspline_value(cc - double(c0 + b), order);
+            double ar = 0.0, ai = 0.0;
+            for (int a = 0; a <= order; ++a) {
+                const double wa = bspline_value(rr - double(r0 + a), order);
+                const cx<double>* line = coeff + (r0 + a) * ldc + c0;
+                double lr = 0.0, li = 0.0;
+                for (int b = 0; b <= order; ++b) {
+                    lr += wc[b] * line[b].x;
+                    li += wc[b] * line[b].y;
+                }
+                ar += wa * lr;
+                ai += wa * li;
+            }
+            v = {T(ar), T(ai)};
+        }
+        o[r * ldo + c] = v;
+    }
+}
+
 // ---------------------------------------------------------------- pupil synthesis
 template <typename T, typename A>
 __global__ void pupil_kernel(int64_t rows, int64_t cols, const A* amp, int64_t lda, const T* opd, int64_t ldp,
@@ -330,6 +461,54 @@ int pm_sample_map(int32_t dtype, int32_t order, int64_t map_rows, int64_t map_co
                            (const cx<double>*)fill, fill_ld, cx<double>{fill_re, fill_im}, (cx<double>*)out, out_ld);
     else
         return fail(PM_ERR_ARG, "pm_sample_map: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
+}
+
+int pm_spline_prefilter(int32_t dtype, int32_t order, int64_t map_rows, int64_t map_cols, const void* map, int64_t map_ld, void* coeff,
+                        int64_t coeff_ld, void* stream) {
+    if (!map || !coeff || map_rows < 1 || map_cols < 1 || map_ld < map_cols || coeff_ld < map_cols + 2 * kSplinePad)
+        return fail(PM_ERR_ARG, "pm_spline_prefilter: bad argument");
+    if (order < 2 || order > 5) return fail(PM_ERR_UNSUPPORTED, "pm_spline_prefilter: spline order must be 2 .. 5 (orders 0 and 1 need no prefilter)");
+    if (dtype != PM_C64 && dtype != PM_C128) return fail(PM_ERR_ARG, "pm_spline_prefilter: dtype must be PM_C64 or PM_C128");
+    hipStream_t st = PM_STREAM(stream);
+    const SplinePoles pl = spline_poles(order);
+    double gain = 1.0;
+    for (int k = 0; k < pl.n; ++k) gain *= (1.0 - pl.z[k]) * (1.0 - 1.0 / pl.z[k]);
+    const int64_t py = map_rows + 2 * kSplinePad, px = map_cols + 2 * kSplinePad;
+    const dim3 block(256), grid(unsigned((py * px + 255) / 256));
+    if (dtype == PM_C64)
+        hipLaunchKernelGGL(spline_pad_kernel<float>, grid, block, 0, st, map_rows, map_cols, (const cx<float>*)map, map_ld, gain * gain,
+                           (cx<double>*)coeff, coeff_ld);
+    else
+        hipLaunchKernelGGL(spline_pad_kernel<double>, grid, block, 0, st, map_rows, map_cols, (const cx<double>*)map, map_ld, gain * gain,
+                           (cx<double>*)coeff, coeff_ld);
+    hipLaunchKernelGGL(spline_filter_kernel, dim3(unsigned((px + 63) / 64)), dim3(64), 0, st, 0, py, px, (cx<double>*)coeff, coeff_ld, pl);
+    hipLaunchKernelGGL(spline_filter_kernel, dim3(unsigned((py + 63) / 64)), dim3(64), 0, st, 1, py, px, (cx<double>*)coeff, coeff_ld, pl);
+    return int(hipGetLastError());
+}
+
+int pm_sample_spline(int32_t dtype, int32_t order, int64_t map_rows, int64_t map_cols, const void* coeff, int64_t coeff_ld, double dx,
+                     double center_x, double center_y, int64_t rows, int64_t cols, const void* xf, int64_t xf_sy, int64_t xf_sx,
+                     const void* yf, int64_t yf_sy, int64_t yf_sx, const void* fill, int64_t fill_ld, double fill_re, double fill_im,
+                     void* out, int64_t out_ld, void* stream) {
+    if (!coeff || !xf || !yf || !out || rows < 0 || cols < 0 || map_rows < 1 || map_cols < 1 || !(dx != 0.0) ||
+        coeff_ld < map_cols + 2 * kSplinePad)
+        return fail(PM_ERR_ARG, "pm_sample_spline: bad argument");
+    if (order < 2 || order > 5) return fail(PM_ERR_UNSUPPORTED, "pm_sample_spline: spline order must be 2 .. 5 (pm_sample_map serves 0 and 1)");
+    if (rows == 0 || cols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(rows, cols, block);
+    hipStream_t st = PM_STREAM(stream);
+    if (dtype == PM_C64)
+        hipLaunchKernelGGL(sample_spline_kernel<float>, grid, block, 0, st, order, map_rows, map_cols, (const cx<double>*)coeff, coeff_ld,
+                           float(dx), float(center_x), float(center_y), rows, cols, (const float*)xf, xf_sy, xf_sx, (const float*)yf, yf_sy,
+                           yf_sx, (const cx<float>*)fill, fill_ld, cx<float>{float(fill_re), float(fill_im)}, (cx<float>*)out, out_ld);
+    else if (dtype == PM_C128)
+        hipLaunchKernelGGL(sample_spline_kernel<double>, grid, block, 0, st, order, map_rows, map_cols, (const cx<double>*)coeff, coeff_ld, dx,
+                           center_x, center_y, rows, cols, (const double*)xf, xf_sy, xf_sx, (const double*)yf, yf_sy, yf_sx,
+                           (const cx<double>*)fill, fill_ld, cx<double>{fill_re, fill_im}, (cx<double>*)out, out_ld);
+    else
+        return fail(PM_ERR_ARG, "pm_sample_spline: dtype must be PM_C64 or PM_C128");
     return int(hipGetLastError());
 }
 

@@ -73,20 +73,21 @@ def prepare_measured_fpm(measurement, dx, center=(0, 0), charge=None, fill=None,
     """Wrap a measured complex focal-plane-mask map as an fpm(xf, yf) callable (coronagraph.py:128-200).
 
     The map is resampled on the device at each level's focal grid (pm_sample_map: map_coordinates order 0 | 1,
-    mode='nearest'); outside the measured extent the mask continues as `fill` (scalar or callable), an ideal vortex of
-    `charge`, or 1.  Spline orders above 1 raise NotImplementedError.
+    mode='nearest'; orders 2 .. 5: pm_spline_prefilter once, then pm_sample_spline); outside the measured extent the mask
+    continues as `fill` (scalar or callable), an ideal vortex of `charge`, or 1.
     """
     meas = L.as_field(measurement)
     if not meas.is_complex():
         meas = meas.to(L.cdtype_of(meas))
-    if order not in (0, 1):
-        raise NotImplementedError('prepare_measured_fpm: spline order 0 or 1 (higher orders need the spline prefilter)')
+    if order not in (0, 1, 2, 3, 4, 5):
+        raise RuntimeError('spline order not supported')   # scipy.ndimage's error for orders outside 0 .. 5
     if fill is None:
         fill = vortex_phase_mask(charge) if charge is not None else 1.0
+    coeff = _ops.spline_prefilter(meas, order) if order >= 2 else None   # once per measured map, as scipy does per call
 
     def fpm(xf, yf):
         fillv = fill(xf, yf) if callable(fill) else fill
-        return _ops.sample_map(meas, dx, center, xf, yf, fill=fillv, order=order)
+        return _ops.sample_map(meas, dx, center, xf, yf, fill=fillv, order=order, coeff=coeff)
     return fpm
 
 

@@ -358,6 +358,10 @@ def multires():
     ex = propagation.prepare_multiresolution(kind='mdft', **par)
     out['meas_fwd'] = propagation.to_fpm_and_back_multiresolution(
         x, propagation.prepare_measured_fpm(meas, 0.6, center=(0.3, -0.2), charge=2), ex)
+    for order in (2, 3, 4, 5):   # prefiltered spline orders (no further draws from rng: earlier entries stay as they were)
+        out[f'meas_o{order}_vortex'] = propagation.prepare_measured_fpm(meas, 0.6, center=(0.3, -0.2), charge=2, order=order)(xf, yf)
+    out['meas_o3_fwd'] = propagation.to_fpm_and_back_multiresolution(
+        x, propagation.prepare_measured_fpm(meas, 0.6, center=(0.3, -0.2), charge=2, order=3), ex)
     np.savez_compressed(os.path.join(HERE, 'multires.npz'), **out)
 
 

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     for s in declared_symbols():
         assert hasattr(lib, s), f'{s} declared in prysm_amd.h but not exported'
         assert s in _lib.SIGNATURES, f'{s} has no ctypes signature in prysm_amd/_lib.py'
-    assert lib.pm_version() == 105
+    assert lib.pm_version() == 106
 
 
 def test_argument_errors_are_reported_without_a_gpu(lib):

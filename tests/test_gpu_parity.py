@@ -696,14 +696,14 @@ def test_multiresolution_golden(pa, golden):
 def test_measured_fpm_golden(pa, golden):
     """prepare_measured_fpm (coronagraph.py:128-200): pm_sample_map against scipy.ndimage.map_coordinates through the
     reference -- orders 0 / 1, vortex / constant / default continuation, fp32 coordinates, and inside a multiresolution
-    round trip; order 3 is refused."""
+    round trip; orders 2 .. 5 through the prefiltered B-spline path."""
     P = pa.propagation
     g = golden('multires')
     meas, xf, yf = g['meas'], g['meas_xf'], g['meas_yf']
-    for order in (0, 1):
+    for order in (0, 1, 2, 3, 4, 5):   # 2 .. 5: pm_spline_prefilter (scipy's padded recursive prefilter) + pm_sample_spline
         got = P.prepare_measured_fpm(meas, 0.6, center=(0.3, -0.2), charge=2, order=order)(xf, yf)
         assert got.dtype == torch.complex128
-        assert rel_max(tonp(got), g[f'meas_o{order}_vortex']) < 1e-12
+        assert rel_max(tonp(got), g[f'meas_o{order}_vortex']) < (1e-12 if order < 4 else 1e-11)
     assert rel_max(tonp(P.prepare_measured_fpm(meas, 0.6)(xf, yf)), g['meas_o1_one']) < 1e-12
     assert rel_max(tonp(P.prepare_measured_fpm(meas, 0.6, fill=0.25 - 0.5j)(xf, yf)), g['meas_o1_fill']) < 1e-12
     # coordinate vectors broadcast (stride 0), fp32 map
@@ -715,8 +715,13 @@ def test_measured_fpm_golden(pa, golden):
                                    window=(0.25, 0.65))
     fpm = P.prepare_measured_fpm(meas, 0.6, center=(0.3, -0.2), charge=2)
     assert rel_max(tonp(P.to_fpm_and_back_multiresolution(g['x'], fpm, ex)), g['meas_fwd']) < TOL64
-    with pytest.raises(NotImplementedError):
-        P.prepare_measured_fpm(meas, 0.6, order=3)
+    fpm3 = P.prepare_measured_fpm(meas, 0.6, center=(0.3, -0.2), charge=2, order=3)
+    assert rel_max(tonp(P.to_fpm_and_back_multiresolution(g['x'], fpm3, ex)), g['meas_o3_fwd']) < TOL64
+    got = P.prepare_measured_fpm(meas.astype(np.complex64), 0.6, fill=0.25 - 0.5j, order=3)(xf[:1, :], yf[:, :1])
+    want = O.prepare_measured_fpm(meas, 0.6, fill=0.25 - 0.5j, order=3)(xf, yf)
+    assert got.dtype == torch.complex64 and rel_max(tonp(got), want) < 5e-4   # fp32 coordinates x the (steeper) cubic slope
+    with pytest.raises(RuntimeError):
+        P.prepare_measured_fpm(meas, 0.6, order=6)
 
 
 def test_otf_adjoints_golden(pa, golden):
