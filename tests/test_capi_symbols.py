@@ -86,6 +86,43 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
         L.check(rc)
 
 
+def test_workspace_queries_of_the_bluestein_path(lib):
+    """Lengths that are not powers of two: the workspace queries are pure host arithmetic (csrc/bluestein.h: MB = power of two >= 2n - 1)."""
+    from prysm_amd import _lib as L
+
+    def a256(b):
+        return (b + 255) // 256 * 256
+    d = L.pm_fft2_desc()
+    d.dtype, d.direction = L.PM_C64, -1
+    # both axes on the path: [a (M x N) | c (M x N) | workspace of the fused 2048 x 2048 convolution chain with 1000 stored rows]
+    d.in_y = d.in_x = d.out_y = d.out_x = L.pm_axis(1000, 1000, 0, 500)
+    d.in_ld = d.out_ld = 1000
+    fused = a256(1000 * 2048 * 8) + a256(2048 * 2048 * 8)
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 2 * a256(1000 * 1000 * 8) + fused
+    # one axis a power of two: natural intermediate + the per-axis scratch (pre-multiplied lines + their MB-point transforms)
+    d.in_y = d.out_y = L.pm_axis(1024, 1024, 0, 512)
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == a256(1024 * 1000 * 8) + a256(1024 * 1000 * 8) + a256(1024 * 2048 * 8)
+    # short lengths stay on the direct kernel: just the natural intermediate
+    d.in_y = d.in_x = d.out_y = d.out_x = L.pm_axis(36, 36, 0, 18)
+    d.in_ld = d.out_ld = 36
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 36 * 36 * 8
+    # 1-D: rows of 1000 points (MB = 2048); powers of two, short lengths and lengths above 4096 need none
+    assert lib.pm_fft1_workspace(L.PM_C128, 1, 300, 1000) == a256(300 * 1000 * 16) + a256(300 * 2048 * 16)
+    assert lib.pm_fft1_workspace(L.PM_C64, 0, 64, 777) == a256(64 * 777 * 8) + a256(64 * 2048 * 8)
+    for n in (1024, 36, 5000):
+        assert lib.pm_fft1_workspace(L.PM_C64, 1, 8, n) == 0
+    # argument errors of the newer entry points are reported before any device work
+    t = L.pm_axis(1000, 1000, 0, 0)
+    assert lib.pm_fft1_ws(L.PM_C64, 0, 1, 4, ctypes.byref(t), ctypes.byref(t), 1.0, ctypes.c_void_p(16), 1000, ctypes.c_void_p(16), 1000,
+                          None, 0, None) == L.PM_ERR_ARG
+    assert b'direction' in lib.pm_last_error()
+    assert lib.pm_encircled_energy_workspace() == 1024 * 8 * 8
+    assert lib.pm_encircled_energy(L.PM_C128, 8, 8, ctypes.c_void_p(16), 8, 1.0, 0, None, ctypes.cast(ctypes.c_void_p(16), ctypes.c_void_p),
+                                   None, 0, None) == L.PM_ERR_WORKSPACE
+    assert lib.pm_spline_prefilter(L.PM_C128, 1, 8, 8, ctypes.c_void_p(16), 8, ctypes.c_void_p(16), 32, None) == L.PM_ERR_UNSUPPORTED
+    assert lib.pm_spline_prefilter(L.PM_C128, 3, 8, 8, ctypes.c_void_p(16), 8, ctypes.c_void_p(16), 16, None) == L.PM_ERR_ARG
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly, not compute on the CPU, when no GPU is visible."""
     import numpy as np
