@@ -282,7 +282,10 @@ size_t pm_cgemm_workspace(int32_t dtype, int64_t M, int64_t N, int64_t K);
 /* --- housekeeping ------------------------------------------------------------------------- */
 int pm_version(void);
 const char* pm_last_error(void);   /* thread-local message for the last negative return */
-int pm_plan_prepare(int32_t dtype, int64_t n);   /* build + cache the twiddle table for length n now */
+int pm_plan_prepare(int32_t dtype, int64_t n);   /* build + cache the tables of a transform length now (twiddles; for a length on the
+                                                  * Bluestein path its chirp tables and the twiddles of the convolution length): the first
+                                                  * transform of a length otherwise does it, with a blocking upload that a hipGraph capture
+                                                  * cannot record */
 void pm_shutdown(void);            /* free cached tables */
 /* performance knobs (never change results): "col_var", "row_var" in {0,1} pick kernel tilings,
  * "nt_in" / "nt_out" in {0,1} make the input loads / output stores non-temporal.  Also read once from

@@ -700,6 +700,12 @@ const char* pm_last_error(void) { return g_err; }
 int pm_plan_prepare(int32_t dtype, int64_t n) {
     if (n < 1) return fail(PM_ERR_ARG, "pm_plan_prepare: n < 1");
     int err = 0;
+    if (dtype != PM_C64 && dtype != PM_C128) return fail(PM_ERR_ARG, "pm_plan_prepare: dtype");
+    if (use_blue(n)) {   // Bluestein tables of n and the twiddles of the convolution length
+        const int64_t mb = blue_conv_len(n);
+        if (dtype == PM_C64) return (blue_tables<float>(n, &err) && twiddles<float>(mb, &err)) ? 0 : err;
+        return (blue_tables<double>(n, &err) && twiddles<double>(mb, &err)) ? 0 : err;
+    }
     if (engine_log2(n) < 0) return twiddles_f64(n, &err) ? 0 : err;
     if (dtype == PM_C64) return twiddles<float>(n, &err) ? 0 : err;
     if (dtype == PM_C128) return twiddles<double>(n, &err) ? 0 : err;
