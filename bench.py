@@ -136,6 +136,55 @@ def polychromatic_per_wavelength_ms(n, cdtype, reps=8):
     return e0.elapsed_time(e1) / reps
 
 
+def _event_ms(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def other_configs():
+    """BASELINE configs 2 - 4 measured in the same run (parity-tested cases, reported here for the roofline the north star
+    asks for; not the headline value): algorithmic bytes / flops per SURVEY 8(d) over HIP-event time on the launch stream."""
+    from prysm_amd import propagation as P
+    from prysm_amd.conf import config
+    out = {}
+    # config 2: 2048^2 complex64 focus, 4 N^2 s bytes
+    x2 = torch.from_numpy(make_field(2048, np.complex64, 2048)).cuda()
+    ms = _event_ms(lambda: P.focus(x2, 1), 100)
+    out['config2_focus_2048_c64'] = {'ms': ms, 'algorithmic_GBps': 4 * 2048 ** 2 * 8 / (ms * 1e-3) / 1e9,
+                                     'frac_of_hbm_peak': 4 * 2048 ** 2 * 8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del x2
+    # config 3: 4096^2 complex128 angular-spectrum step (fused 3 passes), graded on 8 N^2 s bytes
+    x3 = torch.from_numpy(make_field(4096, np.complex128, 4096)).cuda()
+    ms = _event_ms(lambda: P.angular_spectrum(x3, 0.6328, 0.01, 10.0, Q=1), 30)
+    b = 8 * 4096 ** 2 * 16
+    out['config3_angular_spectrum_4096_c128'] = {'ms': ms, 'algorithmic_GBps': b / (ms * 1e-3) / 1e9,
+                                                 'frac_of_hbm_peak': b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 'note': 'graded on 8 N^2 s (two 2-D transforms); the fused chain moves 6 N^2 s'}
+    del x3
+    # config 4: matrix-DFT focus 2048^2 -> 512^2 complex64 on MFMA, 8 My Nx (Ny + Mx) real flops
+    prec = config.precision
+    try:
+        config.precision = 32
+        x4 = torch.from_numpy(make_field(2048, np.complex64, 2048)).cuda()
+        ex = P.prepare_executor(10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0)
+        ms = _event_ms(lambda: P.focus_dft(x4, ex), 50)
+    finally:
+        config.precision = prec
+    fl = 8 * 512 * 2048 * (2048 + 512)
+    out['config4_mdft_2048_to_512_c64'] = {'ms': ms, 'algorithmic_TFLOPs': fl / (ms * 1e-3) / 1e12,
+                                           'frac_of_f32_mfma_peak': fl / (ms * 1e-3) / 1e12 / 157.3, 'bound': 'mfma',
+                                           'note': 'two complex GEMMs on v_mfma_f32_32x32x2_f32; peak 157.3 TFLOP/s (MI355X_MICROARCH.md)'}
+    return out
+
+
 def cpu_baseline(n, cdtype, budget_s):
     """The oracle (port of prysm.propagation.focus) on host cores; scipy.fft workers=1 as prysm ships."""
     from oracle import prysm_oracle as O
@@ -284,6 +333,11 @@ def main():
                          'row_pass_ms': p1, 'column_pass_ms': p2,
                          'note': '2*N^2*s algorithmic bytes per pass / HIP-event duration of that pass, in sequence'},
         }
+        if not args.no_poly and world == 1:
+            try:
+                line['other_configs'] = other_configs()
+            except Exception as exc:   # never lose the headline line to a side measurement
+                line['other_configs'] = {'error': repr(exc)}
         if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only (the other ranks would just wait)
             line['cpu_baseline'] = cpu_baseline(n, cdtype, args.cpu_seconds)
         print(json.dumps(line), flush=True)
