@@ -154,3 +154,86 @@ def test_scalar_helpers(pa):
     wvl, a, z = 123.456, 987.654321, 5
     assert wvl / (1 - np.sqrt(1 - wvl ** 2 / a ** 2)) == pytest.approx(P.talbot_distance(a, wvl), abs=.1)
     assert P.fresnel_number(a, z, wvl) == (a ** 2 / (z * wvl))
+
+
+def test_fftdft_rejects_incompatible_or_nonuniform_grids(pa):
+    """tests/test_fttools.py:212-226 and tests/test_propagation.py:169-175: error classes and messages of FFTDFT."""
+    n = 8
+    x = y = np.arange(-(n // 2), n - n // 2).astype(float)
+    fx = fy = x / n
+    bad = fx.copy()
+    bad[-1] += 0.01
+    with pytest.raises(ValueError, match='uniformly spaced'):
+        pa.fttools.FFTDFT(x, y, bad, fy)
+    with pytest.raises(ValueError, match='not FFT-compatible'):
+        pa.fttools.FFTDFT(x, y, fx * 1.1, fy)
+    assert pa.fttools.FFTDFT(x, y, fx, fy).nbytes() == 4 * 8 * 16
+    with pytest.raises(ValueError, match='not FFT-compatible'):
+        pa.propagation.prepare_executor(pupil_dx=0.1, pupil_samples=32, focal_dx=1.0, focal_samples=32, wavelength=O.HeNe, efl=10.0,
+                                        kind='fftdft')
+
+
+def _grey_circle(radius, npup, dx, ss=16):
+    """supersampled (anti-aliased) circular aperture (reference tests/test_propagation.py:464-469)."""
+    xx, yy = O.make_xy_grid(npup * ss, dx=dx / ss)
+    fine = (np.hypot(xx, yy) < radius).astype(np.float32)
+    return fine.reshape(npup, ss, npup, ss).mean(axis=(1, 3))
+
+
+@pytest.fixture(scope='module')
+def vortex_rig(pa):
+    """charge-2 vortex coronagraph of the reference's tests (tests/test_propagation.py:473-519): 384^2 pupil, undersized Lyot stop,
+    six-level multiresolution executor, final focus at lambda/D / 4."""
+    P = pa.propagation
+    wvl, efl, pupil_dx, npup, nd = O.HeNe, 100.0, 0.05, 384, 320
+    Dap = nd * pupil_dx
+    lamD = efl / Dap * wvl
+    period = wvl * efl / pupil_dx
+    pupil = _grey_circle(Dap / 2, npup, pupil_dx).astype(complex)
+    lyot = _grey_circle(0.8 * Dap / 2, npup, pupil_dx)
+    nf0 = 2 * nd
+    executor = P.prepare_multiresolution(pupil_dx, npup, period / nf0, nf0, wvl, efl, num_levels=6, fine_samples=256, kind='mdft')
+    nf, fdx = 256, lamD / 4
+    final = P.prepare_executor(pupil_dx, npup, fdx, nf, wvl, efl, kind='mdft')
+    ref_peak = (np.abs(tonp(P.focus_dft(pupil, final))) ** 2).max()
+    fx = np.arange(-(nf // 2), nf // 2) * fdx
+    XF, YF = np.meshgrid(fx, fx)
+    return dict(pupil=pupil, lyot=lyot, executor=executor, final=final, ref_peak=ref_peak, rad=np.hypot(XF, YF) / lamD, lamD=lamD)
+
+
+def _dark_hole_max(pa, rig, fpm):
+    P = pa.propagation
+    lyot_field = P.to_fpm_and_back_multiresolution(rig['pupil'], fpm, rig['executor'])
+    from prysm_amd import _lib as L
+    stopped = lyot_field * L.as_device(rig['lyot'].astype(np.float64))
+    psf = np.abs(tonp(P.focus_dft(stopped, rig['final']))) ** 2 / rig['ref_peak']
+    return psf[(rig['rad'] > 3) & (rig['rad'] < 10)].max()
+
+
+def test_multiresolution_vortex_dark_hole_below_1e12(pa, vortex_rig):
+    """tests/test_propagation.py:535-541: behind the 0.8 R Lyot stop the next focus is dark to below 1e-12 of the
+    non-coronagraphic peak -- an end-to-end check of the matrix-DFT pair, the level windows and the vortex mask in fp64."""
+    assert _dark_hole_max(pa, vortex_rig, pa.propagation.vortex_phase_mask(2)) < 1e-12
+
+
+def test_measured_fpm_captures_manufacturing_error(pa, vortex_rig):
+    """tests/test_propagation.py:671-700: a measured ideal map still suppresses strongly; a 50 mrad fabrication ripple
+    makes the dark hole measurably brighter."""
+    P = pa.propagation
+    lamD = vortex_rig['lamD']
+
+    def measured(error=None, charge=2, extent=40, per_lamD=8):
+        mdx = lamD / per_lamD
+        n = int(extent * per_lamD) // 2 * 2 + 1
+        mx, my = O.make_xy_grid(n, dx=mdx)
+        phase = charge * np.arctan2(my, mx)
+        if error is not None:
+            phase = phase + error(np.hypot(mx, my) / lamD)
+        return np.exp(1j * phase), mdx
+
+    ideal_map, mdx = measured()
+    dh_ideal = _dark_hole_max(pa, vortex_rig, P.prepare_measured_fpm(ideal_map, mdx, charge=2))
+    err_map, mdx = measured(error=lambda r: 0.05 * np.sin(2 * np.pi * r / 3.0))
+    dh_error = _dark_hole_max(pa, vortex_rig, P.prepare_measured_fpm(err_map, mdx, charge=2))
+    assert dh_ideal < 1e-5
+    assert dh_error > 3 * dh_ideal
