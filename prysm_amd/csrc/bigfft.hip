@@ -1,0 +1,102 @@
+// Power-of-two lengths ABOVE the engine's longest transform (8192): 16384 and 32768 per axis, by one radix-R step (R = 2 or 4)
+// around engine transforms of length n' = n / R.  MI355X has the memory for such fields (16384^2 complex64 = 2 GiB of 288);
+// before this path they fell to the O(n^2) direct kernel (12 s for 16384^2).
+//
+//   rows    (decimation in frequency, the input is ours to pre-process): for j < n', m < R
+//               y_m[j] = (sum_r x[j + r n'] W_R^{r m}) W_n^{j m},          X[R k + m] = FFT_{n'}(y_m)[k]
+//           big_pre_rows builds the R planes y_m from the caller's windowed / rotated / real / conjugated input; ONE
+//           natural-order engine row pass over all planes follows (capi.hip big2d_run).
+//   columns (decimation in time: the sub-sequences x[R i + r] are rows r, r + R, ... = a leading dimension of R rows):
+//               F_r = FFT_{n'}(x[R i + r]),          X[k' + q n'] = sum_r (W_n^{r k'} F_r[k']) W_R^{r q}
+//           big_finish combines the R sub-transforms and sends every bin through the common epilogue (store_one: scale,
+//           conj, rotation / crop, multiplier, |.|^2), un-interleaving the row split (logical column R k + m of plane m).
+// HBM bound; extra passes over the engine's two (pre-process, combine) are the price of sizes that are rare in practice.
+#include "pm_internal.h"
+
+namespace pm {
+
+// W_R^e for R = 2 or 4 applied exactly: multiply by (-i)^(e * 4 / R)
+template <typename T>
+__device__ __forceinline__ cx<T> mul_wr(cx<T> v, int e, int R) {
+    const int q = (e * (4 / R)) & 3;   // quarter turns of exp(-2 pi i / 4)
+    switch (q) {
+        case 0: return v;
+        case 1: return {v.y, -v.x};    // * (-i)
+        case 2: return {-v.x, -v.y};
+        default: return {-v.y, v.x};   // * (+i)
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ cx<T> big_fetch(const Blue2dIn<T>& in, int i, int j) {
+    const int qy = in.ay.map(i), qx = in.ax.map(j);
+    cx<T> x{T(0), T(0)};
+    if (qy >= 0 && qx >= 0) {
+        const int64_t at = int64_t(qy) * in.ld + qx;
+        if (in.real)
+            x.x = reinterpret_cast<const T*>(in.src)[at];
+        else
+            x = reinterpret_cast<const cx<T>*>(in.src)[at];
+        if (in.conj) x.y = -x.y;
+    }
+    return x;
+}
+
+// Y[m][i][j], planes of M x n' (all M LOGICAL rows: rows outside the stored window come out zero)
+template <typename T>
+__global__ void big_pre_rows_kernel(Blue2dIn<T> in, int M, int np, int R, cx<T>* Y, const cx<T>* twN) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= int64_t(M) * np) return;
+    const int i = int(g / np), j = int(g - int64_t(i) * np);
+    cx<T> x[4];
+    for (int r = 0; r < R; ++r) x[r] = big_fetch(in, i, j + r * np);
+    const int64_t plane = int64_t(M) * np;
+    for (int m = 0; m < R; ++m) {
+        cx<T> s{T(0), T(0)};
+        for (int r = 0; r < R; ++r) s = s + mul_wr(x[r], r * m, R);
+        Y[int64_t(m) * plane + g] = m ? cmul(s, twN[int64_t(j) * m]) : s;
+    }
+}
+
+// F[(m * Rm + r)][k'][k], planes of mp x np;  thread (k', logical column c = Rn k + m) writes the Rm bins k' + q mp
+template <typename T>
+__global__ void big_finish_kernel(const cx<T>* F, int mp, int np, int Rm, int Rn, const cx<T>* twM, ColStoreNat<T> o) {
+    const int64_t N = int64_t(np) * Rn;
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= int64_t(mp) * N) return;
+    const int kp = int(g / N), c = int(g - int64_t(kp) * N);
+    const int k = c / Rn, m = c - k * Rn;
+    const int64_t plane = int64_t(mp) * np;
+    cx<T> t[4];
+    for (int r = 0; r < Rm; ++r) {
+        const cx<T> f = F[(int64_t(m) * Rm + r) * plane + int64_t(kp) * np + k];
+        t[r] = r ? cmul(f, twM[int64_t(r) * kp]) : f;
+    }
+    for (int q = 0; q < Rm; ++q) {
+        cx<T> s{T(0), T(0)};
+        for (int r = 0; r < Rm; ++r) s = s + mul_wr(t[r], r * q, Rm);
+        store_one(o, kp + q * mp, c, s);
+    }
+}
+
+template <typename T>
+int big_pre_rows(const Blue2dIn<T>& in, int M, int np, int R, cx<T>* Y, const cx<T>* twN, hipStream_t st) {
+    const int64_t total = int64_t(M) * np;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(big_pre_rows_kernel<T>, dim3(unsigned((total + 255) / 256)), dim3(256), 0, st, in, M, np, R, Y, twN);
+    return int(hipGetLastError());
+}
+template <typename T>
+int big_finish(const cx<T>* F, int mp, int np, int Rm, int Rn, const cx<T>* twM, const ColStoreNat<T>& o, hipStream_t st) {
+    const int64_t total = int64_t(mp) * np * Rn;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(big_finish_kernel<T>, dim3(unsigned((total + 255) / 256)), dim3(256), 0, st, F, mp, np, Rm, Rn, twM, o);
+    return int(hipGetLastError());
+}
+
+template int big_pre_rows<float>(const Blue2dIn<float>&, int, int, int, cx<float>*, const cx<float>*, hipStream_t);
+template int big_pre_rows<double>(const Blue2dIn<double>&, int, int, int, cx<double>*, const cx<double>*, hipStream_t);
+template int big_finish<float>(const cx<float>*, int, int, int, int, const cx<float>*, const ColStoreNat<float>&, hipStream_t);
+template int big_finish<double>(const cx<double>*, int, int, int, int, const cx<double>*, const ColStoreNat<double>&, hipStream_t);
+
+}  // namespace pm

@@ -121,6 +121,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
     else if (is("blue_min")) t.blue_min = v < 0 ? 0 : v;
     else if (is("blue_2d")) t.blue_2d = v ? 1 : 0;
+    else if (is("big_native_log")) t.big_native_log = v < 1 ? 1 : (v > kEngineMaxLog ? kEngineMaxLog : v);
 }
 
 Tuning& tuning() {
@@ -181,6 +182,7 @@ struct Fft2Plan {
                           // pass then runs two planes of M/2-point tiles
     bool blue_n, blue_m;  // the row / column transforms take the Bluestein path (non-power-of-two lengths, bluestein.hip)
     size_t blue_off;      // its scratch sits behind the intermediates in the workspace (shared by the two passes)
+    int big_rn, big_rm;   // power-of-two lengths above the engine's: radix of the extra step per axis (1 = none), 0 = not this path
     bool blue2d;          // both axes: chirp multiply -> ONE fused fft2 x (B1 (x) B2) ifft2 chain of size MB1 x MB2 -> chirp multiply
                           // (blue2d_run); the workspace is then [a (M x N) | c (M x N) | workspace of the fused chain]
 };
@@ -237,6 +239,20 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     p.ws_field = (p.ws_bytes + 255) & ~size_t(255);
     p.chunk = batch_chunk(p.nbatch, p.ws_field);
     if (p.nbatch > 1) p.ws_bytes = p.ws_field * size_t(p.chunk);
+    // powers of two above the engine's longest transform: both axes powers of two, at least one split (big2d_run)
+    p.big_rn = big_split(N);
+    p.big_rm = big_split(M);
+    if (!(p.big_rn && p.big_rm && (p.big_rn > 1 || p.big_rm > 1)) || (d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY | PM_FLAG_SYNTH_INPUT)))
+        p.big_rn = p.big_rm = 0;
+    if (p.big_rn) {   // [Z: R_n planes of M x N/R_n | F (and the pre-processed rows before it): the same size]
+        p.tc = 0;
+        p.fold = false;
+        p.blue_n = p.blue_m = p.blue2d = false;
+        p.blue_off = 0;
+        const size_t arr = (size_t(M) * size_t(N) * es + 255) & ~size_t(255);
+        p.ws_bytes = 2 * arr;
+        return p;
+    }
     p.blue_n = p.logn < 0 && use_blue(N);
     p.blue_m = p.logm < 0 && use_blue(M);
     p.blue_off = (p.ws_bytes + 255) & ~size_t(255);
@@ -294,6 +310,8 @@ static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out, int logm_t
 
 template <typename T>
 static int blue2d_run(const pm_fft2_desc* d, const void* in, void* out, void* ws, hipStream_t st);
+template <typename T>
+static int big2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st);
 
 // one launch pair over `nb` fields (nb > 1 only when both passes run on the engine)
 template <typename T>
@@ -305,6 +323,7 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
     int err = 0;
     cx<T>* W = reinterpret_cast<cx<T>*>(ws);
     const bool run1 = !(d->flags & PM_FLAG_PASS2_ONLY), run2 = !(d->flags & PM_FLAG_PASS1_ONLY);
+    if (p.big_rn) return big2d_run<T>(d, p, in, out, ws, st);
     if (p.blue2d) return blue2d_run<T>(d, in, out, ws, st);
 
     // ---- pass 1: one transform of length N per STORED input row (all-zero padded rows are skipped)
@@ -579,6 +598,84 @@ static int blue2d_run(const pm_fft2_desc* d, const void* in, void* out, void* ws
     if (rc) return rc;
     const ColStoreNat<T> cs = make_colstore<T>(d, out);
     return blue_post2d<T>(c, int(M), int(N), t1, t2, cs, st);
+}
+
+// ---------------------------------------------------------------- powers of two above the engine's longest transform
+// (bigfft.hip): rows by a decimation-in-frequency step in front of ONE engine row pass over R_n planes, columns by engine
+// passes over the R_m row sub-lattices and a combining epilogue kernel.
+template <typename T>
+static int big2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st) {
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    const int Rn = p.big_rn, Rm = p.big_rm;
+    const int np = int(N / Rn), mp = int(M / Rm);
+    const int lgn = engine_log2(np), lgm = engine_log2(mp);
+    if (lgn < 0 || lgm < 0) return fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: big split %d x %d of %lld x %lld", Rm, Rn, (long long)M, (long long)N);
+    const int dt = d->dtype;
+    const int conj = d->direction > 0 ? 1 : 0;
+    int err = 0;
+    const size_t arr = (size_t(M) * size_t(N) * sizeof(cx<T>) + 255) & ~size_t(255);
+    cx<T>* Z = reinterpret_cast<cx<T>*>(ws);
+    cx<T>* F = reinterpret_cast<cx<T>*>(static_cast<char*>(ws) + arr);
+    const cx<T>* twn = twiddles<T>(np, &err);
+    if (!twn) return err;
+    const cx<T>* twm = twiddles<T>(mp, &err);
+    if (!twm) return err;
+    int rc;
+    // ---- rows -> Z[m][i][k] = X_row_i[R_n k + m], every LOGICAL row i present
+    if (Rn > 1) {
+        const cx<T>* twN = twiddles<T>(N, &err);
+        if (!twN) return err;
+        Blue2dIn<T> bi{in, d->in_ld, to_map(d->in_y), to_map(d->in_x), conj, (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
+        cx<T>* Y = F;   // dead before the column stage writes F
+        if ((rc = big_pre_rows<T>(bi, int(M), np, Rn, Y, twN, st))) return rc;
+        const int nseq = Rn * int(M);
+        RowLoadNat<T> lp{Y, np, AxisMap{np, np, 0, 0}, nseq, 0, 0};
+        RowStoreNat<T> sp{Z, np, AxisMap{np, np, 0, 0}, nseq, 0, T(1), 0, AxisMap{1, 1, 0, 0}};
+        if ((rc = launch_row_nat<T>(lgn, row_variant(dt, lgn), lp, sp, twn, nseq, 0, st))) return rc;
+    } else {
+        const int rows = int(d->in_y.len);
+        if (rows < M) {
+            hipError_t e = hipMemsetAsync(Z, 0, size_t(M) * size_t(N) * sizeof(cx<T>), st);
+            if (e != hipSuccess) return int(e);
+        }
+        if (rows > 0) {
+            // stored row q is logical row (q + off - shift) mod M: the row map of the store puts it there
+            const int sh = int(((d->in_y.off - d->in_y.shift) % M + M) % M);
+            RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, conj, 0};
+            set_input_mode(lp, d);
+            RowStoreNat<T> sp{Z, N, AxisMap{int(N), int(N), 0, 0}, rows, 0, T(1), 1, AxisMap{int(M), int(M), 0, sh}};
+            if ((rc = launch_row_nat<T>(lgn, row_variant(dt, lgn), lp, sp, twn, rows, 0, st))) return rc;
+        }
+    }
+    // ---- columns: plane m is an M x np matrix; F[(m R_m + r)] = FFT_{mp} down the columns of its rows r, r + R_m, ...
+    const int tc = col_tile_width_for(dt, lgm, tuning().col_var);
+    const int ntiles = (np + tc - 1) / tc;
+    const int vec = (sizeof(T) != 4 || np % 2 == 0) ? 1 : 0;
+    const int64_t plane = int64_t(mp) * np;
+    for (int m = 0; m < Rn; ++m) {
+        ColLoadNat<T> cl{Z + int64_t(m) * M * np, int64_t(Rm) * np, AxisMap{mp, mp, 0, 0}, np, 0, vec, int64_t(np)};
+        ColStoreNat<T> cs{};
+        cs.dst = F + int64_t(m) * Rm * plane;
+        cs.ld = np;
+        cs.ay = AxisMap{mp, mp, 0, 0};
+        cs.ax = AxisMap{np, np, 0, 0};
+        cs.epilogue = EPI_NONE;
+        cs.scale = T(1);
+        cs.weight = T(1);
+        cs.mul_kind = MUL_NONE;
+        cs.vec_ok = vec;
+        cs.bstride = plane;
+        if ((rc = launch_col_nat<T>(lgm, tuning().col_var, cl, cs, twm, ntiles, 1, st, Rm))) return rc;
+    }
+    // ---- combine the sub-lattices, un-interleave the row split, common epilogue
+    const cx<T>* twM = twm;
+    if (Rm > 1) {
+        twM = twiddles<T>(M, &err);
+        if (!twM) return err;
+    }
+    ColStoreNat<T> ep = make_colstore<T>(d, out);
+    ep.bstride = 0;
+    return big_finish<T>(F, mp, np, Rm, Rn, twM, ep, st);
 }
 
 template <typename T>

@@ -61,6 +61,11 @@ template <typename T> int blue_pre2d(const Blue2dIn<T>& in, cx<T>* a, const cx<T
 template <typename T>
 int blue_post2d(const cx<T>* t, int n1, int n2, const cx<T>* w1, const cx<T>* w2, const ColStoreNat<T>& out, hipStream_t st);
 
+// power-of-two lengths above the engine's longest transform (bigfft.hip; orchestration: capi.hip big2d_run)
+template <typename T> int big_pre_rows(const Blue2dIn<T>& in, int M, int np, int R, cx<T>* Y, const cx<T>* twN, hipStream_t st);
+template <typename T>
+int big_finish(const cx<T>* F, int mp, int np, int Rm, int Rn, const cx<T>* twM, const ColStoreNat<T>& out, hipStream_t st);
+
 // engine launchers (fft_row_*.hip / fft_col_*.hip); `var` = tuning variant (see fft_kernels.h)
 template <typename T> int launch_row_tiled(int logn, int var, const RowLoadNat<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t, int nbatch = 1);
@@ -97,6 +102,9 @@ struct Tuning {
     int blue_min = 96;        // shortest non-power-of-two length that takes the Bluestein path (shorter ones, and lengths
                              // above 4096, run on the direct O(n^2) kernel); 0 disables the path
     int blue_2d = 1;          // both axes on the Bluestein path: one fused fft2 x B ifft2 chain (1) or axis by axis (0)
+    int big_native_log = 13;  // log2 of the longest length handed to the engine as it is; longer powers of two (up to 4x) take
+                             // one radix-2 / radix-4 step around engine transforms (bigfft.hip).  Tests lower it to run that
+                             // path on small arrays.
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)
 };
@@ -122,6 +130,16 @@ inline int engine_log2(int64_t n) {  // log2(n) if n is a power of two the engin
     int l = 0;
     while ((int64_t(1) << l) < n) ++l;
     return l <= kEngineMaxLog ? l : -1;
+}
+
+// split of a power-of-two length for the big path: R = 1 (native), 2 or 4; 0 = not a length this path takes
+inline int big_split(int64_t n) {
+    if (n < 2 || (n & (n - 1))) return 0;
+    const int64_t native = int64_t(1) << tuning().big_native_log;
+    if (n <= native) return 1;
+    if (n == 2 * native) return 2;
+    if (n == 4 * native) return 4;
+    return 0;
 }
 
 // lengths the Bluestein path takes (bluestein.h: 2n - 1 must fit the engine's longest transform)

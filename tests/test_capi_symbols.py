@@ -106,6 +106,11 @@ def test_workspace_queries_of_the_bluestein_path(lib):
     d.in_y = d.in_x = d.out_y = d.out_x = L.pm_axis(36, 36, 0, 18)
     d.in_ld = d.out_ld = 36
     assert lib.pm_fft2_workspace(ctypes.byref(d)) == 36 * 36 * 8
+    # powers of two above the engine's 8192: two M x N arrays (split planes + sub-lattice transforms)
+    d.in_y = d.out_y = L.pm_axis(16384, 16384, 0, 8192)
+    d.in_x = d.out_x = L.pm_axis(2048, 2048, 0, 1024)
+    d.in_ld = d.out_ld = 2048
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 2 * 16384 * 2048 * 8
     # 1-D: rows of 1000 points (MB = 2048); powers of two, short lengths and lengths above 4096 need none
     assert lib.pm_fft1_workspace(L.PM_C128, 1, 300, 1000) == a256(300 * 1000 * 16) + a256(300 * 2048 * 16)
     assert lib.pm_fft1_workspace(L.PM_C64, 0, 64, 777) == a256(64 * 777 * 8) + a256(64 * 2048 * 8)

@@ -948,6 +948,76 @@ def test_bluestein_angular_spectrum_non_pow2(pa):
     assert rel_max(got, ref) < TOL64
 
 
+@pytest.mark.parametrize('shape', [(64, 128), (32, 64), (128, 16), (128, 128)])
+@pytest.mark.parametrize('dtype', [np.complex64, np.complex128])
+def test_big_power_of_two_path_on_small_arrays(pa, shape, dtype):
+    """csrc/bigfft.hip (16384 / 32768-point axes: one radix-2 / radix-4 step around engine transforms) exercised on small arrays
+    by lowering the native-length knob to 32: radix 1 / 2 / 4 per axis, windows, rotations, crops, real input, inverse, |.|^2."""
+    from prysm_amd import _lib, _ops
+    lib = _lib.load()
+    rng = np.random.default_rng(sum(shape) + (dtype == np.complex64))
+    tol = TOL32 if dtype == np.complex64 else TOL64
+    M, N = shape
+    try:
+        lib.pm_set_tuning(b'big_native_log', 5)
+        x = crandn(rng, shape, dtype)
+        xd = torch.from_numpy(x).cuda()
+        want = np.fft.fft2(x.astype(np.complex128))
+        assert rel_max(_ops.fft2(xd, direction=-1, scale=1.0).cpu().numpy(), want) < tol
+        assert rel_max(_ops.fft2(xd, direction=+1, scale=1.0 / (M * N)).cpu().numpy(), np.fft.ifft2(x.astype(np.complex128))) < tol
+        # the focus family: pad window + both rotations, the adjoint's crop, real input, fused intensity
+        small = x[:M // 2, :N // 2]
+        ref = O.focus(small.astype(np.complex128), 2)
+        assert rel_max(tonp(pa.propagation.focus(small, 2)), ref) < tol
+        assert rel_max(tonp(pa.propagation.focus_intensity(small, 2)), O.intensity(ref)) < 2 * tol
+        g = crandn(rng, shape, dtype)
+        assert rel_max(tonp(pa.propagation.focus_adjoint(g, 2)), O.focus_adjoint(g.astype(np.complex128), 2)) < tol
+        xr = np.ascontiguousarray(x.real)
+        assert rel_max(_ops.fft2(torch.from_numpy(xr).cuda(), direction=-1, scale=1.0).cpu().numpy(), np.fft.fft2(xr.astype(np.float64))) < tol
+        sh = (M // 2, N // 2)
+        got = _ops.fft2(xd, direction=-1, scale=0.5, in_shift=(3, 5), out_shift=sh, out_shape=(M - 6, N - 2), out_off=(4, 1)).cpu().numpy()
+        full = np.roll(0.5 * np.fft.fft2(np.roll(x.astype(np.complex128), (-3, -5), (0, 1))), sh, (0, 1))
+        assert rel_max(got, full[4:4 + M - 6, 1:1 + N - 2]) < tol
+        st = crandn(rng, (2,) + shape, dtype)
+        gs = _ops.fft2(torch.from_numpy(st).cuda(), direction=-1, scale=1.0).cpu().numpy()
+        assert max(rel_max(gs[b], np.fft.fft2(st[b].astype(np.complex128))) for b in range(2)) < tol
+    finally:
+        lib.pm_set_tuning(b'big_native_log', 13)
+
+
+@pytest.mark.parametrize('shape', [(16384, 64), (64, 16384), (32768, 8)])
+def test_big_power_of_two_lengths(pa, shape):
+    """16384- and 32768-point axes at full length against numpy."""
+    from prysm_amd import _ops
+    rng = np.random.default_rng(shape[0])
+    x = crandn(rng, shape)
+    got = _ops.fft2(torch.from_numpy(x).cuda(), direction=-1, scale=1.0).cpu().numpy()
+    assert rel_max(got, np.fft.fft2(x)) < TOL64
+    assert rel_max(tonp(pa.propagation.unfocus(x, 1)), O.unfocus(x, 1)) < TOL64
+
+
+def test_big_16384_squared_separable_field(pa):
+    """focus of a 16384^2 complex64 field (2 GiB; the reference would take minutes): a separable input a (x) b has the separable
+    transform F(a) (x) F(b), so the truth costs two 1-D numpy FFTs."""
+    n = 16384
+    rng = np.random.default_rng(n)
+    a, b = crandn(rng, n), crandn(rng, n)
+    xd = torch.outer(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).to(torch.complex64)
+    got = pa.propagation.focus(xd, 1)
+    fa = np.fft.fftshift(np.fft.fft(np.fft.ifftshift(a), norm='ortho'))
+    fb = np.fft.fftshift(np.fft.fft(np.fft.ifftshift(b), norm='ortho'))
+    want = torch.outer(torch.from_numpy(fa).cuda(), torch.from_numpy(fb).cuda())
+    err = float((got.to(torch.complex128) - want).abs().max() / want.abs().max())
+    assert got.dtype == torch.complex64 and err < 2 * TOL32
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    pa.propagation.focus(xd, 1)
+    ev1.record()
+    torch.cuda.synchronize()
+    print('focus 16384^2 complex64: %.2f ms' % ev0.elapsed_time(ev1))
+
+
 def test_randomised_differential_fuzz(pa):
     """tools/fuzz_fft2.py: random sizes / windows / rotations / crops / input kinds / stacks / epilogues / multipliers /
     precisions / fold settings of pm_fft2 and the fused chain against numpy (a fixed seed keeps it reproducible)."""
