@@ -183,6 +183,7 @@ struct Fft2Plan {
     bool blue_n, blue_m;  // the row / column transforms take the Bluestein path (non-power-of-two lengths, bluestein.hip)
     size_t blue_off;      // its scratch sits behind the intermediates in the workspace (shared by the two passes)
     int big_rn, big_rm;   // power-of-two lengths above the engine's: radix of the extra step per axis (1 = none), 0 = not this path
+    bool blue_big;        // blue2d whose convolution length exceeds the engine's: two big power-of-two transforms around the multiply
     bool blue2d;          // both axes: chirp multiply -> ONE fused fft2 x (B1 (x) B2) ifft2 chain of size MB1 x MB2 -> chirp multiply
                           // (blue2d_run); the workspace is then [a (M x N) | c (M x N) | workspace of the fused chain]
 };
@@ -247,7 +248,7 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     if (p.big_rn) {   // [Z: R_n planes of M x N/R_n | F (and the pre-processed rows before it): the same size]
         p.tc = 0;
         p.fold = false;
-        p.blue_n = p.blue_m = p.blue2d = false;
+        p.blue_n = p.blue_m = p.blue2d = p.blue_big = false;
         p.blue_off = 0;
         const size_t arr = (size_t(M) * size_t(N) * es + 255) & ~size_t(255);
         p.ws_bytes = 2 * arr;
@@ -256,8 +257,18 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     p.blue_n = p.logn < 0 && use_blue(N);
     p.blue_m = p.logm < 0 && use_blue(M);
     p.blue_off = (p.ws_bytes + 255) & ~size_t(255);
-    p.blue2d = p.blue_n && p.blue_m && tuning().blue_2d && !(d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY));
-    if (p.blue2d) {
+    const bool noflags = !(d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY | PM_FLAG_SYNTH_INPUT));
+    p.blue2d = p.blue_n && p.blue_m && tuning().blue_2d && noflags;
+    p.blue_big = !p.blue2d && use_blue_long(N) && use_blue_long(M) && tuning().blue_2d && noflags &&
+                 (big_split(blue_conv_len(N)) > 1 || big_split(blue_conv_len(M)) > 1);
+    if (p.blue_big) {   // [a (M x N) | c (M x N) | spectrum (MB1 x MB2) | workspace of the big transforms]
+        p.blue2d = true;
+        p.blue_n = p.blue_m = false;
+        const size_t arr = (size_t(M) * size_t(N) * es + 255) & ~size_t(255);
+        const int64_t mb1 = blue_conv_len(M), mb2 = blue_conv_len(N);
+        const size_t spec = (size_t(mb1) * size_t(mb2) * es + 255) & ~size_t(255);
+        p.ws_bytes = 2 * arr + spec + 2 * spec;
+    } else if (p.blue2d) {
         const size_t arr = (size_t(M) * size_t(N) * es + 255) & ~size_t(255);
         p.ws_bytes = 2 * arr + blue2d_fused_ws(d->dtype, M, N);
     } else if (p.blue_n || p.blue_m) {
@@ -309,7 +320,7 @@ static ColStoreNat<T> make_colstore(const pm_fft2_desc* d, void* out, int logm_t
 }
 
 template <typename T>
-static int blue2d_run(const pm_fft2_desc* d, const void* in, void* out, void* ws, hipStream_t st);
+static int blue2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st);
 template <typename T>
 static int big2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st);
 
@@ -324,7 +335,7 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
     cx<T>* W = reinterpret_cast<cx<T>*>(ws);
     const bool run1 = !(d->flags & PM_FLAG_PASS2_ONLY), run2 = !(d->flags & PM_FLAG_PASS1_ONLY);
     if (p.big_rn) return big2d_run<T>(d, p, in, out, ws, st);
-    if (p.blue2d) return blue2d_run<T>(d, in, out, ws, st);
+    if (p.blue2d) return blue2d_run<T>(d, p, in, out, ws, st);
 
     // ---- pass 1: one transform of length N per STORED input row (all-zero padded rows are skipped)
     if (run1 && rows > 0) {
@@ -574,7 +585,7 @@ static size_t blue2d_fused_ws(int dtype, int64_t M, int64_t N) {
 }
 
 template <typename T>
-static int blue2d_run(const pm_fft2_desc* d, const void* in, void* out, void* ws, hipStream_t st) {
+static int blue2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st) {
     const int64_t M = d->in_y.n, N = d->in_x.n;
     int err = 0;
     const cx<T>* t1 = blue_tables<T>(M, &err);
@@ -592,6 +603,33 @@ static int blue2d_run(const pm_fft2_desc* d, const void* in, void* out, void* ws
     blue2d_desc(dd, d->dtype, M, N);
     dd.mul = t1 + M;
     dd.mul_x = t2 + N;
+    if (p.blue_big) {
+        // convolution lengths above the engine's (n in (4096, 16384]): spectrum = fft2(pad(a)) x (B1 (x) B2) by one big transform
+        // with the multiplier in its epilogue, then the cropped inverse by a second one (bigfft.hip)
+        const int64_t mb1 = dd.in_y.n, mb2 = dd.in_x.n;
+        const size_t spec = (size_t(mb1) * size_t(mb2) * sizeof(cx<T>) + 255) & ~size_t(255);
+        cx<T>* S = reinterpret_cast<cx<T>*>(fws);
+        void* bws = static_cast<char*>(fws) + spec;
+        pm_fft2_desc d1 = dd;
+        d1.out_y = pm_axis{mb1, mb1, 0, 0};
+        d1.out_x = pm_axis{mb2, mb2, 0, 0};
+        d1.out_ld = mb2;
+        const Fft2Plan p1 = plan_fft2(&d1);
+        if (!p1.big_rn) return fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: no big plan for the Bluestein convolution");
+        if ((rc = big2d_run<T>(&d1, p1, a, S, bws, st))) return rc;
+        pm_fft2_desc d2 = dd;
+        d2.direction = +1;
+        d2.in_y = pm_axis{mb1, mb1, 0, 0};
+        d2.in_x = pm_axis{mb2, mb2, 0, 0};
+        d2.in_ld = mb2;
+        d2.mul_kind = PM_MUL_NONE;
+        d2.mul = d2.mul_x = nullptr;
+        const Fft2Plan p2 = plan_fft2(&d2);
+        if (!p2.big_rn) return fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: no big plan for the Bluestein convolution");
+        if ((rc = big2d_run<T>(&d2, p2, S, c, bws, st))) return rc;
+        const ColStoreNat<T> cs = make_colstore<T>(d, out);
+        return blue_post2d<T>(c, int(M), int(N), t1, t2, cs, st);
+    }
     FusedPlan fp;
     if (!plan_fused(&dd, fp)) return fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: no fused plan for the Bluestein convolution");
     rc = fused_run_chunk<T>(&dd, fp, a, c, fws, st, 1);
@@ -798,10 +836,10 @@ int pm_plan_prepare(int32_t dtype, int64_t n) {
     if (n < 1) return fail(PM_ERR_ARG, "pm_plan_prepare: n < 1");
     int err = 0;
     if (dtype != PM_C64 && dtype != PM_C128) return fail(PM_ERR_ARG, "pm_plan_prepare: dtype");
-    if (use_blue(n)) {   // Bluestein tables of n and the twiddles of the convolution length
-        const int64_t mb = blue_conv_len(n);
-        if (dtype == PM_C64) return (blue_tables<float>(n, &err) && twiddles<float>(mb, &err)) ? 0 : err;
-        return (blue_tables<double>(n, &err) && twiddles<double>(mb, &err)) ? 0 : err;
+    if (use_blue_long(n)) {   // Bluestein tables of n and the twiddles of the convolution length (of its engine part when it is split)
+        const int64_t mb = blue_conv_len(n), part = mb / big_split(mb);
+        if (dtype == PM_C64) return (blue_tables<float>(n, &err) && twiddles<float>(mb, &err) && twiddles<float>(part, &err)) ? 0 : err;
+        return (blue_tables<double>(n, &err) && twiddles<double>(mb, &err) && twiddles<double>(part, &err)) ? 0 : err;
     }
     if (engine_log2(n) < 0) return twiddles_f64(n, &err) ? 0 : err;
     if (dtype == PM_C64) return twiddles<float>(n, &err) ? 0 : err;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/prysm_amd.h"
+#include "bluestein.h"
 #include "fft_io.h"
 
 namespace pm {
@@ -142,10 +143,13 @@ inline int big_split(int64_t n) {
     return 0;
 }
 
-// lengths the Bluestein path takes (bluestein.h: 2n - 1 must fit the engine's longest transform)
-inline bool use_blue(int64_t n) {
+// lengths the Bluestein path takes (bluestein.h): not a power of two, at least blue_min, and a convolution length
+// MB >= 2n - 1 that the engine runs as it is (use_blue: n <= 4096; the axis-by-axis form and pm_fft1_ws need that) or that
+// the big power-of-two path runs (use_blue_long: n <= 16384; only the both-axes form, two big transforms around the multiply)
+inline bool use_blue_long(int64_t n) {
     const int lo = tuning().blue_min;
-    return lo > 0 && engine_log2(n) < 0 && n >= lo && n <= 4096;
+    return lo > 0 && n >= lo && n >= 2 && (n & (n - 1)) != 0 && n <= (int64_t(1) << 20) && big_split(blue_conv_len(n)) >= 1;
 }
+inline bool use_blue(int64_t n) { return use_blue_long(n) && big_split(blue_conv_len(n)) == 1; }
 
 }  // namespace pm

@@ -111,6 +111,11 @@ def test_workspace_queries_of_the_bluestein_path(lib):
     d.in_x = d.out_x = L.pm_axis(2048, 2048, 0, 1024)
     d.in_ld = d.out_ld = 2048
     assert lib.pm_fft2_workspace(ctypes.byref(d)) == 2 * 16384 * 2048 * 8
+    # both axes Bluestein lengths above 4096: [a | c | spectrum (MB1 x MB2) | two more of that for the big transforms]
+    d.in_y = d.out_y = L.pm_axis(5000, 5000, 0, 0)
+    d.in_x = d.out_x = L.pm_axis(4500, 4500, 0, 0)
+    d.in_ld = d.out_ld = 4500
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 2 * a256(5000 * 4500 * 8) + 3 * 16384 * 16384 * 8
     # 1-D: rows of 1000 points (MB = 2048); powers of two, short lengths and lengths above 4096 need none
     assert lib.pm_fft1_workspace(L.PM_C128, 1, 300, 1000) == a256(300 * 1000 * 16) + a256(300 * 2048 * 16)
     assert lib.pm_fft1_workspace(L.PM_C64, 0, 64, 777) == a256(64 * 777 * 8) + a256(64 * 2048 * 8)

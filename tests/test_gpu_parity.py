@@ -1018,6 +1018,54 @@ def test_big_16384_squared_separable_field(pa):
     print('focus 16384^2 complex64: %.2f ms' % ev0.elapsed_time(ev1))
 
 
+@pytest.mark.parametrize('shape,dtype', [((40, 24), np.complex128), ((50, 50), np.complex64), ((24, 100), np.complex128)])
+def test_long_bluestein_on_small_arrays(pa, shape, dtype):
+    """Lengths in (4096, 16384] that are not powers of two convolve at 16384 / 32768 points: chirp multiply, big transform with the
+    chirp spectrum in its epilogue, big inverse with the crop, chirp multiply.  Run here on small arrays (native length 32, path
+    from 20 points) against numpy: forward, inverse, windows, real input."""
+    from prysm_amd import _lib, _ops
+    lib = _lib.load()
+    rng = np.random.default_rng(sum(shape))
+    tol = TOL32 if dtype == np.complex64 else TOL64
+    M, N = shape
+    try:
+        lib.pm_set_tuning(b'big_native_log', 5)
+        lib.pm_set_tuning(b'blue_min', 20)
+        x = crandn(rng, shape, dtype)
+        xd = torch.from_numpy(x).cuda()
+        x128 = x.astype(np.complex128)
+        assert rel_max(_ops.fft2(xd, direction=-1, scale=1.0).cpu().numpy(), np.fft.fft2(x128)) < tol
+        assert rel_max(_ops.fft2(xd, direction=+1, scale=1.0 / (M * N)).cpu().numpy(), np.fft.ifft2(x128)) < tol
+        small = x[:M // 2, :N // 2]
+        ref = O.focus(small.astype(np.complex128), 2)
+        assert rel_max(tonp(pa.propagation.focus(small, 2)), ref) < tol
+        assert rel_max(tonp(pa.propagation.focus_intensity(small, 2)), O.intensity(ref)) < 2 * tol
+        g = crandn(rng, shape, dtype)
+        assert rel_max(tonp(pa.propagation.focus_adjoint(g, 2)), O.focus_adjoint(g.astype(np.complex128), 2)) < tol
+        xr = np.ascontiguousarray(x.real)
+        assert rel_max(_ops.fft2(torch.from_numpy(xr).cuda(), direction=-1, scale=1.0).cpu().numpy(), np.fft.fft2(xr.astype(np.float64))) < tol
+    finally:
+        lib.pm_set_tuning(b'big_native_log', 13)
+        lib.pm_set_tuning(b'blue_min', 96)
+
+
+def test_long_bluestein_5000(pa):
+    """unfocus of a 5000 x 4500 complex64 field (convolution at 16384 points) against numpy; timing of 8000^2 printed."""
+    rng = np.random.default_rng(5000)
+    x = crandn(rng, (5000, 4500), np.complex64)
+    got = tonp(pa.propagation.unfocus(x, 1))
+    assert rel_max(got, O.unfocus(x.astype(np.complex128), 1)) < TOL32
+    xd = torch.from_numpy(crandn(rng, (8000, 8000), np.complex64)).cuda()
+    pa.propagation.focus(xd, 1)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    pa.propagation.focus(xd, 1)
+    ev1.record()
+    torch.cuda.synchronize()
+    print('focus 8000^2 complex64 (Bluestein at 16384^2): %.2f ms' % ev0.elapsed_time(ev1))
+
+
 def test_randomised_differential_fuzz(pa):
     """tools/fuzz_fft2.py: random sizes / windows / rotations / crops / input kinds / stacks / epilogues / multipliers /
     precisions / fold settings of pm_fft2 and the fused chain against numpy (a fixed seed keeps it reproducible)."""
