@@ -259,7 +259,7 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     p.blue_off = (p.ws_bytes + 255) & ~size_t(255);
     const bool noflags = !(d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY | PM_FLAG_SYNTH_INPUT));
     p.blue2d = p.blue_n && p.blue_m && tuning().blue_2d && noflags;
-    p.blue_big = !p.blue2d && use_blue_long(N) && use_blue_long(M) && tuning().blue_2d && noflags &&
+    p.blue_big = !p.blue2d && tuning().blue_2d && noflags && blue_reach(N) && blue_reach(M) && (blue_needs_both(N) || blue_needs_both(M)) &&
                  (big_split(blue_conv_len(N)) > 1 || big_split(blue_conv_len(M)) > 1);
     if (p.blue_big) {   // [a (M x N) | c (M x N) | spectrum (MB1 x MB2) | workspace of the big transforms]
         p.blue2d = true;

@@ -151,5 +151,14 @@ inline bool use_blue_long(int64_t n) {
     return lo > 0 && n >= lo && n >= 2 && (n & (n - 1)) != 0 && n <= (int64_t(1) << 20) && big_split(blue_conv_len(n)) >= 1;
 }
 inline bool use_blue(int64_t n) { return use_blue_long(n) && big_split(blue_conv_len(n)) == 1; }
+// MIXED shapes with one axis the paths above cannot take alone (a length in (4096, 16384] that is not a power of two, or a
+// 16384-point axis beside a non power of two): the both-axes form runs them with the OTHER axis convolved as well -- any length
+// from 2 whose convolution length the transforms reach (wasteful by the padding of that axis, but O(n log n))
+inline bool blue_reach(int64_t n) { return tuning().blue_min > 0 && n >= 2 && n <= (int64_t(1) << 20) && big_split(blue_conv_len(n)) >= 1; }
+inline bool blue_needs_both(int64_t n) {
+    const bool pow2 = (n & (n - 1)) == 0;
+    if (!blue_reach(n)) return false;
+    return pow2 ? big_split(n) > 1 : (n >= tuning().blue_min && !use_blue(n));
+}
 
 }  // namespace pm

@@ -116,6 +116,19 @@ def test_workspace_queries_of_the_bluestein_path(lib):
     d.in_x = d.out_x = L.pm_axis(4500, 4500, 0, 0)
     d.in_ld = d.out_ld = 4500
     assert lib.pm_fft2_workspace(ctypes.byref(d)) == 2 * a256(5000 * 4500 * 8) + 3 * 16384 * 16384 * 8
+    # mixed shapes whose awkward axis the other paths cannot take alone convolve BOTH axes
+    d.in_y = d.out_y = L.pm_axis(8000, 8000, 0, 0)
+    d.in_x = d.out_x = L.pm_axis(8192, 8192, 0, 0)
+    d.in_ld = d.out_ld = 8192
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 2 * a256(8000 * 8192 * 8) + 3 * 16384 * 16384 * 8
+    d.in_y = d.out_y = L.pm_axis(16384, 16384, 0, 0)
+    d.in_x = d.out_x = L.pm_axis(1000, 1000, 0, 0)
+    d.in_ld = d.out_ld = 1000
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 2 * a256(16384 * 1000 * 8) + 3 * 32768 * 2048 * 8
+    # ... 32768 points beside a non power of two is beyond that: its columns stay on the direct kernel (the 1000-point rows
+    # take the axis-by-axis form: natural intermediate + pre-multiplied rows + their 2048-point transforms)
+    d.in_y = d.out_y = L.pm_axis(32768, 32768, 0, 0)
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 32768 * 1000 * 8 + a256(32768 * 1000 * 8) + a256(32768 * 2048 * 8)
     # 1-D: rows of 1000 points (MB = 2048); powers of two, short lengths and lengths above 4096 need none
     assert lib.pm_fft1_workspace(L.PM_C128, 1, 300, 1000) == a256(300 * 1000 * 16) + a256(300 * 2048 * 16)
     assert lib.pm_fft1_workspace(L.PM_C64, 0, 64, 777) == a256(64 * 777 * 8) + a256(64 * 2048 * 8)

@@ -1018,7 +1018,8 @@ def test_big_16384_squared_separable_field(pa):
     print('focus 16384^2 complex64: %.2f ms' % ev0.elapsed_time(ev1))
 
 
-@pytest.mark.parametrize('shape,dtype', [((40, 24), np.complex128), ((50, 50), np.complex64), ((24, 100), np.complex128)])
+@pytest.mark.parametrize('shape,dtype', [((40, 24), np.complex128), ((50, 50), np.complex64), ((24, 100), np.complex128),
+                                         ((40, 16), np.complex128), ((64, 24), np.complex64), ((6, 40), np.complex128)])   # mixed shapes: native / split power of two / short axis beside a long one
 def test_long_bluestein_on_small_arrays(pa, shape, dtype):
     """Lengths in (4096, 16384] that are not powers of two convolve at 16384 / 32768 points: chirp multiply, big transform with the
     chirp spectrum in its epilogue, big inverse with the crop, chirp multiply.  Run here on small arrays (native length 32, path
