@@ -3,7 +3,6 @@ variant M: matrix-DFT onto a 512^2 grid), per-wavelength breakdown."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import prysm_oracle as O
 from prysm_amd import propagation as P, _ops
 from prysm_amd.conf import config
 from prysm_amd.polychromatic import polychromatic_psf
@@ -17,10 +16,11 @@ def t(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 n = 4096
-x, y = O.make_xy_grid(n, diameter=10)
-r, th = O.cart_to_polar(x, y)
-amp = O.circle(5, r)
-opd = O.hopkins_w040(r / 5, 500.0)
+ax = (np.arange(n) - n // 2) * (10.0 / n)          # make_xy_grid(n, diameter=10)
+x, y = np.meshgrid(ax, ax)
+r = np.hypot(x, y)
+amp = (r <= 5).astype(np.float64)                  # circle(5, r)
+opd = 500.0 * (r / 5) ** 4                          # 500 nm of Hopkins W040
 dx = float(x[0, 1] - x[0, 0])
 wvls = np.linspace(0.5, 0.7, 64)[:8]
 wts = np.ones(8)
