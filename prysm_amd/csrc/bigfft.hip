@@ -27,21 +27,6 @@ __device__ __forceinline__ cx<T> mul_wr(cx<T> v, int e, int R) {
     }
 }
 
-template <typename T>
-__device__ __forceinline__ cx<T> big_fetch(const Blue2dIn<T>& in, int i, int j) {
-    const int qy = in.ay.map(i), qx = in.ax.map(j);
-    cx<T> x{T(0), T(0)};
-    if (qy >= 0 && qx >= 0) {
-        const int64_t at = int64_t(qy) * in.ld + qx;
-        if (in.real)
-            x.x = reinterpret_cast<const T*>(in.src)[at];
-        else
-            x = reinterpret_cast<const cx<T>*>(in.src)[at];
-        if (in.conj) x.y = -x.y;
-    }
-    return x;
-}
-
 // Y[m][i][j], planes of M x n' (all M LOGICAL rows: rows outside the stored window come out zero)
 template <typename T>
 __global__ void big_pre_rows_kernel(Blue2dIn<T> in, int M, int np, int R, cx<T>* Y, const cx<T>* twN) {
@@ -49,7 +34,7 @@ __global__ void big_pre_rows_kernel(Blue2dIn<T> in, int M, int np, int R, cx<T>*
     if (g >= int64_t(M) * np) return;
     const int i = int(g / np), j = int(g - int64_t(i) * np);
     cx<T> x[4];
-    for (int r = 0; r < R; ++r) x[r] = big_fetch(in, i, j + r * np);
+    for (int r = 0; r < R; ++r) x[r] = fetch2d(in, i, j + r * np);
     const int64_t plane = int64_t(M) * np;
     for (int m = 0; m < R; ++m) {
         cx<T> s{T(0), T(0)};

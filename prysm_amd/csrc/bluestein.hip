@@ -82,18 +82,7 @@ __global__ void blue_pre2d_kernel(Blue2dIn<T> in, cx<T>* a, const cx<T>* w1, con
     const int n1 = in.ay.n, n2 = in.ax.n;
     if (g >= int64_t(n1) * n2) return;
     const int i = int(g / n2), j = int(g - int64_t(i) * n2);
-    const int qy = in.ay.map(i), qx = in.ax.map(j);
-    cx<T> x{T(0), T(0)};
-    if (qy >= 0 && qx >= 0) {
-        const int64_t at = int64_t(qy) * in.ld + qx;
-        if (in.real)
-            x.x = reinterpret_cast<const T*>(in.src)[at];
-        else
-            x = reinterpret_cast<const cx<T>*>(in.src)[at];
-        if (in.conj) x.y = -x.y;
-        x = cmul(x, cmul(w1[i], w2[j]));
-    }
-    a[g] = x;
+    a[g] = cmul(fetch2d(in, i, j), cmul(w1[i], w2[j]));
 }
 
 template <typename T>

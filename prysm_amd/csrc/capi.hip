@@ -121,6 +121,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
     else if (is("blue_min")) t.blue_min = v < 0 ? 0 : v;
     else if (is("blue_2d")) t.blue_2d = v ? 1 : 0;
+    else if (is("blue_fuse")) t.blue_fuse = v ? 1 : 0;
     else if (is("big_native_log")) t.big_native_log = v < 1 ? 1 : (v > kEngineMaxLog ? kEngineMaxLog : v);
 }
 
@@ -585,6 +586,9 @@ static size_t blue2d_fused_ws(int dtype, int64_t M, int64_t N) {
 }
 
 template <typename T>
+static int blue2d_fused_run(const pm_fft2_desc* d, const void* in, void* out, void* ws, hipStream_t st);
+
+template <typename T>
 static int blue2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st) {
     const int64_t M = d->in_y.n, N = d->in_x.n;
     int err = 0;
@@ -597,6 +601,7 @@ static int blue2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, 
     cx<T>* c = reinterpret_cast<cx<T>*>(static_cast<char*>(ws) + arr);
     void* fws = static_cast<char*>(ws) + 2 * arr;
     Blue2dIn<T> bi{in, d->in_ld, to_map(d->in_y), to_map(d->in_x), d->direction > 0 ? 1 : 0, (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
+    if (!p.blue_big && tuning().blue_fuse) return blue2d_fused_run<T>(d, in, out, fws, st);
     int rc = blue_pre2d<T>(bi, a, t1, t2, st);
     if (rc) return rc;
     pm_fft2_desc dd;
@@ -636,6 +641,52 @@ static int blue2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, 
     if (rc) return rc;
     const ColStoreNat<T> cs = make_colstore<T>(d, out);
     return blue_post2d<T>(c, int(M), int(N), t1, t2, cs, st);
+}
+
+// The same on engine lengths with the two chirp multiplies inside the chain: the first row pass loads the caller's view times
+// w1 (x) w2 (RowLoadChirp), the last one stores conj(.) w1 (x) w2 through the caller's epilogue (RowStoreChirp).  Three launches,
+// no n1 x n2 temporaries.  (The unfolded passes of fused_run_chunk with those two ends.)
+template <typename T>
+static int blue2d_fused_run(const pm_fft2_desc* d, const void* in, void* out, void* ws, hipStream_t st) {
+    const int64_t n1 = d->in_y.n, n2 = d->in_x.n;
+    int err = 0;
+    const cx<T>* t1 = blue_tables<T>(n1, &err);
+    if (!t1) return err;
+    const cx<T>* t2 = blue_tables<T>(n2, &err);
+    if (!t2) return err;
+    pm_fft2_desc dd;
+    blue2d_desc(dd, d->dtype, n1, n2);
+    FusedPlan fp;
+    if (!plan_fused(&dd, fp) || fp.fold) return fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: no fused plan for the Bluestein convolution");
+    const int64_t M = dd.in_y.n, N = dd.in_x.n;   // convolution lengths
+    const int rows = int(n1);
+    cx<T>* W1 = reinterpret_cast<cx<T>*>(ws);
+    cx<T>* W2 = fp.inplace ? W1 : reinterpret_cast<cx<T>*>(reinterpret_cast<char*>(ws) + fp.w1_bytes);
+    const cx<T>* twN = twiddles<T>(N, &err);
+    if (!twN) return err;
+    const cx<T>* twM = twiddles<T>(M, &err);
+    if (!twM) return err;
+    const int tl = fp.tc << fp.log_k;
+    int ltl = 0;
+    while ((1 << ltl) < tl) ++ltl;
+    // pass A: rows x(i, .) w1[i] w2[.] padded to N, forward transform -> tiled W1 (n1 rows)
+    RowLoadChirp<T> lp{Blue2dIn<T>{in, d->in_ld, to_map(d->in_y), to_map(d->in_x), d->direction > 0 ? 1 : 0,
+                                   (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0},
+                       t1, t2, rows};
+    RowStoreTiled<T> sp{W1, rows, ltl, 0};
+    int rc = launch_row_chirp_tiled<T>(fp.logn, row_variant(d->dtype, fp.logn), lp, sp, twN, rows, tuning().row_log_g, st);
+    if (rc) return rc;
+    // pass B: column FFT x (B1 (x) B2) x column IFFT -> tiled W2 (all M rows)
+    const int ntiles = int((N + fp.tc - 1) / fp.tc);
+    ColLoadTiled<T> cl{W1, rows, AxisMap{int(M), rows, 0, 0}, ntiles, fp.log_k, 0};
+    MidMul<T> mm{MUL_SEPARABLE, 0, t1 + n1, t2 + n2, 0, int(N), 0, 0, 0, 0};
+    ColStoreTiled<T> cst{W2, int(M), ntiles, fp.log_k, 0};
+    rc = launch_col_mul<T>(fp.logm, cl, mm, cst, twM, ntiles, sibling_log_g(fp.log_k), st, 1);
+    if (rc) return rc;
+    // pass C: inverse row transforms of the first n1 rows, bins [0, n2) x chirp through the caller's epilogue
+    RowLoadTiled<T> rl{W2, int(M), ltl, 0, rows, 1, 0};
+    RowStoreChirp<T> rs{make_colstore<T>(d, out), t1, t2, int(n1), int(n2), 1};
+    return launch_row_tiled_chirp<T>(fp.logn, row_variant(d->dtype, fp.logn), rl, rs, twN, rows, st);
 }
 
 // ---------------------------------------------------------------- powers of two above the engine's longest transform

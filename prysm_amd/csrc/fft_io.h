@@ -183,6 +183,51 @@ struct ColStoreNat {
     int64_t mul_bstride_x; // elements between per-field hx vectors
 };
 
+// A caller's 2-D array seen through its pm_fft2 view (window / rotation per axis, real arrays, conjugation): the input of the
+// both-axes Bluestein form and of the big power-of-two path.
+template <typename T>
+struct Blue2dIn {
+    const void* src;   // cx<T>* or T* (real)
+    int64_t ld;
+    AxisMap ay, ax;
+    int conj, real;
+};
+// element (i, j) of the LOGICAL array behind the view: zero outside the stored window
+template <typename T>
+PM_HD cx<T> fetch2d(const Blue2dIn<T>& in, int i, int j) {
+    const int qy = in.ay.map(i), qx = in.ax.map(j);
+    cx<T> x{T(0), T(0)};
+    if (qy >= 0 && qx >= 0) {
+        const int64_t at = int64_t(qy) * in.ld + qx;
+        if (in.real)
+            x.x = reinterpret_cast<const T*>(in.src)[at];
+        else
+            x = reinterpret_cast<const cx<T>*>(in.src)[at];
+        if (in.conj) x.y = -x.y;
+    }
+    return x;
+}
+
+// Row pass of the both-axes Bluestein chain with the FIRST chirp multiply in its load: sequence i (i < n1) is the logical row
+// x(i, j) w1[i] w2[j], j < n2, zero padded to the convolution length of the transform (bluestein.h).
+template <typename T>
+struct RowLoadChirp {
+    Blue2dIn<T> in;
+    const cx<T>* w1;
+    const cx<T>* w2;
+    int nseq;       // n1
+};
+// ... and with the LAST chirp multiply and the caller's epilogue in its store: bin (k, c), k < n1, c < n2, goes out as
+// epilogue(conj?(v) w1[k] w2[c]) through store_one (scale, conj, rotation / crop, multiplier, |.|^2)
+template <typename T>
+struct RowStoreChirp {
+    ColStoreNat<T> out;
+    const cx<T>* w1;
+    const cx<T>* w2;
+    int n1, n2;
+    int conj;       // conj-out of the inverse row transform
+};
+
 // slot rotation helper: memory index (before the window offset) of register slot m.
 //   ROT >= 0 : shift == ROT * TPS  ->  p = t + ((m + ROT) mod P) * TPS      (compile-time slot)
 //   ROT <  0 : generic             ->  p = (t + m*TPS + shift) mod N
@@ -291,6 +336,8 @@ template <typename T> PM_HD RowStoreFold<T> at_batch(RowStoreFold<T> p, int b) {
 template <typename T> PM_HD RowStoreNat<T> at_batch(RowStoreNat<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD RowLoadFold<T> at_batch(RowLoadFold<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD RowLoadTiled<T> at_batch(RowLoadTiled<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD RowLoadChirp<T> at_batch(RowLoadChirp<T> p, int) { return p; }    // one field per launch
+template <typename T> PM_HD RowStoreChirp<T> at_batch(RowStoreChirp<T> p, int) { return p; }
 template <typename T> PM_HD ColStoreTiled<T> at_batch(ColStoreTiled<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD ColLoadTiled<T> at_batch(ColLoadTiled<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD ColLoadNat<T> at_batch(ColLoadNat<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
@@ -480,6 +527,26 @@ PM_HD void load(const RowLoadTiled<typename C::T>& p, int blk, ThreadPos pos, cx
             cx<T> val = {T(0), T(0)};
             if (ok) val = p.src[a];
             if (p.conj) val.y = -val.y;
+            v[e][m] = val;
+        }
+    }
+}
+
+template <typename C>
+PM_HD void load(const RowLoadChirp<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    static_assert(C::CI == 1, "row mode");
+    const int n2 = p.in.ax.n;
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) {
+        const int seq = (blk * C::BO + pos.bo) * C::E + e;
+        const bool ok = seq < p.nseq;
+        const cx<T> wy = p.w1[ok ? seq : 0];
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) {
+            const int c = pos.t + m * C::TPS;
+            cx<T> val = {T(0), T(0)};
+            if (ok && c < n2) val = cmul(fetch2d(p.in, seq, c), cmul(wy, p.w2[c]));
             v[e][m] = val;
         }
     }
@@ -709,6 +776,25 @@ PM_HD void store_one(const ColStoreNat<T>& p, int k, int c, cx<T> x) {
             *o = i2;
         else
             *o += p.weight * i2;
+    }
+}
+
+template <typename C>
+PM_HD void store(const RowStoreChirp<typename C::T>& p, int blk, ThreadPos pos, const cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) {
+        const int seq = (blk * C::BO + pos.bo) * C::E + e;
+        if (seq >= p.n1) continue;
+        const cx<T> wy = p.w1[seq];
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) {
+            const int c = pos.t + m * C::TPS;
+            if (c >= p.n2) continue;
+            cx<T> val = v[e][m];
+            if (p.conj) val.y = -val.y;
+            store_one(p.out, seq, c, cmul(val, cmul(wy, p.w2[c])));
+        }
     }
 }
 

@@ -16,4 +16,10 @@ template <> int launch_row_fold<double>(int logn, const RowLoadNat<double>& l, c
 template <> int launch_row_unfold<double>(int logn, const RowLoadFold<double>& l, const RowStoreNat<double>& s, const cx<double>* tw, int npairs, hipStream_t st, int nbatch) {
     return launch_unfold_impl<double>(logn, l, s, tw, npairs, st, nbatch);
 }
+template <> int launch_row_chirp_tiled<double>(int logn, int var, const RowLoadChirp<double>& l, const RowStoreTiled<double>& s, const cx<double>* tw, int nseq, int log_g, hipStream_t st) {
+    return launch_fft<double, false>(logn, var == 2 ? 0 : var, l, s, tw, nseq, log_g, st, 1);
+}
+template <> int launch_row_tiled_chirp<double>(int logn, int var, const RowLoadTiled<double>& l, const RowStoreChirp<double>& s, const cx<double>* tw, int nseq, hipStream_t st) {
+    return launch_fft<double, false>(logn, var == 2 ? 0 : var, l, s, tw, nseq, 0, st, 1);
+}
 }  // namespace pm

@@ -51,16 +51,13 @@ int blue_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, void* scratch, h
 
 // both axes at once (capi.hip blue2d_run): the chirp multiplies around ONE fused fft2 -> x (B1 (x) B2) -> ifft2 chain of size
 // MB1 x MB2 (the 2-D cyclic convolution with the separable chirp)
-template <typename T>
-struct Blue2dIn {
-    const void* src;   // cx<T>* or T* (real)
-    int64_t ld;
-    AxisMap ay, ax;
-    int conj, real;
-};
 template <typename T> int blue_pre2d(const Blue2dIn<T>& in, cx<T>* a, const cx<T>* w1, const cx<T>* w2, hipStream_t st);
 template <typename T>
 int blue_post2d(const cx<T>* t, int n1, int n2, const cx<T>* w1, const cx<T>* w2, const ColStoreNat<T>& out, hipStream_t st);
+
+// the same chain with the chirp multiplies riding on its first load and its last store (fft_row_*.hip instantiations)
+template <typename T> int launch_row_chirp_tiled(int logn, int var, const RowLoadChirp<T>&, const RowStoreTiled<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t);
+template <typename T> int launch_row_tiled_chirp(int logn, int var, const RowLoadTiled<T>&, const RowStoreChirp<T>&, const cx<T>* tw, int nseq, hipStream_t);
 
 // power-of-two lengths above the engine's longest transform (bigfft.hip; orchestration: capi.hip big2d_run)
 template <typename T> int big_pre_rows(const Blue2dIn<T>& in, int M, int np, int R, cx<T>* Y, const cx<T>* twN, hipStream_t st);
@@ -102,6 +99,8 @@ struct Tuning {
     int col_skew = 0;        // experiment: start skew of every other column-pass workgroup, units of ~0.85 us
     int blue_min = 96;        // shortest non-power-of-two length that takes the Bluestein path (shorter ones, and lengths
                              // above 4096, run on the direct O(n^2) kernel); 0 disables the path
+    int blue_fuse = 1;        // both-axes form on engine lengths: chirp multiplies inside the chain's first load / last store (1)
+                             // or as separate kernels around it (0)
     int blue_2d = 1;          // both axes on the Bluestein path: one fused fft2 x B ifft2 chain (1) or axis by axis (0)
     int big_native_log = 13;  // log2 of the longest length handed to the engine as it is; longer powers of two (up to 4x) take
                              // one radix-2 / radix-4 step around engine transforms (bigfft.hip).  Tests lower it to run that

@@ -905,6 +905,12 @@ def test_bluestein_lengths(pa, shape, dtype):
     finally:
         lib.pm_set_tuning(b'blue_2d', 1)
     assert rel_max(per_axis, want) < tol
+    try:   # ... and with the chirp multiplies as separate kernels around the chain instead of inside its first load / last store
+        lib.pm_set_tuning(b'blue_fuse', 0)
+        unfused = _ops.fft2(xd, direction=-1, scale=1.0).cpu().numpy()
+    finally:
+        lib.pm_set_tuning(b'blue_fuse', 1)
+    assert rel_max(unfused, want) < tol
     inv = _ops.fft2(torch.from_numpy(got).cuda(), direction=+1, scale=1.0 / (shape[0] * shape[1])).cpu().numpy()
     assert rel_max(inv, x) < 2 * tol
     # the focus family on these shapes: pad to Q = 2 (non power-of-two padded size), shifts, adjoint crop

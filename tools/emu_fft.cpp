@@ -671,7 +671,124 @@ static void test_blue_cols(int n, int ncols, int in_rows, int in_off, int in_shi
     report(buf, err / nrm, sizeof(T) == 4 ? 3e-6 : 1e-13);
 }
 
+// --- both-axes Bluestein chain with the chirp multiplies inside the first load (RowLoadChirp) and the last store (RowStoreChirp):
+// the three emulated engine passes of blue2d_fused_run (capi.hip) against a naive n1 x n2 DFT of the caller's view, epilogue included
+template <typename T, int LOGM, int LOGN, int RBO, int RE, int CCI, int CE, int CBO, int CCOMP>
+static void test_blue2d_fused(int n1, int n2, int in_rows, int in_cols, int offy, int offx, int shy, int shx, bool real_in, bool inverse,
+                              int out_rows, int out_cols, int ooffy, int ooffx, int oshy, int oshx, int epilogue, int log_k) {
+    using RC = FftCfg<T, LOGN, 1, RE, RBO, 1>;
+    using CC = FftCfg<T, LOGM, CCI, CE, CBO, CCOMP>;
+    const int M = CC::N, N = RC::N, TC = CCI * CE, TL = TC << log_k;
+    if (M != blue_conv_len(n1) || N != blue_conv_len(n2)) { printf("blue2d fused: convolution length mismatch\n"); ++g_fail; return; }
+    int ltl = 0;
+    while ((1 << ltl) < TL) ++ltl;
+    std::mt19937 rng(n1 * 31 + n2);
+    std::normal_distribution<double> nd;
+    std::vector<cx<T>> x(size_t(in_rows) * in_cols);
+    std::vector<T> xr(size_t(in_rows) * in_cols);
+    for (auto& e : x) e = {T(nd(rng)), T(nd(rng))};
+    for (auto& e : xr) e = T(nd(rng));
+    std::vector<cx<T>> t1, t2;
+    blue_make_tables<T>(n1, M, t1);
+    blue_make_tables<T>(n2, N, t2);
+    const int ntl = (N + TL - 1) / TL, ntiles = (N + TC - 1) / TC;
+    std::vector<cx<T>> W1(size_t(ntl) * n1 * TL, cx<T>{T(1e30), T(1e30)}), W2(size_t(ntl) * M * TL, cx<T>{T(1e30), T(1e30)});
+    auto twN = make_tw<T>(N);
+    auto twM = make_tw<T>(M);
+    Blue2dIn<T> view{real_in ? (const void*)xr.data() : (const void*)x.data(), in_cols, AxisMap{n1, in_rows, offy, shy},
+                     AxisMap{n2, in_cols, offx, shx}, inverse ? 1 : 0, real_in ? 1 : 0};
+    RowLoadChirp<T> lp{view, t1.data(), t2.data(), n1};
+    RowStoreTiled<T> sp{W1.data(), n1, ltl};
+    emu_kernel<RC, false>((n1 + RC::BO * RE - 1) / (RC::BO * RE), lp, sp, twN.data());
+    ColLoadTiled<T> cl{W1.data(), n1, AxisMap{M, n1, 0, 0}, ntiles, log_k};
+    MidMul<T> mm{MUL_SEPARABLE, 0, t1.data() + n1, t2.data() + n2, 0, N};
+    ColStoreTiled<T> cst{W2.data(), M, ntiles, log_k};
+    {
+        std::vector<Regs<CC>> regs(CC::NT);
+        std::vector<typename LdsType<CC>::type> lds(CC::LDS_ELEMS + 1);
+        const int ngroups = (ntiles + CC::BO - 1) / CC::BO;
+        for (int g = 0; g < ngroups; ++g) {
+            for (int tid = 0; tid < CC::NT; ++tid) {
+                ThreadPos pos = thread_pos<CC>(tid);
+                load<CC>(cl, g * CC::BO + pos.bo, pos, regs[tid].v);
+            }
+            emu_stages<CC, 0>(regs, lds, twM.data());
+            for (int tid = 0; tid < CC::NT; ++tid) {
+                ThreadPos pos = thread_pos<CC>(tid);
+                mid_multiply_conj<CC>(mm, g * CC::BO + pos.bo, pos, regs[tid].v);
+            }
+            emu_stages<CC, 0>(regs, lds, twM.data());
+            for (int tid = 0; tid < CC::NT; ++tid) {
+                ThreadPos pos = thread_pos<CC>(tid);
+                for (int e = 0; e < CC::E; ++e)
+                    for (int m = 0; m < CC::P; ++m) regs[tid].v[e][m].y = -regs[tid].v[e][m].y;
+                store<CC>(cst, g * CC::BO + pos.bo, pos, regs[tid].v);
+            }
+        }
+    }
+    std::vector<cx<T>> oc(size_t(out_rows) * out_cols, cx<T>{T(-7), T(-7)});
+    std::vector<T> orl(size_t(out_rows) * out_cols, T(-7));
+    ColStoreNat<T> cs{};
+    cs.dst = epilogue ? (void*)orl.data() : (void*)oc.data();
+    cs.ld = out_cols;
+    cs.ay = AxisMap{n1, out_rows, ooffy, oshy};
+    cs.ax = AxisMap{n2, out_cols, ooffx, oshx};
+    cs.conj = inverse ? 1 : 0;
+    cs.epilogue = epilogue;
+    cs.scale = T(0.25);
+    cs.weight = T(1);
+    cs.mul_kind = MUL_NONE;
+    RowLoadTiled<T> rl{W2.data(), M, ltl, 0, n1, 1};
+    RowStoreChirp<T> rs{cs, t1.data(), t2.data(), n1, n2, 1};
+    emu_kernel<RC, false>((n1 + RC::BO * RE - 1) / (RC::BO * RE), rl, rs, twN.data());
+    // truth: separable naive DFT of the logical n1 x n2 array (conj-in / conj-out for the inverse), scale 0.25
+    const ld pi = acosl(-1.0L);
+    std::vector<cld> L(size_t(n1) * n2), R(size_t(n1) * n2), F(size_t(n1) * n2);
+    for (int i = 0; i < n1; ++i)
+        for (int j = 0; j < n2; ++j) {
+            const cx<T> v = fetch2d(view, i, j);
+            L[size_t(i) * n2 + j] = cld(v.x, v.y);
+        }
+    for (int i = 0; i < n1; ++i)
+        for (int k = 0; k < n2; ++k) {
+            cld acc(0, 0);
+            for (int j = 0; j < n2; ++j) acc += L[size_t(i) * n2 + j] * std::polar(ld(1), -2 * pi * ld((int64_t(j) * k) % n2) / n2);
+            R[size_t(i) * n2 + k] = acc;
+        }
+    for (int k = 0; k < n1; ++k)
+        for (int c = 0; c < n2; ++c) {
+            cld acc(0, 0);
+            for (int i = 0; i < n1; ++i) acc += R[size_t(i) * n2 + c] * std::polar(ld(1), -2 * pi * ld((int64_t(i) * k) % n1) / n1);
+            F[size_t(k) * n2 + c] = acc;
+        }
+    double err = 0, nrm = 0;
+    for (int k = 0; k < n1; ++k)
+        for (int c = 0; c < n2; ++c) {
+            const int qy = cs.ay.map(k), qx = cs.ax.map(c);
+            if (qy < 0 || qx < 0) continue;
+            cld ref = F[size_t(k) * n2 + c] * ld(0.25);
+            if (inverse) ref = std::conj(ref);
+            if (epilogue) {
+                err = fmax(err, fabs(double(std::norm(ref)) - double(orl[size_t(qy) * out_cols + qx])));
+                nrm = fmax(nrm, double(std::norm(ref)));
+            } else {
+                const cx<T> got = oc[size_t(qy) * out_cols + qx];
+                err = fmax(err, (double)std::abs(ref - cld(got.x, got.y)));
+                nrm = fmax(nrm, (double)std::abs(ref));
+            }
+        }
+    char buf[200];
+    snprintf(buf, sizeof buf, "bluestein 2-D fused %s %dx%d (conv %dx%d) in=%dx%d@%d,%d sh=%d,%d real=%d inv=%d out=%dx%d epi=%d E=%d", sizeof(T) == 4 ? "c64" : "c128",
+             n1, n2, M, N, in_rows, in_cols, offy, offx, shy, shx, int(real_in), int(inverse), out_rows, out_cols, epilogue, RE);
+    report(buf, err / nrm, sizeof(T) == 4 ? 4e-6 : 1e-13);
+}
+
 int main() {
+    test_blue2d_fused<float, 6, 7, 32, 1, 4, 2, 16, 1>(20, 50, 20, 50, 0, 0, 10, 25, false, false, 20, 50, 0, 0, 10, 25, 0, 1);      // focus-like: both rotations
+    test_blue2d_fused<float, 7, 6, 64, 2, 4, 2, 8, 1>(50, 24, 25, 12, 13, 6, 25, 12, false, true, 30, 20, 10, 2, 25, 12, 0, 0);     // Q = 2 pad, inverse, crop, 2 rows / thread
+    test_blue2d_fused<float, 6, 6, 64, 1, 4, 2, 16, 1>(30, 30, 30, 30, 0, 0, 0, 0, true, false, 30, 30, 0, 0, 15, 15, 1, 1);          // real input, |.|^2
+    test_blue2d_fused<double, 6, 7, 32, 1, 4, 1, 16, 2>(24, 40, 24, 40, 0, 0, 12, 20, false, false, 24, 40, 0, 0, 12, 20, 0, 2);
+    test_blue2d_fused<double, 7, 5, 128, 2, 4, 1, 8, 2>(40, 12, 20, 12, 10, 0, 20, 6, false, true, 40, 12, 0, 0, 0, 0, 0, 1);
     test_blue_rows<float, 8, 16>(100, 5, 100, 0, 0, false, false);
     test_blue_rows<float, 8, 16>(127, 3, 60, 34, 63, true, false);      // padded (Q ~ 2) + ifftshift rotation + inverse
     test_blue_rows<float, 9, 8>(129, 4, 129, 0, 64, false, true);       // real input, MB = 512

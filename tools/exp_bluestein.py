@@ -32,9 +32,10 @@ def main():
         xd = torch.from_numpy(x).cuda()
         want = np.fft.fft2(x.astype(np.complex128))
         res = {}
-        for name, lo in (('bluestein', 1), ('peraxis', 1), ('direct', 0)):
+        for name, lo in (('bluestein', 1), ('unfused', 1), ('peraxis', 1), ('direct', 0)):
             lib.pm_set_tuning(b'blue_min', lo)
             lib.pm_set_tuning(b'blue_2d', 0 if name == 'peraxis' else 1)
+            lib.pm_set_tuning(b'blue_fuse', 0 if name == 'unfused' else 1)
             f = lambda: _ops.fft2(xd, direction=-1, scale=1.0)
             if name == 'direct' and n > 2000:
                 res[name] = (float('nan'), float('nan'))
@@ -42,8 +43,10 @@ def main():
             err = np.abs(f().cpu().numpy() - want).max() / np.abs(want).max()
             res[name] = (timeit(f, 20 if name != 'direct' or n <= 520 else 3), err)
         lib.pm_set_tuning(b'blue_min', 96)
-        print('EXP n=%5d %-10s bluestein 2-D %8.1f us (err %.1e)   per axis %8.1f us (err %.1e)   direct %10.1f us (err %.1e)' %
-              (n, np.dtype(dt).name, res['bluestein'][0], res['bluestein'][1], res['peraxis'][0], res['peraxis'][1],
+        lib.pm_set_tuning(b'blue_2d', 1)
+        lib.pm_set_tuning(b'blue_fuse', 1)
+        print('EXP n=%5d %-10s bluestein 2-D %8.1f us (err %.1e)   chirps as separate kernels %8.1f us   per axis %8.1f us (err %.1e)   direct %10.1f us (err %.1e)' %
+              (n, np.dtype(dt).name, res['bluestein'][0], res['bluestein'][1], res['unfused'][0], res['peraxis'][0], res['peraxis'][1],
                res['direct'][0], res['direct'][1]), flush=True)
 
 
