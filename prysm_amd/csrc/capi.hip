@@ -676,15 +676,15 @@ static int blue2d_fused_run(const pm_fft2_desc* d, const void* in, void* out, vo
     RowStoreTiled<T> sp{W1, rows, ltl, 0};
     int rc = launch_row_chirp_tiled<T>(fp.logn, row_variant(d->dtype, fp.logn), lp, sp, twN, rows, tuning().row_log_g, st);
     if (rc) return rc;
-    // pass B: column FFT x (B1 (x) B2) x column IFFT -> tiled W2 (all M rows)
+    // pass B: column FFT x (B1 (x) B2) x column IFFT -> tiled W2
     const int ntiles = int((N + fp.tc - 1) / fp.tc);
     ColLoadTiled<T> cl{W1, rows, AxisMap{int(M), rows, 0, 0}, ntiles, fp.log_k, 0};
     MidMul<T> mm{MUL_SEPARABLE, 0, t1 + n1, t2 + n2, 0, int(N), 0, 0, 0, 0};
-    ColStoreTiled<T> cst{W2, int(M), ntiles, fp.log_k, 0};
-    rc = launch_col_mul<T>(fp.logm, cl, mm, cst, twM, ntiles, sibling_log_g(fp.log_k), st, 1);
+    ColStoreTiledCrop<T> cst{W2, rows, ntiles, fp.log_k};   // only the n1 rows the crop keeps are stored
+    rc = launch_col_mul_crop<T>(fp.logm, cl, mm, cst, twM, ntiles, sibling_log_g(fp.log_k), st);
     if (rc) return rc;
     // pass C: inverse row transforms of the first n1 rows, bins [0, n2) x chirp through the caller's epilogue
-    RowLoadTiled<T> rl{W2, int(M), ltl, 0, rows, 1, 0};
+    RowLoadTiled<T> rl{W2, rows, ltl, 0, rows, 1, 0};
     RowStoreChirp<T> rs{make_colstore<T>(d, out), t1, t2, int(n1), int(n2), 1};
     return launch_row_tiled_chirp<T>(fp.logn, row_variant(d->dtype, fp.logn), rl, rs, twN, rows, st);
 }

@@ -10,4 +10,7 @@ template <> int launch_col_nat<float>(int logm, int var, const ColLoadNat<float>
 template <> int launch_col_mul<float>(int logm, const ColLoadTiled<float>& l, const MidMul<float>& m, const ColStoreTiled<float>& s, const cx<float>* tw, int ntiles, int log_g, hipStream_t st, int nbatch) {
     return launch_col_mul_impl<float>(logm, l, m, s, tw, ntiles, log_g, st, nbatch);
 }
+template <> int launch_col_mul_crop<float>(int logm, const ColLoadTiled<float>& l, const MidMul<float>& m, const ColStoreTiledCrop<float>& s, const cx<float>* tw, int ntiles, int log_g, hipStream_t st) {
+    return launch_col_mul_impl<float>(logm, l, m, s, tw, ntiles, log_g, st, 1);
+}
 }  // namespace pm

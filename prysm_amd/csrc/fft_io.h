@@ -126,6 +126,16 @@ struct ColStoreTiled {
 
 // spectral multiplier applied between the forward and inverse column transforms, indexed by the
 // unshifted bin (row k, column c)
+// ... storing only rows [0, nrows) of the column results (the cropped convolution of the Bluestein chain): the buffer holds
+// nrows rows per layout tile, rows beyond are never written (nor read by the row pass that follows)
+template <typename T>
+struct ColStoreTiledCrop {
+    cx<T>* dst;
+    int nrows;
+    int ntiles;
+    int log_k;
+};
+
 template <typename T>
 struct MidMul {
     int kind;       // MUL_FULL / MUL_SEPARABLE
@@ -339,6 +349,7 @@ template <typename T> PM_HD RowLoadTiled<T> at_batch(RowLoadTiled<T> p, int b) {
 template <typename T> PM_HD RowLoadChirp<T> at_batch(RowLoadChirp<T> p, int) { return p; }    // one field per launch
 template <typename T> PM_HD RowStoreChirp<T> at_batch(RowStoreChirp<T> p, int) { return p; }
 template <typename T> PM_HD ColStoreTiled<T> at_batch(ColStoreTiled<T> p, int b) { p.dst += int64_t(b) * p.bstride; return p; }
+template <typename T> PM_HD ColStoreTiledCrop<T> at_batch(ColStoreTiledCrop<T> p, int) { return p; }   // one field per launch
 template <typename T> PM_HD ColLoadTiled<T> at_batch(ColLoadTiled<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD ColLoadNat<T> at_batch(ColLoadNat<T> p, int b) { p.src += int64_t(b) * p.bstride; return p; }
 template <typename T> PM_HD MidMul<T> at_batch(MidMul<T> p, int b) {
@@ -687,6 +698,29 @@ PM_HD void store(const ColStoreTiled<typename C::T>& p, int tile, ThreadPos pos,
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
         cx<T>* a = base + int64_t(pos.t + m * C::TPS) * TL;
+        if constexpr (C::E == 2 && sizeof(T) == 4) {
+            *reinterpret_cast<Vec4<T>*>(a) = Vec4<T>{v[0][m].x, v[0][m].y, v[1][m].x, v[1][m].y};
+        } else {
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) a[e] = v[e][m];
+        }
+    }
+}
+
+template <typename C>
+PM_HD void store(const ColStoreTiledCrop<typename C::T>& p, int tile, ThreadPos pos,
+                 const cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    constexpr int TC = C::CI * C::E;
+    if (tile >= p.ntiles) return;
+    const int TL = TC << p.log_k;
+    const int tl = tile >> p.log_k, sub = tile & ((1 << p.log_k) - 1);
+    cx<T>* base = p.dst + int64_t(tl) * p.nrows * TL + sub * TC + pos.cl * C::E;
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const int row = pos.t + m * C::TPS;
+        if (row >= p.nrows) continue;
+        cx<T>* a = base + int64_t(row) * TL;
         if constexpr (C::E == 2 && sizeof(T) == 4) {
             *reinterpret_cast<Vec4<T>*>(a) = Vec4<T>{v[0][m].x, v[0][m].y, v[1][m].x, v[1][m].y};
         } else {

@@ -130,10 +130,10 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
 #ifndef PM_COLMUL_MINWG
 #define PM_COLMUL_MINWG 1
 #endif
-template <typename C>
+template <typename C, typename S = ColStoreTiled<typename C::T>>
 __global__ void __launch_bounds__(C::NT, (C::NT == 512 ? PM_COLMUL_MINWG : 1))   // 2nd argument: min waves per SIMD
     fft_col_mul_kernel(const ColLoadTiled<typename C::T> lp0, const MidMul<typename C::T> mp0,
-                                                            const ColStoreTiled<typename C::T> sp0,
+                                                            const S sp0,
                                                             const cx<typename C::T>* __restrict__ tw, const int log_g) {
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
@@ -160,11 +160,11 @@ __global__ void __launch_bounds__(C::NT, (C::NT == 512 ? PM_COLMUL_MINWG : 1))  
     store<C>(sp, unit, pos, v);
 }
 
-template <typename T, int LOGN>
-int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const ColStoreTiled<T>& sp, const cx<T>* tw, int ntiles,
+template <typename T, int LOGN, typename S>
+int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& sp, const cx<T>* tw, int ntiles,
                        int log_g, hipStream_t st, int nbatch) {
     using C = typename ColCfgSel<T, LOGN, 0>::type;
-    auto kern = fft_col_mul_kernel<C>;
+    auto kern = fft_col_mul_kernel<C, S>;
     if (C::LDS_BYTES > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            int(C::LDS_BYTES));
@@ -176,13 +176,13 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const Col
     return int(hipGetLastError());
 }
 
-template <typename T>
-int launch_col_mul_impl(int logm, const ColLoadTiled<T>& lp, const MidMul<T>& mp, const ColStoreTiled<T>& sp, const cx<T>* tw,
+template <typename T, typename S>
+int launch_col_mul_impl(int logm, const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& sp, const cx<T>* tw,
                         int ntiles, int log_g, hipStream_t st, int nbatch) {
     switch (logm) {
 #define PM_CASE(k) \
     case k:        \
-        return launch_col_mul_one<T, k>(lp, mp, sp, tw, ntiles, log_g, st, nbatch);
+        return launch_col_mul_one<T, k, S>(lp, mp, sp, tw, ntiles, log_g, st, nbatch);
         PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
         PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASE(11) PM_CASE(12) PM_CASE(13)
 #undef PM_CASE
@@ -374,6 +374,7 @@ template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&
 template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_col_mul_crop(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiledCrop<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
 template <typename T> int launch_row_from_tiled(int logn, int var, const RowLoadTiled<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t, int nbatch = 1);
 template <typename T> int launch_row_fold(int logn, const RowLoadNat<T>&, const RowStoreFold<T>&, const cx<T>* tw, int npairs, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_row_unfold(int logn, const RowLoadFold<T>&, const RowStoreNat<T>&, const cx<T>* tw, int npairs, hipStream_t, int nbatch = 1);

@@ -692,7 +692,7 @@ static void test_blue2d_fused(int n1, int n2, int in_rows, int in_cols, int offy
     blue_make_tables<T>(n1, M, t1);
     blue_make_tables<T>(n2, N, t2);
     const int ntl = (N + TL - 1) / TL, ntiles = (N + TC - 1) / TC;
-    std::vector<cx<T>> W1(size_t(ntl) * n1 * TL, cx<T>{T(1e30), T(1e30)}), W2(size_t(ntl) * M * TL, cx<T>{T(1e30), T(1e30)});
+    std::vector<cx<T>> W1(size_t(ntl) * n1 * TL, cx<T>{T(1e30), T(1e30)}), W2(size_t(ntl) * n1 * TL, cx<T>{T(1e30), T(1e30)});
     auto twN = make_tw<T>(N);
     auto twM = make_tw<T>(M);
     Blue2dIn<T> view{real_in ? (const void*)xr.data() : (const void*)x.data(), in_cols, AxisMap{n1, in_rows, offy, shy},
@@ -702,7 +702,7 @@ static void test_blue2d_fused(int n1, int n2, int in_rows, int in_cols, int offy
     emu_kernel<RC, false>((n1 + RC::BO * RE - 1) / (RC::BO * RE), lp, sp, twN.data());
     ColLoadTiled<T> cl{W1.data(), n1, AxisMap{M, n1, 0, 0}, ntiles, log_k};
     MidMul<T> mm{MUL_SEPARABLE, 0, t1.data() + n1, t2.data() + n2, 0, N};
-    ColStoreTiled<T> cst{W2.data(), M, ntiles, log_k};
+    ColStoreTiledCrop<T> cst{W2.data(), n1, ntiles, log_k};
     {
         std::vector<Regs<CC>> regs(CC::NT);
         std::vector<typename LdsType<CC>::type> lds(CC::LDS_ELEMS + 1);
@@ -738,7 +738,7 @@ static void test_blue2d_fused(int n1, int n2, int in_rows, int in_cols, int offy
     cs.scale = T(0.25);
     cs.weight = T(1);
     cs.mul_kind = MUL_NONE;
-    RowLoadTiled<T> rl{W2.data(), M, ltl, 0, n1, 1};
+    RowLoadTiled<T> rl{W2.data(), n1, ltl, 0, n1, 1};
     RowStoreChirp<T> rs{cs, t1.data(), t2.data(), n1, n2, 1};
     emu_kernel<RC, false>((n1 + RC::BO * RE - 1) / (RC::BO * RE), rl, rs, twN.data());
     // truth: separable naive DFT of the logical n1 x n2 array (conj-in / conj-out for the inverse), scale 0.25
