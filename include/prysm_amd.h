@@ -289,9 +289,13 @@ int pm_plan_prepare(int32_t dtype, int64_t n);   /* build + cache the tables of 
                                                   * transform of a length otherwise does it, with a blocking upload that a hipGraph capture
                                                   * cannot record */
 void pm_shutdown(void);            /* free cached tables */
-/* performance knobs (never change results): "col_var", "row_var" in {0,1} pick kernel tilings,
- * "nt_in" / "nt_out" in {0,1} make the input loads / output stores non-temporal.  Also read once from
- * the environment: PM_TUNE="col_var=1,nt_in=1". */
+/* performance knobs (they choose among equivalent routes and tilings; results agree to rounding): "col_var", "row_var" pick kernel
+ * tilings, "nt_in" / "nt_out" in {0,1} make the input loads / output stores non-temporal, "fold", "log_k", "batch_ws_mib",
+ * "gemm_3m", "gemm_min_wgs" tune the engine and the GEMM; routing of awkward lengths: "blue_min" (shortest length on the Bluestein
+ * path, 0 = off), "blue_2d" / "blue_fuse" (both-axes form; chirp multiplies inside the chain), "big_native_log" (log2 of the longest
+ * length given to the engine as it is; the GPU tests lower it to run the 16384-point path on small arrays).  The full list with
+ * defaults and measurements: struct Tuning in prysm_amd/csrc/pm_internal.h.  Also read once from the environment:
+ * PM_TUNE="col_var=1,nt_in=1". */
 int pm_set_tuning(const char* key, int32_t value);
 /* time `reps` launches of each pass of the transform with hipEvents on `stream`; ms[0] = row pass,
  * ms[1] = column pass (average per launch).  Used by bench.py for the roofline object. */
