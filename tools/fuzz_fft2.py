@@ -168,6 +168,12 @@ def main():
         epi = int(rng.choice([0, 0, 1]))
         fold = int(rng.choice([-1, 0, 1]))
         lib.pm_set_tuning(b'fold', fold)
+        # routes of awkward lengths: with the native length lowered to 32 and the Bluestein path opened from 20 points, 64 / 128
+        # take the radix-2 / radix-4 step of the 16384 / 32768-point path and 20 .. 64 the long both-axes Bluestein form
+        route = str(rng.choice(['default', 'default', 'small_native', 'unfused']))
+        lib.pm_set_tuning(b'big_native_log', 5 if route == 'small_native' else 13)
+        lib.pm_set_tuning(b'blue_min', 20 if route == 'small_native' else 96)
+        lib.pm_set_tuning(b'blue_fuse', 0 if route == 'unfused' else 1)
         scale = float(rng.choice([1.0, 1.0 / np.sqrt(M * N)]))
         shp = (B, m, n) if B else (m, n)
         amp = None
@@ -212,8 +218,9 @@ def main():
         worst = max(worst, err / tol)
         if not ok:
             nfail += 1
-            print('case', case, 'FAIL err', err, (M, N, m, n, in_off, in_shift, (om, on), out_off, out_shift, direction, cdt.__name__, kind, B, epi, fold))
-    lib.pm_set_tuning(b'fold', -1)
+            print('case', case, 'FAIL err', err, (M, N, m, n, in_off, in_shift, (om, on), out_off, out_shift, direction, cdt.__name__, kind, B, epi, fold, route))
+    for key, val in ((b'fold', -1), (b'big_native_log', 13), (b'blue_min', 96), (b'blue_fuse', 1)):
+        lib.pm_set_tuning(key, val)
     print(f'fuzz_fft2: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
     nfail += fuzz_fused(max(20, ncases // 2), rng, lib)
     nfail += fuzz_gemm(max(20, ncases // 2), rng, lib)
