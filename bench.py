@@ -2,29 +2,41 @@
 """Headline benchmark: pupil -> focus FFT propagations per second at 4096^2 complex64.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is ONE propagation ``focus(x, Q=1)`` = fftshift(fft2(ifftshift(x), norm='ortho')) of a
-synthetic 4096 x 4096 complex64 field already resident in HBM (BASELINE.json metric; config
-"4096^2 pupil->focus").  Each rank (one process per GPU) propagates its own field: the path
-shards over wavelengths / fields with no data-path collective (weak scaling), so the timed region
-is exactly K propagations per rank.  The one real exchange of the polychromatic recipe -- |E|^2 and a
-sum all-reduce of the 67 MB fp32 image over RCCL -- happens once per polychromatic PSF, not per
-propagation; it is run and timed AFTER the timed region (``reduce_ms``, median of 3) and folded into
-``polychromatic.psf_64wvl_ms``, the time of BASELINE config 5 (64 wavelengths over the N ranks, each = pupil
-synthesis + focus with the fused |.|^2 accumulate, measured on rank 0, + one reduce).
+N > 1 runs N ranks, one process per GPU, over RCCL (torch.distributed backend "nccl").  Either the caller launches
+them (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+--gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are then in the environment), or -- when WORLD_SIZE is not set --
+bench.py re-executes itself under torch.distributed.run with exactly that command line.  N = 1 is the same code path
+without a process group.
 
-Rank 0 prints ONE JSON line.  ``roofline``: the dominant kernel (the slower of the two FFT passes),
-its duration measured with HIP events recorded between the kernels on the launch stream, in
-sequence; achieved = 2 N^2 s algorithmic bytes (read + write of one pass) / duration, peak 8 TB/s.
-``cpu_baseline``: the CPU oracle (a numpy/scipy restatement of prysm's focus, scipy.fft
-single-threaded exactly as prysm ships it) timed on this box's host cores on the same workload.
+A "step" is ONE propagation ``focus(x, Q=1)`` = fftshift(fft2(ifftshift(x), norm='ortho')) of a synthetic
+4096 x 4096 complex64 field already resident in HBM (BASELINE.json metric; config "4096^2 pupil->focus").  The path
+shards over wavelengths / fields with no data-path collective (weak scaling): every rank propagates its own field, the
+timed region is exactly K propagations per rank between barrier + synchronize pairs, MAX over ranks.
+
+After the timed region, outside of it and on every rank:
+* ``n2048``: the same measurement at 2048^2 (the second size the north star names);
+* ``polychromatic``: BASELINE config 5 as ONE timed call of prysm_amd.polychromatic.polychromatic_psf -- 64
+  wavelengths x 4096^2 fp32 sharded over the N ranks, |.|^2 accumulated per rank, one sum-reduce of the image to rank 0
+  over RCCL -- variant F (FFT focus, Q = 1) and variant M (matrix-DFT focus 4096^2 -> 512^2 on MFMA), plus the
+  reduce of the 67 MB fp32 image on its own (``reduce_ms``).
+
+Rank 0 prints ONE JSON line.  ``roofline``: the dominant kernel (the slower of the two FFT passes), its duration
+measured with HIP events recorded between the kernels on the launch stream, in sequence; achieved = 2 N^2 s
+algorithmic bytes (read + write of one pass) / duration, peak 8 TB/s; ``traffic`` = PMC bytes per launch from the
+committed rocprofv3 summary, printed only while the kernel sources still hash to the fingerprint the summary was
+collected at.  ``cpu_baseline``: the CPU oracle (numpy / scipy restatement of prysm's focus, scipy.fft single-threaded
+exactly as prysm ships it) timed on this box's host cores on the same workload (N = 1 only).
 """
 import argparse
 import ctypes
+import glob
+import hashlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,6 +50,8 @@ sys.path.insert(0, ROOT)
 N_EDGE = 4096
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
 HBM_COPY_CEILING_GBS = 6290.0   # measured float4-copy ceiling quoted by the same guide (report both fractions)
+F32_MFMA_PEAK_TF = 157.3
+N_WAVELENGTHS = 64      # BASELINE config 5
 
 
 def parse():
@@ -48,11 +62,29 @@ def parse():
     ap.add_argument('--n', type=int, default=N_EDGE, help='transform edge (default 4096, the headline)')
     ap.add_argument('--dtype', default='c64', choices=['c64', 'c128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-poly', action='store_true', help='skip the polychromatic per-wavelength measurement (profiling runs)')
+    ap.add_argument('--no-poly', action='store_true', help='only the headline loop (profiling runs)')
+    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget for the CPU baseline sample')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
-                    help='torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on one GPU)')
+                    help='torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path when the ranks share a GPU)')
     return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    have = torch.cuda.device_count()
+    if args.backend == 'nccl' and have < args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: only {have} GPU(s) visible; RCCL needs one device per rank '
+                         '(--backend gloo lets ranks share a device, for testing the N > 1 path only)')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def make_field(n, cdtype, seed):
@@ -84,56 +116,42 @@ def kernel_pass_times(x, n, reps=20):
     return float(ms[0]), float(ms[1])
 
 
+def source_fingerprint():
+    """sha256 over the kernel sources and the public header: what a PMC summary is valid for."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'prysm_amd', 'csrc', '*.h')) + glob.glob(os.path.join(ROOT, 'prysm_amd', 'csrc', '*.hip')) +
+                   [os.path.join(ROOT, 'prysm_amd', 'csrc', 'Makefile'), os.path.join(ROOT, 'include', 'prysm_amd.h')])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel, n, dtype_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of THIS command
     (profiles/pmc_bench_summary.json: separate --pmc FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled per
-    the gfx950 correction in MI355X_MICROARCH.md).  Counters cannot be read from inside the process."""
+    the gfx950 correction in MI355X_MICROARCH.md).  Counters cannot be read from inside the process, so the summary
+    carries the fingerprint of the kernel sources it was collected at; when the sources have changed since, the number
+    no longer describes this build and traffic is null."""
     path = os.path.join(ROOT, 'profiles', 'pmc_bench_summary.json')
     if not os.path.exists(path):
-        return None, None
+        return None, 'no PMC summary committed'
     try:
         tab = json.load(open(path))
     except Exception:
-        return None, None
+        return None, 'PMC summary unreadable'
+    stamp = tab.get('_meta', {}).get('source_fingerprint')
+    now = source_fingerprint()
+    if stamp != now:
+        return None, f'stale: PMC summary collected at source fingerprint {stamp}, this build is {now}'
     want = f"fft_{kernel}"
     real = 'float' if dtype_name == 'c64' else 'double'
-    # the folded column pass runs kernels of n/2 points (two planes per launch), the row pass kernels of n points
-    for nn in (n, n // 2):
+    # the folded column pass runs kernels of n/2 (n/4) points, several planes per launch; the row pass kernels of n points
+    for nn in (n, n // 2, n // 4):
         for k, v in tab.items():
             if k.startswith(want) and k.endswith(f'_{real}_N{nn}'):
-                return v['hbm_traffic_bytes'], f'profiles/pmc_bench_summary.json:{k}'
-    return None, None
-
-
-def polychromatic_per_wavelength_ms(n, cdtype, reps=8):
-    """One wavelength of BASELINE config 5, variant F, as the driver runs it per GPU: pupil synthesis
-    (from_amp_and_phase of a circular amplitude and a W040 OPD map) + FFT focus with the fused |.|^2 accumulate."""
-    from prysm_amd import propagation as P
-    rdt = torch.float32 if cdtype == np.complex64 else torch.float64
-    ax = (torch.arange(n, device='cuda', dtype=torch.float64) - n // 2) * (10.0 / n)
-    r = torch.hypot(ax[None, :], ax[:, None])
-    amp = (r <= 5).to(rdt)
-    opd = (500.0 * (r / 5) ** 4).to(rdt)
-    acc = torch.zeros((n, n), dtype=rdt, device='cuda')
-
-    def one(wvl):
-        wf = P.Wavefront.from_amp_and_phase(amp, opd, wvl, 10.0 / n)
-        fus = wf._fusable(1)     # complex64: the pupil is synthesised inside the row pass, never written
-        if fus is not None:
-            P.focus_intensity(fus[1], 1, out=acc, weight=1.0, synth=(fus[0], fus[2]))
-        else:
-            P.focus_intensity(wf.data, 1, out=acc, weight=1.0)
-
-    for k in range(2):
-        one(0.5 + 0.01 * k)
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for k in range(reps):
-        one(0.5 + 0.2 * k / 63)
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+                return v['hbm_traffic_bytes'], f'profiles/pmc_bench_summary.json:{k} (source fingerprint {stamp})'
+    return None, 'kernel not in the PMC summary'
 
 
 def _event_ms(fn, reps, warm=3):
@@ -149,39 +167,65 @@ def _event_ms(fn, reps, warm=3):
     return e0.elapsed_time(e1) / reps
 
 
-def other_configs():
-    """BASELINE configs 2 - 4 measured in the same run (parity-tested cases, reported here for the roofline the north star
-    asks for; not the headline value): algorithmic bytes / flops per SURVEY 8(d) over HIP-event time on the launch stream."""
+def _hbm_entry(ms, nbytes, note=None):
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    e = {'ms': ms, 'algorithmic_GBps': gbs, 'frac_of_hbm_peak': gbs / HBM_PEAK_GBS,
+         'frac_of_measured_copy_ceiling': gbs / HBM_COPY_CEILING_GBS}
+    if note:
+        e['note'] = note
+    return e
+
+
+def other_configs(only=''):
+    """BASELINE configs 2 - 4 and the two honest-HBM focus cases (nothing fits the 256 MiB Infinity Cache) measured in
+    the same run: algorithmic bytes / flops per SURVEY 8(d) over HIP-event time on the launch stream.  Parity-tested
+    cases reported for the roofline the north star asks for; not the headline value."""
     from prysm_amd import propagation as P
+    from prysm_amd import fttools
     from prysm_amd.conf import config
     out = {}
-    # config 2: 2048^2 complex64 focus, 4 N^2 s bytes
-    x2 = torch.from_numpy(make_field(2048, np.complex64, 2048)).cuda()
-    ms = _event_ms(lambda: P.focus(x2, 1), 100)
-    out['config2_focus_2048_c64'] = {'ms': ms, 'algorithmic_GBps': 4 * 2048 ** 2 * 8 / (ms * 1e-3) / 1e9,
-                                     'frac_of_hbm_peak': 4 * 2048 ** 2 * 8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    del x2
-    # config 3: 4096^2 complex128 angular-spectrum step (fused 3 passes), graded on 8 N^2 s bytes
-    x3 = torch.from_numpy(make_field(4096, np.complex128, 4096)).cuda()
-    ms = _event_ms(lambda: P.angular_spectrum(x3, 0.6328, 0.01, 10.0, Q=1), 30)
-    b = 8 * 4096 ** 2 * 16
-    out['config3_angular_spectrum_4096_c128'] = {'ms': ms, 'algorithmic_GBps': b / (ms * 1e-3) / 1e9,
-                                                 'frac_of_hbm_peak': b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                 'note': 'graded on 8 N^2 s (two 2-D transforms); the fused chain moves 6 N^2 s'}
-    del x3
-    # config 4: matrix-DFT focus 2048^2 -> 512^2 complex64 on MFMA, 8 My Nx (Ny + Mx) real flops
-    prec = config.precision
-    try:
-        config.precision = 32
-        x4 = torch.from_numpy(make_field(2048, np.complex64, 2048)).cuda()
-        ex = P.prepare_executor(10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0)
-        ms = _event_ms(lambda: P.focus_dft(x4, ex), 50)
-    finally:
-        config.precision = prec
-    fl = 8 * 512 * 2048 * (2048 + 512)
-    out['config4_mdft_2048_to_512_c64'] = {'ms': ms, 'algorithmic_TFLOPs': fl / (ms * 1e-3) / 1e12,
-                                           'frac_of_f32_mfma_peak': fl / (ms * 1e-3) / 1e12 / 157.3, 'bound': 'mfma',
-                                           'note': 'two complex GEMMs on v_mfma_f32_32x32x2_f32; peak 157.3 TFLOP/s (MI355X_MICROARCH.md)'}
+
+    def want(key):
+        return not only or only == key
+
+    if want('config2'):   # config 2: 2048^2 complex64 focus, 4 N^2 s bytes
+        x2 = torch.from_numpy(make_field(2048, np.complex64, 2048)).cuda()
+        out['config2_focus_2048_c64'] = _hbm_entry(_event_ms(lambda: P.focus(x2, 1), 100), 4 * 2048 ** 2 * 8)
+        del x2
+    if want('config3'):   # config 3: 4096^2 complex128 angular-spectrum step (fused 3 passes), graded on 8 N^2 s bytes
+        x3 = torch.from_numpy(make_field(4096, np.complex128, 4096)).cuda()
+        out['config3_angular_spectrum_4096_c128'] = _hbm_entry(
+            _event_ms(lambda: P.angular_spectrum(x3, 0.6328, 0.01, 10.0, Q=1), 30), 8 * 4096 ** 2 * 16,
+            'graded on 8 N^2 s (two 2-D transforms); the fused chain moves 6 N^2 s')
+        del x3
+    if want('c128'):      # nothing of this one fits the Infinity Cache: 256 MiB in, 256 MiB intermediate, 256 MiB out
+        x5 = torch.from_numpy(make_field(4096, np.complex128, 4096)).cuda()
+        out['focus_4096_c128'] = _hbm_entry(_event_ms(lambda: P.focus(x5, 1), 30), 4 * 4096 ** 2 * 16)
+        del x5
+    if want('n8192'):
+        x6 = torch.from_numpy(make_field(8192, np.complex64, 8192)).cuda()
+        out['focus_8192_c64'] = _hbm_entry(_event_ms(lambda: P.focus(x6, 1), 20), 4 * 8192 ** 2 * 8)
+        del x6
+    torch.cuda.empty_cache()
+    if want('config4'):   # config 4: matrix-DFT focus 2048^2 -> 512^2 complex64 on MFMA, 8 My Nx (Ny + Mx) real flops
+        prec = config.precision
+        try:
+            config.precision = 32
+            x4 = torch.from_numpy(make_field(2048, np.complex64, 2048)).cuda()
+            ex = P.prepare_executor(10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0)
+            ms = _event_ms(lambda: P.focus_dft(x4, ex), 50)
+            fl = 8 * 512 * 2048 * (2048 + 512)
+            out['config4_mdft_2048_to_512_c64'] = {
+                'ms': ms, 'algorithmic_TFLOPs': fl / (ms * 1e-3) / 1e12, 'frac_of_f32_mfma_peak': fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                'bound': 'mfma', 'note': 'two complex GEMMs on v_mfma_f32_32x32x2_f32; peak 157.3 TFLOP/s (MI355X_MICROARCH.md)'}
+            if not only:
+                # the same focal grid by the chirp-Z executor (prysm/fttools.py:235-389), for comparison
+                exz = P.prepare_executor(10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0, kind='czt')
+                msz = _event_ms(lambda: P.focus_dft(x4, exz), 20)
+                out['czt_2048_to_512_c64'] = {'ms': msz, 'note': 'kind="czt" executor on the config-4 grid (batched 1-D FFTs + chirp multiplies)'}
+            del x4, ex
+        finally:
+            config.precision = prec
     return out
 
 
@@ -220,13 +264,109 @@ def cpu_baseline(n, cdtype, budget_s):
     return out
 
 
+class Ranks:
+    """The process group of this run (or none at N = 1): barrier, MAX over ranks."""
+
+    def __init__(self, world):
+        self.world = world
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def max(self, v):
+        if self.world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn):
+        """Wall time of fn() bracketed by barrier + synchronize on both sides, MAX over ranks (seconds)."""
+        torch.cuda.synchronize()
+        self.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        self.barrier()
+        torch.cuda.synchronize()
+        return self.max(time.perf_counter() - t0)
+
+
+def propagation_loop(ranks, x, steps, warmup):
+    """warmup untimed + exactly `steps` timed focus(x, 1) per rank; returns seconds (MAX over ranks)."""
+    from prysm_amd import propagation as P
+    f = None
+    for _ in range(warmup):
+        f = P.focus(x, 1)
+
+    def run():
+        nonlocal f
+        for _ in range(steps):
+            f = None       # release the previous focal field first: the caching allocator then hands the same block
+            f = P.focus(x, 1)   # back, so the steady state touches in + workspace + out (not two alternating outputs)
+
+    return ranks.timed(run), f
+
+
+def polychromatic_config5(ranks, n, reps=3):
+    """BASELINE config 5: 64 wavelengths np.linspace(0.5, 0.7, 64) um, uniform weights, n^2 circular pupil with a
+    500 nm W040 OPD, fp32.  ONE polychromatic_psf call = this rank's ceil(64 / N) wavelengths (pupil synthesis inside the
+    row pass, FFT focus, |.|^2 accumulated by the column pass's epilogue) + one sum-reduce of the image to rank 0."""
+    from prysm_amd.polychromatic import polychromatic_psf
+    ax = (torch.arange(n, device='cuda', dtype=torch.float64) - n // 2) * (10.0 / n)
+    r = torch.hypot(ax[None, :], ax[:, None])
+    amp = (r <= 5).to(torch.float32)
+    opd = (500.0 * (r / 5) ** 4).to(torch.float32)
+    del r
+    wvls = np.linspace(0.5, 0.7, N_WAVELENGTHS)
+    wts = np.ones(N_WAVELENGTHS)
+    dx = 10.0 / n
+    res = {'wavelengths': N_WAVELENGTHS, 'wavelengths_per_gpu': math.ceil(N_WAVELENGTHS / ranks.world), 'pupil': f'{n}x{n} fp32',
+           'reduce': 'torch.distributed.reduce(SUM) of the real image to rank 0 (RCCL over xGMI)' if ranks.world > 1 else 'none (one rank)'}
+
+    def var_f():
+        polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=1, reduce_to_all=False)
+
+    def var_m():
+        polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, focal_dx=0.55 * 10 / 4, samples=512, kind='mdft', reduce_to_all=False)
+
+    for name, fn, k in (('variant_F_fft_focus', var_f, reps), ('variant_M_mdft_512', var_m, max(1, reps - 1))):
+        fn()    # warm: plans, communicator, allocator
+        ts = sorted(ranks.timed(fn) for _ in range(k))
+        t = ts[len(ts) // 2]
+        res[name] = {'psf_ms': t * 1e3, 'psfs_per_s': 1.0 / t, 'wavelengths_per_s': N_WAVELENGTHS / t,
+                     'per_wavelength_ms_per_gpu': t * 1e3 / math.ceil(N_WAVELENGTHS / ranks.world)}
+    fl = 8 * 512 * n * (n + 512) * N_WAVELENGTHS
+    res['variant_M_mdft_512']['algorithmic_TFLOPs_whole_job'] = fl / (res['variant_M_mdft_512']['psf_ms'] * 1e-3) / 1e12
+    res['note'] = ('timed polychromatic_psf calls (barrier + synchronize on both sides, MAX over ranks, median): F = per wavelength '
+                   'pupil synthesis + FFT focus (Q = 1) with fused |.|^2 accumulate; M = prepare_executor + matrix-DFT focus to a '
+                   '512^2 grid (focal_dx 1.375 um) + |.|^2 accumulate; both end with the sum-reduce of the image to rank 0')
+    return res
+
+
+def reduce_alone_ms(ranks, n):
+    """The one data-path collective on its own: sum-reduce of an n^2 fp32 image to rank 0 (median of 5)."""
+    if ranks.world == 1:
+        return 0.0
+    img = torch.ones((n, n), dtype=torch.float32, device='cuda')
+    dist.reduce(img, dst=0)   # warm
+    ts = sorted(ranks.timed(lambda: dist.reduce(img, dst=0)) for _ in range(5))
+    return ts[2] * 1e3
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path)')
+    if args.backend == 'nccl' and world > torch.cuda.device_count():
+        raise SystemExit(f'bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s): RCCL needs one device per rank')
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     if world > 1:
@@ -234,71 +374,42 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))   # RCCL on ROCm
         else:
             dist.init_process_group('gloo')
+    ranks = Ranks(world)
     from prysm_amd import propagation as P
-    from prysm_amd import _ops
 
     n = args.n
     cdtype = np.complex64 if args.dtype == 'c64' else np.complex128
     es = np.dtype(cdtype).itemsize
+    if args.only:   # profiling runs: one other_configs entry, nothing else
+        if rank == 0:
+            print(json.dumps(other_configs(args.only)), flush=True)
+        return
     x = torch.from_numpy(make_field(n, cdtype, 4096 + rank)).cuda()
-    acc = None
+    if world > 1:
+        dist.all_reduce(torch.zeros(1, device='cuda'))     # create the communicator outside every timed region
+    elapsed, f = propagation_loop(ranks, x, args.steps, args.warmup)
+    del f
 
-    def step():
-        return P.focus(x, 1)
+    extra = {}
+    if not args.no_poly:
+        x2 = torch.from_numpy(make_field(2048, np.complex64, 2048 + rank)).cuda()
+        k2 = max(args.steps, 50)
+        t2, _ = propagation_loop(ranks, x2, k2, max(args.warmup, 5))
+        del x2, _
+        extra['n2048'] = {'value': world * k2 / t2, 'unit': 'propagations/s', 'ms_per_step': t2 / k2 * 1e3, 'steps': k2,
+                          'whole_step_frac_of_hbm_peak': 4 * 2048 ** 2 * 8 / (t2 / k2) / 1e9 / HBM_PEAK_GBS,
+                          'workload': 'focus(x, Q=1) on a 2048x2048 complex64 field per GPU, timed like the headline'}
+        extra['reduce_ms'] = reduce_alone_ms(ranks, n)
+        extra['polychromatic'] = polychromatic_config5(ranks, n)
+        extra['polychromatic']['reduce_alone_ms'] = extra['reduce_ms']
 
-    for _ in range(args.warmup):
-        f = step()
-    if world > 1:
-        acc = _ops.abs2(f)
-        dist.all_reduce(acc)     # warm the communicator
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        f = None       # release the previous focal field first: the caching allocator then hands the same block
-        f = step()     # back, so the steady state touches in + workspace + out (not two alternating outputs)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    reduce_ms = 0.0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # the incoherent sum over wavelengths / fields: |E|^2 + one RCCL all-reduce over xGMI, outside the timed region
-        samples = []
-        for _ in range(3):
-            dist.barrier()
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            acc = _ops.abs2(f, out=acc)
-            dist.all_reduce(acc)
-            ev1.record()
-            torch.cuda.synchronize()
-            samples.append(ev0.elapsed_time(ev1))
-        r = torch.tensor([sorted(samples)[1]], dtype=torch.float64, device='cuda')
-        dist.all_reduce(r, op=dist.ReduceOp.MAX)
-        reduce_ms = float(r.item())
-
-    poly_ms = polychromatic_per_wavelength_ms(n, cdtype) if (rank == 0 and not args.no_poly) else 0.0
-    psf_ms = 0.0
-    if rank == 0 and not args.no_poly:
-        # the intensity form of the same step: |focus(x)|^2 with the modulus fused into the column pass (no complex PSF in memory)
-        acc_i = P.focus_intensity(x, 1)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            P.focus_intensity(x, 1, out=acc_i)
-        e1.record()
-        torch.cuda.synchronize()
-        psf_ms = e0.elapsed_time(e1) / 50
     if rank == 0:
+        psf_ms = 0.0
+        if not args.no_poly:
+            # the intensity form of the same step: |focus(x)|^2 with the modulus fused into the column pass (no complex PSF in memory)
+            acc_i = P.focus_intensity(x, 1)
+            psf_ms = _event_ms(lambda: P.focus_intensity(x, 1, out=acc_i), 50)
+            del acc_i
         ms_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
         p1, p2 = kernel_pass_times(x, n)
@@ -315,24 +426,22 @@ def main():
             'config': {'workload': f'focus(x, Q=1) on a {n}x{n} {np.dtype(cdtype).name} field resident in HBM '
                                    '(fftshift(fft2(ifftshift(x), norm=ortho)), complex field out)',
                        'fields_per_gpu_per_step': 1, 'parallelism': f'one field/wavelength per GPU x{world}',
-                       'reduce': 'none in the timed region (independent fields); the polychromatic sum-reduce is timed separately'},
+                       'backend': ('RCCL (torch.distributed nccl)' if args.backend == 'nccl' else 'gloo') if world > 1 else 'none',
+                       'reduce': 'none in the timed region (independent fields); the polychromatic sum-reduce is timed in `polychromatic`'},
             'whole_step_algorithmic_GBps_per_gpu': alg_bytes_step / (ms_step * 1e-3) / 1e9,
             'whole_step_frac_of_hbm_peak': alg_bytes_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'whole_step_frac_of_measured_copy_ceiling': alg_bytes_step / (ms_step * 1e-3) / 1e9 / HBM_COPY_CEILING_GBS,
             'psf_variant': {'ms_per_psf': psf_ms, 'psfs_per_s_per_gpu': (1e3 / psf_ms) if psf_ms else None,
                             'note': 'focus_intensity(x, 1): the same propagation storing |.|^2 (fp32 image) instead of the complex field'},
-            'reduce_ms': reduce_ms,
-            'polychromatic': {'per_wavelength_ms': poly_ms, 'wavelengths_per_gpu': math.ceil(64 / world),
-                              'psf_64wvl_ms': math.ceil(64 / world) * poly_ms + reduce_ms,
-                              'note': 'BASELINE config 5 variant F: per wavelength = pupil synthesis + FFT focus with fused '
-                                      '|.|^2 accumulate (measured on rank 0 after the timed region), plus one sum-reduce'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'frac_of_measured_copy_ceiling': achieved / HBM_COPY_CEILING_GBS,
                          'traffic': traffic, 'traffic_unit': 'bytes per launch',
                          'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes_kernel,
                          'row_pass_ms': p1, 'column_pass_ms': p2,
-                         'note': '2*N^2*s algorithmic bytes per pass / HIP-event duration of that pass, in sequence'},
+                         'note': '2*N^2*s algorithmic bytes per pass / HIP-event duration of that pass; the two passes are timed in '
+                                 'sequence with events between them, which serialises them (their sum exceeds ms_per_step)'},
         }
+        line.update(extra)
         if not args.no_poly and world == 1:
             try:
                 line['other_configs'] = other_configs()

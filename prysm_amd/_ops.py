@@ -67,6 +67,25 @@ def synth_supported(opd, amp, N):
     return amp is None or (amp.dtype in _AMP_CODE and amp.dim() == 2 and amp.shape == opd.shape and amp.stride(-1) == 1)
 
 
+# Filled descriptors and their workspace sizes, keyed by everything in them that is not a pointer or a per-call scalar: a
+# repeated propagation (the inner loop of every model) then costs one struct copy, four pointer stores and ONE library
+# call instead of ~40 ctypes field stores and a workspace query (tools/exp_host_overhead.py: 21 -> 9 us per call).
+_fft2_plans = {}
+
+
+def _check_out(out, x, oshape, odt):
+    """A caller-supplied output / accumulator must be exactly what the kernel writes (it only receives a pointer and a
+    leading dimension): anything else would be silent corruption or an out-of-bounds write."""
+    if not isinstance(out, torch.Tensor) or out.device != x.device:
+        raise ValueError('fft2: `out` must be a tensor on the device of the input')
+    if out.dtype != odt:
+        raise ValueError(f'fft2: `out` must be {odt} for this input and epilogue, got {out.dtype}')
+    if tuple(out.shape) != tuple(oshape):
+        raise ValueError(f'fft2: `out` must have shape {tuple(oshape)}, got {tuple(out.shape)}')
+    if out.stride(-1) != 1:
+        raise ValueError('fft2: the last axis of `out` must be contiguous')
+
+
 def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
          out_shape=None, out_off=(0, 0), out_shift=(0, 0), epilogue=L.PM_EPI_NONE,
          mul=None, mul_x=None, mul_conj=False, out=None, weight=1.0, flags=0, synth=None):
@@ -80,38 +99,70 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
                  (B, M, N) / ((B, M), (B, N)) give one multiplier per field
     synth      : (amp | None, k): x is the real float32 OPD map and the transformed field is amp * exp(i k x),
                  synthesised while the row pass loads it (see synth_supported)
+    out        : optional result / accumulator (PM_EPI_ABS2_ACCUM); must match the dtype and shape the call produces
     """
     lib = L.load()
-    d = L.pm_fft2_desc()
-    d.flags = flags
-    x, (M, N), (om, on) = _fill_views(d, x, shape, in_off, in_shift, out_shape, out_off, out_shift)
-    d.direction = direction
-    d.epilogue = epilogue
-    d.scale = float(scale)
-    d.weight = float(weight)
-    keep = [x]
-    if synth is not None:
-        amp, k = synth
-        d.flags = (d.flags & ~L.PM_FLAG_REAL_INPUT) | L.PM_FLAG_SYNTH_INPUT
-        d.synth_k = float(k)
-        if amp is not None:
-            d.synth_amp = amp.data_ptr()
-            d.synth_amp_dtype = _AMP_CODE[amp.dtype]
-            d.synth_amp_ld = amp.stride(0) if amp.shape[0] > 1 else amp.shape[1]
-            keep.append(amp)
-    _fill_mul(d, x, mul, mul_x, mul_conj, keep)
+    if x.dim() not in (2, 3):
+        raise ValueError('2-D transforms take a 2-D array or a (batch, rows, cols) stack of them')
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    m, n = x.shape[-2:]
+    M, N = (m, n) if shape is None else shape
+    om, on = (M, N) if out_shape is None else out_shape
+    cdt = L.cdtype_of(x)
+    odt = cdt if epilogue == L.PM_EPI_NONE else L._REAL_OF[cdt]
+    oshape = (om, on) if x.dim() == 2 else (x.shape[0], om, on)
     if out is None:
-        odt = L.cdtype_of(x) if epilogue == L.PM_EPI_NONE else L._REAL_OF[L.cdtype_of(x)]
-        oshape = (om, on) if x.dim() == 2 else (x.shape[0], om, on)
         out = torch.empty(oshape, dtype=odt, device=x.device)
-    d.out_ld = out.stride(-2) if om > 1 else on
-    if x.dim() == 3:
-        d.out_bstride = out.stride(0) if out.shape[0] > 1 else om * d.out_ld
-    nbytes = lib.pm_fft2_workspace(ctypes.byref(d))
-    if nbytes == 0:
-        L.check(lib.pm_fft2(ctypes.byref(d), L.ptr(x), L.ptr(out), None, 0, L.stream_ptr()))  # raises with the reason
-    ws = L.workspace(nbytes)
-    L.check(lib.pm_fft2(ctypes.byref(d), L.ptr(x), L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()))
+    else:
+        _check_out(out, x, oshape, odt)
+    amp = synth[0] if synth is not None else None
+    if mul is not None and mul_x is not None and x.dim() == 3 and mul.dim() == 2:
+        mul, mul_x = mul.contiguous(), mul_x.contiguous()      # per-field (hy, hx) vectors: rows of two (B, .) arrays
+    key = (x.dtype, tuple(x.shape), x.stride(), M, N, tuple(in_off), tuple(in_shift), om, on, tuple(out_off), tuple(out_shift),
+           direction, epilogue, flags, float(scale), bool(mul_conj), out.stride(),
+           None if synth is None else (True, None if amp is None else (amp.dtype, amp.stride())),
+           None if mul is None else (tuple(mul.shape), mul.stride()), None if mul_x is None else (tuple(mul_x.shape), mul_x.stride()))
+    plan = _fft2_plans.get(key)
+    if plan is None:
+        d = L.pm_fft2_desc()
+        d.flags = flags
+        _fill_views(d, x, shape, in_off, in_shift, out_shape, out_off, out_shift)
+        d.direction = direction
+        d.epilogue = epilogue
+        d.scale = float(scale)
+        d.weight = 1.0
+        if synth is not None:
+            d.flags = (d.flags & ~L.PM_FLAG_REAL_INPUT) | L.PM_FLAG_SYNTH_INPUT
+            if amp is not None:
+                d.synth_amp_dtype = _AMP_CODE[amp.dtype]
+                d.synth_amp_ld = amp.stride(0) if amp.shape[0] > 1 else amp.shape[1]
+        keep = []
+        _fill_mul(d, x, mul, mul_x, mul_conj, keep)
+        d.out_ld = out.stride(-2) if om > 1 else on
+        if x.dim() == 3:
+            d.out_bstride = out.stride(0) if out.shape[0] > 1 else om * d.out_ld
+        if synth is not None:     # the workspace query validates the descriptor: give it the pointers of this call
+            d.synth_k = float(synth[1])
+            d.synth_amp = amp.data_ptr() if amp is not None else None
+        nbytes = lib.pm_fft2_workspace(ctypes.byref(d))
+        if nbytes == 0:
+            L.check(lib.pm_fft2(ctypes.byref(d), L.ptr(x), L.ptr(out), None, 0, L.stream_ptr()))  # raises with the reason
+        plan = (d, int(nbytes))
+        if len(_fft2_plans) > 512:
+            _fft2_plans.clear()
+        _fft2_plans[key] = plan
+    d = L.pm_fft2_desc.from_buffer_copy(plan[0])
+    d.weight = float(weight)
+    if synth is not None:
+        d.synth_k = float(synth[1])
+        d.synth_amp = amp.data_ptr() if amp is not None else None
+    if mul is not None:
+        d.mul = mul.data_ptr()
+        if mul_x is not None:
+            d.mul_x = mul_x.data_ptr()
+    ws = L.workspace(plan[1])
+    L.check(lib.pm_fft2(ctypes.byref(d), x.data_ptr(), out.data_ptr(), ws.data_ptr(), plan[1], L.stream_ptr()))
     return out
 
 

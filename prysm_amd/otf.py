@@ -22,8 +22,7 @@ def _center(shape):
 def _unwrap_psf(psf, dx):
     """Resolve a PSF container-or-array to a bare array and its sample spacing (otf.py:16-25)."""
     if isinstance(psf, RichData) or (hasattr(psf, 'data') and hasattr(psf, 'dx') and not isinstance(psf, torch.Tensor)):
-        if dx is None:
-            dx = psf.dx
+        dx = psf.dx        # a container's own sampling always wins, as in the reference (otf.py:17-19)
         psf = psf.data
     if dx is None:
         raise ValueError('dx is None: dx must be provided if psf is an array')

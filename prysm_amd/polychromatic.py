@@ -24,25 +24,52 @@ def shard_bounds(n_items, rank, world_size):
     return lo, hi
 
 
-def _reduce_image(acc, world, group, reduce_to_all):
-    """The one data-path collective: sum-reduce of the real image over the ranks (RCCL; gloo in the CPU tests)."""
-    if world > 1:
-        if reduce_to_all:
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+def _reduce_image(acc, world, group, reduce_to_all, method='reduce'):
+    """The one data-path collective: sum-reduce of the real image over the ranks (RCCL; gloo in the CPU tests).
+
+    reduce_to_all           : all_reduce, every rank gets the image.
+    root only, 'reduce'     : torch.distributed.reduce to the first rank of the group; the buffers of the other ranks are
+                              scratch afterwards (gloo and RCCL both leave partial sums in them).
+    root only, 'a2a'        : the fully connected xGMI form of SURVEY 8(e): every rank sends slice j of its image to rank j
+                              (one all-to-all, 7 distinct links per GPU), sums the `world` slices it received in rank order
+                              (pm_sum_modes: fixed order, bitwise reproducible) and the first rank gathers the reduced slices.
+                              Needs numel % world == 0; falls back to 'reduce' otherwise.
+    """
+    if world <= 1:
+        return acc
+    if reduce_to_all:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        return acc
+    root = dist.get_global_rank(group, 0) if group is not None else 0
+    if method == 'a2a' and acc.numel() % world == 0 and acc.is_contiguous():
+        from . import _ops
+        per = acc.numel() // world
+        send = acc.view(world, per)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=group)
+        if acc.is_cuda:
+            part = _ops.sum_modes(recv.view(world, 1, per), [1.0] * world).view(per)
         else:
-            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM, group=group)
+            part = recv.sum(0)
+        me = dist.get_rank()
+        parts = [torch.empty_like(part) for _ in range(world)] if me == root else None
+        dist.gather(part, parts, dst=root, group=group)
+        if me == root:
+            torch.cat(parts, out=acc.view(-1))
+        return acc
+    dist.reduce(acc, dst=root, op=dist.ReduceOp.SUM, group=group)
     return acc
 
 
-def incoherent_sum(propagate, wavelengths, weights, *, group=None, reduce_to_all=True, out=None):
+def incoherent_sum(propagate, wavelengths, weights, *, group=None, reduce_to_all=True, out=None, reduce_method='reduce'):
     """Weighted incoherent sum over wavelengths (or fields), sharded over the ranks of `group`.
 
     propagate(wavelength, weight, acc) -> acc
         computes ``acc += weight * |E(wavelength)|^2`` (acc is None for the first item of a rank and
         must then be created); the fused-epilogue form ``focus_intensity(x, Q, out=acc, weight=w)``
         does this without materialising the field.
-    Returns the summed image on every rank (reduce_to_all) or on rank 0 only (others get their
-    partial sum back).
+    Returns the summed image on every rank (reduce_to_all) or on the first rank of the group only (what the
+    other ranks get back is scratch).
     """
     if len(wavelengths) != len(weights):
         raise ValueError('wavelengths and weights must have the same length')
@@ -55,7 +82,7 @@ def incoherent_sum(propagate, wavelengths, weights, *, group=None, reduce_to_all
         acc = propagate(float(wavelengths[k]), float(weights[k]), acc)
     if acc is None:
         raise ValueError('a rank received no wavelengths and no `out` buffer to define the image shape')
-    return _reduce_image(acc, world, group, reduce_to_all)
+    return _reduce_image(acc, world, group, reduce_to_all, reduce_method)
 
 
 def _fields_per_launch(shape, cdtype_bytes, Q, limit_bytes=1 << 30):
@@ -67,7 +94,7 @@ def _fields_per_launch(shape, cdtype_bytes, Q, limit_bytes=1 << 30):
 
 
 def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, focal_dx=None, samples=None,
-                      kind='mdft', group=None, reduce_to_all=True, batched=None):
+                      kind='mdft', group=None, reduce_to_all=True, batched=None, reduce_method='reduce'):
     """Polychromatic PSF of a pupil (amplitude, OPD in nm) -- the how-to's recipe on N GPUs.
 
     Q given            : FFT focus per wavelength with the |.|^2 fused into the transform (multi-field throughput
@@ -77,6 +104,8 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
                          instead of launch-bound; batched=False is the field-by-field loop with the accumulate
                          epilogue, the faster form from 4096^2 transforms (single fields take the folded kernels).
                          Default (None): stacks below 4096^2 transforms.
+    reduce_method      : 'reduce' (one torch.distributed.reduce) or 'a2a' (all-to-all of slices + ordered local sum + gather:
+                         bitwise reproducible, one message per xGMI link) when only the first rank needs the image.
     focal_dx + samples : per-wavelength fixed-sampling focus (prepare_executor + focus_dft, `kind`),
                          all wavelengths on one focal grid -- the variant of the how-to.
     """
@@ -112,7 +141,7 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
                 else:
                     _ops.pupil_synth(a, o, kk, cd, out=stack[i])     # synthesised straight into the stack
             _ops.sum_modes(focus_intensity(stack, Q), [float(w) for w in weights[b0:b1]], out=acc, accumulate=True)
-        return _reduce_image(acc, world, group, reduce_to_all)
+        return _reduce_image(acc, world, group, reduce_to_all, reduce_method)
 
     def propagate(wvl, w, acc):
         wf = Wavefront.from_amp_and_phase(amp, phs, wvl, dx)
@@ -129,4 +158,4 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
             acc = torch.zeros(E.shape, dtype=L._REAL_OF[E.dtype], device=E.device)
         return _ops.abs2(E, out=acc, weight=w)
 
-    return incoherent_sum(propagate, wavelengths, weights, group=group, reduce_to_all=reduce_to_all)
+    return incoherent_sum(propagate, wavelengths, weights, group=group, reduce_to_all=reduce_to_all, reduce_method=reduce_method)

@@ -9,6 +9,7 @@ import torch
 
 from .. import _lib as L
 from .. import _ops
+from ..conf import config
 from ._kernels import _adjoint_multiply
 from .dft import focus_dft, focus_dft_adjoint, unfocus_dft, unfocus_dft_adjoint
 
@@ -22,6 +23,17 @@ def _mul(a, b):
             and a.is_contiguous() and b.is_contiguous()):
         return _ops.cmul(a, b)
     return a * b
+
+
+def _one_minus(fpm):
+    """1 - fpm of Babinet's principle.  Occulter masks are usually boolean (geometry.circle); numpy promotes `1 - bool_array`
+    to integers, torch refuses it, so masks that are neither floating nor complex take config.precision first."""
+    if isinstance(fpm, numbers.Number):
+        return 1 - fpm
+    t = L.as_device(fpm)
+    if not (t.is_floating_point() or t.is_complex()):
+        t = t.to(L.torch_dtype(config.precision))
+    return 1 - t
 
 
 def to_fpm_and_back(wavefunction, fpm, executor, return_more=False):
@@ -139,7 +151,7 @@ def to_fpm_and_back_multiresolution_adjoint(wavefunction, fpm, executor, return_
 def babinet(wavefunction, lyot, fpm, executor, return_more=False):
     """Propagate through a Lyot-style coronagraph using Babinet's principle (coronagraph.py:308-360)."""
     wavefunction = L.as_complex(wavefunction)
-    fpm = 1 - (fpm if isinstance(fpm, numbers.Number) else L.as_device(fpm))
+    fpm = _one_minus(fpm)
     result = to_fpm_and_back(wavefunction, fpm=fpm, executor=executor, return_more=return_more)
     if return_more:
         field, field_at_fpm, field_after_fpm = result
@@ -164,7 +176,7 @@ def babinet_adjoint(wavefunction, lyot, fpm, executor, field_at_fpm=None,
         raise ValueError('return_lyot_grad=True requires field_at_lyot from the forward propagation')
     lyot_t = None if lyot is None else L.as_device(lyot)
     lyot_is_complex = True if lyot_t is None else lyot_t.is_complex()
-    fpm = 1 - (fpm if isinstance(fpm, numbers.Number) else L.as_device(fpm))
+    fpm = _one_minus(fpm)
     dbar = L.as_complex(wavefunction)
     cbar = _adjoint_multiply(dbar, lyot_t) if lyot_t is not None else dbar
     if return_fpm_grad:

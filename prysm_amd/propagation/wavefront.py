@@ -408,11 +408,20 @@ class Wavefront:
                     Wavefront(after_fpm, self.wavelength, executor.focal_dx, 'psf'))
         return Wavefront(pak, self.wavelength, self.dx, self.space)
 
-    def to_fpm_and_back_adjoint(self, fpm, executor):
-        """Apply the adjoint of to_fpm_and_back (wavefront.py:791-850, gradient at the input pupil)."""
-        fpm = _field_data(fpm)
-        return Wavefront(to_fpm_and_back_adjoint(self.data, fpm=fpm, executor=executor), self.wavelength, self.dx,
-                         self.space)
+    def to_fpm_and_back_adjoint(self, fpm, executor, return_more=False, return_fpm_grad=False, field_at_fpm=None):
+        """Apply the adjoint of to_fpm_and_back (wavefront.py:789-842): self is the gradient at the next pupil.
+
+        Returns the gradient at the input pupil; with return_more also the two focal-plane intermediates, with
+        return_fpm_grad (needs field_at_fpm of the forward pass) also the mask gradient -- focal-plane quantities come
+        back as psf-space Wavefronts sampled at executor.focal_dx, like the reference.
+        """
+        pak = to_fpm_and_back_adjoint(self.data, fpm=_field_data(fpm), executor=executor, return_more=return_more,
+                                      return_fpm_grad=return_fpm_grad, field_at_fpm=_field_data(field_at_fpm))
+        if not (return_more or return_fpm_grad):
+            return Wavefront(pak, self.wavelength, self.dx, self.space)
+        first, *focal = pak
+        return (Wavefront(first, self.wavelength, self.dx, self.space),
+                *(Wavefront(f, self.wavelength, executor.focal_dx, 'psf') for f in focal))
 
     def to_fpm_and_back_multiresolution(self, fpm, executor, return_more=False):
         """Propagate to a focal plane mask and back at multiple resolutions (wavefront.py:852-885)."""
@@ -466,8 +475,23 @@ class Wavefront:
                     Wavefront(at_lyot, self.wavelength, self.dx, self.space))
         return Wavefront(pak, self.wavelength, self.dx, self.space)
 
-    def babinet_adjoint(self, lyot, fpm, executor):
-        """Apply the adjoint of babinet (wavefront.py:1002-1038, gradient at the input pupil)."""
-        fpm, lyot = _field_data(fpm), _field_data(lyot)
-        return Wavefront(babinet_adjoint(self.data, lyot=lyot, fpm=fpm, executor=executor), self.wavelength, self.dx,
-                         self.space)
+    def babinet_adjoint(self, lyot, fpm, executor, field_at_fpm=None, field_at_lyot=None, return_fpm_grad=False,
+                        return_lyot_grad=False):
+        """Apply the adjoint of babinet (wavefront.py:987-1048): self is the gradient after the Lyot stop.
+
+        Returns the gradient at the input pupil, followed -- in this order, when asked for -- by the focal-plane-mask
+        gradient (psf space, executor.focal_dx; needs field_at_fpm) and the Lyot-stop gradient (this wavefront's plane;
+        needs field_at_lyot).
+        """
+        pak = babinet_adjoint(self.data, lyot=_field_data(lyot), fpm=_field_data(fpm), executor=executor,
+                              field_at_fpm=_field_data(field_at_fpm), field_at_lyot=_field_data(field_at_lyot),
+                              return_fpm_grad=return_fpm_grad, return_lyot_grad=return_lyot_grad)
+        if not (return_fpm_grad or return_lyot_grad):
+            return Wavefront(pak, self.wavelength, self.dx, self.space)
+        grads = list(pak)
+        out = [Wavefront(grads.pop(0), self.wavelength, self.dx, self.space)]
+        if return_fpm_grad:
+            out.append(Wavefront(grads.pop(0), self.wavelength, executor.focal_dx, 'psf'))
+        if return_lyot_grad:
+            out.append(Wavefront(grads.pop(0), self.wavelength, self.dx, self.space))
+        return tuple(out)

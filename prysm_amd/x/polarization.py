@@ -25,8 +25,10 @@ def jones_adapter(prop_func):
         wavefunction = args[0]
         other_args = args[1:]
         ndim = wavefunction.ndim if hasattr(wavefunction, 'ndim') else L.as_device(wavefunction).dim()
-        if ndim == 2:
-            return prop_func(*args, **kwargs)      # pass through the non-Jones case
+        shape = tuple(wavefunction.shape) if hasattr(wavefunction, 'shape') else tuple(L.as_device(wavefunction).shape)
+        if not (ndim == 4 and shape[-2:] == (2, 2)):
+            # pass through the non-Jones cases: a 2-D field (the reference's test) and this package's (batch, rows, cols) stacks
+            return prop_func(*args, **kwargs)
         w = L.as_device(wavefunction)
         m, n = w.shape[0], w.shape[1]
         if getattr(prop_func, '__name__', '') in _STACKABLE:

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, reduce_to_all, q):
+def _worker(rank, world, port, reduce_to_all, q, method='reduce', sub=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -44,24 +44,33 @@ def _worker(rank, world, port, reduce_to_all, q):
         I = torch.from_numpy(O.intensity(O.focus(O.from_amp_and_phase(amp, opd, wvl), 2)) * w)
         return I if acc is None else acc.add_(I)
 
-    out = incoherent_sum(propagate, wvls, wts, reduce_to_all=reduce_to_all)
-    lo, hi = shard_bounds(7, rank, world)
+    group, grank, gworld = None, rank, world
+    if sub:    # a sub-group that does NOT contain global rank 0: the reduce root is the group's first rank (global rank 1)
+        group = dist.new_group([1, 2])
+        if rank == 0:
+            q.put((rank, None))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+        grank, gworld = rank - 1, 2
+    out = incoherent_sum(propagate, wvls, wts, reduce_to_all=reduce_to_all, reduce_method=method, group=group)
+    lo, hi = shard_bounds(7, grank, gworld)
     assert seen == [float(w) for w in wvls[lo:hi]]
     q.put((rank, out.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(reduce_to_all):
+def _run(reduce_to_all, method='reduce', world=2, sub=False):
     sys.path.insert(0, ROOT)
     from oracle import prysm_oracle as O
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, reduce_to_all, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, reduce_to_all, q, method, sub)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    res = dict(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -84,3 +93,16 @@ def test_incoherent_sum_all_reduce_world2():
 def test_incoherent_sum_reduce_to_root_world2():
     res, ref = _run(False)
     np.testing.assert_allclose(res[0], ref, rtol=1e-12, atol=1e-12 * ref.max())
+
+
+def test_incoherent_sum_all_to_all_reduce_world2():
+    """root-only result through the all-to-all of slices + ordered local sum + gather (the xGMI form of SURVEY 8e)"""
+    res, ref = _run(False, method='a2a')
+    np.testing.assert_allclose(res[0], ref, rtol=1e-12, atol=1e-12 * ref.max())
+
+
+def test_incoherent_sum_subgroup_without_global_rank0():
+    """dist.reduce's dst is a GLOBAL rank; a group [1, 2] must reduce to global rank 1"""
+    for method in ('reduce', 'a2a'):
+        res, ref = _run(False, method=method, world=3, sub=True)
+        np.testing.assert_allclose(res[1], ref, rtol=1e-12, atol=1e-12 * ref.max())
