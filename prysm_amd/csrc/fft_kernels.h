@@ -38,7 +38,8 @@ template <typename T, int LOGN, int VAR>
 struct ColCfgSel {
     static constexpr int N = 1 << LOGN, P = N >= 16 ? 16 : N, TPS = N / P;
     static constexpr int E = sizeof(T) == 4 ? 2 : 1;
-    static constexpr int CI = LOGN <= 12 ? 4 : 2;   // VAR = 1: stage twiddles from an LDS table (A/B knob; measured slower)
+    // VAR = 2: tiles of 128 B rows (16 complex64 / 8 complex128 columns) for 2048-point columns: whole cache lines per store
+    static constexpr int CI = (VAR == 2 && LOGN == 11) ? 8 : (LOGN <= 12 ? 4 : 2);   // VAR = 1: stage twiddles from an LDS table (A/B knob; measured slower)
     static constexpr int BO = (CI * TPS >= 256) ? 1 : 256 / (CI * TPS);
     static constexpr int COMP = (sizeof(T) == 8 && LOGN >= 11) ? 2 : 1;
     using type = FftCfg<T, LOGN, CI, E, BO, COMP>;
@@ -355,6 +356,7 @@ int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int
         if (var == 2 && !COL) return launch_one<T, COL, k, (COL ? 0 : 2), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         PM_TIMING_CASES(k) \
         if (var == 5 && COL) return launch_one<T, COL, k, (COL ? 5 : 0), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        if (var == 2 && COL && k == 11) return launch_one<T, COL, k, (COL ? 2 : 0), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         if (var == 4 && !COL) return launch_one<T, COL, k, (COL ? 0 : 4), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         if (var == 5 && !COL) return launch_one<T, COL, k, (COL ? 0 : 5), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
         return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st, nbatch);

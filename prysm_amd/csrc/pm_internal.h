@@ -76,8 +76,7 @@ template <typename T> int launch_row_fold(int logn, const RowLoadNat<T>&, const 
 template <typename T> int launch_row_unfold(int logn, const RowLoadFold<T>&, const RowStoreNat<T>&, const cx<T>* tw, int npairs, hipStream_t, int nbatch = 1);
 // tile width of the column pass; MUST match ColCfgSel in fft_kernels.h (CI * E)
 inline int col_tile_width_for(int dtype, int logm, int var) {
-    (void)var;
-    const int ci = logm <= 12 ? 4 : 2;
+    const int ci = (var == 2 && logm == 11) ? 8 : (logm <= 12 ? 4 : 2);
     return ci * (dtype == PM_C64 ? 2 : 1);
 }
 

@@ -1,13 +1,19 @@
-"""2 ranks on ONE GPU (gloo): the polychromatic driver's sharded paths (stacks and field-by-field, FFT and matrix-DFT
-variants) against the oracle's single-process sum.  Launch with torch.distributed.run --nproc-per-node 2."""
+"""2 ranks: the polychromatic driver's sharded paths (stacks and field-by-field, FFT and matrix-DFT variants; all-reduce,
+reduce to root and the all-to-all reduce) against the oracle's single-process sum.  PM_TEST_BACKEND=nccl: one GPU per rank over
+RCCL; gloo (default): both ranks on GPU 0.  Launch with torch.distributed.run --nproc-per-node 2."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
 from oracle import prysm_oracle as O
 
 rank = int(os.environ['RANK'])
-torch.cuda.set_device(0)
-dist.init_process_group('gloo')
+backend = os.environ.get('PM_TEST_BACKEND', 'gloo')
+dev = int(os.environ.get('LOCAL_RANK', '0')) if backend == 'nccl' else 0
+torch.cuda.set_device(dev)
+if backend == 'nccl':
+    dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
+else:
+    dist.init_process_group('gloo')
 from prysm_amd.polychromatic import polychromatic_psf
 from prysm_amd.mathops import array_to_true_numpy as tonp
 
@@ -25,6 +31,11 @@ worst = 0.0
 for batched in (True, False):
     got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2, batched=batched))
     worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))
+# root-only results: one reduce, and the all-to-all of slices + ordered local sum + gather
+for method in ('reduce', 'a2a'):
+    got = polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2, batched=False, reduce_to_all=False, reduce_method=method)
+    if rank == 0:
+        worst = max(worst, float(np.abs(tonp(got) - want).max() / np.abs(want).max()))
 comps = []
 for w in wvls:
     P = O.from_amp_and_phase(amp, opd, float(w))

@@ -1,0 +1,340 @@
+"""GPU parity tests added in round 2:
+
+* BASELINE config 5 at its stated size -- 64 wavelengths x 4096^2 fp32, variant F (FFT focus, both `batched` forms) and
+  variant M (matrix-DFT focus to 512^2) -- against the oracle's single-process sum;
+* the reference identities that were not yet restated on the device: array orientation / +y tilt
+  (tests/test_physics.py:56-74), thin lens == Hopkins defocus (tests/test_propagation.py:440-460), finite-difference checks of
+  the focal-plane-mask / Lyot gradients through the Wavefront API (tests/test_propagation.py:353-427, 589-622);
+* the N > 1 paths (bench.py and the polychromatic driver) as two ranks: RCCL when two GPUs are visible, gloo with both
+  ranks on one GPU otherwise;
+* caller-supplied `out=` validation, boolean occulters, the Jones adapter's pass-through of stacks.
+
+Tolerances as in test_gpu_parity.py.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, rel_max
+from oracle import prysm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-10
+TOL32 = 5e-6
+TOL32_MDFT = 3e-5
+
+
+@pytest.fixture(scope='module')
+def pa():
+    import prysm_amd
+    from prysm_amd import _lib
+    _lib.load()   # fails loudly when the HIP library is missing
+    assert torch.cuda.is_available()
+    return prysm_amd
+
+
+def tonp(x):
+    from prysm_amd.mathops import array_to_true_numpy
+    if hasattr(x, 'data') and not isinstance(x, (np.ndarray, torch.Tensor)):
+        x = x.data
+    return array_to_true_numpy(x)
+
+
+def _real_vdot(a, b):
+    return float(np.real(np.vdot(np.asarray(a), np.asarray(b))))
+
+
+# ----------------------------------------------------------------------------- BASELINE config 5 at size
+
+@pytest.fixture(scope='module')
+def config5():
+    """4096^2 circular amplitude, 500 nm of W040, 64 wavelengths in [0.5, 0.7] um, uniform weights; fp32
+    maps.  The oracle sums are computed once (scipy.fft on all host cores -- the checker, not the thing measured)."""
+    from scipy import fft as sfft
+    n = 4096
+    x, y = O.make_xy_grid(n, diameter=10)
+    r, _ = O.cart_to_polar(x, y)
+    amp = O.circle(5, r).astype(np.float32)
+    opd = O.hopkins_w040(r / 5, 500.0).astype(np.float32)
+    dx = float(x[0, 1] - x[0, 0])
+    del x, y, r
+    wvls = np.linspace(0.5, 0.7, 64)
+    wts = np.ones(64)
+    want_f = np.zeros((n, n))
+    want_m = np.zeros((512, 512))
+    opd64 = opd.astype(np.float64)
+    with sfft.set_workers(os.cpu_count() or 1):
+        for w in wvls:
+            P = O.from_amp_and_phase(amp.astype(np.float64), opd64, float(w))
+            want_f += O.intensity(O.focus(P, 1))
+            want_m += O.intensity(O.prepare_executor(dx, P.shape, 0.55 * 10 / 4, (512, 512), float(w), 100.0)(P))
+    return dict(amp=amp, opd=opd, dx=dx, wvls=wvls, wts=wts, want_f=want_f, want_m=want_m)
+
+
+@pytest.mark.parametrize('batched', [False, True])
+def test_config5_variant_f_full_size(pa, config5, batched):
+    """64 wavelengths x 4096^2 fp32, FFT focus Q = 1, |.|^2 and the weighted sum on the device: field by field with the
+    accumulate epilogue (pupil synthesised inside the row pass), and as stacks + sum_of_2d_modes."""
+    from prysm_amd.polychromatic import polychromatic_psf
+    c = config5
+    got = tonp(polychromatic_psf(c['amp'], c['opd'], c['wvls'], c['wts'], c['dx'], 100.0, Q=1, batched=batched))
+    assert got.dtype == np.float32 and got.shape == (4096, 4096)
+    assert rel_max(got, c['want_f']) < 2e-5     # 64 fp32 intensities accumulated in fp32 against the fp64 oracle sum
+    assert abs(got.sum(dtype=np.float64) / c['want_f'].sum() - 1) < 1e-5     # energy (unitary transform: 64 x sum amp^2)
+
+
+def test_config5_variant_m_full_size(pa, config5):
+    """the how-to's variant: per wavelength prepare_executor + matrix-DFT focus 4096^2 -> 512^2 (MFMA) + |.|^2 accumulate"""
+    from prysm_amd.conf import config
+    from prysm_amd.polychromatic import polychromatic_psf
+    c = config5
+    prec = config.precision
+    try:
+        config.precision = 32
+        got = tonp(polychromatic_psf(c['amp'], c['opd'], c['wvls'], c['wts'], c['dx'], 100.0, focal_dx=0.55 * 10 / 4,
+                                     samples=512, kind='mdft'))
+    finally:
+        config.precision = prec
+    assert got.dtype == np.float32 and got.shape == (512, 512)
+    assert rel_max(got, c['want_m']) < 1e-4     # K = 4096 complex64 contractions, squared and summed 64 times
+
+
+# ----------------------------------------------------------------------------- reference identities
+
+def test_array_orientation_consistency_tilt(pa):
+    """arr[y, x]: a positive +y tilt in the pupil moves the PSF to +y and leaves x centred (tests/test_physics.py:56-74)"""
+    P = pa.propagation
+    N, wvl, Q = 128, .5, 3
+    x, y = O.make_xy_grid(N, diameter=2.1)
+    r, _ = O.cart_to_polar(x, y)
+    amp = O.circle(1, r)
+    phs = 1000 * y
+    for dt in (np.float64, np.float32):
+        wf = P.Wavefront.from_amp_and_phase(amp.astype(dt), phs.astype(dt), wvl, x[0, 1] - x[0, 0])
+        psf = tonp(wf.focus(1, Q=Q).intensity)
+        idx_y, idx_x = np.unravel_index(psf.argmax(), psf.shape)
+        assert idx_x == (N * Q) // 2
+        assert idx_y > (N * Q) // 2
+        ref = O.intensity(O.focus(O.from_amp_and_phase(amp, phs, wvl), Q))
+        assert rel_max(psf, ref) < (TOL64 if dt == np.float64 else 2e-5)
+
+
+def test_thinlens_hopkins_agree(pa):
+    """a weak thin lens in front of the pupil == the matching Hopkins defocus (tests/test_propagation.py:440-460)"""
+    P = pa.propagation
+    x, y = O.make_xy_grid(128, diameter=11)
+    dx = x[0, 1] - x[0, 0]
+    r = np.hypot(x, y)
+    amp = O.circle(5, r)
+    phs = (r / 5) ** 2 * (1.975347661 * O.HeNe * 1000)     # hopkins(0, 2, 0, rho, 0, 1) = rho^2
+    psf = tonp(P.Wavefront.from_amp_and_phase(amp, phs, O.HeNe, dx).focus(efl=100, Q=2).intensity)
+    no_phs_wf = P.Wavefront.from_amp_and_phase(amp, None, O.HeNe, dx)
+    tl = P.Wavefront.thin_lens(10_000, O.HeNe, x, y)
+    psf2 = tonp((no_phs_wf * tl).focus(efl=100, Q=2).intensity)
+    assert np.allclose(psf, psf2, rtol=1e-5)
+    ref = O.intensity(O.focus(O.from_amp_and_phase(amp, phs, O.HeNe), 2))
+    assert rel_max(psf, ref) < TOL64
+
+
+def test_to_fpm_and_back_adjoint_returns_fpm_gradient(pa):
+    """Wavefront.to_fpm_and_back_adjoint(..., return_fpm_grad=True, field_at_fpm=...) against a central difference
+    (tests/test_propagation.py:353-381); ADVICE r1: the keywords were missing from the object API"""
+    P = pa.propagation
+    rng = np.random.default_rng(123)
+    z = rng.normal(size=(8, 8)) + 1j * rng.normal(size=(8, 8))
+    wf = P.Wavefront(cmplx_field=z, dx=1.0, wavelength=O.HeNe, space='pupil')
+    fpm_data = rng.normal(size=(8, 8))
+    fpm = P.Wavefront(cmplx_field=fpm_data, dx=0.1, wavelength=O.HeNe, space='psf')
+    mdft = wf.prepare_executor(efl=10.0, dx=fpm.dx, samples=fpm.data.shape)
+    out, at_fpm, _ = wf.to_fpm_and_back(fpm=fpm, executor=mdft, return_more=True)
+    outbar_data = rng.normal(size=(8, 8)) + 1j * rng.normal(size=(8, 8))
+    outbar = P.Wavefront(cmplx_field=outbar_data, dx=out.dx, wavelength=O.HeNe, space=out.space)
+    abar, fpm_bar = outbar.to_fpm_and_back_adjoint(fpm=fpm, executor=mdft, return_fpm_grad=True, field_at_fpm=at_fpm)
+    assert fpm_bar.space == 'psf' and fpm_bar.dx == mdft.focal_dx and abar.space == 'pupil'
+    more = outbar.to_fpm_and_back_adjoint(fpm=fpm, executor=mdft, return_more=True, return_fpm_grad=True, field_at_fpm=at_fpm)
+    assert len(more) == 4 and [w.space for w in more] == ['pupil', 'psf', 'psf', 'psf']
+    assert rel_max(tonp(more[0]), tonp(abar)) < 1e-14 and rel_max(tonp(more[3]), tonp(fpm_bar)) < 1e-14
+    yy, xx, eps = 3, 4, 1e-6
+    fp, fm = fpm_data.copy(), fpm_data.copy()
+    fp[yy, xx] += eps
+    fm[yy, xx] -= eps
+    j_plus = _real_vdot(outbar_data, tonp(wf.to_fpm_and_back(fpm=fp, executor=mdft)))
+    j_minus = _real_vdot(outbar_data, tonp(wf.to_fpm_and_back(fpm=fm, executor=mdft)))
+    fd = (j_plus - j_minus) / (2 * eps)
+    assert float(np.real(tonp(fpm_bar)[yy, xx])) == pytest.approx(fd, rel=1e-6, abs=1e-8)
+
+
+def test_babinet_adjoint_returns_fpm_and_lyot_gradients(pa):
+    """tests/test_propagation.py:384-427 through the Wavefront API"""
+    P = pa.propagation
+    rng = np.random.default_rng(456)
+    z = rng.normal(size=(8, 8)) + 1j * rng.normal(size=(8, 8))
+    wf = P.Wavefront(cmplx_field=z, dx=1.0, wavelength=O.HeNe, space='pupil')
+    fpm_data = rng.normal(size=(8, 8))
+    lyot_data = rng.normal(size=(8, 8))
+    fpm = P.Wavefront(cmplx_field=fpm_data, dx=0.1, wavelength=O.HeNe, space='psf')
+    lyot = P.Wavefront(cmplx_field=lyot_data, dx=1.0, wavelength=O.HeNe, space='pupil')
+    mdft = wf.prepare_executor(efl=10.0, dx=fpm.dx, samples=fpm.data.shape)
+    out, at_fpm, _, at_lyot = wf.babinet(lyot=lyot, fpm=fpm, executor=mdft, return_more=True)
+    outbar_data = rng.normal(size=(8, 8)) + 1j * rng.normal(size=(8, 8))
+    outbar = P.Wavefront(cmplx_field=outbar_data, dx=out.dx, wavelength=O.HeNe, space=out.space)
+    abar, fpm_bar, lyot_bar = outbar.babinet_adjoint(lyot=lyot, fpm=fpm, executor=mdft, field_at_fpm=at_fpm, field_at_lyot=at_lyot,
+                                                     return_fpm_grad=True, return_lyot_grad=True)
+    assert (abar.space, fpm_bar.space, lyot_bar.space) == ('pupil', 'psf', 'pupil') and fpm_bar.dx == mdft.focal_dx
+    # the plain call still returns one wavefront, equal to the oracle's adjoint
+    plain = outbar.babinet_adjoint(lyot=lyot, fpm=fpm, executor=mdft)
+    ex = O.prepare_executor(1.0, (8, 8), 0.1, (8, 8), O.HeNe, 10.0)
+    assert rel_max(tonp(plain), O.babinet_adjoint(outbar_data, lyot_data, fpm_data, ex)) < TOL64
+    eps = 1e-6
+
+    def J(f, l):
+        return _real_vdot(outbar_data, tonp(wf.babinet(lyot=l, fpm=f, executor=mdft)))
+
+    fy, fx = 2, 5
+    fp, fm = fpm_data.copy(), fpm_data.copy()
+    fp[fy, fx] += eps
+    fm[fy, fx] -= eps
+    fd_fpm = (J(fp, lyot_data) - J(fm, lyot_data)) / (2 * eps)
+    ly, lx = 6, 1
+    lp, lm = lyot_data.copy(), lyot_data.copy()
+    lp[ly, lx] += eps
+    lm[ly, lx] -= eps
+    fd_lyot = (J(fpm_data, lp) - J(fpm_data, lm)) / (2 * eps)
+    assert float(np.real(tonp(fpm_bar)[fy, fx])) == pytest.approx(fd_fpm, rel=1e-6, abs=1e-8)
+    assert float(np.real(tonp(lyot_bar)[ly, lx])) == pytest.approx(fd_lyot, rel=1e-6, abs=1e-8)
+
+
+def test_multiresolution_fpm_grad_matches_fd(pa):
+    """tests/test_propagation.py:589-622"""
+    P = pa.propagation
+    rng = np.random.default_rng(20260704)
+    npup = 16
+    executor = P.prepare_multiresolution(pupil_dx=0.25, pupil_samples=npup, focal_dx=4.0, focal_samples=16, wavelength=O.HeNe,
+                                         efl=10.0, num_levels=2, fine_samples=12)
+    fpm = P.vortex_phase_mask(2)
+    x = rng.standard_normal((npup, npup)) + 1j * rng.standard_normal((npup, npup))
+    out, at_fpm, after_fpm = P.to_fpm_and_back_multiresolution(x, fpm, executor, return_more=True)
+    assert len(at_fpm) == len(after_fpm) == len(executor)
+    ybar = rng.standard_normal((npup, npup)) + 1j * rng.standard_normal((npup, npup))
+    _, fpm_bars = P.to_fpm_and_back_multiresolution_adjoint(ybar, fpm, executor, return_fpm_grad=True, field_at_fpm=at_fpm)
+    k, iy, ix = 1, 3, 5
+    x0 = float(tonp(executor.xf[k])[iy, ix])
+    y0 = float(tonp(executor.yf[k])[iy, ix])
+    eps = 1e-6
+
+    def bumped(sign):
+        def f(xf, yf):
+            return fpm(xf, yf) + sign * eps * ((xf == x0) & (yf == y0))
+        return f
+
+    j_plus = _real_vdot(ybar, tonp(P.to_fpm_and_back_multiresolution(x, bumped(+1), executor)))
+    j_minus = _real_vdot(ybar, tonp(P.to_fpm_and_back_multiresolution(x, bumped(-1), executor)))
+    fd = (j_plus - j_minus) / (2 * eps)
+    assert float(np.real(tonp(fpm_bars[k])[iy, ix])) == pytest.approx(fd, rel=1e-6, abs=1e-8)
+
+
+# ----------------------------------------------------------------------------- ADVICE r1
+
+def test_babinet_takes_a_boolean_occulter(pa):
+    """geometry.circle masks are boolean; numpy's `1 - bool_array` works in the reference (coronagraph.py:339)"""
+    P = pa.propagation
+    rng = np.random.default_rng(9)
+    n = 32
+    x, y = O.make_xy_grid(n, diameter=8)
+    r, _ = O.cart_to_polar(x, y)
+    field = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) * O.circle(4, r)
+    occ = O.circle(1.5, r)       # bool
+    lyot = O.circle(3.5, r)      # bool
+    assert occ.dtype == bool
+    ex = P.prepare_executor(8 / n, (n, n), 1.0, (n, n), O.HeNe, 20.0)
+    exo = O.prepare_executor(8 / n, (n, n), 1.0, (n, n), O.HeNe, 20.0)
+    got = tonp(P.babinet(field, lyot, occ, ex))
+    assert rel_max(got, O.babinet(field, lyot, occ, exo)) < TOL64
+    g = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    gota = tonp(P.babinet_adjoint(g, lyot, occ, ex))
+    assert rel_max(gota, O.babinet_adjoint(g, lyot.astype(float), occ, exo)) < TOL64
+
+
+def test_focus_intensity_rejects_a_mismatched_accumulator(pa):
+    P = pa.propagation
+    x = torch.randn(64, 64, dtype=torch.complex64, device='cuda')
+    good = torch.zeros(128, 128, dtype=torch.float32, device='cuda')
+    P.focus_intensity(x, 2, out=good, weight=0.5)
+    for bad in (torch.zeros(128, 128, dtype=torch.float64, device='cuda'),       # dtype of another precision
+                torch.zeros(64, 64, dtype=torch.float32, device='cuda'),         # shape of another Q
+                torch.zeros(128, 256, dtype=torch.float32, device='cuda')[:, ::2],   # last axis not contiguous
+                torch.zeros(128, 128, dtype=torch.float32)):                     # host tensor
+        with pytest.raises(ValueError):
+            P.focus_intensity(x, 2, out=bad, weight=0.5)
+    # a row-strided view is fine (only the leading dimension is read)
+    wide = torch.zeros(128, 160, dtype=torch.float32, device='cuda')
+    P.focus_intensity(x, 2, out=wide[:, :128], weight=0.5)
+    assert rel_max(tonp(wide[:, :128]), tonp(good)) < 1e-6 and float(wide[:, 128:].abs().max()) == 0.0
+
+
+def test_jones_adapter_passes_stacks_through(pa):
+    from prysm_amd.x import polarization as pol
+    rng = np.random.default_rng(3)
+    wrapped = pol.jones_adapter(pa.propagation.focus)
+    st = (rng.standard_normal((3, 32, 32)) + 1j * rng.standard_normal((3, 32, 32)))
+    got = tonp(wrapped(st, 2))
+    assert got.shape == (3, 64, 64)
+    for b in range(3):
+        assert rel_max(got[b], O.focus(st[b], 2)) < TOL64
+    J = rng.standard_normal((16, 16, 2, 2)) + 1j * rng.standard_normal((16, 16, 2, 2))
+    gj = tonp(wrapped(J, 2))
+    assert gj.shape == (32, 32, 2, 2)
+    assert rel_max(gj[..., 1, 0], O.focus(J[..., 1, 0], 2)) < TOL64
+
+
+# ----------------------------------------------------------------------------- N > 1
+
+def _two_rank_backend():
+    return 'nccl' if torch.cuda.device_count() >= 2 else 'gloo'
+
+
+def _env():
+    env = dict(os.environ)
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    return env
+
+
+def test_bench_two_ranks_selflaunch(pa):
+    """`python bench.py --gpus 2` with no launcher: bench.py re-executes itself under torch.distributed.run, one rank per GPU
+    over RCCL when two GPUs are visible (both ranks on GPU 0 over gloo otherwise) and prints ONE line with n_gpus = 2 and a
+    timed config-5 run."""
+    be = _two_rank_backend()
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2', '--n', '1024',
+           '--no-cpu-baseline', '--backend', be]
+    env = _env()
+    env.pop('WORLD_SIZE', None)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['scaling'] == 'weak'
+    poly = line['polychromatic']
+    assert poly['wavelengths_per_gpu'] == 32
+    assert poly['variant_F_fft_focus']['psf_ms'] > 0 and poly['variant_M_mdft_512']['psf_ms'] > 0
+    assert line['n2048']['value'] > 0 and line['reduce_ms'] > 0
+
+
+def test_polychromatic_two_ranks_vs_oracle(pa):
+    """tests/multi_rank_poly.py: stacks, field-by-field and matrix-DFT variants sharded over two ranks, reduce and the
+    all-to-all reduce, against the oracle's single-process sum"""
+    be = _two_rank_backend()
+    env = _env()
+    env['PM_TEST_BACKEND'] = be
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29541', os.path.join(ROOT, 'tests', 'multi_rank_poly.py')]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
+    assert res.stdout.count('OK') >= 2

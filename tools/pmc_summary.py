@@ -11,8 +11,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def short(n):
@@ -48,7 +51,11 @@ def main():
         wr = w * 1024
         out[k] = {'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w, 'launches': max(nf, nw),
                   'hbm_read_bytes_corrected': rd, 'hbm_write_bytes': wr, 'hbm_traffic_bytes': rd + wr}
-    json.dump(out, open(sys.argv[3], 'w'), indent=1)
+    # what these counters describe: the kernel sources of THIS tree (bench.py prints `traffic` only while they still match)
+    from bench import source_fingerprint
+    meta = {'source_fingerprint': source_fingerprint(), 'command': 'bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-poly',
+            'passes': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs; FETCH_SIZE doubled (gfx950)'}
+    json.dump(dict(out, _meta=meta), open(sys.argv[3], 'w'), indent=1)
     for k, v in out.items():
         print(f"{k:48s} read {v['hbm_read_bytes_corrected'] / 1e6:9.1f} MB  write {v['hbm_write_bytes'] / 1e6:9.1f} MB  x{v['launches']}")
 
