@@ -59,7 +59,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--n', type=int, default=N_EDGE, help='transform edge (default 4096, the headline)')
+    ap.add_argument('--edge', dest='n', type=int, default=N_EDGE, help='transform edge (default 4096, the headline); not --n: torch.distributed.run would read that as an abbreviation of its own options')
     ap.add_argument('--dtype', default='c64', choices=['c64', 'c128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-poly', action='store_true', help='only the headline loop (profiling runs)')

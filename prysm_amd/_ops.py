@@ -69,7 +69,7 @@ def synth_supported(opd, amp, N):
 
 # Filled descriptors and their workspace sizes, keyed by everything in them that is not a pointer or a per-call scalar: a
 # repeated propagation (the inner loop of every model) then costs one struct copy, four pointer stores and ONE library
-# call instead of ~40 ctypes field stores and a workspace query (tools/exp_host_overhead.py: 21 -> 9 us per call).
+# call pair instead of ~40 ctypes field stores.
 _fft2_plans = {}
 
 
@@ -148,7 +148,7 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
         nbytes = lib.pm_fft2_workspace(ctypes.byref(d))
         if nbytes == 0:
             L.check(lib.pm_fft2(ctypes.byref(d), L.ptr(x), L.ptr(out), None, 0, L.stream_ptr()))  # raises with the reason
-        plan = (d, int(nbytes))
+        plan = (d,)
         if len(_fft2_plans) > 512:
             _fft2_plans.clear()
         _fft2_plans[key] = plan
@@ -161,8 +161,11 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
         d.mul = mul.data_ptr()
         if mul_x is not None:
             d.mul_x = mul_x.data_ptr()
-    ws = L.workspace(plan[1])
-    L.check(lib.pm_fft2(ctypes.byref(d), x.data_ptr(), out.data_ptr(), ws.data_ptr(), plan[1], L.stream_ptr()))
+    nbytes = lib.pm_fft2_workspace(ctypes.byref(d))      # not cached: it follows the tuning knobs (pm_set_tuning)
+    ws = L.workspace(nbytes)
+    rc = lib.pm_fft2(ctypes.byref(d), x.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes, L.stream_ptr())
+    if rc:
+        L.check(rc)
     return out
 
 

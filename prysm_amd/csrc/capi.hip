@@ -111,6 +111,9 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("row_var")) t.row_var = v;
     else if (is("gemm_bk")) t.gemm_bk = v;
     else if (is("gemm_bm")) t.gemm_bm = v;
+    else if (is("gemm_dma")) t.gemm_dma = v ? 1 : 0;
+    else if (is("gemm_dma_wgs")) t.gemm_dma_wgs = v < 1 ? 1 : v;
+    else if (is("gemm_tile")) t.gemm_tile = (v == 64 || v == 128) ? v : 0;
     else if (is("gemm_3m")) t.gemm_3m = v ? 1 : 0;
     else if (is("gemm_min_wgs")) t.gemm_min_wgs = v < 1 ? 1 : v;
     else if (is("nt_in")) t.nt_in = v;
@@ -118,6 +121,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("fold")) t.fold = v;
     else if (is("col_spread")) t.col_spread = v < 0 ? 0 : (v > 12 ? 12 : v);
     else if (is("col_skew")) t.col_skew = v < 0 ? 0 : (v > 64 ? 64 : v);
+    else if (is("row_skew")) t.row_skew = v < 0 ? 0 : (v > 64 ? 64 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
     else if (is("blue_min")) t.blue_min = v < 0 ? 0 : v;
     else if (is("blue_2d")) t.blue_2d = v ? 1 : 0;
@@ -361,7 +365,7 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
                 int ltc = 0;
                 while ((1 << ltc) < (p.tc << p.log_k)) ++ltc;
                 RowStoreTiled<T> sp{W, rows, ltc, wstride};
-                rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, tuning().row_log_g, st, nb);
+                rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, tuning().row_log_g | (tuning().row_skew << 8), st, nb);
             } else {
                 RowStoreNat<T> sp{W, N, AxisMap{int(N), int(N), 0, 0}, rows, 0, T(1), 0, AxisMap{1, 1, 0, 0}};
                 rc = launch_row_nat<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, 0, st);

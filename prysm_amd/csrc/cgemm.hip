@@ -6,15 +6,18 @@
 // complex64  : v_mfma_f32_32x32x2_f32  (exact f32, 157.3 TF peak = the whole f32 rate of the chip)
 // complex128 : v_mfma_f64_16x16x4_f64
 //
-// A complex product is four real MFMA chains on split (planar) operands:
-//     Cr += Ar Br + (-Ai) Bi        Ci += Ar Bi + Ai Br
-// Global memory stays interleaved (re, im); the de-interleave, the transposes of opA / opB and the
-// conjugations happen once per K-tile while staging into LDS, where both operands are held
-// k-major ([k][row]) so each MFMA operand read is one conflict-free ds_read of consecutive words.
+// A complex product is THREE real MFMA chains (the "3M" form: P1 = Ar Br, P2 = Ai Bi, P3 = (Ar + Ai)(Br + Bi);
+// Cr = P1 - P2, Ci = P3 - P1 - P2; knob gemm_3m = 0: the four-chain form).  Operands stay interleaved (re, im) in global
+// memory and in LDS; conjugations are signs on the imaginary operands and in the epilogue.
 //
-// Work decomposition for the MDFT shapes (e.g. 512 x 2048 x 2048 then 512 x 512 x 2048): 64 x 64
-// output tiles alone give only 256 / 64 workgroups for 256 CUs, so K is split (blockIdx.z) into
-// slabs reduced by a second tiny kernel in a FIXED order -- deterministic, unlike atomics.
+// Two kernels:
+//  * cgemm_dma_kernel -- complex64, shapes that are multiples of 64 x 64 x 16 with 16-byte aligned operands (every matrix-DFT
+//    product of the BASELINE configs): operand tiles go global -> LDS by LDS-DMA, three LDS buffers, one barrier per K-tile in
+//    the middle of its MFMA stream, fragments read a quarter tile ahead.  64 x 64 or 128 x 128 workgroup tiles.
+//  * cgemm_kernel -- everything else (complex128 on v_mfma_f64_16x16x4_f64, ragged shapes, unaligned operands): register-staged
+//    64 x 64 tiles with masked edges.
+// When the output has too few tiles for 256 CUs, K is split into slabs reduced by a second small kernel in a FIXED order --
+// deterministic, unlike atomics.
 #include "pm_internal.h"
 
 namespace pm {
@@ -61,10 +64,7 @@ struct MfmaTraits<double> {
 //
 // Everything per-thread is computed ONCE: the byte offset of each element from the (workgroup-uniform) base of the
 // current K-tile, and its LDS slot.  Per K-tile the base advances by a scalar add and the loads are
-// `global_load ... v_off, s[base]`; on interior tiles the registers go to LDS as they are.  (Measured with the
-// timing builds -DPM_GEMM_DBG: the MFMA loop alone runs the 512 x 2048 x 2048 product in 110 us; the previous staging
-// -- 64-bit pointer bumps, validity masks, select / conj multiplies, LDS address arithmetic, ~120 VALU instructions per
-// K-tile and thread -- cost another 46 us because VALU work beside MFMAs steals their issue slots.)
+// `global_load ... v_off, s[base]`; on interior tiles the registers go to LDS as they are.
 // Conjugations are NOT applied here: they are folded into the sign of the imaginary parts at the MFMA operands and
 // in the epilogue.  Out-of-range rows are clamped to the last valid row and zeroed when stored (edge tiles only);
 // the K tail (last tile of a slab) takes the masked path too.
@@ -206,27 +206,16 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
     __syncthreads();
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
-#ifndef PM_GEMM_DBG
-#define PM_GEMM_DBG 0   // timing builds (wrong results): 1 = no global loads / LDS staging in the loop, 2 = also no LDS operand
-                        // reads, 3 = global loads but no LDS stores, 4 = LDS stores but no global loads, 5 = everything but the barrier
-#endif
-        if (more && (PM_GEMM_DBG == 0 || PM_GEMM_DBG == 3)) fetch_tile(k0 + BK);   // next K-tile into registers: in flight under the MFMAs of this one
+        if (more) fetch_tile(k0 + BK);   // next K-tile into registers: in flight under the MFMAs of this one
         // operand fragments of k-step n + 1 are read from LDS BEFORE the MFMAs of k-step n are issued (register double
         // buffer), so the LDS latency -- longer while other workgroups stage their tiles -- hides under matrix work
         cx<T> a[2][TI], b[2][TJ];
         auto read_frags = [&](int slot, int ks) {
             const int kk = ks + MT::op_k(lane);
-            if (PM_GEMM_DBG == 2) {
 #pragma unroll
-                for (int i = 0; i < TI; ++i) a[slot][i] = {T(lane + ks), T(i + 1)};
+            for (int i = 0; i < TI; ++i) a[slot][i] = As[buf][kk][wr * WM + i * TM + MT::op_row(lane)];
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) b[slot][j] = {T(ks + 1), T(lane + j)};
-            } else {
-#pragma unroll
-                for (int i = 0; i < TI; ++i) a[slot][i] = As[buf][kk][wr * WM + i * TM + MT::op_row(lane)];
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) b[slot][j] = Bs[buf][kk][wc * WN + j * TM + MT::op_row(lane)];
-            }
+            for (int j = 0; j < TJ; ++j) b[slot][j] = Bs[buf][kk][wc * WN + j * TM + MT::op_row(lane)];
         };
         read_frags(0, 0);
 #pragma unroll
@@ -266,14 +255,8 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
                     }
             }
         }
-        if (more && (PM_GEMM_DBG == 0 || PM_GEMM_DBG == 4)) store_tile(buf ^ 1, k0 + BK);
-        if (PM_GEMM_DBG == 3 && more) {   // keep the loads alive without the LDS stores
-            T sum = T(0);
-#pragma unroll
-            for (int s_ = 0; s_ < SA::E; ++s_) sum += ra[s_].x + rb[s_].y;
-            if (sum == T(-12345.5)) As0[tid] = {sum, sum};
-        }
-        if (PM_GEMM_DBG != 5) __syncthreads();   // timing build 5: no barrier in the loop (wrong results)
+        if (more) store_tile(buf ^ 1, k0 + BK);
+        __syncthreads();
         buf ^= 1;
     }
 
@@ -294,6 +277,232 @@ __global__ void __launch_bounds__(256, 2) cgemm_kernel(int conjA, int conjB, int
                     ci = acc_3[i][j][r] - p1 - p2;
                 }
                 if (row < M && col < N) Cout[row * ldc + col] = {cr * alpha, ci * alpha};
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// complex64, large aligned shapes (the matrix-DFT products): 128 x 128 workgroup tiles, 64 x 64 per wave.
+//
+// Why a second kernel: with 32 x 32 per wave (above) a K-tile of 16 is 24 MFMAs = 0.64 us, shorter than the round trip of
+// the global loads that must land before the next LDS stage, and every K-tile ends in a barrier: the MFMA pipe measured
+// 61.6 % busy (profiles/r01/gemm_sq_counters.txt).  Here a wave owns 2 x 2 MFMA tiles and the three chains of the 3M
+// product: 96 MFMAs = 2.6 us per K-tile and barrier, four 16-byte LDS reads per 24 MFMAs, and the next K-tile's global loads
+// have the whole K-tile to arrive.  192 accumulator registers per lane, so ONE workgroup of four waves per CU (a wave has
+// the 512-register file of its SIMD to itself).
+//
+// K inside a K-tile is PERMUTED: lane half h = lane >> 5 of an MFMA takes k = 8 h + s at step s (s < 8), for A and B alike,
+// so the sum over the tile is the same and a lane's eight k values of one row are contiguous in LDS ([row][k], rows padded to
+// 18 elements = 144 B: the 16-byte reads of 16 consecutive rows fall on 64 distinct banks).  Operands stay interleaved
+// (re, im); conjugations are signs (sa, sb) applied to the 3M sums and in the epilogue.
+// Requirements (host-checked, else the kernel above runs): M % 128 == 0, N % 128 == 0, slab depth % 16 == 0, 16-byte aligned
+// bases, even leading dimensions.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// One operand tile (ROWS rows x 16 k, ROWS = 64 or 128) in LDS, filled by LDS-DMA (global_load_lds_dwordx4: no staging
+// registers, no ds_write -- the eight ds_write_b128 per thread and K-tile of a register-staged version cost the MFMA stream
+// 1600 of its 6144 cycles, tools/exp_mfma2.cpp).  A DMA piece lands lane-linear (wave-uniform base + 16 B x lane), so the image is:
+//   KFAST (memory [row][k]):  [row][8 slots of 16 B], slot = kpair ^ ((row >> 1) & 7) -- the swizzle is applied to the SOURCE
+//                             address of each lane and again when reading; 16-byte fragment reads of the 16-lane LDS groups are
+//                             conflict-free.  Piece j = rows 8 j .. 8 j + 7.
+//   !KFAST (memory [k][row]): [k][ROWS rows] as in memory; a piece is 1 KiB of that image (one k of 128 rows, two of 64);
+//                             fragments by 8-byte reads.
+// ROWS / 8 pieces per tile, ROWS / 32 per wave.
+template <int ROWS, bool KFAST>
+struct DmaTile {
+    static constexpr int PPW = ROWS / 32;   // pieces per wave
+    unsigned goff[PPW];   // this lane's source byte offset from the tile base, per piece
+    __device__ __forceinline__ void init(int64_t ld, int wave, int lane) {
+#pragma unroll
+        for (int s = 0; s < PPW; ++s) {
+            const int j = wave * PPW + s;
+            if (KFAST) {
+                const int row = 8 * j + (lane >> 3), slot = lane & 7;
+                const int c = slot ^ ((row >> 1) & 7);
+                goff[s] = unsigned((int64_t(row) * ld + 2 * c) * 8);
+            } else {
+                const int byte = j * 1024 + lane * 16;
+                const int k = byte / (ROWS * 8), rp = (byte % (ROWS * 8)) / 16;
+                goff[s] = unsigned((int64_t(k) * ld + 2 * rp) * 8);
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(const char* base, char* tile, int wave) const {
+#pragma unroll
+        for (int s = 0; s < PPW; ++s)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + goff[s]),
+                                             (__attribute__((address_space(3))) void*)(tile + (wave * PPW + s) * 1024), 16, 0, 0);
+    }
+};
+
+// TI x TJ MFMA tiles (32 x 32) per wave, 2 x 2 waves: workgroup tile 64 TI x 64 TJ.  (2, 2): 128 x 128, one workgroup per CU
+// (192 accumulator registers per lane), the large-GEMM shape; (1, 1): 64 x 64, for the matrix-DFT products whose output has only
+// a few hundred such tiles -- 512 x 2048 = 256 of them, one per CU without splitting K.
+template <int TI, int TJ, bool AKF, bool BKF>
+__global__ void __launch_bounds__(256) cgemm_dma_kernel(int conjA, int conjB, int ntm, int ntn, int64_t K, int64_t ksplit, float alpha,
+                                                       const cx<float>* __restrict__ A, int64_t lda, const cx<float>* __restrict__ B,
+                                                       int64_t ldb, cx<float>* __restrict__ C, int64_t ldc, int64_t slab_stride) {
+    constexpr int BK = 16, BM = 64 * TI, BN = 64 * TJ, NBUF = 3;
+    constexpr int ABYTES = BM * 128, BBYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char pm_gemm_smem[];
+    char* const As = pm_gemm_smem;                       // [3] operand images
+    char* const Bs = pm_gemm_smem + NBUF * ABYTES;
+
+    // XCD-aware order: workgroups b, b + 8, ... run on one XCD; give each XCD a CONTIGUOUS run of the (slab, n-tile, m-tile)
+    // list, m fastest, so the workgroups that share a B slab (and then an A slab) share that XCD's L2
+    int l = blockIdx.x;
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) l = (l & 7) * (nb >> 3) + (l >> 3);
+    const int tiles = ntm * ntn;
+    const int slab = l / tiles, rr = l - slab * tiles;
+    const int tn = rr / ntm, tm = rr - tn * ntm;
+    const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
+    const int64_t kbeg = int64_t(slab) * ksplit;
+    const int64_t kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
+    const int nkt = int((kend - kbeg) / BK);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int row = lane & 31, h = lane >> 5;
+    const float sa = conjA ? -1.f : 1.f, sb = conjB ? -1.f : 1.f;
+
+    DmaTile<BM, AKF> dA;
+    DmaTile<BN, BKF> dB;
+    dA.init(lda, wave, lane);
+    dB.init(ldb, wave, lane);
+    const char* pa = reinterpret_cast<const char*>(AKF ? A + m0 * lda + kbeg : A + kbeg * lda + m0);
+    const char* pb = reinterpret_cast<const char*>(BKF ? B + n0 * ldb + kbeg : B + kbeg * ldb + n0);
+    const int64_t stepA = (AKF ? int64_t(BK) : int64_t(BK) * lda) * 8, stepB = (BKF ? int64_t(BK) : int64_t(BK) * ldb) * 8;
+
+    f32x16 p1[TI][TJ], p2[TI][TJ], p3[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p1[i][j][r] = p2[i][j][r] = p3[i][j][r] = 0.f;
+
+    // K inside a K-tile is permuted: lane half h takes k = 8 h + 2 q + e at step (quarter q, e), for both operands alike.
+    // fragment byte offsets inside an operand image, row block 0 (block 1: + 32 rows):
+    //   KFAST : row * 128 + ((4 h + q) ^ swz) * 16, swz = (row >> 1) & 7 (the row-block offsets are multiples of 32 rows: same swz)
+    //   !KFAST: (8 h + 2 q + e) * ROWS * 8 + row * 8
+    const int swz = (row >> 1) & 7;
+    const int ra0 = AKF ? (wr * 32 * TI + row) * 128 + ((4 * h) ^ (swz & 4)) * 16 : h * 8 * BM * 8 + (wr * 32 * TI + row) * 8;
+    const int rb0 = BKF ? (wc * 32 * TJ + row) * 128 + ((4 * h) ^ (swz & 4)) * 16 : h * 8 * BN * 8 + (wc * 32 * TJ + row) * 8;
+    int qoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qoff[q] = (q ^ (swz & 3)) * 16;
+    // one quarter of fragments = the (re, im) of 2 k values per row block and operand: fr[slot][block] = (k0.re, k0.im, k1.re, k1.im)
+    f32x4 fa[2][TI], fb[2][TJ];
+    auto read_quarter = [&](int slot, int bufi, int q) {
+        const char* at = As + bufi * ABYTES + ra0;
+        const char* bt = Bs + bufi * BBYTES + rb0;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            if constexpr (AKF) {
+                fa[slot][i] = *reinterpret_cast<const f32x4*>(at + i * 32 * 128 + qoff[q]);
+            } else {
+                const f32x2 u = *reinterpret_cast<const f32x2*>(at + i * 32 * 8 + (2 * q) * BM * 8);
+                const f32x2 v = *reinterpret_cast<const f32x2*>(at + i * 32 * 8 + (2 * q + 1) * BM * 8);
+                fa[slot][i] = f32x4{u[0], u[1], v[0], v[1]};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            if constexpr (BKF) {
+                fb[slot][j] = *reinterpret_cast<const f32x4*>(bt + j * 32 * 128 + qoff[q]);
+            } else {
+                const f32x2 u = *reinterpret_cast<const f32x2*>(bt + j * 32 * 8 + (2 * q) * BN * 8);
+                const f32x2 v = *reinterpret_cast<const f32x2*>(bt + j * 32 * 8 + (2 * q + 1) * BN * 8);
+                fb[slot][j] = f32x4{u[0], u[1], v[0], v[1]};
+            }
+        }
+    };
+
+    // Pipeline (one barrier per K-tile, in the MIDDLE of its MFMA stream; two tiles of DMA in flight):
+    //   tile t lives in LDS buffer t % 3.  In the middle of tile t: wait for this wave's DMA pieces of tile t + 1 (issued a whole
+    //   tile ago), barrier -- every wave's pieces of tile t + 1 are now in LDS and every wave has left tile t - 1 --, then issue
+    //   the DMA of tile t + 2 into buffer (t + 2) % 3 = the buffer of tile t - 1.  Fragments are read one quarter ahead of their
+    //   use, the first quarter of tile t + 1 during the last quarter of tile t.
+    if (nkt > 0) {
+        dA.issue(pa, As, wave);
+        dB.issue(pb, Bs, wave);
+    }
+    if (nkt > 1) {
+        pa += stepA;
+        pb += stepB;
+        dA.issue(pa, As + ABYTES, wave);
+        dB.issue(pb, Bs + BBYTES, wave);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();    // tiles 0 and 1 are in LDS
+    if (nkt > 0) read_quarter(0, 0, 0);
+    int buf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
+        const int pbuf = buf == 0 ? NBUF - 1 : buf - 1;     // = (kt + 2) % 3
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cur = q & 1;
+            if (q < 3) read_quarter(cur ^ 1, buf, q + 1);
+            else if (kt + 1 < nkt) read_quarter(0, nbuf, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {     // the two k values of the quarter
+                float ax[TI], ay[TI], as[TI], bx[TJ], by[TJ], bs[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    ax[i] = fa[cur][i][2 * e];
+                    ay[i] = fa[cur][i][2 * e + 1];
+                    as[i] = ax[i] + sa * ay[i];
+                }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    bx[j] = fb[cur][j][2 * e];
+                    by[j] = fb[cur][j][2 * e + 1];
+                    bs[j] = bx[j] + sb * by[j];
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) {
+                        p1[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[i], bx[j], p1[i][j], 0, 0, 0);
+                        p2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay[i], by[j], p2[i][j], 0, 0, 0);
+                        p3[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[i], bs[j], p3[i][j], 0, 0, 0);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == 1 && kt + 1 < nkt) {
+                // this wave's pieces of tile kt + 1 have landed (hipcc does not count an LDS-DMA issued in the previous trip of
+                // the loop: the wait is written out), then the barrier: everybody's have
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (kt + 2 < nkt) {
+                    pa += stepA;
+                    pb += stepB;
+                    dA.issue(pa, As + pbuf * ABYTES, wave);
+                    dB.issue(pb, Bs + pbuf * BBYTES, wave);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        buf = nbuf;
+    }
+
+    // epilogue: Cr = P1 - sa sb P2, Ci = P3 - P1 - sa sb P2; lanes of a row are adjacent columns (256 B runs)
+    cx<float>* Cout = C + int64_t(slab) * slab_stride;
+    const float ss = sa * sb;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t orow = m0 + wr * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int64_t ocol = n0 + wc * 32 * TJ + j * 32 + row;
+                const float q2 = ss * p2[i][j][r];
+                Cout[orow * ldc + ocol] = {(p1[i][j][r] - q2) * alpha, (p3[i][j][r] - p1[i][j][r] - q2) * alpha};
             }
 }
 
@@ -319,7 +528,36 @@ static int gemm_bm(int64_t M, int dtype = PM_C64) {
     return 64;
 }
 
+// plan of the LDS-DMA kernel: tile shape (128 x 128 when that alone fills the chip, else 64 x 64), and the split of K (slabs
+// reduced in a fixed order by splitk_reduce_kernel) only when even the small tiles leave CUs idle
+struct DmaPlan {
+    int tile;      // 64 or 128
+    int S;
+    int64_t ksplit;
+};
+static bool gemm_dma_plan(int64_t M, int64_t N, int64_t K, DmaPlan* out) {
+    if (!tuning().gemm_dma || !tuning().gemm_3m || M < 64 || N < 64 || (M % 64) || (N % 64) || K < 16 || (K % 16)) return false;
+    DmaPlan p{64, 1, K};
+    const int want = tuning().gemm_dma_wgs;
+    if ((M % 128) == 0 && (N % 128) == 0 && (M / 128) * (N / 128) >= want) p.tile = 128;
+    if (tuning().gemm_tile == 64 || (tuning().gemm_tile == 128 && (M % 128) == 0 && (N % 128) == 0)) p.tile = tuning().gemm_tile;
+    const int64_t tiles = (M / p.tile) * (N / p.tile);
+    // split K until the launch fills the 256 CUs, keeping at least 4 K-tiles per slab
+    while (tiles * p.S < want && K / (p.S * 2) >= 64 && ((K / (p.S * 2)) % 16) == 0 && p.S < 64) p.S *= 2;
+    p.ksplit = K / p.S;
+    if (out) *out = p;
+    return true;
+}
+
+static size_t cgemm_workspace_bytes_64(int dtype, int64_t M, int64_t N, int64_t K, int* S_out);
 size_t cgemm_workspace_bytes(int dtype, int64_t M, int64_t N, int64_t K, int* S_out) {
+    // the caller's operands decide between the two kernels (alignment), so the query covers both
+    size_t a = cgemm_workspace_bytes_64(dtype, M, N, K, S_out), b = 0;
+    DmaPlan dp;
+    if (dtype == PM_C64 && gemm_dma_plan(M, N, K, &dp) && dp.S > 1) b = size_t(dp.S) * size_t(M) * size_t(N) * 8;
+    return a > b ? a : b;
+}
+static size_t cgemm_workspace_bytes_64(int dtype, int64_t M, int64_t N, int64_t K, int* S_out) {
     const int BM = gemm_bm(M, dtype), BN = 64, BK = 32;   // slab depth multiple of the deepest K-tile
     const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int S = 1;
@@ -335,7 +573,7 @@ int cgemm_ws_bm(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha,
                 const cx<T>* B, int64_t ldb, cx<T>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
     constexpr int BN = 64;
     int S = 1;
-    const size_t need = cgemm_workspace_bytes(sizeof(T) == 4 ? PM_C64 : PM_C128, M, N, K, &S);
+    const size_t need = cgemm_workspace_bytes_64(sizeof(T) == 4 ? PM_C64 : PM_C128, M, N, K, &S);
     if (S > 1 && (!ws || ws_bytes < need)) S = 1;   // no workspace: fall back to unsplit (still correct)
     int64_t ksplit = (K + S - 1) / S;
     ksplit = (ksplit + BK - 1) / BK * BK;
@@ -398,9 +636,57 @@ int cgemm_ws_bk(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha,
     return cgemm_ws_bm<T, BK, 64>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
 }
 
+template <int TI>
+static int cgemm_dma_launch(bool akf, bool bkf, int cA, int cB, int ntm, int ntn, int S, int64_t K, int64_t ksplit, float al,
+                            const cx<float>* A, int64_t lda, const cx<float>* B, int64_t ldb, cx<float>* out, int64_t ldo, int64_t slab,
+                            hipStream_t st) {
+    constexpr int LDSB = 3 * 2 * (64 * TI) * 128;
+#define PM_GD(AK, BK_)                                                                                                                \
+    {                                                                                                                                 \
+        auto kern = cgemm_dma_kernel<TI, TI, AK, BK_>;                                                                                \
+        if (LDSB > 48 * 1024)                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);         \
+        hipLaunchKernelGGL(kern, dim3(unsigned(ntm * ntn * S)), dim3(256), LDSB, st, cA, cB, ntm, ntn, K, ksplit, al, A, lda, B, ldb, out, \
+                           ldo, slab);                                                                                                \
+    }
+    if (akf && bkf) PM_GD(true, true)
+    else if (akf) PM_GD(true, false)
+    else if (bkf) PM_GD(false, true)
+    else PM_GD(false, false)
+#undef PM_GD
+    return int(hipGetLastError());
+}
+
+static int cgemm_dma_run(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, const cx<float>* A, int64_t lda,
+                         const cx<float>* B, int64_t ldb, cx<float>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, DmaPlan p) {
+    if (p.S > 1 && (!ws || ws_bytes < size_t(p.S) * size_t(M) * size_t(N) * 8)) {   // no workspace: unsplit
+        p.S = 1;
+        p.ksplit = K;
+    }
+    const bool akf = !(opA & 2), bkf = (opB & 2) != 0;
+    const int cA = opA & 1, cB = opB & 1;
+    const int ntm = int(M / p.tile), ntn = int(N / p.tile);
+    cx<float>* out = p.S > 1 ? reinterpret_cast<cx<float>*>(ws) : C;
+    const int64_t ldo = p.S > 1 ? N : ldc, slab = p.S > 1 ? M * N : 0;
+    const float al = p.S > 1 ? 1.f : float(alpha);
+    int rc = p.tile == 128 ? cgemm_dma_launch<2>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st)
+                           : cgemm_dma_launch<1>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st);
+    if (rc || p.S == 1) return rc;
+    const int64_t total = M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, p.S, float(alpha),
+                       reinterpret_cast<const cx<float>*>(ws), M * N, C, ldc);
+    return int(hipGetLastError());
+}
+
 template <typename T>
 int cgemm_ws(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, const cx<T>* A, int64_t lda,
              const cx<T>* B, int64_t ldb, cx<T>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
+    if constexpr (sizeof(T) == 4) {
+        DmaPlan dp;
+        if (gemm_dma_plan(M, N, K, &dp) && (lda % 2) == 0 && (ldb % 2) == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 &&
+            reinterpret_cast<uintptr_t>(B) % 16 == 0)
+            return cgemm_dma_run(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st, dp);
+    }
     // K-tile depth: 16 (fp32) / 8 (fp64) = 33 KiB of LDS, 4 workgroups per CU; tuning gemm_bk = 32 / 16 doubles it
     // (66.5 KiB, 2 per CU, half the barriers per flop)
     const int bk = tuning().gemm_bk;

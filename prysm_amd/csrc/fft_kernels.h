@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp,
     // log_g_skew: bits 0-7 sibling-group size, bits 8+ start skew (column pass, experiment): every other workgroup
     // of the first wave sleeps skew x ~0.85 us so the CUs do not run their load / compute / store phases in lockstep
     const int log_g = log_g_skew & 0xff;
-    if (COL && ((log_g_skew >> 8) & 0xff) && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+    if (((log_g_skew >> 8) & 0xff) && ((blockIdx.x >> 3) & 1)) {
         for (int i = 0; i < ((log_g_skew >> 8) & 0xff); ++i) __builtin_amdgcn_s_sleep(32);
     }
     int unit = group_remap(blockIdx.x, gridDim.x, log_g);

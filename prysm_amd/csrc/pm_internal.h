@@ -90,12 +90,18 @@ struct Tuning {
     int nt_in = -1, nt_out = -1;
     int log_k = -1;     // layout tiles of the intermediate are 2^log_k column-pass tiles wide; -1 auto
     int gemm_3m = 1;          // complex products as three real MFMA chains (3M) instead of four
+    int gemm_dma = 1;         // complex64 shapes that are multiples of 64 x 64 x 16 take the LDS-DMA kernel (cgemm_dma_kernel)
+    int gemm_dma_wgs = 512;   // ... 128 x 128 tiles when there are at least this many, else 64 x 64 (two or three workgroups per CU hide each
+                              // other's barriers); K is split until the launch has this many workgroups.  Measured (profiles/r02/exp_gemm_shapes.log):
+                              // config 4 pair 148.5 us at 512 with 64 x 64 tiles against 155.5 (128 x 128, 256) and 164.1 (64 x 64, 256)
+    int gemm_tile = 0;        // force its tile edge (64 / 128); 0 = auto
     int gemm_bm = 64;         // rows of the GEMM workgroup tile (64 or 128)
     int gemm_bk = 0;          // 0 default K-tile depth, 32 doubles it
     int gemm_min_wgs = 1024;   // split K until the GEMM launch has at least this many workgroups
     int row_log_g = 1;  // sibling group of row-pass workgroups (rows q .. q+2^g-1 on one XCD)
     int fold = -1;           // radix-2 step of the column transform folded into the row pass: -1 auto, 0 never, 1 wherever legal
     int col_spread = 0;      // experiment: log2 of the stride permutation of column-pass sibling groups
+    int row_skew = 0;        // experiment: the same for the row pass
     int col_skew = 0;        // experiment: start skew of every other column-pass workgroup, units of ~0.85 us
     int blue_min = 96;        // shortest non-power-of-two length that takes the Bluestein path (shorter ones, and lengths
                              // above 4096, run on the direct O(n^2) kernel); 0 disables the path

@@ -311,7 +311,7 @@ def test_bench_two_ranks_selflaunch(pa):
     over RCCL when two GPUs are visible (both ranks on GPU 0 over gloo otherwise) and prints ONE line with n_gpus = 2 and a
     timed config-5 run."""
     be = _two_rank_backend()
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2', '--n', '1024',
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2', '--edge', '1024',
            '--no-cpu-baseline', '--backend', be]
     env = _env()
     env.pop('WORLD_SIZE', None)

@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+rm -rf gpurun_out/pmc_gemm
+( cd /tmp && timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/pmc_gemm -- python $R/tools/exp_gemm_trace.py ) > gpurun_out/rocprof_pmc_gemm.log 2>&1
+ls gpurun_out/pmc_gemm/*/ ; head -3 gpurun_out/pmc_gemm/*/*counter_collection.csv
+python tools/pmc_clock.py gpurun_out/pmc_gemm 2>&1 | tee gpurun_out/gemm_clock.txt

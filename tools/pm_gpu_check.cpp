@@ -509,7 +509,7 @@ static void sweep_fft2(int64_t n, const std::vector<Knobs>& cfgs, int rounds) {
 // generic interleaved A/B: "tune N c64|c128 rounds cfg cfg ..." with cfg = "key=val,key=val" (pm_set_tuning keys; keys not
 // named in a cfg are reset to their defaults first)
 static void set_cfg(const std::string& cfg) {
-    static const char* defaults = "row_var=-1,col_var=0,nt_in=-1,nt_out=-1,log_k=-1,row_log_g=1,col_skew=0,col_spread=0,fold=-1";
+    static const char* defaults = "row_var=-1,col_var=0,nt_in=-1,nt_out=-1,log_k=-1,row_log_g=1,col_skew=0,row_skew=0,col_spread=0,fold=-1";
     for (const std::string& src : {std::string(defaults), cfg}) {
         size_t i = 0;
         while (i < src.size()) {
@@ -839,20 +839,36 @@ int main(int argc, char** argv) {
                 check_cgemm<float>(opA, opB, 70, 45, 100, 2e-5, false);
                 check_cgemm<double>(opA, opB, 33, 50, 37, 1e-13, false);
             }
+        // the 128 x 128 kernel: every op pair, slab depths of 1 .. 5 K-tiles, split and unsplit
+        for (int opA = 0; opA < 4; ++opA)
+            for (int opB = 0; opB < 4; ++opB) {
+                check_cgemm<float>(opA, opB, 256, 128, 48, 2e-5, true);
+                check_cgemm<float>(opA, opB, 192, 64, 80, 2e-5, true);      // 64 x 64 tiles
+            }
+        pm_set_tuning("gemm_tile", 128);
+        for (int opA = 0; opA < 4; ++opA)
+            for (int opB = 0; opB < 4; ++opB) check_cgemm<float>(opA, opB, 256, 128, 48, 2e-5, true);
+        pm_set_tuning("gemm_tile", 0);
+        for (int64_t K : {16, 32, 64, 80, 256}) {
+            check_cgemm<float>(0, 0, 128, 256, K, 2e-5, true);
+            check_cgemm<float>(3, 2, 128, 128, K, 2e-5, false);
+        }
         check_cgemm<float>(0, 0, 512, 2048, 2048, 5e-5, true);
         check_cgemm<float>(0, 2, 512, 512, 2048, 5e-5, true);
         check_cgemm<float>(3, 0, 2048, 512, 512, 5e-5, true);
         check_cgemm<float>(0, 1, 2048, 2048, 512, 5e-5, true);
         check_cgemm<double>(3, 1, 200, 300, 1000, 1e-12, true);
-        for (int wgs : {1024, 1032, 512, 520}) {   // odd values: gemm_bk = 32 variant
-            pm_set_tuning("gemm_min_wgs", wgs & ~15);
-            pm_set_tuning("gemm_bk", (wgs & 8) ? 32 : 0);
-            printf("gemm_min_wgs=%d gemm_bk=%d\n", wgs & ~15, (wgs & 8) ? 32 : 0);
+        for (int tile : {0, 64, 128}) {
+            pm_set_tuning("gemm_tile", tile);
+            printf("gemm_tile=%d\n", tile);
             bench_cgemm<float>(512, 2048, 2048, 0);
             bench_cgemm<float>(512, 512, 2048, 2);
             bench_cgemm<float>(2048, 512, 512, 0);
-            bench_cgemm<double>(512, 2048, 2048, 0);
+            bench_cgemm<float>(512, 4096, 4096, 0);
+            bench_cgemm<float>(512, 512, 4096, 2);
         }
+        pm_set_tuning("gemm_tile", 0);
+        bench_cgemm<double>(512, 2048, 2048, 0);
         pm_set_tuning("gemm_min_wgs", 1024);
         pm_set_tuning("gemm_bk", 32);
         bench_cgemm<float>(4096, 4096, 4096, 0);
@@ -933,6 +949,20 @@ int main(int argc, char** argv) {
                 check_cgemm<float>(opA, opB, 70, 45, 100, 2e-5, false);
                 check_cgemm<double>(opA, opB, 33, 50, 37, 1e-13, false);
             }
+        // the 128 x 128 kernel: every op pair, slab depths of 1 .. 5 K-tiles, split and unsplit
+        for (int opA = 0; opA < 4; ++opA)
+            for (int opB = 0; opB < 4; ++opB) {
+                check_cgemm<float>(opA, opB, 256, 128, 48, 2e-5, true);
+                check_cgemm<float>(opA, opB, 192, 64, 80, 2e-5, true);      // 64 x 64 tiles
+            }
+        pm_set_tuning("gemm_tile", 128);
+        for (int opA = 0; opA < 4; ++opA)
+            for (int opB = 0; opB < 4; ++opB) check_cgemm<float>(opA, opB, 256, 128, 48, 2e-5, true);
+        pm_set_tuning("gemm_tile", 0);
+        for (int64_t K : {16, 32, 64, 80, 256}) {
+            check_cgemm<float>(0, 0, 128, 256, K, 2e-5, true);
+            check_cgemm<float>(3, 2, 128, 128, K, 2e-5, false);
+        }
         check_cgemm<float>(0, 0, 512, 2048, 2048, 5e-5, true);
         check_cgemm<float>(0, 2, 512, 512, 2048, 5e-5, true);
         check_cgemm<double>(3, 1, 200, 300, 1000, 1e-12, true);
