@@ -332,12 +332,18 @@ def polychromatic_config5(ranks, n, reps=3):
     def var_m():
         polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, focal_dx=0.55 * 10 / 4, samples=512, kind='mdft', reduce_to_all=False)
 
-    for name, fn, k in (('variant_F_fft_focus', var_f, reps), ('variant_M_mdft_512', var_m, max(1, reps - 1))):
-        fn()    # warm: plans, communicator, allocator
-        ts = sorted(ranks.timed(fn) for _ in range(k))
-        t = ts[len(ts) // 2]
-        res[name] = {'psf_ms': t * 1e3, 'psfs_per_s': 1.0 / t, 'wavelengths_per_s': N_WAVELENGTHS / t,
-                     'per_wavelength_ms_per_gpu': t * 1e3 / math.ceil(N_WAVELENGTHS / ranks.world)}
+    from prysm_amd.conf import config
+    prec = config.precision
+    config.precision = 32     # fp32 maps -> complex64 pupils; at the default precision 64 the executors' bases would be complex128
+    try:                      # and promote the whole matrix DFT to fp64 MFMA (numpy's result-type rule)
+        for name, fn, k in (('variant_F_fft_focus', var_f, reps), ('variant_M_mdft_512', var_m, reps)):
+            fn()    # warm: plans, communicator, allocator
+            ts = sorted(ranks.timed(fn) for _ in range(k))
+            t = ts[len(ts) // 2]
+            res[name] = {'psf_ms': t * 1e3, 'psfs_per_s': 1.0 / t, 'wavelengths_per_s': N_WAVELENGTHS / t,
+                         'per_wavelength_ms_per_gpu': t * 1e3 / math.ceil(N_WAVELENGTHS / ranks.world)}
+    finally:
+        config.precision = prec
     fl = 8 * 512 * n * (n + 512) * N_WAVELENGTHS
     res['variant_M_mdft_512']['algorithmic_TFLOPs_whole_job'] = fl / (res['variant_M_mdft_512']['psf_ms'] * 1e-3) / 1e12
     res['note'] = ('timed polychromatic_psf calls (barrier + synchronize on both sides, MAX over ranks, median): F = per wavelength '

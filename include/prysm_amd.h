@@ -270,6 +270,14 @@ int pm_embed(int32_t elem_bytes, int64_t irows, int64_t icols, const void* in, i
 int pm_mdft_basis(int32_t dtype, int64_t M, int64_t N, const void* f, const void* x, int32_t sign, void* E,
                   int64_t E_ld, void* stream);
 
+/* The same basis for the FFT-centred grids of dft.coordinates_for_focus (prysm/propagation/dft.py:58-65), generated inside the
+ * kernel instead of read from vectors -- prepare_executor then costs two launches, not a dozen small array operations:
+ *     x[n] = (n - N/2) * x_step                      (fftrange(N) * pupil_dx)
+ *     f[m] = ((m - M/2) * f_step + f_shift) * f_scale   ((fftrange(M) * focal_dx + focal_shift) / (wavelength * efl))
+ * every operation rounded once in the real type of dtype, i.e. bit for bit the vectors numpy builds at config.precision. */
+int pm_mdft_basis_grid(int32_t dtype, int64_t M, int64_t N, double f_step, double f_shift, double f_scale, double x_step,
+                       int32_t sign, void* E, int64_t E_ld, void* stream);
+
 /* C (M x N) = alpha * opA(A) (M x K) @ opB(B) (K x N), complex, on the MFMA matrix cores.
  *   opA: 0 = A, 1 = conj(A), 2 = A^T, 3 = A^H     (A stored M x K for 0/1, K x M for 2/3)
  *   opB: likewise                                   (B stored K x N for 0/1, N x K for 2/3)
@@ -295,7 +303,7 @@ void pm_shutdown(void);            /* free cached tables */
  * path, 0 = off), "blue_2d" / "blue_fuse" (both-axes form; chirp multiplies inside the chain), "big_native_log" (log2 of the longest
  * length given to the engine as it is; the GPU tests lower it to run the 16384-point path on small arrays).  The full list with
  * defaults and measurements: struct Tuning in prysm_amd/csrc/pm_internal.h.  Also read once from the environment:
- * PM_TUNE="col_var=1,nt_in=1". */
+ * PM_TUNE="nt_in=1,fold=0". */
 int pm_set_tuning(const char* key, int32_t value);
 /* time `reps` launches of each pass of the transform with hipEvents on `stream`; ms[0] = row pass,
  * ms[1] = column pass (average per launch).  Used by bench.py for the roofline object. */

@@ -76,6 +76,7 @@ SIGNATURES = {
     'pm_outer': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'pm_embed': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp]),
     'pm_mdft_basis': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    'pm_mdft_basis_grid': (c_i32, [c_i32, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_i32, c_vp, c_i64, c_vp]),
     'pm_cgemm': (c_i32, [c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_f64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                          c_vp, c_sz, c_vp]),
     'pm_cgemm_workspace': (c_sz, [c_i32, c_i64, c_i64, c_i64]),

@@ -450,6 +450,16 @@ def mdft_basis(f, x, sign, cdtype):
     return E
 
 
+def mdft_basis_grid(M, N, f_step, f_shift, f_scale, x_step, sign, cdtype):
+    """E[m, n] = exp(sign 2 pi i f[m] x[n]) for x = fftrange(N) * x_step, f = (fftrange(M) * f_step + f_shift) * f_scale, each
+    rounded in the real type of cdtype as the elementwise array expressions would (pm_mdft_basis_grid)."""
+    lib = L.load()
+    E = torch.empty((M, N), dtype=cdtype, device=L.device())
+    L.check(lib.pm_mdft_basis_grid(L._COMPLEX_CODE[cdtype], M, N, float(f_step), float(f_shift), float(f_scale), float(x_step),
+                                   int(sign), L.ptr(E), E.stride(0), L.stream_ptr()))
+    return E
+
+
 def cgemm(A, B, opA=0, opB=0, alpha=1.0):
     """alpha * op(A) @ op(B) on the MFMA cores.  op: 0 none, 1 conj, 2 transpose, 3 conjugate transpose."""
     lib = L.load()

@@ -119,9 +119,6 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("nt_in")) t.nt_in = v;
     else if (is("nt_out")) t.nt_out = v;
     else if (is("fold")) t.fold = v;
-    else if (is("col_spread")) t.col_spread = v < 0 ? 0 : (v > 12 ? 12 : v);
-    else if (is("col_skew")) t.col_skew = v < 0 ? 0 : (v > 64 ? 64 : v);
-    else if (is("row_skew")) t.row_skew = v < 0 ? 0 : (v > 64 ? 64 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
     else if (is("blue_min")) t.blue_min = v < 0 ? 0 : v;
     else if (is("blue_2d")) t.blue_2d = v ? 1 : 0;
@@ -132,7 +129,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
 Tuning& tuning() {
     static Tuning t = [] {
         Tuning x;
-        const char* e = getenv("PM_TUNE");   // e.g. PM_TUNE="col_var=1,nt_in=1"
+        const char* e = getenv("PM_TUNE");   // e.g. PM_TUNE="nt_in=1,fold=0"
         while (e && *e) {
             const char* eq = strchr(e, '=');
             if (!eq) break;
@@ -144,8 +141,6 @@ Tuning& tuning() {
     }();
     return t;
 }
-
-int tuning_row_var_for_timing() { return tuning().row_var; }
 
 // sibling group of column-pass workgroups: the tiles of one layout-tile row, at most 8
 static int sibling_log_g(int log_k) { return log_k < 1 ? 1 : (log_k > 3 ? 3 : log_k); }
@@ -177,6 +172,7 @@ static void set_input_mode(RowLoadNat<T>& lp, const pm_fft2_desc* d) {
 struct Fft2Plan {
     int logn, logm;       // engine log2 sizes or -1 (direct)
     int tc;               // column-pass tile width when both passes run on the engine, else 0 (natural intermediate)
+    int col_var;          // column-pass tiling (ColCfgSel): 2 = 128 B tiles for the planes of a folded 4096-row complex128 transform
     int log_k;            // layout tile width TL = tc << log_k
     size_t ws_bytes;      // total
     size_t ws_field;      // bytes of intermediate per field (256 B aligned)
@@ -226,7 +222,8 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
             const int f = tuning().fold;
             p.fold = f > 0 || (f < 0 && p.logm >= 12);
         }
-        p.tc = col_tile_width_for(d->dtype, p.fold ? p.logm - 1 : p.logm, tuning().col_var);
+        p.col_var = tuning().col_var >= 0 ? tuning().col_var : ((p.fold && d->dtype == PM_C128 && p.logm == 12) ? 2 : 0);
+        p.tc = col_tile_width_for(d->dtype, p.fold ? p.logm - 1 : p.logm, p.col_var);
         p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 8192 ? 3 : (N >= 4096 ? 2 : 1));   // auto: >= 256 B pieces from 4096 columns
         // folded 4096^2 complex64 (intermediate = 128 MiB, inside the Infinity Cache): 8 KiB row pieces measured 95.0 vs 97.8 us
         // (profiles/r01/tune_log_k.log); every other size / precision measured best with the narrow tiles above
@@ -365,7 +362,7 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
                 int ltc = 0;
                 while ((1 << ltc) < (p.tc << p.log_k)) ++ltc;
                 RowStoreTiled<T> sp{W, rows, ltc, wstride};
-                rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, tuning().row_log_g | (tuning().row_skew << 8), st, nb);
+                rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, tuning().row_log_g, st, nb);
             } else {
                 RowStoreNat<T> sp{W, N, AxisMap{int(N), int(N), 0, 0}, rows, 0, T(1), 0, AxisMap{1, 1, 0, 0}};
                 rc = launch_row_nat<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, 0, st);
@@ -401,7 +398,7 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         cs.ay = AxisMap{H, int(d->out_y.len / 2), int(d->out_y.off / 2), int(d->out_y.shift / 2)};
         cs.bstride = d->out_ld;
         cs.ld = 2 * d->out_ld;
-        return launch_col_tiled<T>(p.logm - 1, tuning().col_var, cl, cs, tw, ntiles, sibling_log_g(p.log_k), st, 2);
+        return launch_col_tiled<T>(p.logm - 1, p.col_var, cl, cs, tw, ntiles, sibling_log_g(p.log_k), st, 2);
     }
     if (p.logm >= 0) {
         const cx<T>* tw = twiddles<T>(M, &err);
@@ -409,13 +406,12 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         if (p.tc) {
             const int ntiles = int((N + p.tc - 1) / p.tc);
             ColLoadTiled<T> cl{W, rows, to_map(d->in_y), ntiles, p.log_k, wstride};
-            return launch_col_tiled<T>(p.logm, tuning().col_var, cl, cs, tw, ntiles, sibling_log_g(p.log_k) | (tuning().col_skew << 8) | (tuning().col_spread << 16),
-                                       st, nb);
+            return launch_col_tiled<T>(p.logm, p.col_var, cl, cs, tw, ntiles, sibling_log_g(p.log_k), st, nb);
         }
-        const int tc = col_tile_width_for(d->dtype, p.logm, tuning().col_var);
+        const int tc = col_tile_width_for(d->dtype, p.logm, 0);
         const int ntiles = int((N + tc - 1) / tc);
         ColLoadNat<T> cl{W, N, to_map(d->in_y), int(N), 0, (N % 2 == 0) ? 1 : 0};
-        return launch_col_nat<T>(p.logm, tuning().col_var, cl, cs, tw, ntiles, 1, st);
+        return launch_col_nat<T>(p.logm, 0, cl, cs, tw, ntiles, 1, st);
     }
     DirectIn<T> di{W, 1, N, to_map(d->in_y), int(N), 0};   // sequence = column c at W[c], element stride N
     if (p.blue_m) return blue_cols<T>(di, cs, static_cast<char*>(ws) + p.blue_off, st);

@@ -150,7 +150,7 @@ struct Dft<T, 16> {
 // ---------------------------------------------------------------------------
 // twiddles of one stage for one thread: W^(4a b0) (a < R/4) and W^(b b0) (b < 4) per butterfly q; the
 // remaining W^((4a+b) b0) are products (one extra rounding).  They depend on the thread slot only, not on
-// the sequence, so a persistent kernel loads them once and keeps them in registers.
+// the sequence.
 // ---------------------------------------------------------------------------
 template <typename C, int S>
 struct StageTw {
@@ -225,7 +225,7 @@ PM_HD void stage_compute(cx<typename C::T> (&v)[C::E][C::P], const StageTw<C, S>
     }
 }
 
-// convenience: load the stage twiddles, then compute (non-persistent kernels, CPU emulation)
+// convenience: load the stage twiddles, then compute
 template <typename C, int S>
 PM_HD void stage_compute(cx<typename C::T> (&v)[C::E][C::P], int t, const cx<typename C::T>* __restrict__ tw) {
     StageTw<C, S> w;
@@ -291,138 +291,7 @@ struct LdsType<FftCfg<T, L, CI, E, BO, 2>> {
     using type = T;
 };
 
-// ---- per-workgroup LDS twiddle table (column pass, complex64) -----------------------------------------
-// Stage S needs NT(S) = 3 + R/4 - 1 table values per distinct (j mod Ns); Ns of them per stage.  For
-// N = 4096 that is (16 + 256) * 6 entries = 13 KiB, placed behind the exchange chunk.  Reading them with
-// ds_read (lgkmcnt) instead of global gathers (vmcnt, L2 latency) matters in the column pass, where one
-// workgroup per CU has nobody to hide a 1 us round trip behind, twice per tile.
-template <typename C, int S>
-struct TwLds {
-    static constexpr int R = C::radix(S), NS = C::ns(S);
-    static constexpr int NT = (S > 0 && R > 1) ? (R == 2 ? 1 : 3 + (R / 4 - 1)) : 0;
-    static constexpr int ENTRIES = (S > 0 && R > 1) ? NS * NT : 0;
-};
-template <typename C, int S = 1>
-constexpr int tw_lds_entries() {
-    if constexpr (S >= C::NSTAGE) return 0;
-    else return TwLds<C, S>::ENTRIES + tw_lds_entries<C, S + 1>();
-}
-template <typename C, int S = 1>
-constexpr int tw_lds_offset(int stage) {   // first entry of `stage` inside the table
-    if constexpr (S >= C::NSTAGE) return 0;
-    else return stage <= S ? 0 : TwLds<C, S>::ENTRIES + tw_lds_offset<C, S + 1>(stage);
-}
-
-// fill: entry (jm, slot) of stage S = W^(mult(slot) * jm * N/(Ns R)); mult = 1,2,3 then 4,8,12,...
-template <typename C, int S = 1>
-PM_HD void fill_tw_lds(cx<typename C::T>* tab, int tid, int nthreads, const cx<typename C::T>* __restrict__ tw) {
-    if constexpr (S < C::NSTAGE) {
-        using TL = TwLds<C, S>;
-        constexpr int R = TL::R, NS = TL::NS, NT = TL::NT;
-        constexpr int off = tw_lds_offset<C>(S);
-        for (int e = tid; e < TL::ENTRIES; e += nthreads) {
-            const int jm = e / NT, slot = e % NT;
-            const int mult = (R == 2) ? 1 : (slot < 3 ? slot + 1 : 4 * (slot - 2));
-            tab[off + e] = tw[mult * jm * (C::N / (NS * R))];
-        }
-        fill_tw_lds<C, S + 1>(tab, tid, nthreads, tw);
-    }
-}
-
-template <typename C, int S>
-PM_HD void load_stage_tw_lds(StageTw<C, S>& w, int t, const cx<typename C::T>* tab) {
-    using TL = TwLds<C, S>;
-    constexpr int R = TL::R, NS = TL::NS, NT = TL::NT, Q = C::P / R, NP = C::TPS;
-    constexpr int off = tw_lds_offset<C>(S);
-    if constexpr (S > 0 && R > 1) {
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int jm = (t + q * NP) & (NS - 1);
-            const cx<typename C::T>* e = tab + off + jm * NT;
-            if constexpr (R == 2) {
-                w.wb[q][1] = e[0];
-            } else {
-#pragma unroll
-                for (int b = 1; b < 4; ++b) w.wb[q][b] = e[b - 1];
-#pragma unroll
-                for (int a = 1; a < R / 4; ++a) w.wa[q][a] = e[2 + a];
-            }
-        }
-    }
-}
-
-// twiddles of every stage of a transform (stage 0 has none)
-template <typename C, int S = 1, bool END = (S >= C::NSTAGE)>
-struct TwSet {
-    StageTw<C, S> w;
-    TwSet<C, S + 1> rest;
-};
-template <typename C, int S>
-struct TwSet<C, S, true> {};
-
-template <typename C, int S = 1>
-PM_HD void load_tw_set(TwSet<C, S>& ts, int t, const cx<typename C::T>* __restrict__ tw) {
-    if constexpr (S < C::NSTAGE) {
-        load_stage_tw<C, S>(ts.w, t, tw);
-        load_tw_set<C, S + 1>(ts.rest, t, tw);
-    }
-}
-
 #if defined(__HIPCC__)
-// transform with preloaded twiddles (persistent kernels): no global loads inside, so the only vmcnt waits in
-// the loop body belong to the data loads of the NEXT sequence, which stay in flight under this transform
-template <typename C, int S = 0, typename TS>
-__device__ __forceinline__ void fft_run_tw(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw, const TS& ts) {
-    using LT = typename LdsType<C>::type;
-    LT* lds = reinterpret_cast<LT*>(lds_raw);
-    if constexpr (S == 0) {
-        StageTw<C, 0> none;
-        stage_compute<C, 0>(v, none);
-    } else {
-        stage_compute<C, S>(v, ts.w);
-    }
-    if constexpr (S + 1 < C::NSTAGE) {
-#pragma unroll
-        for (int e = 0; e < C::E; ++e) {
-#pragma unroll
-            for (int comp = 0; comp < C::COMP; ++comp) {
-                exch_write<C, S>(v, e, comp, pos, lds);
-                __syncthreads();
-                exch_read<C>(v, e, comp, pos, lds);
-                __syncthreads();
-            }
-        }
-        if constexpr (S == 0)
-            fft_run_tw<C, 1>(v, pos, lds_raw, ts);
-        else
-            fft_run_tw<C, S + 1>(v, pos, lds_raw, ts.rest);
-    }
-}
-
-// transform whose stage twiddles come from the workgroup's LDS table (filled by fill_tw_lds + barrier)
-template <typename C, int S = 0>
-__device__ __forceinline__ void fft_run_twlds(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw,
-                                              const cx<typename C::T>* tab) {
-    using LT = typename LdsType<C>::type;
-    LT* lds = reinterpret_cast<LT*>(lds_raw);
-    StageTw<C, S> w;
-    if constexpr (S > 0) load_stage_tw_lds<C, S>(w, pos.t, tab);
-    stage_compute<C, S>(v, w);
-    if constexpr (S + 1 < C::NSTAGE) {
-#pragma unroll
-        for (int e = 0; e < C::E; ++e) {
-#pragma unroll
-            for (int comp = 0; comp < C::COMP; ++comp) {
-                exch_write<C, S>(v, e, comp, pos, lds);
-                __syncthreads();
-                exch_read<C>(v, e, comp, pos, lds);
-                __syncthreads();
-            }
-        }
-        fft_run_twlds<C, S + 1>(v, pos, lds_raw, tab);
-    }
-}
-
 // full transform of the registers of this thread; all threads of the workgroup must call it
 template <typename C, int S = 0>
 __device__ __forceinline__ void fft_run(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw,
@@ -450,8 +319,8 @@ __device__ __forceinline__ void fft_run(cx<typename C::T> (&v)[C::E][C::P], Thre
 // instead of in front of a barrier.  Same arithmetic and the same number of barriers as fft_run.
 //   invariant on entry to stage S > 0: v[0] is exchanged and ready for stage S; v[1] holds the un-exchanged
 //   output of stage S - 1.
-// With PM_TW_PREFETCH the twiddles of stage S + 1 are requested at the START of stage S (one stage ahead), so their L2
-// round trip runs under the butterflies and the exchange of stage S.
+// The twiddles of stage S + 1 are requested after the exchange of stage S (requesting them a stage ahead measured equal at 2048^2 ..
+// 8192^2 and costs ~12 VGPRs: 8192-point rows would drop to 3 waves / SIMD).
 template <typename C, int S>
 __device__ __forceinline__ void fft_run_pipe2_stage(cx<typename C::T> (&v)[C::E][C::P], ThreadPos pos, void* lds_raw,
                                                     const cx<typename C::T>* __restrict__ tw, const StageTw<C, S>& w) {
@@ -459,12 +328,6 @@ __device__ __forceinline__ void fft_run_pipe2_stage(cx<typename C::T> (&v)[C::E]
     LT* lds = reinterpret_cast<LT*>(lds_raw);
     constexpr int SN = (S + 1 < C::NSTAGE) ? S + 1 : S;
     StageTw<C, SN> wn;
-#ifdef PM_TW_PREFETCH
-    constexpr bool kAhead = true;    // A/B builds (make EXTRA=-DPM_TW_PREFETCH): request the twiddles one stage ahead.
-#else                                // Measured equal within noise at 2048^2 / 4096^2 / 8192^2 and it costs ~12 VGPRs
-    constexpr bool kAhead = false;   // (8192-point rows drop to 3 waves / SIMD), so the default requests them in-stage.
-#endif
-    if constexpr (kAhead && S + 1 < C::NSTAGE) load_stage_tw<C, SN>(wn, pos.t, tw);
     if constexpr (S == 0) {
         stage_compute<C, 0, 0, 1>(v, w);
         if constexpr (C::NSTAGE == 1) {
@@ -475,7 +338,7 @@ __device__ __forceinline__ void fft_run_pipe2_stage(cx<typename C::T> (&v)[C::E]
             __syncthreads();
             exch_read<C>(v, 0, 0, pos, lds);
             __syncthreads();
-            if constexpr (!kAhead) load_stage_tw<C, SN>(wn, pos.t, tw);
+            load_stage_tw<C, SN>(wn, pos.t, tw);
             fft_run_pipe2_stage<C, 1>(v, pos, lds_raw, tw, wn);
         }
     } else {
@@ -490,7 +353,7 @@ __device__ __forceinline__ void fft_run_pipe2_stage(cx<typename C::T> (&v)[C::E]
             __syncthreads();
             exch_read<C>(v, 0, 0, pos, lds);
             __syncthreads();
-            if constexpr (!kAhead) load_stage_tw<C, SN>(wn, pos.t, tw);
+            load_stage_tw<C, SN>(wn, pos.t, tw);
             fft_run_pipe2_stage<C, S + 1>(v, pos, lds_raw, tw, wn);
         } else {
             stage_compute<C, S, 1, 2>(v, w);   // no trailing barrier: callers that reuse the LDS synchronise themselves

@@ -80,10 +80,13 @@ inline int col_tile_width_for(int dtype, int logm, int var) {
     return ci * (dtype == PM_C64 ? 2 : 1);
 }
 
-// runtime tuning knobs (capi.hip): PM_TUNE="col_var=1,row_var=0,nt_in=1,nt_out=1" or pm_set_tuning()
+// runtime tuning knobs (capi.hip): PM_TUNE="row_var=0,nt_in=1,nt_out=1" or pm_set_tuning().  They choose among equivalent tilings
+// and routes that each ship for some size / precision; one-off experiments live in tools/ (exp_*.cpp, exp_*.py), not here.
 struct Tuning {
-    int col_var = 0;
-    int row_var = -1;   // row-pass variant: 0 plain, 1 half-LDS (re/im exchanged separately), 2 persistent double-buffered, -1 auto
+    int col_var = -1;   // column-pass tiling (ColCfgSel): 0 64 B tiles, 2 128 B tiles for 2048-point columns, -1 auto (2 for the planes of a
+                        // folded 4096-row complex128 transform)
+    int row_var = -1;   // row-pass tiling (RowCfgSel): 0 plain, 1 half-LDS (re / im exchanged separately), 4 two rows per thread, 5 one row
+                        // per workgroup, -1 auto (row_variant() below)
     // non-temporal input loads / output stores: 0 off, 1 on, -1 auto (by array size vs the 256 MiB
     // Infinity Cache: measured on MI355X, streaming hints pay once the arrays no longer fit beside the
     // intermediate -- input from ~128 MiB, output from ~256 MiB; they cost a few % below that)
@@ -100,9 +103,6 @@ struct Tuning {
     int gemm_min_wgs = 1024;   // split K until the GEMM launch has at least this many workgroups
     int row_log_g = 1;  // sibling group of row-pass workgroups (rows q .. q+2^g-1 on one XCD)
     int fold = -1;           // radix-2 step of the column transform folded into the row pass: -1 auto, 0 never, 1 wherever legal
-    int col_spread = 0;      // experiment: log2 of the stride permutation of column-pass sibling groups
-    int row_skew = 0;        // experiment: the same for the row pass
-    int col_skew = 0;        // experiment: start skew of every other column-pass workgroup, units of ~0.85 us
     int blue_min = 96;        // shortest non-power-of-two length that takes the Bluestein path (shorter ones, and lengths
                              // above 4096, run on the direct O(n^2) kernel); 0 disables the path
     int blue_fuse = 1;        // both-axes form on engine lengths: chirp multiplies inside the chain's first load / last store (1)
@@ -115,9 +115,7 @@ struct Tuning {
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)
 };
 Tuning& tuning();
-// measured on MI355X (profiles/r01/sweep*.log): with predicate-free full-window loads the plain row kernel is
-// the fastest at 4096 points (58 us vs 65-70 us persistent); the half-LDS variant wins for 2048-point rows
-// (complex128: 24.6 vs 30.5 us).  The persistent double-buffered kernel stays available as row_var = 2.
+// measured on MI355X (profiles/r01/sweep*.log): the half-LDS variant wins for complex128 rows of 2048 points (24.6 vs 30.5 us)
 inline int row_variant(int dtype, int logn) {
     const int v = tuning().row_var;
     if (v >= 0) return v;

@@ -353,6 +353,33 @@ __global__ void mdft_basis_kernel(int64_t M, int64_t N, const T* f, const T* x, 
     }
 }
 
+// rounded-once products / sums in T: hipcc contracts a * b + c into an fma by default (and HIP's __fmul_rn is a plain product that
+// contracts just the same after inlining), but the grids must equal the vectors torch / numpy build operation by operation
+template <typename T> __device__ __forceinline__ T mul_rn(T a, T b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+template <typename T> __device__ __forceinline__ T add_rn(T a, T b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+
+// the same basis with both vectors given as FFT-centred grids, built in the kernel exactly as coordinates_for_focus builds them:
+//   x[n] = (n - N/2) * x_step,   f[m] = ((m - M/2) * f_step + f_shift) * f_scale,   every operation rounded in T
+template <typename T>
+__global__ void mdft_basis_grid_kernel(int64_t M, int64_t N, T f_step, T f_shift, T f_scale, T x_step, double sign, cx<T>* E, int64_t ldE) {
+#pragma clang fp contract(off)
+    const int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double xv = double(mul_rn(T(n - N / 2), x_step));
+    for (int64_t m = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; m < M; m += int64_t(gridDim.y) * blockDim.y) {
+        const T fv = mul_rn(add_rn(mul_rn(T(m - M / 2), f_step), f_shift), f_scale);
+        double s, co;
+        sincos_turns(sign * double(fv) * xv, &s, &co);
+        E[m * ldE + n] = {T(co), T(s)};
+    }
+}
+
 }  // namespace pm
 
 using namespace pm;
@@ -623,6 +650,23 @@ int pm_mdft_basis(int32_t dtype, int64_t M, int64_t N, const void* f, const void
         hipLaunchKernelGGL(mdft_basis_kernel<double>, grid, block, 0, PM_STREAM(stream), M, N, (const double*)f, (const double*)x, double(sign), (cx<double>*)E, E_ld);
     else
         return fail(PM_ERR_ARG, "pm_mdft_basis: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
+}
+
+int pm_mdft_basis_grid(int32_t dtype, int64_t M, int64_t N, double f_step, double f_shift, double f_scale, double x_step,
+                       int32_t sign, void* E, int64_t E_ld, void* stream) {
+    if (!E || M < 0 || N < 0 || (sign != 1 && sign != -1)) return fail(PM_ERR_ARG, "pm_mdft_basis_grid: bad argument");
+    if (M == 0 || N == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(M, N, block);
+    if (dtype == PM_C64)
+        hipLaunchKernelGGL(mdft_basis_grid_kernel<float>, grid, block, 0, PM_STREAM(stream), M, N, float(f_step), float(f_shift),
+                           float(f_scale), float(x_step), double(sign), (cx<float>*)E, E_ld);
+    else if (dtype == PM_C128)
+        hipLaunchKernelGGL(mdft_basis_grid_kernel<double>, grid, block, 0, PM_STREAM(stream), M, N, f_step, f_shift, f_scale, x_step,
+                           double(sign), (cx<double>*)E, E_ld);
+    else
+        return fail(PM_ERR_ARG, "pm_mdft_basis_grid: dtype must be PM_C64 or PM_C128");
     return int(hipGetLastError());
 }
 

@@ -123,6 +123,22 @@ class MDFT:
         self._forward_left_first = My * Nx * (Ny + Mx) <= Ny * Mx * (Nx + My)
         self._adjoint_left_first = Ny * Mx * (My + Nx) <= My * Nx * (Mx + Ny)
 
+    @classmethod
+    def _for_focus_grids(cls, pupil_samples, focal_samples, pupil_dx, focal_dx, focal_shift, inv_lz, rdtype, sign, norm):
+        """The operator prepare_executor builds -- MDFT(*coordinates_for_focus(...)) -- without materialising the four coordinate
+        vectors: the bases are generated from the grid parameters (pm_mdft_basis_grid), bit for bit the same matrices."""
+        pny, pnx = pupil_samples
+        fny, fnx = focal_samples
+        fsx, fsy = focal_shift
+        cd = L._COMPLEX_OF[rdtype]
+        self = cls.__new__(cls)
+        self.Ex = _ops.mdft_basis_grid(fnx, pnx, focal_dx, fsx, inv_lz, pupil_dx, sign, cd)
+        self.Ey = _ops.mdft_basis_grid(fny, pny, focal_dx, fsy, inv_lz, pupil_dx, sign, cd)
+        self.norm = norm
+        self._forward_left_first = fny * pnx * (pny + fnx) <= pny * fnx * (pnx + fny)
+        self._adjoint_left_first = pny * fnx * (fny + pnx) <= fny * pnx * (fnx + pny)
+        return self
+
     def _cast(self, ary):
         a = _promote_input(ary, self.Ex.dtype)
         if a.dtype != self.Ex.dtype:   # complex128 data through float32 bases: numpy promotes the bases

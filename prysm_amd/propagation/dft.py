@@ -42,12 +42,20 @@ def prepare_executor(pupil_dx, pupil_samples, focal_dx, focal_samples,
     norm = pupil_dx * focal_dx / (wavelength * efl) is baked into the executor; pupil_dx and
     focal_dx are stashed on it.  executor(pupil) focuses, executor.adjoint(focal) unfocuses.
     """
-    x, y, fx, fy = coordinates_for_focus(pupil_dx, pupil_samples, focal_dx, focal_samples,
-                                         wavelength, efl, focal_shift)
     norm = (pupil_dx * focal_dx) / (wavelength * efl)
     if kind == 'mdft':
-        op = MDFT(x, y, fx, fy, sign=-1, norm=norm)
-    elif kind == 'czt':
+        # MDFT(*coordinates_for_focus(...)) with the coordinate grids generated inside the basis kernel (two launches per
+        # executor instead of a dozen small array operations -- the polychromatic recipe builds one executor per wavelength)
+        ps = pupil_samples if isinstance(pupil_samples, Iterable) else (pupil_samples, pupil_samples)
+        fs = focal_samples if isinstance(focal_samples, Iterable) else (focal_samples, focal_samples)
+        op = MDFT._for_focus_grids(tuple(int(v) for v in ps), tuple(int(v) for v in fs), pupil_dx, focal_dx, focal_shift,
+                                   1.0 / (wavelength * efl), L.torch_dtype(config.precision), -1, norm)
+        op.pupil_dx = pupil_dx
+        op.focal_dx = focal_dx
+        return op
+    x, y, fx, fy = coordinates_for_focus(pupil_dx, pupil_samples, focal_dx, focal_samples,
+                                         wavelength, efl, focal_shift)
+    if kind == 'czt':
         op = CZT(x, y, fx, fy, sign=-1, norm=norm)
     elif kind == 'fftdft':
         op = FFTDFT(x, y, fx, fy, sign=-1, norm=norm)

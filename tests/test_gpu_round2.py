@@ -239,6 +239,27 @@ def test_multiresolution_fpm_grad_matches_fd(pa):
     assert float(np.real(tonp(fpm_bars[k])[iy, ix])) == pytest.approx(fd, rel=1e-6, abs=1e-8)
 
 
+def test_prepare_executor_grid_bases_equal_vector_bases(pa):
+    """prepare_executor(kind='mdft') generates the bases from the grid parameters (pm_mdft_basis_grid); MDFT(x, y, fx, fy) of the
+    coordinate vectors is the reference construction (prysm/propagation/dft.py:97-105, fttools.py:187-191): identical matrices"""
+    from prysm_amd.conf import config
+    from prysm_amd.fttools import MDFT
+    P = pa.propagation
+    prec = config.precision
+    try:
+        for precision in (32, 64):
+            config.precision = precision
+            for args in ((10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0, (0, 0)),
+                         (0.05, (96, 130), 0.7, (33, 64), 0.55, 80.0, (0.35, -1.25))):
+                ex = P.prepare_executor(*args[:6], focal_shift=args[6])
+                ref = MDFT(*P.coordinates_for_focus(*args[:6], focal_shift=args[6]), sign=-1, norm=ex.norm)
+                assert ex.Ex.dtype == ref.Ex.dtype and torch.equal(ex.Ex, ref.Ex) and torch.equal(ex.Ey, ref.Ey)
+                assert (ex._forward_left_first, ex._adjoint_left_first) == (ref._forward_left_first, ref._adjoint_left_first)
+                assert ex.pupil_dx == args[0] and ex.focal_dx == args[2]
+    finally:
+        config.precision = prec
+
+
 # ----------------------------------------------------------------------------- ADVICE r1
 
 def test_babinet_takes_a_boolean_occulter(pa):

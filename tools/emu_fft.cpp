@@ -480,40 +480,6 @@ static void test_fused_fold(int in_cols, int out_rows, int out_cols, int log_k, 
     report(buf, err / nrm, sizeof(T) == 4 ? 5e-6 : 1e-13);
 }
 
-// --- LDS twiddle table of the column kernel == the global-table twiddles, every stage, every thread slot ----
-template <typename C, int S>
-static int cmp_tw_stage(const cx<typename C::T>* tab, const cx<typename C::T>* tw) {
-    int bad = 0;
-    if constexpr (S < C::NSTAGE) {
-        constexpr int R = C::radix(S), Q = C::P / R;
-        for (int t = 0; t < C::TPS; ++t) {
-            StageTw<C, S> a, b;
-            load_stage_tw<C, S>(a, t, tw);
-            load_stage_tw_lds<C, S>(b, t, tab);
-            for (int q = 0; q < Q; ++q) {
-                if (R == 2) bad += (a.wb[q][1].x != b.wb[q][1].x) || (a.wb[q][1].y != b.wb[q][1].y);
-                else {
-                    for (int k = 1; k < 4; ++k) bad += (a.wb[q][k].x != b.wb[q][k].x) || (a.wb[q][k].y != b.wb[q][k].y);
-                    for (int k = 1; k < R / 4; ++k) bad += (a.wa[q][k].x != b.wa[q][k].x) || (a.wa[q][k].y != b.wa[q][k].y);
-                }
-            }
-        }
-        bad += cmp_tw_stage<C, S + 1>(tab, tw);
-    }
-    return bad;
-}
-template <typename T, int LOGN>
-static void test_tw_lds() {
-    using C = FftCfg<T, LOGN, 4, 2, 1, 1>;
-    auto tw = make_tw<T>(C::N);
-    std::vector<cx<T>> tab(tw_lds_entries<C>() + 1);
-    fill_tw_lds<C>(tab.data(), 0, 1, tw.data());
-    const int bad = cmp_tw_stage<C, 1>(tab.data(), tw.data());
-    char buf[96];
-    snprintf(buf, sizeof buf, "LDS twiddle table N=%d entries=%d", C::N, tw_lds_entries<C>());
-    report(buf, double(bad), 0.5);
-}
-
 // --- Bluestein (bluestein.h / bluestein.hip): a non-power-of-two length n through engine transforms of length MB.  Rows run
 // the emulated engine passes with exactly the load / store descriptors blue_rows builds; columns restate the natural column
 // pass by its contract (pad window on the load, crop window on the store, conj-in / conj-out inverse) --------------------
@@ -797,11 +763,6 @@ int main() {
     test_blue_cols<float>(100, 6, 100, 0, 50, 100, 0, 50, 0);
     test_blue_cols<float>(97, 5, 40, 29, 48, 60, 18, 48, 1);            // padded rows, crop, |.|^2
     test_blue_cols<double>(150, 3, 150, 0, 0, 150, 0, 75, 0);
-    test_tw_lds<float, 5>();
-    test_tw_lds<float, 8>();
-    test_tw_lds<float, 11>();
-    test_tw_lds<float, 12>();
-    test_tw_lds<float, 13>();
     // rows: every stage structure (P<16, single stage, 16x2, 16x16, 16x16x8, 16^3, 16^3x2)
     test_row<float, 1, 256, 1>(300, 2, 0, 0, 0, false);
     test_row<float, 3, 256, 1>(5, 8, 0, 0, 0, false);

@@ -104,14 +104,18 @@ def fuzz_gemm(ncases, rng, lib):
     opf = {0: lambda z: z, 1: np.conj, 2: lambda z: z.T, 3: lambda z: z.conj().T}
     for case in range(ncases):
         big = rng.random() < 0.2
+        dma = (not big) and rng.random() < 0.3     # the LDS-DMA kernel's shapes: multiples of 64 x 64 x 16, both tile sizes, split or not
         M, N, K = (int(rng.choice([64, 128, 512, 1000])), int(rng.choice([64, 300, 2048])), int(rng.choice([512, 2048, 3000]))) if big else \
-                  (int(rng.integers(1, 200)), int(rng.integers(1, 200)), int(rng.integers(1, 300)))
+                  ((64 * int(rng.integers(1, 6)), 64 * int(rng.integers(1, 6)), 16 * int(rng.integers(1, 40))) if dma else
+                   (int(rng.integers(1, 200)), int(rng.integers(1, 200)), int(rng.integers(1, 300))))
+        lib.pm_set_tuning(b'gemm_tile', int(rng.choice([0, 64, 128])))
+        lib.pm_set_tuning(b'gemm_dma_wgs', int(rng.choice([1, 64, 512])))
         cdt = np.complex64 if rng.random() < 0.5 else np.complex128
         opA, opB = int(rng.integers(0, 4)), int(rng.integers(0, 4))
         alpha = float(rng.choice([1.0, 0.37]))
         lib.pm_set_tuning(b'gemm_min_wgs', int(rng.choice([1, 1024])))
         lib.pm_set_tuning(b'gemm_3m', int(rng.choice([0, 1])))
-        pad = int(rng.choice([0, 0, 3]))       # leading dimension larger than the row
+        pad = int(rng.choice([0, 0, 3, 4]))    # leading dimension larger than the row (an odd one keeps complex64 off the DMA kernel)
         sa = (K, M) if opA & 2 else (M, K)
         sb = (N, K) if opB & 2 else (K, N)
         A = (rng.standard_normal((sa[0], sa[1] + pad)) + 1j * rng.standard_normal((sa[0], sa[1] + pad))).astype(cdt)
@@ -133,6 +137,8 @@ def fuzz_gemm(ncases, rng, lib):
             print('gemm case', case, 'FAIL err', err, (M, N, K, opA, opB, cdt.__name__, pad))
     lib.pm_set_tuning(b'gemm_min_wgs', 1024)
     lib.pm_set_tuning(b'gemm_3m', 1)
+    lib.pm_set_tuning(b'gemm_tile', 0)
+    lib.pm_set_tuning(b'gemm_dma_wgs', 512)
     print(f'fuzz_gemm: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
     return nfail
 

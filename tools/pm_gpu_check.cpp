@@ -509,7 +509,7 @@ static void sweep_fft2(int64_t n, const std::vector<Knobs>& cfgs, int rounds) {
 // generic interleaved A/B: "tune N c64|c128 rounds cfg cfg ..." with cfg = "key=val,key=val" (pm_set_tuning keys; keys not
 // named in a cfg are reset to their defaults first)
 static void set_cfg(const std::string& cfg) {
-    static const char* defaults = "row_var=-1,col_var=0,nt_in=-1,nt_out=-1,log_k=-1,row_log_g=1,col_skew=0,row_skew=0,col_spread=0,fold=-1";
+    static const char* defaults = "row_var=-1,col_var=-1,nt_in=-1,nt_out=-1,log_k=-1,row_log_g=1,fold=-1";
     for (const std::string& src : {std::string(defaults), cfg}) {
         size_t i = 0;
         while (i < src.size()) {
