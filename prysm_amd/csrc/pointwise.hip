@@ -368,7 +368,6 @@ template <typename T> __device__ __forceinline__ T add_rn(T a, T b) {
 //   x[n] = (n - N/2) * x_step,   f[m] = ((m - M/2) * f_step + f_shift) * f_scale,   every operation rounded in T
 template <typename T>
 __global__ void mdft_basis_grid_kernel(int64_t M, int64_t N, T f_step, T f_shift, T f_scale, T x_step, double sign, cx<T>* E, int64_t ldE) {
-#pragma clang fp contract(off)
     const int64_t n = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const double xv = double(mul_rn(T(n - N / 2), x_step));
