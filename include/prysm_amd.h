@@ -52,7 +52,9 @@ enum {
 enum {
     PM_EPI_NONE = 0,       /* complex output */
     PM_EPI_ABS2 = 1,       /* real output  |scale * X|^2           (Wavefront.intensity fused) */
-    PM_EPI_ABS2_ACCUM = 2  /* real output  out += weight*|scale*X|^2 (incoherent polychromatic sum) */
+    PM_EPI_ABS2_ACCUM = 2, /* real output  out += weight*|scale*X|^2 (incoherent polychromatic sum) */
+    PM_EPI_ABS = 3,        /* real output  |scale * X|    (otf.mtf_from_psf, prysm/otf.py:77-103)  -- real-input transforms only */
+    PM_EPI_ARG = 4         /* real output  angle(scale*X) (otf.ptf_from_psf, prysm/otf.py:106-135) -- real-input transforms only */
 };
 
 /* multiplier applied to the complex result before it is stored */
@@ -66,10 +68,16 @@ enum {
                              * synthesised while the row pass loads it -- Wavefront.from_amp_and_phase
                              * (prysm/propagation/wavefront.py:58-79) fused into focus: the complex pupil never exists in
                              * memory.  PM_C64 with power-of-two row lengths only (PM_ERR_UNSUPPORTED otherwise). */
+    PM_FLAG_NORM_DC = 16,   /* divide the result by its DC bin X[0][0] before the epilogue -- the centre normalisation
+                             * `data / data[cy, cx]` of the OTF routines (prysm/otf.py:62-74).  Real-input transforms on the
+                             * Hermitian path only (see PM_FLAG_REAL_INPUT), where that bin is real; PM_ERR_UNSUPPORTED otherwise */
     PM_FLAG_REAL_INPUT = 4  /* `in` is a REAL array of the precision that goes with dtype (float / double); in_ld and
                              * in_bstride count real elements.  fft2 of a real PSF / object / actuator map
                              * (prysm/otf.py:31, prysm/convolution.py:27-28,82-85) without a complex copy: pass 1 reads
-                             * half the bytes */
+                             * half the bytes.  A FORWARD transform of an unpadded real field with power-of-two lengths (>= 32
+                             * per row) and an unwindowed output takes the Hermitian path: half-length row transforms, N/2 + 1
+                             * columns through the column pass, each result stored twice (at (u, k) and, conjugated, at
+                             * (-u, -k)); PM_EPI_ABS / PM_EPI_ARG / PM_FLAG_NORM_DC exist on that path */
 };
 
 /* One axis of a windowed, rotated view.  A logical (transform-sized) axis of

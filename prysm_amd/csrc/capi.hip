@@ -11,6 +11,7 @@
 
 #include "bluestein.h"
 #include "pm_internal.h"
+#include "fft_r2c_types.h"
 
 namespace pm {
 
@@ -119,6 +120,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("nt_in")) t.nt_in = v;
     else if (is("nt_out")) t.nt_out = v;
     else if (is("fold")) t.fold = v;
+    else if (is("r2c")) t.r2c = v < 0 ? -1 : (v > 1 ? 2 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
     else if (is("blue_min")) t.blue_min = v < 0 ? 0 : v;
     else if (is("blue_2d")) t.blue_2d = v ? 1 : 0;
@@ -172,6 +174,7 @@ static void set_input_mode(RowLoadNat<T>& lp, const pm_fft2_desc* d) {
 struct Fft2Plan {
     int logn, logm;       // engine log2 sizes or -1 (direct)
     int tc;               // column-pass tile width when both passes run on the engine, else 0 (natural intermediate)
+    bool r2c;             // real input on the Hermitian path (fft_r2c.h): N/2-point row transforms, N/2 + 1 columns, mirrored stores
     int col_var;          // column-pass tiling (ColCfgSel): 2 = 128 B tiles for the planes of a folded 4096-row complex128 transform
     int log_k;            // layout tile width TL = tc << log_k
     size_t ws_bytes;      // total
@@ -202,6 +205,23 @@ static bool fold_legal(const pm_fft2_desc* d, int logn, int logm) {
            d->batch <= 1 && (d->out_ld % 2) == 0;
 }
 
+// Hermitian path (fft_r2c.h): a FORWARD transform of an unpadded real field, both lengths on the engine (rows of at least 32
+// samples), rotations by 0 or half a length, an output that keeps every bin, no multiplier, one field.
+static bool r2c_legal(const pm_fft2_desc* d, int logn, int logm) {
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    if (!(d->flags & PM_FLAG_REAL_INPUT) || (d->flags & (PM_FLAG_SYNTH_INPUT | PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY))) return false;
+    if (tuning().r2c == 0 || d->direction != -1 || logn < 5 || logm < 1 || d->batch > 1 || d->mul_kind != PM_MUL_NONE) return false;
+    // Measured (profiles/r02/exp_r2c.log): with a real epilogue or the centre normalisation the Hermitian path is 2.5x faster than
+    // transform + elementwise sweeps (4096^2 fp32 MTF 105 vs 268 us); for a plain complex spectrum its column pass -- half the
+    // tiles, each storing every bin twice, one 1024-thread workgroup per CU with nothing to overlap -- loses to the complex path
+    // that only READS the real array (111 vs 101 us), so that case stays there unless the knob r2c = 2 forces it.
+    if (tuning().r2c < 2 && d->epilogue == PM_EPI_NONE && !(d->flags & PM_FLAG_NORM_DC)) return false;
+    if (d->dtype == PM_C128 && logn > 12) return false;     // complex128 rows of 4096 complex points exchange re / im separately
+    if (d->in_y.len != M || d->in_x.len != N || d->out_y.len != M || d->out_x.len != N) return false;
+    if (!(d->in_x.shift == 0 || d->in_x.shift == N / 2) || (d->in_ld % 2) != 0) return false;
+    return true;
+}
+
 static int64_t batch_chunk(int64_t nb, size_t ws_field) {
     const size_t budget = size_t(tuning().batch_ws_mib) << 20;
     int64_t c = int64_t(budget / (ws_field ? ws_field : 1));
@@ -217,7 +237,15 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     const size_t es = d->dtype == PM_C64 ? 8 : 16;
     const int64_t rows = d->in_y.len;   // only stored input rows are transformed in pass 1
     p.fold = false;
-    if (p.logn >= 0 && p.logm >= 0) {
+    p.r2c = p.logn >= 0 && p.logm >= 0 && r2c_legal(d, p.logn, p.logm);
+    if (p.r2c) {
+        p.col_var = 0;
+        p.tc = col_tile_width_for(d->dtype, p.logm, 0);
+        p.log_k = tuning().log_k >= 0 ? tuning().log_k : 2;
+        while (p.log_k > 0 && ((N / 2) % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
+        const int64_t nc = N / 2, tl = int64_t(p.tc) << p.log_k;
+        p.ws_bytes = size_t((nc + tl - 1) / tl) * size_t(M) * size_t(tl) * es;
+    } else if (p.logn >= 0 && p.logm >= 0) {
         if (fold_legal(d, p.logn, p.logm)) {
             const int f = tuning().fold;
             p.fold = f > 0 || (f < 0 && p.logm >= 12);
@@ -338,6 +366,33 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
     const bool run1 = !(d->flags & PM_FLAG_PASS2_ONLY), run2 = !(d->flags & PM_FLAG_PASS1_ONLY);
     if (p.big_rn) return big2d_run<T>(d, p, in, out, ws, st);
     if (p.blue2d) return blue2d_run<T>(d, p, in, out, ws, st);
+    if (p.r2c) {
+        // rows: the real array read as N/2 complex points per row -> N/2 columns of the tiled intermediate (column 0 = X[0] + i X[N/2])
+        const int64_t n2 = N / 2, tl = int64_t(p.tc) << p.log_k;
+        int ltl = 0;
+        while ((int64_t(1) << ltl) < tl) ++ltl;
+        const cx<T>* tw2 = twiddles<T>(n2, &err);
+        if (!tw2) return err;
+        const cx<T>* twn = twiddles<T>(N, &err);
+        if (!twn) return err;
+        const cx<T>* twm = twiddles<T>(M, &err);
+        if (!twm) return err;
+        const size_t in_bytes = size_t(M) * size_t(N) * sizeof(T);
+        RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld / 2, AxisMap{int(n2), int(n2), 0, int(d->in_x.shift / 2)}, int(M), 0,
+                         tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0), 0};
+        R2CRowStore<T> rs{W, int(M), ltl, twn};
+        int rc = launch_row_r2c<T>(p.logn - 1, lp, rs, tw2, int(M), tuning().row_log_g, st);
+        if (rc) return rc < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: no Hermitian row kernel for %lld points", (long long)N) : rc;
+        // columns: M-point transforms of the N/2 columns, each bin stored at (u, k) and conjugated at (-u, -k)
+        const int ntiles = int((n2 + p.tc - 1) / p.tc);
+        ColLoadTiled<T> cl{W, int(M), to_map(d->in_y), ntiles, p.log_k, 0};
+        HermStore<T> hs{out, d->out_ld, to_map(d->out_y), to_map(d->out_x), int(M), int(N), d->epilogue, T(d->scale), T(d->weight),
+                        (d->flags & PM_FLAG_NORM_DC) ? 1 : 0, W, tl, int(M), 0};
+        const size_t oes = d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T);
+        hs.fast = (d->out_y.shift == 0 || d->out_y.shift == M / 2) && (d->out_x.shift == 0 || d->out_x.shift == N / 2) &&
+                  (N % (2 * p.tc)) == 0 && (d->out_ld % 2) == 0 && reinterpret_cast<uintptr_t>(out) % (2 * oes) == 0;
+        return launch_col_herm<T>(p.logm, cl, hs, twm, ntiles, sibling_log_g(p.log_k), st);
+    }
 
     // ---- pass 1: one transform of length N per STORED input row (all-zero padded rows are skipped)
     if (run1 && rows > 0) {
@@ -785,7 +840,11 @@ static int check_fft2(const pm_fft2_desc* d) {
     if (!d) return fail(PM_ERR_ARG, "pm_fft2: null descriptor");
     if (d->dtype != PM_C64 && d->dtype != PM_C128) return fail(PM_ERR_ARG, "pm_fft2: dtype must be PM_C64 or PM_C128");
     if (d->direction != 1 && d->direction != -1) return fail(PM_ERR_ARG, "pm_fft2: direction must be -1 or +1");
-    if (d->epilogue < PM_EPI_NONE || d->epilogue > PM_EPI_ABS2_ACCUM) return fail(PM_ERR_ARG, "pm_fft2: bad epilogue");
+    if (d->epilogue < PM_EPI_NONE || d->epilogue > PM_EPI_ARG) return fail(PM_ERR_ARG, "pm_fft2: bad epilogue");
+    if ((d->epilogue > PM_EPI_ABS2_ACCUM || (d->flags & PM_FLAG_NORM_DC)) &&
+        !r2c_legal(d, engine_log2(d->in_x.n), engine_log2(d->in_y.n)))
+        return fail(PM_ERR_UNSUPPORTED, "pm_fft2: PM_EPI_ABS / PM_EPI_ARG / PM_FLAG_NORM_DC exist on the Hermitian path only (a forward "
+                    "transform of an unpadded real field with power-of-two lengths and an unwindowed output)");
     if (d->mul_kind < PM_MUL_NONE || d->mul_kind > PM_MUL_SEPARABLE) return fail(PM_ERR_ARG, "pm_fft2: bad mul_kind");
     if (d->mul_kind != PM_MUL_NONE && !d->mul) return fail(PM_ERR_ARG, "pm_fft2: mul is null");
     if (d->mul_kind == PM_MUL_SEPARABLE && !d->mul_x) return fail(PM_ERR_ARG, "pm_fft2: mul_x is null");

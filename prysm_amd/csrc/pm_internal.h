@@ -102,6 +102,8 @@ struct Tuning {
     int gemm_bk = 0;          // 0 default K-tile depth, 32 doubles it
     int gemm_min_wgs = 1024;   // split K until the GEMM launch has at least this many workgroups
     int row_log_g = 1;  // sibling group of row-pass workgroups (rows q .. q+2^g-1 on one XCD)
+    int r2c = 1;             // real inputs take the Hermitian path where it is legal AND pays (capi.hip r2c_legal): real epilogues / centre
+                             // normalisation; 0: never, 2: also for a plain complex spectrum
     int fold = -1;           // radix-2 step of the column transform folded into the row pass: -1 auto, 0 never, 1 wherever legal
     int blue_min = 96;        // shortest non-power-of-two length that takes the Bluestein path (shorter ones, and lengths
                              // above 4096, run on the direct O(n^2) kernel); 0 disables the path

@@ -1,7 +1,11 @@
 """MTF / PTF / OTF from a PSF (prysm/otf.py) -- SURVEY 8(f) rank 1, a "next" row of the hot path.
 
 The forward transform fftshift(fft2(ifftshift(psf))) is the same fused pm_fft2 call as `focus`
-(unnormalised, shifts folded into the index maps).  The centre normalisation and abs / angle are
+(unnormalised, shifts folded into the index maps).  A REAL PSF with power-of-two lengths takes the
+Hermitian path of the library (half-length row transforms, half the column tiles, mirrored stores)
+and, when only the MTF / PTF / OTF is wanted, the centre normalisation and abs / angle ride in the
+epilogue of its column pass: one launch pair, no elementwise sweeps.  Other inputs, and
+return_more=True (which also hands back the unnormalised transform), compose the transform with
 elementwise device ops.
 """
 import math
@@ -48,6 +52,22 @@ def transform_psf_adjoint(data_bar):
     return _ops.fft2(x, direction=+1, scale=1.0, in_shift=shift, out_shift=shift)
 
 
+def _fused_from_psf(psf, dx, epilogue):
+    """|F / F_c|, angle(F / F_c) or F / F_c straight out of the transform (PM_FLAG_NORM_DC + epilogue), or None when the
+    library has no Hermitian path for this input (complex PSF, lengths that are not powers of two, ...)."""
+    psf, dx = _unwrap_psf(psf, dx)
+    x = L.as_field(psf)
+    if x.is_complex() or x.dim() != 2:
+        return None
+    M, N = x.shape
+    shift = (M // 2, N // 2)
+    try:
+        data = _ops.fft2(x, direction=-1, scale=1.0, in_shift=shift, out_shift=shift, epilogue=epilogue, flags=L.PM_FLAG_NORM_DC)
+    except NotImplementedError:
+        return None
+    return data, 1000 / (M * dx)
+
+
 def _normalized_transform(psf, dx):
     """Forward-transform a PSF and divide by its central value (otf.py:62-74)."""
     data, df = transform_psf(psf, dx)
@@ -58,6 +78,10 @@ def _normalized_transform(psf, dx):
 
 def mtf_from_psf(psf, dx=None, return_more=False):
     """Compute the MTF from a given PSF (otf.py:77-103)."""
+    if not return_more:
+        fused = _fused_from_psf(psf, dx, L.PM_EPI_ABS)
+        if fused is not None:
+            return RichData(data=fused[0], dx=fused[1], wavelength=None)
     normalized, data, df = _normalized_transform(psf, dx)
     rd = RichData(data=torch.abs(normalized), dx=df, wavelength=None)
     if return_more:
@@ -67,6 +91,10 @@ def mtf_from_psf(psf, dx=None, return_more=False):
 
 def ptf_from_psf(psf, dx=None, return_more=False):
     """Compute the PTF from a given PSF (otf.py:106-135)."""
+    if not return_more:
+        fused = _fused_from_psf(psf, dx, L.PM_EPI_ARG)
+        if fused is not None:
+            return RichData(data=fused[0], dx=fused[1], wavelength=None)
     normalized, data, df = _normalized_transform(psf, dx)
     rd = RichData(data=torch.angle(normalized), dx=df, wavelength=None)
     if return_more:
@@ -76,6 +104,10 @@ def ptf_from_psf(psf, dx=None, return_more=False):
 
 def otf_from_psf(psf, dx=None, return_more=False):
     """Compute the OTF from a given PSF (otf.py:138-164)."""
+    if not return_more:
+        fused = _fused_from_psf(psf, dx, L.PM_EPI_NONE)
+        if fused is not None:
+            return RichData(data=fused[0], dx=fused[1], wavelength=None)
     normalized, data, df = _normalized_transform(psf, dx)
     rd = RichData(data=normalized, dx=df, wavelength=None)
     if return_more:

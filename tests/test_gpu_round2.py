@@ -260,6 +260,80 @@ def test_prepare_executor_grid_bases_equal_vector_bases(pa):
         config.precision = prec
 
 
+# ----------------------------------------------------------------------------- real-input (Hermitian) transforms
+
+def _np_transform_psf(psf):
+    return np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(psf.astype(np.float64))))
+
+
+@pytest.mark.parametrize('shape', [(32, 32), (64, 256), (256, 64), (2, 32), (512, 512), (1024, 2048), (4096, 4096)])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_real_input_hermitian_transform_vs_numpy(pa, shape, dtype):
+    """transform_psf of a real array (prysm/otf.py:28-33): the library computes N/2 + 1 columns and stores every bin twice; the
+    complex path (knob r2c = 0) must agree with it to rounding and both with numpy"""
+    from prysm_amd import _lib, otf
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    psf = rng.random(shape).astype(dtype) + 0.01
+    want = _np_transform_psf(psf)
+    tol = TOL32 if dtype == np.float32 else TOL64
+    lib = _lib.load()
+    try:
+        lib.pm_set_tuning(b'r2c', 2)      # the Hermitian path also for the plain complex spectrum (by default only where it pays)
+        got, df = otf.transform_psf(psf, 0.5)
+        assert tonp(got).dtype == (np.complex64 if dtype == np.float32 else np.complex128)
+        assert rel_max(tonp(got), want) < tol
+        lib.pm_set_tuning(b'r2c', 0)
+        ref, _ = otf.transform_psf(psf, 0.5)
+    finally:
+        lib.pm_set_tuning(b'r2c', 1)
+    assert rel_max(tonp(got), tonp(ref)) < tol
+    assert df == pytest.approx(1000 / (shape[0] * 0.5))
+
+
+@pytest.mark.parametrize('shape', [(64, 64), (128, 512), (2048, 2048)])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_fused_mtf_ptf_otf_vs_numpy(pa, shape, dtype):
+    """mtf_from_psf / ptf_from_psf / otf_from_psf with the centre normalisation and abs / angle in the column pass's epilogue
+    (prysm/otf.py:62-164), against the reference expressions in numpy and against the composed (return_more) route"""
+    from prysm_amd import otf
+    rng = np.random.default_rng(shape[1])
+    y, x = np.indices(shape)
+    psf = (np.exp(-((y - shape[0] // 2 - 1.5) ** 2 + (x - shape[1] // 2 + 2.25) ** 2) / 40.0) + 0.05 * rng.random(shape)).astype(dtype)
+    F = _np_transform_psf(psf)
+    norm = F / F[shape[0] // 2, shape[1] // 2]
+    tol = TOL32 if dtype == np.float32 else TOL64
+    mtf = tonp(otf.mtf_from_psf(psf, 0.5))
+    assert mtf.dtype == dtype and rel_max(mtf, np.abs(norm)) < tol
+    o = tonp(otf.otf_from_psf(psf, 0.5))
+    assert rel_max(o, norm) < tol
+    ptf = tonp(otf.ptf_from_psf(psf, 0.5))
+    # the phase is ill-conditioned where the modulus vanishes: compare where |OTF| is well above the rounding floor
+    ok = np.abs(norm) > (1e-3 if dtype == np.float32 else 1e-8)
+    dphi = np.angle(np.exp(1j * (ptf - np.angle(norm))))
+    assert np.abs(dphi[ok]).max() < (2e-3 if dtype == np.float32 else 1e-6)
+    # composed route (also returns the unnormalised transform)
+    mtf2, data = otf.mtf_from_psf(psf, 0.5, return_more=True)
+    assert rel_max(tonp(mtf2), mtf) < tol and rel_max(tonp(data), F) < tol
+    # a negative DC flips the sign of the normalised transform: abs unchanged, phase by pi
+    neg = tonp(otf.otf_from_psf(-psf, 0.5))
+    assert rel_max(neg, norm) < tol
+
+
+def test_hermitian_epilogues_refused_elsewhere(pa):
+    """PM_EPI_ABS / PM_FLAG_NORM_DC exist on the Hermitian path only: complex input or awkward lengths fall back to the composed
+    route in otf.py, and the C ABI says PM_ERR_UNSUPPORTED"""
+    from prysm_amd import _lib as L, _ops, otf
+    rng = np.random.default_rng(5)
+    psf = rng.random((48, 100))            # not powers of two: composed route
+    F = _np_transform_psf(psf)
+    assert rel_max(tonp(otf.mtf_from_psf(psf, 1.0)), np.abs(F / F[24, 50])) < TOL64
+    z = torch.randn(64, 64, dtype=torch.complex64, device='cuda')
+    with pytest.raises(NotImplementedError):
+        _ops.fft2(z, direction=-1, scale=1.0, epilogue=L.PM_EPI_ABS)
+    with pytest.raises(NotImplementedError):
+        _ops.fft2(z.real.contiguous(), direction=-1, scale=1.0, shape=(128, 128), flags=L.PM_FLAG_NORM_DC)     # padded input
+
+
 # ----------------------------------------------------------------------------- ADVICE r1
 
 def test_babinet_takes_a_boolean_occulter(pa):

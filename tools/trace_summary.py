@@ -5,7 +5,7 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 agg = collections.defaultdict(list)
 prev = None
-for r in rows[len(rows) // 2:]:
+for r in rows:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     name = r['Kernel_Name'].split('(')[0][:70] + ' g' + r.get('Grid_Size_X', r.get('Grid_Size', '?'))
     agg[name].append(((e - s) / 1e3, (s - prev) / 1e3 if prev else 0.0))
