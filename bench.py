@@ -63,7 +63,7 @@ def parse():
     ap.add_argument('--dtype', default='c64', choices=['c64', 'c128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-poly', action='store_true', help='only the headline loop (profiling runs)')
-    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192)')
+    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192|mtf)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget for the CPU baseline sample')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path when the ranks share a GPU)')
@@ -206,6 +206,15 @@ def other_configs(only=''):
         x6 = torch.from_numpy(make_field(8192, np.complex64, 8192)).cuda()
         out['focus_8192_c64'] = _hbm_entry(_event_ms(lambda: P.focus(x6, 1), 20), 4 * 8192 ** 2 * 8)
         del x6
+    if want('mtf'):       # MTF of a real 4096^2 fp32 PSF -- Hermitian transform with the centre normalisation and |.| in
+        from prysm_amd import otf     # the column pass's epilogue (one launch pair) against transform + elementwise sweeps
+        psf = torch.rand(4096, 4096, dtype=torch.float32, device='cuda') + 0.01
+        ms = _event_ms(lambda: otf.mtf_from_psf(psf, 1.0), 30)
+        msc = _event_ms(lambda: otf.mtf_from_psf(psf, 1.0, return_more=True), 10)
+        out['mtf_from_psf_4096_f32'] = {'ms': ms, 'composed_ms': msc,
+                                        'note': 'fused: real-input (Hermitian) transform, N/2 columns, DC normalisation + abs in the store; composed '
+                                                '(return_more=True): complex spectrum + division + abs as separate device sweeps'}
+        del psf
     torch.cuda.empty_cache()
     if want('config4'):   # config 4: matrix-DFT focus 2048^2 -> 512^2 complex64 on MFMA, 8 My Nx (Ny + Mx) real flops
         prec = config.precision

@@ -210,12 +210,13 @@ static bool fold_legal(const pm_fft2_desc* d, int logn, int logm) {
 static bool r2c_legal(const pm_fft2_desc* d, int logn, int logm) {
     const int64_t M = d->in_y.n, N = d->in_x.n;
     if (!(d->flags & PM_FLAG_REAL_INPUT) || (d->flags & (PM_FLAG_SYNTH_INPUT | PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY))) return false;
-    if (tuning().r2c == 0 || d->direction != -1 || logn < 5 || logm < 1 || d->batch > 1 || d->mul_kind != PM_MUL_NONE) return false;
-    // Measured (profiles/r02/exp_r2c.log): with a real epilogue or the centre normalisation the Hermitian path is 2.5x faster than
-    // transform + elementwise sweeps (4096^2 fp32 MTF 105 vs 268 us); for a plain complex spectrum its column pass -- half the
-    // tiles, each storing every bin twice, one 1024-thread workgroup per CU with nothing to overlap -- loses to the complex path
-    // that only READS the real array (111 vs 101 us), so that case stays there unless the knob r2c = 2 forces it.
-    if (tuning().r2c < 2 && d->epilogue == PM_EPI_NONE && !(d->flags & PM_FLAG_NORM_DC)) return false;
+    if (tuning().r2c == 0 || d->direction != -1 || logn < 5 || logm < 5 || d->batch > 1 || d->mul_kind != PM_MUL_NONE) return false;
+    if (d->epilogue == PM_EPI_ABS2_ACCUM) return false;
+    // Measured (profiles/r02/exp_r2c.log): with a real epilogue or the centre normalisation the Hermitian path beats transform +
+    // elementwise sweeps at every size (fp32 MTF: 4096^2 90 vs 266 us, 2048^2 42 vs 64 us); a plain complex spectrum gains from
+    // 4096^2 (87 vs 104 us, 8192^2 421 vs 449 us) and loses below (2048^2: 38 vs 31 us -- the extra exchange phases are pure
+    // latency there), so small plain transforms stay on the complex path that only READS the real array (knob r2c = 2 forces it).
+    if (tuning().r2c < 2 && d->epilogue == PM_EPI_NONE && !(d->flags & PM_FLAG_NORM_DC) && M * N < (int64_t(1) << 24)) return false;
     if (d->dtype == PM_C128 && logn > 12) return false;     // complex128 rows of 4096 complex points exchange re / im separately
     if (d->in_y.len != M || d->in_x.len != N || d->out_y.len != M || d->out_x.len != N) return false;
     if (!(d->in_x.shift == 0 || d->in_x.shift == N / 2) || (d->in_ld % 2) != 0) return false;
@@ -242,6 +243,13 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
         p.col_var = 0;
         p.tc = col_tile_width_for(d->dtype, p.logm, 0);
         p.log_k = tuning().log_k >= 0 ? tuning().log_k : 2;
+        // fold (one radix-2 step of the column transform in the row pass, as in the complex path): half-length column tiles, two
+        // workgroups per CU whose load / transform / store phases overlap -- here from 1024-point columns, because the Hermitian
+        // column pass has only half the tiles to fill the chip with
+        const int f = tuning().fold;
+        p.fold = (f > 0 || (f < 0 && p.logm >= 10)) && p.logm >= 5 && (d->in_y.shift == 0 || d->in_y.shift == M / 2) &&
+                 (d->out_y.shift == 0 || d->out_y.shift == M / 2);
+        if (p.fold) p.tc = col_tile_width_for(d->dtype, p.logm - 1, 0);
         while (p.log_k > 0 && ((N / 2) % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
         const int64_t nc = N / 2, tl = int64_t(p.tc) << p.log_k;
         p.ws_bytes = size_t((nc + tl - 1) / tl) * size_t(M) * size_t(tl) * es;
@@ -380,17 +388,37 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         const size_t in_bytes = size_t(M) * size_t(N) * sizeof(T);
         RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld / 2, AxisMap{int(n2), int(n2), 0, int(d->in_x.shift / 2)}, int(M), 0,
                          tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0), 0};
-        R2CRowStore<T> rs{W, int(M), ltl, twn};
-        int rc = launch_row_r2c<T>(p.logn - 1, lp, rs, tw2, int(M), tuning().row_log_g, st);
+        const int H = int(M / 2);
+        const int64_t ntl = (n2 + tl - 1) / tl, plane = ntl * H * tl;
+        R2CRowStore<T> rs{W, int(M), ltl, twn, 0, 0, nullptr, 0};
+        if (p.fold) {
+            lp.eoff = H;
+            rs.nseq = H;
+            rs.fold = 1;
+            rs.plane_stride = plane;
+            rs.twm = twm;
+            rs.swap = d->in_y.shift == M / 2 ? 1 : 0;
+        }
+        int rc = launch_row_r2c<T>(p.logn - 1, lp, rs, tw2, p.fold ? H : int(M), p.fold ? 0 : tuning().row_log_g, st);
         if (rc) return rc < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: no Hermitian row kernel for %lld points", (long long)N) : rc;
         // columns: M-point transforms of the N/2 columns, each bin stored at (u, k) and conjugated at (-u, -k)
         const int ntiles = int((n2 + p.tc - 1) / p.tc);
+        const size_t oes = d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T);
+        const int fast = ((d->out_y.shift == 0 || d->out_y.shift == M / 2) && (d->out_x.shift == 0 || d->out_x.shift == N / 2) &&
+                          (N % (2 * p.tc)) == 0 && (d->out_ld % 2) == 0 && reinterpret_cast<uintptr_t>(out) % (2 * oes) == 0) ? 1 : 0;
+        if (p.fold) {
+            // two planes of M/2-point column transforms; plane b holds the bins 2 u' + b = output rows of that parity: the output is
+            // seen with a doubled leading dimension, plane 1 one row further
+            const cx<T>* twh = twiddles<T>(H, &err);
+            if (!twh) return err;
+            ColLoadTiled<T> cl{W, H, AxisMap{H, H, 0, 0}, ntiles, p.log_k, plane};
+            HermStore<T> hs{out, 2 * d->out_ld, AxisMap{H, H, 0, int(d->out_y.shift / 2)}, to_map(d->out_x), H, int(N), d->epilogue,
+                            T(d->scale), T(d->weight), (d->flags & PM_FLAG_NORM_DC) ? 1 : 0, W, tl, H, 0, d->out_ld, fast};
+            return launch_col_herm<T>(p.logm - 1, cl, hs, twh, ntiles, sibling_log_g(p.log_k), st);
+        }
         ColLoadTiled<T> cl{W, int(M), to_map(d->in_y), ntiles, p.log_k, 0};
         HermStore<T> hs{out, d->out_ld, to_map(d->out_y), to_map(d->out_x), int(M), int(N), d->epilogue, T(d->scale), T(d->weight),
-                        (d->flags & PM_FLAG_NORM_DC) ? 1 : 0, W, tl, int(M), 0};
-        const size_t oes = d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T);
-        hs.fast = (d->out_y.shift == 0 || d->out_y.shift == M / 2) && (d->out_x.shift == 0 || d->out_x.shift == N / 2) &&
-                  (N % (2 * p.tc)) == 0 && (d->out_ld % 2) == 0 && reinterpret_cast<uintptr_t>(out) % (2 * oes) == 0;
+                        (d->flags & PM_FLAG_NORM_DC) ? 1 : 0, W, tl, int(M), -1, 0, fast};
         return launch_col_herm<T>(p.logm, cl, hs, twm, ntiles, sibling_log_g(p.log_k), st);
     }
 

@@ -23,73 +23,83 @@
 namespace pm {
 
 // ---------------------------------------------------------------- row pass
-template <typename C, typename L>
+// X[k] of one real row from its packed transform Z and the partner Z[(N2 - k) mod N2]
+template <typename T>
+PM_HD cx<T> r2c_combine(cx<T> z, cx<T> zp, cx<T> w, bool k0) {
+    if (k0) return {z.x + z.y, z.x - z.y};      // X[0] = Re Z[0] + Im Z[0] and X[N/2] = Re Z[0] - Im Z[0], both real, share column 0
+    // Xe = (z + conj zp) / 2, Xo = -i (z - conj zp) / 2
+    const cx<T> xe = {T(0.5) * (z.x + zp.x), T(0.5) * (z.y - zp.y)};
+    const cx<T> d = {T(0.5) * (z.x - zp.x), T(0.5) * (z.y + zp.y)};
+    return xe + cmul(w, mul_mi(d));
+}
+
+// W_N^k for the thread's bins k = t + m N/32: W_N^t (ONE table read, requested before the transform so its latency is hidden)
+// times the constants W_32^m -- sixteen dependent table reads per thread after the transform cost the row pass ~10 %
+template <typename T>
+PM_HD cx<T> w32(int m) {
+    constexpr double tab[16][2] = {{1.00000000000000000000e+00, -0.00000000000000000000e+00}, {9.80785280403230430579e-01, -1.95090322016128248084e-01}, {9.23879532511286738483e-01, -3.82683432365089781779e-01}, {8.31469612302545235671e-01, -5.55570233019602177649e-01}, {7.07106781186547572737e-01, -7.07106781186547461715e-01}, {5.55570233019602288671e-01, -8.31469612302545235671e-01}, {3.82683432365089837290e-01, -9.23879532511286738483e-01}, {1.95090322016128331351e-01, -9.80785280403230430579e-01}, {6.12323399573676603587e-17, -1.00000000000000000000e+00}, {-1.95090322016128192573e-01, -9.80785280403230430579e-01}, {-3.82683432365089726268e-01, -9.23879532511286738483e-01}, {-5.55570233019601955604e-01, -8.31469612302545457716e-01}, {-7.07106781186547461715e-01, -7.07106781186547572737e-01}, {-8.31469612302545346694e-01, -5.55570233019602177649e-01}, {-9.23879532511286738483e-01, -3.82683432365089892802e-01}, {-9.80785280403230430579e-01, -1.95090322016128608906e-01}};
+    return {T(tab[m][0]), T(tab[m][1])};
+}
+
+template <typename C, typename L, bool FOLD>
 __global__ void __launch_bounds__(C::NT) fft_row_r2c_kernel(const L lp, const R2CRowStore<typename C::T> sp,
                                                             const cx<typename C::T>* __restrict__ tw, const int log_g) {
     using T = typename C::T;
     static_assert(C::COMP == 1 && C::CI == 1, "row mode, complex exchange");
+    static_assert(!FOLD || C::E == 2, "the fold pairs the two rows of a thread");
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(pm_smem);
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
     const int unit = group_remap(blockIdx.x, gridDim.x, log_g);
+    static_assert(C::P == 16, "rows of at least 32 samples");
     cx<T> v[C::E][C::P];
+    const cx<T> wt = sp.twn[pos.t];
     load<C>(lp, unit, pos, v);
     if constexpr (C::E == 2 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
     else fft_run<C>(v, pos, pm_smem, tw);
     constexpr int N2 = C::N;          // complex points per row = N / 2
     const int tcm = (1 << sp.log_tc) - 1;
+    // partner exchange: every sequence of the workgroup in natural order (one LDS region per slot e), then read Z[(N2 - k) mod N2]
+    __syncthreads();
 #pragma unroll
-    for (int e = 0; e < C::E; ++e) {
-        // partner exchange: everybody's Z in natural order, then read Z[(N2 - k) mod N2]
-        __syncthreads();
+    for (int e = 0; e < C::E; ++e)
 #pragma unroll
-        for (int m = 0; m < C::P; ++m) lds[lds_addr<C>(pos.bo, 0, pos.t + m * C::TPS)] = v[e][m];
-        __syncthreads();
-        const int seq = (unit * C::BO + pos.bo) * C::E + e;
-        const bool ok = seq < sp.nseq;
+        for (int m = 0; m < C::P; ++m) lds[e * C::LDS_ELEMS + lds_addr<C>(pos.bo, 0, pos.t + m * C::TPS)] = v[e][m];
+    __syncthreads();
+    if constexpr (FOLD) {
+        const int i = unit * C::BO + pos.bo;       // pair index = logical row of the lower half
+        if (i >= sp.nseq) return;
+        const cx<T> wi = sp.twm[i];
+        const int lo = sp.swap ? 1 : 0, hi = lo ^ 1;
 #pragma unroll
         for (int m = 0; m < C::P; ++m) {
             const int k = pos.t + m * C::TPS;
-            const cx<T> z = v[e][m];
-            const cx<T> zp = lds[lds_addr<C>(pos.bo, 0, (N2 - k) & (N2 - 1))];
-            // Xe = (z + conj zp) / 2, Xo = -i (z - conj zp) / 2
-            const cx<T> xe = {T(0.5) * (z.x + zp.x), T(0.5) * (z.y - zp.y)};
-            const cx<T> d = {T(0.5) * (z.x - zp.x), T(0.5) * (z.y + zp.y)};
-            const cx<T> xo = mul_mi(d);
-            const cx<T> w = sp.twn[k];
-            const cx<T> x = xe + cmul(w, xo);
-            if (ok) {
+            const int pa = lds_addr<C>(pos.bo, 0, (N2 - k) & (N2 - 1));
+            const cx<T> w = cmul(wt, w32<T>(m));
+            const cx<T> x0 = r2c_combine(v[lo][m], lds[lo * C::LDS_ELEMS + pa], w, k == 0);
+            const cx<T> x1 = r2c_combine(v[hi][m], lds[hi * C::LDS_ELEMS + pa], w, k == 0);
+            const int64_t a = ((int64_t(k >> sp.log_tc) * sp.nseq + i) << sp.log_tc) + (k & tcm);
+            sp.dst[a] = x0 + x1;
+            sp.dst[a + sp.plane_stride] = cmul(x0 - x1, wi);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) {
+            const int seq = (unit * C::BO + pos.bo) * C::E + e;
+            if (seq >= sp.nseq) continue;
+#pragma unroll
+            for (int m = 0; m < C::P; ++m) {
+                const int k = pos.t + m * C::TPS;
+                const cx<T> zp = lds[e * C::LDS_ELEMS + lds_addr<C>(pos.bo, 0, (N2 - k) & (N2 - 1))];
                 const int64_t a = ((int64_t(k >> sp.log_tc) * sp.nseq + seq) << sp.log_tc) + (k & tcm);
-                // k = 0: X[0] = Re Z[0] + Im Z[0] and X[N/2] = Re Z[0] - Im Z[0], both real, share column 0
-                sp.dst[a] = k == 0 ? cx<T>{z.x + z.y, z.x - z.y} : x;
+                sp.dst[a] = r2c_combine(v[e][m], zp, cmul(wt, w32<T>(m)), k == 0);
             }
         }
     }
 }
 
 // ---------------------------------------------------------------- column pass
-// one result through the epilogue; `mirror`: the conjugate image
-template <typename T>
-PM_HD void herm_put(const HermStore<T>& p, int qy, int qx, cx<T> x, bool mirror) {
-    if (qy < 0 || qx < 0) return;
-    if (mirror) x.y = -x.y;
-    const int64_t at = int64_t(qy) * p.ld + qx;
-    if (p.epilogue == EPI_NONE) {
-        reinterpret_cast<cx<T>*>(p.dst)[at] = x;
-        return;
-    }
-    T* o = reinterpret_cast<T*>(p.dst) + at;
-    if (p.epilogue == EPI_ARG) {
-        *o = atan2(x.y, x.x);
-        return;
-    }
-    const T i2 = x.x * x.x + x.y * x.y;
-    if (p.epilogue == EPI_ABS2) *o = i2;
-    else if (p.epilogue == EPI_ABS) *o = sqrt(i2);
-    else *o += p.weight * i2;
-}
-
-// real value of the epilogue EPI for x, and for conj(x)
+// real value of the epilogue EPI for x (mirror: for conj(x))
 template <typename T, int EPI>
 PM_HD T herm_real(cx<T> x, bool mirror) {
     if constexpr (EPI == EPI_ARG) {
@@ -101,6 +111,43 @@ PM_HD T herm_real(cx<T> x, bool mirror) {
         else return i2;
     }
 }
+
+// one result through the epilogue; `mirror`: the conjugate image (per-element path: the thread that owns column 0, odd views)
+template <typename T, int EPI>
+PM_HD void herm_put(const HermStore<T>& p, int qy, int qx, cx<T> x, bool mirror) {
+    if (qy < 0 || qx < 0) return;
+    const int64_t at = int64_t(qy) * p.ld + qx;
+    if constexpr (EPI == EPI_NONE) {
+        if (mirror) x.y = -x.y;
+        reinterpret_cast<cx<T>*>(p.dst)[at] = x;
+    } else {
+        reinterpret_cast<T*>(p.dst)[at] = herm_real<T, EPI>(x, mirror);
+    }
+}
+
+// 8 / 16-byte stores at addresses that are only 4 / 8-byte aligned (the mirrored pair of columns starts one element off the
+// natural boundary): the hardware takes them, the compiler would split them into single-dword stores.  The trailing s_nop covers
+// the "VMEM store of more than 8 bytes followed by a write of its data registers" hazard, which hipcc cannot see through the asm.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void store_pair_unaligned(float* a, float x, float y) {
+    typedef float V2 __attribute__((ext_vector_type(2)));
+    const V2 w = {x, y};
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" : : "v"(a), "v"(w) : "memory");
+}
+__device__ __forceinline__ void store_pair_unaligned(double* a, double x, double y) {
+    typedef double V2 __attribute__((ext_vector_type(2)));
+    const V2 w = {x, y};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(a), "v"(w) : "memory");
+}
+__device__ __forceinline__ void store_quad_unaligned(float* a, float x, float y, float z, float u) {
+    typedef float V4 __attribute__((ext_vector_type(4)));
+    const V4 w = {x, y, z, u};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(a), "v"(w) : "memory");
+}
+#else
+template <typename T> inline void store_pair_unaligned(T* a, T x, T y) { a[0] = x; a[1] = y; }
+inline void store_quad_unaligned(float* a, float x, float y, float z, float u) { a[0] = x; a[1] = y; a[2] = z; a[3] = u; }
+#endif
 
 // Fast store: unwindowed output, rotations by 0 or half a length on both axes, the thread's columns strictly inside (0, N/2).
 // Memory positions follow from the rotation alone -- a bin at position p has its conjugate image at (n - p) mod n on either axis,
@@ -115,7 +162,8 @@ PM_HD void herm_store_fast(const HermStore<typename C::T>& p, int col0, ThreadPo
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
         const int pp = slot_pos<C, ROT>(pos.t, m, p.ay.shift);
-        const int pm_ = pp == 0 ? 0 : p.M - pp;
+        // image row: (M - pp) mod M; in the plane of the odd bins of a folded transform (rows 2 pp + 1 of the output) M - 1 - pp
+        const int pm_ = p.plane == 1 ? p.M - 1 - pp : (pp == 0 ? 0 : p.M - pp);
         cx<T> x[C::E];
 #pragma unroll
         for (int e = 0; e < C::E; ++e) x[e] = cscale(v[e][m], s);
@@ -124,8 +172,7 @@ PM_HD void herm_store_fast(const HermStore<typename C::T>& p, int col0, ThreadPo
             cx<T>* b = reinterpret_cast<cx<T>*>(p.dst) + int64_t(pm_) * p.ld + qm;
             if constexpr (C::E == 2 && sizeof(T) == 4) {
                 *reinterpret_cast<Vec4<T>*>(a) = Vec4<T>{x[0].x, x[0].y, x[1].x, x[1].y};
-                typedef T V4 __attribute__((ext_vector_type(4), aligned(8)));
-                *reinterpret_cast<V4*>(b) = V4{x[1].x, -x[1].y, x[0].x, -x[0].y};
+                store_quad_unaligned(reinterpret_cast<T*>(b), x[1].x, -x[1].y, x[0].x, -x[0].y);
             } else {
 #pragma unroll
                 for (int e = 0; e < C::E; ++e) {
@@ -136,18 +183,10 @@ PM_HD void herm_store_fast(const HermStore<typename C::T>& p, int col0, ThreadPo
         } else {
             T* a = reinterpret_cast<T*>(p.dst) + int64_t(pp) * p.ld + qx0;
             T* b = reinterpret_cast<T*>(p.dst) + int64_t(pm_) * p.ld + qm;
-            if constexpr (EPI == EPI_ABS2_ACCUM) {
-#pragma unroll
-                for (int e = 0; e < C::E; ++e) {
-                    const T i2 = herm_real<T, EPI_ABS2>(x[e], false);
-                    a[e] += p.weight * i2;
-                    b[C::E - 1 - e] += p.weight * i2;
-                }
-            } else if constexpr (C::E == 2) {
+            if constexpr (C::E == 2) {
                 const T r0 = herm_real<T, EPI>(x[0], false), r1 = herm_real<T, EPI>(x[1], false);
                 *reinterpret_cast<cx<T>*>(a) = cx<T>{r0, r1};                         // a pair of reals, 8-byte aligned
-                typedef T V2 __attribute__((ext_vector_type(2), aligned(4)));
-                *reinterpret_cast<V2*>(b) = V2{EPI == EPI_ARG ? -r1 : r1, EPI == EPI_ARG ? -r0 : r0};
+                store_pair_unaligned(b, EPI == EPI_ARG ? -r1 : r1, EPI == EPI_ARG ? -r0 : r0);
             } else {
                 const T r0 = herm_real<T, EPI>(x[0], false);
                 a[0] = r0;
@@ -157,19 +196,8 @@ PM_HD void herm_store_fast(const HermStore<typename C::T>& p, int col0, ThreadPo
     }
 }
 
-template <typename C, int ROT>
-PM_HD void herm_store_fast_epi(const HermStore<typename C::T>& p, int col0, ThreadPos pos, const cx<typename C::T> (&v)[C::E][C::P], typename C::T s) {
-    switch (p.epilogue) {
-        case EPI_NONE: herm_store_fast<C, ROT, EPI_NONE>(p, col0, pos, v, s); break;
-        case EPI_ABS2: herm_store_fast<C, ROT, EPI_ABS2>(p, col0, pos, v, s); break;
-        case EPI_ABS2_ACCUM: herm_store_fast<C, ROT, EPI_ABS2_ACCUM>(p, col0, pos, v, s); break;
-        case EPI_ABS: herm_store_fast<C, ROT, EPI_ABS>(p, col0, pos, v, s); break;
-        default: herm_store_fast<C, ROT, EPI_ARG>(p, col0, pos, v, s); break;
-    }
-}
-
-template <typename C>
-__global__ void __launch_bounds__(C::NT) fft_col_herm_kernel(const ColLoadTiled<typename C::T> lp, const HermStore<typename C::T> sp,
+template <typename C, int EPI>
+__global__ void __launch_bounds__(C::NT) fft_col_herm_kernel(const ColLoadTiled<typename C::T> lp0, const HermStore<typename C::T> sp0,
                                                             const cx<typename C::T>* __restrict__ tw, const int log_g) {
     using T = typename C::T;
     constexpr int TC = C::CI * C::E;
@@ -177,21 +205,29 @@ __global__ void __launch_bounds__(C::NT) fft_col_herm_kernel(const ColLoadTiled<
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
     const int unit = group_remap(blockIdx.x, gridDim.x, log_g) * C::BO + pos.bo;
     cx<T> v[C::E][C::P];
+    const auto lp = at_batch(lp0, blockIdx.y);       // blockIdx.y: plane of a folded transform
+    HermStore<T> sp = sp0;
+    if (sp.plane >= 0) {
+        sp.plane = blockIdx.y;
+        if constexpr (EPI == EPI_NONE) sp.dst = reinterpret_cast<cx<T>*>(sp.dst) + int64_t(blockIdx.y) * sp.plane_dst;
+        else sp.dst = reinterpret_cast<T*>(sp.dst) + int64_t(blockIdx.y) * sp.plane_dst;
+    }
     load<C>(lp, unit, pos, v);
     T s = sp.scale;
     if (sp.norm_dc) {
-        // F[0][0] = sum over rows of X_row[0] (real): partial sums per thread, then a fixed-order tree through LDS -- the same
-        // value, bit for bit, in every workgroup
+        // F[0][0] = sum over rows of X_row[0] (real), the same value, bit for bit, in every workgroup
+        // (strided partial sums per thread, each wave reduced in registers in a fixed order, the wave sums through LDS)
         double* red = reinterpret_cast<double*>(pm_smem);
         double acc = 0.0;
         for (int q = threadIdx.x; q < sp.nrows_w; q += C::NT) acc += double(sp.w0[int64_t(q) * sp.w0_stride].x);
-        red[threadIdx.x] = acc;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+        constexpr int NW = (C::NT + 63) / 64;
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
         __syncthreads();
-        for (int half = C::NT / 2; half > 0; half >>= 1) {
-            if (int(threadIdx.x) < half) red[threadIdx.x] += red[threadIdx.x + half];
-            __syncthreads();
-        }
-        const double dc = red[0];
+        double dc = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dc += red[w];
         __syncthreads();     // the exchange of the transform reuses this LDS
         s = T(double(sp.scale) / dc);
     }
@@ -213,15 +249,18 @@ __global__ void __launch_bounds__(C::NT) fft_col_herm_kernel(const ColLoadTiled<
         __syncthreads();
         if (col0 == 0) {
 #pragma unroll
-            for (int m = 0; m < C::P; ++m) part[m] = ex[pos.bo * C::N + ((C::N - pos.t - m * C::TPS) & (C::N - 1))];
+            for (int m = 0; m < C::P; ++m) {
+                const int u = pos.t + m * C::TPS;       // bin within the plane; its partner: (M - u) mod M, or M - 1 - u among the odd bins
+                part[m] = ex[pos.bo * C::N + (sp.plane == 1 ? C::N - 1 - u : ((C::N - u) & (C::N - 1)))];
+            }
         }
     }
     const int rot = rot_of<C>(sp.ay.shift);
     // the thread's columns strictly inside (0, N/2): every bin has its image; the thread that owns column 0 takes the
     // per-element path below
     if (sp.fast && rot >= 0 && col0 > 0 && col0 + C::E - 1 < n2) {
-        if (rot == 0) herm_store_fast_epi<C, 0>(sp, col0, pos, v, s);
-        else herm_store_fast_epi<C, (C::P >= 2 ? C::P / 2 : 0)>(sp, col0, pos, v, s);
+        if (rot == 0) herm_store_fast<C, 0, EPI>(sp, col0, pos, v, s);
+        else herm_store_fast<C, (C::P >= 2 ? C::P / 2 : 0), EPI>(sp, col0, pos, v, s);
         return;
     }
     int qx[C::E], qxm[C::E];
@@ -236,7 +275,7 @@ __global__ void __launch_bounds__(C::NT) fft_col_herm_kernel(const ColLoadTiled<
     for (int m = 0; m < C::P; ++m) {
         const int u = pos.t + m * C::TPS;
         const int qy = sp.ay.map(u);
-        const int qym = sp.ay.map(u == 0 ? 0 : sp.M - u);
+        const int qym = sp.ay.map(sp.plane == 1 ? sp.M - 1 - u : (u == 0 ? 0 : sp.M - u));
 #pragma unroll
         for (int e = 0; e < C::E; ++e) {
             const cx<T> x = cscale(v[e][m], s);
@@ -244,57 +283,73 @@ __global__ void __launch_bounds__(C::NT) fft_col_herm_kernel(const ColLoadTiled<
                 const cx<T> xp = cscale(part[m], s);
                 const cx<T> f0 = {T(0.5) * (x.x + xp.x), T(0.5) * (x.y - xp.y)};
                 const cx<T> d = {T(0.5) * (x.x - xp.x), T(0.5) * (x.y + xp.y)};
-                herm_put(sp, qy, qx[e], f0, false);
-                herm_put(sp, qy, qxn, mul_mi(d), false);
+                herm_put<T, EPI>(sp, qy, qx[e], f0, false);
+                herm_put<T, EPI>(sp, qy, qxn, mul_mi(d), false);
             } else {
-                herm_put(sp, qy, qx[e], x, false);
-                herm_put(sp, qym, qxm[e], x, true);
+                herm_put<T, EPI>(sp, qy, qx[e], x, false);
+                herm_put<T, EPI>(sp, qym, qxm[e], x, true);
             }
         }
     }
 }
 
 // ---------------------------------------------------------------- launchers (instantiated in fft_r2c_f32.hip / fft_r2c_f64.hip)
-template <typename T, int LOGN2, int VAR>
-int launch_row_r2c_one(const RowLoadNat<T>& lp, const R2CRowStore<T>& sp, const cx<T>* tw, int nseq, int log_g, hipStream_t st) {
+template <typename T, int LOGN2, int VAR, bool FOLD>
+int launch_row_r2c_one(const RowLoadNat<T>& lp, const R2CRowStore<T>& sp, const cx<T>* tw, int nunits, int log_g, hipStream_t st) {
     using C = typename RowCfgSel<T, LOGN2, VAR>::type;
-    auto kern = fft_row_r2c_kernel<C, RowLoadNat<T>>;
-    // the partner exchange needs one whole sequence per row group in LDS even when the transform itself has a single stage
-    constexpr size_t LDSB = size_t(C::LDS_ELEMS) * sizeof(cx<T>);
+    auto kern = fft_row_r2c_kernel<C, RowLoadNat<T>, FOLD>;
+    // the partner exchange keeps every sequence of the workgroup in LDS (one region per slot e), also when the transform itself
+    // has a single stage
+    constexpr size_t part = size_t(C::E) * C::LDS_ELEMS * sizeof(cx<T>);
+    constexpr size_t LDSB = C::LDS_BYTES > part ? C::LDS_BYTES : part;
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
         if (e != hipSuccess) return int(e);
     }
-    const int per_wg = C::BO * C::E;
-    const int grid = (nseq + per_wg - 1) / per_wg;
+    const int per_wg = C::BO * (FOLD ? 1 : C::E);    // units: rows, or row PAIRS of a folded transform
+    const int grid = (nunits + per_wg - 1) / per_wg;
     if (grid <= 0) return 0;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
     return int(hipGetLastError());
 }
 
 template <typename T>
-int launch_row_r2c_impl(int logn2, const RowLoadNat<T>& lp, const R2CRowStore<T>& sp, const cx<T>* tw, int nseq, int log_g, hipStream_t st) {
+int launch_row_r2c_impl(int logn2, const RowLoadNat<T>& lp, const R2CRowStore<T>& sp, const cx<T>* tw, int nunits, int log_g, hipStream_t st) {
+    if (sp.fold) {      // two rows (i, i + M/2) per thread
+        switch (logn2) {
+#define PM_CASE(k) \
+    case k:        \
+        return launch_row_r2c_one<T, k, 4, true>(lp, sp, tw, nunits, log_g, st);
+            PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7) PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASE(11)
+#undef PM_CASE
+            case 12:
+                if constexpr (sizeof(T) == 4) return launch_row_r2c_one<T, 12, 4, true>(lp, sp, tw, nunits, log_g, st);
+                else return -2;
+            default:
+                return -2;
+        }
+    }
     switch (logn2) {
 #define PM_CASE(k) \
     case k:        \
-        return launch_row_r2c_one<T, k, 0>(lp, sp, tw, nseq, log_g, st);
+        return launch_row_r2c_one<T, k, 0, false>(lp, sp, tw, nunits, log_g, st);
         PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7) PM_CASE(8) PM_CASE(9) PM_CASE(10)
 #undef PM_CASE
         case 11:
-            if constexpr (sizeof(T) == 4) return launch_row_r2c_one<T, 11, 5>(lp, sp, tw, nseq, log_g, st);
-            else return launch_row_r2c_one<T, 11, 0>(lp, sp, tw, nseq, log_g, st);
+            if constexpr (sizeof(T) == 4) return launch_row_r2c_one<T, 11, 5, false>(lp, sp, tw, nunits, log_g, st);
+            else return launch_row_r2c_one<T, 11, 0, false>(lp, sp, tw, nunits, log_g, st);
         case 12:
-            if constexpr (sizeof(T) == 4) return launch_row_r2c_one<T, 12, 4>(lp, sp, tw, nseq, log_g, st);
+            if constexpr (sizeof(T) == 4) return launch_row_r2c_one<T, 12, 4, false>(lp, sp, tw, nunits, log_g, st);
             else return -2;     // complex128 rows of 4096 complex points exchange re / im separately (COMP = 2): not on this path
         default:
             return -2;
     }
 }
 
-template <typename T, int LOGM>
-int launch_col_herm_one(const ColLoadTiled<T>& lp, const HermStore<T>& sp, const cx<T>* tw, int ntiles, int log_g, hipStream_t st) {
+template <typename T, int LOGM, int EPI>
+int launch_col_herm_epi(const ColLoadTiled<T>& lp, const HermStore<T>& sp, const cx<T>* tw, int ntiles, int log_g, hipStream_t st) {
     using C = typename ColCfgSel<T, LOGM, 0>::type;
-    auto kern = fft_col_herm_kernel<C>;
+    auto kern = fft_col_herm_kernel<C, EPI>;
     constexpr size_t red = size_t(C::NT) * sizeof(double);                  // the DC reduction
     constexpr size_t part = size_t(C::BO) * C::N * sizeof(cx<T>);           // the partner exchange of the packed column
     constexpr size_t need = red > part ? red : part;
@@ -305,8 +360,19 @@ int launch_col_herm_one(const ColLoadTiled<T>& lp, const HermStore<T>& sp, const
     }
     const int grid = (ntiles + C::BO - 1) / C::BO;
     if (grid <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
+    hipLaunchKernelGGL(kern, dim3(grid, sp.plane >= 0 ? 2 : 1), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
     return int(hipGetLastError());
+}
+
+template <typename T, int LOGM>
+int launch_col_herm_one(const ColLoadTiled<T>& lp, const HermStore<T>& sp, const cx<T>* tw, int ntiles, int log_g, hipStream_t st) {
+    switch (sp.epilogue) {      // one kernel per epilogue: the phase angle alone (atan2, 32 times per thread) is most of a kernel's code
+        case EPI_NONE: return launch_col_herm_epi<T, LOGM, EPI_NONE>(lp, sp, tw, ntiles, log_g, st);
+        case EPI_ABS2: return launch_col_herm_epi<T, LOGM, EPI_ABS2>(lp, sp, tw, ntiles, log_g, st);
+        case EPI_ABS: return launch_col_herm_epi<T, LOGM, EPI_ABS>(lp, sp, tw, ntiles, log_g, st);
+        case EPI_ARG: return launch_col_herm_epi<T, LOGM, EPI_ARG>(lp, sp, tw, ntiles, log_g, st);
+        default: return -2;
+    }
 }
 
 template <typename T>
@@ -315,8 +381,7 @@ int launch_col_herm_impl(int logm, const ColLoadTiled<T>& lp, const HermStore<T>
 #define PM_CASE(k) \
     case k:        \
         return launch_col_herm_one<T, k>(lp, sp, tw, ntiles, log_g, st);
-        PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
-        PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASE(11) PM_CASE(12) PM_CASE(13)
+        PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7) PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASE(11) PM_CASE(12) PM_CASE(13)
 #undef PM_CASE
         default:
             return -2;

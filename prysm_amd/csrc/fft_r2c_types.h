@@ -15,6 +15,12 @@ struct R2CRowStore {
     int nseq;           // rows
     int log_tc;         // log2 of the layout tile width
     const cx<T>* twn;   // W_N^k, k < N (the table of the FULL row length)
+    // fold (see RowStoreFold in fft_io.h): the thread's two rows are the pair (i, i + M/2); plane 0 row i = y[i] + y[i + M/2],
+    // plane 1 row i = (y[i] - y[i + M/2]) W_M^i, nseq = M/2 rows per plane
+    int fold;
+    int64_t plane_stride;   // elements between the planes
+    const cx<T>* twm;       // W_M^k
+    int swap;               // input rows were rotated by M/2: slot 0 holds logical row i + M/2
 };
 
 template <typename T>
@@ -29,6 +35,9 @@ struct HermStore {
     const cx<T>* w0;    // column 0 of the intermediate (layout tile 0), element q at w0[q * w0_stride]
     int64_t w0_stride;
     int nrows_w;        // rows stored in the intermediate
+    int plane;          // folded column transform: -1 none, else the planes are told apart by blockIdx.y (0: even bins, 1: odd bins);
+                        // M is then the length of ONE plane's transform, dst / ld / ay describe the plane's rows (ld doubled)
+    int64_t plane_dst;  // elements (of the output type) from plane 0's first row to plane 1's
     int fast;           // unwindowed output, rotations by 0 or half a length, 16-byte alignable rows: the map-free store applies
 };
 

@@ -279,13 +279,16 @@ def test_real_input_hermitian_transform_vs_numpy(pa, shape, dtype):
     lib = _lib.load()
     try:
         lib.pm_set_tuning(b'r2c', 2)      # the Hermitian path also for the plain complex spectrum (by default only where it pays)
-        got, df = otf.transform_psf(psf, 0.5)
-        assert tonp(got).dtype == (np.complex64 if dtype == np.float32 else np.complex128)
-        assert rel_max(tonp(got), want) < tol
+        for fold in (-1, 1, 0):           # auto; the radix-2 step of the column transform folded into the row pass; never
+            lib.pm_set_tuning(b'fold', fold)
+            got, df = otf.transform_psf(psf, 0.5)
+            assert tonp(got).dtype == (np.complex64 if dtype == np.float32 else np.complex128)
+            assert rel_max(tonp(got), want) < tol, fold
         lib.pm_set_tuning(b'r2c', 0)
         ref, _ = otf.transform_psf(psf, 0.5)
     finally:
         lib.pm_set_tuning(b'r2c', 1)
+        lib.pm_set_tuning(b'fold', -1)
     assert rel_max(tonp(got), tonp(ref)) < tol
     assert df == pytest.approx(1000 / (shape[0] * 0.5))
 
@@ -302,8 +305,17 @@ def test_fused_mtf_ptf_otf_vs_numpy(pa, shape, dtype):
     F = _np_transform_psf(psf)
     norm = F / F[shape[0] // 2, shape[1] // 2]
     tol = TOL32 if dtype == np.float32 else TOL64
-    mtf = tonp(otf.mtf_from_psf(psf, 0.5))
-    assert mtf.dtype == dtype and rel_max(mtf, np.abs(norm)) < tol
+    from prysm_amd import _lib
+    lib = _lib.load()
+    try:
+        for fold in (1, 0, -1):
+            lib.pm_set_tuning(b'fold', fold)
+            mtf = tonp(otf.mtf_from_psf(psf, 0.5))
+            assert mtf.dtype == dtype and rel_max(mtf, np.abs(norm)) < tol, fold
+            o = tonp(otf.otf_from_psf(psf, 0.5))
+            assert rel_max(o, norm) < tol, fold
+    finally:
+        lib.pm_set_tuning(b'fold', -1)
     o = tonp(otf.otf_from_psf(psf, 0.5))
     assert rel_max(o, norm) < tol
     ptf = tonp(otf.ptf_from_psf(psf, 0.5))
