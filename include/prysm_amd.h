@@ -181,6 +181,18 @@ int pm_fft1_ws(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, co
                const pm_axis* t_out, double scale, const void* in, int64_t in_ld, void* out, int64_t out_ld,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* One axis of a chirp-Z transform in ONE kernel (fttools.CZT.__call__ / .adjoint, prysm/fttools.py:297-361: per axis
+ * `fft(x * b, K) -> * H -> ifft -> slice -> * a * phase`):
+ *     out[.., m] = scale * post[m] * IFFT_K( FFT_K( pad_K(pre . in) ) . H )[out_off + m],     m < out_len,
+ * the 1 / K of the inverse included.  axis = 1: the nseq sequences are rows of `in` (in_len samples each, placed at
+ * [in_off, in_off + in_len) of the K-point sequence -- 0 for the forward transform, Mx - 1 ... for the adjoint's zero embedding);
+ * axis = 0: columns.  pre (in_len), H (K) and post (out_len) are complex device vectors of `dtype`, each optionally conjugated
+ * (the adjoint); pre and post may be NULL.  K: a power of two from 16 to 8192 (PM_ERR_UNSUPPORTED otherwise: the caller composes
+ * pm_fft1 and pm_scale_sep).  The K-point sequence stays in the registers of its workgroup between the two transforms. */
+int pm_czt_axis(int32_t dtype, int32_t axis, int64_t nseq, int64_t K, int64_t in_len, int64_t in_off, int64_t out_len, int64_t out_off,
+                const void* pre, int32_t pre_conj, const void* H, int32_t h_conj, const void* post, int32_t post_conj, double scale,
+                const void* in, int64_t in_ld, void* out, int64_t out_ld, void* stream);
+
 /* --- pointwise / synthesis kernels -------------------------------------------------------- */
 
 /* out = a * b (op 0), a * conj(b) (op 1); complex, same shape (rows x cols).

@@ -233,6 +233,21 @@ def fft1(x, n=None, axis=-1, direction=-1, scale=1.0, out_len=None, out_off=0, i
     return out
 
 
+def czt_axis(x, K, axis, H, *, pre=None, post=None, out_len, in_off=0, out_off=0, conj=False, scale=1.0):
+    """One axis of a chirp-Z transform in one kernel (pm_czt_axis): scale * post * IFFT_K(FFT_K(pad_K(pre * x)) * H)[out_off : out_off
+    + out_len] along `axis` of the 2-D tensor x; `conj` conjugates pre, H and post (the adjoint).  K must be an engine length."""
+    lib = L.load()
+    axis = axis % 2
+    rows, cols = x.shape
+    nseq, in_len = (rows, cols) if axis == 1 else (cols, rows)
+    oshape = (rows, out_len) if axis == 1 else (out_len, cols)
+    out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    c = 1 if conj else 0
+    L.check(lib.pm_czt_axis(L.code(x), axis, nseq, int(K), in_len, int(in_off), int(out_len), int(out_off), L.ptr(pre), c, L.ptr(H), c,
+                            L.ptr(post), c, float(scale), L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
 def cmul(a, b, conj_b=False):
     lib = L.load()
     out = torch.empty_like(a)

@@ -213,17 +213,41 @@ class CZT:
         self._Nx, self._Ny, self._Mx, self._My = Nx, Ny, Mx, My
         self._Kx, self._Ky = Kx, Ky
         self._sx, self._sy = Nx - 1, Ny - 1
-        x_first_cost = Ny * Kx * math.log2(Kx) + Mx * Ky * math.log2(Ky)
-        y_first_cost = Nx * Ky * math.log2(Ky) + My * Kx * math.log2(Kx)
+        # which axis first: the reference minimises flops (fttools.py:283-289); here a pass is also slower when it has too few
+        # sequences to fill the chip -- a row pass runs one or two rows per workgroup, a column pass a tile of 64 B of columns --
+        # e.g. 2048^2 -> 512^2: x first leaves the y pass 512 columns = 64 workgroups on 256 CUs (73 us), y first 37 us
+        def _cost(nrow_seq, krow, ncol_seq, kcol):
+            tc = 8 if _cdtype() == torch.complex64 else 4
+            row_wgs = nrow_seq / (2 if krow >= 4096 and _cdtype() == torch.complex64 else max(1, 4096 // max(krow, 16) // 16))
+            col_wgs = ncol_seq / tc
+            return (nrow_seq * krow * math.log2(krow) / min(1.0, max(row_wgs, 1) / 256.0) +
+                    ncol_seq * kcol * math.log2(kcol) / min(1.0, max(col_wgs, 1) / 256.0))
+        x_first_cost = _cost(Ny, Kx, Mx, Ky)      # rows of the (Ny x Nx) input first, then the columns of the (Ny x Mx) result
+        y_first_cost = _cost(My, Kx, Nx, Ky)      # columns of the input first, then the rows of the (My x Nx) result
         self._x_first = x_first_cost <= y_first_cost
 
-    def _xaxis(self, out, scale=1.0):
+    # Engine lengths: one kernel per axis (pm_czt_axis: chirp multiply, K-point transform, x H, inverse, slice, chirp multiply -- the
+    # K-point sequence never leaves the registers of its workgroup); otherwise the composition of pm_fft1 and pm_scale_sep.
+    def _fused(self, K):
+        return _ops._is_pow2_engine(K) and K >= 16
+
+    def _xaxis(self, out, scale=1.0, pre=None):
+        if self._fused(self._Kx):
+            return _ops.czt_axis(out, self._Kx, 1, self._Hcol, pre=pre, post=self._post_col, out_len=self._Mx, out_off=self._sx,
+                                 scale=scale)
+        if pre is not None:
+            out = _ops.scale_sep(out, col_vec=pre)
         out = _ops.fft1(out, self._Kx, axis=1)
         out = _ops.scale_sep(out, col_vec=self._Hcol)
         out = _ops.fft1(out, axis=1, direction=+1, scale=1.0 / self._Kx, out_len=self._Mx, out_off=self._sx)
         return _ops.scale_sep(out, col_vec=self._post_col, scale=scale)
 
-    def _yaxis(self, out, scale=1.0):
+    def _yaxis(self, out, scale=1.0, pre=None):
+        if self._fused(self._Ky):
+            return _ops.czt_axis(out, self._Ky, 0, self._Hrow, pre=pre, post=self._post_row, out_len=self._My, out_off=self._sy,
+                                 scale=scale)
+        if pre is not None:
+            out = _ops.scale_sep(out, row_vec=pre)
         out = _ops.fft1(out, self._Ky, axis=0)
         out = _ops.scale_sep(out, row_vec=self._Hrow)
         out = _ops.fft1(out, axis=0, direction=+1, scale=1.0 / self._Ky, out_len=self._My, out_off=self._sy)
@@ -231,31 +255,52 @@ class CZT:
 
     def __call__(self, ary):
         a = _promote_input(ary, _cdtype()).to(_cdtype())
-        out = _ops.scale_sep(a, row_vec=self._brow, col_vec=self._bcol)
+        if a.stride(-1) != 1:
+            a = a.contiguous()
+        # the input chirps b ride on the load of each axis' kernel (they commute with the other axis' transform)
         if self._x_first:
-            return self._yaxis(self._xaxis(out), scale=self.norm)
-        return self._xaxis(self._yaxis(out), scale=self.norm)
+            return self._yaxis(self._xaxis(a, pre=self._bcol), scale=self.norm, pre=self._brow)
+        return self._xaxis(self._yaxis(a, pre=self._brow), scale=self.norm, pre=self._bcol)
 
-    def _xadj(self, out):
+    def _xadj(self, out, pre=None, post=None, scale=1.0):
         # zero-embed at [sx, sx+Mx) of length Kx, fft, * conj(H), ifft, keep [:Nx]
+        if self._fused(self._Kx):
+            return _ops.czt_axis(out, self._Kx, 1, self._Hcol, pre=pre, post=post, out_len=self._Nx, in_off=self._sx, conj=True,
+                                 scale=scale)
+        if pre is not None:
+            out = _ops.scale_sep(out, col_vec=pre, col_conj=True)
+        out = self._xadj_composed(out)
+        return _ops.scale_sep(out, col_vec=post, col_conj=True, scale=scale) if (post is not None or scale != 1.0) else out
+
+    def _xadj_composed(self, out):
         out = _ops.fft1(out, self._Kx, axis=1, in_off=self._sx)
         out = _ops.scale_sep(out, col_vec=self._Hcol, col_conj=True)
         return _ops.fft1(out, axis=1, direction=+1, scale=1.0 / self._Kx, out_len=self._Nx)
 
-    def _yadj(self, out):
+    def _yadj(self, out, pre=None, post=None, scale=1.0):
+        if self._fused(self._Ky):
+            return _ops.czt_axis(out, self._Ky, 0, self._Hrow, pre=pre, post=post, out_len=self._Ny, in_off=self._sy, conj=True,
+                                 scale=scale)
+        if pre is not None:
+            out = _ops.scale_sep(out, row_vec=pre, row_conj=True)
+        out = self._yadj_composed(out)
+        return _ops.scale_sep(out, row_vec=post, row_conj=True, scale=scale) if (post is not None or scale != 1.0) else out
+
+    def _yadj_composed(self, out):
         out = _ops.fft1(out, self._Ky, axis=0, in_off=self._sy)
         out = _ops.scale_sep(out, row_vec=self._Hrow, row_conj=True)
         return _ops.fft1(out, axis=0, direction=+1, scale=1.0 / self._Ky, out_len=self._Ny)
 
     def adjoint(self, grad):
         g = _promote_input(grad, _cdtype()).to(_cdtype())
-        out = _ops.scale_sep(g, row_vec=self._post_row, col_vec=self._post_col, row_conj=True, col_conj=True)
+        if g.stride(-1) != 1:
+            g = g.contiguous()
+        # conj(a * phase) on the way in, conj(b) on the way out, per axis (each commutes with the other axis' transform)
         if self._x_first:
-            out = self._xadj(self._yadj(out))
-        else:
-            out = self._yadj(self._xadj(out))
-        return _ops.scale_sep(out, row_vec=self._brow, col_vec=self._bcol, row_conj=True, col_conj=True,
-                              scale=self.norm)
+            out = self._yadj(g, pre=self._post_row, post=self._brow)
+            return self._xadj(out, pre=self._post_col, post=self._bcol, scale=self.norm)
+        out = self._xadj(g, pre=self._post_col, post=self._bcol)
+        return self._yadj(out, pre=self._post_row, post=self._brow, scale=self.norm)
 
     def nbytes(self):
         total = 0
