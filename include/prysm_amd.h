@@ -282,6 +282,13 @@ int pm_embed(int32_t elem_bytes, int64_t irows, int64_t icols, const void* in, i
              int64_t ocols, int64_t off_y, int64_t off_x, const void* fill_elem_host, void* out, int64_t out_ld,
              void* stream);
 
+/* The index-mapping modes of np.pad that fttools.pad2d(mode=...) forwards to (prysm/fttools.py:96-98): out (orows x ocols) holds
+ * in at (off_y, off_x) and, around it, in[map(r)][map(c)] with mode 1 = 'edge', 2 = 'reflect', 3 = 'symmetric', 4 = 'wrap'
+ * (any pad width, also wider than the array).  elem_bytes in {1, 4, 8, 16}.  The statistical modes ('mean', 'maximum', 'minimum',
+ * 'median', 'linear_ramp') are not on the device: the mirror package raises NotImplementedError for them. */
+int pm_pad_index(int32_t elem_bytes, int32_t mode, int64_t irows, int64_t icols, const void* in, int64_t in_ld, int64_t orows,
+                 int64_t ocols, int64_t off_y, int64_t off_x, void* out, int64_t out_ld, void* stream);
+
 /* --- matrix DFT --------------------------------------------------------------------------- */
 
 /* E[m][n] = exp(sign * 2 pi i * f[m] * x[n]) (M x N), phases reduced in fp64, rounded once.

@@ -77,6 +77,7 @@ SIGNATURES = {
     'pm_as_tf_vectors': (c_i32, [c_i32, c_i64, c_i64, c_f64, c_f64, c_f64, c_vp, c_vp, c_vp]),
     'pm_outer': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'pm_embed': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    'pm_pad_index': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]),
     'pm_mdft_basis': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
     'pm_mdft_basis_grid': (c_i32, [c_i32, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_i32, c_vp, c_i64, c_vp]),
     'pm_cgemm': (c_i32, [c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_f64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,

@@ -455,6 +455,25 @@ def embed(x, out_shape, off, fill=0):
     return out
 
 
+_PAD_MODES = {'edge': 1, 'reflect': 2, 'symmetric': 3, 'wrap': 4}
+
+
+def pad_index(x, out_shape, off, mode):
+    """np.pad(x, ..., mode=mode) for the index-mapping modes ('edge', 'reflect', 'symmetric', 'wrap'): x lands at `off` of `out_shape`."""
+    lib = L.load()
+    m, n = x.shape
+    om, on = out_shape
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    es = x.element_size()
+    if es == 2:
+        raise NotImplementedError('pad2d of 2-byte element arrays is not supported')
+    out = torch.empty((om, on), dtype=x.dtype, device=x.device)
+    L.check(lib.pm_pad_index(es, _PAD_MODES[mode], m, n, L.ptr(x), x.stride(0) if m > 1 else n, om, on, int(off[0]), int(off[1]),
+                             L.ptr(out), out.stride(0) if om > 1 else on, L.stream_ptr()))
+    return out
+
+
 def mdft_basis(f, x, sign, cdtype):
     """E[m, n] = exp(sign 2 pi i f[m] x[n])."""
     lib = L.load()

@@ -338,6 +338,32 @@ __global__ void embed_kernel(int64_t irows, int64_t icols, const V* in, int64_t 
     }
 }
 
+// np.pad's index-mapping modes (fttools.pad2d(mode=...), prysm/fttools.py:96-98): output index r (relative to the first input
+// sample) reads input index map(r); 1 edge, 2 reflect (period 2n - 2, the edge sample not repeated), 3 symmetric (period 2n), 4 wrap
+__device__ __forceinline__ int64_t pad_map(int64_t r, int64_t n, int mode) {
+    if (r >= 0 && r < n) return r;
+    if (n == 1) return 0;
+    if (mode == 1) return r < 0 ? 0 : n - 1;
+    if (mode == 4) {
+        r %= n;
+        return r < 0 ? r + n : r;
+    }
+    const int64_t period = mode == 2 ? 2 * n - 2 : 2 * n;
+    r %= period;
+    if (r < 0) r += period;
+    if (r < n) return r;
+    return mode == 2 ? period - r : period - 1 - r;
+}
+template <typename V>
+__global__ void pad_index_kernel(int mode, int64_t irows, int64_t icols, const V* in, int64_t ldi, int64_t orows, int64_t ocols,
+                                 int64_t offy, int64_t offx, V* o, int64_t ldo) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= ocols) return;
+    const int64_t ic = pad_map(c - offx, icols, mode);
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < orows; r += int64_t(gridDim.y) * blockDim.y)
+        o[r * ldo + c] = in[pad_map(r - offy, irows, mode) * ldi + ic];
+}
+
 // ---------------------------------------------------------------- MDFT basis
 template <typename T>
 __global__ void mdft_basis_kernel(int64_t M, int64_t N, const T* f, const T* x, double sign, cx<T>* E, int64_t ldE) {
@@ -634,6 +660,27 @@ int pm_embed(int32_t elem_bytes, int64_t irows, int64_t icols, const void* in, i
         default: return fail(PM_ERR_ARG, "pm_embed: elem_bytes must be 1, 4, 8 or 16");
     }
 #undef PM_EMBED
+    return int(hipGetLastError());
+}
+
+int pm_pad_index(int32_t elem_bytes, int32_t mode, int64_t irows, int64_t icols, const void* in, int64_t in_ld, int64_t orows,
+                 int64_t ocols, int64_t off_y, int64_t off_x, void* out, int64_t out_ld, void* stream) {
+    if (!in || !out || irows < 1 || icols < 1 || orows < 0 || ocols < 0 || mode < 1 || mode > 4)
+        return fail(PM_ERR_ARG, "pm_pad_index: bad argument");
+    if (orows == 0 || ocols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(orows, ocols, block);
+    hipStream_t st = PM_STREAM(stream);
+#define PM_PADI(V) \
+    hipLaunchKernelGGL(pad_index_kernel<V>, grid, block, 0, st, mode, irows, icols, (const V*)in, in_ld, orows, ocols, off_y, off_x, (V*)out, out_ld)
+    switch (elem_bytes) {
+        case 1: PM_PADI(unsigned char); break;
+        case 4: PM_PADI(float); break;
+        case 8: PM_PADI(double); break;
+        case 16: PM_PADI(double2); break;
+        default: return fail(PM_ERR_ARG, "pm_pad_index: elem_bytes must be 1, 4, 8 or 16");
+    }
+#undef PM_PADI
     return int(hipGetLastError());
 }
 

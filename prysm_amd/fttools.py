@@ -56,11 +56,16 @@ def pad2d(array, Q=2, value=0, mode='constant', out_shape=None):
         out_shape = [math.ceil(s * Q) for s in in_shape]
     elif isinstance(out_shape, int):
         out_shape = [out_shape] * array.dim()
-    if mode != 'constant':
-        raise NotImplementedError("pad2d: only mode='constant' runs on the device")
     shape_diff = [o - i for o, i in zip(out_shape, in_shape)]
-    off = [math.ceil(d / 2) for d in shape_diff]
-    return _ops.embed(array, tuple(out_shape), off, fill=value)
+    off = [math.ceil(d / 2) for d in shape_diff]      # np.pad widths (d - d // 2, d // 2): the same offset
+    if mode == 'constant':
+        return _ops.embed(array, tuple(out_shape), off, fill=value)
+    if mode in _ops._PAD_MODES and array.dim() == 2 and all(d >= 0 for d in shape_diff):
+        return _ops.pad_index(array, tuple(out_shape), off, mode)
+    if mode == 'empty':
+        return _ops.embed(array, tuple(out_shape), off, fill=0)     # np.pad leaves the border undefined; zeros are a valid instance
+    raise NotImplementedError(f"pad2d: np.pad mode {mode!r} is not on the device (constant, edge, reflect, symmetric, wrap and "
+                              "empty are); the statistical modes need reductions over the array")
 
 
 def crop_center(img, out_shape):

@@ -346,6 +346,22 @@ def test_hermitian_epilogues_refused_elsewhere(pa):
         _ops.fft2(z.real.contiguous(), direction=-1, scale=1.0, shape=(128, 128), flags=L.PM_FLAG_NORM_DC)     # padded input
 
 
+@pytest.mark.parametrize('mode', ['edge', 'reflect', 'symmetric', 'wrap'])
+def test_pad2d_modes_match_numpy_pad(pa, mode):
+    """fttools.pad2d(mode != 'constant') forwards to np.pad with widths (d - d // 2, d // 2) (prysm/fttools.py:79-98)"""
+    from prysm_amd import fttools
+    rng = np.random.default_rng(11)
+    for shape, out_shape in (((9, 12), (14, 18)), ((5, 4), (17, 21)), ((1, 6), (4, 6)), ((8, 8), (8, 8))):
+        for dt in (np.float32, np.complex128, np.bool_):
+            a = (rng.random(shape) > 0.5) if dt is np.bool_ else rng.standard_normal(shape).astype(dt)
+            diff = [o - i for o, i in zip(out_shape, shape)]
+            want = np.pad(a, [(d - d // 2, d // 2) for d in diff], mode=mode)
+            got = tonp(fttools.pad2d(a, out_shape=out_shape, mode=mode))
+            assert got.dtype == want.dtype and np.array_equal(got, want), (shape, out_shape, dt)
+    with pytest.raises(NotImplementedError):
+        fttools.pad2d(np.ones((4, 4)), Q=2, mode='mean')
+
+
 # ----------------------------------------------------------------------------- ADVICE r1
 
 def test_babinet_takes_a_boolean_occulter(pa):
