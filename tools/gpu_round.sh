@@ -1,17 +1,22 @@
 #!/bin/bash
-# One GPU-box session: parity tests, smoke, bench, rocprof kernel trace + PMC traffic.  Output -> gpurun_out/
-mkdir -p gpurun_out
+# One GPU-box session for the round's judged artefacts: parity tests, smoke, the default bench line, rocprofv3 kernel stats and
+# PMC traffic (FETCH_SIZE / WRITE_SIZE in separate runs) for the headline loop and for every other BASELINE config.  Output ->
+# gpurun_out/round/ ; tools/save_profiles.sh copies the summaries into profiles/<round>/.
 export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-$PWD}
-( timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 ) > gpurun_out/pytest_gpu.log 2>&1
-( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > gpurun_out/smoke.log 2>&1
-( timeout 600 python bench.py --steps 200 --warmup 20 ) > gpurun_out/bench.log 2>&1
-B="python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-poly"
-rm -rf gpurun_out/prof_bench gpurun_out/pmc_bench_fetch gpurun_out/pmc_bench_write
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -- $B ) > gpurun_out/rocprof_bench.log 2>&1
-( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_bench_fetch -- $B ) > gpurun_out/rocprof_pmc_fetch.log 2>&1
-( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_bench_write -- $B ) > gpurun_out/rocprof_pmc_write.log 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_bench_fetch gpurun_out/pmc_bench_write gpurun_out/pmc_bench_summary.json > gpurun_out/pmc_bench_summary.txt 2>&1
-for m in bench batch fused gemm; do ( timeout 300 $R/tools/pm_gpu_check $m 2>&1 | grep -E "BENCH|CHECK" ) > gpurun_out/check_$m.log 2>&1; done
-tail -3 gpurun_out/pytest_gpu.log; cat gpurun_out/smoke.log | tail -2; cat gpurun_out/bench.log | tail -1 | cut -c1-600
-cat gpurun_out/pmc_bench_summary.txt
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
+( timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 ) > $O/pytest_gpu.log 2>&1
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
+( timeout 900 python bench.py ) > $O/bench.log 2>&1
+prof() {   # name, bench arguments...
+  n=$1; shift
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$n -- python $R/bench.py "$@" ) > $O/rocprof_$n.log 2>&1
+  ( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$n -- python $R/bench.py "$@" ) > $O/rocprof_pmcf_$n.log 2>&1
+  ( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$n -- python $R/bench.py "$@" ) > $O/rocprof_pmcw_$n.log 2>&1
+  python tools/pmc_summary.py $O/pmc_fetch_$n $O/pmc_write_$n $O/pmc_${n}_summary.json "bench.py $*" > $O/pmc_${n}_summary.txt 2>&1
+  cp "$(ls $O/prof_$n/*/*kernel_stats.csv | tail -1)" $O/${n}_kernel_stats.csv
+}
+prof bench --steps 40 --warmup 5 --no-cpu-baseline --no-poly
+for c in config2 config3 config4 c128 n8192 mtf; do prof $c --only $c; done
+( cd /tmp && timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq_config4 -- python $R/bench.py --only config4 ) > $O/rocprof_sq_config4.log 2>&1
+python tools/pmc_clock.py $O/pmc_sq_config4 2>&1 | grep pm:: > $O/config4_mfma_busy.txt
+tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; tail -1 $O/bench.log | cut -c1-400; cat $O/pmc_bench_summary.txt; cat $O/config4_mfma_busy.txt

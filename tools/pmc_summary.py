@@ -19,6 +19,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def short(n):
+    m = re.search(r'cgemm_dma_kernel<(\d+), (\d+)', n)
+    if m:
+        return f'cgemm_dma_{64 * int(m.group(1))}x{64 * int(m.group(2))}_f32'
     if 'cgemm' in n:
         return 'cgemm_' + ('f32' if '<float' in n else 'f64')
     if 'splitk' in n:
@@ -26,8 +29,15 @@ def short(n):
     m = re.search(r'FftCfg<(\w+), (\d+), (\d+), (\d+), (\d+), (\d+)>', n)
     if m:
         kind = 'row_pass' if 'RowLoad' in n else 'column_pass'
-        pers = '_persistent' if 'persistent' in n else ''
-        return f'fft_{kind}{pers}_{m.group(1)}_N{1 << int(m.group(2))}'
+        if 'r2c' in n:
+            kind = 'row_pass_r2c'
+        elif 'herm' in n:
+            kind = 'column_pass_herm'
+        elif 'conv1' in n:
+            kind = 'czt_axis_' + ('cols' if ', true>' in n else 'rows')
+        elif 'col_mul' in n:
+            kind = 'column_pass_mul'
+        return f'fft_{kind}_{m.group(1)}_N{1 << int(m.group(2))}'
     return re.sub(r'\(.*', '', n)[:60]
 
 
@@ -53,7 +63,7 @@ def main():
                   'hbm_read_bytes_corrected': rd, 'hbm_write_bytes': wr, 'hbm_traffic_bytes': rd + wr}
     # what these counters describe: the kernel sources of THIS tree (bench.py prints `traffic` only while they still match)
     from bench import source_fingerprint
-    meta = {'source_fingerprint': source_fingerprint(), 'command': 'bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-poly',
+    meta = {'source_fingerprint': source_fingerprint(), 'command': sys.argv[4] if len(sys.argv) > 4 else 'bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-poly',
             'passes': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs; FETCH_SIZE doubled (gfx950)'}
     json.dump(dict(out, _meta=meta), open(sys.argv[3], 'w'), indent=1)
     for k, v in out.items():
