@@ -154,17 +154,22 @@ def pmc_traffic(kernel, n, dtype_name):
     return None, 'kernel not in the PMC summary'
 
 
-def _event_ms(fn, reps, warm=3):
+def _event_ms(fn, reps, warm=3, batches=3):
+    """HIP-event time per call: the median of `batches` back-to-back batches of `reps` calls (side measurements only; the
+    headline loop is timed once, as the contract says)."""
     for _ in range(warm):
         fn()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    out = []
+    for _ in range(batches):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / reps)
+    return sorted(out)[len(out) // 2]
 
 
 def _hbm_entry(ms, nbytes, note=None):
