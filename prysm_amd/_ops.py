@@ -98,7 +98,8 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
     mul, mul_x : None | full (M, N) multiplier | (column vector hy (M,), row vector hx (N,)); with a stack,
                  (B, M, N) / ((B, M), (B, N)) give one multiplier per field
     synth      : (amp | None, k): x is the real float32 OPD map and the transformed field is amp * exp(i k x),
-                 synthesised while the row pass loads it (see synth_supported)
+                 synthesised while the row pass loads it (see synth_supported); ('packed', k): x is a complex64 tensor
+                 holding (amplitude, OPD) pairs (pack_amp_opd)
     out        : optional result / accumulator (PM_EPI_ABS2_ACCUM); must match the dtype and shape the call produces
     """
     lib = L.load()
@@ -116,12 +117,13 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
         out = torch.empty(oshape, dtype=odt, device=x.device)
     else:
         _check_out(out, x, oshape, odt)
-    amp = synth[0] if synth is not None else None
+    packed = synth is not None and isinstance(synth[0], str)
+    amp = synth[0] if (synth is not None and not packed) else None
     if mul is not None and mul_x is not None and x.dim() == 3 and mul.dim() == 2:
         mul, mul_x = mul.contiguous(), mul_x.contiguous()      # per-field (hy, hx) vectors: rows of two (B, .) arrays
     key = (x.dtype, tuple(x.shape), x.stride(), M, N, tuple(in_off), tuple(in_shift), om, on, tuple(out_off), tuple(out_shift),
            direction, epilogue, flags, float(scale), bool(mul_conj), out.stride(),
-           None if synth is None else (True, None if amp is None else (amp.dtype, amp.stride())),
+           None if synth is None else (True, packed, None if amp is None else (amp.dtype, amp.stride())),
            None if mul is None else (tuple(mul.shape), mul.stride()), None if mul_x is None else (tuple(mul_x.shape), mul_x.stride()))
     plan = _fft2_plans.get(key)
     if plan is None:
@@ -133,7 +135,7 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
         d.scale = float(scale)
         d.weight = 1.0
         if synth is not None:
-            d.flags = (d.flags & ~L.PM_FLAG_REAL_INPUT) | L.PM_FLAG_SYNTH_INPUT
+            d.flags = (d.flags & ~L.PM_FLAG_REAL_INPUT) | L.PM_FLAG_SYNTH_INPUT | (L.PM_FLAG_SYNTH_PACKED if packed else 0)
             if amp is not None:
                 d.synth_amp_dtype = _AMP_CODE[amp.dtype]
                 d.synth_amp_ld = amp.stride(0) if amp.shape[0] > 1 else amp.shape[1]
@@ -167,6 +169,13 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
     if rc:
         L.check(rc)
     return out
+
+
+def pack_amp_opd(amp, opd):
+    """(amplitude, OPD) float32 pairs as a complex64 tensor -- the input of fft2(..., synth=('packed', k)).  A loop over
+    wavelengths packs its two maps once and then reads ONE 8-byte element per sample in every transform."""
+    a = torch.ones_like(opd) if amp is None else amp.to(torch.float32)
+    return torch.view_as_complex(torch.stack((a, opd.to(torch.float32)), dim=-1).contiguous())
 
 
 def _is_pow2_engine(n):

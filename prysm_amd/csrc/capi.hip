@@ -161,8 +161,8 @@ static int check_axis(const pm_axis& a, const char* name) {
 // input mode of the row loader from the descriptor flags: complex, real, or pupil synthesis
 template <typename T>
 static void set_input_mode(RowLoadNat<T>& lp, const pm_fft2_desc* d) {
-    lp.real = (d->flags & PM_FLAG_SYNTH_INPUT) ? 2 : ((d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0);
-    if (lp.real == 2) {
+    lp.real = (d->flags & PM_FLAG_SYNTH_INPUT) ? ((d->flags & PM_FLAG_SYNTH_PACKED) ? 3 : 2) : ((d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0);
+    if (lp.real >= 2) {
         lp.amp = d->synth_amp;
         lp.amp_kind = !d->synth_amp ? 0 : (d->synth_amp_dtype == PM_F32 ? 1 : (d->synth_amp_dtype == PM_F64 ? 2 : 3));
         lp.amp_ld = d->synth_amp_ld;
@@ -884,6 +884,8 @@ static int check_fft2(const pm_fft2_desc* d) {
     if (d->in_y.n != d->out_y.n || d->in_x.n != d->out_x.n)
         return fail(PM_ERR_ARG, "pm_fft2: input and output views must share the transform size");
     if (d->in_ld < d->in_x.len || d->out_ld < d->out_x.len) return fail(PM_ERR_ARG, "pm_fft2: leading dimension < row length");
+    if ((d->flags & PM_FLAG_SYNTH_PACKED) && !(d->flags & PM_FLAG_SYNTH_INPUT))
+        return fail(PM_ERR_ARG, "pm_fft2: PM_FLAG_SYNTH_PACKED qualifies PM_FLAG_SYNTH_INPUT");
     if (d->flags & PM_FLAG_SYNTH_INPUT) {
         if (d->direction != -1) return fail(PM_ERR_ARG, "pm_fft2: PM_FLAG_SYNTH_INPUT is a forward transform");
         if (d->dtype != PM_C64 || engine_log2(d->in_x.n) < 0 || d->batch > 1)

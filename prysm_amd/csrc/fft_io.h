@@ -39,6 +39,8 @@ struct RowLoadNat {
     int real;       // the array is REAL (T, not cx<T>): src points at T, ld / bstride count real elements, imag = 0
     int eoff;       // E > 1: sequence of slot e is unit*E + e (eoff == 0, consecutive rows) or unit + e*eoff (rows eoff apart:
                     // the pair (i, i + M/2) of a folded column transform)
+    // real == 3: the same synthesis from PACKED (amplitude, OPD) pairs -- src is read as complex (re = amplitude, im = OPD): one
+    // 8-byte load per element instead of two 4-byte loads from two arrays (a wavelength loop packs the two maps once)
     // real == 2: PUPIL SYNTHESIS on the fly -- src is the real OPD map and the element is amp * exp(2 pi i * k2 * opd)
     // (Wavefront.from_amp_and_phase, prysm/propagation/wavefront.py:58-79, fused into the load: the complex pupil is
     // never written to memory).  amp_kind: 0 unit amplitude, 1 float, 2 double, 3 bool / uint8.
@@ -335,7 +337,7 @@ PM_HD T synth_amp(const void* amp, int kind, int64_t idx) {
 // Field b of a batch (blockIdx.y) is the same problem at an offset: a copy of the parameter block with
 // the base pointers advanced.  The parameter blocks live in SGPRs, so this is a handful of scalar ops.
 template <typename T> PM_HD RowLoadNat<T> at_batch(RowLoadNat<T> p, int b) {
-    if (p.real)
+    if (p.real == 1 || p.real == 2)
         p.src = reinterpret_cast<const cx<T>*>(reinterpret_cast<const T*>(p.src) + int64_t(b) * p.bstride);
     else
         p.src += int64_t(b) * p.bstride;
@@ -390,7 +392,10 @@ PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
             const int pp = slot_pos<C, ROT>(pos.t, m, p.ax.shift);
             cx<T> val = {T(0), T(0)};
             if (FULL || (pp >= lo && pp < hi)) {
-                if constexpr (MODE == 2)
+                if constexpr (MODE == 3) {
+                    const cx<T> ao = p.nt ? nt_load_cx(row + pp) : row[pp];
+                    val = synth_value<T>(ao.y, ao.x, p.k2);
+                } else if constexpr (MODE == 2)
                     val = synth_value<T>(rrow[pp], synth_amp<T>(p.amp, p.amp_kind, arow + pp), p.k2);
                 else if constexpr (MODE == 1)
                     val.x = p.nt ? nt_load_s(rrow + pp) : rrow[pp];
@@ -399,7 +404,7 @@ PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
             }
             v[e][m] = val;
         }
-        if (MODE != 1 && p.conj) {
+        if (MODE == 0 && p.conj) {
 #pragma unroll
             for (int m = 0; m < C::P; ++m) v[e][m].y = -v[e][m].y;
         }
@@ -428,6 +433,10 @@ PM_HD void load(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<t
     if constexpr (sizeof(typename C::T) == 4) {   // synthesis only on the complex64 path (fp64 sincospi would dominate the pass)
         if (p.real == 2) {
             load_sel<C, 2>(p, blk, pos, v);
+            return;
+        }
+        if (p.real == 3) {
+            load_sel<C, 3>(p, blk, pos, v);
             return;
         }
     }

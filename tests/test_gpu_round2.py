@@ -105,6 +105,23 @@ def test_config5_variant_m_full_size(pa, config5):
     assert rel_max(got, c['want_m']) < 1e-4     # K = 4096 complex64 contractions, squared and summed 64 times
 
 
+def test_packed_amp_opd_synthesis_equals_two_array_synthesis(pa):
+    """PM_FLAG_SYNTH_PACKED: the pupil synthesised from (amplitude, OPD) pairs read as one 8-byte element is bit for bit the
+    pupil synthesised from the two arrays (same arithmetic, different loads), folded and unfolded, padded and not"""
+    from prysm_amd import _ops
+    P = pa.propagation
+    rng = np.random.default_rng(21)
+    for n, Q in ((256, 1), (256, 2), (4096, 1)):
+        amp = torch.from_numpy((rng.random((n, n)) > 0.3).astype(np.float32)).cuda()
+        opd = torch.from_numpy((300 * rng.standard_normal((n, n))).astype(np.float32)).cuda()
+        k = 2 * np.pi / 0.55 / 1e3
+        a = P.focus_intensity(opd, Q, synth=(amp, k))
+        b = P.focus_intensity(_ops.pack_amp_opd(amp, opd), Q, synth=('packed', k))
+        assert torch.equal(a, b), (n, Q)
+    ref = O.intensity(O.focus(O.from_amp_and_phase(amp.cpu().numpy().astype(np.float64), opd.cpu().numpy().astype(np.float64), 0.55), 1))
+    assert rel_max(tonp(b), ref) < 2e-5
+
+
 # ----------------------------------------------------------------------------- reference identities
 
 def test_array_orientation_consistency_tilt(pa):

@@ -308,7 +308,7 @@ static void calibrate() {
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0));
     HIPCHECK(hipEventCreate(&e1));
-    for (size_t mb : {128, 512, 2048}) {
+    for (size_t mb : {8, 32, 128, 512, 2048}) {
         void *a, *b;
         HIPCHECK(hipMalloc(&a, mb << 20));
         HIPCHECK(hipMalloc(&b, mb << 20));
@@ -329,7 +329,7 @@ static void calibrate() {
     }
     // the three-buffer cycle of one propagation (in -> ws -> out, 128 MiB each) done by plain copies: the
     // time two PERFECT streaming passes would take in the same cache regime as the real transform
-    for (size_t mb : {128, 256}) {
+    for (size_t mb : {8, 32, 128, 256}) {
         void *in, *ws, *out;
         HIPCHECK(hipMalloc(&in, mb << 20));
         HIPCHECK(hipMalloc(&ws, mb << 20));
