@@ -141,8 +141,9 @@ typedef struct pm_fft2_desc {
     double synth_k;
 } pm_fft2_desc;
 
-/* Transform lengths (per axis): powers of two from 2 to 8192 run on the Stockham engine; 16384 and 32768 (when both axes are
- * powers of two) take one radix-2 / radix-4 step around engine transforms (16384^2 complex64: 6.2 ms); other lengths from 96 to 4096 run on
+/* Transform lengths (per axis): powers of two from 2 to 8192 run on the Stockham engine; 16384 and 32768 take one radix-2 / radix-4
+ * step around engine transforms (16384^2 complex64: 6.2 ms), and so do 3 / 5 / 7 x 2^k from 96 (1536, 2560, 3584, 6144 ...: radix 3 / 5 / 7)
+ * when the other axis is a power of two or such a length too; other lengths from 96 to 4096 run on
  * the same engine through Bluestein's identity (chirp multiply, power-of-two convolution of length >= 2n - 1, chirp multiply;
  * when both axes are such lengths the 2-D convolution is ONE fused fft2 x B ifft2 chain, and that form reaches 16384 per axis by
  * convolving at 16384 / 32768 points: 8000^2 complex64 11.4 ms); shorter lengths, and other lengths

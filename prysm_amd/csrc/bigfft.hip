@@ -1,5 +1,7 @@
-// Power-of-two lengths ABOVE the engine's longest transform (8192): 16384 and 32768 per axis, by one radix-R step (R = 2 or 4)
-// around engine transforms of length n' = n / R.  MI355X has the memory for such fields (16384^2 complex64 = 2 GiB of 288);
+// Lengths n = R n' with n' a power of two the engine transforms: the powers of two ABOVE its longest transform (16384 and 32768
+// per axis, R = 2 or 4) and the mixed-radix lengths 3 / 5 / 7 x 2^k (1536, 2560, 3584, 6144 ...: what scipy's next_fast_len and
+// Q = 1.5 pads produce), by one radix-R step around engine transforms of length n'.  The mixed lengths used to pay Bluestein's
+// convolution at the next power of two above 2n (7 - 16x the area in 2-D).  MI355X has the memory for such fields (16384^2 complex64 = 2 GiB of 288);
 // before this path they fell to the O(n^2) direct kernel (12 s for 16384^2).
 //
 //   rows    (decimation in frequency, the input is ours to pre-process): for j < n', m < R
@@ -15,16 +17,23 @@
 
 namespace pm {
 
-// W_R^e for R = 2 or 4 applied exactly: multiply by (-i)^(e * 4 / R)
+constexpr int kMaxRadix = 8;
+
+// v W_R^e.  R = 2 or 4: exact, a multiplication by (-i)^(e * 4 / R); other R: W_R^e = W_n^{(e mod R) n'} from the table of the
+// full length (step = n' = n / R)
 template <typename T>
-__device__ __forceinline__ cx<T> mul_wr(cx<T> v, int e, int R) {
-    const int q = (e * (4 / R)) & 3;   // quarter turns of exp(-2 pi i / 4)
-    switch (q) {
-        case 0: return v;
-        case 1: return {v.y, -v.x};    // * (-i)
-        case 2: return {-v.x, -v.y};
-        default: return {-v.y, v.x};   // * (+i)
+__device__ __forceinline__ cx<T> mul_wr(cx<T> v, int e, int R, const cx<T>* twn, int64_t step) {
+    if (R == 2 || R == 4) {
+        const int q = (e * (4 / R)) & 3;   // quarter turns of exp(-2 pi i / 4)
+        switch (q) {
+            case 0: return v;
+            case 1: return {v.y, -v.x};    // * (-i)
+            case 2: return {-v.x, -v.y};
+            default: return {-v.y, v.x};   // * (+i)
+        }
     }
+    const int em = e % R;
+    return em ? cmul(v, twn[int64_t(em) * step]) : v;
 }
 
 // Y[m][i][j], planes of M x n' (all M LOGICAL rows: rows outside the stored window come out zero)
@@ -33,12 +42,12 @@ __global__ void big_pre_rows_kernel(Blue2dIn<T> in, int M, int np, int R, cx<T>*
     const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (g >= int64_t(M) * np) return;
     const int i = int(g / np), j = int(g - int64_t(i) * np);
-    cx<T> x[4];
+    cx<T> x[kMaxRadix];
     for (int r = 0; r < R; ++r) x[r] = fetch2d(in, i, j + r * np);
     const int64_t plane = int64_t(M) * np;
     for (int m = 0; m < R; ++m) {
         cx<T> s{T(0), T(0)};
-        for (int r = 0; r < R; ++r) s = s + mul_wr(x[r], r * m, R);
+        for (int r = 0; r < R; ++r) s = s + mul_wr(x[r], r * m, R, twN, int64_t(np));
         Y[int64_t(m) * plane + g] = m ? cmul(s, twN[int64_t(j) * m]) : s;
     }
 }
@@ -52,14 +61,14 @@ __global__ void big_finish_kernel(const cx<T>* F, int mp, int np, int Rm, int Rn
     const int kp = int(g / N), c = int(g - int64_t(kp) * N);
     const int k = c / Rn, m = c - k * Rn;
     const int64_t plane = int64_t(mp) * np;
-    cx<T> t[4];
+    cx<T> t[kMaxRadix];
     for (int r = 0; r < Rm; ++r) {
         const cx<T> f = F[(int64_t(m) * Rm + r) * plane + int64_t(kp) * np + k];
         t[r] = r ? cmul(f, twM[int64_t(r) * kp]) : f;
     }
     for (int q = 0; q < Rm; ++q) {
         cx<T> s{T(0), T(0)};
-        for (int r = 0; r < Rm; ++r) s = s + mul_wr(t[r], r * q, Rm);
+        for (int r = 0; r < Rm; ++r) s = s + mul_wr(t[r], r * q, Rm, twM, int64_t(mp));
         store_one(o, kp + q * mp, c, s);
     }
 }

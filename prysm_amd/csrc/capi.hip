@@ -121,6 +121,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("nt_in")) t.nt_in = v;
     else if (is("nt_out")) t.nt_out = v;
     else if (is("fold")) t.fold = v;
+    else if (is("mixed_radix")) t.mixed_radix = v ? 1 : 0;
     else if (is("r2c")) t.r2c = v < 0 ? -1 : (v > 1 ? 2 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
     else if (is("blue_min")) t.blue_min = v < 0 ? 0 : v;
@@ -992,6 +993,13 @@ int pm_plan_prepare(int32_t dtype, int64_t n) {
     if (n < 1) return fail(PM_ERR_ARG, "pm_plan_prepare: n < 1");
     int err = 0;
     if (dtype != PM_C64 && dtype != PM_C128) return fail(PM_ERR_ARG, "pm_plan_prepare: dtype");
+    if (big_split(n) > 1) {   // one radix-R step around engine transforms (bigfft.hip): the tables of n and of n / R
+        const int64_t part = n / big_split(n);
+        const bool ok = dtype == PM_C64 ? (twiddles<float>(n, &err) && twiddles<float>(part, &err))
+                                        : (twiddles<double>(n, &err) && twiddles<double>(part, &err));
+        if (!ok) return err;
+        if (engine_log2(n) >= 0 || !use_blue_long(n)) return 0;     // a mixed-radix length beside an awkward one still takes Bluestein
+    }
     if (use_blue_long(n)) {   // Bluestein tables of n and the twiddles of the convolution length (of its engine part when it is split)
         const int64_t mb = blue_conv_len(n), part = mb / big_split(mb);
         if (dtype == PM_C64) return (blue_tables<float>(n, &err) && twiddles<float>(mb, &err) && twiddles<float>(part, &err)) ? 0 : err;

@@ -110,6 +110,7 @@ struct Tuning {
     int blue_fuse = 1;        // both-axes form on engine lengths: chirp multiplies inside the chain's first load / last store (1)
                              // or as separate kernels around it (0)
     int blue_2d = 1;          // both axes on the Bluestein path: one fused fft2 x B ifft2 chain (1) or axis by axis (0)
+    int mixed_radix = 1;      // lengths 3 / 5 / 7 x 2^k take one radix-R step around engine transforms (bigfft.hip); 0: Bluestein, as in round 1
     int big_native_log = 13;  // log2 of the longest length handed to the engine as it is; longer powers of two (up to 4x) take
                              // one radix-2 / radix-4 step around engine transforms (bigfft.hip).  Tests lower it to run that
                              // path on small arrays.
@@ -138,13 +139,23 @@ inline int engine_log2(int64_t n) {  // log2(n) if n is a power of two the engin
     return l <= kEngineMaxLog ? l : -1;
 }
 
-// split of a power-of-two length for the big path: R = 1 (native), 2 or 4; 0 = not a length this path takes
+// split n = R n' for the path of bigfft.hip (n' a power of two the engine transforms): R = 1 (native), 2 or 4 (powers of two above the
+// engine's longest transform), 3 / 5 / 7 (mixed-radix lengths from 96: 1536, 2560, 3584 ...); 0 = not a length this path takes
 inline int big_split(int64_t n) {
-    if (n < 2 || (n & (n - 1))) return 0;
+    if (n < 2) return 0;
     const int64_t native = int64_t(1) << tuning().big_native_log;
-    if (n <= native) return 1;
-    if (n == 2 * native) return 2;
-    if (n == 4 * native) return 4;
+    if ((n & (n - 1)) == 0) {
+        if (n <= native) return 1;
+        if (n == 2 * native) return 2;
+        if (n == 4 * native) return 4;
+        return 0;
+    }
+    if (!tuning().mixed_radix || n < 96) return 0;
+    for (int R = 3; R <= 7; R += 2) {
+        if (n % R) continue;
+        const int64_t q = n / R;
+        if ((q & (q - 1)) == 0 && q >= 16 && q <= native && q <= (int64_t(1) << kEngineMaxLog)) return R;
+    }
     return 0;
 }
 

@@ -122,6 +122,39 @@ def test_packed_amp_opd_synthesis_equals_two_array_synthesis(pa):
     assert rel_max(tonp(b), ref) < 2e-5
 
 
+@pytest.mark.parametrize('shape', [(96, 160), (1536, 1536), (2560, 1024), (448, 1536), (3072, 5120)])
+@pytest.mark.parametrize('dtype', [np.complex64, np.complex128])
+def test_mixed_radix_lengths_vs_numpy(pa, shape, dtype):
+    """lengths 3 / 5 / 7 x 2^k (Q = 1.5 pads, scipy's next_fast_len values) take one radix-R step around engine transforms instead of
+    Bluestein's convolution at the next power of two above 2 n: same results as numpy, and as the Bluestein route (knob mixed_radix = 0)"""
+    from prysm_amd import _lib
+    P = pa.propagation
+    rng = np.random.default_rng(shape[0] + shape[1])
+    x = crandn_(rng, shape, dtype)
+    xd = torch.from_numpy(x).cuda()
+    tol = TOL32 if dtype == np.complex64 else TOL64
+    want = O.focus(x.astype(np.complex128), 1)
+    got = tonp(P.focus(xd, 1))
+    assert got.dtype == dtype and rel_max(got, want) < tol
+    # windows, crops and the inverse through the same path: unfocus of a padded field, and its adjoint (crop)
+    if shape[0] <= 1536:
+        m, n = (shape[0] * 2) // 3, (shape[1] * 2) // 3
+        y = crandn_(rng, (m, n), dtype)
+        assert rel_max(tonp(P.unfocus(y, 1.5)), O.unfocus(y.astype(np.complex128), 1.5)) < tol
+        assert rel_max(tonp(P.focus_adjoint(xd, 1.5)), O.focus_adjoint(x.astype(np.complex128), 1.5)) < tol
+        lib = _lib.load()
+        try:
+            lib.pm_set_tuning(b'mixed_radix', 0)
+            ref = tonp(P.focus(xd, 1))
+        finally:
+            lib.pm_set_tuning(b'mixed_radix', 1)
+        assert rel_max(got, ref) < tol
+
+
+def crandn_(rng, shape, dtype):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+
+
 # ----------------------------------------------------------------------------- reference identities
 
 def test_array_orientation_consistency_tilt(pa):
