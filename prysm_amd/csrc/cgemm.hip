@@ -531,17 +531,20 @@ static int gemm_bm(int64_t M, int dtype = PM_C64) {
 // plan of the LDS-DMA kernel: tile shape (128 x 128 when that alone fills the chip, else 64 x 64), and the split of K (slabs
 // reduced in a fixed order by splitk_reduce_kernel) only when even the small tiles leave CUs idle
 struct DmaPlan {
-    int tile;      // 64 or 128
+    int tm, tn;    // workgroup tile: 64 x 64 or 128 x 128 (128 x 64 measured in between: profiles/r02/exp_gemm_shapes.log)
     int S;
     int64_t ksplit;
 };
 static bool gemm_dma_plan(int64_t M, int64_t N, int64_t K, DmaPlan* out) {
     if (!tuning().gemm_dma || !tuning().gemm_3m || M < 64 || N < 64 || (M % 64) || (N % 64) || K < 16 || (K % 16)) return false;
-    DmaPlan p{64, 1, K};
+    DmaPlan p{64, 64, 1, K};
     const int want = tuning().gemm_dma_wgs;
-    if ((M % 128) == 0 && (N % 128) == 0 && (M / 128) * (N / 128) >= want) p.tile = 128;
-    if (tuning().gemm_tile == 64 || (tuning().gemm_tile == 128 && (M % 128) == 0 && (N % 128) == 0)) p.tile = tuning().gemm_tile;
-    const int64_t tiles = (M / p.tile) * (N / p.tile);
+    const bool m128 = (M % 128) == 0, n128 = (N % 128) == 0;
+    if (m128 && n128 && (M / 128) * (N / 128) >= want) p.tm = p.tn = 128;
+    const int t = tuning().gemm_tile;
+    if (t == 64) p.tm = p.tn = 64;
+    else if (t == 128 && m128 && n128) p.tm = p.tn = 128;
+    const int64_t tiles = (M / p.tm) * (N / p.tn);
     // split K until the launch fills the 256 CUs, keeping at least 4 K-tiles per slab
     while (tiles * p.S < want && K / (p.S * 2) >= 64 && ((K / (p.S * 2)) % 16) == 0 && p.S < 64) p.S *= 2;
     p.ksplit = K / p.S;
@@ -636,14 +639,14 @@ int cgemm_ws_bk(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha,
     return cgemm_ws_bm<T, BK, 64>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
 }
 
-template <int TI>
+template <int TI, int TJ>
 static int cgemm_dma_launch(bool akf, bool bkf, int cA, int cB, int ntm, int ntn, int S, int64_t K, int64_t ksplit, float al,
                             const cx<float>* A, int64_t lda, const cx<float>* B, int64_t ldb, cx<float>* out, int64_t ldo, int64_t slab,
                             hipStream_t st) {
-    constexpr int LDSB = 3 * 2 * (64 * TI) * 128;
+    constexpr int LDSB = 3 * (64 * TI + 64 * TJ) * 128;
 #define PM_GD(AK, BK_)                                                                                                                \
     {                                                                                                                                 \
-        auto kern = cgemm_dma_kernel<TI, TI, AK, BK_>;                                                                                \
+        auto kern = cgemm_dma_kernel<TI, TJ, AK, BK_>;                                                                                \
         if (LDSB > 48 * 1024)                                                                                                         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);         \
         hipLaunchKernelGGL(kern, dim3(unsigned(ntm * ntn * S)), dim3(256), LDSB, st, cA, cB, ntm, ntn, K, ksplit, al, A, lda, B, ldb, out, \
@@ -665,12 +668,12 @@ static int cgemm_dma_run(int opA, int opB, int64_t M, int64_t N, int64_t K, doub
     }
     const bool akf = !(opA & 2), bkf = (opB & 2) != 0;
     const int cA = opA & 1, cB = opB & 1;
-    const int ntm = int(M / p.tile), ntn = int(N / p.tile);
+    const int ntm = int(M / p.tm), ntn = int(N / p.tn);
     cx<float>* out = p.S > 1 ? reinterpret_cast<cx<float>*>(ws) : C;
     const int64_t ldo = p.S > 1 ? N : ldc, slab = p.S > 1 ? M * N : 0;
     const float al = p.S > 1 ? 1.f : float(alpha);
-    int rc = p.tile == 128 ? cgemm_dma_launch<2>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st)
-                           : cgemm_dma_launch<1>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st);
+    int rc = p.tm == 128 ? cgemm_dma_launch<2, 2>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st)
+                         : cgemm_dma_launch<1, 1>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st);
     if (rc || p.S == 1) return rc;
     const int64_t total = M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, p.S, float(alpha),

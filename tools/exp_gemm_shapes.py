@@ -23,4 +23,4 @@ for tile in (64, 128):
         pair = t(lambda: _ops.cgemm(_ops.cgemm(Ey, ary), Ex, 0, 2))
         g15 = t(lambda: _ops.cgemm(Ey5, ary5), 10); T5 = _ops.cgemm(Ey5, ary5)
         g25 = t(lambda: _ops.cgemm(T5, Ex5, 0, 2), 10)
-        print(f'tile {tile:3d} wgs {wgs:4d}: config4 G1 {g1:6.1f} G2 {g2:5.1f} pair {pair:6.1f} us ({21.47e3/pair:5.1f} TF) | config5 G1 {g15:6.1f} G2 {g25:5.1f} ({77.3e3/(g15+g25):5.1f} TF)')
+        print(f'tile {tile:5d} wgs {wgs:4d}: config4 G1 {g1:6.1f} G2 {g2:5.1f} pair {pair:6.1f} us ({21.47e3/pair:5.1f} TF) | config5 G1 {g15:6.1f} G2 {g25:5.1f} ({77.3e3/(g15+g25):5.1f} TF)')
