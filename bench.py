@@ -366,6 +366,32 @@ def polychromatic_config5(ranks, n, reps=3):
     return res
 
 
+def polychromatic_2048(ranks, n=2048, reps=5):
+    """The same 64-wavelength sum on a 2048^2 pupil (north_star quotes the propagation metric at 2048^2 and 4096^2): the driver's
+    default there -- each rank's share as ONE pm_fft2_spectral call, groups of 8 wavelengths per launch pair -- beside the
+    per-wavelength loop and the stacked form it replaces at this size."""
+    from prysm_amd.polychromatic import polychromatic_psf
+    ax = (torch.arange(n, device='cuda', dtype=torch.float64) - n // 2) * (10.0 / n)
+    r = torch.hypot(ax[None, :], ax[:, None])
+    amp = (r <= 5).to(torch.float32)
+    opd = (500.0 * (r / 5) ** 4).to(torch.float32)
+    wvls = np.linspace(0.5, 0.7, N_WAVELENGTHS)
+    wts = np.ones(N_WAVELENGTHS)
+    res = {'wavelengths': N_WAVELENGTHS, 'pupil': f'{n}x{n} fp32', 'Q': 1}
+    forms = (('spectral_groups', dict()), ('per_wavelength_loop', dict(spectral=False, batched=False)), ('stacks', dict(batched=True)))
+    for name, kw in forms:
+        fn = lambda: polychromatic_psf(amp, opd, wvls, wts, 10.0 / n, 100.0, Q=1, reduce_to_all=False, **kw)   # noqa: E731
+        fn()
+        ts = sorted(ranks.timed(fn) for _ in range(reps))
+        t = ts[len(ts) // 2]
+        res[name] = {'psf_ms': t * 1e3, 'wavelengths_per_s': N_WAVELENGTHS / t,
+                     'per_wavelength_us_per_gpu': t * 1e6 / math.ceil(N_WAVELENGTHS / ranks.world)}
+    # bytes per sample and wavelength of the grouped form: 16 + 16 / 8 (csrc/fft_spectral.h)
+    per = res['spectral_groups']['per_wavelength_us_per_gpu'] * 1e-6
+    res['spectral_groups']['frac_of_hbm_peak'] = 18.0 * n * n / per / 1e9 / HBM_PEAK_GBS
+    return res
+
+
 def reduce_alone_ms(ranks, n):
     """The one data-path collective on its own: sum-reduce of an n^2 fp32 image to rank 0 (median of 5)."""
     if ranks.world == 1:
@@ -422,6 +448,7 @@ def main():
         extra['reduce_ms'] = reduce_alone_ms(ranks, n)
         extra['polychromatic'] = polychromatic_config5(ranks, n)
         extra['polychromatic']['reduce_alone_ms'] = extra['reduce_ms']
+        extra['polychromatic_2048'] = polychromatic_2048(ranks)
 
     if rank == 0:
         psf_ms = 0.0

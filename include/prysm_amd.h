@@ -156,6 +156,20 @@ size_t pm_fft2_workspace(const pm_fft2_desc* d);
 int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes,
             void* stream);
 
+/* The wavelength loop of a polychromatic PSF (docs/source/how-tos/Polychromatic Propagation.ipynb cell 3:
+ *     for wvl, w in zip(wavelengths, weights): psf += w * abs(focus(amp * exp(1j * 2 pi / wvl * opd)))**2  ),
+ * result-equivalent to `count` pm_fft2 calls with d->synth_k = k[b], d->weight = weight[b] on the same input and accumulator
+ * (the descriptor must carry PM_FLAG_SYNTH_INPUT and PM_EPI_ABS2_ACCUM; its own synth_k / weight are ignored; k and weight
+ * are HOST arrays).  With PM_FLAG_SYNTH_PACKED, complex64 and engine lengths the loop runs as one launch pair per group of
+ * wavelengths: the row pass reads the packed (amplitude, OPD) map once per group, the column pass sums w_b |.|^2 over the
+ * group in registers and touches the accumulator once -- 16 + 16 / B bytes per sample and wavelength instead of 32 (B = 4:
+ * tuning key "spectral").  The sum runs in wavelength order; only its association differs from the loop's
+ * (acc + (w_0 i_0 + w_1 i_1 + ..) per group).  Other descriptors run the plain loop.
+ * Workspace: pm_fft2_spectral_workspace(d, count) bytes. */
+size_t pm_fft2_spectral_workspace(const pm_fft2_desc* d, int32_t count);
+int pm_fft2_spectral(const pm_fft2_desc* d, int32_t count, const double* k, const double* weight, const void* in, void* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* Fused  out = window( ifft2( fft2( pad(in) ) * H ) )  in THREE passes (row FFT, column FFT x H x column IFFT
  * in registers, row IFFT): 6 N^2 s bytes of HBM traffic instead of the 8 N^2 s of two pm_fft2 calls.
  * Replaces fft.ifft2(fft.fft2(field) * tf) of angular_spectrum / angular_spectrum_adjoint

@@ -48,6 +48,9 @@ SIGNATURES = {
     'pm_set_tuning': (c_i32, [ctypes.c_char_p, c_i32]),
     'pm_fft2_workspace': (c_sz, [ctypes.POINTER(pm_fft2_desc)]),
     'pm_fft2': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_vp, c_vp, c_vp, c_sz, c_vp]),
+    'pm_fft2_spectral_workspace': (c_sz, [ctypes.POINTER(pm_fft2_desc), c_i32]),
+    'pm_fft2_spectral': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_i32, ctypes.POINTER(c_f64), ctypes.POINTER(c_f64), c_vp, c_vp, c_vp, c_sz,
+                         c_vp]),
     'pm_fft2_mul_ifft2_workspace': (c_sz, [ctypes.POINTER(pm_fft2_desc)]),
     'pm_fft2_mul_ifft2': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_vp, c_vp, c_vp, c_sz, c_vp]),
     'pm_fft2_time_passes': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_vp, c_vp, c_vp, c_sz, c_i32,

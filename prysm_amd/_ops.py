@@ -88,7 +88,7 @@ def _check_out(out, x, oshape, odt):
 
 def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
          out_shape=None, out_off=(0, 0), out_shift=(0, 0), epilogue=L.PM_EPI_NONE,
-         mul=None, mul_x=None, mul_conj=False, out=None, weight=1.0, flags=0, synth=None):
+         mul=None, mul_x=None, mul_conj=False, out=None, weight=1.0, flags=0, synth=None, spectral=None):
     """Fused 2-D transform (pm_fft2).
 
     x          : (m, n) complex tensor, or a (B, m, n) stack transformed in one launch pair; each field sits at
@@ -100,6 +100,8 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
     synth      : (amp | None, k): x is the real float32 OPD map and the transformed field is amp * exp(i k x),
                  synthesised while the row pass loads it (see synth_supported); ('packed', k): x is a complex64 tensor
                  holding (amplitude, OPD) pairs (pack_amp_opd)
+    spectral   : (k values, weights) with synth and PM_EPI_ABS2_ACCUM: out += sum_b weights[b] |transform at k[b]|^2, the whole
+                 wavelength loop in one call (pm_fft2_spectral: groups of wavelengths share one launch pair); synth[1] is ignored
     out        : optional result / accumulator (PM_EPI_ABS2_ACCUM); must match the dtype and shape the call produces
     """
     lib = L.load()
@@ -163,6 +165,18 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
         d.mul = mul.data_ptr()
         if mul_x is not None:
             d.mul_x = mul_x.data_ptr()
+    if spectral is not None:
+        ks, wts = spectral
+        cnt = len(ks)
+        if synth is None or epilogue != L.PM_EPI_ABS2_ACCUM or len(wts) != cnt:
+            raise ValueError('spectral=(k, weights) needs synth, the accumulate epilogue and as many weights as wavenumbers')
+        ka = (ctypes.c_double * cnt)(*[float(v) for v in ks])
+        wa = (ctypes.c_double * cnt)(*[float(v) for v in wts])
+        nbytes = lib.pm_fft2_spectral_workspace(ctypes.byref(d), cnt)
+        ws = L.workspace(nbytes)
+        L.check(lib.pm_fft2_spectral(ctypes.byref(d), cnt, ka, wa, x.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None,
+                                     nbytes, L.stream_ptr()))
+        return out
     nbytes = lib.pm_fft2_workspace(ctypes.byref(d))      # not cached: it follows the tuning knobs (pm_set_tuning)
     ws = L.workspace(nbytes)
     rc = lib.pm_fft2(ctypes.byref(d), x.data_ptr(), out.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes, L.stream_ptr())

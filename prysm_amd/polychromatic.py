@@ -94,7 +94,7 @@ def _fields_per_launch(shape, cdtype_bytes, Q, limit_bytes=1 << 30):
 
 
 def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, focal_dx=None, samples=None,
-                      kind='mdft', group=None, reduce_to_all=True, batched=None, reduce_method='reduce'):
+                      kind='mdft', group=None, reduce_to_all=True, batched=None, reduce_method='reduce', spectral=True):
     """Polychromatic PSF of a pupil (amplitude, OPD in nm) -- the how-to's recipe on N GPUs.
 
     Q given            : FFT focus per wavelength with the |.|^2 fused into the transform (multi-field throughput
@@ -104,6 +104,8 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
                          instead of launch-bound; batched=False is the field-by-field loop with the accumulate
                          epilogue, the faster form from 4096^2 transforms (single fields take the folded kernels).
                          Default (None): stacks below 4096^2 transforms.
+    spectral           : with Q and float32 maps of power-of-two width, a rank's wavelength loop runs as ONE call whose launch pairs
+                         each cover a group of wavelengths (pm_fft2_spectral; False: one transform pair per wavelength).
     reduce_method      : 'reduce' (one torch.distributed.reduce) or 'a2a' (all-to-all of slices + ordered local sum + gather:
                          bitwise reproducible, one message per xGMI link) when only the first rank needs the image.
     focal_dx + samples : per-wavelength fixed-sampling focus (prepare_executor + focus_dft, `kind`),
@@ -117,8 +119,15 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
     amp = L.as_device(amplitude)
     phs = L.as_device(opd)
 
+    packed = None
+    if Q is not None and not batched:
+        # the pupil is synthesised inside every wavelength's transform (float32 maps, power-of-two width): pack (amplitude, OPD)
+        # once so each of those row passes reads one 8-byte element per sample instead of two 4-byte ones from two arrays
+        probe = Wavefront.from_amp_and_phase(amp, phs, float(wavelengths[0]), dx)._fusable(Q) if len(wavelengths) else None
+        if probe is not None and len(wavelengths) > 1:
+            packed = _ops.pack_amp_opd(probe[0], probe[1])
     if Q is not None and batched is None:
-        batched = math.ceil(amp.shape[-2] * Q) * math.ceil(amp.shape[-1] * Q) < 4096 * 4096
+        batched = (packed is None or not spectral) and math.ceil(amp.shape[-2] * Q) * math.ceil(amp.shape[-1] * Q) < 4096 * 4096
     if Q is not None and batched:
         if len(wavelengths) != len(weights):
             raise ValueError('wavelengths and weights must have the same length')
@@ -143,13 +152,21 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
             _ops.sum_modes(focus_intensity(stack, Q), [float(w) for w in weights[b0:b1]], out=acc, accumulate=True)
         return _reduce_image(acc, world, group, reduce_to_all, reduce_method)
 
-    packed = None
-    if Q is not None:
-        # the pupil is synthesised inside every wavelength's transform (float32 maps, power-of-two width): pack (amplitude, OPD)
-        # once so each of those row passes reads one 8-byte element per sample instead of two 4-byte ones from two arrays
-        probe = Wavefront.from_amp_and_phase(amp, phs, float(wavelengths[0]), dx)._fusable(Q) if len(wavelengths) else None
-        if probe is not None and len(wavelengths) > 1:
-            packed = _ops.pack_amp_opd(probe[0], probe[1])
+    if packed is not None and spectral:
+        # the rank's whole wavelength loop in one call: groups of wavelengths share a launch pair (the packed map is read once per
+        # group, the image touched once per group -- csrc/fft_spectral.h)
+        if len(wavelengths) != len(weights):
+            raise ValueError('wavelengths and weights must have the same length')
+        use_dist = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if use_dist else 0
+        world = dist.get_world_size(group) if use_dist else 1
+        lo, hi = shard_bounds(len(wavelengths), rank, world)
+        m, n = packed.shape
+        acc = torch.zeros((math.ceil(m * Q), math.ceil(n * Q)), dtype=torch.float32, device=packed.device)
+        if hi > lo:
+            ks = [2 * math.pi / float(wavelengths[k]) / 1e3 for k in range(lo, hi)]
+            focus_intensity(packed, Q, out=acc, synth=('packed', ks[0]), spectral=(ks, [float(w) for w in weights[lo:hi]]))
+        return _reduce_image(acc, world, group, reduce_to_all, reduce_method)
 
     def propagate(wvl, w, acc):
         if packed is not None:

@@ -61,22 +61,23 @@ def unfocus_adjoint(wavefunction, Q):
     return _centered_fft2(wavefunction, 1, -1, crop_to=_shape_before_pad(shape, Q))
 
 
-def focus_intensity(wavefunction, Q, out=None, weight=None, synth=None):
+def focus_intensity(wavefunction, Q, out=None, weight=None, synth=None, spectral=None):
     """|focus(wavefunction, Q)|^2 with the modulus fused into the last FFT pass.
 
     Equivalent to ``Wavefront.focus(...).intensity.data`` (wavefront.py:146-151, 478-504) but the
     complex focal field is never written: the column pass stores re^2 + im^2 directly.  With ``out``
     and ``weight`` the result is accumulated, ``out += weight * |.|^2`` (the incoherent sum of the
-    polychromatic recipe).
+    polychromatic recipe).  ``spectral=(k values, weights)`` with ``synth`` and ``out`` runs that whole loop in one call:
+    ``out += sum_b weights[b] |focus(amp exp(i k_b opd))|^2`` (pm_fft2_spectral).
     """
     x = L.as_field(wavefunction)
     m, n = x.shape[-2:]
     M, N = _padded_shape((m, n), Q)
     in_off = (math.ceil((M - m) / 2), math.ceil((N - n) / 2))
     shift = (M // 2, N // 2)
-    epi = L.PM_EPI_ABS2 if (out is None or weight is None) else L.PM_EPI_ABS2_ACCUM
+    epi = L.PM_EPI_ABS2 if (out is None or (weight is None and spectral is None)) else L.PM_EPI_ABS2_ACCUM
     return _ops.fft2(x, direction=-1, scale=1.0 / math.sqrt(M * N), shape=(M, N), in_off=in_off, in_shift=shift,
-                     out_shift=shift, epilogue=epi, out=out, weight=1.0 if weight is None else weight, synth=synth)
+                     out_shift=shift, epilogue=epi, out=out, weight=1.0 if weight is None else weight, synth=synth, spectral=spectral)
 
 
 def Q_for_sampling(input_diameter, prop_dist, wavelength, output_dx):

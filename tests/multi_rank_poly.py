@@ -36,6 +36,14 @@ for method in ('reduce', 'a2a'):
     got = polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2, batched=False, reduce_to_all=False, reduce_method=method)
     if rank == 0:
         worst = max(worst, float(np.abs(tonp(got) - want).max() / np.abs(want).max()))
+# float32 maps: each rank's share of the loop is ONE pm_fft2_spectral call (groups of wavelengths per launch pair)
+got = tonp(polychromatic_psf(amp.astype(np.float32), opd.astype(np.float32), wvls, wts, dx, 100.0, Q=2))
+want32 = O.sum_of_2d_modes(np.asarray([O.intensity(O.focus(O.from_amp_and_phase(amp.astype(np.float32).astype(np.float64),
+                                                                              opd.astype(np.float32).astype(np.float64), float(w)), 2))
+                                       for w in wvls]), wts)
+worst32 = float(np.abs(got - want32).max() / np.abs(want32).max())
+if worst32 > 2e-5:
+    worst = max(worst, worst32)     # fp32 transforms: their own tolerance; a miss fails the run
 comps = []
 for w in wvls:
     P = O.from_amp_and_phase(amp, opd, float(w))

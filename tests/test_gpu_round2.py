@@ -511,3 +511,101 @@ def test_polychromatic_two_ranks_vs_oracle(pa):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
     assert res.stdout.count('OK') >= 2
+
+
+# ----------------------------------------------------------------------------- the wavelength loop as one call (pm_fft2_spectral)
+
+def _spectral_case(rng, m, n):
+    amp = torch.from_numpy((rng.random((m, n)) > 0.25).astype(np.float32)).cuda()
+    opd = torch.from_numpy((200 * rng.standard_normal((m, n))).astype(np.float32)).cuda()
+    return amp, opd
+
+
+@pytest.mark.parametrize('m,n,Q,count', [(64, 64, 1, 3), (256, 256, 1, 11), (256, 512, 1, 8), (256, 256, 2, 5), (1024, 1024, 1, 9),
+                                         (2048, 2048, 1, 4), (32, 2048, 1, 2)])
+def test_spectral_call_equals_the_wavelength_loop(pa, m, n, Q, count):
+    """pm_fft2_spectral (groups of wavelengths per launch pair: packed map read once, w |.|^2 summed in registers) against the
+    loop it replaces -- one accumulate-epilogue transform pair per wavelength -- and against the fp64 oracle sum; every group size
+    and both register / memory forms of its two kernels (tuning keys spectral, spectral_mode)."""
+    from prysm_amd import _lib, _ops
+    P = pa.propagation
+    lib = _lib.load()
+    rng = np.random.default_rng(m * 7 + n + count)
+    amp, opd = _spectral_case(rng, m, n)
+    packed = _ops.pack_amp_opd(amp, opd)
+    wvls = np.linspace(0.5, 0.7, count)
+    ks = [2 * np.pi / w / 1e3 for w in wvls]
+    wts = list(np.linspace(0.5, 1.5, count))
+    M, N = int(m * Q), int(n * Q)
+    loop = torch.zeros((M, N), device='cuda')
+    for k, w in zip(ks, wts):
+        P.focus_intensity(packed, Q, out=loop, weight=w, synth=('packed', k))
+    a64, o64 = amp.cpu().numpy().astype(np.float64), opd.cpu().numpy().astype(np.float64)
+    want = sum(w * O.intensity(O.focus(O.from_amp_and_phase(a64, o64, float(wl)), Q)) for wl, w in zip(wvls, wts))
+    assert rel_max(tonp(loop), want) < 2e-5
+    try:
+        for group in (1, 2, 3, 8):
+            for mode in (0, 1, 2, 3):
+                assert lib.pm_set_tuning(b'spectral', group) == 0 and lib.pm_set_tuning(b'spectral_mode', mode) == 0
+                got = torch.full((M, N), 0.0, device='cuda')
+                P.focus_intensity(packed, Q, out=got, synth=('packed', ks[0]), spectral=(ks, wts))
+                # same terms in the same order; only the association of the fp32 sum differs (per group: acc + (w0 i0 + w1 i1 ...))
+                assert rel_max(tonp(got), tonp(loop)) < 2e-6, (group, mode)
+                assert rel_max(tonp(got), want) < 2e-5, (group, mode)
+    finally:
+        lib.pm_set_tuning(b'spectral', 8)
+        lib.pm_set_tuning(b'spectral_mode', 3)
+
+
+def test_spectral_call_accumulates_and_falls_back(pa):
+    """the call ADDS to its accumulator; descriptors outside the fused form (two-array synthesis; 4096^2 bins, where the loop is as
+    fast) run the plain loop and give the same image"""
+    from prysm_amd import _lib, _ops
+    P = pa.propagation
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    amp, opd = _spectral_case(rng, 256, 256)
+    packed = _ops.pack_amp_opd(amp, opd)
+    ks = [2 * np.pi / w / 1e3 for w in (0.5, 0.6, 0.7)]
+    wts = [1.0, 2.0, 0.5]
+    base = torch.rand((256, 256), device='cuda')
+    once = torch.zeros((256, 256), device='cuda')
+    P.focus_intensity(packed, 1, out=once, synth=('packed', ks[0]), spectral=(ks, wts))
+    got = base.clone()
+    P.focus_intensity(packed, 1, out=got, synth=('packed', ks[0]), spectral=(ks, wts))
+    assert rel_max(tonp(got), tonp(base + once)) < 1e-6
+    two = torch.zeros((256, 256), device='cuda')
+    P.focus_intensity(opd, 1, out=two, synth=(amp, ks[0]), spectral=(ks, wts))     # amplitude and OPD as two arrays: the loop
+    assert rel_max(tonp(two), tonp(once)) < 2e-6
+    try:
+        assert lib.pm_set_tuning(b'spectral_area_log', 10) == 0     # 256^2 = 2^16 bins >= 2^10: the loop
+        loop = torch.zeros((256, 256), device='cuda')
+        P.focus_intensity(packed, 1, out=loop, synth=('packed', ks[0]), spectral=(ks, wts))
+    finally:
+        lib.pm_set_tuning(b'spectral_area_log', 24)
+    assert rel_max(tonp(loop), tonp(once)) < 2e-6
+    with pytest.raises(ValueError):
+        P.focus_intensity(packed, 1, out=once, synth=('packed', ks[0]), spectral=(ks, wts[:2]))
+
+
+@pytest.mark.parametrize('n,Q', [(512, 2), (1024, 1)])
+def test_polychromatic_psf_spectral_equals_loop_and_oracle(pa, n, Q):
+    """the driver's default below 4096^2 transforms (one pm_fft2_spectral call per rank) against its per-wavelength loop
+    (spectral=False), the stacked form (batched=True) and the oracle sum"""
+    from prysm_amd.polychromatic import polychromatic_psf
+    x, y = O.make_xy_grid(n, diameter=10)
+    r, _ = O.cart_to_polar(x, y)
+    amp = O.circle(5, r).astype(np.float32)
+    opd = O.hopkins_w040(r / 5, 400.0).astype(np.float32)
+    dx = float(x[0, 1] - x[0, 0])
+    wvls = np.linspace(0.5, 0.7, 13)
+    wts = np.linspace(1.0, 2.0, 13)
+    want = sum(w * O.intensity(O.focus(O.from_amp_and_phase(amp.astype(np.float64), opd.astype(np.float64), float(wl)), Q))
+               for wl, w in zip(wvls, wts))
+    fused = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=Q))
+    loop = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=Q, spectral=False, batched=False))
+    stacks = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=Q, batched=True))
+    assert fused.dtype == np.float32 and fused.shape == want.shape
+    assert rel_max(fused, want) < 2e-5
+    assert rel_max(fused, loop) < 2e-6
+    assert rel_max(fused, stacks) < 2e-6
