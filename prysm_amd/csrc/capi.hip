@@ -914,6 +914,90 @@ static int check_fft2(const pm_fft2_desc* d) {
     return 0;
 }
 
+// 1-D transforms of the lengths of bigfft.hip, n = R n' (16384, 32768; 3 / 5 / 7 x 2^k): one radix-R step around engine transforms
+// of length n', the pieces of big2d_run with the other axis left alone.
+//   axis 1 (rows)     decimation in frequency: big_pre_rows -> ONE engine row pass over the R planes -> big_finish with a unit column
+//                     radix un-interleaves the bins (X[R k + m] = plane m, bin k) through the output view;  workspace 2 batch n
+//   axis 0 (columns)  decimation in time: the sub-sequence r is rows r, r + R, ... of the caller's array -- a leading dimension of R
+//                     rows and the stored window cut to the rows of that residue -- R engine column passes -> big_finish combines;
+//                     workspace batch n
+static size_t fft1_big_scratch(size_t es, int axis, int64_t batch, int64_t n) {
+    const size_t arr = (size_t(batch) * size_t(n) * es + 255) & ~size_t(255);
+    return axis == 1 ? 2 * arr : arr;
+}
+static bool fft1_big_ok(const pm_axis* ti) { return big_split(ti->n) > 1 && ti->shift == 0; }
+
+template <typename T>
+static int fft1_big(int conj, int axis, int64_t batch, const pm_axis* ti, const pm_axis* to, double scale, const void* in, int64_t in_ld,
+                    void* out, int64_t out_ld, hipStream_t st, void* ws) {
+    const int64_t n = ti->n;
+    const int R = big_split(n), np = int(n / R), lg = engine_log2(np);
+    const int dt = sizeof(T) == 4 ? PM_C64 : PM_C128;
+    int err = 0, rc;
+    const cx<T>* twp = twiddles<T>(np, &err);
+    if (!twp) return err;
+    const cx<T>* twN = twiddles<T>(n, &err);
+    if (!twN) return err;
+    ColStoreNat<T> o{};
+    o.dst = out;
+    o.ld = out_ld;
+    o.conj = conj;
+    o.epilogue = EPI_NONE;
+    o.scale = T(scale);
+    o.weight = T(1);
+    o.mul_kind = MUL_NONE;
+    const int nb = int(batch);
+    if (axis == 1) {
+        o.ay = AxisMap{nb, nb, 0, 0};
+        o.ax = to_map(*to);
+        const size_t arr = (size_t(batch) * size_t(n) * sizeof(cx<T>) + 255) & ~size_t(255);
+        cx<T>* Y = reinterpret_cast<cx<T>*>(ws);
+        cx<T>* Z = reinterpret_cast<cx<T>*>(static_cast<char*>(ws) + arr);
+        Blue2dIn<T> bi{in, in_ld, AxisMap{nb, nb, 0, 0}, to_map(*ti), conj, 0};
+        if ((rc = big_pre_rows<T>(bi, nb, np, R, Y, twN, st))) return rc;
+        const int nseq = R * nb;
+        RowLoadNat<T> lp{Y, np, AxisMap{np, np, 0, 0}, nseq, 0, 0};
+        RowStoreNat<T> sp{Z, np, AxisMap{np, np, 0, 0}, nseq, 0, T(1), 0, AxisMap{1, 1, 0, 0}};
+        if ((rc = launch_row_nat<T>(lg, row_variant(dt, lg), lp, sp, twp, nseq, 0, st))) return rc;
+        return big_finish<T>(Z, nb, np, 1, R, twp, o, st);
+    }
+    o.ay = to_map(*to);
+    o.ax = AxisMap{nb, nb, 0, 0};
+    cx<T>* F = reinterpret_cast<cx<T>*>(ws);
+    const int64_t plane = int64_t(np) * batch;
+    const int tc = col_tile_width_for(dt, lg, tuning().col_var);
+    const int ntiles = int((batch + tc - 1) / tc);
+    const int vec_in = (sizeof(T) != 4 || ((in_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0))) ? 1 : 0;
+    const int vec_f = (sizeof(T) != 4 || batch % 2 == 0) ? 1 : 0;
+    const int64_t off = ti->off, end = ti->off + ti->len;
+    for (int r = 0; r < R; ++r) {
+        // logical rows r + R i (i < np) of the zero-padded sequence; stored: off <= r + R i < off + len
+        const int64_t ilo = off > r ? (off - r + R - 1) / R : 0;
+        int64_t ihi = end > r ? (end - r + R - 1) / R : 0;
+        if (ihi > np) ihi = np;
+        cx<T>* Fr = F + int64_t(r) * plane;
+        if (ihi <= ilo) {
+            hipError_t e = hipMemsetAsync(Fr, 0, size_t(plane) * sizeof(cx<T>), st);
+            if (e != hipSuccess) return int(e);
+            continue;
+        }
+        const cx<T>* base = reinterpret_cast<const cx<T>*>(in) + (int64_t(R) * ilo + r - off) * in_ld;
+        ColLoadNat<T> cl{base, int64_t(R) * in_ld, AxisMap{np, int(ihi - ilo), int(ilo), 0}, nb, conj, vec_in, 0};
+        ColStoreNat<T> cs{};
+        cs.dst = Fr;
+        cs.ld = batch;
+        cs.ay = AxisMap{np, np, 0, 0};
+        cs.ax = AxisMap{nb, nb, 0, 0};
+        cs.epilogue = EPI_NONE;
+        cs.scale = T(1);
+        cs.weight = T(1);
+        cs.mul_kind = MUL_NONE;
+        cs.vec_ok = vec_f;
+        if ((rc = launch_col_nat<T>(lg, tuning().col_var, cl, cs, twp, ntiles, 1, st, 1))) return rc;
+    }
+    return big_finish<T>(F, np, nb, R, 1, twN, o, st);
+}
+
 template <typename T>
 static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, const pm_axis* to, double scale,
                     const void* in, int64_t in_ld, void* out, int64_t out_ld, hipStream_t st, void* blue_ws = nullptr) {
@@ -921,6 +1005,8 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
     const int lg = engine_log2(n);
     const int conj = direction > 0 ? 1 : 0;
     int err = 0;
+    if (blue_ws && fft1_big_ok(ti)) return fft1_big<T>(conj, axis, batch, ti, to, scale, in, in_ld, out, out_ld, st, blue_ws);
+    if (big_split(n) > 1) blue_ws = nullptr;     // the workspace was sized for the radix-R path
     if (axis == 1) {
         RowStoreNat<T> sp{reinterpret_cast<cx<T>*>(out), out_ld, to_map(*to), int(batch), conj, T(scale), 0, AxisMap{1, 1, 0, 0}};
         if (lg >= 0) {
@@ -1248,8 +1334,10 @@ int pm_fft1(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const
 }
 
 size_t pm_fft1_workspace(int32_t dtype, int32_t axis, int64_t batch, int64_t n) {
-    if ((dtype != PM_C64 && dtype != PM_C128) || batch <= 0 || !use_blue(n)) return 0;
+    if ((dtype != PM_C64 && dtype != PM_C128) || batch <= 0) return 0;
     const size_t es = dtype == PM_C64 ? 8 : 16;
+    if (big_split(n) > 1) return fft1_big_scratch(es, axis, batch, n);     // 16384 / 32768 and 3 / 5 / 7 x 2^k: a radix-R step
+    if (!use_blue(n)) return 0;
     return axis == 1 ? blue_rows_scratch(es, batch, n) : blue_cols_scratch(es, batch, n);
 }
 
@@ -1260,8 +1348,9 @@ int pm_fft1_ws(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, co
     if (rc) return rc;
     if (!in || !out) return fail(PM_ERR_ARG, "pm_fft1: null argument");
     if (batch == 0) return 0;
-    // a workspace of pm_fft1_workspace() bytes puts non-power-of-two lengths on the Bluestein path; without one they run on
-    // the direct O(n^2) kernel
+    // a workspace of pm_fft1_workspace() bytes puts lengths above 8192 and mixed-radix lengths on the radix-R path, other
+    // non-power-of-two lengths on the Bluestein path; without one they run on the direct O(n^2) kernel.  (A rotated input view of a
+    // radix-R length has no Bluestein scratch in that workspace either: it runs direct.)
     const size_t need = pm_fft1_workspace(dtype, axis, batch, t_in->n);
     void* bws = (need && workspace && workspace_bytes >= need && reinterpret_cast<uintptr_t>(workspace) % 256 == 0) ? workspace : nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

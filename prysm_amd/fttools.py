@@ -32,12 +32,26 @@ def _next_power_of_2(n):
 
 
 def next_fast_len(n):
-    """The next fast FFT size (prysm/fttools.py:23-31).
+    """The next fast FFT size (prysm/fttools.py:23-31: scipy's next_fast_len, a power of two as the fallback).
 
-    The engine's fast lengths are the powers of two (the reference's own fallback when the FFT
-    backend offers no next_fast_len).
+    Fast lengths here are what the device transforms without Bluestein's detour: powers of two up to 32768, and from 96 the
+    mixed-radix lengths 3 / 5 / 7 x 2^k with 2^k <= 8192 (one radix-3 / 5 / 7 step around engine transforms, csrc/bigfft.hip),
+    e.g. 2560 for 2559 where a power of two gives 4096.
     """
-    return _next_power_of_2(n)
+    n = int(n)
+    best = _next_power_of_2(n)
+    for R in (3, 5, 7):
+        q = max(16, _next_power_of_2(-(-n // R)))
+        if q <= 8192 and R * q >= 96 and R * q <= 32768:
+            best = min(best, R * q)
+    return best
+
+
+def _czt_len(n):
+    """Convolution length of one chirp-Z axis: a power of two while the whole axis fits one fused kernel (pm_czt_axis, up to 8192
+    points), else the next fast length (16384-point convolutions take the radix-R path of pm_fft1: 10240 for 8703)."""
+    p2 = _next_power_of_2(n)
+    return p2 if p2 <= 8192 else next_fast_len(n)
 
 
 def fftfreq(n, d=1.0):
@@ -204,8 +218,8 @@ class CZT:
         alpha_x, alpha_y = dx * dfx, dy * dfy
         shift_x = float(fxs[Mx // 2]) / dfx
         shift_y = float(fys[My // 2]) / dfy
-        Kx = next_fast_len(Nx + Mx - 1)
-        Ky = next_fast_len(Ny + My - 1)
+        Kx = _czt_len(Nx + Mx - 1)
+        Ky = _czt_len(Ny + My - 1)
         Hx, bx, ax = _prepare_czt_basis(Nx, Mx, Kx, shift_x, alpha_x, sign)
         Hy, by, ay = _prepare_czt_basis(Ny, My, Ky, shift_y, alpha_y, sign)
         self._brow, self._Hrow, self._arow = by, Hy, ay        # vectors along axis 0

@@ -609,3 +609,54 @@ def test_polychromatic_psf_spectral_equals_loop_and_oracle(pa, n, Q):
     assert rel_max(fused, want) < 2e-5
     assert rel_max(fused, loop) < 2e-6
     assert rel_max(fused, stacks) < 2e-6
+
+
+# ----------------------------------------------------------------------------- 1-D transforms of 16384 / 32768 and 3 / 5 / 7 x 2^k points
+
+@pytest.mark.parametrize('cdtype', [np.complex64, np.complex128])
+@pytest.mark.parametrize('n', [96, 1536, 2560, 3584, 16384, 20480])
+def test_fft1_radix_r_lengths_vs_numpy(pa, n, cdtype):
+    """pm_fft1 at the lengths that used to take Bluestein's detour (mixed radix) or the O(n^2) kernel (above 8192): both axes, both
+    directions, zero padded inputs (numpy's fft(x, n)) and cropped outputs, odd and even batch extents"""
+    from prysm_amd import _ops
+    rng = np.random.default_rng(n)
+    tol = 2e-5 if cdtype == np.complex64 else 1e-10
+    for batch, length, in_off in ((6, n, 0), (5, n - n // 3, 0), (8, n // 2 + 1, n // 4)):
+        x = (rng.standard_normal((batch, length)) + 1j * rng.standard_normal((batch, length))).astype(cdtype)
+        for axis in (1, 0):
+            xa = x if axis == 1 else np.ascontiguousarray(x.T)
+            xd = torch.from_numpy(xa).cuda()
+            padded = np.zeros((batch, n), dtype=np.complex128)
+            padded[:, in_off:in_off + length] = x
+            for direction in (-1, +1):
+                want = np.fft.fft(padded, axis=1) if direction < 0 else np.fft.ifft(padded, axis=1) * n
+                got = tonp(_ops.fft1(xd, n, axis=axis, direction=direction, in_off=in_off))
+                got = got if axis == 1 else got.T
+                assert rel_max(got, want) < tol, (batch, length, in_off, axis, direction)
+            # a window of the bins, with a scale
+            lo, ln = n // 5, n // 3
+            got = tonp(_ops.fft1(xd, n, axis=axis, direction=-1, in_off=in_off, out_off=lo, out_len=ln, scale=0.5))
+            got = got if axis == 1 else got.T
+            assert rel_max(got, 0.5 * np.fft.fft(padded, axis=1)[:, lo:lo + ln]) < tol, (batch, length, in_off, axis, 'window')
+
+
+def test_czt_long_convolution_uses_fast_length(pa):
+    """a chirp-Z axis whose convolution no longer fits one fused kernel (K > 8192) convolves at the next fast length -- 12288 = 3 x
+    4096 for 6000 + 6000 - 1 points, where a power of two would be 16384 -- through pm_fft1's radix-R path; against the matrix DFT"""
+    ft = pa.fttools
+    assert ft.next_fast_len(2559) == 2560 and ft.next_fast_len(97) == 112 and ft.next_fast_len(4096) == 4096
+    assert ft.next_fast_len(8703) == 10240 and ft.next_fast_len(20000) == 20480 and ft.next_fast_len(30000) == 32768
+    rng = np.random.default_rng(3)
+    nx, mx, ny, my = 6000, 6000, 16, 12
+    r = lambda n: tonp(ft.fftrange(n)).astype(float)   # noqa: E731
+    x, y = r(nx) * 0.2, r(ny) * 0.17
+    fx, fy = (r(mx) + 0.25) / (nx * 0.2 * 1.3), (r(my) - 0.5) * 0.11
+    inp = rng.standard_normal((ny, nx)) + 1j * rng.standard_normal((ny, nx))
+    czt = ft.CZT(x, y, fx, fy)
+    assert czt._Kx == 12288
+    want = tonp(ft.MDFT(x, y, fx, fy)(inp))
+    assert rel_max(tonp(czt(inp)), want) < 1e-8     # quadratic chirp phases of ~1e6 turns at 6000 points: ~1e-9 in fp64
+    g = rng.standard_normal((my, mx)) + 1j * rng.standard_normal((my, mx))
+    lhs = np.vdot(tonp(czt(inp)), g)
+    rhs = np.vdot(inp, tonp(czt.adjoint(g)))
+    assert abs(lhs - rhs) < 1e-8 * abs(lhs)
