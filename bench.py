@@ -63,7 +63,7 @@ def parse():
     ap.add_argument('--dtype', default='c64', choices=['c64', 'c128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-poly', action='store_true', help='only the headline loop (profiling runs)')
-    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192|mtf)')
+    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192|mtf|poly2048)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget for the CPU baseline sample')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path when the ranks share a GPU)')
@@ -427,6 +427,11 @@ def main():
     cdtype = np.complex64 if args.dtype == 'c64' else np.complex128
     es = np.dtype(cdtype).itemsize
     if args.only:   # profiling runs: one other_configs entry, nothing else
+        if args.only == 'poly2048':
+            res = polychromatic_2048(ranks)
+            if rank == 0:
+                print(json.dumps({'polychromatic_2048': res}), flush=True)
+            return
         if rank == 0:
             print(json.dumps(other_configs(args.only)), flush=True)
         return

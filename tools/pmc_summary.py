@@ -29,7 +29,9 @@ def short(n):
     m = re.search(r'FftCfg<(\w+), (\d+), (\d+), (\d+), (\d+), (\d+)>', n)
     if m:
         kind = 'row_pass' if 'RowLoad' in n else 'column_pass'
-        if 'r2c' in n:
+        if 'spectral' in n:
+            kind += '_spectral'
+        elif 'r2c' in n:
             kind = 'row_pass_r2c'
         elif 'herm' in n:
             kind = 'column_pass_herm'
