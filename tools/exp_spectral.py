@@ -48,15 +48,17 @@ def main():
             t0 = timeit(run)
             ref = acc.clone()
             print(f'n={n} Q={Q}: loop {t0 * 1e3 / nl:7.1f} us/wavelength', flush=True)
-            for grp in [int(v) for v in os.environ.get('GROUPS', '2,4,8').split(',')]:
+            lib.pm_set_tuning(b'spectral_area_log', 30)      # also the sizes the library leaves to the loop
+            for grp in [int(v) for v in os.environ.get('PMG', '2,4,8').split(',')]:
                 for mode in [int(v) for v in os.environ.get('MODES', '0,1,2,3').split(',')]:
                     lib.pm_set_tuning(b'spectral', grp)
                     lib.pm_set_tuning(b'spectral_mode', mode)
                     t = timeit(run)
                     err = float((acc - ref).abs().max() / ref.abs().max())
                     print(f'    group {grp} mode {mode}: {t * 1e3 / nl:7.1f} us/wavelength  ({t0 / t:4.2f}x)  max rel err {err:.2e}', flush=True)
-            lib.pm_set_tuning(b'spectral', 4)
+            lib.pm_set_tuning(b'spectral', 8)
             lib.pm_set_tuning(b'spectral_mode', 3)
+            lib.pm_set_tuning(b'spectral_area_log', 24)
 
 
 if __name__ == '__main__':
