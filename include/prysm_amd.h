@@ -190,9 +190,9 @@ int pm_fft2_mul_ifft2(const pm_fft2_desc* d, const void* in, void* out, void* wo
 int pm_fft1(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in,
             const pm_axis* t_out, double scale, const void* in, int64_t in_ld, void* out, int64_t out_ld,
             void* stream);
-/* The same with a workspace: pm_fft1_workspace() bytes (256 B aligned; 0 when none is needed) put lengths that are not
- * powers of two (96 .. 4096) on the FFT engine through Bluestein's identity; without it (pm_fft1, or a smaller / NULL
- * workspace) such lengths run on the direct O(n^2) kernel.  FFTDFT with K = 1 / (dx dfx) not a power of two
+/* The same with a workspace: pm_fft1_workspace() bytes (256 B aligned; 0 when none is needed) put 16384 / 32768 and 3 / 5 / 7 x 2^k
+ * points on the FFT engine by one radix-R step (an unrotated input view), other lengths that are not powers of two (96 .. 4096)
+ * through Bluestein's identity; without it (pm_fft1, or a smaller / NULL workspace) such lengths run on the direct O(n^2) kernel.  FFTDFT with K = 1 / (dx dfx) not a power of two
  * (prysm/fttools.py:484-533) is the caller that needs it. */
 size_t pm_fft1_workspace(int32_t dtype, int32_t axis, int64_t batch, int64_t n);
 int pm_fft1_ws(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in,
