@@ -1127,9 +1127,9 @@ int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, s
 // ---- the wavelength loop as launch pairs over groups of wavelengths (fft_spectral.h)
 // fast form: complex64 packed synthesis, |.|^2 accumulation, both lengths on the engine with a tiled intermediate, fewer than 4096^2
 // bins.  Measured (profiles/r02/exp_spectral.log, us per wavelength, loop -> groups of 8): 1024^2 24.7 -> 11.0, 2048^2 40.6 -> 22.6,
-// 1024^2 padded to 2048^2 34.0 -> 13.3; at 4096^2 the loop's passes are bound by the latency of one workgroup's transform at two
-// workgroups per CU, not by bytes (rocprofv3: 47.6 + 50.7 us per wavelength against 45.0 + 55.9 in groups of 8, whose intermediates no
-// longer fit the Infinity Cache), so those sizes keep the loop.
+// 1024^2 padded to 2048^2 34.0 -> 13.3; at 4096^2 the loop's passes already run at 84 % of copy speed with their intermediate in the
+// Infinity Cache, and the grouped kernels pay for their registers with occupancy (rocprofv3: 47.6 + 50.7 us per wavelength against
+// 45.0 + 55.9 in groups of 8), so those sizes keep the loop.
 static bool spectral_fast(const pm_fft2_desc* d, const Fft2Plan& p) {
     const int want = PM_FLAG_SYNTH_INPUT | PM_FLAG_SYNTH_PACKED;
     return tuning().spectral > 1 && d->dtype == PM_C64 && (d->flags & want) == want && !(d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY)) &&
