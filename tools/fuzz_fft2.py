@@ -1,6 +1,6 @@
 """Randomised differential test of pm_fft2 / pm_fft2_mul_ifft2 through prysm_amd._ops against numpy on the host:
 random sizes (engine and direct-DFT lengths), windows, rotations, crops, real / complex / synthesised input, stacks,
-epilogues, multipliers, precisions, with and without the fold.  Usage: python tools/fuzz_fft2.py [ncases] [seed]"""
+epilogues, multipliers, precisions, with and without the fold; then pm_fft1 and pm_fft2_spectral the same way.  Usage: python tools/fuzz_fft2.py [ncases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -143,11 +143,103 @@ def fuzz_gemm(ncases, rng, lib):
     return nfail
 
 
+def fuzz_fft1(ncases, rng, lib):
+    """pm_fft1_ws through _ops.fft1: engine, direct, Bluestein, mixed-radix (3 / 5 / 7 x 2^k) and -- with the native length lowered --
+    radix-2 / radix-4 lengths, both axes and directions, zero-padded inputs at an offset, windows of the bins, a scale."""
+    sizes = [2, 8, 64, 256, 1024, 4096, 3, 12, 36, 96, 100, 127, 160, 192, 224, 384, 640, 1000, 1536, 2560, 3584, 6144]
+    nfail, worst = 0, 0.0
+    for case in range(ncases):
+        n = int(rng.choice(sizes))
+        small = rng.random() < 0.3 and n in (64, 256)
+        lib.pm_set_tuning(b'big_native_log', 5 if small else 13)      # 64 / 128 then take the radix-2 / radix-4 step; 256 goes direct
+        if small:
+            n = int(rng.choice([64, 128]))
+        cdt = np.complex64 if rng.random() < 0.5 else np.complex128
+        batch = int(rng.choice([1, 2, 5, 8, 33]))
+        ln = n if rng.random() < 0.5 else int(rng.integers(1, n + 1))
+        off = int(rng.integers(0, n - ln + 1))
+        axis = int(rng.integers(0, 2))
+        direction = -1 if rng.random() < 0.5 else +1
+        olen = n if rng.random() < 0.5 else int(rng.integers(1, n + 1))
+        ooff = int(rng.integers(0, n - olen + 1))
+        scale = float(rng.choice([1.0, 1.0 / n]))
+        x = (rng.standard_normal((batch, ln)) + 1j * rng.standard_normal((batch, ln))).astype(cdt)
+        padded = np.zeros((batch, n), dtype=np.complex128)
+        padded[:, off:off + ln] = x
+        want = (np.fft.fft(padded, axis=1) if direction < 0 else np.fft.ifft(padded, axis=1) * n)[:, ooff:ooff + olen] * scale
+        xa = x if axis == 1 else np.ascontiguousarray(x.T)
+        try:
+            got = _ops.fft1(torch.from_numpy(xa).cuda(), n, axis=axis, direction=direction, in_off=off, out_off=ooff, out_len=olen,
+                            scale=scale).cpu().numpy()
+        except Exception as exc:
+            print('fft1 case', case, 'EXC', repr(exc)[:200], (n, batch, ln, off, axis, direction, cdt.__name__))
+            nfail += 1
+            continue
+        got = got if axis == 1 else got.T
+        err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+        tol = 3e-5 if cdt == np.complex64 else 1e-10
+        worst = max(worst, err / tol)
+        if not err < tol:
+            nfail += 1
+            print('fft1 case', case, 'FAIL err', err, (n, batch, ln, off, olen, ooff, axis, direction, cdt.__name__, small))
+    lib.pm_set_tuning(b'big_native_log', 13)
+    print(f'fuzz_fft1: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
+    return nfail
+
+
+def fuzz_spectral(ncases, rng, lib):
+    """pm_fft2_spectral (the wavelength loop as launch pairs over groups of wavelengths) against the fp64 sum of its terms: random
+    shapes, pads, wavelength counts, group sizes and kernel forms, onto a non-zero accumulator."""
+    from prysm_amd.propagation import focus_intensity
+    sizes = [32, 64, 128, 256, 512, 1024]
+    nfail, worst = 0, 0.0
+    for case in range(ncases):
+        m, n = int(rng.choice(sizes)), int(rng.choice(sizes))
+        Q = int(rng.choice([1, 1, 2]))
+        count = int(rng.integers(1, 12))
+        group, mode = int(rng.choice([1, 2, 3, 5, 8])), int(rng.integers(0, 4))
+        lib.pm_set_tuning(b'spectral', group)
+        lib.pm_set_tuning(b'spectral_mode', mode)
+        lib.pm_set_tuning(b'fold', int(rng.choice([-1, 0, 1])))
+        amp = (rng.random((m, n)) > 0.3).astype(np.float32)
+        opd = (rng.standard_normal((m, n)) * 200).astype(np.float32)
+        ks = [2 * np.pi / w / 1e3 for w in rng.uniform(0.4, 0.9, count)]
+        wts = list(rng.uniform(0.2, 2.0, count))
+        base = rng.random((m * Q, n * Q)).astype(np.float32)
+        P = np.zeros((m * Q, n * Q), dtype=np.complex128)
+        oy, ox = (m * Q - m + 1) // 2, (n * Q - n + 1) // 2
+        want = base.astype(np.float64)
+        for k, w in zip(ks, wts):
+            P[:] = 0
+            P[oy:oy + m, ox:ox + n] = amp.astype(np.float64) * np.exp(1j * k * opd.astype(np.float64))
+            F = np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(P), norm='ortho'))
+            want = want + w * (F.real ** 2 + F.imag ** 2)
+        try:
+            acc = torch.from_numpy(base.copy()).cuda()
+            focus_intensity(_ops.pack_amp_opd(torch.from_numpy(amp).cuda(), torch.from_numpy(opd).cuda()), Q, out=acc,
+                            synth=('packed', ks[0]), spectral=(ks, wts))
+            got = acc.cpu().numpy()
+        except Exception as exc:
+            print('spectral case', case, 'EXC', repr(exc)[:200], (m, n, Q, count, group, mode))
+            nfail += 1
+            continue
+        err = float(np.abs(got - want).max() / np.abs(want).max())
+        tol = 2e-5
+        worst = max(worst, err / tol)
+        if not err < tol:
+            nfail += 1
+            print('spectral case', case, 'FAIL err', err, (m, n, Q, count, group, mode))
+    for key, val in ((b'spectral', 8), (b'spectral_mode', 3), (b'fold', -1)):
+        lib.pm_set_tuning(key, val)
+    print(f'fuzz_spectral: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
+    return nfail
+
+
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     lib = L.load()
-    sizes = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 3, 5, 9, 12, 20, 36, 100, 96, 127, 200, 384, 1000]   # engine, direct and Bluestein lengths
+    sizes = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 3, 5, 9, 12, 20, 36, 100, 96, 127, 160, 200, 224, 384, 1000, 1536]   # engine, direct, Bluestein and mixed-radix lengths
     worst = 0.0
     nfail = 0
     for case in range(ncases):
@@ -230,6 +322,8 @@ def main():
     print(f'fuzz_fft2: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
     nfail += fuzz_fused(max(20, ncases // 2), rng, lib)
     nfail += fuzz_gemm(max(20, ncases // 2), rng, lib)
+    nfail += fuzz_fft1(max(30, ncases // 2), rng, lib)
+    nfail += fuzz_spectral(max(12, ncases // 4), rng, lib)
     return 1 if nfail else 0
 
 if __name__ == '__main__':
