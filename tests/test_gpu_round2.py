@@ -105,6 +105,23 @@ def test_config5_variant_m_full_size(pa, config5):
     assert rel_max(got, c['want_m']) < 1e-4     # K = 4096 complex64 contractions, squared and summed 64 times
 
 
+def test_config5_variant_m_by_chirp_z(pa, config5):
+    """the same 512^2 focal grid per wavelength through the chirp-Z executor (kind='czt': fused convolution kernels, K = 8192) gives
+    the image of the matrix-DFT variant"""
+    from prysm_amd.conf import config
+    from prysm_amd.polychromatic import polychromatic_psf
+    c = config5
+    prec = config.precision
+    try:
+        config.precision = 32
+        got = tonp(polychromatic_psf(c['amp'], c['opd'], c['wvls'], c['wts'], c['dx'], 100.0, focal_dx=0.55 * 10 / 4,
+                                     samples=512, kind='czt'))
+    finally:
+        config.precision = prec
+    assert got.dtype == np.float32 and got.shape == (512, 512)
+    assert rel_max(got, c['want_m']) < 1e-4
+
+
 def test_packed_amp_opd_synthesis_equals_two_array_synthesis(pa):
     """PM_FLAG_SYNTH_PACKED: the pupil synthesised from (amplitude, OPD) pairs read as one 8-byte element is bit for bit the
     pupil synthesised from the two arrays (same arithmetic, different loads), folded and unfolded, padded and not"""
