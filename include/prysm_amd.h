@@ -303,7 +303,7 @@ int pm_embed(int32_t elem_bytes, int64_t irows, int64_t icols, const void* in, i
 /* The index-mapping modes of np.pad that fttools.pad2d(mode=...) forwards to (prysm/fttools.py:96-98): out (orows x ocols) holds
  * in at (off_y, off_x) and, around it, in[map(r)][map(c)] with mode 1 = 'edge', 2 = 'reflect', 3 = 'symmetric', 4 = 'wrap'
  * (any pad width, also wider than the array).  elem_bytes in {1, 4, 8, 16}.  The statistical modes ('mean', 'maximum', 'minimum',
- * 'median', 'linear_ramp') are not on the device: the mirror package raises NotImplementedError for them. */
+ * 'median') and 'linear_ramp' are not entry points: the mirror package composes them from device tensor reductions (off the hot path). */
 int pm_pad_index(int32_t elem_bytes, int32_t mode, int64_t irows, int64_t icols, const void* in, int64_t in_ld, int64_t orows,
                  int64_t ocols, int64_t off_y, int64_t off_x, void* out, int64_t out_ld, void* stream);
 

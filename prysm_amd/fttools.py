@@ -78,8 +78,51 @@ def pad2d(array, Q=2, value=0, mode='constant', out_shape=None):
         return _ops.pad_index(array, tuple(out_shape), off, mode)
     if mode == 'empty':
         return _ops.embed(array, tuple(out_shape), off, fill=0)     # np.pad leaves the border undefined; zeros are a valid instance
-    raise NotImplementedError(f"pad2d: np.pad mode {mode!r} is not on the device (constant, edge, reflect, symmetric, wrap and "
-                              "empty are); the statistical modes need reductions over the array")
+    if mode in _STAT_PADS and array.dim() == 2 and all(d >= 0 for d in shape_diff):
+        return _pad_stat(array, [(d - d // 2, d // 2) for d in shape_diff], mode)
+    raise NotImplementedError(f"pad2d: np.pad mode {mode!r} is not implemented (constant, edge, reflect, symmetric, wrap, empty, mean, "
+                              "maximum, minimum, median and linear_ramp are)")
+
+
+_STAT_PADS = ('mean', 'maximum', 'minimum', 'median', 'linear_ramp')
+
+
+def _pad_stat(a, widths, mode):
+    """np.pad's statistical modes and linear_ramp (defaults: statistics over the whole axis, end value 0), axis by axis like numpy
+    -- the second axis sees the rows the first one added.  Off the hot path: tensor reductions and concatenations on the device."""
+    if mode in ('maximum', 'minimum', 'median') and a.is_complex():
+        raise TypeError(f'pad2d: mode {mode!r} needs a real array')
+    for axis, (before, after) in enumerate(widths):
+        if before == 0 and after == 0:
+            continue
+        if mode == 'linear_ramp':
+            first, last = a.narrow(axis, 0, 1), a.narrow(axis, a.shape[axis] - 1, 1)
+            work = a if a.is_floating_point() or a.is_complex() else a.to(torch.float64)
+            first, last = first.to(work.dtype), last.to(work.dtype)
+            shp = [1, 1]
+            shp[axis] = -1
+            kb = (torch.arange(before, device=a.device, dtype=torch.float64) / max(before, 1)).reshape(shp)
+            ka = ((torch.arange(after, device=a.device, dtype=torch.float64) + 1) / max(after, 1)).reshape(shp)
+            rd = work.real.dtype if work.is_complex() else work.dtype
+            pre = first * kb.to(rd)                       # end value 0 -> edge, outermost sample first
+            post = last * (1 - ka).to(rd)                 # edge -> end value 0
+            out = torch.cat((pre, work, post), dim=axis)
+            a = out if work is a else out.to(a.dtype)     # integer arrays: numpy rounds the ramp back as well
+            continue
+        if mode == 'mean':
+            stat = a.to(torch.float64 if not (a.is_floating_point() or a.is_complex()) else a.dtype).mean(dim=axis, keepdim=True).to(a.dtype)
+        elif mode == 'maximum':
+            stat = a.amax(dim=axis, keepdim=True)
+        elif mode == 'minimum':
+            stat = a.amin(dim=axis, keepdim=True)
+        else:
+            stat = torch.quantile(a.to(torch.float64), 0.5, dim=axis, keepdim=True).to(a.dtype)
+        reps = [1, 1]
+        reps[axis] = before
+        pre = stat.repeat(reps)
+        reps[axis] = after
+        a = torch.cat((pre, a, stat.repeat(reps)), dim=axis)
+    return a
 
 
 def crop_center(img, out_shape):

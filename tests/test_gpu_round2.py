@@ -426,7 +426,24 @@ def test_pad2d_modes_match_numpy_pad(pa, mode):
             got = tonp(fttools.pad2d(a, out_shape=out_shape, mode=mode))
             assert got.dtype == want.dtype and np.array_equal(got, want), (shape, out_shape, dt)
     with pytest.raises(NotImplementedError):
-        fttools.pad2d(np.ones((4, 4)), Q=2, mode='mean')
+        fttools.pad2d(np.ones((4, 4)), Q=2, mode='no_such_mode')
+
+
+@pytest.mark.parametrize('mode', ['mean', 'maximum', 'minimum', 'median', 'linear_ramp'])
+def test_pad2d_statistical_modes_match_numpy_pad(pa, mode):
+    """np.pad's statistical modes and linear_ramp at their defaults (statistics over the whole axis, end value 0), axis by axis"""
+    from prysm_amd import fttools
+    rng = np.random.default_rng(12)
+    for shape, out_shape in (((9, 12), (14, 18)), ((5, 4), (17, 21)), ((1, 6), (4, 6)), ((8, 8), (8, 8)), ((6, 7), (6, 12))):
+        for dt in (np.float32, np.float64) + ((np.complex128,) if mode in ('mean', 'linear_ramp') else ()):
+            a = rng.standard_normal(shape).astype(dt)
+            if dt is np.complex128:
+                a = a + 1j * rng.standard_normal(shape)
+            diff = [o - i for o, i in zip(out_shape, shape)]
+            want = np.pad(a, [(d - d // 2, d // 2) for d in diff], mode=mode)
+            got = tonp(fttools.pad2d(a, out_shape=out_shape, mode=mode))
+            assert got.dtype == want.dtype and got.shape == want.shape
+            assert np.allclose(got, want, rtol=1e-6 if dt is np.float32 else 1e-13, atol=1e-6 if dt is np.float32 else 1e-13), (shape, out_shape, dt)
 
 
 # ----------------------------------------------------------------------------- ADVICE r1
