@@ -63,7 +63,7 @@ def parse():
     ap.add_argument('--dtype', default='c64', choices=['c64', 'c128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-poly', action='store_true', help='only the headline loop (profiling runs)')
-    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192|mtf|poly2048)')
+    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192|mtf|conv|poly2048)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget for the CPU baseline sample')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path when the ranks share a GPU)')
@@ -220,6 +220,18 @@ def other_configs(only=''):
                                         'note': 'fused: real-input (Hermitian) transform, N/2 columns, DC normalisation + abs in the store; composed '
                                                 '(return_more=True): complex spectrum + division + abs as separate device sweeps'}
         del psf
+    if want('conv'):      # a real 4096^2 fp32 object through a transfer function (apply_transfer_functions: the image-chain
+        from prysm_amd import _ops     # step after the PSF) -- half spectra end to end against the complex chain on the same arrays
+        obj = torch.rand(4096, 4096, dtype=torch.float32, device='cuda')
+        Hc = torch.randn(4096, 4096, dtype=torch.complex64, device='cuda')
+        kw = dict(scale=1.0 / 4096 ** 2, mul=Hc, in_shift=(2048, 2048), out_shift=(2048, 2048))
+        ms = _event_ms(lambda: _ops.fft2_mul_ifft2(obj, real_out=True, **kw), 30)
+        msc = _event_ms(lambda: _ops.fft2_mul_ifft2(obj, **kw), 30)
+        out['conv_real_4096_f32'] = {'ms': ms, 'complex_chain_ms': msc, 'algorithmic_GBps': 32 * 4096 ** 2 / (ms * 1e-3) / 1e9,
+                                     'frac_of_hbm_peak': 32 * 4096 ** 2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     'note': 'real(ifft2(fft2(obj) H)) of a real object: R2C rows, Hermitian part of H between the column transforms, '
+                                             'C2R rows = 32 B per sample (4 + 4, 8 + 8 of H, 4 + 4); the complex chain moves 56'}
+        del obj, Hc
     torch.cuda.empty_cache()
     if want('config4'):   # config 4: matrix-DFT focus 2048^2 -> 512^2 complex64 on MFMA, 8 My Nx (Ny + Mx) real flops
         prec = config.precision

@@ -74,6 +74,13 @@ enum {
     PM_FLAG_NORM_DC = 16,   /* divide the result by its DC bin X[0][0] before the epilogue -- the centre normalisation
                              * `data / data[cy, cx]` of the OTF routines (prysm/otf.py:62-74).  Real-input transforms on the
                              * Hermitian path only (see PM_FLAG_REAL_INPUT), where that bin is real; PM_ERR_UNSUPPORTED otherwise */
+    PM_FLAG_REAL_OUTPUT = 64, /* pm_fft2_mul_ifft2 with PM_FLAG_REAL_INPUT: `out` is a REAL array (out_ld in real elements) that receives
+                             * the REAL PART of the result -- what convolution.conv / apply_transfer_functions keep for a real object
+                             * (prysm/convolution.py:29-31, 110-113).  The chain then runs on half spectra end to end (real rows as
+                             * N/2 packed complex points, the Hermitian part of the multiplier, N/2-point inverse row transforms):
+                             * 32 instead of 56 bytes per sample.  A full (PM_MUL_FULL) multiplier, unpadded power-of-two sizes
+                             * (rows of 64 .. 8192 samples), rotations by 0 or N/2 along x, unwindowed output, one field;
+                             * PM_ERR_UNSUPPORTED otherwise (the caller takes the real part of the complex chain instead). */
     PM_FLAG_REAL_INPUT = 4  /* `in` is a REAL array of the precision that goes with dtype (float / double); in_ld and
                              * in_bstride count real elements.  fft2 of a real PSF / object / actuator map
                              * (prysm/otf.py:31, prysm/convolution.py:27-28,82-85) without a complex copy: pass 1 reads

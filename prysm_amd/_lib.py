@@ -18,6 +18,7 @@ PM_C64, PM_C128, PM_F32, PM_F64, PM_BOOL = 0, 1, 2, 3, 4
 PM_EPI_NONE, PM_EPI_ABS2, PM_EPI_ABS2_ACCUM, PM_EPI_ABS, PM_EPI_ARG = 0, 1, 2, 3, 4
 PM_MUL_NONE, PM_MUL_FULL, PM_MUL_SEPARABLE = 0, 1, 2
 PM_FLAG_PASS1_ONLY, PM_FLAG_PASS2_ONLY, PM_FLAG_REAL_INPUT, PM_FLAG_SYNTH_INPUT, PM_FLAG_NORM_DC, PM_FLAG_SYNTH_PACKED = 1, 2, 4, 8, 16, 32
+PM_FLAG_REAL_OUTPUT = 64
 PM_ERR_ARG, PM_ERR_UNSUPPORTED, PM_ERR_WORKSPACE = -1, -2, -3
 
 c_i32, c_i64, c_f64, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t

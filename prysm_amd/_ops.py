@@ -197,8 +197,11 @@ def _is_pow2_engine(n):
 
 
 def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_off=(0, 0), in_shift=(0, 0),
-                   out_shape=None, out_off=(0, 0), out_shift=(0, 0)):
+                   out_shape=None, out_off=(0, 0), out_shift=(0, 0), real_out=False):
     """window(ifft2(fft2(pad(x)) * H)) * scale.
+
+    real_out: for a REAL x return the real part of the result as a real tensor -- on half spectra end to end when the shapes allow
+    (PM_FLAG_REAL_OUTPUT: unpadded power-of-two sizes, a full multiplier), else `.real` of the complex result.
 
     Power-of-two transform sizes run the fused three-pass kernel chain (pm_fft2_mul_ifft2: the multiply and
     both column transforms happen in registers); other sizes compose two pm_fft2 calls.
@@ -211,7 +214,8 @@ def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_
     if not (_is_pow2_engine(M) and _is_pow2_engine(N)):
         F = fft2(x, direction=-1, scale=1.0, shape=shape, in_off=in_off, in_shift=in_shift, mul=mul, mul_x=mul_x,
                  mul_conj=mul_conj)
-        return fft2(F, direction=+1, scale=scale, out_shape=out_shape, out_off=out_off, out_shift=out_shift)
+        r = fft2(F, direction=+1, scale=scale, out_shape=out_shape, out_off=out_off, out_shift=out_shift)
+        return r.real if (real_out and not x.is_complex()) else r
     d = L.pm_fft2_desc()
     x, (M, N), (om, on) = _fill_views(d, x, shape, in_off, in_shift, out_shape, out_off, out_shift)
     d.direction = -1
@@ -220,6 +224,17 @@ def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_
     keep = [x]
     _fill_mul(d, x, mul, mul_x, mul_conj, keep)
     oshape = (om, on) if x.dim() == 2 else (x.shape[0], om, on)
+    if real_out and not x.is_complex() and x.dim() == 2 and mul_x is None:
+        # the half-spectrum chain: the workspace query answers whether this descriptor is one it takes
+        d.flags |= L.PM_FLAG_REAL_OUTPUT
+        out = torch.empty(oshape, dtype=L._REAL_OF[L.cdtype_of(x)], device=x.device)
+        d.out_ld = out.stride(-2) if om > 1 else on
+        nbytes = lib.pm_fft2_mul_ifft2_workspace(ctypes.byref(d))
+        if nbytes:
+            ws = L.workspace(int(nbytes))
+            L.check(lib.pm_fft2_mul_ifft2(ctypes.byref(d), L.ptr(x), L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()))
+            return out
+        d.flags &= ~L.PM_FLAG_REAL_OUTPUT
     out = torch.empty(oshape, dtype=L.cdtype_of(x), device=x.device)
     d.out_ld = out.stride(-2) if om > 1 else on
     if x.dim() == 3:
@@ -227,7 +242,7 @@ def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_
     nbytes = lib.pm_fft2_mul_ifft2_workspace(ctypes.byref(d))
     ws = L.workspace(max(int(nbytes), 16))
     L.check(lib.pm_fft2_mul_ifft2(ctypes.byref(d), L.ptr(x), L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()))
-    return out
+    return out.real if (real_out and not x.is_complex()) else out
 
 
 def fft1(x, n=None, axis=-1, direction=-1, scale=1.0, out_len=None, out_off=0, in_off=0):

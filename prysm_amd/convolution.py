@@ -3,7 +3,8 @@
 conv = fftshift(ifft2(fft2(ifftshift(o)) * fft2(ifftshift(h)))): one fused pm_fft2 for H, then the fused
 3-pass fft2 -> x H -> ifft2 chain; the shifts are index rotations, the product with H happens in registers between
 the two column transforms and the 1/(MN) rides on the last store.  Real objects / PSFs / actuator maps are read as
-they are (PM_FLAG_REAL_INPUT).  apply_transfer_functions is the same chain with the product of the given
+they are (PM_FLAG_REAL_INPUT), and a real object's result -- the reference keeps its real part -- comes out of a chain that runs on
+half spectra end to end (PM_FLAG_REAL_OUTPUT, csrc/fft_c2r.h) for unpadded power-of-two sizes.  apply_transfer_functions is the same chain with the product of the given
 transfer functions as H (the DM surface render of prysm/x/dm.py:254,330).
 """
 import inspect
@@ -34,8 +35,8 @@ def conv(obj, psf):
     M, N = o.shape
     shift = (M // 2, N // 2)
     H = _ops.fft2(h, direction=-1, scale=1.0, in_shift=shift)
-    i = _ops.fft2_mul_ifft2(o, scale=1.0 / (M * N), mul=H, in_shift=shift, out_shift=shift)
-    return i.real if real else i
+    # a real object keeps the real part: the chain then runs on half spectra end to end where the shapes allow (PM_FLAG_REAL_OUTPUT)
+    return _ops.fft2_mul_ifft2(o, scale=1.0 / (M * N), mul=H, in_shift=shift, out_shift=shift, real_out=real)
 
 
 def _ifftshift2(t):
@@ -85,5 +86,4 @@ def apply_transfer_functions(obj, dx, tfs, fx=None, fy=None, ft=None, fr=None, s
     if shift:
         H = _ifftshift2(H)      # centred transfer functions -> origin at [0, 0]
     sh = (M // 2, N // 2)
-    i = _ops.fft2_mul_ifft2(o, scale=1.0 / (M * N), mul=H.contiguous(), in_shift=sh, out_shift=sh)
-    return i.real if real else i
+    return _ops.fft2_mul_ifft2(o, scale=1.0 / (M * N), mul=H.contiguous(), in_shift=sh, out_shift=sh, real_out=real)

@@ -14,6 +14,7 @@
 #include "fft_r2c_types.h"
 #include "fft_conv1_types.h"
 #include "fft_spectral_types.h"
+#include "fft_c2r_types.h"
 
 namespace pm {
 
@@ -1064,6 +1065,64 @@ static int czt_axis_run(int32_t axis, int64_t nseq, int64_t K, int64_t in_len, i
     return axis == 1 ? launch_conv1_rows<T>(lg, p, tw, st) : launch_conv1_cols<T>(lg, p, tw, st);
 }
 
+// ---- real object, real result: the chain on half spectra (fft_c2r.h)
+struct HermConvPlan {
+    int logn, logm, tc, log_k;
+    size_t ws_bytes;
+};
+static bool herm_conv_plan(const pm_fft2_desc* d, HermConvPlan& p) {
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    p.logn = engine_log2(N);
+    p.logm = engine_log2(M);
+    if (!(d->flags & PM_FLAG_REAL_INPUT) || (d->flags & (PM_FLAG_SYNTH_INPUT | PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY))) return false;
+    if (p.logn < 6 || p.logm < 1 || d->batch > 1 || d->mul_kind != PM_MUL_FULL) return false;
+    if (d->dtype == PM_C128 && p.logn > 12) return false;
+    if (d->in_y.len != M || d->in_x.len != N || d->out_y.len != M || d->out_x.len != N) return false;
+    if (!(d->in_x.shift == 0 || d->in_x.shift == N / 2) || !(d->out_x.shift == 0 || d->out_x.shift == N / 2)) return false;
+    if ((d->in_ld % 2) != 0 || (d->out_ld % 2) != 0) return false;
+    p.tc = col_tile_width_for(d->dtype, p.logm, 0);
+    p.log_k = tuning().log_k >= 0 ? tuning().log_k : 2;
+    while (p.log_k > 0 && ((N / 2) % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
+    if ((N / 2) % p.tc) return false;
+    const size_t es = d->dtype == PM_C64 ? 8 : 16;
+    p.ws_bytes = size_t(M) * size_t(N / 2) * es;
+    return true;
+}
+
+template <typename T>
+static int herm_conv_run(const pm_fft2_desc* d, const HermConvPlan& p, const void* in, void* out, void* ws, hipStream_t st) {
+    const int64_t M = d->in_y.n, N = d->in_x.n, n2 = N / 2;
+    int err = 0;
+    cx<T>* W = reinterpret_cast<cx<T>*>(ws);
+    const cx<T>* tw2 = twiddles<T>(n2, &err);
+    if (!tw2) return err;
+    const cx<T>* twn = twiddles<T>(N, &err);
+    if (!twn) return err;
+    const cx<T>* twm = twiddles<T>(M, &err);
+    if (!twm) return err;
+    const int64_t tl = int64_t(p.tc) << p.log_k;
+    int ltl = 0;
+    while ((int64_t(1) << ltl) < tl) ++ltl;
+    // rows: the real array as N/2 complex points per row -> N/2 columns, column 0 = X[0] + i X[N/2]
+    RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld / 2, AxisMap{int(n2), int(n2), 0, int(d->in_x.shift / 2)}, int(M), 0, 0, 0};
+    R2CRowStore<T> rs{W, int(M), ltl, twn, 0, 0, nullptr, 0};
+    int rc = launch_row_r2c<T>(p.logn - 1, lp, rs, tw2, int(M), tuning().row_log_g, st);
+    if (rc) return rc < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: no Hermitian row kernel for %lld points", (long long)N) : rc;
+    // columns: transform, x the Hermitian part of H, inverse transform, in place
+    const int ntiles = int(n2 / p.tc);
+    ColLoadTiled<T> cl{W, int(M), to_map(d->in_y), ntiles, p.log_k, 0};
+    HermMul<T> hm{reinterpret_cast<const cx<T>*>(d->mul), d->mul_ld, int(M), int(N), d->mul_conj ? 1 : 0};
+    ColStoreTiled<T> cst{W, int(M), ntiles, p.log_k, 0};
+    rc = launch_col_mul_herm<T>(p.logm, cl, hm, cst, twm, ntiles, sibling_log_g(p.log_k), st);
+    if (rc) return rc < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: no Hermitian column kernel for %lld points", (long long)M) : rc;
+    // rows back: half spectra -> N real samples per row = N/2 complex elements of the output seen as complex
+    RowLoadTiled<T> rl{W, int(M), ltl, 0, int(M), 0, 0};
+    RowStoreNat<T> ro{reinterpret_cast<cx<T>*>(out), d->out_ld / 2, AxisMap{int(n2), int(n2), 0, int(d->out_x.shift / 2)}, int(M), 1,
+                      T(d->scale), 1, to_map(d->out_y), 0, 0};
+    rc = launch_row_c2r<T>(p.logn - 1, rl, ro, tw2, twn, int(M), st);
+    return rc < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: no half-spectrum row kernel for %lld points", (long long)N) : rc;
+}
+
 }  // namespace pm
 
 using namespace pm;
@@ -1229,6 +1288,10 @@ int pm_fft2_spectral(const pm_fft2_desc* d, int32_t count, const double* k, cons
 
 size_t pm_fft2_mul_ifft2_workspace(const pm_fft2_desc* d) {
     if (check_fft2(d)) return 0;
+    if (d->flags & PM_FLAG_REAL_OUTPUT) {
+        HermConvPlan hp;
+        return herm_conv_plan(d, hp) ? hp.ws_bytes : 0;
+    }
     FusedPlan p;
     if (!plan_fused(d, p)) return 0;
     return p.ws_bytes;
@@ -1239,6 +1302,18 @@ int pm_fft2_mul_ifft2(const pm_fft2_desc* d, const void* in, void* out, void* wo
     if (rc) return rc;
     if (!in || !out) return fail(PM_ERR_ARG, "pm_fft2_mul_ifft2: null buffer");
     if (d->mul_kind == PM_MUL_NONE) return fail(PM_ERR_ARG, "pm_fft2_mul_ifft2: a multiplier is required");
+    if (d->flags & PM_FLAG_REAL_OUTPUT) {
+        HermConvPlan hp;
+        if (!herm_conv_plan(d, hp))
+            return fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: PM_FLAG_REAL_OUTPUT needs a real unpadded power-of-two field (rows of 64 .. 8192 "
+                        "samples), a full multiplier, x rotations by 0 or N/2 and an unwindowed output; take the real part of the complex "
+                        "chain instead");
+        if (!workspace || workspace_bytes < hp.ws_bytes)
+            return fail(PM_ERR_WORKSPACE, "pm_fft2_mul_ifft2: workspace of %zu bytes required, %zu given", hp.ws_bytes, workspace_bytes);
+        hipStream_t hst = reinterpret_cast<hipStream_t>(stream);
+        if (d->dtype == PM_C64) return herm_conv_run<float>(d, hp, in, out, workspace, hst);
+        return herm_conv_run<double>(d, hp, in, out, workspace, hst);
+    }
     FusedPlan p;
     if (!plan_fused(d, p))
         return fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: both lengths must be powers of two <= 8192 (got %lld x %lld); "

@@ -694,3 +694,58 @@ def test_czt_long_convolution_uses_fast_length(pa):
     lhs = np.vdot(tonp(czt(inp)), g)
     rhs = np.vdot(inp, tonp(czt.adjoint(g)))
     assert abs(lhs - rhs) < 1e-8 * abs(lhs)
+
+
+# ----------------------------------------------------------------------------- real object -> real result on half spectra (fft_c2r.h)
+
+@pytest.mark.parametrize('shape,dtype', [((64, 64), np.float64), ((32, 128), np.float32), ((256, 64), np.float64), ((2, 64), np.float64),
+                                         ((512, 2048), np.float32), ((2048, 1024), np.float64), ((4096, 4096), np.float32),
+                                         ((16, 8192), np.float32)])
+def test_real_convolution_on_half_spectra_vs_numpy(pa, shape, dtype):
+    """conv / apply_transfer_functions of a REAL object keep the real part of ifft2(fft2(o) H) (prysm/convolution.py:29-31,110-113);
+    PM_FLAG_REAL_OUTPUT runs the chain on half spectra: against numpy for a Hermitian H (a real PSF's transfer function), a general
+    complex H (only its Hermitian part survives the real part), conj(H), centred and uncentred, and against the complex chain"""
+    from prysm_amd import _lib, _ops
+    rng = np.random.default_rng(shape[0] * 11 + shape[1])
+    M, N = shape
+    cdt = np.complex64 if dtype == np.float32 else np.complex128
+    tol = 2e-5 if dtype == np.float32 else 1e-10
+    o = rng.standard_normal(shape).astype(dtype)
+    od = torch.from_numpy(o).cuda()
+    psf = rng.random(shape).astype(dtype)
+    H_real_psf = np.fft.fft2(psf.astype(np.float64))
+    H_any = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    for H, conj in ((H_real_psf, False), (H_any, False), (H_any, True)):
+        Hd = torch.from_numpy(H.astype(cdt)).cuda()
+        for sh in ((0, 0), (M // 2, N // 2), (1 if M > 2 else 0, 0)):
+            x = np.roll(o.astype(np.float64), (-sh[0], -sh[1]), axis=(0, 1))
+            full = np.fft.ifft2(np.fft.fft2(x) * (np.conj(H) if conj else H))
+            want = np.roll(full.real, sh, axis=(0, 1))
+            got = _ops.fft2_mul_ifft2(od, scale=1.0 / (M * N), mul=Hd, mul_conj=conj, in_shift=sh, out_shift=sh, real_out=True)
+            assert got.dtype == (torch.float32 if dtype == np.float32 else torch.float64) and not got.is_complex()
+            assert got.is_contiguous()       # the half-spectrum chain (a `.real` view of the complex result would not be)
+            assert rel_max(tonp(got), want) < tol, (conj, sh)
+            cplx = _ops.fft2_mul_ifft2(od, scale=1.0 / (M * N), mul=Hd, mul_conj=conj, in_shift=sh, out_shift=sh)
+            assert rel_max(tonp(got), tonp(cplx).real) < tol
+
+
+def test_real_convolution_callers_and_fallback(pa):
+    """convolution.conv / apply_transfer_functions take the half-spectrum chain for real power-of-two objects and fall back to the
+    complex chain's real part elsewhere (odd sizes, rows under 64 samples, x rotations other than N/2)"""
+    from prysm_amd import _ops, convolution as C
+    rng = np.random.default_rng(8)
+    for shape in ((128, 256), (100, 256), (32, 32), (9, 12)):
+        o = rng.standard_normal(shape)
+        psf = rng.random(shape)
+        want = np.fft.fftshift(np.fft.ifft2(np.fft.fft2(np.fft.ifftshift(o)) * np.fft.fft2(np.fft.ifftshift(psf)))).real
+        got = C.conv(o, psf)
+        assert not got.is_complex() and rel_max(tonp(got), want) < 1e-10, shape
+        tf = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+        want2 = np.fft.fftshift(np.fft.ifft2(np.fft.fft2(np.fft.ifftshift(o)) * tf)).real
+        got2 = C.apply_transfer_functions(o, 1.0, [tf])
+        assert not got2.is_complex() and rel_max(tonp(got2), want2) < 1e-10, shape
+    o = rng.standard_normal((64, 128))
+    H = torch.from_numpy(rng.standard_normal((64, 128)) + 1j * rng.standard_normal((64, 128))).cuda()
+    got = _ops.fft2_mul_ifft2(torch.from_numpy(o).cuda(), scale=1.0, mul=H, in_shift=(0, 5), out_shift=(0, 5), real_out=True)   # x rotation by 5
+    want = np.roll(np.fft.ifft2(np.fft.fft2(np.roll(o, (0, -5), axis=(0, 1))) * H.cpu().numpy()).real * o.size, (0, 5), axis=(0, 1))
+    assert rel_max(tonp(got), want) < 1e-10

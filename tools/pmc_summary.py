@@ -29,7 +29,11 @@ def short(n):
     m = re.search(r'FftCfg<(\w+), (\d+), (\d+), (\d+), (\d+), (\d+)>', n)
     if m:
         kind = 'row_pass' if 'RowLoad' in n else 'column_pass'
-        if 'spectral' in n:
+        if 'c2r' in n:
+            kind = 'row_pass_c2r'
+        elif 'col_mul_herm' in n:
+            kind = 'column_pass_mul_herm'
+        elif 'spectral' in n:
             kind += '_spectral'
         elif 'r2c' in n:
             kind = 'row_pass_r2c'
