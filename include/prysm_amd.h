@@ -78,8 +78,9 @@ enum {
                              * the REAL PART of the result -- what convolution.conv / apply_transfer_functions keep for a real object
                              * (prysm/convolution.py:29-31, 110-113).  The chain then runs on half spectra end to end (real rows as
                              * N/2 packed complex points, the Hermitian part of the multiplier, N/2-point inverse row transforms):
-                             * 32 instead of 56 bytes per sample.  A full (PM_MUL_FULL) multiplier, unpadded power-of-two sizes
-                             * (rows of 64 .. 8192 samples), rotations by 0 or N/2 along x, unwindowed output, one field;
+                             * 32 instead of 56 bytes per sample.  A full (PM_MUL_FULL) multiplier, unpadded power-of-two sizes from
+                             * 2048^2 samples (rows of 64 .. 8192; smaller fields: tuning key "r2c" = 2), rotations by 0 or N/2 along x,
+                             * unwindowed output, one field;
                              * PM_ERR_UNSUPPORTED otherwise (the caller takes the real part of the complex chain instead). */
     PM_FLAG_REAL_INPUT = 4  /* `in` is a REAL array of the precision that goes with dtype (float / double); in_ld and
                              * in_bstride count real elements.  fft2 of a real PSF / object / actuator map

@@ -1068,6 +1068,7 @@ static int czt_axis_run(int32_t axis, int64_t nseq, int64_t K, int64_t in_len, i
 // ---- real object, real result: the chain on half spectra (fft_c2r.h)
 struct HermConvPlan {
     int logn, logm, tc, log_k;
+    bool fold;          // radix-2 step of the column transforms in the first / last row pass, as in the complex chain
     size_t ws_bytes;
 };
 static bool herm_conv_plan(const pm_fft2_desc* d, HermConvPlan& p) {
@@ -1077,10 +1078,20 @@ static bool herm_conv_plan(const pm_fft2_desc* d, HermConvPlan& p) {
     if (!(d->flags & PM_FLAG_REAL_INPUT) || (d->flags & (PM_FLAG_SYNTH_INPUT | PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY))) return false;
     if (p.logn < 6 || p.logm < 1 || d->batch > 1 || d->mul_kind != PM_MUL_FULL) return false;
     if (d->dtype == PM_C128 && p.logn > 12) return false;
+    // Measured (profiles/r02/exp_conv.log, us, half spectra against the complex chain): 1024^2 fp32 39 vs 35 (three launch-bound passes
+    // with an extra exchange each), 2048^2 59 vs 59 / fp64 74 vs 93, 4096^2 147 vs 214 / fp64 302 vs 419, 8192^2 589 vs 882: from 2048^2
+    // (knob r2c = 2: always, 0: never)
+    if (tuning().r2c == 0 || (tuning().r2c < 2 && M * N < (int64_t(1) << 22))) return false;
     if (d->in_y.len != M || d->in_x.len != N || d->out_y.len != M || d->out_x.len != N) return false;
     if (!(d->in_x.shift == 0 || d->in_x.shift == N / 2) || !(d->out_x.shift == 0 || d->out_x.shift == N / 2)) return false;
     if ((d->in_ld % 2) != 0 || (d->out_ld % 2) != 0) return false;
-    p.tc = col_tile_width_for(d->dtype, p.logm, 0);
+    // fold: rows of 4096 / 8192 samples (the two-rows-per-thread kernels exist for 2048 / 4096 complex points), rotations by 0 or M/2
+    const int f = tuning().fold;
+    // (automatic where it measured faster: 8192-row objects 589 vs 806 us, 4096-row fp64 302 vs 318; 4096-row fp32 is 151 vs 147)
+    p.fold = (f > 0 || (f < 0 && (p.logm >= 13 || (p.logm == 12 && d->dtype == PM_C128)))) && p.logm >= 2 &&
+             (p.logn == 12 || (p.logn == 13 && d->dtype == PM_C64)) &&
+             (d->in_y.shift == 0 || d->in_y.shift == M / 2);
+    p.tc = col_tile_width_for(d->dtype, p.fold ? p.logm - 1 : p.logm, 0);
     p.log_k = tuning().log_k >= 0 ? tuning().log_k : 2;
     while (p.log_k > 0 && ((N / 2) % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
     if ((N / 2) % p.tc) return false;
@@ -1106,12 +1117,38 @@ static int herm_conv_run(const pm_fft2_desc* d, const HermConvPlan& p, const voi
     // rows: the real array as N/2 complex points per row -> N/2 columns, column 0 = X[0] + i X[N/2]
     RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld / 2, AxisMap{int(n2), int(n2), 0, int(d->in_x.shift / 2)}, int(M), 0, 0, 0};
     R2CRowStore<T> rs{W, int(M), ltl, twn, 0, 0, nullptr, 0};
+    if (p.fold) {
+        // folded: two planes of M/2 rows (even / odd bins of the column transform), M/2-point column tiles, the last pass rebuilds row pairs
+        const int H = int(M / 2);
+        const int64_t plane = (n2 / tl) * H * tl;
+        const cx<T>* twh = twiddles<T>(H, &err);
+        if (!twh) return err;
+        lp.eoff = H;
+        rs.nseq = H;
+        rs.fold = 1;
+        rs.plane_stride = plane;
+        rs.twm = twm;
+        rs.swap = d->in_y.shift == M / 2 ? 1 : 0;
+        int rcf = launch_row_r2c<T>(p.logn - 1, lp, rs, tw2, H, 0, st);
+        if (rcf) return rcf < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: no folded Hermitian row kernel for %lld points", (long long)N) : rcf;
+        const int ntf = int(n2 / p.tc);
+        ColLoadTiled<T> clf{W, H, AxisMap{H, H, 0, 0}, ntf, p.log_k, plane};
+        HermMul<T> hmf{reinterpret_cast<const cx<T>*>(d->mul), d->mul_ld, int(M), int(N), d->mul_conj ? 1 : 0, 1};
+        ColStoreTiled<T> csf{W, H, ntf, p.log_k, plane};
+        rcf = launch_col_mul_herm<T>(p.logm - 1, clf, hmf, csf, twh, ntf, sibling_log_g(p.log_k), st);
+        if (rcf) return rcf < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: no Hermitian column kernel for %lld points", (long long)H) : rcf;
+        RowLoadFold<T> rlf{W, plane, H, ltl, twm, 0, 0};
+        RowStoreNat<T> rof{reinterpret_cast<cx<T>*>(out), d->out_ld / 2, AxisMap{int(n2), int(n2), 0, int(d->out_x.shift / 2)}, int(M), 1,
+                           T(d->scale), 1, to_map(d->out_y), 0, H};
+        rcf = launch_row_c2r_fold<T>(p.logn - 1, rlf, rof, tw2, twn, H, st);
+        return rcf < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: no folded half-spectrum row kernel for %lld points", (long long)N) : rcf;
+    }
     int rc = launch_row_r2c<T>(p.logn - 1, lp, rs, tw2, int(M), tuning().row_log_g, st);
     if (rc) return rc < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: no Hermitian row kernel for %lld points", (long long)N) : rc;
     // columns: transform, x the Hermitian part of H, inverse transform, in place
     const int ntiles = int(n2 / p.tc);
     ColLoadTiled<T> cl{W, int(M), to_map(d->in_y), ntiles, p.log_k, 0};
-    HermMul<T> hm{reinterpret_cast<const cx<T>*>(d->mul), d->mul_ld, int(M), int(N), d->mul_conj ? 1 : 0};
+    HermMul<T> hm{reinterpret_cast<const cx<T>*>(d->mul), d->mul_ld, int(M), int(N), d->mul_conj ? 1 : 0, 0};
     ColStoreTiled<T> cst{W, int(M), ntiles, p.log_k, 0};
     rc = launch_col_mul_herm<T>(p.logm, cl, hm, cst, twm, ntiles, sibling_log_g(p.log_k), st);
     if (rc) return rc < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: no Hermitian column kernel for %lld points", (long long)M) : rc;

@@ -27,14 +27,18 @@ PM_HD cx<T> herm_part(const HermMul<T>& h, int u, int k) {      // 2 Hh(u, k); t
 }
 
 template <typename C>
-__global__ void __launch_bounds__(C::NT) fft_col_mul_herm_kernel(const ColLoadTiled<typename C::T> lp, const HermMul<typename C::T> hm,
-                                                                const ColStoreTiled<typename C::T> sp,
+__global__ void __launch_bounds__(C::NT) fft_col_mul_herm_kernel(const ColLoadTiled<typename C::T> lp0, const HermMul<typename C::T> hm,
+                                                                const ColStoreTiled<typename C::T> sp0,
                                                                 const cx<typename C::T>* __restrict__ tw, const int log_g) {
     using T = typename C::T;
     constexpr int TC = C::CI * C::E;
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
     const int unit = group_remap(blockIdx.x, gridDim.x, log_g) * C::BO + pos.bo;
+    const ColLoadTiled<T> lp = at_batch(lp0, blockIdx.y);       // blockIdx.y: plane of a folded transform
+    const ColStoreTiled<T> sp = at_batch(sp0, blockIdx.y);
+    const int pb = hm.planes ? int(blockIdx.y) : 0;             // this plane's bins are u = 2 u' + pb (u = u' unfolded)
+    const int ush = hm.planes ? 1 : 0;
     cx<T> v[C::E][C::P];
     load<C>(lp, unit, pos, v);
     if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
@@ -54,13 +58,16 @@ __global__ void __launch_bounds__(C::NT) fft_col_mul_herm_kernel(const ColLoadTi
         __syncthreads();
         if (col0 == 0) {
 #pragma unroll
-            for (int m = 0; m < C::P; ++m) part[m] = ex[pos.bo * C::N + ((C::N - (pos.t + m * C::TPS)) & (C::N - 1))];
+            for (int m = 0; m < C::P; ++m) {
+                const int up = pos.t + m * C::TPS;      // the partner -u: (L - u') mod L in the plane of the even bins, L - 1 - u' among the odd ones
+                part[m] = ex[pos.bo * C::N + (pb ? C::N - 1 - up : ((C::N - up) & (C::N - 1)))];
+            }
         }
     }
     const T half = T(0.5);
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
-        const int u = pos.t + m * C::TPS;
+        const int u = ((pos.t + m * C::TPS) << ush) + pb;      // bin of the full length-M transform
 #pragma unroll
         for (int e = 0; e < C::E; ++e) {
             const int k = col0 + e;
@@ -90,8 +97,8 @@ __global__ void __launch_bounds__(C::NT) fft_col_mul_herm_kernel(const ColLoadTi
     store<C>(sp, unit, pos, v);
 }
 
-template <typename C>
-__global__ void __launch_bounds__(C::NT) fft_row_c2r_kernel(const RowLoadTiled<typename C::T> lp, const RowStoreNat<typename C::T> sp,
+template <typename C, typename L>
+__global__ void __launch_bounds__(C::NT) fft_row_c2r_kernel(const L lp, const RowStoreNat<typename C::T> sp,
                                                            const cx<typename C::T>* __restrict__ tw, const cx<typename C::T>* __restrict__ twn) {
     using T = typename C::T;
     static_assert(C::COMP == 1 && C::CI == 1 && C::P == 16, "row mode, complex exchange, rows of at least 32 samples");
@@ -145,7 +152,7 @@ int launch_col_mul_herm_one(const ColLoadTiled<T>& lp, const HermMul<T>& hm, con
     }
     const int grid = (ntiles + C::BO - 1) / C::BO;
     if (grid <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDSB, st, lp, hm, sp, tw, log_g);
+    hipLaunchKernelGGL(kern, dim3(grid, hm.planes ? 2 : 1), dim3(C::NT), LDSB, st, lp, hm, sp, tw, log_g);
     return int(hipGetLastError());
 }
 
@@ -166,7 +173,7 @@ int launch_col_mul_herm_impl(int logm, const ColLoadTiled<T>& lp, const HermMul<
 template <typename T, int LOGN2, int VAR>
 int launch_row_c2r_one(const RowLoadTiled<T>& lp, const RowStoreNat<T>& sp, const cx<T>* tw, const cx<T>* twn, int nseq, hipStream_t st) {
     using C = typename RowCfgSel<T, LOGN2, VAR>::type;
-    auto kern = fft_row_c2r_kernel<C>;
+    auto kern = fft_row_c2r_kernel<C, RowLoadTiled<T>>;
     constexpr size_t part = size_t(C::E) * C::LDS_ELEMS * sizeof(cx<T>);
     constexpr size_t LDSB = C::LDS_BYTES > part ? C::LDS_BYTES : part;
     if (LDSB > 48 * 1024) {
@@ -195,6 +202,34 @@ int launch_row_c2r_impl(int logn2, const RowLoadTiled<T>& lp, const RowStoreNat<
         case 12:
             if constexpr (sizeof(T) == 4) return launch_row_c2r_one<T, 12, 4>(lp, sp, tw, twn, nseq, st);
             else return -2;     // complex128 rows of 4096 complex points exchange re / im separately: not on this path
+        default: return -2;
+    }
+}
+
+template <typename T, int LOGN2>
+int launch_row_c2r_fold_one(const RowLoadFold<T>& lp, const RowStoreNat<T>& sp, const cx<T>* tw, const cx<T>* twn, int npairs, hipStream_t st) {
+    using C = typename RowCfgSel<T, LOGN2, 4>::type;       // two rows per thread: the pair (n, n + M/2) the unfold rebuilds
+    auto kern = fft_row_c2r_kernel<C, RowLoadFold<T>>;
+    constexpr size_t part = size_t(C::E) * C::LDS_ELEMS * sizeof(cx<T>);
+    constexpr size_t LDSB = C::LDS_BYTES > part ? C::LDS_BYTES : part;
+    if (LDSB > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
+        if (e != hipSuccess) return int(e);
+    }
+    const int grid = (npairs + C::BO - 1) / C::BO;
+    if (grid <= 0) return 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDSB, st, lp, sp, tw, twn);
+    return int(hipGetLastError());
+}
+
+template <typename T>
+int launch_row_c2r_fold_impl(int logn2, const RowLoadFold<T>& lp, const RowStoreNat<T>& sp, const cx<T>* tw, const cx<T>* twn, int npairs,
+                             hipStream_t st) {
+    switch (logn2) {
+        case 11: return launch_row_c2r_fold_one<T, 11>(lp, sp, tw, twn, npairs, st);
+        case 12:
+            if constexpr (sizeof(T) == 4) return launch_row_c2r_fold_one<T, 12>(lp, sp, tw, twn, npairs, st);
+            else return -2;
         default: return -2;
     }
 }

@@ -7,4 +7,7 @@ template <> int launch_col_mul_herm<double>(int logm, const ColLoadTiled<double>
 template <> int launch_row_c2r<double>(int logn2, const RowLoadTiled<double>& l, const RowStoreNat<double>& s, const cx<double>* tw2, const cx<double>* twn, int nseq, hipStream_t st) {
     return launch_row_c2r_impl<double>(logn2, l, s, tw2, twn, nseq, st);
 }
+template <> int launch_row_c2r_fold<double>(int logn2, const RowLoadFold<double>& l, const RowStoreNat<double>& s, const cx<double>* tw2, const cx<double>* twn, int npairs, hipStream_t st) {
+    return launch_row_c2r_fold_impl<double>(logn2, l, s, tw2, twn, npairs, st);
+}
 }  // namespace pm

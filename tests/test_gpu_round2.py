@@ -715,18 +715,23 @@ def test_real_convolution_on_half_spectra_vs_numpy(pa, shape, dtype):
     psf = rng.random(shape).astype(dtype)
     H_real_psf = np.fft.fft2(psf.astype(np.float64))
     H_any = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
-    for H, conj in ((H_real_psf, False), (H_any, False), (H_any, True)):
-        Hd = torch.from_numpy(H.astype(cdt)).cuda()
-        for sh in ((0, 0), (M // 2, N // 2), (1 if M > 2 else 0, 0)):
-            x = np.roll(o.astype(np.float64), (-sh[0], -sh[1]), axis=(0, 1))
-            full = np.fft.ifft2(np.fft.fft2(x) * (np.conj(H) if conj else H))
-            want = np.roll(full.real, sh, axis=(0, 1))
-            got = _ops.fft2_mul_ifft2(od, scale=1.0 / (M * N), mul=Hd, mul_conj=conj, in_shift=sh, out_shift=sh, real_out=True)
-            assert got.dtype == (torch.float32 if dtype == np.float32 else torch.float64) and not got.is_complex()
-            assert got.is_contiguous()       # the half-spectrum chain (a `.real` view of the complex result would not be)
-            assert rel_max(tonp(got), want) < tol, (conj, sh)
-            cplx = _ops.fft2_mul_ifft2(od, scale=1.0 / (M * N), mul=Hd, mul_conj=conj, in_shift=sh, out_shift=sh)
-            assert rel_max(tonp(got), tonp(cplx).real) < tol
+    lib = _lib.load()
+    assert lib.pm_set_tuning(b'r2c', 2) == 0       # also below 2048^2, where the library prefers the complex chain (it is as fast there)
+    try:
+        for H, conj in ((H_real_psf, False), (H_any, False), (H_any, True)):
+            Hd = torch.from_numpy(H.astype(cdt)).cuda()
+            for sh in ((0, 0), (M // 2, N // 2), (1 if M > 2 else 0, 0)):
+                x = np.roll(o.astype(np.float64), (-sh[0], -sh[1]), axis=(0, 1))
+                full = np.fft.ifft2(np.fft.fft2(x) * (np.conj(H) if conj else H))
+                want = np.roll(full.real, sh, axis=(0, 1))
+                got = _ops.fft2_mul_ifft2(od, scale=1.0 / (M * N), mul=Hd, mul_conj=conj, in_shift=sh, out_shift=sh, real_out=True)
+                assert got.dtype == (torch.float32 if dtype == np.float32 else torch.float64) and not got.is_complex()
+                assert got.is_contiguous()       # the half-spectrum chain (a `.real` view of the complex result would not be)
+                assert rel_max(tonp(got), want) < tol, (conj, sh)
+                cplx = _ops.fft2_mul_ifft2(od, scale=1.0 / (M * N), mul=Hd, mul_conj=conj, in_shift=sh, out_shift=sh)
+                assert rel_max(tonp(got), tonp(cplx).real) < tol
+    finally:
+        lib.pm_set_tuning(b'r2c', 1)
 
 
 def test_real_convolution_callers_and_fallback(pa):
@@ -749,3 +754,33 @@ def test_real_convolution_callers_and_fallback(pa):
     got = _ops.fft2_mul_ifft2(torch.from_numpy(o).cuda(), scale=1.0, mul=H, in_shift=(0, 5), out_shift=(0, 5), real_out=True)   # x rotation by 5
     want = np.roll(np.fft.ifft2(np.fft.fft2(np.roll(o, (0, -5), axis=(0, 1))) * H.cpu().numpy()).real * o.size, (0, 5), axis=(0, 1))
     assert rel_max(tonp(got), want) < 1e-10
+
+
+@pytest.mark.parametrize('shape,dtype', [((4, 4096), np.float64), ((64, 4096), np.float32), ((16, 8192), np.float32), ((4096, 4096), np.float64)])
+def test_real_convolution_folded_form(pa, shape, dtype):
+    """the half-spectrum chain with the radix-2 step of the column transforms folded into its first and last row pass (automatic from
+    4096-row objects with rows of 4096 / 8192 samples; forced here on short columns too), against numpy and the unfolded form"""
+    from prysm_amd import _lib, _ops
+    lib = _lib.load()
+    rng = np.random.default_rng(shape[0] + shape[1])
+    M, N = shape
+    cdt = np.complex64 if dtype == np.float32 else np.complex128
+    tol = 2e-5 if dtype == np.float32 else 1e-10
+    o = rng.standard_normal(shape).astype(dtype)
+    od = torch.from_numpy(o).cuda()
+    H = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    Hd = torch.from_numpy(H.astype(cdt)).cuda()
+    try:
+        lib.pm_set_tuning(b'r2c', 2)
+        for sh in ((0, 0), (M // 2, N // 2), (0, N // 2)):
+            x = np.roll(o.astype(np.float64), (-sh[0], -sh[1]), axis=(0, 1))
+            want = np.roll(np.fft.ifft2(np.fft.fft2(x) * H).real, sh, axis=(0, 1))
+            assert lib.pm_set_tuning(b'fold', 1) == 0
+            got = _ops.fft2_mul_ifft2(od, scale=1.0 / (M * N), mul=Hd, in_shift=sh, out_shift=sh, real_out=True)
+            assert got.is_contiguous() and rel_max(tonp(got), want) < tol, sh
+            lib.pm_set_tuning(b'fold', 0)
+            flat = _ops.fft2_mul_ifft2(od, scale=1.0 / (M * N), mul=Hd, in_shift=sh, out_shift=sh, real_out=True)
+            assert rel_max(tonp(got), tonp(flat)) < tol
+    finally:
+        lib.pm_set_tuning(b'fold', -1)
+        lib.pm_set_tuning(b'r2c', 1)
