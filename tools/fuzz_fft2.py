@@ -143,6 +143,49 @@ def fuzz_gemm(ncases, rng, lib):
     return nfail
 
 
+def fuzz_real_conv(ncases, rng, lib):
+    """real_out=True of the same chain on a REAL object: real(ifft2(fft2(x) H)) -- the half-spectrum chain (forced for every legal
+    shape, folded and not) or the real part of the complex chain, random rotations, general / conjugated multipliers, both precisions."""
+    sizes = [2, 8, 32, 64, 128, 256, 1024, 4096, 12, 100]
+    nfail, worst = 0, 0.0
+    lib.pm_set_tuning(b'r2c', 2)
+    for case in range(ncases):
+        M, N = int(rng.choice(sizes)), int(rng.choice(sizes[2:]))
+        if M * N > (1 << 22):
+            M = 64
+        rdt = np.float32 if rng.random() < 0.5 else np.float64
+        cdt = np.complex64 if rdt == np.float32 else np.complex128
+        shy = int(rng.choice([0, M // 2, int(rng.integers(0, M))]))
+        shx = int(rng.choice([0, N // 2, N // 2, int(rng.integers(0, N))]))
+        conj = rng.random() < 0.3
+        fold = int(rng.choice([-1, 0, 1]))
+        lib.pm_set_tuning(b'fold', fold)
+        x = rng.standard_normal((M, N)).astype(rdt)
+        H = (rng.standard_normal((M, N)) + 1j * rng.standard_normal((M, N))).astype(cdt)
+        try:
+            got = _ops.fft2_mul_ifft2(torch.from_numpy(x).cuda(), scale=1.0 / (M * N), mul=torch.from_numpy(H).cuda(), mul_conj=conj,
+                                      in_shift=(shy, shx), out_shift=(shy, shx), real_out=True)
+            assert not got.is_complex()
+            got = got.cpu().numpy()
+        except Exception as exc:
+            print('real conv case', case, 'EXC', repr(exc)[:200], (M, N, rdt.__name__, shy, shx, conj, fold))
+            nfail += 1
+            continue
+        xr = np.roll(x.astype(np.float64), (-shy, -shx), axis=(0, 1))
+        h = H.astype(np.complex128)
+        want = np.roll(np.fft.ifft2(np.fft.fft2(xr) * (np.conj(h) if conj else h)).real, (shy, shx), axis=(0, 1))
+        err = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+        tol = 1e-4 if rdt == np.float32 else 1e-10
+        worst = max(worst, err / tol)
+        if not err < tol:
+            nfail += 1
+            print('real conv case', case, 'FAIL err', err, (M, N, rdt.__name__, shy, shx, conj, fold))
+    lib.pm_set_tuning(b'fold', -1)
+    lib.pm_set_tuning(b'r2c', 1)
+    print(f'fuzz_real_conv: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
+    return nfail
+
+
 def fuzz_fft1(ncases, rng, lib):
     """pm_fft1_ws through _ops.fft1: engine, direct, Bluestein, mixed-radix (3 / 5 / 7 x 2^k) and -- with the native length lowered --
     radix-2 / radix-4 lengths, both axes and directions, zero-padded inputs at an offset, windows of the bins, a scale."""
@@ -323,6 +366,7 @@ def main():
     nfail += fuzz_fused(max(20, ncases // 2), rng, lib)
     nfail += fuzz_gemm(max(20, ncases // 2), rng, lib)
     nfail += fuzz_fft1(max(30, ncases // 2), rng, lib)
+    nfail += fuzz_real_conv(max(20, ncases // 3), rng, lib)
     nfail += fuzz_spectral(max(12, ncases // 4), rng, lib)
     return 1 if nfail else 0
 
