@@ -6,7 +6,6 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
 ( timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 ) > $O/pytest_gpu.log 2>&1
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
-( timeout 900 python bench.py ) > $O/bench.log 2>&1
 prof() {   # name, bench arguments...
   n=$1; shift
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$n -- python $R/bench.py "$@" ) > $O/rocprof_$n.log 2>&1
@@ -16,6 +15,9 @@ prof() {   # name, bench arguments...
   cp "$(ls $O/prof_$n/*/*kernel_stats.csv | tail -1)" $O/${n}_kernel_stats.csv
 }
 prof bench --steps 40 --warmup 5 --no-cpu-baseline --no-poly
+# the default bench line AFTER the PMC passes of the same sources: its roofline.traffic comes from the summary just collected
+cp $O/pmc_bench_summary.json $R/profiles/pmc_bench_summary.json
+( timeout 900 python bench.py ) > $O/bench.log 2>&1
 for c in config2 config3 config4 c128 n8192 mtf conv poly2048; do prof $c --only $c; done
 ( cd /tmp && timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq_config4 -- python $R/bench.py --only config4 ) > $O/rocprof_sq_config4.log 2>&1
 python tools/pmc_clock.py $O/pmc_sq_config4 2>&1 | grep pm:: > $O/config4_mfma_busy.txt
