@@ -186,7 +186,6 @@ def other_configs(only=''):
     the same run: algorithmic bytes / flops per SURVEY 8(d) over HIP-event time on the launch stream.  Parity-tested
     cases reported for the roofline the north star asks for; not the headline value."""
     from prysm_amd import propagation as P
-    from prysm_amd import fttools
     from prysm_amd.conf import config
     out = {}
 

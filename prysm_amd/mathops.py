@@ -13,7 +13,7 @@ import numpy as _np
 import torch
 
 from . import _lib as L
-from .npfacade import NumpyFacade, DeviceArray, _wrap
+from .npfacade import NumpyFacade, _wrap
 
 _scalar_types = (Number, _np.generic)
 

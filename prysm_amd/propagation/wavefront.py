@@ -14,7 +14,6 @@ import torch
 
 from .. import _lib as L
 from .. import _ops
-from ..conf import config
 from .._richdata import RichData
 from ._kernels import phase_prefix
 from .fft import (

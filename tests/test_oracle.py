@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import prysm_oracle as O
-from conftest import rel_l2, rel_max
+from conftest import rel_max
 
 TOL = 1e-12
 
