@@ -126,6 +126,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("mixed_radix")) t.mixed_radix = v ? 1 : 0;
     else if (is("r2c")) t.r2c = v < 0 ? -1 : (v > 1 ? 2 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
+    else if (is("herm_wide")) t.herm_wide = v;
     else if (is("spectral")) t.spectral = v;
     else if (is("spectral_mode")) t.spectral_mode = v & 3;
     else if (is("spectral_area_log")) t.spectral_area_log = v;
@@ -257,6 +258,11 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
         p.fold = (f > 0 || (f < 0 && p.logm >= 10)) && p.logm >= 5 && (d->in_y.shift == 0 || d->in_y.shift == M / 2) &&
                  (d->out_y.shift == 0 || d->out_y.shift == M / 2);
         if (p.fold) p.tc = col_tile_width_for(d->dtype, p.logm - 1, 0);
+        const int tlog = p.fold ? p.logm - 1 : p.logm;
+        if (tuning().herm_wide && tlog == 11 && (N / 2) % col_tile_width_for(d->dtype, 11, 2) == 0) {
+            p.col_var = 2;
+            p.tc = col_tile_width_for(d->dtype, 11, 2);
+        }
         while (p.log_k > 0 && ((N / 2) % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
         const int64_t nc = N / 2, tl = int64_t(p.tc) << p.log_k;
         p.ws_bytes = size_t((nc + tl - 1) / tl) * size_t(M) * size_t(tl) * es;
@@ -420,12 +426,12 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
             if (!twh) return err;
             ColLoadTiled<T> cl{W, H, AxisMap{H, H, 0, 0}, ntiles, p.log_k, plane};
             HermStore<T> hs{out, 2 * d->out_ld, AxisMap{H, H, 0, int(d->out_y.shift / 2)}, to_map(d->out_x), H, int(N), d->epilogue,
-                            T(d->scale), T(d->weight), (d->flags & PM_FLAG_NORM_DC) ? 1 : 0, W, tl, H, 0, d->out_ld, fast};
+                            T(d->scale), T(d->weight), (d->flags & PM_FLAG_NORM_DC) ? 1 : 0, W, tl, H, 0, d->out_ld, fast, p.col_var == 2 ? 1 : 0};
             return launch_col_herm<T>(p.logm - 1, cl, hs, twh, ntiles, sibling_log_g(p.log_k), st);
         }
         ColLoadTiled<T> cl{W, int(M), to_map(d->in_y), ntiles, p.log_k, 0};
         HermStore<T> hs{out, d->out_ld, to_map(d->out_y), to_map(d->out_x), int(M), int(N), d->epilogue, T(d->scale), T(d->weight),
-                        (d->flags & PM_FLAG_NORM_DC) ? 1 : 0, W, tl, int(M), -1, 0, fast};
+                        (d->flags & PM_FLAG_NORM_DC) ? 1 : 0, W, tl, int(M), -1, 0, fast, p.col_var == 2 ? 1 : 0};
         return launch_col_herm<T>(p.logm, cl, hs, twm, ntiles, sibling_log_g(p.log_k), st);
     }
 

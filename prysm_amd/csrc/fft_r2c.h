@@ -346,9 +346,9 @@ int launch_row_r2c_impl(int logn2, const RowLoadNat<T>& lp, const R2CRowStore<T>
     }
 }
 
-template <typename T, int LOGM, int EPI>
+template <typename T, int LOGM, int EPI, int VAR = 0>
 int launch_col_herm_epi(const ColLoadTiled<T>& lp, const HermStore<T>& sp, const cx<T>* tw, int ntiles, int log_g, hipStream_t st) {
-    using C = typename ColCfgSel<T, LOGM, 0>::type;
+    using C = typename ColCfgSel<T, LOGM, VAR>::type;
     auto kern = fft_col_herm_kernel<C, EPI>;
     constexpr size_t red = size_t(C::NT) * sizeof(double);                  // the DC reduction
     constexpr size_t part = size_t(C::BO) * C::N * sizeof(cx<T>);           // the partner exchange of the packed column
@@ -366,6 +366,17 @@ int launch_col_herm_epi(const ColLoadTiled<T>& lp, const HermStore<T>& sp, const
 
 template <typename T, int LOGM>
 int launch_col_herm_one(const ColLoadTiled<T>& lp, const HermStore<T>& sp, const cx<T>* tw, int ntiles, int log_g, hipStream_t st) {
+    if constexpr (LOGM == 11) {
+        if (sp.wide) {
+            switch (sp.epilogue) {
+                case EPI_NONE: return launch_col_herm_epi<T, LOGM, EPI_NONE, 2>(lp, sp, tw, ntiles, log_g, st);
+                case EPI_ABS2: return launch_col_herm_epi<T, LOGM, EPI_ABS2, 2>(lp, sp, tw, ntiles, log_g, st);
+                case EPI_ABS: return launch_col_herm_epi<T, LOGM, EPI_ABS, 2>(lp, sp, tw, ntiles, log_g, st);
+                case EPI_ARG: return launch_col_herm_epi<T, LOGM, EPI_ARG, 2>(lp, sp, tw, ntiles, log_g, st);
+                default: return -2;
+            }
+        }
+    }
     switch (sp.epilogue) {      // one kernel per epilogue: the phase angle alone (atan2, 32 times per thread) is most of a kernel's code
         case EPI_NONE: return launch_col_herm_epi<T, LOGM, EPI_NONE>(lp, sp, tw, ntiles, log_g, st);
         case EPI_ABS2: return launch_col_herm_epi<T, LOGM, EPI_ABS2>(lp, sp, tw, ntiles, log_g, st);

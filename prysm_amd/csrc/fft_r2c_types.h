@@ -39,6 +39,7 @@ struct HermStore {
                         // M is then the length of ONE plane's transform, dst / ld / ay describe the plane's rows (ld doubled)
     int64_t plane_dst;  // elements (of the output type) from plane 0's first row to plane 1's
     int fast;           // unwindowed output, rotations by 0 or half a length, 16-byte alignable rows: the map-free store applies
+    int wide;           // 2048-point tiles of 16 complex64 / 8 complex128 columns (ColCfgSel variant 2): 64 B pieces of a real output
 };
 
 template <typename T> int launch_row_r2c(int logn2, const RowLoadNat<T>&, const R2CRowStore<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t);

@@ -114,6 +114,8 @@ struct Tuning {
     int big_native_log = 13;  // log2 of the longest length handed to the engine as it is; longer powers of two (up to 4x) take
                              // one radix-2 / radix-4 step around engine transforms (bigfft.hip).  Tests lower it to run that
                              // path on small arrays.
+    int herm_wide = 1;        // Hermitian column pass: tiles of 16 complex64 / 8 complex128 columns for 2048-point columns -- its real epilogues then
+                              // write 64 B pieces, direct and mirrored (MTF 4096^2 fp32 88.4 -> 81.4 us, fp64 176 -> 168; profiles/r02/exp_mtf_wide.log)
     int spectral = 8;         // pm_fft2_spectral: wavelengths per launch pair (fft_spectral.h; <= 8); 1: the plain loop of pm_fft2 calls
     int spectral_area_log = 24;   // ... for transforms of fewer than 2^this bins (capi.hip spectral_fast has the measurements)
     int spectral_mode = 3;    // ... bit 0: its row pass keeps the packed map in registers, bit 1: its column pass accumulates in registers
