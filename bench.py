@@ -361,7 +361,10 @@ def polychromatic_config5(ranks, n, reps=3):
     prec = config.precision
     config.precision = 32     # fp32 maps -> complex64 pupils; at the default precision 64 the executors' bases would be complex128
     try:                      # and promote the whole matrix DFT to fp64 MFMA (numpy's result-type rule)
-        for name, fn, k in (('variant_F_fft_focus', var_f, reps), ('variant_M_mdft_512', var_m, reps)):
+        def var_c():
+            polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, focal_dx=0.55 * 10 / 4, samples=512, kind='czt', reduce_to_all=False)
+
+        for name, fn, k in (('variant_F_fft_focus', var_f, reps), ('variant_M_mdft_512', var_m, reps), ('variant_M_czt_512', var_c, reps)):
             fn()    # warm: plans, communicator, allocator
             ts = sorted(ranks.timed(fn) for _ in range(k))
             t = ts[len(ts) // 2]
@@ -373,7 +376,9 @@ def polychromatic_config5(ranks, n, reps=3):
     res['variant_M_mdft_512']['algorithmic_TFLOPs_whole_job'] = fl / (res['variant_M_mdft_512']['psf_ms'] * 1e-3) / 1e12
     res['note'] = ('timed polychromatic_psf calls (barrier + synchronize on both sides, MAX over ranks, median): F = per wavelength '
                    'pupil synthesis + FFT focus (Q = 1) with fused |.|^2 accumulate; M = prepare_executor + matrix-DFT focus to a '
-                   '512^2 grid (focal_dx 1.375 um) + |.|^2 accumulate; both end with the sum-reduce of the image to rank 0')
+                   '512^2 grid (focal_dx 1.375 um) + |.|^2 accumulate; variant_M_czt_512 = the same grid and image through the chirp-Z '
+                   'executor prysm offers beside the matrix DFT (kind="czt": two fused convolution kernels per wavelength instead of two '
+                   'GEMMs); all end with the sum-reduce of the image to rank 0')
     return res
 
 

@@ -315,6 +315,14 @@ int pm_embed(int32_t elem_bytes, int64_t irows, int64_t icols, const void* in, i
 int pm_pad_index(int32_t elem_bytes, int32_t mode, int64_t irows, int64_t icols, const void* in, int64_t in_ld, int64_t orows,
                  int64_t ocols, int64_t off_y, int64_t off_x, void* out, int64_t out_ld, void* stream);
 
+/* The chirps of one chirp-Z axis from its scalars, one launch (prysm/fttools.py:364-389 _prepare_czt_basis: arange / exp / zero-pad
+ * as a dozen array operations per axis -- the polychromatic recipe builds one executor per wavelength): with e(t) = exp(2 pi i t),
+ *   b[j] = e(half n^2), n = j - N/2 (j < N);   a[i] = e(half q^2), q = i - M/2 + shift (i < M);
+ *   h[t] = e(-half (d + shift)^2), d = t - M/2 - (N - 1 - N/2) for t < N + M - 1, zero up to K  (its transform is the H of pm_czt_axis);
+ * half = sign dx dfx / 2, shift = f[M/2] / dfx. */
+int pm_czt_vectors(int32_t dtype, int64_t N, int64_t M, int64_t K, double shift, double half, void* b, void* a, void* h,
+                   void* stream);
+
 /* --- matrix DFT --------------------------------------------------------------------------- */
 
 /* E[m][n] = exp(sign * 2 pi i * f[m] * x[n]) (M x N), phases reduced in fp64, rounded once.

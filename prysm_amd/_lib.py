@@ -61,6 +61,7 @@ SIGNATURES = {
     'pm_fft1_workspace': (c_sz, [c_i32, c_i32, c_i64, c_i64]),
     'pm_fft1_ws': (c_i32, [c_i32, c_i32, c_i32, c_i64, ctypes.POINTER(pm_axis), ctypes.POINTER(pm_axis), c_f64,
                            c_vp, c_i64, c_vp, c_i64, c_vp, c_sz, c_vp]),
+    'pm_czt_vectors': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_f64, c_f64, c_vp, c_vp, c_vp, c_vp]),
     'pm_czt_axis': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_f64,
                             c_vp, c_i64, c_vp, c_i64, c_vp]),
     'pm_cmul': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),

@@ -271,6 +271,17 @@ def fft1(x, n=None, axis=-1, direction=-1, scale=1.0, out_len=None, out_off=0, i
     return out
 
 
+def czt_vectors(N, M, K, shift, half, cdtype):
+    """The chirps (b, a, h) of one chirp-Z axis from its scalars in one launch (pm_czt_vectors)."""
+    lib = L.load()
+    dev = L.device()
+    b = torch.empty(N, dtype=cdtype, device=dev)
+    a = torch.empty(M, dtype=cdtype, device=dev)
+    h = torch.empty(K, dtype=cdtype, device=dev)
+    L.check(lib.pm_czt_vectors(L.code(b), N, M, K, float(shift), float(half), L.ptr(b), L.ptr(a), L.ptr(h), L.stream_ptr()))
+    return b, a, h
+
+
 def czt_axis(x, K, axis, H, *, pre=None, post=None, out_len, in_off=0, out_off=0, conj=False, scale=1.0):
     """One axis of a chirp-Z transform in one kernel (pm_czt_axis): scale * post * IFFT_K(FFT_K(pad_K(pre * x)) * H)[out_off : out_off
     + out_len] along `axis` of the 2-D tensor x; `conj` conjugates pre, H and post (the adjoint).  K must be an engine length."""

@@ -379,6 +379,35 @@ __global__ void mdft_basis_kernel(int64_t M, int64_t N, const T* f, const T* x, 
     }
 }
 
+// ---------------------------------------------------------------- chirp-Z vectors
+// The three chirps of one CZT axis (prysm/fttools.py:364-389 _prepare_czt_basis) from its scalars, one launch: input chirp
+// b[j] = e(half n^2), n = j - N/2; output chirp a[i] = e(half q^2), q = i - M/2 + shift; convolution kernel h[t] = e(-half (d + shift)^2),
+// d = t - M/2 - (N - 1 - N/2) for t < N + M - 1 and 0 up to K; e(t) = exp(2 pi i t) with the turns reduced in fp64.
+template <typename T>
+__global__ void czt_vectors_kernel(int64_t N, int64_t M, int64_t K, double shift, double half, cx<T>* b, cx<T>* a, cx<T>* h) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    double s, c;
+    if (g < N) {
+        const double n = double(g - N / 2);
+        sincos_turns(half * n * n, &s, &c);
+        b[g] = {T(c), T(s)};
+    } else if (g < N + M) {
+        const int64_t i = g - N;
+        const double q = double(i - M / 2) + shift;
+        sincos_turns(half * q * q, &s, &c);
+        a[i] = {T(c), T(s)};
+    } else if (g < N + M + K) {
+        const int64_t t = g - N - M;
+        cx<T> v = {T(0), T(0)};
+        if (t < N + M - 1) {
+            const double d = double(t - M / 2 - (N - 1 - N / 2)) + shift;
+            sincos_turns(-half * d * d, &s, &c);
+            v = {T(c), T(s)};
+        }
+        h[t] = v;
+    }
+}
+
 // rounded-once products / sums in T: hipcc contracts a * b + c into an fma by default (and HIP's __fmul_rn is a plain product that
 // contracts just the same after inlining), but the grids must equal the vectors torch / numpy build operation by operation
 template <typename T> __device__ __forceinline__ T mul_rn(T a, T b) {
@@ -713,6 +742,21 @@ int pm_mdft_basis_grid(int32_t dtype, int64_t M, int64_t N, double f_step, doubl
                            double(sign), (cx<double>*)E, E_ld);
     else
         return fail(PM_ERR_ARG, "pm_mdft_basis_grid: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
+}
+
+int pm_czt_vectors(int32_t dtype, int64_t N, int64_t M, int64_t K, double shift, double half, void* b, void* a, void* h, void* stream) {
+    if (!b || !a || !h || N < 1 || M < 1 || K < N + M - 1) return fail(PM_ERR_ARG, "pm_czt_vectors: bad argument");
+    const int64_t total = N + M + K;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == PM_C64)
+        hipLaunchKernelGGL(czt_vectors_kernel<float>, grid, dim3(256), 0, PM_STREAM(stream), N, M, K, shift, half, (cx<float>*)b, (cx<float>*)a,
+                           (cx<float>*)h);
+    else if (dtype == PM_C128)
+        hipLaunchKernelGGL(czt_vectors_kernel<double>, grid, dim3(256), 0, PM_STREAM(stream), N, M, K, shift, half, (cx<double>*)b,
+                           (cx<double>*)a, (cx<double>*)h);
+    else
+        return fail(PM_ERR_ARG, "pm_czt_vectors: dtype must be PM_C64 or PM_C128");
     return int(hipGetLastError());
 }
 

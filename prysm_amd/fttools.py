@@ -272,6 +272,43 @@ class CZT:
         # post-slice factors a * phase, applied in one sweep
         self._post_col = (self._acol * self._x_phase).contiguous()
         self._post_row = (self._arow * self._y_phase).contiguous()
+        self._finish(Nx, Ny, Mx, My, Kx, Ky)
+
+    @classmethod
+    def _for_focus_grids(cls, pupil_samples, focal_samples, pupil_dx, focal_dx, focal_shift, inv_lz, rdtype, sign, norm):
+        """The operator prepare_executor builds -- CZT(*coordinates_for_focus(...)) -- from the grid parameters: the handful of
+        coordinate samples the constructor reads (x[0], x[1], f[0], f[1], f[M/2]) are formed on the host in the precision the
+        vectors would have, and the chirps of each axis come from one kernel (pm_czt_vectors) + one transform, where the constructor
+        issues a dozen small array operations and five device-to-host reads per axis (750 -> ~100 us per executor; the polychromatic
+        recipe builds one per wavelength).  Pupil grids are FFT-centred, so x[N/2] = 0 and the centre phase ramp is 1."""
+        if sign not in (-1, 1):
+            raise ValueError(f'sign must be -1 or +1, got {sign}')
+        dt = truenp.float32 if rdtype == torch.float32 else truenp.float64
+        cd = L._COMPLEX_OF[rdtype]
+        self = cls.__new__(cls)
+        self.sign, self.norm = sign, norm
+
+        def axis(N, M, fshift):
+            xv = lambda j: float(dt(j - N // 2) * dt(pupil_dx))                                     # noqa: E731
+            fv = lambda i: float((dt(i - M // 2) * dt(focal_dx) + dt(fshift)) * dt(inv_lz))          # noqa: E731
+            dxs = xv(1) - xv(0)
+            dfs = fv(1) - fv(0)
+            K = _czt_len(N + M - 1)
+            b, a, h = _ops.czt_vectors(N, M, K, fv(M // 2) / dfs, sign * dxs * dfs / 2.0, cd)
+            return _ops.fft1(h, K, axis=-1), b, a, K
+
+        (pny, pnx), (fny, fnx) = pupil_samples, focal_samples
+        fsx, fsy = focal_shift
+        Hx, bx, ax, Kx = axis(pnx, fnx, fsx)
+        Hy, by, ay, Ky = axis(pny, fny, fsy)
+        self._brow, self._Hrow, self._arow = by, Hy, ay
+        self._bcol, self._Hcol, self._acol = bx, Hx, ax
+        self._x_phase = self._y_phase = None
+        self._post_col, self._post_row = ax, ay
+        self._finish(pnx, pny, fnx, fny, Kx, Ky)
+        return self
+
+    def _finish(self, Nx, Ny, Mx, My, Kx, Ky):
         self._Nx, self._Ny, self._Mx, self._My = Nx, Ny, Mx, My
         self._Kx, self._Ky = Kx, Ky
         self._sx, self._sy = Nx - 1, Ny - 1
@@ -366,9 +403,9 @@ class CZT:
 
     def nbytes(self):
         total = 0
-        for arr in (self._brow, self._bcol, self._Hrow, self._Hcol, self._arow, self._acol,
-                    self._x_phase, self._y_phase):
+        for arr in (self._brow, self._bcol, self._Hrow, self._Hcol, self._arow, self._acol):
             total += arr.numel() * arr.element_size()
+        total += (self._Mx + self._My) * self._arow.element_size()      # the two centre phase ramps (all ones for a centred pupil grid)
         return total
 
 

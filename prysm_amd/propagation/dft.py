@@ -53,6 +53,16 @@ def prepare_executor(pupil_dx, pupil_samples, focal_dx, focal_samples,
         op.pupil_dx = pupil_dx
         op.focal_dx = focal_dx
         return op
+    if kind == 'czt':
+        # CZT(*coordinates_for_focus(...)) from the grid parameters, like the MDFT above (one kernel + one transform per axis)
+        ps = pupil_samples if isinstance(pupil_samples, Iterable) else (pupil_samples, pupil_samples)
+        fs = focal_samples if isinstance(focal_samples, Iterable) else (focal_samples, focal_samples)
+        if min(int(v) for v in ps) >= 2 and min(int(v) for v in fs) >= 2:
+            op = CZT._for_focus_grids(tuple(int(v) for v in ps), tuple(int(v) for v in fs), pupil_dx, focal_dx, focal_shift,
+                                      1.0 / (wavelength * efl), L.torch_dtype(config.precision), -1, norm)
+            op.pupil_dx = pupil_dx
+            op.focal_dx = focal_dx
+            return op
     x, y, fx, fy = coordinates_for_focus(pupil_dx, pupil_samples, focal_dx, focal_samples,
                                          wavelength, efl, focal_shift)
     if kind == 'czt':

@@ -784,3 +784,32 @@ def test_real_convolution_folded_form(pa, shape, dtype):
     finally:
         lib.pm_set_tuning(b'fold', -1)
         lib.pm_set_tuning(b'r2c', 1)
+
+
+@pytest.mark.parametrize('prec', [32, 64])
+def test_czt_executor_from_grid_parameters_equals_the_constructor(pa, prec):
+    """prepare_executor(kind='czt') builds its chirps from the grid parameters (pm_czt_vectors, no coordinate vectors, no device reads);
+    the result equals CZT(*coordinates_for_focus(...)) and the oracle's executor, forward and adjoint, with a focal shift"""
+    from prysm_amd.conf import config
+    from prysm_amd.propagation import dft
+    P = pa.propagation
+    ft = pa.fttools
+    rng = np.random.default_rng(prec)
+    old = config.precision
+    try:
+        config.precision = prec
+        cdt = np.complex64 if prec == 32 else np.complex128
+        tol = 3e-5 if prec == 32 else 1e-10
+        for ps, fs, shift in (((64, 96), (40, 24), (0.0, 0.0)), ((128, 128), (64, 64), (1.3, -0.7)), ((33, 20), (12, 17), (0.2, 0.1))):
+            args = (0.05, ps, 1.1, fs, O.HeNe, 100.0)
+            ex = P.prepare_executor(*args, focal_shift=shift, kind='czt')
+            ref = ft.CZT(*dft.coordinates_for_focus(*args, focal_shift=shift), sign=-1, norm=ex.norm)
+            x = (rng.standard_normal(ps) + 1j * rng.standard_normal(ps)).astype(cdt)
+            g = (rng.standard_normal(fs) + 1j * rng.standard_normal(fs)).astype(cdt)
+            assert rel_max(tonp(ex(x)), tonp(ref(x))) < tol / 10
+            assert rel_max(tonp(ex.adjoint(g)), tonp(ref.adjoint(g))) < tol / 10
+            want = O.prepare_executor(*args, focal_shift=shift)(x.astype(np.complex128))
+            assert rel_max(tonp(ex(x)), want) < tol
+            assert ex.nbytes() == ref.nbytes()
+    finally:
+        config.precision = old
