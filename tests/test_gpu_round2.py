@@ -813,3 +813,18 @@ def test_czt_executor_from_grid_parameters_equals_the_constructor(pa, prec):
             assert ex.nbytes() == ref.nbytes()
     finally:
         config.precision = old
+
+
+def test_conv_golden_fixture_on_half_spectra(pa):
+    """the reference's own conv output (tests/golden/wavefront.npz, generated by importing prysm) through the half-spectrum chain
+    (forced: a 64 x 64 object is below the size from which the library prefers it)"""
+    from prysm_amd import _lib
+    lib = _lib.load()
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'wavefront.npz'))
+    try:
+        assert lib.pm_set_tuning(b'r2c', 2) == 0
+        out = pa.convolution.conv(g['conv_obj'], g['conv_psf'])
+        assert not out.is_complex() and out.is_contiguous()
+        assert rel_max(tonp(out), g['conv_out']) < TOL64
+    finally:
+        lib.pm_set_tuning(b'r2c', 1)
