@@ -634,3 +634,25 @@ def test_apply_transfer_functions_composes_smear_and_jitter(pa):
     assert np.isfinite(out).all()
     # a constant object only has a DC term, and both transfer functions are 1 there
     np.testing.assert_allclose(out, 1, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------- tests/test_physics.py
+
+@pytest.mark.parametrize('efl, epd, wvl', [(10.0, 1.000, 0.5), (10.0, 1.000, 1.0), (3.00, 1.125, 3.0)])
+def test_diffprop_matches_analyticmtf(pa, P, efl, epd, wvl):
+    """tests/test_physics.py:41-57: the MTF of the FFT-propagated PSF of a circular pupil against the diffraction-limited MTF
+    2/pi (acos s - s sqrt(1 - s^2)), s = f / (1 / (lambda fno)), along both axes (atol 1e-3, as upstream); the analytic formula
+    (prysm/otf.py:496-545) and the centre slices (RichData.slices) are written out here"""
+    fno = efl / epd
+    x, y = make_xy_grid(128, dx=epd / 128)
+    amp = (np.hypot(x, y) <= epd / 2).astype(float)
+    wf = P.Wavefront.from_amp_and_phase(amp, None, wvl, float(x[0, 1] - x[0, 0]))
+    psf = wf.focus(efl, Q=3).intensity
+    mtf = pa.otf.mtf_from_psf(psf.data, psf.dx)
+    data = tonp(mtf)
+    n = data.shape[0]
+    u = (np.arange(n) - n // 2) * float(mtf.dx)
+    s = np.minimum(np.abs(u / (1 / (wvl / 1000 * fno))), 1.0)
+    analytic = 2 / np.pi * (np.arccos(s) - s * np.sqrt(1 - s ** 2))
+    assert np.allclose(analytic, data[n // 2, :], atol=1e-3)
+    assert np.allclose(analytic, data[:, n // 2], atol=1e-3)
