@@ -1236,7 +1236,7 @@ static bool spectral_fast(const pm_fft2_desc* d, const Fft2Plan& p) {
     const int want = PM_FLAG_SYNTH_INPUT | PM_FLAG_SYNTH_PACKED;
     return tuning().spectral > 1 && d->dtype == PM_C64 && (d->flags & want) == want && !(d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY)) &&
            d->epilogue == PM_EPI_ABS2_ACCUM && d->batch <= 1 && d->mul_kind == PM_MUL_NONE && !p.r2c && !p.big_rn && !p.blue2d &&
-           p.logn >= 5 && p.logm >= 5 && p.tc != 0 && p.col_var == 0 && d->in_y.len > 0 && p.logn + p.logm < tuning().spectral_area_log;
+           p.logn >= 5 && p.logm >= (p.fold ? 6 : 5) && p.tc != 0 && p.col_var == 0 && d->in_y.len > 0 && p.logn + p.logm < tuning().spectral_area_log;
 }
 static int spectral_group(int32_t count) {
     int g = tuning().spectral;
@@ -1324,7 +1324,8 @@ int pm_fft2_spectral(const pm_fft2_desc* d, int32_t count, const double* k, cons
             w.w[i] = float(weight[b0 + i]);
             w.k2[i] = k[b0 + i] / two_pi;
         }
-        if ((rc = fft2_spectral_group(d, p, w, in, out, workspace, st))) return rc;
+        if ((rc = fft2_spectral_group(d, p, w, in, out, workspace, st)))
+            return rc == -2 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_spectral: internal: no grouped kernel for %lld x %lld", (long long)d->in_y.n, (long long)d->in_x.n) : rc;
     }
     return 0;
 }
