@@ -219,3 +219,44 @@ def test_numpy_facade_runs_the_references_array_code():
         assert have.shape == want.shape and have.dtype == want.dtype, (k, have.dtype, want.dtype)
         tol = 1e-6 if want.dtype in (np.complex64, np.float32) else 1e-14
         assert np.abs(have.astype(complex) - want.astype(complex)).max() <= tol * max(np.abs(want).max(), 1), k
+
+
+def test_next_fast_len_and_czt_length():
+    """fast lengths are what the device transforms without Bluestein's detour: powers of two, and from 96 the lengths 3 / 5 / 7 x 2^k
+    (prysm/fttools.py:23-31 asks the FFT backend); a chirp-Z axis stays on a power of two while one fused kernel holds it (K <= 8192)"""
+    from prysm_amd.fttools import next_fast_len, _czt_len
+    want = {1: 1, 2: 2, 17: 32, 95: 96, 97: 112, 100: 112, 2559: 2560, 3000: 3072, 4096: 4096, 5000: 5120, 7000: 7168, 8703: 10240,
+            9000: 10240, 20000: 20480, 30000: 32768}
+    for n, v in want.items():
+        assert next_fast_len(n) == v, n
+        assert next_fast_len(n) >= n
+    for n in range(1, 3000, 7):
+        v = next_fast_len(n)
+        r = v
+        while r % 2 == 0:
+            r //= 2
+        assert v >= n and r in (1, 3, 5, 7) and (r == 1 or v >= 96)
+    assert _czt_len(2559) == 4096 and _czt_len(4607) == 8192 and _czt_len(8703) == 10240 and _czt_len(11999) == 12288
+
+
+@pytest.mark.parametrize('mode', ['mean', 'maximum', 'minimum', 'median', 'linear_ramp'])
+def test_pad_statistical_modes_on_host_tensors(mode):
+    """fttools._pad_stat is tensor reductions + concatenations: the same code on CPU tensors against np.pad (the GPU suite runs it on
+    the device)"""
+    import torch
+    from prysm_amd.fttools import _pad_stat
+    rng = np.random.default_rng(4)
+    for shape, out_shape in (((9, 12), (14, 18)), ((5, 4), (17, 21)), ((1, 6), (4, 6)), ((6, 7), (6, 12))):
+        for dt in (np.float32, np.float64, np.complex128):
+            if dt is np.complex128 and mode not in ('mean', 'linear_ramp'):
+                with pytest.raises(TypeError):
+                    _pad_stat(torch.zeros(shape, dtype=torch.complex128), [(1, 1), (1, 1)], mode)
+                continue
+            a = rng.standard_normal(shape).astype(dt)
+            if dt is np.complex128:
+                a = a + 1j * rng.standard_normal(shape)
+            widths = [(o - i - (o - i) // 2, (o - i) // 2) for o, i in zip(out_shape, shape)]
+            want = np.pad(a, widths, mode=mode)
+            got = _pad_stat(torch.from_numpy(a), widths, mode).numpy()
+            assert got.dtype == want.dtype and got.shape == want.shape
+            assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
