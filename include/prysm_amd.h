@@ -67,8 +67,9 @@ enum {
     PM_FLAG_SYNTH_INPUT = 8, /* `in` is the real OPD map (float); the transformed field is synth_amp * exp(i synth_k opd),
                              * synthesised while the row pass loads it -- Wavefront.from_amp_and_phase
                              * (prysm/propagation/wavefront.py:58-79) fused into focus: the complex pupil never exists in
-                             * memory.  PM_C64 with power-of-two row lengths only (PM_ERR_UNSUPPORTED otherwise). */
-    PM_FLAG_SYNTH_PACKED = 32, /* with PM_FLAG_SYNTH_INPUT: `in` holds (amplitude, OPD) float PAIRS (in_ld in pairs), synth_amp is ignored.
+                             * memory.  `in` is float for PM_C64, double for PM_C128 (fp64 sincospi per sample: 4096^2 329 -> 255 us
+                             * against synthesis + transform); power-of-two row lengths only (PM_ERR_UNSUPPORTED otherwise). */
+    PM_FLAG_SYNTH_PACKED = 32, /* with PM_FLAG_SYNTH_INPUT: `in` holds (amplitude, OPD) float / double PAIRS (in_ld in pairs), synth_amp is ignored.
                              * One 8-byte load per element instead of two 4-byte loads from two arrays: a loop over wavelengths packs
                              * its two maps once (the polychromatic recipe: 133 -> 101 us per wavelength at 4096^2) */
     PM_FLAG_NORM_DC = 16,   /* divide the result by its DC bin X[0][0] before the epilogue -- the centre normalisation

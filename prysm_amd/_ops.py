@@ -60,9 +60,9 @@ def _fill_mul(d, x, mul, mul_x, mul_conj, keep):
 
 
 def synth_supported(opd, amp, N):
-    """Whether pm_fft2 can synthesise amp * exp(i k opd) while loading (PM_FLAG_SYNTH_INPUT): complex64 path, 2-D,
-    power-of-two row length, real / bool amplitude."""
-    if opd.dim() != 2 or opd.dtype != torch.float32 or not _is_pow2_engine(N):
+    """Whether pm_fft2 can synthesise amp * exp(i k opd) while loading (PM_FLAG_SYNTH_INPUT): a 2-D float32 / float64 OPD map
+    (complex64 / complex128 transform), power-of-two row length, real / bool amplitude."""
+    if opd.dim() != 2 or opd.dtype not in (torch.float32, torch.float64) or not _is_pow2_engine(N):
         return False
     return amp is None or (amp.dtype in _AMP_CODE and amp.dim() == 2 and amp.shape == opd.shape and amp.stride(-1) == 1)
 
@@ -186,10 +186,11 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
 
 
 def pack_amp_opd(amp, opd):
-    """(amplitude, OPD) float32 pairs as a complex64 tensor -- the input of fft2(..., synth=('packed', k)).  A loop over
-    wavelengths packs its two maps once and then reads ONE 8-byte element per sample in every transform."""
-    a = torch.ones_like(opd) if amp is None else amp.to(torch.float32)
-    return torch.view_as_complex(torch.stack((a, opd.to(torch.float32)), dim=-1).contiguous())
+    """(amplitude, OPD) pairs in the OPD map's precision as a complex tensor -- the input of fft2(..., synth=('packed', k)).  A loop
+    over wavelengths packs its two maps once and then reads ONE element per sample in every transform."""
+    rd = opd.dtype if opd.dtype in (torch.float32, torch.float64) else torch.float32
+    a = torch.ones_like(opd, dtype=rd) if amp is None else amp.to(rd)
+    return torch.view_as_complex(torch.stack((a, opd.to(rd)), dim=-1).contiguous())
 
 
 def _is_pow2_engine(n):

@@ -900,8 +900,8 @@ static int check_fft2(const pm_fft2_desc* d) {
         return fail(PM_ERR_ARG, "pm_fft2: PM_FLAG_SYNTH_PACKED qualifies PM_FLAG_SYNTH_INPUT");
     if (d->flags & PM_FLAG_SYNTH_INPUT) {
         if (d->direction != -1) return fail(PM_ERR_ARG, "pm_fft2: PM_FLAG_SYNTH_INPUT is a forward transform");
-        if (d->dtype != PM_C64 || engine_log2(d->in_x.n) < 0 || d->batch > 1)
-            return fail(PM_ERR_UNSUPPORTED, "pm_fft2: PM_FLAG_SYNTH_INPUT needs PM_C64, a power-of-two row length and no batch");
+        if (engine_log2(d->in_x.n) < 0 || d->batch > 1)
+            return fail(PM_ERR_UNSUPPORTED, "pm_fft2: PM_FLAG_SYNTH_INPUT needs a power-of-two row length and no batch");
         if (d->synth_amp && d->synth_amp_dtype != PM_F32 && d->synth_amp_dtype != PM_F64 && d->synth_amp_dtype != PM_BOOL)
             return fail(PM_ERR_ARG, "pm_fft2: synth_amp_dtype");
         if (d->synth_amp && d->synth_amp_ld < d->in_x.len) return fail(PM_ERR_ARG, "pm_fft2: synth_amp_ld < row length");
@@ -1309,7 +1309,8 @@ int pm_fft2_spectral(const pm_fft2_desc* d, int32_t count, const double* k, cons
         for (int32_t b = 0; b < count; ++b) {
             dd.synth_k = k[b];
             dd.weight = weight[b];
-            if ((rc = fft2_run<float>(&dd, p, in, out, workspace, st))) return rc;
+            rc = d->dtype == PM_C64 ? fft2_run<float>(&dd, p, in, out, workspace, st) : fft2_run<double>(&dd, p, in, out, workspace, st);
+            if (rc) return rc;
         }
         return 0;
     }

@@ -430,7 +430,7 @@ PM_HD void load_sel(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, 
 
 template <typename C>
 PM_HD void load(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
-    if constexpr (sizeof(typename C::T) == 4) {   // synthesis only on the complex64 path (fp64 sincospi would dominate the pass)
+    {
         if (p.real == 2) {
             load_sel<C, 2>(p, blk, pos, v);
             return;

@@ -104,7 +104,7 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
                          instead of launch-bound; batched=False is the field-by-field loop with the accumulate
                          epilogue, the faster form from 4096^2 transforms (single fields take the folded kernels).
                          Default (None): stacks below 4096^2 transforms.
-    spectral           : with Q and float32 maps of power-of-two width, a rank's wavelength loop runs as ONE call whose launch pairs
+    spectral           : with Q and float maps of power-of-two width, a rank's wavelength loop runs as ONE call whose launch pairs
                          each cover a group of wavelengths (pm_fft2_spectral; False: one transform pair per wavelength).
     reduce_method      : 'reduce' (one torch.distributed.reduce) or 'a2a' (all-to-all of slices + ordered local sum + gather:
                          bitwise reproducible, one message per xGMI link) when only the first rank needs the image.
@@ -121,7 +121,7 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
 
     packed = None
     if Q is not None and not batched:
-        # the pupil is synthesised inside every wavelength's transform (float32 maps, power-of-two width): pack (amplitude, OPD)
+        # the pupil is synthesised inside every wavelength's transform (float maps, power-of-two width): pack (amplitude, OPD)
         # once so each of those row passes reads one 8-byte element per sample instead of two 4-byte ones from two arrays
         probe = Wavefront.from_amp_and_phase(amp, phs, float(wavelengths[0]), dx)._fusable(Q) if len(wavelengths) else None
         if probe is not None and len(wavelengths) > 1:
@@ -162,7 +162,7 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
         world = dist.get_world_size(group) if use_dist else 1
         lo, hi = shard_bounds(len(wavelengths), rank, world)
         m, n = packed.shape
-        acc = torch.zeros((math.ceil(m * Q), math.ceil(n * Q)), dtype=torch.float32, device=packed.device)
+        acc = torch.zeros((math.ceil(m * Q), math.ceil(n * Q)), dtype=L._REAL_OF[packed.dtype], device=packed.device)
         if hi > lo:
             ks = [2 * math.pi / float(wavelengths[k]) / 1e3 for k in range(lo, hi)]
             focus_intensity(packed, Q, out=acc, synth=('packed', ks[0]), spectral=(ks, [float(w) for w in weights[lo:hi]]))
@@ -177,7 +177,7 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
             return focus_intensity(packed, Q, out=acc, weight=w, synth=syn)
         wf = Wavefront.from_amp_and_phase(amp, phs, wvl, dx)
         if Q is not None:
-            fus = wf._fusable(Q)      # float32 maps, power-of-two width: the pupil is synthesised inside the transform
+            fus = wf._fusable(Q)      # float maps, power-of-two width: the pupil is synthesised inside the transform
             src, syn = (fus[1], (fus[0], fus[2])) if fus is not None else (wf.data, None)
             if acc is None:
                 first = focus_intensity(src, Q, synth=syn)

@@ -90,13 +90,13 @@ class Wavefront:
         return a.astype(dtype) if dtype is not None else a
 
     def _fusable(self, Q):
-        """(amp, opd, k) when the pupil can be synthesised inside the FFT (not yet materialised, complex64, power-of-two
-        padded width), else None."""
+        """(amp, opd, k) when the pupil can be synthesised inside the FFT (not yet materialised, power-of-two padded width),
+        else None."""
         if self._data is not None or self._synth is None:
             return None
         amp, opd, k, cd = self._synth
         N = math.ceil(opd.shape[1] * Q)
-        if cd == torch.complex64 and _ops.synth_supported(opd, amp, N):
+        if cd == L._COMPLEX_OF[opd.dtype] and _ops.synth_supported(opd, amp, N):
             return amp, opd, k
         return None
 

@@ -831,3 +831,41 @@ def test_conv_golden_fixture_on_half_spectra(pa):
         assert rel_max(tonp(out), g['conv_out']) < TOL64
     finally:
         lib.pm_set_tuning(b'r2c', 1)
+
+
+def test_fused_pupil_synthesis_complex128(pa):
+    """PM_FLAG_SYNTH_INPUT for float64 maps (complex128 transforms: fp64 sincospi per sample inside the row pass): the lazy wavefront
+    stays lazy, the result is bit for bit the separate synthesis kernel + transform, equals the oracle, bool / float32 / float64 / no
+    amplitude, folded (4096 rows) and not, packed pairs too; and the polychromatic loop on float64 maps"""
+    from prysm_amd import _ops
+    from prysm_amd.polychromatic import polychromatic_psf
+    P = pa.propagation
+    rng = np.random.default_rng(15)
+    for n, Q in ((256, 1), (128, 2), (4096, 1)):
+        x, y = O.make_xy_grid(n, diameter=10)
+        r, _ = O.cart_to_polar(x, y)
+        opd = O.hopkins_w040(r / 5, 800.0) + 30 * rng.standard_normal((n, n))
+        for amp in (O.circle(5, r), rng.random((n, n)).astype(np.float32), rng.random((n, n)), None):
+            wf = P.Wavefront.from_amp_and_phase(amp, opd, 0.55, 10.0 / n)
+            assert wf._fusable(Q) is not None
+            got = wf.focus(100.0, Q)
+            assert got.data.dtype == torch.complex128 and wf._data is None
+            want = O.focus(O.from_amp_and_phase(np.ones((n, n)) if amp is None else amp, opd, 0.55), Q)
+            assert rel_max(tonp(got), want) < TOL64
+            inten = wf.focus_intensity(100.0, Q)
+            assert rel_max(tonp(inten), O.intensity(want)) < 4 * TOL64
+            if n <= 256:
+                field = wf.data                                       # materialised by the separate kernel
+                assert torch.equal(P.focus(field, Q), got.data)       # same arithmetic, different loads
+                a_dev = None if amp is None else torch.from_numpy(np.asarray(amp)).cuda()
+                pk = _ops.pack_amp_opd(a_dev, torch.from_numpy(opd).cuda())
+                assert pk.dtype == torch.complex128
+                assert torch.equal(P.focus_intensity(pk, Q, synth=('packed', 2 * np.pi / 0.55 / 1e3)), inten.data)
+    n = 256
+    x, y = O.make_xy_grid(n, diameter=10)
+    r, _ = O.cart_to_polar(x, y)
+    amp, opd = O.circle(5, r), O.hopkins_w040(r / 5, 300.0)
+    wv, wt = np.linspace(0.5, 0.7, 5), np.linspace(1.0, 2.0, 5)
+    want = sum(w * O.intensity(O.focus(O.from_amp_and_phase(amp, opd, float(l)), 2)) for l, w in zip(wv, wt))
+    got = polychromatic_psf(amp, opd, wv, wt, 10.0 / n, 100.0, Q=2)
+    assert got.dtype == torch.float64 and rel_max(tonp(got), want) < 4 * TOL64
