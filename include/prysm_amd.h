@@ -151,11 +151,11 @@ typedef struct pm_fft2_desc {
 } pm_fft2_desc;
 
 /* Transform lengths (per axis): powers of two from 2 to 8192 run on the Stockham engine; 16384 and 32768 take one radix-2 / radix-4
- * step around engine transforms (16384^2 complex64: 6.2 ms), and so do 3 / 5 / 7 x 2^k from 96 (1536, 2560, 3584, 6144 ...: radix 3 / 5 / 7)
+ * step around engine transforms (16384^2 complex64: 4.3 ms), and so do 3 / 5 / 7 x 2^k from 96 (1536, 2560, 3584, 6144 ...: radix 3 / 5 / 7)
  * when the other axis is a power of two or such a length too; other lengths from 96 to 4096 run on
  * the same engine through Bluestein's identity (chirp multiply, power-of-two convolution of length >= 2n - 1, chirp multiply;
  * when both axes are such lengths the 2-D convolution is ONE fused fft2 x B ifft2 chain, and that form reaches 16384 per axis by
- * convolving at 16384 / 32768 points: 8000^2 complex64 11.4 ms); shorter lengths, and other lengths
+ * convolving at 16384 / 32768 points: 8000^2 complex64 8.6 ms); shorter lengths, and other lengths
  * up to 32768, run on a direct O(n^2) kernel with fp64 accumulation.  Anything else is PM_ERR_UNSUPPORTED.  The reference
  * takes any length through scipy.fft (prysm/propagation/fft.py:24).
  *

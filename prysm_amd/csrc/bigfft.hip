@@ -17,7 +17,6 @@
 
 namespace pm {
 
-constexpr int kMaxRadix = 8;
 
 // v W_R^e.  R = 2 or 4: exact, a multiplication by (-i)^(e * 4 / R); other R: W_R^e = W_n^{(e mod R) n'} from the table of the
 // full length (step = n' = n / R)
@@ -37,37 +36,45 @@ __device__ __forceinline__ cx<T> mul_wr(cx<T> v, int e, int R, const cx<T>* twn,
 }
 
 // Y[m][i][j], planes of M x n' (all M LOGICAL rows: rows outside the stored window come out zero)
-template <typename T>
-__global__ void big_pre_rows_kernel(Blue2dIn<T> in, int M, int np, int R, cx<T>* Y, const cx<T>* twN) {
-    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (g >= int64_t(M) * np) return;
-    const int i = int(g / np), j = int(g - int64_t(i) * np);
-    cx<T> x[kMaxRadix];
+// R is a template parameter: with a run-time radix the arrays x[] / t[] below are indexed dynamically and live in scratch memory
+// (16384^2: the pre-processing kernel then ran at 1.5 TB/s)
+template <typename T, int R>
+__global__ void big_pre_rows_kernel(Blue2dIn<T> in, int M, int np, cx<T>* Y, const cx<T>* twN, int row0) {
+    // one row per blockIdx.y: no 64-bit division per thread (it cost this kernel half its time at 16384^2)
+    const int i = row0 + int(blockIdx.y), j = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j >= np) return;
+    const int64_t g = int64_t(i) * np + j;
+    cx<T> x[R];
+#pragma unroll
     for (int r = 0; r < R; ++r) x[r] = fetch2d(in, i, j + r * np);
     const int64_t plane = int64_t(M) * np;
+#pragma unroll
     for (int m = 0; m < R; ++m) {
         cx<T> s{T(0), T(0)};
+#pragma unroll
         for (int r = 0; r < R; ++r) s = s + mul_wr(x[r], r * m, R, twN, int64_t(np));
         Y[int64_t(m) * plane + g] = m ? cmul(s, twN[int64_t(j) * m]) : s;
     }
 }
 
 // F[(m * Rm + r)][k'][k], planes of mp x np;  thread (k', logical column c = Rn k + m) writes the Rm bins k' + q mp
-template <typename T>
-__global__ void big_finish_kernel(const cx<T>* F, int mp, int np, int Rm, int Rn, const cx<T>* twM, ColStoreNat<T> o) {
-    const int64_t N = int64_t(np) * Rn;
-    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (g >= int64_t(mp) * N) return;
-    const int kp = int(g / N), c = int(g - int64_t(kp) * N);
-    const int k = c / Rn, m = c - k * Rn;
+template <typename T, int Rm>
+__global__ void big_finish_kernel(const cx<T>* F, int mp, int np, int Rn, const cx<T>* twM, ColStoreNat<T> o, int row0) {
+    const int N = np * Rn;
+    const int kp = row0 + int(blockIdx.y), c = int(blockIdx.x * blockDim.x + threadIdx.x);      // one row of bins per blockIdx.y
+    if (c >= N) return;
+    const int k = int(unsigned(c) / unsigned(Rn)), m = c - k * Rn;
     const int64_t plane = int64_t(mp) * np;
-    cx<T> t[kMaxRadix];
+    cx<T> t[Rm];
+#pragma unroll
     for (int r = 0; r < Rm; ++r) {
         const cx<T> f = F[(int64_t(m) * Rm + r) * plane + int64_t(kp) * np + k];
         t[r] = r ? cmul(f, twM[int64_t(r) * kp]) : f;
     }
+#pragma unroll
     for (int q = 0; q < Rm; ++q) {
         cx<T> s{T(0), T(0)};
+#pragma unroll
         for (int r = 0; r < Rm; ++r) s = s + mul_wr(t[r], r * q, Rm, twM, int64_t(mp));
         store_one(o, kp + q * mp, c, s);
     }
@@ -77,14 +84,38 @@ template <typename T>
 int big_pre_rows(const Blue2dIn<T>& in, int M, int np, int R, cx<T>* Y, const cx<T>* twN, hipStream_t st) {
     const int64_t total = int64_t(M) * np;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(big_pre_rows_kernel<T>, dim3(unsigned((total + 255) / 256)), dim3(256), 0, st, in, M, np, R, Y, twN);
+    for (int r0 = 0; r0 < M; r0 += 32768) {     // grid.y is limited to 65535: a 1-D transform may have more rows than that
+        const int nr = M - r0 < 32768 ? M - r0 : 32768;
+        const dim3 grid(unsigned((np + 255) / 256), unsigned(nr));
+        switch (R) {
+#define PM_R(r) \
+    case r:     \
+        hipLaunchKernelGGL((big_pre_rows_kernel<T, r>), grid, dim3(256), 0, st, in, M, np, Y, twN, r0); \
+        break;
+            PM_R(1) PM_R(2) PM_R(3) PM_R(4) PM_R(5) PM_R(7)
+#undef PM_R
+            default: return -2;
+        }
+    }
     return int(hipGetLastError());
 }
 template <typename T>
 int big_finish(const cx<T>* F, int mp, int np, int Rm, int Rn, const cx<T>* twM, const ColStoreNat<T>& o, hipStream_t st) {
     const int64_t total = int64_t(mp) * np * Rn;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(big_finish_kernel<T>, dim3(unsigned((total + 255) / 256)), dim3(256), 0, st, F, mp, np, Rm, Rn, twM, o);
+    for (int r0 = 0; r0 < mp; r0 += 32768) {
+        const int nr = mp - r0 < 32768 ? mp - r0 : 32768;
+        const dim3 grid(unsigned((int64_t(np) * Rn + 255) / 256), unsigned(nr));
+        switch (Rm) {
+#define PM_R(r) \
+    case r:     \
+        hipLaunchKernelGGL((big_finish_kernel<T, r>), grid, dim3(256), 0, st, F, mp, np, Rn, twM, o, r0); \
+        break;
+            PM_R(1) PM_R(2) PM_R(3) PM_R(4) PM_R(5) PM_R(7)
+#undef PM_R
+            default: return -2;
+        }
+    }
     return int(hipGetLastError());
 }
 
