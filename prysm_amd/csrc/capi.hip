@@ -1166,6 +1166,67 @@ static int herm_conv_run(const pm_fft2_desc* d, const HermConvPlan& p, const voi
     return rc < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: no half-spectrum row kernel for %lld points", (long long)N) : rc;
 }
 
+// ---- the wavelength loop as launch pairs over groups of wavelengths (fft_spectral.h)
+// fast form: complex64 packed synthesis, |.|^2 accumulation, both lengths on the engine with a tiled intermediate, fewer than 4096^2
+// bins.  Measured (profiles/r02/exp_spectral.log, us per wavelength, loop -> groups of 8): 1024^2 24.7 -> 11.0, 2048^2 40.6 -> 22.6,
+// 1024^2 padded to 2048^2 34.0 -> 13.3; at 4096^2 the loop's passes already run at 84 % of copy speed with their intermediate in the
+// Infinity Cache, and the grouped kernels pay for their registers with occupancy (rocprofv3: 47.6 + 50.7 us per wavelength against
+// 45.0 + 55.9 in groups of 8; DESIGN.md 3.3d), so those sizes keep the loop.
+static bool spectral_fast(const pm_fft2_desc* d, const Fft2Plan& p) {
+    const int want = PM_FLAG_SYNTH_INPUT | PM_FLAG_SYNTH_PACKED;
+    // complex128: rows of up to 2048 samples, unfolded (the grouped double-precision kernels exist for those; profiles/r02/exp_spectral_c128.log)
+    if (d->dtype == PM_C128 && (p.logn > 11 || p.fold)) return false;
+    return tuning().spectral > 1 && (d->flags & want) == want && !(d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY)) &&
+           d->epilogue == PM_EPI_ABS2_ACCUM && d->batch <= 1 && d->mul_kind == PM_MUL_NONE && !p.r2c && !p.big_rn && !p.blue2d &&
+           p.logn >= 5 && p.logm >= (p.fold ? 6 : 5) && p.logm - (p.fold ? 1 : 0) <= 11 /* the accumulating column kernel spills beyond 2048-point tiles */ &&
+           p.tc != 0 && p.col_var == 0 && d->in_y.len > 0 && p.logn + p.logm < tuning().spectral_area_log;
+}
+static int spectral_group(int32_t count) {
+    int g = tuning().spectral;
+    if (g > kSpectralMax) g = kSpectralMax;
+    return g < count ? g : count;
+}
+
+template <typename T>
+static int fft2_spectral_group(const pm_fft2_desc* d, const Fft2Plan& p, const Spectral& w, const void* in, void* out, void* ws, hipStream_t st) {
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    const int rows = int(d->in_y.len);
+    int err = 0;
+    cx<T>* W = reinterpret_cast<cx<T>*>(ws);
+    const cx<T>* tw = twiddles<T>(N, &err);
+    if (!tw) return err;
+    const size_t in_bytes = size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
+    const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
+    RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, 0, nt_in, 0};
+    int ltc = 0;
+    while ((1 << ltc) < (p.tc << p.log_k)) ++ltc;
+    const int64_t tl = int64_t(1) << ltc, ntl = (N + tl - 1) / tl;
+    ColStoreNat<T> cs = make_colstore<T>(d, out, p.fold ? p.logm - 1 : -1);
+    const int ntiles = int((N + p.tc - 1) / p.tc);
+    int rc;
+    if (p.fold) {
+        const int H = int(M / 2);
+        const cx<T>* twm = twiddles<T>(M, &err);
+        if (!twm) return err;
+        const cx<T>* twh = twiddles<T>(H, &err);
+        if (!twh) return err;
+        lp.eoff = H;
+        RowStoreFold<T> sp{W, ntl * H * tl, H, ltc, twm, d->in_y.shift == M / 2 ? 1 : 0, 0};
+        if ((rc = launch_row_spectral_fold<T>(p.logn, lp, sp, tw, H, w, st))) return rc;
+        ColLoadTiled<T> cl{W, H, AxisMap{H, H, 0, 0}, ntiles, p.log_k, ntl * H * tl};
+        cs.ay = AxisMap{H, int(d->out_y.len / 2), int(d->out_y.off / 2), int(d->out_y.shift / 2)};
+        cs.bstride = d->out_ld;
+        cs.ld = 2 * d->out_ld;
+        return launch_col_spectral<T>(p.logm - 1, cl, cs, twh, ntiles, sibling_log_g(p.log_k), w, st, 2);
+    }
+    const cx<T>* twm = twiddles<T>(M, &err);
+    if (!twm) return err;
+    RowStoreTiled<T> sp{W, rows, ltc, 0};
+    if ((rc = launch_row_spectral<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, tuning().row_log_g, w, st))) return rc;
+    ColLoadTiled<T> cl{W, rows, to_map(d->in_y), ntiles, p.log_k, 0};
+    return launch_col_spectral<T>(p.logm, cl, cs, twm, ntiles, sibling_log_g(p.log_k), w, st, 1);
+}
+
 }  // namespace pm
 
 using namespace pm;
@@ -1226,65 +1287,6 @@ int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, s
     return fft2_run<double>(d, p, in, out, workspace, st);
 }
 
-// ---- the wavelength loop as launch pairs over groups of wavelengths (fft_spectral.h)
-// fast form: complex64 packed synthesis, |.|^2 accumulation, both lengths on the engine with a tiled intermediate, fewer than 4096^2
-// bins.  Measured (profiles/r02/exp_spectral.log, us per wavelength, loop -> groups of 8): 1024^2 24.7 -> 11.0, 2048^2 40.6 -> 22.6,
-// 1024^2 padded to 2048^2 34.0 -> 13.3; at 4096^2 the loop's passes already run at 84 % of copy speed with their intermediate in the
-// Infinity Cache, and the grouped kernels pay for their registers with occupancy (rocprofv3: 47.6 + 50.7 us per wavelength against
-// 45.0 + 55.9 in groups of 8; DESIGN.md 3.3d), so those sizes keep the loop.
-static bool spectral_fast(const pm_fft2_desc* d, const Fft2Plan& p) {
-    const int want = PM_FLAG_SYNTH_INPUT | PM_FLAG_SYNTH_PACKED;
-    return tuning().spectral > 1 && d->dtype == PM_C64 && (d->flags & want) == want && !(d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY)) &&
-           d->epilogue == PM_EPI_ABS2_ACCUM && d->batch <= 1 && d->mul_kind == PM_MUL_NONE && !p.r2c && !p.big_rn && !p.blue2d &&
-           p.logn >= 5 && p.logm >= (p.fold ? 6 : 5) && p.logm - (p.fold ? 1 : 0) <= 11 /* the accumulating column kernel spills beyond 2048-point tiles */ &&
-           p.tc != 0 && p.col_var == 0 && d->in_y.len > 0 && p.logn + p.logm < tuning().spectral_area_log;
-}
-static int spectral_group(int32_t count) {
-    int g = tuning().spectral;
-    if (g > kSpectralMax) g = kSpectralMax;
-    return g < count ? g : count;
-}
-
-static int fft2_spectral_group(const pm_fft2_desc* d, const Fft2Plan& p, const Spectral& w, const void* in, void* out, void* ws, hipStream_t st) {
-    using T = float;
-    const int64_t M = d->in_y.n, N = d->in_x.n;
-    const int rows = int(d->in_y.len);
-    int err = 0;
-    cx<T>* W = reinterpret_cast<cx<T>*>(ws);
-    const cx<T>* tw = twiddles<T>(N, &err);
-    if (!tw) return err;
-    const size_t in_bytes = size_t(rows) * size_t(d->in_x.len) * sizeof(cx<T>);
-    const int nt_in = tuning().nt_in >= 0 ? tuning().nt_in : (in_bytes >= (size_t(96) << 20) ? 1 : 0);
-    RowLoadNat<T> lp{reinterpret_cast<const cx<T>*>(in), d->in_ld, to_map(d->in_x), rows, 0, nt_in, 0};
-    int ltc = 0;
-    while ((1 << ltc) < (p.tc << p.log_k)) ++ltc;
-    const int64_t tl = int64_t(1) << ltc, ntl = (N + tl - 1) / tl;
-    ColStoreNat<T> cs = make_colstore<T>(d, out, p.fold ? p.logm - 1 : -1);
-    const int ntiles = int((N + p.tc - 1) / p.tc);
-    int rc;
-    if (p.fold) {
-        const int H = int(M / 2);
-        const cx<T>* twm = twiddles<T>(M, &err);
-        if (!twm) return err;
-        const cx<T>* twh = twiddles<T>(H, &err);
-        if (!twh) return err;
-        lp.eoff = H;
-        RowStoreFold<T> sp{W, ntl * H * tl, H, ltc, twm, d->in_y.shift == M / 2 ? 1 : 0, 0};
-        if ((rc = launch_row_spectral_fold(p.logn, lp, sp, tw, H, w, st))) return rc;
-        ColLoadTiled<T> cl{W, H, AxisMap{H, H, 0, 0}, ntiles, p.log_k, ntl * H * tl};
-        cs.ay = AxisMap{H, int(d->out_y.len / 2), int(d->out_y.off / 2), int(d->out_y.shift / 2)};
-        cs.bstride = d->out_ld;
-        cs.ld = 2 * d->out_ld;
-        return launch_col_spectral(p.logm - 1, cl, cs, twh, ntiles, sibling_log_g(p.log_k), w, st, 2);
-    }
-    const cx<T>* twm = twiddles<T>(M, &err);
-    if (!twm) return err;
-    RowStoreTiled<T> sp{W, rows, ltc, 0};
-    if ((rc = launch_row_spectral(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, tuning().row_log_g, w, st))) return rc;
-    ColLoadTiled<T> cl{W, rows, to_map(d->in_y), ntiles, p.log_k, 0};
-    return launch_col_spectral(p.logm, cl, cs, twm, ntiles, sibling_log_g(p.log_k), w, st, 1);
-}
-
 size_t pm_fft2_spectral_workspace(const pm_fft2_desc* d, int32_t count) {
     if (check_fft2(d) || count <= 0) return 0;
     const Fft2Plan p = plan_fft2(d);
@@ -1320,13 +1322,15 @@ int pm_fft2_spectral(const pm_fft2_desc* d, int32_t count, const double* k, cons
     for (int32_t b0 = 0; b0 < count; b0 += g) {
         Spectral w{};
         w.nb = count - b0 < g ? count - b0 : g;
-        w.fstride = int64_t(p.ws_field / sizeof(cx<float>));
+        w.fstride = int64_t(p.ws_field / (d->dtype == PM_C64 ? sizeof(cx<float>) : sizeof(cx<double>)));
         w.mode = tuning().spectral_mode;
         for (int i = 0; i < w.nb; ++i) {
-            w.w[i] = float(weight[b0 + i]);
+            w.w[i] = weight[b0 + i];
             w.k2[i] = k[b0 + i] / two_pi;
         }
-        if ((rc = fft2_spectral_group(d, p, w, in, out, workspace, st)))
+        rc = d->dtype == PM_C64 ? fft2_spectral_group<float>(d, p, w, in, out, workspace, st)
+                                : fft2_spectral_group<double>(d, p, w, in, out, workspace, st);
+        if (rc)
             return rc == -2 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_spectral: internal: no grouped kernel for %lld x %lld", (long long)d->in_y.n, (long long)d->in_x.n) : rc;
     }
     return 0;

@@ -869,3 +869,38 @@ def test_fused_pupil_synthesis_complex128(pa):
     want = sum(w * O.intensity(O.focus(O.from_amp_and_phase(amp, opd, float(l)), 2)) for l, w in zip(wv, wt))
     got = polychromatic_psf(amp, opd, wv, wt, 10.0 / n, 100.0, Q=2)
     assert got.dtype == torch.float64 and rel_max(tonp(got), want) < 4 * TOL64
+
+
+@pytest.mark.parametrize('m,n,Q,count', [(64, 64, 1, 3), (256, 256, 1, 9), (256, 512, 1, 8), (128, 128, 2, 5), (1024, 1024, 1, 4),
+                                         (2048, 2048, 1, 3), (64, 4096, 1, 2)])
+def test_spectral_call_complex128(pa, m, n, Q, count):
+    """the grouped wavelength kernels for float64 maps (complex128 transforms; rows of up to 2048 samples -- longer rows keep the loop):
+    against the loop they replace and the fp64 oracle sum, every group size and kernel form"""
+    from prysm_amd import _lib, _ops
+    P = pa.propagation
+    lib = _lib.load()
+    rng = np.random.default_rng(m + 3 * n + count)
+    amp = (rng.random((m, n)) > 0.25).astype(np.float64)
+    opd = 200 * rng.standard_normal((m, n))
+    packed = _ops.pack_amp_opd(torch.from_numpy(amp).cuda(), torch.from_numpy(opd).cuda())
+    assert packed.dtype == torch.complex128
+    wvls = np.linspace(0.5, 0.7, count)
+    ks = [2 * np.pi / w / 1e3 for w in wvls]
+    wts = list(np.linspace(0.5, 1.5, count))
+    M, N = int(m * Q), int(n * Q)
+    loop = torch.zeros((M, N), device='cuda', dtype=torch.float64)
+    for k, w in zip(ks, wts):
+        P.focus_intensity(packed, Q, out=loop, weight=w, synth=('packed', k))
+    want = sum(w * O.intensity(O.focus(O.from_amp_and_phase(amp, opd, float(wl)), Q)) for wl, w in zip(wvls, wts))
+    assert rel_max(tonp(loop), want) < 4 * TOL64
+    try:
+        for group in (1, 3, 8):
+            for mode in (0, 1, 2, 3):
+                assert lib.pm_set_tuning(b'spectral', group) == 0 and lib.pm_set_tuning(b'spectral_mode', mode) == 0
+                got = torch.zeros((M, N), device='cuda', dtype=torch.float64)
+                P.focus_intensity(packed, Q, out=got, synth=('packed', ks[0]), spectral=(ks, wts))
+                assert rel_max(tonp(got), tonp(loop)) < 1e-13, (group, mode)
+                assert rel_max(tonp(got), want) < 4 * TOL64, (group, mode)
+    finally:
+        lib.pm_set_tuning(b'spectral', 8)
+        lib.pm_set_tuning(b'spectral_mode', 3)

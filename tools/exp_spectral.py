@@ -28,18 +28,19 @@ def timeit(fn, reps=5):
 def main():
     lib = L.load()
     sizes = [int(v) for v in sys.argv[1:]] or [4096, 2048, 1024]
+    rdt = torch.float64 if os.environ.get('PM_F64') else torch.float32
     nl = 16
     for n in sizes:
         for Q in (1, 2) if n <= 2048 else (1,):
             g = torch.Generator(device='cuda').manual_seed(1)
             amp = (torch.rand((n, n), device='cuda', generator=g) > 0.2).float()
             opd = torch.randn((n, n), device='cuda', generator=g) * 50
-            packed = _ops.pack_amp_opd(amp, opd)
+            packed = _ops.pack_amp_opd(amp.to(rdt), opd.to(rdt))
             wl = np.linspace(0.5, 0.7, nl)
             ks = [2 * math.pi / w / 1e3 for w in wl]
             wts = list(np.linspace(0.5, 1.5, nl))
             M = n * Q
-            acc = torch.zeros((M, M), device='cuda')
+            acc = torch.zeros((M, M), device='cuda', dtype=rdt)
 
             def run():
                 acc.zero_()

@@ -246,11 +246,12 @@ def fuzz_spectral(ncases, rng, lib):
         lib.pm_set_tuning(b'spectral', group)
         lib.pm_set_tuning(b'spectral_mode', mode)
         lib.pm_set_tuning(b'fold', int(rng.choice([-1, 0, 1])))
-        amp = (rng.random((m, n)) > 0.3).astype(np.float32)
-        opd = (rng.standard_normal((m, n)) * 200).astype(np.float32)
+        rdt = np.float32 if rng.random() < 0.6 else np.float64      # float64 maps: the complex128 grouped kernels
+        amp = (rng.random((m, n)) > 0.3).astype(rdt)
+        opd = (rng.standard_normal((m, n)) * 200).astype(rdt)
         ks = [2 * np.pi / w / 1e3 for w in rng.uniform(0.4, 0.9, count)]
         wts = list(rng.uniform(0.2, 2.0, count))
-        base = rng.random((m * Q, n * Q)).astype(np.float32)
+        base = rng.random((m * Q, n * Q)).astype(rdt)
         P = np.zeros((m * Q, n * Q), dtype=np.complex128)
         oy, ox = (m * Q - m + 1) // 2, (n * Q - n + 1) // 2
         want = base.astype(np.float64)
@@ -269,11 +270,11 @@ def fuzz_spectral(ncases, rng, lib):
             nfail += 1
             continue
         err = float(np.abs(got - want).max() / np.abs(want).max())
-        tol = 2e-5
+        tol = 2e-5 if rdt == np.float32 else 1e-10
         worst = max(worst, err / tol)
         if not err < tol:
             nfail += 1
-            print('spectral case', case, 'FAIL err', err, (m, n, Q, count, group, mode))
+            print('spectral case', case, 'FAIL err', err, (m, n, Q, count, group, mode, rdt.__name__))
     for key, val in ((b'spectral', 8), (b'spectral_mode', 3), (b'fold', -1)):
         lib.pm_set_tuning(key, val)
     print(f'fuzz_spectral: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
