@@ -169,10 +169,11 @@ int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, s
  *     for wvl, w in zip(wavelengths, weights): psf += w * abs(focus(amp * exp(1j * 2 pi / wvl * opd)))**2  ),
  * result-equivalent to `count` pm_fft2 calls with d->synth_k = k[b], d->weight = weight[b] on the same input and accumulator
  * (the descriptor must carry PM_FLAG_SYNTH_INPUT and PM_EPI_ABS2_ACCUM; its own synth_k / weight are ignored; k and weight
- * are HOST arrays).  With PM_FLAG_SYNTH_PACKED, complex64 and engine lengths the loop runs as one launch pair per group of
- * wavelengths: the row pass reads the packed (amplitude, OPD) map once per group, the column pass sums w_b |.|^2 over the
- * group in registers and touches the accumulator once -- 16 + 16 / B bytes per sample and wavelength instead of 32 (B = 4:
- * tuning key "spectral").  The sum runs in wavelength order; only its association differs from the loop's
+ * are HOST arrays).  With PM_FLAG_SYNTH_PACKED and engine lengths below 4096^2 bins (complex128: rows of up to 2048 samples) the loop
+ * runs as one launch pair per group of wavelengths: the row pass reads the packed (amplitude, OPD) map once per group, the column
+ * pass sums w_b |.|^2 over the group in registers and touches the accumulator once -- 16 + 16 / B bytes per sample and wavelength
+ * instead of 32 in complex64 (B = 8: tuning keys "spectral", "spectral_area_log"; measured 1.8 - 2.5x the loop from 1024^2 to 2048^2,
+ * no gain at 4096^2, which keeps the loop).  The sum runs in wavelength order; only its association differs from the loop's
  * (acc + (w_0 i_0 + w_1 i_1 + ..) per group).  Other descriptors run the plain loop.
  * Workspace: pm_fft2_spectral_workspace(d, count) bytes. */
 size_t pm_fft2_spectral_workspace(const pm_fft2_desc* d, int32_t count);
