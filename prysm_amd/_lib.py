@@ -140,11 +140,41 @@ _NP2TORCH = {
 }
 
 
+_have_gpu = None
+_devices = {}
+
+
 def device():
     """The MI355X this process computes on (torch's current device)."""
-    if not torch.cuda.is_available():
+    global _have_gpu
+    if _have_gpu is None:
+        _have_gpu = torch.cuda.is_available()       # asked once: the answer does not change within a process, the question costs 2 us
+        if _have_gpu:
+            torch.cuda.init()      # the raw accessors below assume torch's lazy runtime initialisation has happened
+    if not _have_gpu:
         raise RuntimeError('prysm_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm; there is no CPU path')
-    return torch.device('cuda', torch.cuda.current_device())
+    i = _cur_dev()
+    d = _devices.get(i)
+    if d is None:
+        d = _devices[i] = torch.device('cuda', i)
+    return d
+
+
+# torch.cuda.current_stream() / current_device() build Python objects and re-check the runtime on every call (~6 us of the ~21 us a
+# small propagation costs on the host, tools/exp_host_profile.py); the raw accessors return the same integers
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
+def _cur_dev():
+    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
+
+
+def _cur_stream():
+    """hipStream_t of torch's current stream on the current device, as an integer."""
+    if _raw_stream is not None:
+        return _raw_stream(_cur_dev())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def torch_dtype(dt):
@@ -203,7 +233,7 @@ def code(t):
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_cur_stream())
 
 
 def ptr(t):
@@ -217,7 +247,7 @@ def workspace(nbytes):
     """Scratch buffer in HBM, reused per (device, stream); stream-ordered so back-to-back calls are safe."""
     if nbytes <= 0:
         return None
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    key = (_cur_dev(), _cur_stream())
     w = _workspaces.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(int(nbytes), dtype=torch.uint8, device=device())
