@@ -7,7 +7,10 @@
   the focal-plane-mask / Lyot gradients through the Wavefront API (tests/test_propagation.py:353-427, 589-622);
 * the N > 1 paths (bench.py and the polychromatic driver) as two ranks: RCCL when two GPUs are visible, gloo with both
   ranks on one GPU otherwise;
-* caller-supplied `out=` validation, boolean occulters, the Jones adapter's pass-through of stacks.
+* caller-supplied `out=` validation, boolean occulters, the Jones adapter's pass-through of stacks;
+* later in the round: the wavelength loop as one call (pm_fft2_spectral, both precisions), 1-D transforms of 16384 / 32768 and
+  3 / 5 / 7 x 2^k points, every np.pad mode of pad2d, the real convolution chain on half spectra (PM_FLAG_REAL_OUTPUT, folded and
+  not), complex128 pupil synthesis inside the row load, the chirp-Z executor built from grid parameters, config 5 variant M through it.
 
 Tolerances as in test_gpu_parity.py.
 """
