@@ -415,6 +415,14 @@ def polychromatic_2048(ranks, n=2048, reps=5):
     # bytes per sample and wavelength of the grouped form: 16 + 16 / 8 (csrc/fft_spectral.h)
     per = res['spectral_groups']['per_wavelength_us_per_gpu'] * 1e-6
     res['spectral_groups']['frac_of_hbm_peak'] = 18.0 * n * n / per / 1e9 / HBM_PEAK_GBS
+    # the same maps in float64 -- prysm's default precision: complex128 transforms, pupil synthesised in the row load, grouped kernels
+    amp64, opd64 = amp.double(), opd.double()
+    res['float64_maps'] = {}
+    for name, kw in forms[:2]:
+        fn = lambda: polychromatic_psf(amp64, opd64, wvls, wts, 10.0 / n, 100.0, Q=1, reduce_to_all=False, **kw)   # noqa: E731
+        fn()
+        ts = sorted(ranks.timed(fn) for _ in range(3))
+        res['float64_maps'][name] = {'psf_ms': ts[1] * 1e3, 'per_wavelength_us_per_gpu': ts[1] * 1e6 / math.ceil(N_WAVELENGTHS / ranks.world)}
     return res
 
 
