@@ -38,6 +38,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -63,8 +64,13 @@ def parse():
     ap.add_argument('--dtype', default='c64', choices=['c64', 'c128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-poly', action='store_true', help='only the headline loop (profiling runs)')
-    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192|padded|mtf|conv|poly2048)')
+    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192|padded|mtf|conv|adjoint|poly2048)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget for the CPU baseline sample')
+    ap.add_argument('--reduce-method', default='auto', choices=['auto', 'reduce', 'a2a'],
+                    help='how the polychromatic image reaches rank 0: one torch.distributed.reduce, or all-to-all of slices + ordered local '
+                         'sum + gather (one message per xGMI link); auto = whichever reduces the 67 MB image faster in this run')
+    ap.add_argument('--extras-budget', type=float, default=900.0,
+                    help='seconds the side measurements after the timed region may take before the headline line is printed without them')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path when the ranks share a GPU)')
     return ap.parse_args()
@@ -200,7 +206,10 @@ def other_configs(only=''):
         x3 = torch.from_numpy(make_field(4096, np.complex128, 4096)).cuda()
         out['config3_angular_spectrum_4096_c128'] = _hbm_entry(
             _event_ms(lambda: P.angular_spectrum(x3, 0.6328, 0.01, 10.0, Q=1), 30), 8 * 4096 ** 2 * 16,
-            'graded on 8 N^2 s (two 2-D transforms); the fused chain moves 6 N^2 s')
+            'graded on 8 N^2 s (two 2-D transforms); the fused chain moves 6 N^2 s: moved_* is the fraction on those')
+        e3 = out['config3_angular_spectrum_4096_c128']
+        e3['moved_GBps'] = 0.75 * e3['algorithmic_GBps']
+        e3['moved_frac_of_hbm_peak'] = 0.75 * e3['frac_of_hbm_peak']
         del x3
     if want('c128'):      # nothing of this one fits the Infinity Cache: 256 MiB in, 256 MiB intermediate, 256 MiB out
         x5 = torch.from_numpy(make_field(4096, np.complex128, 4096)).cuda()
@@ -241,6 +250,41 @@ def other_configs(only=''):
                                      'note': 'real(ifft2(fft2(obj) H)) of a real object: R2C rows, Hermitian part of H between the column transforms, '
                                              'C2R rows = 32 B per sample (4 + 4, 8 + 8 of H, 4 + 4); the complex chain moves 56'}
         del obj, Hc
+    if want('adjoint'):   # the gradient path (what optimisers run), same grading as the forward operators
+        adj = {}
+        g = torch.from_numpy(make_field(4096, np.complex64, 77)).cuda()
+        adj['focus_adjoint_4096_to_2048_c64_Q2'] = _hbm_entry(
+            _event_ms(lambda: P.focus_adjoint(g, 2), 50), 4 * 4096 ** 2 * 8,
+            'ifft2 (ortho) of a 4096^2 focal-plane gradient + crop to the 2048^2 pupil in the store window; graded on 4 N^2 s of the '
+            'transform size, moves 2.75 N^2 s (the last pass only transforms and stores the kept rows)')
+        e = adj['focus_adjoint_4096_to_2048_c64_Q2']
+        e['moved_frac_of_hbm_peak'] = 2.5 / 4 * e['frac_of_hbm_peak']
+        adj['focus_adjoint_4096_c64_Q1'] = _hbm_entry(_event_ms(lambda: P.focus_adjoint(g, 1), 50), 4 * 4096 ** 2 * 8)
+        W = P.Wavefront(g, 0.6328, 1.0, space='psf')
+        ib = torch.rand(4096, 4096, dtype=torch.float32, device='cuda')
+        adj['intensity_adjoint_4096_c64'] = _hbm_entry(_event_ms(lambda: W.intensity_adjoint(ib), 50), (4 + 8 + 8) * 4096 ** 2,
+                                                      '2 Ibar E as one sweep (pm_rmul): 4 + 8 B read, 8 B written per sample')
+        del g, W, ib
+        g3 = torch.from_numpy(make_field(4096, np.complex128, 78)).cuda()
+        adj['angular_spectrum_adjoint_4096_c128'] = _hbm_entry(
+            _event_ms(lambda: P.angular_spectrum_adjoint(g3, 0.6328, 0.01, 10.0, Q=1), 30), 8 * 4096 ** 2 * 16,
+            'the same fused 3-pass chain with conj(H); graded on 8 N^2 s, moves 6 N^2 s')
+        adj['angular_spectrum_adjoint_4096_c128']['moved_frac_of_hbm_peak'] = 0.75 * adj['angular_spectrum_adjoint_4096_c128']['frac_of_hbm_peak']
+        del g3
+        prec = config.precision
+        try:
+            config.precision = 32
+            ex = P.prepare_executor(10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0)
+            gm = torch.from_numpy(make_field(512, np.complex64, 79)).cuda()
+            ms = _event_ms(lambda: P.focus_dft_adjoint(gm, ex), 50)
+            fl = 8 * 2048 * 512 * (512 + 2048)     # Ey^H (2048 x 512) @ g (512 x 512) @ conj(Ex) (512 x 2048), cheaper product first
+            adj['mdft_adjoint_512_to_2048_c64'] = {
+                'ms': ms, 'algorithmic_TFLOPs': fl / (ms * 1e-3) / 1e12, 'frac_of_f32_mfma_peak': fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                'bound': 'mfma', 'note': 'MDFT.adjoint of config 4: (Ey^H @ g @ conj(Ex)) norm, 512^2 -> 2048^2, two complex GEMMs'}
+            del gm, ex
+        finally:
+            config.precision = prec
+        out['adjoints'] = adj
     torch.cuda.empty_cache()
     if want('config4'):   # config 4: matrix-DFT focus 2048^2 -> 512^2 complex64 on MFMA, 8 My Nx (Ny + Mx) real flops
         prec = config.precision
@@ -345,11 +389,13 @@ def propagation_loop(ranks, x, steps, warmup):
     return ranks.timed(run), f
 
 
-def polychromatic_config5(ranks, n, reps=3):
+def polychromatic_config5(ranks, n, reduce_ms, method='auto', reps=3, frames=6):
     """BASELINE config 5: 64 wavelengths np.linspace(0.5, 0.7, 64) um, uniform weights, n^2 circular pupil with a
     500 nm W040 OPD, fp32.  ONE polychromatic_psf call = this rank's ceil(64 / N) wavelengths (pupil synthesis inside the
-    row pass, FFT focus, |.|^2 accumulated by the column pass's epilogue) + one sum-reduce of the image to rank 0."""
-    from prysm_amd.polychromatic import polychromatic_psf
+    row pass, FFT focus, |.|^2 accumulated by the column pass's epilogue) + one sum-reduce of the image to rank 0.
+    `reduce_ms`: reduce_alone_ms() of this run; `method` 'auto' takes the faster form.  Variant F is timed with BOTH reduce forms
+    and as a pipelined sequence of `frames` PSFs (PsfPipeline: frame k's reduce on a side stream under frame k + 1's transforms)."""
+    from prysm_amd.polychromatic import polychromatic_psf, PsfPipeline
     ax = (torch.arange(n, device='cuda', dtype=torch.float64) - n // 2) * (10.0 / n)
     r = torch.hypot(ax[None, :], ax[:, None])
     amp = (r <= 5).to(torch.float32)
@@ -358,28 +404,57 @@ def polychromatic_config5(ranks, n, reps=3):
     wvls = np.linspace(0.5, 0.7, N_WAVELENGTHS)
     wts = np.ones(N_WAVELENGTHS)
     dx = 10.0 / n
+    if method == 'auto':
+        method = 'a2a' if (ranks.world > 1 and reduce_ms['a2a'] < reduce_ms['reduce']) else 'reduce'
+    forms = {'reduce': 'torch.distributed.reduce(SUM) of the real image to rank 0 (RCCL over xGMI)',
+             'a2a': 'all_to_all_single of image slices + ordered local sum (pm_sum_modes) + gather to rank 0 (RCCL over xGMI)'}
     res = {'wavelengths': N_WAVELENGTHS, 'wavelengths_per_gpu': math.ceil(N_WAVELENGTHS / ranks.world), 'pupil': f'{n}x{n} fp32',
-           'reduce': 'torch.distributed.reduce(SUM) of the real image to rank 0 (RCCL over xGMI)' if ranks.world > 1 else 'none (one rank)'}
+           'reduce_method': method if ranks.world > 1 else 'none (one rank)',
+           'reduce': forms[method] if ranks.world > 1 else 'none (one rank)'}
 
-    def var_f():
-        polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=1, reduce_to_all=False)
+    def var_f(m=method):
+        polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=1, reduce_to_all=False, reduce_method=m)
 
     def var_m():
-        polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, focal_dx=0.55 * 10 / 4, samples=512, kind='mdft', reduce_to_all=False)
+        polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, focal_dx=0.55 * 10 / 4, samples=512, kind='mdft', reduce_to_all=False,
+                          reduce_method=method)
+
+    def timed_median(fn, k):
+        fn()    # warm: plans, communicator, allocator
+        ts = sorted(ranks.timed(fn) for _ in range(k))
+        return ts[len(ts) // 2]
+
+    def entry(t):
+        return {'psf_ms': t * 1e3, 'psfs_per_s': 1.0 / t, 'wavelengths_per_s': N_WAVELENGTHS / t,
+                'per_wavelength_ms_per_gpu': t * 1e3 / math.ceil(N_WAVELENGTHS / ranks.world)}
 
     from prysm_amd.conf import config
     prec = config.precision
     config.precision = 32     # fp32 maps -> complex64 pupils; at the default precision 64 the executors' bases would be complex128
     try:                      # and promote the whole matrix DFT to fp64 MFMA (numpy's result-type rule)
         def var_c():
-            polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, focal_dx=0.55 * 10 / 4, samples=512, kind='czt', reduce_to_all=False)
+            polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, focal_dx=0.55 * 10 / 4, samples=512, kind='czt', reduce_to_all=False,
+                              reduce_method=method)
 
-        for name, fn, k in (('variant_F_fft_focus', var_f, reps), ('variant_M_mdft_512', var_m, reps), ('variant_M_czt_512', var_c, reps)):
-            fn()    # warm: plans, communicator, allocator
-            ts = sorted(ranks.timed(fn) for _ in range(k))
-            t = ts[len(ts) // 2]
-            res[name] = {'psf_ms': t * 1e3, 'psfs_per_s': 1.0 / t, 'wavelengths_per_s': N_WAVELENGTHS / t,
-                         'per_wavelength_ms_per_gpu': t * 1e3 / math.ceil(N_WAVELENGTHS / ranks.world)}
+        res['variant_F_fft_focus'] = entry(timed_median(var_f, reps))
+        if ranks.world > 1:     # the other reduce form on the same call, for the record
+            other = 'reduce' if method == 'a2a' else 'a2a'
+            res['variant_F_fft_focus']['psf_ms_by_reduce_method'] = {method: res['variant_F_fft_focus']['psf_ms'],
+                                                                     other: timed_median(lambda: var_f(other), reps) * 1e3}
+        # pipelined: a sequence of PSFs (frames of a time series / forward passes of an optimiser), one in flight behind the next
+        pipe = PsfPipeline(wvls, wts, dx, 100.0, Q=1, reduce_to_all=False, reduce_method=method, depth=2)
+
+        def run_frames():
+            pend = [pipe.submit(amp, opd) for _ in range(frames)]
+            for p_ in pend:
+                p_.result()
+            pipe.drain()
+
+        tp = timed_median(run_frames, reps)
+        res['variant_F_fft_focus'].update({'pipelined_psfs_per_s': frames / tp, 'pipelined_ms_per_psf': tp * 1e3 / frames,
+                                           'pipelined_frames': frames})
+        res['variant_M_mdft_512'] = entry(timed_median(var_m, reps))
+        res['variant_M_czt_512'] = entry(timed_median(var_c, reps))
     finally:
         config.precision = prec
     fl = 8 * 512 * n * (n + 512) * N_WAVELENGTHS
@@ -388,7 +463,9 @@ def polychromatic_config5(ranks, n, reps=3):
                    'pupil synthesis + FFT focus (Q = 1) with fused |.|^2 accumulate; M = prepare_executor + matrix-DFT focus to a '
                    '512^2 grid (focal_dx 1.375 um) + |.|^2 accumulate; variant_M_czt_512 = the same grid and image through the chirp-Z '
                    'executor prysm offers beside the matrix DFT (kind="czt": two fused convolution kernels per wavelength instead of two '
-                   'GEMMs); all end with the sum-reduce of the image to rank 0')
+                   'GEMMs); all end with the sum-reduce of the image to rank 0.  pipelined_*: the same PSF `pipelined_frames` times through '
+                   'PsfPipeline -- the reduce of frame k runs on a side stream while frame k + 1 computes; the (amplitude, OPD) maps are '
+                   'packed once per tensor pair, outside the call')
     return res
 
 
@@ -427,13 +504,43 @@ def polychromatic_2048(ranks, n=2048, reps=5):
 
 
 def reduce_alone_ms(ranks, n):
-    """The one data-path collective on its own: sum-reduce of an n^2 fp32 image to rank 0 (median of 5)."""
+    """The one data-path collective on its own, both root-only forms: sum-reduce of an n^2 fp32 image to rank 0 (median of 5) as
+    ONE torch.distributed.reduce and as all-to-all of slices + ordered local sum + gather (polychromatic._reduce_image)."""
     if ranks.world == 1:
-        return 0.0
+        return {'reduce': 0.0, 'a2a': 0.0}
+    from prysm_amd.polychromatic import _reduce_image
     img = torch.ones((n, n), dtype=torch.float32, device='cuda')
-    dist.reduce(img, dst=0)   # warm
-    ts = sorted(ranks.timed(lambda: dist.reduce(img, dst=0)) for _ in range(5))
-    return ts[2] * 1e3
+    out = {}
+    for method in ('reduce', 'a2a'):
+        fn = lambda: _reduce_image(img, ranks.world, None, False, method, True)   # noqa: E731
+        fn()   # warm
+        ts = sorted(ranks.timed(fn) for _ in range(5))
+        out[method] = ts[2] * 1e3
+    return out
+
+
+XGMI_LINK_GBS = 153.0     # per direction and link, 7 links per GPU (task brief / SURVEY 8e)
+
+
+def scaling_model(t1_ms, image_bytes, measured=None):
+    """What config 5 variant F should do at N = 2, 4, 8 -- printed so the driver's SCALE run can be checked against it.
+    compute(N) = t1 / N (contiguous wavelength blocks, no collective inside); the image reduce by its two forms over fully
+    connected xGMI: 'a2a' = every rank sends N - 1 slices of S / N over N - 1 distinct links, then the root receives N - 1 reduced
+    slices over N - 1 links: 2 (S / N) / BW_link; 'reduce' (RCCL ring) = the image crosses N - 1 links in pipelined chunks, bounded
+    below by S / BW_link.  Link efficiency 0.8 assumed.  single-shot efficiency = t1 / (N (t1 / N + reduce)); pipelined = the
+    reduce of frame k under the transforms of frame k + 1 (PsfPipeline): t1 / (N max(t1 / N, reduce))."""
+    bw = XGMI_LINK_GBS * 0.8 * 1e9
+    out = {'t1_ms': t1_ms, 'image_MB': image_bytes / 1e6, 'link_GBps_assumed': XGMI_LINK_GBS * 0.8, 'per_N': {}}
+    for N in (2, 4, 8):
+        comp = t1_ms / N
+        red = {'a2a': 2 * (image_bytes / N) / bw * 1e3 + 0.03, 'reduce': image_bytes / bw * 1e3 + 0.03}
+        out['per_N'][str(N)] = {
+            'compute_ms': comp, 'reduce_ms_model': red,
+            'efficiency_single_shot': {k: t1_ms / (N * (comp + v)) for k, v in red.items()},
+            'efficiency_pipelined': {k: t1_ms / (N * max(comp, v)) for k, v in red.items()}}
+    if measured:
+        out['measured_this_run'] = measured
+    return out
 
 
 def main():
@@ -475,27 +582,9 @@ def main():
     elapsed, f = propagation_loop(ranks, x, args.steps, args.warmup)
     del f
 
-    extra = {}
-    if not args.no_poly:
-        x2 = torch.from_numpy(make_field(2048, np.complex64, 2048 + rank)).cuda()
-        k2 = max(args.steps, 50)
-        t2, _ = propagation_loop(ranks, x2, k2, max(args.warmup, 5))
-        del x2, _
-        extra['n2048'] = {'value': world * k2 / t2, 'unit': 'propagations/s', 'ms_per_step': t2 / k2 * 1e3, 'steps': k2,
-                          'whole_step_frac_of_hbm_peak': 4 * 2048 ** 2 * 8 / (t2 / k2) / 1e9 / HBM_PEAK_GBS,
-                          'workload': 'focus(x, Q=1) on a 2048x2048 complex64 field per GPU, timed like the headline'}
-        extra['reduce_ms'] = reduce_alone_ms(ranks, n)
-        extra['polychromatic'] = polychromatic_config5(ranks, n)
-        extra['polychromatic']['reduce_alone_ms'] = extra['reduce_ms']
-        extra['polychromatic_2048'] = polychromatic_2048(ranks)
-
+    # ---- the headline line, complete as the contract wants it, BEFORE any side measurement
+    line = None
     if rank == 0:
-        psf_ms = 0.0
-        if not args.no_poly:
-            # the intensity form of the same step: |focus(x)|^2 with the modulus fused into the column pass (no complex PSF in memory)
-            acc_i = P.focus_intensity(x, 1)
-            psf_ms = _event_ms(lambda: P.focus_intensity(x, 1, out=acc_i), 50)
-            del acc_i
         ms_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
         p1, p2 = kernel_pass_times(x, n)
@@ -517,8 +606,6 @@ def main():
             'whole_step_algorithmic_GBps_per_gpu': alg_bytes_step / (ms_step * 1e-3) / 1e9,
             'whole_step_frac_of_hbm_peak': alg_bytes_step / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'whole_step_frac_of_measured_copy_ceiling': alg_bytes_step / (ms_step * 1e-3) / 1e9 / HBM_COPY_CEILING_GBS,
-            'psf_variant': {'ms_per_psf': psf_ms, 'psfs_per_s_per_gpu': (1e3 / psf_ms) if psf_ms else None,
-                            'note': 'focus_intensity(x, 1): the same propagation storing |.|^2 (fp32 image) instead of the complex field'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'frac_of_measured_copy_ceiling': achieved / HBM_COPY_CEILING_GBS,
                          'traffic': traffic, 'traffic_unit': 'bytes per launch',
@@ -527,6 +614,62 @@ def main():
                          'note': '2*N^2*s algorithmic bytes per pass / HIP-event duration of that pass; the two passes are timed in '
                                  'sequence with events between them, which serialises them (their sum exceeds ms_per_step)'},
         }
+
+    # The side measurements below include this code's collectives (config 5).  A hang or a crash there must not cost the run its
+    # headline: after --extras-budget seconds rank 0 prints the line it already has and every rank leaves (one JSON line either way).
+    printed = threading.Event()
+
+    def give_up():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            line['extras'] = f'not finished within --extras-budget {args.extras_budget:.0f} s; headline only'
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    dog = threading.Timer(args.extras_budget + (0.0 if rank == 0 else 5.0), give_up)
+    dog.daemon = True
+    dog.start()
+
+    extra = {}
+    if not args.no_poly:
+        try:
+            x2 = torch.from_numpy(make_field(2048, np.complex64, 2048 + rank)).cuda()
+            k2 = max(args.steps, 50)
+            t2, _ = propagation_loop(ranks, x2, k2, max(args.warmup, 5))
+            del x2, _
+            extra['n2048'] = {'value': world * k2 / t2, 'unit': 'propagations/s', 'ms_per_step': t2 / k2 * 1e3, 'steps': k2,
+                              'whole_step_frac_of_hbm_peak': 4 * 2048 ** 2 * 8 / (t2 / k2) / 1e9 / HBM_PEAK_GBS,
+                              'workload': 'focus(x, Q=1) on a 2048x2048 complex64 field per GPU, timed like the headline'}
+            red = reduce_alone_ms(ranks, n)
+            extra['polychromatic'] = polychromatic_config5(ranks, n, red, args.reduce_method)
+            extra['polychromatic']['reduce_alone_ms'] = red
+            extra['reduce_ms'] = red['a2a'] if extra['polychromatic']['reduce_method'] == 'a2a' else red['reduce']
+            f = extra['polychromatic']['variant_F_fft_focus']
+            t1 = f['per_wavelength_ms_per_gpu'] * N_WAVELENGTHS      # this run's compute rate scaled to one GPU's 64 wavelengths
+            extra['polychromatic']['scaling_model'] = scaling_model(
+                t1 if world == 1 else max(f['psf_ms'] - extra['reduce_ms'], 0.0) * world, n * n * 4,
+                {'n_gpus': world, 'psf_ms': f['psf_ms'], 'reduce_alone_ms': red, 'pipelined_ms_per_psf': f['pipelined_ms_per_psf']})
+            extra['polychromatic_2048'] = polychromatic_2048(ranks)
+        except Exception as exc:     # a rank that fails here leaves the others in a collective: the watchdog ends them
+            extra['extras_error'] = repr(exc)
+            if world > 1:
+                if rank == 0:
+                    printed.set()
+                    line.update(extra)
+                    print(json.dumps(line), flush=True)
+                os._exit(0 if rank == 0 else 1)
+
+    if rank == 0:
+        if not args.no_poly:
+            # the intensity form of the same step: |focus(x)|^2 with the modulus fused into the column pass (no complex PSF in memory)
+            try:
+                acc_i = P.focus_intensity(x, 1)
+                psf_ms = _event_ms(lambda: P.focus_intensity(x, 1, out=acc_i), 50)
+                del acc_i
+                line['psf_variant'] = {'ms_per_psf': psf_ms, 'psfs_per_s_per_gpu': 1e3 / psf_ms,
+                                       'note': 'focus_intensity(x, 1): the same propagation storing |.|^2 (fp32 image) instead of the complex field'}
+            except Exception as exc:
+                line['psf_variant'] = {'error': repr(exc)}
         line.update(extra)
         if not args.no_poly and world == 1:
             try:
@@ -534,8 +677,14 @@ def main():
             except Exception as exc:   # never lose the headline line to a side measurement
                 line['other_configs'] = {'error': repr(exc)}
         if not args.no_cpu_baseline and world == 1:     # reported at N = 1 only (the other ranks would just wait)
-            line['cpu_baseline'] = cpu_baseline(n, cdtype, args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+            try:
+                line['cpu_baseline'] = cpu_baseline(n, cdtype, args.cpu_seconds)
+            except Exception as exc:
+                line['cpu_baseline'] = {'error': repr(exc)}
+        if not printed.is_set():
+            printed.set()
+            print(json.dumps(line), flush=True)
+    dog.cancel()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -228,6 +228,11 @@ int pm_czt_axis(int32_t dtype, int32_t axis, int64_t nseq, int64_t K, int64_t in
 int pm_cmul(int32_t dtype, int32_t op, int64_t rows, int64_t cols, const void* a, int64_t a_ld, const void* b,
             int64_t b_ld, void* out, int64_t out_ld, void* stream);
 
+/* out = scale * r * a: r REAL (float for PM_C64, double for PM_C128), a complex, same shape.
+ * Wavefront.intensity_adjoint, Gbar = 2 * Ibar * E (prysm/propagation/wavefront.py:282-298), as one sweep. */
+int pm_rmul(int32_t dtype, int64_t rows, int64_t cols, const void* r, int64_t r_ld, const void* a, int64_t a_ld, double scale,
+            void* out, int64_t out_ld, void* stream);
+
 /* out[i][j] = in[i][j] * ry[i] * cx[j] * scale, ry / cx optional complex vectors, each optionally conjugated.
  * The chirp / phase-ramp multiplies of CZT and FFTDFT (prysm/fttools.py:297-323,508-535). */
 int pm_scale_sep(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t in_ld, const void* ry,

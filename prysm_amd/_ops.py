@@ -11,6 +11,11 @@ import torch
 from . import _lib as L
 
 
+# The kernels write through raw pointers, which torch's version counters do not see: a caller-supplied `out=` tensor is marked
+# modified here, so caches keyed on (tensor identity, version) -- polychromatic.packed_pupil -- notice maps rewritten in place.
+_bump = torch.autograd.graph.increment_version
+
+
 def _axis(n, length=None, off=0, shift=0):
     return L.pm_axis(int(n), int(n if length is None else length), int(off), int(shift))
 
@@ -119,6 +124,7 @@ def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
         out = torch.empty(oshape, dtype=odt, device=x.device)
     else:
         _check_out(out, x, oshape, odt)
+        _bump(out)
     packed = synth is not None and isinstance(synth[0], str)
     amp = synth[0] if (synth is not None and not packed) else None
     if mul is not None and mul_x is not None and x.dim() == 3 and mul.dim() == 2:
@@ -307,6 +313,16 @@ def cmul(a, b, conj_b=False):
     return out
 
 
+def rmul(r, a, scale=1.0):
+    """scale * r * a for a REAL image r and a complex field a of the matching precision (pm_rmul; one sweep)."""
+    lib = L.load()
+    out = torch.empty_like(a)
+    rows, cols = a.shape
+    L.check(lib.pm_rmul(L.code(a), rows, cols, L.ptr(r), r.stride(0), L.ptr(a), a.stride(0), float(scale), L.ptr(out), out.stride(0),
+                        L.stream_ptr()))
+    return out
+
+
 def scale_sep(x, row_vec=None, col_vec=None, row_conj=False, col_conj=False, scale=1.0):
     """out[i, j] = x[i, j] * row_vec[i] * col_vec[j] * scale (row_vec indexes rows, col_vec columns)."""
     lib = L.load()
@@ -325,8 +341,10 @@ def abs2(x, out=None, weight=None):
     acc = 0
     if out is None:
         out = torch.empty((rows, cols), dtype=L._REAL_OF[x.dtype], device=x.device)
-    elif weight is not None:
-        acc = 1
+    else:
+        _bump(out)
+        if weight is not None:
+            acc = 1
     L.check(lib.pm_abs2(L.code(x), rows, cols, L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), acc,
                         float(1.0 if weight is None else weight), L.stream_ptr()))
     return out
@@ -347,6 +365,8 @@ def sum_modes(modes, weights, out=None, accumulate=False):
     if out is None:
         out = torch.empty((rows, cols), dtype=modes.dtype, device=modes.device)
         accumulate = False
+    else:
+        _bump(out)
     code = L.PM_C64 if modes.dtype == torch.float32 else L.PM_C128
     if modes.dtype not in (torch.float32, torch.float64):
         raise TypeError('sum_modes: float32 or float64 images')
@@ -452,6 +472,8 @@ def pupil_synth(amp, opd, k, cdtype, out=None):
     rows, cols = opd.shape
     if out is None:
         out = torch.empty((rows, cols), dtype=cdtype, device=opd.device)
+    else:
+        _bump(out)
     a_code, a_ld = L.PM_F32, cols
     if amp is not None:
         if amp.dtype not in _AMP_CODE:

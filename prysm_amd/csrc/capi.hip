@@ -126,6 +126,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("mixed_radix")) t.mixed_radix = v ? 1 : 0;
     else if (is("r2c")) t.r2c = v < 0 ? -1 : (v > 1 ? 2 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
+    else if (is("colmul_mode")) t.colmul_mode = v;
     else if (is("herm_wide")) t.herm_wide = v;
     else if (is("spectral")) t.spectral = v;
     else if (is("spectral_mode")) t.spectral_mode = v & 3;
@@ -150,6 +151,17 @@ Tuning& tuning() {
         return x;
     }();
     return t;
+}
+
+int pm_num_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
 }
 
 // sibling group of column-pass workgroups: the tiles of one layout-tile row, at most 8
@@ -618,7 +630,7 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
         mm.vec_ok = (d->mul_kind == PM_MUL_FULL && sizeof(T) == 4 && d->mul_ld % 2 == 0 &&
                      reinterpret_cast<uintptr_t>(d->mul) % 16 == 0) ? 1 : 0;
         ColStoreTiled<T> cst{W1, H, ntiles, p.log_k, plane};
-        rc = launch_col_mul<T>(p.logm - 1, cl, mm, cst, twH, ntiles, sibling_log_g(p.log_k), st, 2);
+        rc = launch_col_mul<T>(p.logm - 1, cl, mm, cst, twH, ntiles, sibling_log_g(p.log_k), st, 2, tuning().colmul_mode);
         if (rc) return rc;
         RowLoadFold<T> rl{W1, plane, H, ltl, twM, 1, 0};
         RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), int(M), 1, T(d->scale), 1, to_map(d->out_y), 0, H};
@@ -642,7 +654,7 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
                  (d->mul_kind == PM_MUL_FULL && sizeof(T) == 4 && d->mul_ld % 2 == 0 && d->mul_bstride % 2 == 0 &&
                   reinterpret_cast<uintptr_t>(d->mul) % 16 == 0) ? 1 : 0};
     ColStoreTiled<T> cst{W2, int(M), ntiles, p.log_k, wstride};
-    int rc = launch_col_mul<T>(p.logm, cl, mm, cst, twM, ntiles, sibling_log_g(p.log_k), st, nb);
+    int rc = launch_col_mul<T>(p.logm, cl, mm, cst, twM, ntiles, sibling_log_g(p.log_k), st, nb, tuning().colmul_mode);
     if (rc) return rc;
     // pass C: inverse row transforms of the rows inside the output window -> natural output, scale applied here.
     // Sequence s is stored row s of W2 (= logical row s); the output row map rotates / crops it.

@@ -69,11 +69,30 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp, cons
 // Measured (profiles/r01/fused_as.log): 4096^2 complex128 448 vs 473 us, complex64 210 vs 239 us, 2048^2 complex64
 // 55 vs 75 us against two pm_fft2 calls.  (Built without the SLP vectorizer -- with it this kernel spilled > 150
 // VGPRs under the 128-register cap of the 1024-thread workgroup and lost.)
-#ifndef PM_COLMUL_MINWG
-#define PM_COLMUL_MINWG 1
-#endif
-template <typename C, typename S = ColStoreTiled<typename C::T>>
-__global__ void __launch_bounds__(C::NT, (C::NT == 512 ? PM_COLMUL_MINWG : 1))   // 2nd argument: min waves per SIMD
+// MINW: minimum waves per SIMD the register allocation must leave room for (1: whatever the kernel wants -- 184 VGPRs for
+// 2048-point complex128 tiles, ONE 512-thread workgroup per CU; 4: two of them per CU, 128 VGPRs).
+template <typename C, typename S, int MINW, int KIND = -1>
+__device__ __forceinline__ void col_mul_body(cx<typename C::T> (&v)[C::E][C::P], const MidMul<typename C::T>& mp, int unit, ThreadPos pos,
+                                             char* smem, const cx<typename C::T>* __restrict__ tw) {
+    if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, smem, tw);
+    else fft_run<C>(v, pos, smem, tw);
+    if constexpr (KIND < 0) mid_multiply_conj<C>(mp, unit, pos, v);
+    else mid_multiply_conj_kind<C, KIND>(mp, unit, pos, v);
+    __syncthreads();   // LDS of the forward exchange is reused by the inverse
+    // opaque copy of the slot: otherwise the twiddles (and their products) of the first transform are CSE'd
+    // with the second and kept live across it -- hundreds of spilled registers at 1024 threads
+    ThreadPos pos2 = pos;
+    asm volatile("" : "+v"(pos2.t), "+v"(pos2.cl), "+v"(pos2.bo));
+    if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos2, smem, tw);
+    else fft_run<C>(v, pos2, smem, tw);
+#pragma unroll
+    for (int e = 0; e < C::E; ++e)
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) v[e][m].y = -v[e][m].y;
+}
+
+template <typename C, typename S = ColStoreTiled<typename C::T>, int MINW = 1>
+__global__ void __launch_bounds__(C::NT, (C::NT == 512 ? MINW : 1))   // 2nd argument: min waves per SIMD
     fft_col_mul_kernel(const ColLoadTiled<typename C::T> lp0, const MidMul<typename C::T> mp0,
                                                             const S sp0,
                                                             const cx<typename C::T>* __restrict__ tw, const int log_g) {
@@ -85,46 +104,229 @@ __global__ void __launch_bounds__(C::NT, (C::NT == 512 ? PM_COLMUL_MINWG : 1))  
     const auto sp = at_batch(sp0, blockIdx.y);
     cx<typename C::T> v[C::E][C::P];
     load<C>(lp, unit, pos, v);
-    if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
-    else fft_run<C>(v, pos, pm_smem, tw);
-    mid_multiply_conj<C>(mp, unit, pos, v);
-    __syncthreads();   // LDS of the forward exchange is reused by the inverse
-    // opaque copy of the slot: otherwise the twiddles (and their products) of the first transform are CSE'd
-    // with the second and kept live across it -- hundreds of spilled registers at 1024 threads
-    ThreadPos pos2 = pos;
-    asm volatile("" : "+v"(pos2.t), "+v"(pos2.cl), "+v"(pos2.bo));
-    if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos2, pm_smem, tw);
-    else fft_run<C>(v, pos2, pm_smem, tw);
-#pragma unroll
-    for (int e = 0; e < C::E; ++e)
-#pragma unroll
-        for (int m = 0; m < C::P; ++m) v[e][m].y = -v[e][m].y;
+    col_mul_body<C, S, MINW>(v, mp, unit, pos, pm_smem, tw);
     store<C>(sp, unit, pos, v);
 }
 
+// The same pass as a PERSISTENT workgroup that prefetches: one 512-thread workgroup per CU walks its tiles and issues the loads of
+// tile t + 1 into a second register set BEFORE the two transforms of tile t, so HBM reads are in flight under the butterflies and
+// the stores of tile t drain under the transforms of tile t + 1.  The one-tile-per-workgroup form above runs ONE workgroup per CU at
+// 2048-point complex128 tiles (184 VGPRs) and did load -> FFT -> x H -> IFFT -> store strictly in sequence: 156.6 us for 536.9 MB
+// = 0.43 of the HBM roofline with PMC traffic 1.01x (config 3's middle pass).  Registers: 2 x 64 for the two
+// tiles + the transform's own ~60, inside the 256 a two-waves-per-SIMD kernel owns.  Virtual block vb = blockIdx.x + k gridDim.x
+// keeps vb % 8 = the XCD of the physical block (gridDim.x is a multiple of 8), so group_remap's sibling tiles still meet in one L2.
+// Host-checked: every tile exists and is read whole and unrotated (the folded chain's planes).  Addresses are ONE uniform 64-bit
+// base per register slot (scalar registers) + ONE 32-bit per-thread byte offset: with the generic loaders the compiler hoisted
+// the 16 + 16 + 16 per-slot 64-bit vector addresses of load / multiplier / store out of the tile loop (96 VGPRs, hundreds of
+// spills beside the second register set).  The multiplier kind is a template argument.
+template <typename C>
+struct PfAddr {
+    using T = typename C::T;
+    static constexpr int TC = C::CI * C::E;
+    static constexpr int ES = int(sizeof(cx<T>));
+    uint32_t vdata;   // byte offset of this thread's first element inside a tile block (load and store layouts are the same)
+    int TL;
+    int64_t mstep;    // bytes between register slots m and m + 1
+    __device__ __forceinline__ PfAddr(ThreadPos pos, int log_k) {
+        TL = TC << log_k;
+        vdata = uint32_t(pos.t * TL + pos.cl * C::E) * ES;
+        mstep = int64_t(C::TPS) * TL * ES;
+    }
+    __device__ __forceinline__ int64_t tile_off(int tile, int nrows, int log_k) const {   // bytes, uniform
+        const int tl = tile >> log_k, sub = tile & ((1 << log_k) - 1);
+        return (int64_t(tl) * nrows * TL + sub * TC) * ES;
+    }
+};
+
+template <typename C>
+__device__ __forceinline__ void pf_load(const ColLoadTiled<typename C::T>& p, int tile, const PfAddr<C>& A, cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    const char* tb = reinterpret_cast<const char*>(p.src) + A.tile_off(tile, p.nrows, p.log_k);
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const char* a = tb + m * A.mstep + A.vdata;
+        if constexpr (C::E == 2) {
+            const Vec4<T> w = *reinterpret_cast<const Vec4<T>*>(a);
+            v[0][m] = {w.a, w.b};
+            v[1][m] = {w.c, w.d};
+        } else {
+            v[0][m] = *reinterpret_cast<const cx<T>*>(a);
+        }
+    }
+}
+
+template <typename C>
+__device__ __forceinline__ void pf_store(const ColStoreTiled<typename C::T>& p, int tile, const PfAddr<C>& A, const cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    char* tb = reinterpret_cast<char*>(p.dst) + A.tile_off(tile, p.nrows, p.log_k);
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        char* a = tb + m * A.mstep + A.vdata;
+        if constexpr (C::E == 2) *reinterpret_cast<Vec4<T>*>(a) = Vec4<T>{v[0][m].x, v[0][m].y, v[1][m].x, v[1][m].y};
+        else *reinterpret_cast<cx<T>*>(a) = v[0][m];
+    }
+}
+
+// v *= hy[k] hx[c], then conjugate (the separable case of mid_multiply_conj_kind); hy from the workgroup's LDS copy
+template <typename C>
+__device__ __forceinline__ void pf_multiply_conj(const cx<typename C::T>* hyl, const cx<typename C::T> (&hx)[C::E], int conj, ThreadPos pos,
+                                                 cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const cx<T> hy = hyl[pos.t + m * C::TPS];
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) {
+            const cx<T> h = cmul(hy, hx[e]);
+            const cx<T> x = conj ? cmulc(v[e][m], h) : cmul(v[e][m], h);
+            v[e][m] = {x.x, -x.y};
+        }
+    }
+}
+
+// LDS: [exchange fabric C::LDS_BYTES | twiddle table W_N^k, N entries | hy of this plane, N entries].  Every load the two transforms
+// and the multiply need comes from LDS (lgkmcnt), because the vector memory counter is IN ORDER on gfx9: a twiddle fetched from
+// global memory after the prefetch was issued could only be waited for by waiting for the whole prefetch.  The only vector-memory
+// operations inside the tile loop are the prefetch (next tile + its hx) and the stores.
+template <typename C>
+struct PfLds {
+    static constexpr size_t TW_OFF = (C::LDS_BYTES + 255) & ~size_t(255);
+    static constexpr size_t HY_OFF = TW_OFF + size_t(C::N) * sizeof(cx<typename C::T>);
+    static constexpr size_t BYTES = HY_OFF + size_t(C::N) * sizeof(cx<typename C::T>);
+};
+
+template <typename C, typename S = ColStoreTiled<typename C::T>>
+__global__ void __launch_bounds__(C::NT, 1)
+    fft_col_mul_pf_kernel(const ColLoadTiled<typename C::T> lp0, const MidMul<typename C::T> mp0, const S sp0,
+                          const cx<typename C::T>* __restrict__ tw, const int log_g, const int nvb) {
+    using T = typename C::T;
+    static_assert(C::BO == 1, "one tile per workgroup");
+    extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+    constexpr int TC = C::CI * C::E;
+    const ThreadPos pos = thread_pos<C>(threadIdx.x);
+    const auto lp = at_batch(lp0, blockIdx.y);
+    const auto mp = at_batch(mp0, blockIdx.y);
+    const auto sp = at_batch(sp0, blockIdx.y);
+    const PfAddr<C> A(pos, lp.log_k);
+    cx<T>* const twl = reinterpret_cast<cx<T>*>(pm_smem + PfLds<C>::TW_OFF);
+    cx<T>* const hyl = reinterpret_cast<cx<T>*>(pm_smem + PfLds<C>::HY_OFF);
+    {
+        const int ys = mp.ystep > 1 ? mp.ystep : 1;
+        for (int i = threadIdx.x; i < C::N; i += C::NT) {
+            twl[i] = tw[i];
+            hyl[i] = mp.mul[int64_t(i) * ys];
+        }
+    }
+    cx<T> v[C::E][C::P], vn[C::E][C::P], hx[C::E], hxn[C::E];
+    int vb = blockIdx.x;
+    int unit = group_remap(vb, nvb, log_g);
+    pf_load<C>(lp, unit, A, v);
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) hx[e] = mp.mul_x[unit * TC + pos.cl * C::E + e];
+    // The first tile must have ARRIVED before the loop (an opaque use of its registers): the compiler's s_waitcnt pass places ONE
+    // static wait where a tile's registers are first read, and that point is reached from the loop's back edge too -- if the first
+    // tile could still be pending there, the wait it needs (everything but the newest loads) would also apply in every later trip,
+    // where the newest loads are the prefetch: the prefetch would be drained before each transform.
+#pragma unroll
+    for (int e = 0; e < C::E; ++e)
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) asm volatile("" : "+v"(v[e][m].x), "+v"(v[e][m].y));
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) asm volatile("" : "+v"(hx[e].x), "+v"(hx[e].y));
+    __syncthreads();   // the tables are in LDS
+    for (;;) {
+        const int vb2 = vb + int(gridDim.x);
+        const bool more = vb2 < nvb;       // uniform over the workgroup
+        int unit2 = 0;
+        if (more) {
+            unit2 = group_remap(vb2, nvb, log_g);
+            pf_load<C>(lp, unit2, A, vn);   // in flight until the copy below
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) hxn[e] = mp.mul_x[unit2 * TC + pos.cl * C::E + e];
+        }
+        // opaque copies of the slot, per tile and per transform: twiddles and the separable multiplier depend only on the slot, so
+        // the compiler would hoist their loads out of the tile loop (and CSE them across the two transforms) and hold ~130
+        // registers of them beside the two tiles
+        ThreadPos pos1 = pos;
+        asm volatile("" : "+v"(pos1.t), "+v"(pos1.cl), "+v"(pos1.bo));
+        if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos1, pm_smem, twl);
+        else fft_run<C>(v, pos1, pm_smem, twl);
+        pf_multiply_conj<C>(hyl, hx, mp.conj, pos1, v);
+        __syncthreads();   // LDS of the forward exchange is reused by the inverse
+        ThreadPos pos2 = pos;
+        asm volatile("" : "+v"(pos2.t), "+v"(pos2.cl), "+v"(pos2.bo));
+        if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos2, pm_smem, twl);
+        else fft_run<C>(v, pos2, pm_smem, twl);
+#pragma unroll
+        for (int e = 0; e < C::E; ++e)
+#pragma unroll
+            for (int m = 0; m < C::P; ++m) v[e][m].y = -v[e][m].y;
+        pf_store<C>(sp, unit, A, v);
+        if (!more) break;
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) {
+            hx[e] = hxn[e];
+#pragma unroll
+            for (int m = 0; m < C::P; ++m) v[e][m] = vn[e][m];
+        }
+        unit = unit2;
+        vb = vb2;
+        __syncthreads();   // the next forward exchange reuses the LDS the inverse has just read
+    }
+}
+
+int pm_num_cus();   // capi.hip: compute units of the current device (cached)
+
+// mode (tuning colmul_mode; 512-thread tiles = 2048-point columns only): 0 one tile per workgroup, 1 the same under a 128-VGPR cap
+// (two workgroups per CU), 2 persistent workgroups that prefetch the next tile (fft_col_mul_pf_kernel)
 template <typename T, int LOGN, typename S>
 int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& sp, const cx<T>* tw, int ntiles,
-                       int log_g, hipStream_t st, int nbatch) {
+                       int log_g, hipStream_t st, int nbatch, int mode) {
     using C = typename ColCfgSel<T, LOGN, 0>::type;
+    const int grid = (ntiles + C::BO - 1) / C::BO;
+    if (grid <= 0) return 0;
+    if constexpr (C::NT == 512 && std::is_same<S, ColStoreTiled<T>>::value) {
+        if (mode == 2) {
+            // physical blocks: one per CU over all planes, a multiple of 8 << log_g so that siblings stay siblings
+            const int unit8 = 8 << log_g;
+            int gx = pm_num_cus() / (nbatch > 0 ? nbatch : 1);
+            gx = gx / unit8 * unit8;
+            const bool whole = lp.ay.off == 0 && lp.ay.len == C::N && lp.ay.shift == 0 && lp.ntiles == grid * C::BO && sp.ntiles == lp.ntiles;
+            if (gx >= unit8 && grid % unit8 == 0 && grid > gx && whole && mp.kind == MUL_SEPARABLE && mp.ncols >= grid * C::CI * C::E) {
+                auto kern = fft_col_mul_pf_kernel<C, S>;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   int(PfLds<C>::BYTES));
+                if (e != hipSuccess) return int(e);
+                hipLaunchKernelGGL(kern, dim3(gx, nbatch), dim3(C::NT), PfLds<C>::BYTES, st, lp, mp, sp, tw, log_g, grid);
+                return int(hipGetLastError());
+            }
+        }
+        if (mode == 1) {
+            auto kern = fft_col_mul_kernel<C, S, 4>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               int(C::LDS_BYTES));
+            if (e != hipSuccess) return int(e);
+            hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), C::LDS_BYTES, st, lp, mp, sp, tw, log_g);
+            return int(hipGetLastError());
+        }
+    }
     auto kern = fft_col_mul_kernel<C, S>;
     if (C::LDS_BYTES > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            int(C::LDS_BYTES));
         if (e != hipSuccess) return int(e);
     }
-    const int grid = (ntiles + C::BO - 1) / C::BO;
-    if (grid <= 0) return 0;
     hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), C::LDS_BYTES, st, lp, mp, sp, tw, log_g);
     return int(hipGetLastError());
 }
 
 template <typename T, typename S>
 int launch_col_mul_impl(int logm, const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& sp, const cx<T>* tw,
-                        int ntiles, int log_g, hipStream_t st, int nbatch) {
+                        int ntiles, int log_g, hipStream_t st, int nbatch, int mode = 0) {
     switch (logm) {
 #define PM_CASE(k) \
     case k:        \
-        return launch_col_mul_one<T, k, S>(lp, mp, sp, tw, ntiles, log_g, st, nbatch);
+        return launch_col_mul_one<T, k, S>(lp, mp, sp, tw, ntiles, log_g, st, nbatch, mode);
         PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
         PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASE(11) PM_CASE(12) PM_CASE(13)
 #undef PM_CASE
@@ -233,7 +435,7 @@ template <typename T> int launch_row_tiled(int logn, int var, const RowLoadNat<T
 template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
-template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1, int mode = 0);
 template <typename T> int launch_col_mul_crop(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiledCrop<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
 template <typename T> int launch_row_from_tiled(int logn, int var, const RowLoadTiled<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t, int nbatch = 1);
 template <typename T> int launch_row_fold(int logn, const RowLoadNat<T>&, const RowStoreFold<T>&, const cx<T>* tw, int npairs, int log_g, hipStream_t, int nbatch = 1);

@@ -69,7 +69,8 @@ template <typename T> int launch_row_tiled(int logn, int var, const RowLoadNat<T
 template <typename T> int launch_row_nat(int logn, int var, const RowLoadNat<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_col_tiled(int logm, int var, const ColLoadTiled<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
 template <typename T> int launch_col_nat(int logm, int var, const ColLoadNat<T>&, const ColStoreNat<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
-template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1);
+template <typename T> int launch_col_mul(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiled<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t, int nbatch = 1, int mode = 0);
+int pm_num_cus();   // compute units of the current device (cached per device)
 template <typename T> int launch_col_mul_crop(int logm, const ColLoadTiled<T>&, const MidMul<T>&, const ColStoreTiledCrop<T>&, const cx<T>* tw, int ntiles, int log_g, hipStream_t);
 template <typename T> int launch_row_from_tiled(int logn, int var, const RowLoadTiled<T>&, const RowStoreNat<T>&, const cx<T>* tw, int nseq, hipStream_t, int nbatch = 1);
 template <typename T> int launch_row_fold(int logn, const RowLoadNat<T>&, const RowStoreFold<T>&, const cx<T>* tw, int npairs, int log_g, hipStream_t, int nbatch = 1);
@@ -119,6 +120,8 @@ struct Tuning {
     int spectral = 8;         // pm_fft2_spectral: wavelengths per launch pair (fft_spectral.h; <= 8); 1: the plain loop of pm_fft2 calls
     int spectral_area_log = 24;   // ... for transforms of fewer than 2^this bins (capi.hip spectral_fast has the measurements)
     int spectral_mode = 3;    // ... bit 0: its row pass keeps the packed map in registers, bit 1: its column pass accumulates in registers
+    int colmul_mode = 0;      // middle pass of the fused chain at 2048-point column tiles (fft_kernels.h launch_col_mul_one): 0 one tile per
+                              // workgroup, 1 the same under a 128-VGPR cap (two workgroups per CU), 2 persistent prefetching workgroups
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)
 };

@@ -47,6 +47,16 @@ int cmul_launch(int op, int64_t rows, int64_t cols, const void* a, int64_t lda, 
     return int(hipGetLastError());
 }
 
+// ---------------------------------------------------------------- real x complex
+template <typename T>
+__global__ void rmul_kernel(int64_t rows, int64_t cols, const T* r_, int64_t ldr, const cx<T>* a, int64_t lda, T scale,
+                            cx<T>* o, int64_t ldo) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < rows; r += int64_t(gridDim.y) * blockDim.y)
+        o[r * ldo + c] = cscale(a[r * lda + c], scale * r_[r * ldr + c]);
+}
+
 // ---------------------------------------------------------------- separable scale
 template <typename T>
 __global__ void scale_sep_kernel(int64_t rows, int64_t cols, const cx<T>* in, int64_t ldi, const cx<T>* ry, int ryc,
@@ -449,6 +459,23 @@ int pm_cmul(int32_t dtype, int32_t op, int64_t rows, int64_t cols, const void* a
     if (dtype == PM_C64) return cmul_launch<float>(op, rows, cols, a, a_ld, b, b_ld, out, out_ld, PM_STREAM(stream));
     if (dtype == PM_C128) return cmul_launch<double>(op, rows, cols, a, a_ld, b, b_ld, out, out_ld, PM_STREAM(stream));
     return fail(PM_ERR_ARG, "pm_cmul: dtype must be PM_C64 or PM_C128");
+}
+
+int pm_rmul(int32_t dtype, int64_t rows, int64_t cols, const void* r, int64_t r_ld, const void* a, int64_t a_ld, double scale,
+            void* out, int64_t out_ld, void* stream) {
+    if (!r || !a || !out || rows < 0 || cols < 0) return fail(PM_ERR_ARG, "pm_rmul: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(rows, cols, block);
+    if (dtype == PM_C64)
+        hipLaunchKernelGGL(rmul_kernel<float>, grid, block, 0, PM_STREAM(stream), rows, cols, (const float*)r, r_ld, (const cx<float>*)a,
+                           a_ld, float(scale), (cx<float>*)out, out_ld);
+    else if (dtype == PM_C128)
+        hipLaunchKernelGGL(rmul_kernel<double>, grid, block, 0, PM_STREAM(stream), rows, cols, (const double*)r, r_ld,
+                           (const cx<double>*)a, a_ld, scale, (cx<double>*)out, out_ld);
+    else
+        return fail(PM_ERR_ARG, "pm_rmul: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
 }
 
 int pm_scale_sep(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t in_ld, const void* ry,

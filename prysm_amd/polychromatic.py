@@ -11,6 +11,7 @@ sum-reduce of the real image (RCCL over xGMI; `backend="nccl"` is RCCL on ROCm) 
 incoherent sum.  One process per GPU; world size 1 needs no process group.
 """
 import math
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -24,7 +25,42 @@ def shard_bounds(n_items, rank, world_size):
     return lo, hi
 
 
-def _reduce_image(acc, world, group, reduce_to_all, method='reduce'):
+# (amplitude, OPD) -> packed map, keyed on tensor IDENTITY and torch's version counters: a model that calls polychromatic_psf
+# repeatedly with the same two maps (a wavelength sweep per frame, an optimiser's forward pass with unchanged amplitude and OPD
+# tensors) packs them once instead of paying two extra sweeps of the pupil inside every call (6 % of an 8-wavelength share at 4096^2).
+# Identity, not address: a freed map's address is reused by the next one.  In-place torch ops bump the version; the library's own
+# `out=` writes do too (_ops._bump).
+_PACK_CACHE = []
+_PACK_CACHE_MAX = 4
+
+
+def _version(t):
+    return None if t is None else t._version
+
+
+def packed_pupil(amp, opd, a_syn, o_syn):
+    """pack_amp_opd(a_syn, o_syn), cached on the identity + version of the caller's tensors `amp` / `opd`."""
+    from . import _ops
+    for i, (ra, va, ro, vo, packed) in enumerate(_PACK_CACHE):
+        if (ra() if ra is not None else None) is amp and ro() is opd and va == _version(amp) and vo == _version(opd):
+            if i:
+                _PACK_CACHE.insert(0, _PACK_CACHE.pop(i))
+            return packed
+    packed = _ops.pack_amp_opd(a_syn, o_syn)
+    _PACK_CACHE.insert(0, (None if amp is None else weakref.ref(amp), _version(amp), weakref.ref(opd), _version(opd), packed))
+    del _PACK_CACHE[_PACK_CACHE_MAX:]
+    _PACK_CACHE[:] = [e for e in _PACK_CACHE if (e[0] is None or e[0]() is not None) and e[2]() is not None]
+    return packed
+
+
+def _group_info(group):
+    """(process group in use?, rank in group, world).  A group of ONE rank still runs its collective: the call is then the same
+    code path at every N (and the world-1 RCCL test on a one-GPU box executes exactly what the 8-GPU node executes)."""
+    use = dist.is_available() and dist.is_initialized()
+    return use, (dist.get_rank(group) if use else 0), (dist.get_world_size(group) if use else 1)
+
+
+def _reduce_image(acc, world, group, reduce_to_all, method='reduce', use_dist=None):
     """The one data-path collective: sum-reduce of the real image over the ranks (RCCL; gloo in the CPU tests).
 
     reduce_to_all           : all_reduce, every rank gets the image.
@@ -35,7 +71,9 @@ def _reduce_image(acc, world, group, reduce_to_all, method='reduce'):
                               (pm_sum_modes: fixed order, bitwise reproducible) and the first rank gathers the reduced slices.
                               Needs numel % world == 0; falls back to 'reduce' otherwise.
     """
-    if world <= 1:
+    if use_dist is None:
+        use_dist = world > 1
+    if not use_dist:
         return acc
     if reduce_to_all:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
@@ -73,16 +111,19 @@ def incoherent_sum(propagate, wavelengths, weights, *, group=None, reduce_to_all
     """
     if len(wavelengths) != len(weights):
         raise ValueError('wavelengths and weights must have the same length')
-    use_dist = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank(group) if use_dist else 0
-    world = dist.get_world_size(group) if use_dist else 1
+    use_dist, rank, world = _group_info(group)
     lo, hi = shard_bounds(len(wavelengths), rank, world)
+    acc = _loop_sum(propagate, wavelengths, weights, lo, hi, out)
+    return _reduce_image(acc, world, group, reduce_to_all, reduce_method, use_dist)
+
+
+def _loop_sum(propagate, wavelengths, weights, lo, hi, out=None):
     acc = out
     for k in range(lo, hi):
         acc = propagate(float(wavelengths[k]), float(weights[k]), acc)
     if acc is None:
         raise ValueError('a rank received no wavelengths and no `out` buffer to define the image shape')
-    return _reduce_image(acc, world, group, reduce_to_all, reduce_method)
+    return acc
 
 
 def _fields_per_launch(shape, cdtype_bytes, Q, limit_bytes=1 << 30):
@@ -93,48 +134,29 @@ def _fields_per_launch(shape, cdtype_bytes, Q, limit_bytes=1 << 30):
     return max(1, min(64, limit_bytes // per_field))
 
 
-def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, focal_dx=None, samples=None,
-                      kind='mdft', group=None, reduce_to_all=True, batched=None, reduce_method='reduce', spectral=True):
-    """Polychromatic PSF of a pupil (amplitude, OPD in nm) -- the how-to's recipe on N GPUs.
-
-    Q given            : FFT focus per wavelength with the |.|^2 fused into the transform (multi-field throughput
-                         variant; focal sampling is chromatic, as the reference docs note).  With `batched` the
-                         wavelengths of a rank are propagated as stacks -- one launch pair per stack, then one
-                         weighted sum (sum_of_2d_modes) -- which is what makes <= 2048^2 transforms bandwidth-bound
-                         instead of launch-bound; batched=False is the field-by-field loop with the accumulate
-                         epilogue, the faster form from 4096^2 transforms (single fields take the folded kernels).
-                         Default (None): stacks below 4096^2 transforms.
-    spectral           : with Q and float maps of power-of-two width, a rank's wavelength loop runs as ONE call whose launch pairs
-                         each cover a group of wavelengths (pm_fft2_spectral; False: one transform pair per wavelength).
-    reduce_method      : 'reduce' (one torch.distributed.reduce) or 'a2a' (all-to-all of slices + ordered local sum + gather:
-                         bitwise reproducible, one message per xGMI link) when only the first rank needs the image.
-    focal_dx + samples : per-wavelength fixed-sampling focus (prepare_executor + focus_dft, `kind`),
-                         all wavelengths on one focal grid -- the variant of the how-to.
-    """
+def _local_sum(amplitude, opd, wavelengths, weights, lo, hi, dx, efl, Q, focal_dx, samples, kind, batched, spectral):
+    """sum_k w_k |E_k|^2 over this rank's wavelengths [lo, hi): the compute half of polychromatic_psf (no collective)."""
     from . import _lib as L
     from . import _ops
     from .propagation import Wavefront, focus_intensity
     from .propagation.wavefront import _synth_args
 
+    if len(wavelengths) != len(weights):
+        raise ValueError('wavelengths and weights must have the same length')
     amp = L.as_device(amplitude)
     phs = L.as_device(opd)
 
     packed = None
     if Q is not None and not batched:
         # the pupil is synthesised inside every wavelength's transform (float maps, power-of-two width): pack (amplitude, OPD)
-        # once so each of those row passes reads one 8-byte element per sample instead of two 4-byte ones from two arrays
+        # once -- per pair of maps, not per call (packed_pupil) -- so each of those row passes reads one 8-byte element per sample
+        # instead of two 4-byte ones from two arrays
         probe = Wavefront.from_amp_and_phase(amp, phs, float(wavelengths[0]), dx)._fusable(Q) if len(wavelengths) else None
         if probe is not None and len(wavelengths) > 1:
-            packed = _ops.pack_amp_opd(probe[0], probe[1])
+            packed = packed_pupil(amp, phs, probe[0], probe[1])
     if Q is not None and batched is None:
         batched = (packed is None or not spectral) and math.ceil(amp.shape[-2] * Q) * math.ceil(amp.shape[-1] * Q) < 4096 * 4096
     if Q is not None and batched:
-        if len(wavelengths) != len(weights):
-            raise ValueError('wavelengths and weights must have the same length')
-        use_dist = dist.is_available() and dist.is_initialized()
-        rank = dist.get_rank(group) if use_dist else 0
-        world = dist.get_world_size(group) if use_dist else 1
-        lo, hi = shard_bounds(len(wavelengths), rank, world)
         a, o, cd = _synth_args(amp, phs)
         m, n = o.shape
         M, N = math.ceil(m * Q), math.ceil(n * Q)
@@ -150,23 +172,17 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
                 else:
                     _ops.pupil_synth(a, o, kk, cd, out=stack[i])     # synthesised straight into the stack
             _ops.sum_modes(focus_intensity(stack, Q), [float(w) for w in weights[b0:b1]], out=acc, accumulate=True)
-        return _reduce_image(acc, world, group, reduce_to_all, reduce_method)
+        return acc
 
     if packed is not None and spectral:
         # the rank's whole wavelength loop in one call: groups of wavelengths share a launch pair (the packed map is read once per
         # group, the image touched once per group -- csrc/fft_spectral.h)
-        if len(wavelengths) != len(weights):
-            raise ValueError('wavelengths and weights must have the same length')
-        use_dist = dist.is_available() and dist.is_initialized()
-        rank = dist.get_rank(group) if use_dist else 0
-        world = dist.get_world_size(group) if use_dist else 1
-        lo, hi = shard_bounds(len(wavelengths), rank, world)
         m, n = packed.shape
         acc = torch.zeros((math.ceil(m * Q), math.ceil(n * Q)), dtype=L._REAL_OF[packed.dtype], device=packed.device)
         if hi > lo:
             ks = [2 * math.pi / float(wavelengths[k]) / 1e3 for k in range(lo, hi)]
             focus_intensity(packed, Q, out=acc, synth=('packed', ks[0]), spectral=(ks, [float(w) for w in weights[lo:hi]]))
-        return _reduce_image(acc, world, group, reduce_to_all, reduce_method)
+        return acc
 
     def propagate(wvl, w, acc):
         if packed is not None:
@@ -189,4 +205,108 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
             acc = torch.zeros(E.shape, dtype=L._REAL_OF[E.dtype], device=E.device)
         return _ops.abs2(E, out=acc, weight=w)
 
-    return incoherent_sum(propagate, wavelengths, weights, group=group, reduce_to_all=reduce_to_all, reduce_method=reduce_method)
+    return _loop_sum(propagate, wavelengths, weights, lo, hi)
+
+
+def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, focal_dx=None, samples=None,
+                      kind='mdft', group=None, reduce_to_all=True, batched=None, reduce_method='reduce', spectral=True):
+    """Polychromatic PSF of a pupil (amplitude, OPD in nm) -- the how-to's recipe on N GPUs.
+
+    Q given            : FFT focus per wavelength with the |.|^2 fused into the transform (multi-field throughput
+                         variant; focal sampling is chromatic, as the reference docs note).  With `batched` the
+                         wavelengths of a rank are propagated as stacks -- one launch pair per stack, then one
+                         weighted sum (sum_of_2d_modes) -- which is what makes <= 2048^2 transforms bandwidth-bound
+                         instead of launch-bound; batched=False is the field-by-field loop with the accumulate
+                         epilogue, the faster form from 4096^2 transforms (single fields take the folded kernels).
+                         Default (None): stacks below 4096^2 transforms.
+    spectral           : with Q and float maps of power-of-two width, a rank's wavelength loop runs as ONE call whose launch pairs
+                         each cover a group of wavelengths (pm_fft2_spectral; False: one transform pair per wavelength).
+    reduce_method      : 'reduce' (one torch.distributed.reduce) or 'a2a' (all-to-all of slices + ordered local sum + gather:
+                         bitwise reproducible, one message per xGMI link) when only the first rank needs the image.
+    focal_dx + samples : per-wavelength fixed-sampling focus (prepare_executor + focus_dft, `kind`),
+                         all wavelengths on one focal grid -- the variant of the how-to.
+
+    The (amplitude, OPD) maps are packed once per pair of tensors (packed_pupil), not once per call.  A process group of one
+    rank still runs its collective (same code path at every N); without a process group there is none.
+    """
+    use_dist, rank, world = _group_info(group)
+    lo, hi = shard_bounds(len(wavelengths), rank, world)
+    acc = _local_sum(amplitude, opd, wavelengths, weights, lo, hi, dx, efl, Q, focal_dx, samples, kind, batched, spectral)
+    return _reduce_image(acc, world, group, reduce_to_all, reduce_method, use_dist)
+
+
+class PendingImage:
+    """A polychromatic PSF whose image reduce may still be running on the pipeline's side stream."""
+
+    def __init__(self, image, event, keep):
+        self._image, self._event, self._keep = image, event, keep
+
+    def result(self):
+        """The image (first rank of the group, or every rank with reduce_to_all); torch's CURRENT stream waits for the reduce."""
+        if self._event is not None:
+            torch.cuda.current_stream().wait_event(self._event)
+            self._event = None
+        self._keep = None
+        return self._image
+
+    def done(self):
+        return self._event is None or self._event.query()
+
+
+class PsfPipeline:
+    """A SEQUENCE of polychromatic PSFs (frames of a time series, the forward passes of an optimiser, field points ...) with the
+    one collective of frame k running on a side stream while frame k + 1 computes.
+
+    A single polychromatic_psf call ends with its image reduce exposed: at 8 GPUs, 8 wavelengths x ~105 us of transforms per rank
+    stand against a 67 MB fp32 reduce that takes a comparable time over xGMI, so one call alone cannot scale near-linearly.  The
+    frames of a sequence are independent, and the reduce needs no compute units to speak of, so it hides behind the next frame's
+    transforms: ``submit`` enqueues a frame's wavelength loop on the current stream, then hands its image to the side stream
+    (which waits for the loop, runs `_reduce_image` there -- RCCL orders itself behind the stream it is called on -- and records
+    an event); ``PendingImage.result()`` makes the consumer's stream wait for that event.  Every rank submits the same frames in
+    the same order, so the collectives match.  At most `depth` frames are in flight (their accumulators are live).
+    CPU tensors (the gloo tests) run the same calls synchronously.
+    """
+
+    def __init__(self, wavelengths, weights, dx, efl, *, Q=None, focal_dx=None, samples=None, kind='mdft', group=None,
+                 reduce_to_all=False, batched=None, reduce_method='reduce', spectral=True, depth=2, propagate=None):
+        """propagate(amplitude, opd, wavelength, weight, acc) -> acc: optional replacement of the per-wavelength step (as in
+        incoherent_sum; the CPU tests inject the oracle here)."""
+        if len(wavelengths) != len(weights):
+            raise ValueError('wavelengths and weights must have the same length')
+        self.wavelengths, self.weights, self.dx, self.efl = list(wavelengths), list(weights), dx, efl
+        self.kw = dict(Q=Q, focal_dx=focal_dx, samples=samples, kind=kind, batched=batched, spectral=spectral)
+        self.group, self.reduce_to_all, self.reduce_method = group, reduce_to_all, reduce_method
+        self.depth = max(1, int(depth))
+        self._propagate = propagate
+        self._side = None
+        self._inflight = []
+
+    def submit(self, amplitude, opd):
+        use_dist, rank, world = _group_info(self.group)
+        lo, hi = shard_bounds(len(self.wavelengths), rank, world)
+        while len(self._inflight) >= self.depth:      # bound the live accumulators: wait (host side) for the oldest reduce
+            ev = self._inflight.pop(0)
+            ev.synchronize()
+        if self._propagate is not None:
+            acc = _loop_sum(lambda wvl, w, a: self._propagate(amplitude, opd, wvl, w, a), self.wavelengths, self.weights, lo, hi)
+        else:
+            acc = _local_sum(amplitude, opd, self.wavelengths, self.weights, lo, hi, self.dx, self.efl, **self.kw)
+        if not acc.is_cuda or not use_dist:
+            return PendingImage(_reduce_image(acc, world, self.group, self.reduce_to_all, self.reduce_method, use_dist), None, None)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=acc.device)
+        main = torch.cuda.current_stream(acc.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            img = _reduce_image(acc, world, self.group, self.reduce_to_all, self.reduce_method, use_dist)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        acc.record_stream(self._side)      # the accumulator came from the main stream's allocator pool
+        self._inflight.append(ev)
+        return PendingImage(img, ev, acc)
+
+    def drain(self):
+        """Block the host until every submitted frame's reduce has finished."""
+        for ev in self._inflight:
+            ev.synchronize()
+        self._inflight = []

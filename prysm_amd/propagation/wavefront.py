@@ -210,7 +210,12 @@ class Wavefront:
         if isinstance(ibar, RichData):
             ibar = ibar.data
         ibar = L.as_device(ibar)
-        Gbar = 2 * ibar * self.data
+        E = self.data
+        if (ibar.dim() == 2 and E.dim() == 2 and E.is_complex() and ibar.dtype == L._REAL_OF[E.dtype] and ibar.shape == E.shape and
+                ibar.stride(1) == 1 and E.stride(1) == 1):
+            Gbar = _ops.rmul(ibar, E, 2.0)        # one sweep (pm_rmul) instead of two torch ones
+        else:
+            Gbar = 2 * ibar * E
         return Wavefront(Gbar, self.wavelength, self.dx, self.space)
 
     def pad2d(self, Q, value=0, mode='constant', out_shape=None, inplace=True):

@@ -1,6 +1,9 @@
-"""2 ranks: the polychromatic driver's sharded paths (stacks and field-by-field, FFT and matrix-DFT variants; all-reduce,
+"""1 or 2 ranks (WORLD_SIZE): the polychromatic driver's sharded paths (stacks and field-by-field, FFT and matrix-DFT variants; all-reduce,
 reduce to root and the all-to-all reduce) against the oracle's single-process sum.  PM_TEST_BACKEND=nccl: one GPU per rank over
-RCCL; gloo (default): both ranks on GPU 0.  Launch with torch.distributed.run --nproc-per-node 2."""
+RCCL; gloo (default): both ranks on GPU 0.  Launch with torch.distributed.run --nproc-per-node 2 -- or 1 with PM_TEST_BACKEND=nccl:
+a process group of ONE rank still runs every collective (RCCL init, reduce, all_to_all_single, gather, all_reduce), which is how a
+one-GPU box executes the code path of the 8-GPU node.  Also: PsfPipeline (a frame's reduce on a side stream under the next
+frame's transforms) against the same sums."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
@@ -14,7 +17,7 @@ if backend == 'nccl':
     dist.init_process_group('nccl', device_id=torch.device('cuda', dev))
 else:
     dist.init_process_group('gloo')
-from prysm_amd.polychromatic import polychromatic_psf
+from prysm_amd.polychromatic import polychromatic_psf, PsfPipeline
 from prysm_amd.mathops import array_to_true_numpy as tonp
 
 n = 128
@@ -51,7 +54,23 @@ for w in wvls:
 want_m = O.sum_of_2d_modes(np.asarray(comps), wts)
 got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, focal_dx=0.55 * 10 / 4, samples=64, kind='mdft'))
 worst = max(worst, float(np.abs(got - want_m).max() / np.abs(want_m).max()))
-print(f'rank {rank}: polychromatic 2-rank sum vs oracle, worst relative error {worst:.2e}', 'OK' if worst < 1e-10 else 'FAIL', flush=True)
+# a sequence of frames through the pipeline: every reduce form, the reduce of frame f overlapping the transforms of frame f + 1
+scales = (300.0, 150.0, 450.0, 300.0)
+wantf = {}
+for sc in set(scales):
+    o2 = O.hopkins_w040(r / 5, sc)
+    wantf[sc] = O.sum_of_2d_modes(np.asarray([O.intensity(O.focus(O.from_amp_and_phase(amp, o2, float(w)), 2)) for w in wvls]), wts)
+amp_t = torch.from_numpy(amp).cuda()
+for kw in (dict(reduce_to_all=True), dict(reduce_method='reduce'), dict(reduce_method='a2a')):
+    pipe = PsfPipeline(wvls, wts, dx, 100.0, Q=2, batched=False, depth=2, **kw)
+    pend = [pipe.submit(amp_t, torch.from_numpy(O.hopkins_w040(r / 5, sc)).cuda()) for sc in scales]
+    imgs = [p.result() for p in pend]
+    torch.cuda.synchronize()
+    if rank == 0 or kw.get('reduce_to_all'):
+        for sc, im in zip(scales, imgs):
+            worst = max(worst, float(np.abs(tonp(im) - wantf[sc]).max() / np.abs(wantf[sc]).max()))
+    pipe.drain()
+print(f'rank {rank}: polychromatic {dist.get_world_size()}-rank sum vs oracle, worst relative error {worst:.2e}', 'OK' if worst < 1e-10 else 'FAIL', flush=True)
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if worst < 1e-10 else 1)

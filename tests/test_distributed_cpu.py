@@ -106,3 +106,76 @@ def test_incoherent_sum_subgroup_without_global_rank0():
     for method in ('reduce', 'a2a'):
         res, ref = _run(False, method=method, world=3, sub=True)
         np.testing.assert_allclose(res[1], ref, rtol=1e-12, atol=1e-12 * ref.max())
+
+
+def _pipeline_worker(rank, world, port, q, method):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import prysm_oracle as O
+    from prysm_amd.polychromatic import PsfPipeline
+    n = 32
+    x, y = O.make_xy_grid(n, diameter=10)
+    r, _ = O.cart_to_polar(x, y)
+    amp = O.circle(5, r)
+    wvls, wts = np.linspace(0.5, 0.7, 5), np.linspace(1.0, 2.0, 5)
+
+    def propagate(a, o, wvl, w, acc):
+        I = torch.from_numpy(O.intensity(O.focus(O.from_amp_and_phase(a, o, wvl), 2)) * w)
+        return I if acc is None else acc.add_(I)
+
+    pipe = PsfPipeline(wvls, wts, 10.0 / n, 100.0, Q=2, reduce_method=method, propagate=propagate, depth=2)
+    pend = [pipe.submit(amp, O.hopkins_w040(r / 5, 100.0 * (f + 1))) for f in range(3)]    # three frames, different OPDs
+    pipe.drain()
+    q.put((rank, [p.result().numpy() for p in pend]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_psf_pipeline_frames_world2():
+    """PsfPipeline: a sequence of frames, each frame's reduce issued behind its own wavelength loop (synchronous on CPU tensors):
+    the root receives every frame's oracle sum, in order, for both root-only reduce forms"""
+    sys.path.insert(0, ROOT)
+    from oracle import prysm_oracle as O
+    n = 32
+    x, y = O.make_xy_grid(n, diameter=10)
+    r, _ = O.cart_to_polar(x, y)
+    amp = O.circle(5, r)
+    wvls, wts = np.linspace(0.5, 0.7, 5), np.linspace(1.0, 2.0, 5)
+    for method in ('reduce', 'a2a'):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_pipeline_worker, args=(r_, 2, port, q, method)) for r_ in range(2)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        for f in range(3):
+            opd = O.hopkins_w040(r / 5, 100.0 * (f + 1))
+            ref = O.sum_of_2d_modes(np.asarray([O.intensity(O.focus(O.from_amp_and_phase(amp, opd, w), 2)) for w in wvls]), wts)
+            np.testing.assert_allclose(res[0][f], ref, rtol=1e-12, atol=1e-12 * ref.max())
+
+
+def test_packed_pupil_cache_identity_and_version():
+    """packed_pupil: one pack per (amplitude, OPD) tensor pair; an in-place change (version bump) or a different tensor object
+    -- even one that would reuse the freed tensor's address -- misses"""
+    sys.path.insert(0, ROOT)
+    from prysm_amd import polychromatic as pc
+    pc._PACK_CACHE.clear()
+    amp, opd = torch.ones(8, 8), torch.arange(64.0).reshape(8, 8)
+    p1 = pc.packed_pupil(amp, opd, amp, opd)
+    assert pc.packed_pupil(amp, opd, amp, opd) is p1
+    opd.add_(1.0)                                   # rewritten in place: stale
+    p2 = pc.packed_pupil(amp, opd, amp, opd)
+    assert p2 is not p1 and torch.equal(p2.imag, opd)
+    torch.autograd.graph.increment_version(opd)     # what the library's out= writes do (_ops._bump)
+    assert pc.packed_pupil(amp, opd, amp, opd) is not p2
+    opd2 = opd.clone()
+    assert pc.packed_pupil(amp, opd2, amp, opd2) is not pc.packed_pupil(amp, opd, amp, opd)
+    del opd2
+    assert len(pc._PACK_CACHE) <= pc._PACK_CACHE_MAX
+    p3 = pc.packed_pupil(None, opd, None, opd)      # no amplitude map: unit amplitude
+    assert torch.equal(p3.real, torch.ones(8, 8)) and pc.packed_pupil(None, opd, None, opd) is p3

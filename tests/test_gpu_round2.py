@@ -550,6 +550,19 @@ def test_polychromatic_two_ranks_vs_oracle(pa):
     assert res.stdout.count('OK') >= 2
 
 
+def test_polychromatic_one_rank_rccl_group(pa):
+    """the same script as ONE rank under an `nccl` process group -- RCCL initialises and reduce,
+    all_to_all_single, gather and all_reduce execute on the device for real (a group of one rank still runs its collective,
+    polychromatic._group_info), plus the pipelined form with its side stream"""
+    env = _env()
+    env['PM_TEST_BACKEND'] = 'nccl'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29543', os.path.join(ROOT, 'tests', 'multi_rank_poly.py')]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
+    assert res.stdout.count('OK') >= 1
+
+
 # ----------------------------------------------------------------------------- the wavelength loop as one call (pm_fft2_spectral)
 
 def _spectral_case(rng, m, n):
