@@ -357,6 +357,15 @@ int pm_cgemm(int32_t dtype, int32_t opA, int32_t opB, int64_t M, int64_t N, int6
 /* bytes of split-K workspace pm_cgemm wants for this shape (0 = none; without it the GEMM runs unsplit) */
 size_t pm_cgemm_workspace(int32_t dtype, int64_t M, int64_t N, int64_t K);
 
+/* R = (accumulate ? R : 0) + weight * |alpha * opA(A) @ opB(B)|^2, R REAL (float for PM_C64): the second product of a matrix-DFT
+ * focus with Wavefront.intensity (prysm/propagation/wavefront.py:146-151) and the weighted sum of the polychromatic recipe
+ * (polynomials.sum_of_2d_modes, prysm/polynomials/fitting.py:7-37) in its epilogue -- the complex focal field is never written.
+ * Same workspace as pm_cgemm.  Only the shapes the LDS-DMA kernel takes (PM_C64, M and N multiples of 64, K of 16, 16-byte aligned
+ * operands, even leading dimensions); PM_ERR_UNSUPPORTED otherwise: compose pm_cgemm and pm_abs2. */
+int pm_cgemm_abs2(int32_t dtype, int32_t opA, int32_t opB, int64_t M, int64_t N, int64_t K, double alpha, const void* A,
+                  int64_t lda, const void* B, int64_t ldb, void* R, int64_t ldr, double weight, int32_t accumulate, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
 /* --- housekeeping ------------------------------------------------------------------------- */
 int pm_version(void);
 const char* pm_last_error(void);   /* thread-local message for the last negative return */

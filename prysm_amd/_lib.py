@@ -89,6 +89,8 @@ SIGNATURES = {
     'pm_cgemm': (c_i32, [c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_f64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                          c_vp, c_sz, c_vp]),
     'pm_cgemm_workspace': (c_sz, [c_i32, c_i64, c_i64, c_i64]),
+    'pm_cgemm_abs2': (c_i32, [c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_f64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_f64, c_i32,
+                              c_vp, c_sz, c_vp]),
 }
 
 _lib = None

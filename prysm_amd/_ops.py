@@ -581,5 +581,34 @@ def cgemm(A, B, opA=0, opB=0, alpha=1.0):
     return C
 
 
+def cgemm_abs2(A, B, opA=0, opB=0, alpha=1.0, out=None, weight=1.0):
+    """weight * |alpha op(A) @ op(B)|^2 as a REAL image, added to `out` when given (pm_cgemm_abs2: the |.|^2 and the weighted
+    accumulate in the product's epilogue, no complex result in memory).  Returns None when the shapes are not the LDS-DMA
+    kernel's (the caller composes cgemm + abs2)."""
+    lib = L.load()
+    M, K = (A.shape[1], A.shape[0]) if opA & 2 else A.shape
+    K2, N = (B.shape[1], B.shape[0]) if opB & 2 else B.shape
+    if K != K2:
+        raise ValueError(f'matmul: inner dimensions differ ({K} vs {K2})')
+    if A.dtype != torch.complex64 or B.dtype != torch.complex64 or M % 64 or N % 64 or K % 16 or M < 64 or N < 64:
+        return None
+    acc = 1
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        acc = 0
+    else:
+        if out.dtype != torch.float32 or tuple(out.shape) != (M, N) or out.stride(1) != 1 or out.device != A.device:
+            raise ValueError('cgemm_abs2: `out` must be a float32 (M, N) image on the device of the operands')
+        _bump(out)
+    nbytes = lib.pm_cgemm_workspace(L.code(A), M, N, K)
+    ws = L.workspace(nbytes)
+    rc = lib.pm_cgemm_abs2(L.code(A), opA, opB, M, N, K, float(alpha), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out),
+                           out.stride(0), float(weight), acc, L.ptr(ws), 0 if ws is None else ws.numel(), L.stream_ptr())
+    if rc == L.PM_ERR_UNSUPPORTED:
+        return None
+    L.check(rc)
+    return out
+
+
 def ceil_half(d):
     return math.ceil(d / 2)

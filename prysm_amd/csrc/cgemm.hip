@@ -308,9 +308,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   !KFAST (memory [k][row]): [k][ROWS rows] as in memory; a piece is 1 KiB of that image (one k of 128 rows, two of 64);
 //                             fragments by 8-byte reads.
 // ROWS / 8 pieces per tile, ROWS / 32 per wave.
-template <int ROWS, bool KFAST>
+// ROWS / 8 pieces per tile, shared by the NWS waves that stage it (ROWS / (8 NWS) each).
+template <int ROWS, bool KFAST, int NWS>
 struct DmaTile {
-    static constexpr int PPW = ROWS / 32;   // pieces per wave
+    static constexpr int PPW = ROWS / 8 / NWS;   // pieces per wave
+    static_assert(PPW >= 1 && PPW * 8 * NWS == ROWS, "tile rows must divide over the staging waves");
     unsigned goff[PPW];   // this lane's source byte offset from the tile base, per piece
     __device__ __forceinline__ void init(int64_t ld, int wave, int lane) {
 #pragma unroll
@@ -335,18 +337,27 @@ struct DmaTile {
     }
 };
 
-// TI x TJ MFMA tiles (32 x 32) per wave, 2 x 2 waves: workgroup tile 64 TI x 64 TJ.  (2, 2): 128 x 128, one workgroup per CU
-// (192 accumulator registers per lane), the large-GEMM shape; (1, 1): 64 x 64, for the matrix-DFT products whose output has only
-// a few hundred such tiles -- 512 x 2048 = 256 of them, one per CU without splitting K.
-template <int TI, int TJ, bool AKF, bool BKF>
+// TI x TJ MFMA tiles (32 x 32) per wave; the four waves of a workgroup are arranged WM x WN x WK (rows, columns, K):
+//   (2, 2) tiles, 2 x 2 x 1: 128 x 128, one workgroup per CU (192 accumulator registers per lane), the large-GEMM shape;
+//   (1, 1) tiles, 2 x 2 x 1:  64 x 64;
+//   (1, 1) tiles, 2 x 1 x 2:  64 x 32, the two wave PAIRS each take half of the K range;
+//   (1, 1) tiles, 1 x 1 x 4:  32 x 32, every wave a quarter of the K range.
+// WK > 1 is split-K INSIDE the workgroup: each K-group has its own three-deep LDS ring (A rows 32 TI WM, B rows 32 TJ WN), the groups
+// walk their K ranges in lockstep (same barriers) and their partial sums meet through LDS at the end, added in K order -- fixed
+// order, bitwise reproducible, no slab round trip through HBM and no second launch.  That is what lets the matrix-DFT products fill
+// the chip without splitting K across workgroups: 512 x 2048 x 2048 as 512 workgroups of 64 x 32, 512 x 512 x 2048 as 256 of 32 x 32
+// (round 2: K split in 2 / 8 slabs + splitk_reduce_kernel, 6.2 + 5.3 us of config 4's 161).
+// EPI = 1: the epilogue stores w |alpha c|^2 into (or adds it to) a REAL matrix instead of the complex result (the incoherent sum of
+// the polychromatic recipe: focus_dft + intensity + weighted accumulate without the 512^2 complex round trip).
+template <int TI, int TJ, int WM, int WN, int WK, bool AKF, bool BKF, int EPI>
 __global__ void __launch_bounds__(256) cgemm_dma_kernel(int conjA, int conjB, int ntm, int ntn, int64_t K, int64_t ksplit, float alpha,
                                                        const cx<float>* __restrict__ A, int64_t lda, const cx<float>* __restrict__ B,
-                                                       int64_t ldb, cx<float>* __restrict__ C, int64_t ldc, int64_t slab_stride) {
-    constexpr int BK = 16, BM = 64 * TI, BN = 64 * TJ, NBUF = 3;
-    constexpr int ABYTES = BM * 128, BBYTES = BN * 128;
+                                                       int64_t ldb, cx<float>* __restrict__ C, int64_t ldc, int64_t slab_stride,
+                                                       float weight, int accumulate) {
+    static_assert(WM * WN * WK == 4, "four waves");
+    constexpr int BK = 16, BM = 32 * TI * WM, BN = 32 * TJ * WN, NBUF = 3, NWS = WM * WN;
+    constexpr int ABYTES = BM * 128, BBYTES = BN * 128, SGBYTES = NBUF * (ABYTES + BBYTES);
     extern __shared__ __attribute__((aligned(16))) char pm_gemm_smem[];
-    char* const As = pm_gemm_smem;                       // [3] operand images
-    char* const Bs = pm_gemm_smem + NBUF * ABYTES;
 
     // XCD-aware order: workgroups b, b + 8, ... run on one XCD; give each XCD a CONTIGUOUS run of the (slab, n-tile, m-tile)
     // list, m fastest, so the workgroups that share a B slab (and then an A slab) share that XCD's L2
@@ -357,20 +368,27 @@ __global__ void __launch_bounds__(256) cgemm_dma_kernel(int conjA, int conjB, in
     const int slab = l / tiles, rr = l - slab * tiles;
     const int tn = rr / ntm, tm = rr - tn * ntm;
     const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
-    const int64_t kbeg = int64_t(slab) * ksplit;
-    const int64_t kend = (kbeg + ksplit < K) ? kbeg + ksplit : K;
-    const int nkt = int((kend - kbeg) / BK);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int sg = wave / NWS, ws = wave - sg * NWS;       // K-group, wave inside it
+    const int wr = ws / WN, wc = ws - wr * WN;
     const int row = lane & 31, h = lane >> 5;
     const float sa = conjA ? -1.f : 1.f, sb = conjB ? -1.f : 1.f;
+    char* const As = pm_gemm_smem + sg * SGBYTES;           // [3] operand images of this K-group
+    char* const Bs = As + NBUF * ABYTES;
 
-    DmaTile<BM, AKF> dA;
-    DmaTile<BN, BKF> dB;
-    dA.init(lda, wave, lane);
-    dB.init(ldb, wave, lane);
+    // K range of this workgroup's slab, then of this K-group inside it (the host makes both multiples of 16)
+    const int64_t kslab = int64_t(slab) * ksplit;
+    const int64_t kslab_end = (kslab + ksplit < K) ? kslab + ksplit : K;
+    const int64_t kper = (kslab_end - kslab) / WK;
+    const int64_t kbeg = kslab + sg * kper;
+    const int nkt = int(kper / BK);
+
+    DmaTile<BM, AKF, NWS> dA;
+    DmaTile<BN, BKF, NWS> dB;
+    dA.init(lda, ws, lane);
+    dB.init(ldb, ws, lane);
     const char* pa = reinterpret_cast<const char*>(AKF ? A + m0 * lda + kbeg : A + kbeg * lda + m0);
     const char* pb = reinterpret_cast<const char*>(BKF ? B + n0 * ldb + kbeg : B + kbeg * ldb + n0);
     const int64_t stepA = (AKF ? int64_t(BK) : int64_t(BK) * lda) * 8, stepB = (BKF ? int64_t(BK) : int64_t(BK) * ldb) * 8;
@@ -426,14 +444,14 @@ __global__ void __launch_bounds__(256) cgemm_dma_kernel(int conjA, int conjB, in
     //   the DMA of tile t + 2 into buffer (t + 2) % 3 = the buffer of tile t - 1.  Fragments are read one quarter ahead of their
     //   use, the first quarter of tile t + 1 during the last quarter of tile t.
     if (nkt > 0) {
-        dA.issue(pa, As, wave);
-        dB.issue(pb, Bs, wave);
+        dA.issue(pa, As, ws);
+        dB.issue(pb, Bs, ws);
     }
     if (nkt > 1) {
         pa += stepA;
         pb += stepB;
-        dA.issue(pa, As + ABYTES, wave);
-        dB.issue(pb, Bs + BBYTES, wave);
+        dA.issue(pa, As + ABYTES, ws);
+        dB.issue(pb, Bs + BBYTES, ws);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();    // tiles 0 and 1 are in LDS
@@ -481,8 +499,8 @@ __global__ void __launch_bounds__(256) cgemm_dma_kernel(int conjA, int conjB, in
                 if (kt + 2 < nkt) {
                     pa += stepA;
                     pb += stepB;
-                    dA.issue(pa, As + pbuf * ABYTES, wave);
-                    dB.issue(pb, Bs + pbuf * BBYTES, wave);
+                    dA.issue(pa, As + pbuf * ABYTES, ws);
+                    dB.issue(pb, Bs + pbuf * BBYTES, ws);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -490,6 +508,44 @@ __global__ void __launch_bounds__(256) cgemm_dma_kernel(int conjA, int conjB, in
         buf = nbuf;
     }
 
+    if constexpr (WK > 1) {
+        // partial sums of the K-groups meet through LDS (the rings are done with): group g > 0 parks its 48 TI TJ accumulator
+        // registers lane-contiguously, group 0 adds them in the order g = 1, 2, ... and stores
+        float* red = reinterpret_cast<float*>(pm_gemm_smem);
+        constexpr int PER = TI * TJ * 48 * 64;       // floats per wave
+        __syncthreads();
+        if (sg > 0) {
+            float* mine = red + ((sg - 1) * NWS + ws) * PER + lane;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int at = ((i * TJ + j) * 48 + r) * 64;
+                        mine[at] = p1[i][j][r];
+                        mine[at + 16 * 64] = p2[i][j][r];
+                        mine[at + 32 * 64] = p3[i][j][r];
+                    }
+        }
+        __syncthreads();
+        if (sg > 0) return;
+#pragma unroll
+        for (int g = 1; g < WK; ++g) {
+            const float* theirs = red + ((g - 1) * NWS + ws) * PER + lane;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int at = ((i * TJ + j) * 48 + r) * 64;
+                        p1[i][j][r] += theirs[at];
+                        p2[i][j][r] += theirs[at + 16 * 64];
+                        p3[i][j][r] += theirs[at + 32 * 64];
+                    }
+        }
+    }
     // epilogue: Cr = P1 - sa sb P2, Ci = P3 - P1 - sa sb P2; lanes of a row are adjacent columns (256 B runs)
     cx<float>* Cout = C + int64_t(slab) * slab_stride;
     const float ss = sa * sb;
@@ -502,7 +558,14 @@ __global__ void __launch_bounds__(256) cgemm_dma_kernel(int conjA, int conjB, in
                 const int64_t orow = m0 + wr * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int64_t ocol = n0 + wc * 32 * TJ + j * 32 + row;
                 const float q2 = ss * p2[i][j][r];
-                Cout[orow * ldc + ocol] = {(p1[i][j][r] - q2) * alpha, (p3[i][j][r] - p1[i][j][r] - q2) * alpha};
+                const float cr = (p1[i][j][r] - q2) * alpha, ci = (p3[i][j][r] - p1[i][j][r] - q2) * alpha;
+                if constexpr (EPI == 1) {
+                    float* R = reinterpret_cast<float*>(C) + orow * ldc + ocol;
+                    const float i2 = weight * (cr * cr + ci * ci);
+                    *R = accumulate ? *R + i2 : i2;
+                } else {
+                    Cout[orow * ldc + ocol] = {cr, ci};
+                }
             }
 }
 
@@ -521,6 +584,26 @@ __global__ void splitk_reduce_kernel(int64_t M, int64_t N, int S, T alpha, const
     C[r * ldc + c] = {sr * alpha, si * alpha};
 }
 
+// ... with the |.|^2 epilogue of pm_cgemm_abs2: R = (accumulate ? R : 0) + weight |alpha sum|^2
+template <typename T>
+__global__ void splitk_reduce_abs2_kernel(int64_t M, int64_t N, int S, T alpha, const cx<T>* __restrict__ slabs,
+                                          int64_t slab_stride, T* __restrict__ R, int64_t ldr, T weight, int accumulate) {
+    const int64_t g = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (g >= M * N) return;
+    const int64_t r = g / N, c = g % N;
+    T sr = T(0), si = T(0);
+    for (int s = 0; s < S; ++s) {
+        const cx<T> v = slabs[int64_t(s) * slab_stride + g];
+        sr += v.x;
+        si += v.y;
+    }
+    sr *= alpha;
+    si *= alpha;
+    const T i2 = weight * (sr * sr + si * si);
+    T* o = R + r * ldr + c;
+    *o = accumulate ? *o + i2 : i2;
+}
+
 static int gemm_bm(int64_t M, int dtype = PM_C64) {
     if (dtype != PM_C64) return 64;   // rows per workgroup tile: 128 (two MFMA tiles per wave along M) when M allows it
     const int t = tuning().gemm_bm;
@@ -528,25 +611,31 @@ static int gemm_bm(int64_t M, int dtype = PM_C64) {
     return 64;
 }
 
-// plan of the LDS-DMA kernel: tile shape (128 x 128 when that alone fills the chip, else 64 x 64), and the split of K (slabs
-// reduced in a fixed order by splitk_reduce_kernel) only when even the small tiles leave CUs idle
+// plan of the LDS-DMA kernel: workgroup tile and wave arrangement, and the split of K across workgroups (slabs reduced in a fixed
+// order by splitk_reduce_kernel) only when even 32 x 32 tiles leave CUs idle
 struct DmaPlan {
-    int tm, tn;    // workgroup tile: 64 x 64 or 128 x 128 (128 x 64 measured in between: profiles/r02/exp_gemm_shapes.log)
+    int tm, tn;    // workgroup tile: 128 x 128, 64 x 64 (128 x 64 measured in between: profiles/r02/exp_gemm_shapes.log), 64 x 32 or 32 x 32
+    int wk;        // K-groups inside the workgroup (1, 2 with 64 x 32, 4 with 32 x 32)
     int S;
     int64_t ksplit;
 };
 static bool gemm_dma_plan(int64_t M, int64_t N, int64_t K, DmaPlan* out) {
     if (!tuning().gemm_dma || !tuning().gemm_3m || M < 64 || N < 64 || (M % 64) || (N % 64) || K < 16 || (K % 16)) return false;
-    DmaPlan p{64, 64, 1, K};
+    DmaPlan p{64, 64, 1, 1, K};
     const int want = tuning().gemm_dma_wgs;
     const bool m128 = (M % 128) == 0, n128 = (N % 128) == 0;
+    const int64_t t64 = (M / 64) * (N / 64);
     if (m128 && n128 && (M / 128) * (N / 128) >= want) p.tm = p.tn = 128;
+    else if (tuning().gemm_wk && t64 < want && 2 * t64 >= want && (K % 32) == 0) { p.tn = 32; p.wk = 2; }     // 64 x 32, K halves
+    else if (tuning().gemm_wk && 2 * t64 < want && 4 * t64 >= pm_num_cus() && (K % 64) == 0) { p.tm = p.tn = 32; p.wk = 4; }
     const int t = tuning().gemm_tile;
-    if (t == 64) p.tm = p.tn = 64;
-    else if (t == 128 && m128 && n128) p.tm = p.tn = 128;
+    if (t == 64) { p.tm = p.tn = 64; p.wk = 1; }
+    else if (t == 128 && m128 && n128) { p.tm = p.tn = 128; p.wk = 1; }
     const int64_t tiles = (M / p.tm) * (N / p.tn);
-    // split K until the launch fills the 256 CUs, keeping at least 4 K-tiles per slab
-    while (tiles * p.S < want && K / (p.S * 2) >= 64 && ((K / (p.S * 2)) % 16) == 0 && p.S < 64) p.S *= 2;
+    // split K across workgroups until the launch fills the 256 CUs, keeping at least 4 K-tiles per slab (the in-workgroup forms exist
+    // to avoid this: they are only chosen when they fill the chip by themselves)
+    if (p.wk == 1)
+        while (tiles * p.S < want && K / (p.S * 2) >= 64 && ((K / (p.S * 2)) % 16) == 0 && p.S < 64) p.S *= 2;
     p.ksplit = K / p.S;
     if (out) *out = p;
     return true;
@@ -639,18 +728,26 @@ int cgemm_ws_bk(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha,
     return cgemm_ws_bm<T, BK, 64>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
 }
 
-template <int TI, int TJ>
+struct DmaEpi {
+    int kind;          // 0 complex result, 1 real |.|^2 (pm_cgemm_abs2)
+    float weight;
+    int accumulate;
+};
+
+template <int TI, int TJ, int WM, int WN, int WK, int EPI>
 static int cgemm_dma_launch(bool akf, bool bkf, int cA, int cB, int ntm, int ntn, int S, int64_t K, int64_t ksplit, float al,
                             const cx<float>* A, int64_t lda, const cx<float>* B, int64_t ldb, cx<float>* out, int64_t ldo, int64_t slab,
-                            hipStream_t st) {
-    constexpr int LDSB = 3 * (64 * TI + 64 * TJ) * 128;
+                            hipStream_t st, const DmaEpi& ep) {
+    constexpr int RING = 3 * (32 * TI * WM + 32 * TJ * WN) * 128 * WK;
+    constexpr int RED = WK > 1 ? (WK - 1) * WM * WN * TI * TJ * 48 * 64 * 4 : 0;
+    constexpr int LDSB = RING > RED ? RING : RED;
 #define PM_GD(AK, BK_)                                                                                                                \
     {                                                                                                                                 \
-        auto kern = cgemm_dma_kernel<TI, TJ, AK, BK_>;                                                                                \
+        auto kern = cgemm_dma_kernel<TI, TJ, WM, WN, WK, AK, BK_, EPI>;                                                               \
         if (LDSB > 48 * 1024)                                                                                                         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);         \
         hipLaunchKernelGGL(kern, dim3(unsigned(ntm * ntn * S)), dim3(256), LDSB, st, cA, cB, ntm, ntn, K, ksplit, al, A, lda, B, ldb, out, \
-                           ldo, slab);                                                                                                \
+                           ldo, slab, ep.weight, ep.accumulate);                                                                      \
     }
     if (akf && bkf) PM_GD(true, true)
     else if (akf) PM_GD(true, false)
@@ -660,8 +757,10 @@ static int cgemm_dma_launch(bool akf, bool bkf, int cA, int cB, int ntm, int ntn
     return int(hipGetLastError());
 }
 
+// C: the complex result (ep.kind == 0, leading dimension ldc in complex elements) or the REAL image (ep.kind == 1, ldc in real elements)
 static int cgemm_dma_run(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, const cx<float>* A, int64_t lda,
-                         const cx<float>* B, int64_t ldb, cx<float>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, DmaPlan p) {
+                         const cx<float>* B, int64_t ldb, cx<float>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st, DmaPlan p,
+                         DmaEpi ep = DmaEpi{0, 1.f, 0}) {
     if (p.S > 1 && (!ws || ws_bytes < size_t(p.S) * size_t(M) * size_t(N) * 8)) {   // no workspace: unsplit
         p.S = 1;
         p.ksplit = K;
@@ -672,12 +771,25 @@ static int cgemm_dma_run(int opA, int opB, int64_t M, int64_t N, int64_t K, doub
     cx<float>* out = p.S > 1 ? reinterpret_cast<cx<float>*>(ws) : C;
     const int64_t ldo = p.S > 1 ? N : ldc, slab = p.S > 1 ? M * N : 0;
     const float al = p.S > 1 ? 1.f : float(alpha);
-    int rc = p.tm == 128 ? cgemm_dma_launch<2, 2>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st)
-                         : cgemm_dma_launch<1, 1>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st);
+    const DmaEpi none{0, 1.f, 0};
+    int rc;
+#define PM_RUN(TI, TJ, WM, WN, WK)                                                                                                            \
+    rc = (ep.kind == 1 && p.S == 1)                                                                                                           \
+             ? cgemm_dma_launch<TI, TJ, WM, WN, WK, 1>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st, ep) \
+             : cgemm_dma_launch<TI, TJ, WM, WN, WK, 0>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st, none)
+    if (p.tm == 128) PM_RUN(2, 2, 2, 2, 1);
+    else if (p.wk == 2) PM_RUN(1, 1, 2, 1, 2);
+    else if (p.wk == 4) PM_RUN(1, 1, 1, 1, 4);
+    else PM_RUN(1, 1, 2, 2, 1);
+#undef PM_RUN
     if (rc || p.S == 1) return rc;
     const int64_t total = M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, p.S, float(alpha),
-                       reinterpret_cast<const cx<float>*>(ws), M * N, C, ldc);
+    if (ep.kind == 1)
+        hipLaunchKernelGGL(splitk_reduce_abs2_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, p.S, float(alpha),
+                           reinterpret_cast<const cx<float>*>(ws), M * N, reinterpret_cast<float*>(C), ldc, ep.weight, ep.accumulate);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, p.S, float(alpha),
+                           reinterpret_cast<const cx<float>*>(ws), M * N, C, ldc);
     return int(hipGetLastError());
 }
 
@@ -727,6 +839,25 @@ int pm_cgemm(int32_t dtype, int32_t opA, int32_t opB, int64_t M, int64_t N, int6
         return cgemm_ws<double>(opA, opB, M, N, K, alpha, (const cx<double>*)A, lda, (const cx<double>*)B, ldb, (cx<double>*)C,
                                 ldc, workspace, workspace_bytes, st);
     return fail(PM_ERR_ARG, "pm_cgemm: dtype must be PM_C64 or PM_C128");
+}
+
+int pm_cgemm_abs2(int32_t dtype, int32_t opA, int32_t opB, int64_t M, int64_t N, int64_t K, double alpha, const void* A,
+                  int64_t lda, const void* B, int64_t ldb, void* R, int64_t ldr, double weight, int32_t accumulate, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+    if (!A || !B || !R) return fail(PM_ERR_ARG, "pm_cgemm_abs2: null buffer");
+    if (M < 0 || N < 0 || K < 0 || opA < 0 || opA > 3 || opB < 0 || opB > 3) return fail(PM_ERR_ARG, "pm_cgemm_abs2: bad argument");
+    if (M == 0 || N == 0) return 0;
+    if (dtype != PM_C64 && dtype != PM_C128) return fail(PM_ERR_ARG, "pm_cgemm_abs2: dtype must be PM_C64 or PM_C128");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    DmaPlan dp;
+    const cx<float>* a = reinterpret_cast<const cx<float>*>(A);
+    const cx<float>* b = reinterpret_cast<const cx<float>*>(B);
+    if (dtype == PM_C64 && lda < (int64_t(1) << 22) && ldb < (int64_t(1) << 22) && gemm_dma_plan(M, N, K, &dp) && (lda % 2) == 0 &&
+        (ldb % 2) == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0)
+        return cgemm_dma_run(opA, opB, M, N, K, alpha, a, lda, b, ldb, reinterpret_cast<cx<float>*>(R), ldr, workspace, workspace_bytes, st, dp,
+                             DmaEpi{1, float(weight), accumulate ? 1 : 0});
+    return fail(PM_ERR_UNSUPPORTED, "pm_cgemm_abs2: only the LDS-DMA shapes (complex64, multiples of 64 x 64 x 16, aligned operands); "
+                                    "compose pm_cgemm and pm_abs2");
 }
 
 }  // extern "C"

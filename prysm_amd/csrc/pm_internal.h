@@ -98,6 +98,8 @@ struct Tuning {
     int gemm_dma_wgs = 512;   // ... 128 x 128 tiles when there are at least this many, else 64 x 64 (two or three workgroups per CU hide each
                               // other's barriers); K is split until the launch has this many workgroups.  Measured (profiles/r02/exp_gemm_shapes.log):
                               // config 4 pair 148.5 us at 512 with 64 x 64 tiles against 155.5 (128 x 128, 256) and 164.1 (64 x 64, 256)
+    int gemm_wk = 1;          // ... 64 x 32 / 32 x 32 tiles with K split over the wave groups INSIDE the workgroup when that fills the chip without
+                              // slabs (cgemm.hip gemm_dma_plan); 0: round 2's forms only
     int gemm_tile = 0;        // force its tile edge (64 / 128); 0 = auto
     int gemm_bm = 64;         // rows of the GEMM workgroup tile (64 or 128)
     int gemm_bk = 0;          // 0 default K-tile depth, 32 doubles it

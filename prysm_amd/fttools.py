@@ -216,6 +216,24 @@ class MDFT:
         out = _ops.cgemm(Ey, a, 0, 0)
         return _ops.cgemm(out, Ex, 0, 2, alpha=self.norm)
 
+    def intensity(self, ary, out=None, weight=1.0):
+        """weight * |self(ary)|^2 as a real image, added to `out` when given: focus_dft + Wavefront.intensity
+        (prysm/propagation/wavefront.py:146-151) + the weighted accumulate of the polychromatic recipe, with the modulus in the
+        epilogue of the second product (pm_cgemm_abs2) -- the complex focal field is not written.  Falls back to the composed form
+        for shapes / precisions that kernel does not take."""
+        a, Ex, Ey = self._cast(ary)
+        if not self._forward_left_first:
+            res = _ops.cgemm_abs2(Ey, _ops.cgemm(a, Ex, 0, 2), 0, 0, alpha=self.norm, out=out, weight=weight)
+        else:
+            res = _ops.cgemm_abs2(_ops.cgemm(Ey, a, 0, 0), Ex, 0, 2, alpha=self.norm, out=out, weight=weight)
+        if res is not None:
+            return res
+        E = self(ary)
+        if out is None:
+            I = _ops.abs2(E)
+            return I if weight == 1.0 else I * weight
+        return _ops.abs2(E, out=out, weight=weight)
+
     def adjoint(self, grad):
         """Apply the conjugate transpose (prysm/fttools.py:209-228): norm * Ey^H @ grad @ conj(Ex)."""
         g, Ex, Ey = self._cast(grad)

@@ -157,3 +157,85 @@ def test_intensity_adjoint_one_sweep(pa, dtype, rdtype, tol):
     ib64 = rng.random((16, 16))                      # float64 gradient on a complex64 field: numpy promotes, so do we
     got = tonp(P.Wavefront(E, 0.6328, 1.0, space='psf').intensity_adjoint(ib64))
     assert rel_max(got, 2 * ib64 * E.astype(np.complex128)) < 1e-6
+
+
+# ----------------------------------------------------------------------------- GEMM: K split inside the workgroup, |.|^2 epilogue
+
+def _op_np(a, op):
+    if op & 1:
+        a = np.conj(a)
+    if op & 2:
+        a = a.T
+    return a
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 2048, 64), (1024, 1024, 96), (512, 512, 64), (512, 1024, 192), (768, 1024, 128),
+                                   (512, 512, 2048), (512, 2048, 2048)])
+def test_cgemm_in_workgroup_k_split_all_ops(pa, M, N, K):
+    """the 64 x 32 (two K-groups) and 32 x 32 (four K-groups) forms of the LDS-DMA kernel -- what the matrix-DFT products of
+    config 4 now run on -- for every transposed / conjugated operand storage, against numpy in fp64; gemm_wk = 0 (round 2's
+    split-K slabs) must agree to rounding"""
+    from prysm_amd import _lib, _ops
+    lib = _lib.load()
+    rng = np.random.default_rng(M + N + K)
+    ops = [(0, 0), (3, 1), (0, 2), (2, 3)] if K >= 1024 else [(a, b) for a in range(4) for b in range(4)]
+    for opA, opB in ops:
+        A = crandn(rng, (K, M) if opA & 2 else (M, K), np.complex64)
+        B = crandn(rng, (N, K) if opB & 2 else (K, N), np.complex64)
+        ref = _op_np(A.astype(np.complex128), opA) @ _op_np(B.astype(np.complex128), opB)
+        At, Bt = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        got = tonp(_ops.cgemm(At, Bt, opA, opB, alpha=0.5))
+        assert rel_max(got, 0.5 * ref) < TOL32_MDFT, (opA, opB)
+        lib.pm_set_tuning(b'gemm_wk', 0)
+        try:
+            old = tonp(_ops.cgemm(At, Bt, opA, opB, alpha=0.5))
+        finally:
+            lib.pm_set_tuning(b'gemm_wk', 1)
+        assert rel_max(got, old) < 1e-5, (opA, opB)
+        # bitwise reproducible: the K-groups are summed in a fixed order
+        assert np.array_equal(got, tonp(_ops.cgemm(At, Bt, opA, opB, alpha=0.5)))
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 512, 256), (512, 2048, 128), (2048, 2048, 64), (256, 256, 512), (128, 64, 1024)])
+def test_cgemm_abs2_epilogue(pa, M, N, K):
+    """pm_cgemm_abs2: weight |alpha A @ B^T|^2 stored / accumulated as a real image (in-kernel epilogue for the unsplit plans, the
+    slab reduce's epilogue when K is split across workgroups) against numpy"""
+    from prysm_amd import _ops
+    rng = np.random.default_rng(M * 3 + N + K)
+    A = crandn(rng, (M, K), np.complex64)
+    B = crandn(rng, (N, K), np.complex64)
+    ref = np.abs(0.25 * (A.astype(np.complex128) @ B.astype(np.complex128).T)) ** 2
+    At, Bt = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    I = _ops.cgemm_abs2(At, Bt, 0, 2, alpha=0.25)
+    assert I is not None and I.dtype == torch.float32
+    assert rel_max(tonp(I), ref) < 2 * TOL32_MDFT
+    base = torch.from_numpy(rng.random((M, N)).astype(np.float32)).cuda()
+    want = tonp(base).astype(np.float64) + 1.5 * ref
+    out = _ops.cgemm_abs2(At, Bt, 0, 2, alpha=0.25, out=base, weight=1.5)
+    assert out is base and rel_max(tonp(base), want) < 2 * TOL32_MDFT
+    assert _ops.cgemm_abs2(At[:, :K - 3].contiguous(), Bt[:, :K - 3].contiguous(), 0, 2) is None     # ragged K: not this kernel's
+
+
+def test_mdft_intensity_matches_composed(pa):
+    """MDFT.intensity (focus_dft + intensity + weighted accumulate, modulus in the second product's epilogue) on config 4's grid
+    against the fp64 oracle, and its fallback for complex128 bases"""
+    P = pa.propagation
+    rng = np.random.default_rng(2048512)
+    x = crandn(rng, (2048, 2048), np.complex64)
+    pdx, efl, wvl = 10 / 2048, 100.0, O.HeNe
+    fdx = wvl * 10 / 8
+    ref = O.intensity(O.prepare_executor(pdx, (2048, 2048), fdx, (512, 512), wvl, efl)(x.astype(np.complex128)))
+    prec = pa.config.precision
+    pa.config.precision = 32
+    try:
+        ex = P.prepare_executor(pdx, (2048, 2048), fdx, (512, 512), wvl, efl)
+        I = ex.intensity(x)
+        assert I.dtype == torch.float32 and rel_max(tonp(I), ref) < 2 * TOL32_MDFT
+        acc = torch.zeros((512, 512), device='cuda')
+        ex.intensity(x, out=acc, weight=0.5)
+        ex.intensity(x, out=acc, weight=0.25)
+        assert rel_max(tonp(acc), 0.75 * ref) < 2 * TOL32_MDFT
+    finally:
+        pa.config.precision = prec
+    ex64 = P.prepare_executor(pdx, (2048, 2048), fdx, (512, 512), wvl, efl)
+    assert rel_max(tonp(ex64.intensity(x.astype(np.complex128), weight=2.0)), 2.0 * ref) < TOL64
