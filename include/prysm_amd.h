@@ -244,6 +244,11 @@ int pm_scale_sep(int32_t dtype, int64_t rows, int64_t cols, const void* in, int6
 int pm_abs2(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t in_ld, void* out, int64_t out_ld,
             int32_t accumulate, double weight, void* stream);
 
+/* out_abs = |in|, out_arg = atan2(im, re) of a complex array in ONE sweep (either output may be NULL): the MTF and PTF of
+ * otf.mtf_ptf_otf_from_psf (prysm/otf.py:167-203) from the centre-normalised OTF the transform already produced. */
+int pm_abs_arg(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t in_ld, void* out_abs, int64_t abs_ld, void* out_arg,
+               int64_t arg_ld, void* stream);
+
 /* out = sum_b weights[b] * modes[b] (accumulate = 0) or out += ...; REAL images of the precision that goes with
  * dtype (PM_C64: float, PM_C128: double), modes[b] at modes + b*mode_stride elements; weights is a HOST array.
  * polynomials.sum_of_2d_modes = tensordot(weights, modes, axes=(0, 0)) (prysm/polynomials/fitting.py:7-37), the

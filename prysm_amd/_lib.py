@@ -68,6 +68,7 @@ SIGNATURES = {
     'pm_rmul': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_f64, c_vp, c_i64, c_vp]),
     'pm_scale_sep': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_f64, c_vp, c_i64, c_vp]),
     'pm_abs2': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_f64, c_vp]),
+    'pm_abs_arg': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'pm_sum_modes': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, ctypes.POINTER(c_f64), c_i32, c_vp, c_i64, c_vp]),
     'pm_encircled_energy_workspace': (c_sz, []),
     'pm_encircled_energy': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_f64, c_i64, ctypes.POINTER(c_f64), c_vp, c_vp, c_sz, c_vp]),

@@ -231,7 +231,7 @@ def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_
     keep = [x]
     _fill_mul(d, x, mul, mul_x, mul_conj, keep)
     oshape = (om, on) if x.dim() == 2 else (x.shape[0], om, on)
-    if real_out and not x.is_complex() and x.dim() == 2 and mul_x is None:
+    if real_out and not x.is_complex() and x.dim() == 2 and mul_x is None and x.data_ptr() % (2 * x.element_size()) == 0:
         # the half-spectrum chain: the workspace query answers whether this descriptor is one it takes
         d.flags |= L.PM_FLAG_REAL_OUTPUT
         out = torch.empty(oshape, dtype=L._REAL_OF[L.cdtype_of(x)], device=x.device)
@@ -348,6 +348,18 @@ def abs2(x, out=None, weight=None):
     L.check(lib.pm_abs2(L.code(x), rows, cols, L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), acc,
                         float(1.0 if weight is None else weight), L.stream_ptr()))
     return out
+
+
+def abs_arg(x):
+    """(|x|, angle(x)) of a complex 2-D array in one sweep (pm_abs_arg)."""
+    lib = L.load()
+    rows, cols = x.shape
+    rd = L._REAL_OF[x.dtype]
+    oabs = torch.empty((rows, cols), dtype=rd, device=x.device)
+    oarg = torch.empty((rows, cols), dtype=rd, device=x.device)
+    L.check(lib.pm_abs_arg(L.code(x), rows, cols, L.ptr(x), x.stride(0), L.ptr(oabs), oabs.stride(0), L.ptr(oarg), oarg.stride(0),
+                           L.stream_ptr()))
+    return oabs, oarg
 
 
 def sum_modes(modes, weights, out=None, accumulate=False):

@@ -119,7 +119,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("gemm_dma_wgs")) t.gemm_dma_wgs = v < 1 ? 1 : v;
     else if (is("gemm_tile")) t.gemm_tile = (v == 64 || v == 128) ? v : 0;
     else if (is("gemm_3m")) t.gemm_3m = v ? 1 : 0;
-    else if (is("gemm_wk")) t.gemm_wk = v ? 1 : 0;
+    else if (is("gemm_wk")) t.gemm_wk = v & 7;
     else if (is("gemm_min_wgs")) t.gemm_min_wgs = v < 1 ? 1 : v;
     else if (is("nt_in")) t.nt_in = v;
     else if (is("nt_out")) t.nt_out = v;
@@ -251,7 +251,7 @@ static int64_t batch_chunk(int64_t nb, size_t ws_field) {
     return c < nb ? c : nb;
 }
 
-static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
+static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
     Fft2Plan p;
     const int64_t M = d->in_y.n, N = d->in_x.n;
     p.logn = engine_log2(N);
@@ -259,7 +259,7 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d) {
     const size_t es = d->dtype == PM_C64 ? 8 : 16;
     const int64_t rows = d->in_y.len;   // only stored input rows are transformed in pass 1
     p.fold = false;
-    p.r2c = p.logn >= 0 && p.logm >= 0 && r2c_legal(d, p.logn, p.logm);
+    p.r2c = allow_r2c && p.logn >= 0 && p.logm >= 0 && r2c_legal(d, p.logn, p.logm);
     if (p.r2c) {
         p.col_var = 0;
         p.tc = col_tile_width_for(d->dtype, p.logm, 0);
@@ -1285,14 +1285,20 @@ void pm_shutdown(void) {
 
 size_t pm_fft2_workspace(const pm_fft2_desc* d) {
     if (check_fft2(d)) return 0;
-    return plan_fft2(d).ws_bytes;
+    const Fft2Plan p = plan_fft2(d);
+    if (!p.r2c) return p.ws_bytes;
+    // the Hermitian path reads the real array as complex pairs: a base address that is not aligned like a complex element sends the
+    // call down the complex path instead (pm_fft2 below), whose intermediate is larger -- the query covers both
+    const size_t other = plan_fft2(d, false).ws_bytes;
+    return other > p.ws_bytes ? other : p.ws_bytes;
 }
 
 int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_fft2(d);
     if (rc) return rc;
     if (!in || !out) return fail(PM_ERR_ARG, "pm_fft2: null buffer");
-    const Fft2Plan p = plan_fft2(d);
+    Fft2Plan p = plan_fft2(d);
+    if (p.r2c && reinterpret_cast<uintptr_t>(in) % (d->dtype == PM_C64 ? 8 : 16) != 0) p = plan_fft2(d, false);
     if (!workspace || workspace_bytes < p.ws_bytes)
         return fail(PM_ERR_WORKSPACE, "pm_fft2: workspace of %zu bytes required, %zu given", p.ws_bytes, workspace_bytes);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1371,6 +1377,9 @@ int pm_fft2_mul_ifft2(const pm_fft2_desc* d, const void* in, void* out, void* wo
             return fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: PM_FLAG_REAL_OUTPUT needs a real unpadded power-of-two field (rows of 64 .. 8192 "
                         "samples), a full multiplier, x rotations by 0 or N/2 and an unwindowed output; take the real part of the complex "
                         "chain instead");
+        if (reinterpret_cast<uintptr_t>(in) % (d->dtype == PM_C64 ? 8 : 16) != 0 || reinterpret_cast<uintptr_t>(out) % (d->dtype == PM_C64 ? 8 : 16) != 0)
+            return fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: PM_FLAG_REAL_OUTPUT reads and writes the real arrays as pairs; their base "
+                        "addresses must be aligned like a complex element (take the real part of the complex chain instead)");
         if (!workspace || workspace_bytes < hp.ws_bytes)
             return fail(PM_ERR_WORKSPACE, "pm_fft2_mul_ifft2: workspace of %zu bytes required, %zu given", hp.ws_bytes, workspace_bytes);
         hipStream_t hst = reinterpret_cast<hipStream_t>(stream);

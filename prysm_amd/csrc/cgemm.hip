@@ -341,7 +341,9 @@ struct DmaTile {
 //   (2, 2) tiles, 2 x 2 x 1: 128 x 128, one workgroup per CU (192 accumulator registers per lane), the large-GEMM shape;
 //   (1, 1) tiles, 2 x 2 x 1:  64 x 64;
 //   (1, 1) tiles, 2 x 1 x 2:  64 x 32, the two wave PAIRS each take half of the K range;
-//   (1, 1) tiles, 1 x 1 x 4:  32 x 32, every wave a quarter of the K range.
+//   (1, 1) tiles, 1 x 1 x 4:  32 x 32, every wave a quarter of the K range;
+//   (1, 1) tiles, 2 x 2 x 2:  64 x 64 with EIGHT waves -- two K-groups that are each the plain 64 x 64 arrangement (same staging cost
+//                             per wave), one workgroup per CU.
 // WK > 1 is split-K INSIDE the workgroup: each K-group has its own three-deep LDS ring (A rows 32 TI WM, B rows 32 TJ WN), the groups
 // walk their K ranges in lockstep (same barriers) and their partial sums meet through LDS at the end, added in K order -- fixed
 // order, bitwise reproducible, no slab round trip through HBM and no second launch.  That is what lets the matrix-DFT products fill
@@ -350,11 +352,11 @@ struct DmaTile {
 // EPI = 1: the epilogue stores w |alpha c|^2 into (or adds it to) a REAL matrix instead of the complex result (the incoherent sum of
 // the polychromatic recipe: focus_dft + intensity + weighted accumulate without the 512^2 complex round trip).
 template <int TI, int TJ, int WM, int WN, int WK, bool AKF, bool BKF, int EPI>
-__global__ void __launch_bounds__(256) cgemm_dma_kernel(int conjA, int conjB, int ntm, int ntn, int64_t K, int64_t ksplit, float alpha,
+__global__ void __launch_bounds__(64 * WM * WN * WK) cgemm_dma_kernel(int conjA, int conjB, int ntm, int ntn, int64_t K, int64_t ksplit, float alpha,
                                                        const cx<float>* __restrict__ A, int64_t lda, const cx<float>* __restrict__ B,
                                                        int64_t ldb, cx<float>* __restrict__ C, int64_t ldc, int64_t slab_stride,
                                                        float weight, int accumulate) {
-    static_assert(WM * WN * WK == 4, "four waves");
+    static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "four waves, or eight: two K-groups of the 2 x 2 arrangement");
     constexpr int BK = 16, BM = 32 * TI * WM, BN = 32 * TJ * WN, NBUF = 3, NWS = WM * WN;
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, SGBYTES = NBUF * (ABYTES + BBYTES);
     extern __shared__ __attribute__((aligned(16))) char pm_gemm_smem[];
@@ -625,9 +627,11 @@ static bool gemm_dma_plan(int64_t M, int64_t N, int64_t K, DmaPlan* out) {
     const int want = tuning().gemm_dma_wgs;
     const bool m128 = (M % 128) == 0, n128 = (N % 128) == 0;
     const int64_t t64 = (M / 64) * (N / 64);
+    const int wkm = tuning().gemm_wk;     // bit 0: 64 x 64 with two K-groups (8 waves), bit 1: 64 x 32 with two, bit 2: 32 x 32 with four
     if (m128 && n128 && (M / 128) * (N / 128) >= want) p.tm = p.tn = 128;
-    else if (tuning().gemm_wk && t64 < want && 2 * t64 >= want && (K % 32) == 0) { p.tn = 32; p.wk = 2; }     // 64 x 32, K halves
-    else if (tuning().gemm_wk && 2 * t64 < want && 4 * t64 >= pm_num_cus() && (K % 64) == 0) { p.tm = p.tn = 32; p.wk = 4; }
+    else if ((wkm & 1) && t64 < want && 2 * t64 >= want && (K % 32) == 0) p.wk = 2;                                  // 64 x 64, K halves
+    else if ((wkm & 2) && t64 < want && 2 * t64 >= want && (K % 32) == 0) { p.tn = 32; p.wk = 2; }                   // 64 x 32, K halves
+    else if ((wkm & 4) && 2 * t64 < want && 4 * t64 >= pm_num_cus() && (K % 64) == 0) { p.tm = p.tn = 32; p.wk = 4; }
     const int t = tuning().gemm_tile;
     if (t == 64) { p.tm = p.tn = 64; p.wk = 1; }
     else if (t == 128 && m128 && n128) { p.tm = p.tn = 128; p.wk = 1; }
@@ -746,7 +750,7 @@ static int cgemm_dma_launch(bool akf, bool bkf, int cA, int cB, int ntm, int ntn
         auto kern = cgemm_dma_kernel<TI, TJ, WM, WN, WK, AK, BK_, EPI>;                                                               \
         if (LDSB > 48 * 1024)                                                                                                         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);         \
-        hipLaunchKernelGGL(kern, dim3(unsigned(ntm * ntn * S)), dim3(256), LDSB, st, cA, cB, ntm, ntn, K, ksplit, al, A, lda, B, ldb, out, \
+        hipLaunchKernelGGL(kern, dim3(unsigned(ntm * ntn * S)), dim3(64 * WM * WN * WK), LDSB, st, cA, cB, ntm, ntn, K, ksplit, al, A, lda, B, ldb, out, \
                            ldo, slab, ep.weight, ep.accumulate);                                                                      \
     }
     if (akf && bkf) PM_GD(true, true)
@@ -778,6 +782,7 @@ static int cgemm_dma_run(int opA, int opB, int64_t M, int64_t N, int64_t K, doub
              ? cgemm_dma_launch<TI, TJ, WM, WN, WK, 1>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st, ep) \
              : cgemm_dma_launch<TI, TJ, WM, WN, WK, 0>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st, none)
     if (p.tm == 128) PM_RUN(2, 2, 2, 2, 1);
+    else if (p.wk == 2 && p.tn == 64) PM_RUN(1, 1, 2, 2, 2);
     else if (p.wk == 2) PM_RUN(1, 1, 2, 1, 2);
     else if (p.wk == 4) PM_RUN(1, 1, 1, 1, 4);
     else PM_RUN(1, 1, 2, 2, 1);

@@ -98,8 +98,8 @@ struct Tuning {
     int gemm_dma_wgs = 512;   // ... 128 x 128 tiles when there are at least this many, else 64 x 64 (two or three workgroups per CU hide each
                               // other's barriers); K is split until the launch has this many workgroups.  Measured (profiles/r02/exp_gemm_shapes.log):
                               // config 4 pair 148.5 us at 512 with 64 x 64 tiles against 155.5 (128 x 128, 256) and 164.1 (64 x 64, 256)
-    int gemm_wk = 1;          // ... 64 x 32 / 32 x 32 tiles with K split over the wave groups INSIDE the workgroup when that fills the chip without
-                              // slabs (cgemm.hip gemm_dma_plan); 0: round 2's forms only
+    int gemm_wk = 5;          // ... K split over wave groups INSIDE the workgroup when that fills the chip without slabs (cgemm.hip gemm_dma_plan):
+                              // bit 0 64 x 64 tiles with two K-groups (8 waves), bit 1 64 x 32 with two, bit 2 32 x 32 with four; 0: round 2's forms only
     int gemm_tile = 0;        // force its tile edge (64 / 128); 0 = auto
     int gemm_bm = 64;         // rows of the GEMM workgroup tile (64 or 128)
     int gemm_bk = 0;          // 0 default K-tile depth, 32 doubles it
@@ -122,8 +122,11 @@ struct Tuning {
     int spectral = 8;         // pm_fft2_spectral: wavelengths per launch pair (fft_spectral.h; <= 8); 1: the plain loop of pm_fft2 calls
     int spectral_area_log = 24;   // ... for transforms of fewer than 2^this bins (capi.hip spectral_fast has the measurements)
     int spectral_mode = 3;    // ... bit 0: its row pass keeps the packed map in registers, bit 1: its column pass accumulates in registers
-    int colmul_mode = 0;      // middle pass of the fused chain at 2048-point column tiles (fft_kernels.h launch_col_mul_one): 0 one tile per
-                              // workgroup, 1 the same under a 128-VGPR cap (two workgroups per CU), 2 persistent prefetching workgroups
+    int colmul_mode = 2;      // middle pass of the fused chain at 2048-point column tiles (fft_kernels.h launch_col_mul_one): 0 one tile per
+                              // workgroup, 1 the same under a 128-VGPR cap (two workgroups per CU), 2 persistent prefetching workgroups where
+                              // the pass qualifies (whole unrotated tiles, separable multiplier).  Measured (profiles/r03/exp_colmul.log, us, modes
+                              // 0 / 1 / 2): middle pass of config 3 159.1 / 198.1 / 135.7; chain 4096^2 complex128 391 / 430 / 378, complex64
+                              // 190 / 176 / 178, 2048^2 complex128 90.5 / 93.9 / 87.1
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)
 };

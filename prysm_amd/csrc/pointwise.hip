@@ -57,6 +57,18 @@ __global__ void rmul_kernel(int64_t rows, int64_t cols, const T* r_, int64_t ldr
         o[r * ldo + c] = cscale(a[r * lda + c], scale * r_[r * ldr + c]);
 }
 
+// ---------------------------------------------------------------- modulus and phase of one complex array in one sweep
+template <typename T>
+__global__ void abs_arg_kernel(int64_t rows, int64_t cols, const cx<T>* in, int64_t ldi, T* oabs, int64_t lda, T* oarg, int64_t ldg) {
+    const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    for (int64_t r = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; r < rows; r += int64_t(gridDim.y) * blockDim.y) {
+        const cx<T> z = in[r * ldi + c];
+        if (oabs) oabs[r * lda + c] = sqrt(z.x * z.x + z.y * z.y);
+        if (oarg) oarg[r * ldg + c] = atan2(z.y, z.x);
+    }
+}
+
 // ---------------------------------------------------------------- separable scale
 template <typename T>
 __global__ void scale_sep_kernel(int64_t rows, int64_t cols, const cx<T>* in, int64_t ldi, const cx<T>* ry, int ryc,
@@ -515,6 +527,23 @@ int pm_abs2(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t i
             hipLaunchKernelGGL((abs2_kernel<double, 0>), grid, block, 0, st, rows, cols, (const cx<double>*)in, in_ld, (double*)out, out_ld, 1.0);
     } else
         return fail(PM_ERR_ARG, "pm_abs2: dtype must be PM_C64 or PM_C128");
+    return int(hipGetLastError());
+}
+
+int pm_abs_arg(int32_t dtype, int64_t rows, int64_t cols, const void* in, int64_t in_ld, void* out_abs, int64_t abs_ld, void* out_arg,
+               int64_t arg_ld, void* stream) {
+    if (!in || (!out_abs && !out_arg) || rows < 0 || cols < 0) return fail(PM_ERR_ARG, "pm_abs_arg: bad argument");
+    if (rows == 0 || cols == 0) return 0;
+    dim3 block;
+    dim3 grid = grid2d(rows, cols, block);
+    if (dtype == PM_C64)
+        hipLaunchKernelGGL(abs_arg_kernel<float>, grid, block, 0, PM_STREAM(stream), rows, cols, (const cx<float>*)in, in_ld, (float*)out_abs,
+                           abs_ld, (float*)out_arg, arg_ld);
+    else if (dtype == PM_C128)
+        hipLaunchKernelGGL(abs_arg_kernel<double>, grid, block, 0, PM_STREAM(stream), rows, cols, (const cx<double>*)in, in_ld,
+                           (double*)out_abs, abs_ld, (double*)out_arg, arg_ld);
+    else
+        return fail(PM_ERR_ARG, "pm_abs_arg: dtype must be PM_C64 or PM_C128");
     return int(hipGetLastError());
 }
 

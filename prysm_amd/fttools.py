@@ -14,7 +14,7 @@ from .conf import config
 
 
 def _rdtype():
-    return L.torch_dtype(config.precision)
+    return L.torch_dtype(config.compute_precision)
 
 
 def _cdtype():
@@ -37,6 +37,11 @@ def next_fast_len(n):
     Fast lengths here are what the device transforms without Bluestein's detour: powers of two up to 32768, and from 96 the
     mixed-radix lengths 3 / 5 / 7 x 2^k with 2^k <= 8192 (one radix-3 / 5 / 7 step around engine transforms, csrc/bigfft.hip),
     e.g. 2560 for 2559 where a power of two gives 4096.
+
+    Trade-off (these are not scipy's values, which also admit 2^a 3^b 5^c ... lengths): an array padded to a mixed-radix length
+    transforms ~3x faster than through Bluestein but leaves the paths that need engine powers of two -- the fused
+    fft2 -> multiply -> ifft2 chain, pupil synthesis inside the row load, the Hermitian real-input path, grouped wavelengths --
+    for the composed / radix-R routes.  Callers that want those paths pad to a power of two (``1 << ceil(log2(n))``).
     """
     n = int(n)
     best = _next_power_of_2(n)
@@ -56,7 +61,7 @@ def _czt_len(n):
 
 def fftfreq(n, d=1.0):
     """FFT frequency vector in config.precision (prysm/fttools.py:34-40)."""
-    out = truenp.fft.fftfreq(n, d).astype(config.precision)
+    out = truenp.fft.fftfreq(n, d).astype(config.compute_precision)
     return L.as_device(out)
 
 
@@ -107,16 +112,23 @@ def _pad_stat(a, widths, mode):
             pre = first * kb.to(rd)                       # end value 0 -> edge, outermost sample first
             post = last * (1 - ka).to(rd)                 # edge -> end value 0
             out = torch.cat((pre, work, post), dim=axis)
-            a = out if work is a else out.to(a.dtype)     # integer arrays: numpy rounds the ramp back as well
+            a = out if work is a else torch.round(out).to(a.dtype)     # integer arrays: numpy rounds the ramp (half to even), it does not truncate
             continue
         if mode == 'mean':
-            stat = a.to(torch.float64 if not (a.is_floating_point() or a.is_complex()) else a.dtype).mean(dim=axis, keepdim=True).to(a.dtype)
+            if a.is_floating_point() or a.is_complex():
+                stat = a.mean(dim=axis, keepdim=True)
+            else:       # integer arrays: np.pad rounds the statistic (half to even) before casting back
+                stat = torch.round(a.to(torch.float64).mean(dim=axis, keepdim=True)).to(a.dtype)
         elif mode == 'maximum':
             stat = a.amax(dim=axis, keepdim=True)
         elif mode == 'minimum':
             stat = a.amin(dim=axis, keepdim=True)
         else:
-            stat = torch.quantile(a.to(torch.float64), 0.5, dim=axis, keepdim=True).to(a.dtype)
+            # median = mean of the two middle order statistics (torch.quantile refuses arrays beyond ~16M elements: 4096^2)
+            srt = torch.sort(a.to(torch.float64), dim=axis).values
+            n = a.shape[axis]
+            mid = (srt.narrow(axis, (n - 1) // 2, 1) + srt.narrow(axis, n // 2, 1)) * 0.5
+            stat = (mid if a.is_floating_point() else torch.round(mid)).to(a.dtype)
         reps = [1, 1]
         reps[axis] = before
         pre = stat.repeat(reps)
@@ -558,9 +570,9 @@ def fourier_resample(f, zoom):
         raise ValueError('zoom produces an empty output')
     sh = (m // 2, n // 2)
     F = _ops.fft2(x, direction=-1, scale=1.0, in_shift=sh, out_shift=sh)
-    xx = fftrange(n, dtype=config.precision)
-    yy = fftrange(m, dtype=config.precision)
-    fx = fftrange(N, dtype=config.precision) * (1.0 / zoom[1] / n)
-    fy = fftrange(M, dtype=config.precision) * (1.0 / zoom[0] / m)
+    xx = fftrange(n, dtype=config.compute_precision)
+    yy = fftrange(m, dtype=config.compute_precision)
+    fx = fftrange(N, dtype=config.compute_precision) * (1.0 / zoom[1] / n)
+    fy = fftrange(M, dtype=config.compute_precision) * (1.0 / zoom[0] / m)
     fprime = MDFT(xx, yy, fx, fy, sign=+1, norm=1.0 / (m * n))(F)
     return fprime.real if real else fprime

@@ -60,12 +60,31 @@ def _fused_from_psf(psf, dx, epilogue):
     if x.is_complex() or x.dim() != 2:
         return None
     M, N = x.shape
+    if not _hermitian_ok(x):
+        return None
     shift = (M // 2, N // 2)
     try:
         data = _ops.fft2(x, direction=-1, scale=1.0, in_shift=shift, out_shift=shift, epilogue=epilogue, flags=L.PM_FLAG_NORM_DC)
-    except NotImplementedError:
+    except NotImplementedError:      # the predicate above mirrors the library's (capi.hip r2c_legal); kept as the backstop
         return None
     return data, 1000 / (M * dx)
+
+
+def _hermitian_ok(x):
+    """Cheap mirror of the library's test for its Hermitian path (capi.hip r2c_legal): a real float32 / float64 2-D array, both
+    lengths powers of two from 32 that one workgroup transforms (rows of at most 8192 samples, 4096 for float64), even leading
+    dimension, base address aligned like a complex element.  Asked BEFORE building a descriptor: an ineligible PSF (1000^2, a
+    sliced view ...) used to pay a failed library call and an exception on every MTF / PTF / OTF call."""
+    if x.is_complex() or x.dim() != 2 or x.dtype not in (torch.float32, torch.float64):
+        return False
+    M, N = x.shape
+
+    def pow2(n):
+        return n >= 32 and (n & (n - 1)) == 0
+
+    nmax = 8192 if x.dtype == torch.float32 else 4096
+    return (pow2(M) and pow2(N) and M <= 8192 and N <= nmax and x.stride(1) == 1 and x.stride(0) % 2 == 0 and
+            x.data_ptr() % (2 * x.element_size()) == 0)
 
 
 def _normalized_transform(psf, dx):
@@ -117,9 +136,21 @@ def otf_from_psf(psf, dx=None, return_more=False):
 
 def mtf_ptf_otf_from_psf(psf, dx=None, return_more=False):
     """MTF, PTF and OTF with a single forward transform (otf.py:167-203)."""
+    if not return_more:
+        # the centre-normalised OTF straight out of the Hermitian transform pair, then |.| and the angle in ONE sweep (pm_abs_arg):
+        # three launches, no torch arithmetic (round 2: transform + division + abs + angle as four device sweeps)
+        fused = _fused_from_psf(psf, dx, L.PM_EPI_NONE)
+        if fused is not None:
+            a, g = _ops.abs_arg(fused[0])
+            return (RichData(data=a, dx=fused[1], wavelength=None), RichData(data=g, dx=fused[1], wavelength=None),
+                    RichData(data=fused[0], dx=fused[1], wavelength=None))
     normalized, data, df = _normalized_transform(psf, dx)
-    mtf = RichData(data=torch.abs(normalized), dx=df, wavelength=None)
-    ptf = RichData(data=torch.angle(normalized), dx=df, wavelength=None)
+    if normalized.dim() == 2 and normalized.is_complex() and normalized.stride(1) == 1:
+        a, g = _ops.abs_arg(normalized)
+    else:
+        a, g = torch.abs(normalized), torch.angle(normalized)
+    mtf = RichData(data=a, dx=df, wavelength=None)
+    ptf = RichData(data=g, dx=df, wavelength=None)
     otf = RichData(data=normalized, dx=df, wavelength=None)
     if return_more:
         return mtf, ptf, otf, data

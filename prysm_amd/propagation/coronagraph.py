@@ -32,7 +32,7 @@ def _one_minus(fpm):
         return 1 - fpm
     t = L.as_device(fpm)
     if not (t.is_floating_point() or t.is_complex()):
-        t = t.to(L.torch_dtype(config.precision))
+        t = t.to(L.torch_dtype(config.compute_precision))
     return 1 - t
 
 

@@ -26,7 +26,7 @@ def coordinates_for_focus(pupil_dx, pupil_samples, focal_dx, focal_samples,
     pny, pnx = pupil_samples
     fny, fnx = focal_samples
     fsx, fsy = focal_shift
-    dtype = config.precision
+    dtype = config.compute_precision
     x = fftrange(pnx, dtype=dtype) * pupil_dx
     y = fftrange(pny, dtype=dtype) * pupil_dx
     inv_lz = 1.0 / (wavelength * efl)
@@ -49,7 +49,7 @@ def prepare_executor(pupil_dx, pupil_samples, focal_dx, focal_samples,
         ps = pupil_samples if isinstance(pupil_samples, Iterable) else (pupil_samples, pupil_samples)
         fs = focal_samples if isinstance(focal_samples, Iterable) else (focal_samples, focal_samples)
         op = MDFT._for_focus_grids(tuple(int(v) for v in ps), tuple(int(v) for v in fs), pupil_dx, focal_dx, focal_shift,
-                                   1.0 / (wavelength * efl), L.torch_dtype(config.precision), -1, norm)
+                                   1.0 / (wavelength * efl), L.torch_dtype(config.compute_precision), -1, norm)
         op.pupil_dx = pupil_dx
         op.focal_dx = focal_dx
         return op
@@ -59,7 +59,7 @@ def prepare_executor(pupil_dx, pupil_samples, focal_dx, focal_samples,
         fs = focal_samples if isinstance(focal_samples, Iterable) else (focal_samples, focal_samples)
         if min(int(v) for v in ps) >= 2 and min(int(v) for v in fs) >= 2:
             op = CZT._for_focus_grids(tuple(int(v) for v in ps), tuple(int(v) for v in fs), pupil_dx, focal_dx, focal_shift,
-                                      1.0 / (wavelength * efl), L.torch_dtype(config.precision), -1, norm)
+                                      1.0 / (wavelength * efl), L.torch_dtype(config.compute_precision), -1, norm)
             op.pupil_dx = pupil_dx
             op.focal_dx = focal_dx
             return op
@@ -146,8 +146,8 @@ def prepare_multiresolution(pupil_dx, pupil_samples, focal_dx, focal_samples,
         fdx = focal_dx / scaling**k
         shift = fdx / 2.0
         ex = prepare_executor(pupil_dx, pupil_samples, fdx, nf, wavelength, efl, focal_shift=(shift, shift), kind=kind)
-        xline = fftrange(nfx, dtype=config.precision) * fdx + shift
-        yline = fftrange(nfy, dtype=config.precision) * fdx + shift
+        xline = fftrange(nfx, dtype=config.compute_precision) * fdx + shift
+        yline = fftrange(nfy, dtype=config.compute_precision) * fdx + shift
         yf, xf = torch.meshgrid(yline, xline, indexing='ij')
         executors.append(ex)
         xfs.append(xf)

@@ -62,7 +62,7 @@ def test_angular_spectrum_middle_pass_forms(pa, mode, n, dtype, tol):
     try:
         got = tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1))
     finally:
-        lib.pm_set_tuning(b'colmul_mode', 0)
+        lib.pm_set_tuning(b'colmul_mode', 2)
         pa.config.precision = prec
     ref = O.angular_spectrum(x.astype(np.complex128), O.HeNe, 0.01, 10.0, Q=1)
     assert got.dtype == dtype
@@ -82,7 +82,7 @@ def test_angular_spectrum_tf_and_adjoint_middle_pass_forms(pa, mode):
         got_tf = tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1, tf=tf))
         got_adj = tonp(pa.propagation.angular_spectrum_adjoint(x, O.HeNe, 0.01, 10.0, Q=1))
     finally:
-        lib.pm_set_tuning(b'colmul_mode', 0)
+        lib.pm_set_tuning(b'colmul_mode', 2)
     assert rel_max(got_tf, O.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1, tf=tf)) < TOL64
     assert rel_max(got_adj, O.angular_spectrum_adjoint(x, O.HeNe, 0.01, 10.0, Q=1)) < TOL64
 
@@ -186,12 +186,13 @@ def test_cgemm_in_workgroup_k_split_all_ops(pa, M, N, K):
         At, Bt = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
         got = tonp(_ops.cgemm(At, Bt, opA, opB, alpha=0.5))
         assert rel_max(got, 0.5 * ref) < TOL32_MDFT, (opA, opB)
-        lib.pm_set_tuning(b'gemm_wk', 0)
-        try:
-            old = tonp(_ops.cgemm(At, Bt, opA, opB, alpha=0.5))
-        finally:
-            lib.pm_set_tuning(b'gemm_wk', 1)
-        assert rel_max(got, old) < 1e-5, (opA, opB)
+        for form in (0, 2, 7):        # round 2's slabs; the 64 x 32 form; every in-workgroup form
+            lib.pm_set_tuning(b'gemm_wk', form)
+            try:
+                old = tonp(_ops.cgemm(At, Bt, opA, opB, alpha=0.5))
+            finally:
+                lib.pm_set_tuning(b'gemm_wk', 5)
+            assert rel_max(got, old) < 1e-5, (opA, opB, form)
         # bitwise reproducible: the K-groups are summed in a fixed order
         assert np.array_equal(got, tonp(_ops.cgemm(At, Bt, opA, opB, alpha=0.5)))
 
