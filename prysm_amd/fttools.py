@@ -112,7 +112,7 @@ def _pad_stat(a, widths, mode):
             pre = first * kb.to(rd)                       # end value 0 -> edge, outermost sample first
             post = last * (1 - ka).to(rd)                 # edge -> end value 0
             out = torch.cat((pre, work, post), dim=axis)
-            a = out if work is a else torch.round(out).to(a.dtype)     # integer arrays: numpy rounds the ramp (half to even), it does not truncate
+            a = out if work is a else torch.floor(out).to(a.dtype)     # integer arrays: numpy builds the ramp with linspace(dtype=int), which FLOORS
             continue
         if mode == 'mean':
             if a.is_floating_point() or a.is_complex():

@@ -240,3 +240,60 @@ def test_mdft_intensity_matches_composed(pa):
         pa.config.precision = prec
     ex64 = P.prepare_executor(pdx, (2048, 2048), fdx, (512, 512), wvl, efl)
     assert rel_max(tonp(ex64.intensity(x.astype(np.complex128), weight=2.0)), 2.0 * ref) < TOL64
+
+
+# ----------------------------------------------------------------------------- OTF family: three outputs, misaligned real inputs
+
+@pytest.mark.parametrize('shape,dtype,tol', [((512, 512), np.float32, 5e-6), ((256, 1024), np.float64, 1e-12), ((100, 60), np.float64, 1e-12)])
+def test_mtf_ptf_otf_three_outputs(pa, shape, dtype, tol):
+    """mtf_ptf_otf_from_psf (otf.py:167-203): centre-normalised OTF from the Hermitian transform pair + |.| and angle in one sweep
+    (pm_abs_arg); the 100 x 60 PSF takes the complex path and the same sweep"""
+    from prysm_amd import otf
+    rng = np.random.default_rng(shape[0] + shape[1])
+    psf = (rng.random(shape) + 0.05).astype(dtype)
+    F = np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(psf.astype(np.float64))))
+    Fn = F / F[shape[0] // 2, shape[1] // 2]
+    m, p, o = otf.mtf_ptf_otf_from_psf(psf, 1.0)
+    assert rel_max(tonp(o.data), Fn) < tol and rel_max(tonp(m.data), np.abs(Fn)) < tol
+    d = np.angle(np.exp(1j * (tonp(p.data).astype(np.float64) - np.angle(Fn))))     # phases compared on the circle
+    sel = np.abs(Fn) > 1e-3
+    assert np.max(np.abs(d[sel])) < (2e-4 if dtype == np.float32 else 1e-9)
+    m2, p2, o2, raw = otf.mtf_ptf_otf_from_psf(psf, 1.0, return_more=True)
+    assert rel_max(tonp(raw), F) < tol and rel_max(tonp(m2.data), np.abs(Fn)) < tol
+
+
+def test_real_input_at_an_odd_float_offset(pa):
+    """a real view whose base address is one float off a complex boundary must not be read with misaligned pair loads:
+    the library sends it down the complex path (its workspace query covers both), results unchanged"""
+    from prysm_amd import _ops, otf
+    rng = np.random.default_rng(31)
+    big = torch.from_numpy(rng.random((256, 258)).astype(np.float32) + 0.1).cuda()
+    view = big[:, 1:257]
+    assert view.data_ptr() % 8 == 4 and view.stride(0) % 2 == 0
+    ref = np.fft.fft2(tonp(view).astype(np.float64))
+    got = tonp(_ops.fft2(view, direction=-1, scale=1.0, epilogue=_ops.L.PM_EPI_ABS2))
+    assert rel_max(got, np.abs(ref) ** 2) < 2e-5
+    F = np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(tonp(view).astype(np.float64))))
+    assert rel_max(tonp(otf.mtf_from_psf(view, 1.0).data), np.abs(F / F[128, 128])) < 5e-6
+    H = torch.from_numpy(crandn(rng, (256, 256), np.complex64)).cuda()
+    conv = tonp(_ops.fft2_mul_ifft2(view, scale=1.0 / 256 ** 2, mul=H, real_out=True))
+    want = np.real(np.fft.ifft2(np.fft.fft2(tonp(view).astype(np.float64)) * tonp(H).astype(np.complex128)))
+    assert rel_max(conv, want) < 5e-6
+
+
+def test_config_precision_16_runs_at_float32(pa):
+    """config.precision = 16 (accepted as the reference accepts it): synthesised arrays are complex64 / float32"""
+    P = pa.propagation
+    prec = pa.config.precision
+    pa.config.precision = 16
+    try:
+        assert pa.config.precision is np.float16 and pa.config.precision_complex is np.complex64
+        tf = P.angular_spectrum_transfer_function((64, 64), 0.6328, 0.01, 5.0)
+        assert tonp(tf).dtype == np.complex64
+        ex = P.prepare_executor(0.05, (64, 64), 1.0, (32, 32), 0.6328, 100.0)
+        assert ex.Ex.dtype == torch.complex64
+        x = crandn(np.random.default_rng(1), (64, 64), np.complex64)
+        ref = O.prepare_executor(0.05, (64, 64), 1.0, (32, 32), 0.6328, 100.0)(x.astype(np.complex128))
+        assert rel_max(tonp(P.focus_dft(x, ex)), ref) < TOL32_MDFT
+    finally:
+        pa.config.precision = prec

@@ -17,8 +17,14 @@ def test_config_precision():
         c.precision = p
         assert c.precision is np.float32 and c.precision_complex is np.complex64
     c.precision = 64
-    assert c.precision_complex is np.complex128
-    for bad in (8, 'int32', 'nope', True):
+    assert c.precision_complex is np.complex128 and c.compute_precision is np.float64
+    # 16 is accepted as the reference accepts it (test_config.py:29-33: float16 / complex64); the device synthesises in float32
+    for p in (16, np.int64(16), 'float16', np.float16):
+        c.precision = p
+        assert c.precision is np.float16 and c.precision_complex is np.complex64 and c.compute_precision is np.float32
+    c.precision = np.int64(32)
+    assert c.precision is np.float32 and c.compute_precision is np.float32
+    for bad in (8, 1, 'int32', 'int16', np.int32, np.complex64, 'nope', True):
         with pytest.raises(ValueError):
             c.precision = bad
 
@@ -260,3 +266,38 @@ def test_pad_statistical_modes_on_host_tensors(mode):
             got = _pad_stat(torch.from_numpy(a), widths, mode).numpy()
             assert got.dtype == want.dtype and got.shape == want.shape
             assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('mode', ['mean', 'median', 'linear_ramp', 'maximum'])
+def test_pad_statistical_modes_round_integer_arrays_like_numpy(mode):
+    """np.pad ROUNDS the statistic / ramp of an integer array (half to even) before casting back; truncation was off by
+    one.  Also the median of arrays beyond torch.quantile's 16M-element limit (by sort)."""
+    import torch
+    from prysm_amd.fttools import _pad_stat
+    rng = np.random.default_rng(11)
+    for shape, widths in (((7, 9), [(2, 3), (4, 1)]), ((4, 6), [(5, 0), (0, 7)])):
+        a = rng.integers(-50, 50, size=shape).astype(np.int64)
+        want = np.pad(a, widths, mode=mode)
+        got = _pad_stat(torch.from_numpy(a), widths, mode).numpy()
+        assert got.dtype == want.dtype and np.array_equal(got, want), (mode, shape)
+    if mode == 'median':
+        big = torch.from_numpy(rng.standard_normal((4100, 4100)).astype(np.float32))       # 16.8M elements
+        got = _pad_stat(big, [(1, 0), (0, 1)], 'median')
+        want = np.pad(big.numpy(), [(1, 0), (0, 1)], mode='median')
+        assert np.allclose(got.numpy()[0, :5], want[0, :5]) and np.allclose(got.numpy()[:5, -1], want[:5, -1])
+
+
+def test_hermitian_path_predicate():
+    """otf._hermitian_ok mirrors the library's eligibility test (capi.hip r2c_legal) so ineligible PSFs never pay a failed call"""
+    import torch
+    from prysm_amd.otf import _hermitian_ok
+    assert _hermitian_ok(torch.zeros(64, 128))
+    assert _hermitian_ok(torch.zeros(4096, 4096, dtype=torch.float64)[:32, :32].contiguous())
+    assert not _hermitian_ok(torch.zeros(1000, 1000))                       # not powers of two
+    assert not _hermitian_ok(torch.zeros(16, 64))                           # too short
+    assert not _hermitian_ok(torch.zeros(64, 64, dtype=torch.complex64))    # complex PSF
+    assert not _hermitian_ok(torch.zeros(64, 8192, dtype=torch.float64))    # complex128 rows of 4096 complex points
+    big = torch.zeros(64, 130)
+    assert not _hermitian_ok(big[:, 1:65])                                  # base address one float off a complex boundary
+    assert _hermitian_ok(big[:, 2:66])
+    assert not _hermitian_ok(torch.zeros(64, 131)[:, :64])                  # odd leading dimension
