@@ -301,7 +301,20 @@ def other_configs(only=''):
                 # the same focal grid by the chirp-Z executor (prysm/fttools.py:235-389), for comparison
                 exz = P.prepare_executor(10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0, kind='czt')
                 msz = _event_ms(lambda: P.focus_dft(x4, exz), 20)
-                out['czt_2048_to_512_c64'] = {'ms': msz, 'note': 'kind="czt" executor on the config-4 grid (batched 1-D FFTs + chirp multiplies)'}
+                out['czt_2048_to_512_c64'] = {'ms': msz, 'note': 'kind="czt" executor on the config-4 grid (one fused convolution kernel per axis)'}
+                # ... and by the FFT-accelerated DFT (prysm/fttools.py:392-535; K = 8192 per axis: one pm_fft1_ramp kernel per axis).  In
+                # complex128: the reference's spacing test rejects this grid at precision 32
+                config.precision = 64
+                exf = P.prepare_executor(10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0, kind='fftdft')
+                x4d = x4.to(torch.complex128)
+                msf = _event_ms(lambda: P.focus_dft(x4d, exf), 20)
+                exm = P.prepare_executor(10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0, kind='mdft')
+                msm = _event_ms(lambda: P.focus_dft(x4d, exm), 10)
+                out['fftdft_2048_to_512_c128'] = {'ms': msf, 'mdft_c128_ms': msm,
+                                                  'note': 'kind="fftdft" executor on the config-4 grid, complex128 (ramps in the load / store of '
+                                                          'one 8192-point transform kernel per axis); mdft_c128_ms: the matrix DFT at the same precision'}
+                del x4d, exf, exm
+                config.precision = 32
             del x4, ex
         finally:
             config.precision = prec

@@ -221,6 +221,15 @@ int pm_czt_axis(int32_t dtype, int32_t axis, int64_t nseq, int64_t K, int64_t in
                 const void* pre, int32_t pre_conj, const void* H, int32_t h_conj, const void* post, int32_t post_conj, double scale,
                 const void* in, int64_t in_ld, void* out, int64_t out_ld, void* stream);
 
+/* One axis of fttools.FFTDFT (prysm/fttools.py:392-535: phase ramp, zero-padded FFT of length K, crop, phase ramp) in ONE kernel:
+ *     out[.., m] = scale * post[m] * T_K( pad_K(pre . in) )[out_off + m],     m < out_len,
+ * T_K the unnormalised K-point transform with exp(-2 pi i ..) (direction = -1) or exp(+2 pi i ..) (+1); windows, vectors and axis as
+ * in pm_czt_axis (same kernel with the multiplier and the second transform switched off).  K: a power of two from 16 to 8192
+ * (PM_ERR_UNSUPPORTED otherwise: compose pm_fft1_ws and pm_scale_sep). */
+int pm_fft1_ramp(int32_t dtype, int32_t direction, int32_t axis, int64_t nseq, int64_t K, int64_t in_len, int64_t in_off, int64_t out_len,
+                 int64_t out_off, const void* pre, int32_t pre_conj, const void* post, int32_t post_conj, double scale, const void* in,
+                 int64_t in_ld, void* out, int64_t out_ld, void* stream);
+
 /* --- pointwise / synthesis kernels -------------------------------------------------------- */
 
 /* out = a * b (op 0), a * conj(b) (op 1); complex, same shape (rows x cols).

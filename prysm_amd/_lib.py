@@ -64,6 +64,8 @@ SIGNATURES = {
     'pm_czt_vectors': (c_i32, [c_i32, c_i64, c_i64, c_i64, c_f64, c_f64, c_vp, c_vp, c_vp, c_vp]),
     'pm_czt_axis': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_f64,
                             c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'pm_fft1_ramp': (c_i32, [c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp, c_i32, c_f64,
+                             c_vp, c_i64, c_vp, c_i64, c_vp]),
     'pm_cmul': (c_i32, [c_i32, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     'pm_rmul': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_f64, c_vp, c_i64, c_vp]),
     'pm_scale_sep': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_f64, c_vp, c_i64, c_vp]),

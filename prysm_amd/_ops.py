@@ -304,6 +304,22 @@ def czt_axis(x, K, axis, H, *, pre=None, post=None, out_len, in_off=0, out_off=0
     return out
 
 
+def fft1_ramp(x, K, axis, direction, *, pre=None, post=None, out_len, conj=False, scale=1.0):
+    """One axis of an FFT-accelerated DFT in one kernel (pm_fft1_ramp): scale * post * T_K(pad_K(pre * x))[:out_len] along `axis` of
+    the 2-D tensor x, T_K unnormalised with the sign of `direction`; `conj` conjugates pre and post (the adjoint).  K must be an
+    engine length."""
+    lib = L.load()
+    axis = axis % 2
+    rows, cols = x.shape
+    nseq, in_len = (rows, cols) if axis == 1 else (cols, rows)
+    oshape = (rows, out_len) if axis == 1 else (out_len, cols)
+    out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    c = 1 if conj else 0
+    L.check(lib.pm_fft1_ramp(L.code(x), int(direction), axis, nseq, int(K), in_len, 0, int(out_len), 0, L.ptr(pre), c, L.ptr(post), c,
+                             float(scale), L.ptr(x), x.stride(0), L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
 def cmul(a, b, conj_b=False):
     lib = L.load()
     out = torch.empty_like(a)

@@ -1072,14 +1072,15 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
 template <typename T>
 static int czt_axis_run(int32_t axis, int64_t nseq, int64_t K, int64_t in_len, int64_t in_off, int64_t out_len, int64_t out_off,
                         const void* pre, int pre_conj, const void* H, int h_conj, const void* post, int post_conj, double scale,
-                        const void* in, int64_t in_ld, void* out, int64_t out_ld, hipStream_t st) {
+                        const void* in, int64_t in_ld, void* out, int64_t out_ld, hipStream_t st, int single = 0) {
     int err = 0;
     const cx<T>* tw = twiddles<T>(K, &err);
     if (!tw) return err;
     // 1 / K of the inverse transform rides on the scale
     Conv1<T> p{reinterpret_cast<const cx<T>*>(in), in_ld, reinterpret_cast<cx<T>*>(out), out_ld, int(nseq), int(in_len), int(in_off),
                int(out_len), int(out_off), reinterpret_cast<const cx<T>*>(pre), reinterpret_cast<const cx<T>*>(H),
-               reinterpret_cast<const cx<T>*>(post), pre_conj ? 1 : 0, h_conj ? 1 : 0, post_conj ? 1 : 0, T(scale / double(K))};
+               reinterpret_cast<const cx<T>*>(post), pre_conj ? 1 : 0, h_conj ? 1 : 0, post_conj ? 1 : 0,
+               T(single ? scale : scale / double(K)), single};
     const int lg = engine_log2(K);
     return axis == 1 ? launch_conv1_rows<T>(lg, p, tw, st) : launch_conv1_cols<T>(lg, p, tw, st);
 }
@@ -1248,8 +1249,24 @@ extern "C" {
 
 int pm_version(void) { return PM_VERSION; }
 
+// Variants that measured slower are compiled only with -DPM_EXPERIMENTS (tools/ A/B builds): the product library refuses the knob
+// values that would select them instead of silently running something else.
+static bool experiment_only(const char* key, int v) {
+#ifdef PM_EXPERIMENTS
+    (void)key; (void)v;
+    return false;
+#else
+    auto is = [&](const char* k) { return !strcmp(key, k); };
+    return (is("spectral_mode") && (v & 3) != 3) || (is("gemm_3m") && !v) || (is("gemm_bm") && v == 128) || (is("gemm_bk") && v == 32) ||
+           (is("colmul_mode") && v == 1) || (is("gemm_wk") && (v & 2));
+#endif
+}
+
 int pm_set_tuning(const char* key, int32_t value) {
     if (!key) return fail(PM_ERR_ARG, "pm_set_tuning: null key");
+    if (experiment_only(key, value))
+        return fail(PM_ERR_UNSUPPORTED, "pm_set_tuning: %s = %d selects a variant this build does not contain (rebuild with -DPM_EXPERIMENTS)", key,
+                    int(value));
     tune_set(tuning(), key, strlen(key), value);
     return 0;
 }
@@ -1473,6 +1490,29 @@ int pm_czt_axis(int32_t dtype, int32_t axis, int64_t nseq, int64_t K, int64_t in
                  : czt_axis_run<double>(axis, nseq, K, in_len, in_off, out_len, out_off, pre, pre_conj, H, h_conj, post, post_conj, scale,
                                         in, in_ld, out, out_ld, st);
     return rc == -2 ? fail(PM_ERR_UNSUPPORTED, "pm_czt_axis: no kernel for K = %lld", (long long)K) : rc;
+}
+
+int pm_fft1_ramp(int32_t dtype, int32_t direction, int32_t axis, int64_t nseq, int64_t K, int64_t in_len, int64_t in_off, int64_t out_len,
+                 int64_t out_off, const void* pre, int32_t pre_conj, const void* post, int32_t post_conj, double scale, const void* in,
+                 int64_t in_ld, void* out, int64_t out_ld, void* stream) {
+    if (dtype != PM_C64 && dtype != PM_C128) return fail(PM_ERR_ARG, "pm_fft1_ramp: dtype must be PM_C64 or PM_C128");
+    if (axis != 0 && axis != 1) return fail(PM_ERR_ARG, "pm_fft1_ramp: axis must be 0 or 1");
+    if (direction != -1 && direction != 1) return fail(PM_ERR_ARG, "pm_fft1_ramp: direction must be -1 or +1");
+    if (!in || !out) return fail(PM_ERR_ARG, "pm_fft1_ramp: null argument");
+    if (nseq < 0 || in_len < 0 || out_len < 0 || in_off < 0 || out_off < 0 || in_off + in_len > K || out_off + out_len > K)
+        return fail(PM_ERR_ARG, "pm_fft1_ramp: the input and output windows must lie inside [0, K)");
+    const int lg = engine_log2(K);
+    if (lg < 4) return fail(PM_ERR_UNSUPPORTED, "pm_fft1_ramp: K = %lld must be a power of two from 16 to 8192 (compose pm_fft1 and "
+                            "pm_scale_sep otherwise)", (long long)K);
+    if (nseq == 0 || out_len == 0) return 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int single = direction < 0 ? 1 : 2;
+    int rc = dtype == PM_C64
+                 ? czt_axis_run<float>(axis, nseq, K, in_len, in_off, out_len, out_off, pre, pre_conj, nullptr, 0, post, post_conj, scale, in,
+                                       in_ld, out, out_ld, st, single)
+                 : czt_axis_run<double>(axis, nseq, K, in_len, in_off, out_len, out_off, pre, pre_conj, nullptr, 0, post, post_conj, scale,
+                                        in, in_ld, out, out_ld, st, single);
+    return rc == -2 ? fail(PM_ERR_UNSUPPORTED, "pm_fft1_ramp: no kernel for K = %lld", (long long)K) : rc;
 }
 
 int pm_fft1(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in, const pm_axis* t_out,

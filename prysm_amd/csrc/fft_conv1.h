@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(C::NT) fft_conv1_kernel(const Conv1<typename C
             if (in && seq < p.nseq) {
                 x = COL ? p.in[int64_t(q) * p.in_ld + seq] : p.in[int64_t(seq) * p.in_ld + q];
                 if (p.pre) x = mulc(x, f, p.pre_conj);
+                if (p.single == 2) x.y = -x.y;      // inverse transform = conj-in / conj-out of the forward one
             }
             v[e][m] = x;
         }
@@ -53,22 +54,25 @@ __global__ void __launch_bounds__(C::NT) fft_conv1_kernel(const Conv1<typename C
     // ---- forward transform, x H, inverse transform (conj-in / conj-out of the same engine transform)
     if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
     else fft_run<C>(v, pos, pm_smem, tw);
+    if (!p.single) {       // uniform over the launch
 #pragma unroll
-    for (int m = 0; m < C::P; ++m) {
-        const cx<T> h = p.H[pos.t + m * C::TPS];
+        for (int m = 0; m < C::P; ++m) {
+            const cx<T> h = p.H[pos.t + m * C::TPS];
 #pragma unroll
-        for (int e = 0; e < C::E; ++e) {
-            const cx<T> x = mulc(v[e][m], h, p.h_conj);
-            v[e][m] = {x.x, -x.y};
+            for (int e = 0; e < C::E; ++e) {
+                const cx<T> x = mulc(v[e][m], h, p.h_conj);
+                v[e][m] = {x.x, -x.y};
+            }
         }
+        __syncthreads();   // LDS of the forward exchange is reused by the inverse
+        // opaque copy of the slot: otherwise the twiddles (and their products) of the first transform are CSE'd with the second
+        // and kept live across it (see fft_col_mul_kernel)
+        ThreadPos pos2 = pos;
+        asm volatile("" : "+v"(pos2.t), "+v"(pos2.cl), "+v"(pos2.bo));
+        if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos2, pm_smem, tw);
+        else fft_run<C>(v, pos2, pm_smem, tw);
     }
-    __syncthreads();   // LDS of the forward exchange is reused by the inverse
-    // opaque copy of the slot: otherwise the twiddles (and their products) of the first transform are CSE'd with the second
-    // and kept live across it (see fft_col_mul_kernel)
-    ThreadPos pos2 = pos;
-    asm volatile("" : "+v"(pos2.t), "+v"(pos2.cl), "+v"(pos2.bo));
-    if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos2, pm_smem, tw);
-    else fft_run<C>(v, pos2, pm_smem, tw);
+    const T osign = p.single == 1 ? T(1) : T(-1);      // conj-out of an inverse transform (the convolution's second, or single == 2)
     // ---- store the window [out_off, out_off + out_len) of the K results: conj (inverse), scale, x post
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
@@ -85,7 +89,7 @@ __global__ void __launch_bounds__(C::NT) fft_conv1_kernel(const Conv1<typename C
         for (int e = 0; e < C::E; ++e) {
             const int seq = COL ? unit * TC + pos.cl * C::E + e : (unit * C::BO + pos.bo) * C::E + e;
             if (seq >= p.nseq) continue;
-            const cx<T> x = cmul(cx<T>{v[e][m].x, -v[e][m].y}, f);
+            const cx<T> x = cmul(cx<T>{v[e][m].x, osign * v[e][m].y}, f);
             if (COL) p.out[int64_t(q) * p.out_ld + seq] = x;
             else p.out[int64_t(seq) * p.out_ld + q] = x;
         }

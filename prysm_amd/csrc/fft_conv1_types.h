@@ -20,6 +20,9 @@ struct Conv1 {
     const cx<T>* post;      // out_len factors on the output (or null)
     int pre_conj, h_conj, post_conj;
     T scale;
+    int single;             // 0: the convolution above; 1 / 2: ONE transform of the K-point sequence, forward exp(-2 pi i ..) / inverse
+                            // exp(+..) unnormalised (H unused): out[m] = scale post[m] FFT_K(pad_K(pre . in))[out_off + m] -- one axis of
+                            // fttools.FFTDFT with its phase ramps in the load and the store (pm_fft1_ramp)
 };
 
 template <typename T> int launch_conv1_rows(int logk, const Conv1<T>&, const cx<T>* tw, hipStream_t);

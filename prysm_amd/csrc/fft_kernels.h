@@ -275,6 +275,64 @@ __global__ void __launch_bounds__(C::NT, 1)
     }
 }
 
+// Mode 3: one tile per workgroup like mode 0, but built to fit TWO 512-thread workgroups per CU (128 VGPRs) without spilling: the
+// lean addressing of the persistent kernel (one uniform base + one 32-bit offset per stream instead of 16 vector addresses each),
+// the separable multiplier fetched four slots at a time.  Sixteen waves per CU issue memory operations instead of eight, and the
+// load / transform / store phases of the two workgroups overlap.
+template <typename C, typename S = ColStoreTiled<typename C::T>>
+__global__ void __launch_bounds__(C::NT, 4)
+    fft_col_mul_lean_kernel(const ColLoadTiled<typename C::T> lp0, const MidMul<typename C::T> mp0, const S sp0,
+                            const cx<typename C::T>* __restrict__ tw, const int log_g) {
+    using T = typename C::T;
+    static_assert(C::BO == 1, "one tile per workgroup");
+    extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+    constexpr int TC = C::CI * C::E, ES = int(sizeof(cx<T>));
+    const ThreadPos pos = thread_pos<C>(threadIdx.x);
+    const auto lp = at_batch(lp0, blockIdx.y);
+    const auto mp = at_batch(mp0, blockIdx.y);
+    const auto sp = at_batch(sp0, blockIdx.y);
+    const PfAddr<C> A(pos, lp.log_k);
+    const int unit = group_remap(blockIdx.x, gridDim.x, log_g);
+    cx<T> v[C::E][C::P];
+    pf_load<C>(lp, unit, A, v);
+    if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
+    else fft_run<C>(v, pos, pm_smem, tw);
+    {
+        cx<T> hx[C::E];
+#pragma unroll
+        for (int e = 0; e < C::E; ++e) hx[e] = mp.mul_x[unit * TC + pos.cl * C::E + e];
+        const int ys = mp.ystep > 1 ? mp.ystep : 1;
+        const uint32_t voff = uint32_t(pos.t * ys) * ES;
+        const int64_t mstep = int64_t(C::TPS) * ys * ES;
+        const char* hb = reinterpret_cast<const char*>(mp.mul);
+#pragma unroll
+        for (int m0 = 0; m0 < C::P; m0 += 4) {
+            cx<T> hy[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hy[j] = *reinterpret_cast<const cx<T>*>(hb + (m0 + j) * mstep + voff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < C::E; ++e) {
+                    const cx<T> h = cmul(hy[j], hx[e]);
+                    const cx<T> x = mp.conj ? cmulc(v[e][m0 + j], h) : cmul(v[e][m0 + j], h);
+                    v[e][m0 + j] = {x.x, -x.y};
+                }
+            __builtin_amdgcn_sched_barrier(0);      // keep the four-slot batches apart: all sixteen hy at once are 64 VGPRs
+        }
+    }
+    __syncthreads();   // LDS of the forward exchange is reused by the inverse
+    ThreadPos pos2 = pos;   // opaque copy: see col_mul_body
+    asm volatile("" : "+v"(pos2.t), "+v"(pos2.cl), "+v"(pos2.bo));
+    if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos2, pm_smem, tw);
+    else fft_run<C>(v, pos2, pm_smem, tw);
+#pragma unroll
+    for (int e = 0; e < C::E; ++e)
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) v[e][m].y = -v[e][m].y;
+    pf_store<C>(sp, unit, A, v);
+}
+
 int pm_num_cus();   // capi.hip: compute units of the current device (cached)
 
 // mode (tuning colmul_mode; 512-thread tiles = 2048-point columns only): 0 one tile per workgroup, 1 the same under a 128-VGPR cap
@@ -301,6 +359,18 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& 
                 return int(hipGetLastError());
             }
         }
+        if (mode == 3) {
+            const bool whole = lp.ay.off == 0 && lp.ay.len == C::N && lp.ay.shift == 0 && lp.ntiles == grid * C::BO && sp.ntiles == lp.ntiles;
+            if (whole && mp.kind == MUL_SEPARABLE && mp.ncols >= grid * C::CI * C::E) {
+                auto kern = fft_col_mul_lean_kernel<C, S>;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   int(C::LDS_BYTES));
+                if (e != hipSuccess) return int(e);
+                hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), C::LDS_BYTES, st, lp, mp, sp, tw, log_g);
+                return int(hipGetLastError());
+            }
+        }
+#ifdef PM_EXPERIMENTS     // spills 45 registers and loses (198 vs 159 us): tools/ builds only
         if (mode == 1) {
             auto kern = fft_col_mul_kernel<C, S, 4>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -309,6 +379,7 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& 
             hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), C::LDS_BYTES, st, lp, mp, sp, tw, log_g);
             return int(hipGetLastError());
         }
+#endif
     }
     auto kern = fft_col_mul_kernel<C, S>;
     if (C::LDS_BYTES > 48 * 1024) {

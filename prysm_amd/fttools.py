@@ -490,8 +490,22 @@ class FFTDFT:
         y_first_cost = Nx * Ky * math.log2(Ky) + My * Kx * math.log2(Kx)
         self._x_first = x_first_cost <= y_first_cost
 
+    # Engine lengths K (powers of two up to 8192): ONE kernel per axis with the phase ramps in the transform's load and store
+    # (pm_fft1_ramp: ramp multiply, zero pad, K-point transform, crop, ramp multiply); otherwise the composition of pm_scale_sep and
+    # pm_fft1_ws (four launches, the intermediate through memory).  Round 2 always composed.
+    def _fused(self):
+        return all(_ops._is_pow2_engine(K) and K >= 16 for K in (self._Kx, self._Ky))
+
     def __call__(self, ary):
         a = _promote_input(ary, _cdtype()).to(_cdtype())
+        if self._fused() and a.dim() == 2:
+            if self._x_first:
+                out = _ops.fft1_ramp(a, self._Kx, 1, self._x_direction, pre=self._pre_x, post=self._post_x, out_len=self._Mx)
+                return _ops.fft1_ramp(out, self._Ky, 0, self._y_direction, pre=self._pre_y, post=self._post_y, out_len=self._My,
+                                      scale=self.norm)
+            out = _ops.fft1_ramp(a, self._Ky, 0, self._y_direction, pre=self._pre_y, post=self._post_y, out_len=self._My)
+            return _ops.fft1_ramp(out, self._Kx, 1, self._x_direction, pre=self._pre_x, post=self._post_x, out_len=self._Mx,
+                                  scale=self.norm)
         out = _ops.scale_sep(a, row_vec=self._pre_y, col_vec=self._pre_x)
         # fft(ary, K) or ifft(ary, K) * K == the unnormalised transform of either sign
         if self._x_first:
@@ -504,6 +518,15 @@ class FFTDFT:
 
     def adjoint(self, grad):
         g = _promote_input(grad, _cdtype()).to(_cdtype())
+        if self._fused() and g.dim() == 2:
+            # adjoint of (ramp, pad, transform, crop, ramp) per axis: conj(post) . g, zero pad to K, opposite sign, keep the first N, conj(pre)
+            if self._x_first:
+                out = _ops.fft1_ramp(g, self._Ky, 0, -self._y_direction, pre=self._post_y, post=self._pre_y, out_len=self._Ny, conj=True)
+                return _ops.fft1_ramp(out, self._Kx, 1, -self._x_direction, pre=self._post_x, post=self._pre_x, out_len=self._Nx, conj=True,
+                                      scale=self.norm)
+            out = _ops.fft1_ramp(g, self._Kx, 1, -self._x_direction, pre=self._post_x, post=self._pre_x, out_len=self._Nx, conj=True)
+            return _ops.fft1_ramp(out, self._Ky, 0, -self._y_direction, pre=self._post_y, post=self._pre_y, out_len=self._Ny, conj=True,
+                                  scale=self.norm)
         out = _ops.scale_sep(g, row_vec=self._post_y, col_vec=self._post_x, row_conj=True, col_conj=True)
         # adjoint of a cropped unnormalised transform: zero pad to K, opposite sign, keep the first N
         if self._x_first:

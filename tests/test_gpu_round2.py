@@ -598,7 +598,10 @@ def test_spectral_call_equals_the_wavelength_loop(pa, m, n, Q, count):
             lib.pm_set_tuning(b'fold', 1)      # the folded kernels (automatic from 4096 rows) on short columns too
         for group in (1, 2, 3, 8):
             for mode in (0, 1, 2, 3):
-                assert lib.pm_set_tuning(b'spectral', group) == 0 and lib.pm_set_tuning(b'spectral_mode', mode) == 0
+                assert lib.pm_set_tuning(b'spectral', group) == 0
+                if lib.pm_set_tuning(b'spectral_mode', mode) != 0:     # forms 0 - 2 lost and are built with -DPM_EXPERIMENTS only
+                    assert mode != 3
+                    continue
                 got = torch.full((M, N), 0.0, device='cuda')
                 P.focus_intensity(packed, Q, out=got, synth=('packed', ks[0]), spectral=(ks, wts))
                 # same terms in the same order; only the association of the fp32 sum differs (per group: acc + (w0 i0 + w1 i1 ...))
@@ -912,7 +915,10 @@ def test_spectral_call_complex128(pa, m, n, Q, count):
     try:
         for group in (1, 3, 8):
             for mode in (0, 1, 2, 3):
-                assert lib.pm_set_tuning(b'spectral', group) == 0 and lib.pm_set_tuning(b'spectral_mode', mode) == 0
+                assert lib.pm_set_tuning(b'spectral', group) == 0
+                if lib.pm_set_tuning(b'spectral_mode', mode) != 0:
+                    assert mode != 3
+                    continue
                 got = torch.zeros((M, N), device='cuda', dtype=torch.float64)
                 P.focus_intensity(packed, Q, out=got, synth=('packed', ks[0]), spectral=(ks, wts))
                 assert rel_max(tonp(got), tonp(loop)) < 1e-13, (group, mode)

@@ -46,7 +46,7 @@ def crandn(rng, shape, dtype=np.complex128):
 
 # ----------------------------------------------------------------------------- fused chain: the three middle-pass forms
 
-@pytest.mark.parametrize('mode', [0, 1, 2])
+@pytest.mark.parametrize('mode', [0, 1, 2, 3])
 @pytest.mark.parametrize('n,dtype,tol', [(4096, np.complex128, TOL64), (4096, np.complex64, TOL32), (2048, np.complex128, TOL64),
                                          (2048, np.complex64, TOL32)])
 def test_angular_spectrum_middle_pass_forms(pa, mode, n, dtype, tol):
@@ -58,7 +58,8 @@ def test_angular_spectrum_middle_pass_forms(pa, mode, n, dtype, tol):
     x = crandn(rng, (n, n), dtype)
     prec = pa.config.precision
     pa.config.precision = 32 if dtype == np.complex64 else 64
-    lib.pm_set_tuning(b'colmul_mode', mode)
+    if lib.pm_set_tuning(b'colmul_mode', mode) != 0:
+        pytest.skip('form built with -DPM_EXPERIMENTS only')
     try:
         got = tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1))
     finally:
@@ -69,7 +70,7 @@ def test_angular_spectrum_middle_pass_forms(pa, mode, n, dtype, tol):
     assert rel_max(got, ref) < tol
 
 
-@pytest.mark.parametrize('mode', [0, 1, 2])
+@pytest.mark.parametrize('mode', [0, 1, 2, 3])
 def test_angular_spectrum_tf_and_adjoint_middle_pass_forms(pa, mode):
     """tf= (a full multiplier: the persistent form declines it and the call must still be right) and the adjoint (conj H) at 4096^2"""
     from prysm_amd import _lib
@@ -77,7 +78,8 @@ def test_angular_spectrum_tf_and_adjoint_middle_pass_forms(pa, mode):
     rng = np.random.default_rng(77 + mode)
     x = crandn(rng, (4096, 4096))
     tf = O.angular_spectrum_transfer_function((4096, 4096), O.HeNe, 0.01, 10.0)
-    lib.pm_set_tuning(b'colmul_mode', mode)
+    if lib.pm_set_tuning(b'colmul_mode', mode) != 0:
+        pytest.skip('form built with -DPM_EXPERIMENTS only')
     try:
         got_tf = tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1, tf=tf))
         got_adj = tonp(pa.propagation.angular_spectrum_adjoint(x, O.HeNe, 0.01, 10.0, Q=1))
@@ -186,8 +188,9 @@ def test_cgemm_in_workgroup_k_split_all_ops(pa, M, N, K):
         At, Bt = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
         got = tonp(_ops.cgemm(At, Bt, opA, opB, alpha=0.5))
         assert rel_max(got, 0.5 * ref) < TOL32_MDFT, (opA, opB)
-        for form in (0, 2, 7):        # round 2's slabs; the 64 x 32 form; every in-workgroup form
-            lib.pm_set_tuning(b'gemm_wk', form)
+        for form in (0, 2, 5, 7):     # round 2's slabs; the 64 x 32 form (experiment builds); the shipped forms; every in-workgroup form
+            if lib.pm_set_tuning(b'gemm_wk', form) != 0:
+                continue
             try:
                 old = tonp(_ops.cgemm(At, Bt, opA, opB, alpha=0.5))
             finally:
@@ -297,3 +300,47 @@ def test_config_precision_16_runs_at_float32(pa):
         assert rel_max(tonp(P.focus_dft(x, ex)), ref) < TOL32_MDFT
     finally:
         pa.config.precision = prec
+
+
+# ----------------------------------------------------------------------------- FFTDFT with the ramps in the transform's load / store
+
+@pytest.mark.parametrize('sign', (-1, 1))
+@pytest.mark.parametrize('input_shape,output_shape,fft_shape,dys', [((7, 9), (5, 6), (16, 16), -1), ((5, 6), (7, 9), (16, 32), 1),
+                                                                    ((40, 33), (21, 64), (64, 64), 1), ((200, 120), (64, 100), (256, 128), -1)])
+def test_fftdft_fused_axes_match_mdft(pa, sign, input_shape, output_shape, fft_shape, dys):
+    """FFTDFT on engine lengths K: one pm_fft1_ramp kernel per axis (ramp, pad, transform, crop, ramp) -- forward against the matrix
+    DFT on the same grids (tests/test_fttools.py:160-184), adjoint by the dot-product identity (:187-211); dy < 0 runs the
+    inverse-transform axis"""
+    rng = np.random.default_rng(sum(input_shape) + sign)
+    (ny, nx), (my, mx), (ky, kx) = input_shape, output_shape, fft_shape
+    r = lambda n: tonp(pa.fttools.fftrange(n)).astype(float)   # noqa: E731
+    dx, dy = 0.2, 0.17 * dys
+    x, y = r(nx) * dx + 0.33, r(ny) * dy - 0.41
+    fx, fy = (r(mx) + 0.25) / (kx * dx), (r(my) - 0.5) / (ky * abs(dy))
+    inp = crandn(rng, input_shape)
+    mdft = pa.fttools.MDFT(x, y, fx, fy, sign=sign, norm=0.3)
+    op = pa.fttools.FFTDFT(x, y, fx, fy, sign=sign, norm=0.3)
+    assert op._fused()
+    want = tonp(mdft(inp))
+    for x_first in (True, False):
+        op._x_first = x_first
+        np.testing.assert_allclose(tonp(op(inp)), want, rtol=1e-11, atol=1e-11 * np.abs(want).max())
+        grad = crandn(rng, output_shape)
+        lhs = np.vdot(tonp(op(inp)), grad)
+        rhs = np.vdot(inp, tonp(op.adjoint(grad)))
+        np.testing.assert_allclose(lhs, rhs, rtol=1e-11)
+        np.testing.assert_allclose(tonp(op.adjoint(grad)), tonp(mdft.adjoint(grad)), rtol=1e-11, atol=1e-11 * np.abs(want).max())
+
+
+def test_fftdft_config4_grid_vs_oracle(pa):
+    """prepare_executor(kind='fftdft') on config 4's grid (2048^2 -> 512^2, K = 8192 per axis) in complex128 against the oracle's
+    matrix DFT -- the largest engine length, rows and columns of 8192 points in one kernel each"""
+    P = pa.propagation
+    rng = np.random.default_rng(8192)
+    x = crandn(rng, (2048, 2048))
+    pdx, efl, wvl = 10 / 2048, 100.0, O.HeNe
+    fdx = wvl * 10 / 8
+    ref = O.prepare_executor(pdx, (2048, 2048), fdx, (512, 512), wvl, efl)(x)
+    ex = P.prepare_executor(pdx, (2048, 2048), fdx, (512, 512), wvl, efl, kind='fftdft')
+    assert ex._fused() and ex._Kx == 8192
+    assert rel_max(tonp(P.focus_dft(x, ex)), ref) < 1e-9
