@@ -108,17 +108,10 @@ __global__ void __launch_bounds__(C::NT, (C::NT == 512 ? MINW : 1))   // 2nd arg
     store<C>(sp, unit, pos, v);
 }
 
-// The same pass as a PERSISTENT workgroup that prefetches: one 512-thread workgroup per CU walks its tiles and issues the loads of
-// tile t + 1 into a second register set BEFORE the two transforms of tile t, so HBM reads are in flight under the butterflies and
-// the stores of tile t drain under the transforms of tile t + 1.  The one-tile-per-workgroup form above runs ONE workgroup per CU at
-// 2048-point complex128 tiles (184 VGPRs) and did load -> FFT -> x H -> IFFT -> store strictly in sequence: 156.6 us for 536.9 MB
-// = 0.43 of the HBM roofline with PMC traffic 1.01x (config 3's middle pass, VERDICT r2 weak #1).  Registers: 2 x 64 for the two
-// tiles + the transform's own ~60, inside the 256 a two-waves-per-SIMD kernel owns.  Virtual block vb = blockIdx.x + k gridDim.x
-// keeps vb % 8 = the XCD of the physical block (gridDim.x is a multiple of 8), so group_remap's sibling tiles still meet in one L2.
-// Host-checked: every tile exists and is read whole and unrotated (the folded chain's planes).  Addresses are ONE uniform 64-bit
-// base per register slot (scalar registers) + ONE 32-bit per-thread byte offset: with the generic loaders the compiler hoisted
-// the 16 + 16 + 16 per-slot 64-bit vector addresses of load / multiplier / store out of the tile loop (96 VGPRs, hundreds of
-// spills beside the second register set).  The multiplier kind is a template argument.
+// Lean addressing for the tiled column passes of the fused chain (whole, unrotated tiles -- host-checked): ONE uniform 64-bit base
+// per register slot (scalar registers) + ONE 32-bit per-thread byte offset.  With the generic loaders the compiler keeps the 16 +
+// 16 + 16 per-slot 64-bit vector addresses of load / multiplier / store live (96 VGPRs): the difference between 184 registers (one
+// 512-thread workgroup per CU) and 126 (two).
 template <typename C>
 struct PfAddr {
     using T = typename C::T;
@@ -167,6 +160,18 @@ __device__ __forceinline__ void pf_store(const ColStoreTiled<typename C::T>& p, 
     }
 }
 
+#ifdef PM_EXPERIMENTS
+// The same pass as a PERSISTENT workgroup that prefetches: one 512-thread workgroup per CU walks its tiles and issues the loads of
+// tile t + 1 into a second register set BEFORE the two transforms of tile t, so HBM reads are in flight under the butterflies and
+// the stores of tile t drain under the transforms of tile t + 1.  The one-tile-per-workgroup form above runs ONE workgroup per CU at
+// 2048-point complex128 tiles (184 VGPRs) and did load -> FFT -> x H -> IFFT -> store strictly in sequence: 156.6 us for 536.9 MB
+// = 0.43 of the HBM roofline with PMC traffic 1.01x (config 3's middle pass, VERDICT r2 weak #1).  Registers: 2 x 64 for the two
+// tiles + the transform's own ~60, inside the 256 a two-waves-per-SIMD kernel owns.  Virtual block vb = blockIdx.x + k gridDim.x
+// keeps vb % 8 = the XCD of the physical block (gridDim.x is a multiple of 8), so group_remap's sibling tiles still meet in one L2.
+// Host-checked: every tile exists and is read whole and unrotated (the folded chain's planes).  Addresses are ONE uniform 64-bit
+// base per register slot (scalar registers) + ONE 32-bit per-thread byte offset: with the generic loaders the compiler hoisted
+// the 16 + 16 + 16 per-slot 64-bit vector addresses of load / multiplier / store out of the tile loop (96 VGPRs, hundreds of
+// spills beside the second register set).  The multiplier kind is a template argument.
 // v *= hy[k] hx[c], then conjugate (the separable case of mid_multiply_conj_kind); hy from the workgroup's LDS copy
 template <typename C>
 __device__ __forceinline__ void pf_multiply_conj(const cx<typename C::T>* hyl, const cx<typename C::T> (&hx)[C::E], int conj, ThreadPos pos,
@@ -275,11 +280,13 @@ __global__ void __launch_bounds__(C::NT, 1)
     }
 }
 
+#endif   // PM_EXPERIMENTS
+
 // Mode 3: one tile per workgroup like mode 0, but built to fit TWO 512-thread workgroups per CU (128 VGPRs) without spilling: the
 // lean addressing of the persistent kernel (one uniform base + one 32-bit offset per stream instead of 16 vector addresses each),
 // the separable multiplier fetched four slots at a time.  Sixteen waves per CU issue memory operations instead of eight, and the
 // load / transform / store phases of the two workgroups overlap.
-template <typename C, typename S = ColStoreTiled<typename C::T>>
+template <typename C, int KIND, typename S = ColStoreTiled<typename C::T>>
 __global__ void __launch_bounds__(C::NT, 4)
     fft_col_mul_lean_kernel(const ColLoadTiled<typename C::T> lp0, const MidMul<typename C::T> mp0, const S sp0,
                             const cx<typename C::T>* __restrict__ tw, const int log_g) {
@@ -297,7 +304,7 @@ __global__ void __launch_bounds__(C::NT, 4)
     pf_load<C>(lp, unit, A, v);
     if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
     else fft_run<C>(v, pos, pm_smem, tw);
-    {
+    if constexpr (KIND == MUL_SEPARABLE) {
         cx<T> hx[C::E];
 #pragma unroll
         for (int e = 0; e < C::E; ++e) hx[e] = mp.mul_x[unit * TC + pos.cl * C::E + e];
@@ -319,6 +326,39 @@ __global__ void __launch_bounds__(C::NT, 4)
                     v[e][m0 + j] = {x.x, -x.y};
                 }
             __builtin_amdgcn_sched_barrier(0);      // keep the four-slot batches apart: all sixteen hy at once are 64 VGPRs
+        }
+    } else {
+        // full multiplier H[k][c] (tf=, convolution kernels): this thread's columns of rows k = t + m TPS, four rows at a time
+        const uint32_t voff = uint32_t(int64_t(pos.t) * mp.ld + pos.cl * C::E) * ES;
+        const int64_t mstep = int64_t(C::TPS) * mp.ld * ES;
+        const char* hb = reinterpret_cast<const char*>(mp.mul + unit * TC);
+#pragma unroll
+        for (int m0 = 0; m0 < C::P; m0 += 4) {
+            cx<T> hf[4][C::E];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* a = hb + (m0 + j) * mstep + voff;
+                if constexpr (C::E == 2) {
+                    if (mp.vec_ok) {
+                        const Vec4<T> w = *reinterpret_cast<const Vec4<T>*>(a);
+                        hf[j][0] = {w.a, w.b};
+                        hf[j][1] = {w.c, w.d};
+                    } else {
+                        hf[j][0] = reinterpret_cast<const cx<T>*>(a)[0];
+                        hf[j][1] = reinterpret_cast<const cx<T>*>(a)[1];
+                    }
+                } else {
+                    hf[j][0] = *reinterpret_cast<const cx<T>*>(a);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < C::E; ++e) {
+                    const cx<T> x = mp.conj ? cmulc(v[e][m0 + j], hf[j][e]) : cmul(v[e][m0 + j], hf[j][e]);
+                    v[e][m0 + j] = {x.x, -x.y};
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();   // LDS of the forward exchange is reused by the inverse
@@ -344,6 +384,7 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& 
     const int grid = (ntiles + C::BO - 1) / C::BO;
     if (grid <= 0) return 0;
     if constexpr (C::NT == 512 && std::is_same<S, ColStoreTiled<T>>::value) {
+#ifdef PM_EXPERIMENTS     // the persistent prefetching form: 135.7 us against 115.4 for the lean two-per-CU form below; tools/ builds only
         if (mode == 2) {
             // physical blocks: one per CU over all planes, a multiple of 8 << log_g so that siblings stay siblings
             const int unit8 = 8 << log_g;
@@ -359,10 +400,13 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& 
                 return int(hipGetLastError());
             }
         }
+#endif
         if (mode == 3) {
             const bool whole = lp.ay.off == 0 && lp.ay.len == C::N && lp.ay.shift == 0 && lp.ntiles == grid * C::BO && sp.ntiles == lp.ntiles;
-            if (whole && mp.kind == MUL_SEPARABLE && mp.ncols >= grid * C::CI * C::E) {
-                auto kern = fft_col_mul_lean_kernel<C, S>;
+            // (a full multiplier's per-thread byte offset must fit 32 bits: rows t < TPS of an ld-element array)
+            const bool off32 = mp.kind != MUL_FULL || int64_t(C::TPS) * mp.ld * int64_t(sizeof(cx<T>)) < (int64_t(1) << 31);
+            if (whole && off32 && (mp.kind == MUL_SEPARABLE || mp.kind == MUL_FULL) && mp.ncols >= grid * C::CI * C::E) {
+                auto kern = mp.kind == MUL_FULL ? fft_col_mul_lean_kernel<C, MUL_FULL, S> : fft_col_mul_lean_kernel<C, MUL_SEPARABLE, S>;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    int(C::LDS_BYTES));
                 if (e != hipSuccess) return int(e);

@@ -122,11 +122,12 @@ struct Tuning {
     int spectral = 8;         // pm_fft2_spectral: wavelengths per launch pair (fft_spectral.h; <= 8); 1: the plain loop of pm_fft2 calls
     int spectral_area_log = 24;   // ... for transforms of fewer than 2^this bins (capi.hip spectral_fast has the measurements)
     int spectral_mode = 3;    // ... bit 0: its row pass keeps the packed map in registers, bit 1: its column pass accumulates in registers
-    int colmul_mode = 2;      // middle pass of the fused chain at 2048-point column tiles (fft_kernels.h launch_col_mul_one): 0 one tile per
-                              // workgroup, 1 the same under a 128-VGPR cap (two workgroups per CU), 2 persistent prefetching workgroups where
-                              // the pass qualifies (whole unrotated tiles, separable multiplier).  Measured (profiles/r03/exp_colmul.log, us, modes
-                              // 0 / 1 / 2): middle pass of config 3 159.1 / 198.1 / 135.7; chain 4096^2 complex128 391 / 430 / 378, complex64
-                              // 190 / 176 / 178, 2048^2 complex128 90.5 / 93.9 / 87.1
+    int colmul_mode = 3;      // middle pass of the fused chain at 2048-point column tiles (fft_kernels.h launch_col_mul_one): 3 lean addressing,
+                              // two 512-thread workgroups per CU (126 VGPRs) where the pass qualifies (whole unrotated tiles, separable
+                              // multiplier), else 0 = one tile per workgroup (184 VGPRs, one per CU); experiment builds: 1 the generic kernel under
+                              // a 128-VGPR cap (spills), 2 persistent prefetching workgroups (twiddles / hy in LDS).  Measured
+                              // (profiles/r03/exp_colmul.log, us, modes 0 / 1 / 2 / 3): middle pass of config 3 159.1 / 198.1 / 135.7 / 115.4;
+                              // chain 4096^2 complex128 383 / 430 / 365 / 355, complex64 186 / 176 / 175 / 165, 2048^2 complex128 90 / 94 / 86 / 81
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)
 };
