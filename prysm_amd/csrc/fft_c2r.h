@@ -47,22 +47,17 @@ __global__ void __launch_bounds__(C::NT) fft_col_mul_herm_kernel(const ColLoadTi
     const int col0 = unit * TC + pos.cl * C::E;
     // the packed column: its transform P separates as X0[u] = (P[u] + conj P[-u]) / 2, XN[u] = (P[u] - conj P[-u]) / (2i); the
     // partner P[-u] comes through LDS in the workgroup that owns tile 0 (short columns: every workgroup passes the barriers)
-    cx<T> part[C::P];
+    // (read from LDS where it is used, slot by slot: held in a register array, the 16 partners were 32 VGPRs beside the 64 of the
+    // field through the whole multiply -- 83 spilled registers under the 128-register cap of the 1024-thread tiles, and a spill
+    // reload waits for every outstanding load: 86 us = 0.39 of the HBM roofline for the middle pass of a real 4096^2 convolution)
+    cx<T>* const ex = reinterpret_cast<cx<T>*>(pm_smem);
     if (C::BO > 1 || unit == 0) {
-        cx<T>* ex = reinterpret_cast<cx<T>*>(pm_smem);
         __syncthreads();
         if (col0 == 0) {
 #pragma unroll
             for (int m = 0; m < C::P; ++m) ex[pos.bo * C::N + pos.t + m * C::TPS] = v[0][m];
         }
         __syncthreads();
-        if (col0 == 0) {
-#pragma unroll
-            for (int m = 0; m < C::P; ++m) {
-                const int up = pos.t + m * C::TPS;      // the partner -u: (L - u') mod L in the plane of the even bins, L - 1 - u' among the odd ones
-                part[m] = ex[pos.bo * C::N + (pb ? C::N - 1 - up : ((C::N - up) & (C::N - 1)))];
-            }
-        }
     }
     const T half = T(0.5);
 #pragma unroll
@@ -73,7 +68,8 @@ __global__ void __launch_bounds__(C::NT) fft_col_mul_herm_kernel(const ColLoadTi
             const int k = col0 + e;
             cx<T> y = {T(0), T(0)};
             if (k == 0) {
-                const cx<T> p = v[e][m], q = part[m];
+                const int up = pos.t + m * C::TPS;      // the partner -u: (L - u') mod L in the plane of the even bins, L - 1 - u' among the odd ones
+                const cx<T> p = v[e][m], q = ex[pos.bo * C::N + (pb ? C::N - 1 - up : ((C::N - up) & (C::N - 1)))];
                 const cx<T> x0 = {half * (p.x + q.x), half * (p.y - q.y)};                 // (P + conj Pm) / 2
                 const cx<T> xn = mul_mi(cx<T>{half * (p.x - q.x), half * (p.y + q.y)});    // (P - conj Pm) / (2 i)
                 const cx<T> y0 = cmul(x0, cscale(herm_part(hm, u, 0), half));
@@ -84,6 +80,7 @@ __global__ void __launch_bounds__(C::NT) fft_col_mul_herm_kernel(const ColLoadTi
             }
             v[e][m] = {y.x, -y.y};      // conj: the inverse transform is the forward one between two conjugations
         }
+        __builtin_amdgcn_sched_barrier(0);      // one slot at a time: hoisted, the 4 x 16 multiplier loads and their 64-bit addresses spill
     }
     __syncthreads();     // LDS of the forward exchange (and of the partner exchange) is reused by the inverse
     ThreadPos pos2 = pos;   // opaque copy: see fft_col_mul_kernel

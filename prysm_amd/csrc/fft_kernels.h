@@ -118,10 +118,12 @@ struct PfAddr {
     static constexpr int TC = C::CI * C::E;
     static constexpr int ES = int(sizeof(cx<T>));
     uint32_t vdata;   // byte offset of this thread's first element inside a tile block (load and store layouts are the same)
+    int row0;         // the thread's first row (slot 0)
     int TL;
     int64_t mstep;    // bytes between register slots m and m + 1
     __device__ __forceinline__ PfAddr(ThreadPos pos, int log_k) {
         TL = TC << log_k;
+        row0 = pos.t;
         vdata = uint32_t(pos.t * TL + pos.cl * C::E) * ES;
         mstep = int64_t(C::TPS) * TL * ES;
     }
@@ -131,19 +133,29 @@ struct PfAddr {
     }
 };
 
+// rows [ay.off, ay.off + ay.len) of the length-N columns are stored (memory row = logical row - off), the rest is zero padding;
+// ay.shift must be 0 (host-checked)
 template <typename C>
 __device__ __forceinline__ void pf_load(const ColLoadTiled<typename C::T>& p, int tile, const PfAddr<C>& A, cx<typename C::T> (&v)[C::E][C::P]) {
     using T = typename C::T;
-    const char* tb = reinterpret_cast<const char*>(p.src) + A.tile_off(tile, p.nrows, p.log_k);
+    const char* tb = reinterpret_cast<const char*>(p.src) + A.tile_off(tile, p.nrows, p.log_k) - int64_t(p.ay.off) * A.TL * PfAddr<C>::ES;
+    const int lo = p.ay.off, hi = p.ay.off + p.ay.len;
+    const bool full = p.ay.len == C::N;      // uniform
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
         const char* a = tb + m * A.mstep + A.vdata;
-        if constexpr (C::E == 2) {
-            const Vec4<T> w = *reinterpret_cast<const Vec4<T>*>(a);
-            v[0][m] = {w.a, w.b};
-            v[1][m] = {w.c, w.d};
+        const int pp = A.row0 + m * C::TPS;
+        if (full || (pp >= lo && pp < hi)) {
+            if constexpr (C::E == 2) {
+                const Vec4<T> w = *reinterpret_cast<const Vec4<T>*>(a);
+                v[0][m] = {w.a, w.b};
+                v[1][m] = {w.c, w.d};
+            } else {
+                v[0][m] = *reinterpret_cast<const cx<T>*>(a);
+            }
         } else {
-            v[0][m] = *reinterpret_cast<const cx<T>*>(a);
+#pragma unroll
+            for (int e = 0; e < C::E; ++e) v[e][m] = {T(0), T(0)};
         }
     }
 }
@@ -154,6 +166,19 @@ __device__ __forceinline__ void pf_store(const ColStoreTiled<typename C::T>& p, 
     char* tb = reinterpret_cast<char*>(p.dst) + A.tile_off(tile, p.nrows, p.log_k);
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
+        char* a = tb + m * A.mstep + A.vdata;
+        if constexpr (C::E == 2) *reinterpret_cast<Vec4<T>*>(a) = Vec4<T>{v[0][m].x, v[0][m].y, v[1][m].x, v[1][m].y};
+        else *reinterpret_cast<cx<T>*>(a) = v[0][m];
+    }
+}
+// ... only rows [0, nrows) of the results (the cropped convolution of the Bluestein chain)
+template <typename C>
+__device__ __forceinline__ void pf_store(const ColStoreTiledCrop<typename C::T>& p, int tile, const PfAddr<C>& A, const cx<typename C::T> (&v)[C::E][C::P]) {
+    using T = typename C::T;
+    char* tb = reinterpret_cast<char*>(p.dst) + A.tile_off(tile, p.nrows, p.log_k);
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        if (A.row0 + m * C::TPS >= p.nrows) continue;
         char* a = tb + m * A.mstep + A.vdata;
         if constexpr (C::E == 2) *reinterpret_cast<Vec4<T>*>(a) = Vec4<T>{v[0][m].x, v[0][m].y, v[1][m].x, v[1][m].y};
         else *reinterpret_cast<cx<T>*>(a) = v[0][m];
@@ -383,9 +408,9 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& 
     using C = typename ColCfgSel<T, LOGN, 0>::type;
     const int grid = (ntiles + C::BO - 1) / C::BO;
     if (grid <= 0) return 0;
-    if constexpr (C::NT == 512 && std::is_same<S, ColStoreTiled<T>>::value) {
+    if constexpr (C::BO == 1 && C::NT >= 512) {
 #ifdef PM_EXPERIMENTS     // the persistent prefetching form: 135.7 us against 115.4 for the lean two-per-CU form below; tools/ builds only
-        if (mode == 2) {
+        if (mode == 2 && C::NT == 512 && std::is_same<S, ColStoreTiled<T>>::value) {
             // physical blocks: one per CU over all planes, a multiple of 8 << log_g so that siblings stay siblings
             const int unit8 = 8 << log_g;
             int gx = pm_num_cus() / (nbatch > 0 ? nbatch : 1);
@@ -402,7 +427,8 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& 
         }
 #endif
         if (mode == 3) {
-            const bool whole = lp.ay.off == 0 && lp.ay.len == C::N && lp.ay.shift == 0 && lp.ntiles == grid * C::BO && sp.ntiles == lp.ntiles;
+            // an unrotated window of stored rows (zero padding around it is synthesised), every tile present
+            const bool whole = lp.ay.shift == 0 && lp.ay.n == C::N && lp.ntiles == grid * C::BO && sp.ntiles == lp.ntiles;
             // (a full multiplier's per-thread byte offset must fit 32 bits: rows t < TPS of an ld-element array)
             const bool off32 = mp.kind != MUL_FULL || int64_t(C::TPS) * mp.ld * int64_t(sizeof(cx<T>)) < (int64_t(1) << 31);
             if (whole && off32 && (mp.kind == MUL_SEPARABLE || mp.kind == MUL_FULL) && mp.ncols >= grid * C::CI * C::E) {
@@ -415,7 +441,7 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& 
             }
         }
 #ifdef PM_EXPERIMENTS     // spills 45 registers and loses (198 vs 159 us): tools/ builds only
-        if (mode == 1) {
+        if (mode == 1 && C::NT == 512 && std::is_same<S, ColStoreTiled<T>>::value) {
             auto kern = fft_col_mul_kernel<C, S, 4>;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                int(C::LDS_BYTES));

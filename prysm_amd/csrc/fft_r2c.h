@@ -238,22 +238,16 @@ __global__ void __launch_bounds__(C::NT) fft_col_herm_kernel(const ColLoadTiled<
     // Column 0 carries X[0] + i X[N/2] of two real columns: its transform C separates as F0[u] = (C[u] + conj C[M - u]) / 2,
     // FN2[u] = (C[u] - conj C[M - u]) / (2i).  The partner C[M - u] comes through LDS, in the workgroup that owns tile 0 (with
     // several tiles per workgroup -- short columns -- every workgroup passes the barriers).
-    cx<T> part[C::P];
+    // (the partners are read from LDS where they are used, slot by slot, not gathered into a 32-register array first: see
+    // fft_col_mul_herm_kernel)
+    cx<T>* const ex = reinterpret_cast<cx<T>*>(pm_smem);
     if (C::BO > 1 || unit == 0) {
-        cx<T>* ex = reinterpret_cast<cx<T>*>(pm_smem);
         __syncthreads();
         if (col0 == 0) {
 #pragma unroll
             for (int m = 0; m < C::P; ++m) ex[pos.bo * C::N + pos.t + m * C::TPS] = v[0][m];
         }
         __syncthreads();
-        if (col0 == 0) {
-#pragma unroll
-            for (int m = 0; m < C::P; ++m) {
-                const int u = pos.t + m * C::TPS;       // bin within the plane; its partner: (M - u) mod M, or M - 1 - u among the odd bins
-                part[m] = ex[pos.bo * C::N + (sp.plane == 1 ? C::N - 1 - u : ((C::N - u) & (C::N - 1)))];
-            }
-        }
     }
     const int rot = rot_of<C>(sp.ay.shift);
     // the thread's columns strictly inside (0, N/2): every bin has its image; the thread that owns column 0 takes the
@@ -280,7 +274,8 @@ __global__ void __launch_bounds__(C::NT) fft_col_herm_kernel(const ColLoadTiled<
         for (int e = 0; e < C::E; ++e) {
             const cx<T> x = cscale(v[e][m], s);
             if (col0 + e == 0) {
-                const cx<T> xp = cscale(part[m], s);
+                // bin u within the plane; its partner: (M - u) mod M, or M - 1 - u among the odd bins
+                const cx<T> xp = cscale(ex[pos.bo * C::N + (sp.plane == 1 ? C::N - 1 - u : ((C::N - u) & (C::N - 1)))], s);
                 const cx<T> f0 = {T(0.5) * (x.x + xp.x), T(0.5) * (x.y - xp.y)};
                 const cx<T> d = {T(0.5) * (x.x - xp.x), T(0.5) * (x.y + xp.y)};
                 herm_put<T, EPI>(sp, qy, qx[e], f0, false);
