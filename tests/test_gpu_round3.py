@@ -314,8 +314,8 @@ def test_fftdft_fused_axes_match_mdft(pa, sign, input_shape, output_shape, fft_s
     rng = np.random.default_rng(sum(input_shape) + sign)
     (ny, nx), (my, mx), (ky, kx) = input_shape, output_shape, fft_shape
     r = lambda n: tonp(pa.fttools.fftrange(n)).astype(float)   # noqa: E731
-    dx, dy = 0.2, 0.17 * dys
-    x, y = r(nx) * dx + 0.33, r(ny) * dy - 0.41
+    dx, dy = 0.25, 0.125 * dys       # binary spacings: the reference's 32-eps spacing test (fttools.py:491,503) rejects grids whose
+    x, y = r(nx) * dx + 0.375, r(ny) * dy - 0.5      # rounded coordinates miss 1 / K by more than that at K = 256
     fx, fy = (r(mx) + 0.25) / (kx * dx), (r(my) - 0.5) / (ky * abs(dy))
     inp = crandn(rng, input_shape)
     mdft = pa.fttools.MDFT(x, y, fx, fy, sign=sign, norm=0.3)
