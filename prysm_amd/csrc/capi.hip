@@ -1258,7 +1258,7 @@ static bool experiment_only(const char* key, int v) {
 #else
     auto is = [&](const char* k) { return !strcmp(key, k); };
     return (is("spectral_mode") && (v & 3) != 3) || (is("gemm_3m") && !v) || (is("gemm_bm") && v == 128) || (is("gemm_bk") && v == 32) ||
-           (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 2));
+           (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 6));
 #endif
 }
 

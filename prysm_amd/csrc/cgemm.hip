@@ -340,15 +340,15 @@ struct DmaTile {
 // TI x TJ MFMA tiles (32 x 32) per wave; the four waves of a workgroup are arranged WM x WN x WK (rows, columns, K):
 //   (2, 2) tiles, 2 x 2 x 1: 128 x 128, one workgroup per CU (192 accumulator registers per lane), the large-GEMM shape;
 //   (1, 1) tiles, 2 x 2 x 1:  64 x 64;
-//   (1, 1) tiles, 2 x 1 x 2:  64 x 32, the two wave PAIRS each take half of the K range;
-//   (1, 1) tiles, 1 x 1 x 4:  32 x 32, every wave a quarter of the K range;
+//   (1, 1) tiles, 2 x 1 x 2:  64 x 32, the two wave PAIRS each take half of the K range            (experiment builds: lost)
+//   (1, 1) tiles, 1 x 1 x 4:  32 x 32, every wave a quarter of the K range                         (experiment builds: no better than slabs)
 //   (1, 1) tiles, 2 x 2 x 2:  64 x 64 with EIGHT waves -- two K-groups that are each the plain 64 x 64 arrangement (same staging cost
 //                             per wave), one workgroup per CU.
 // WK > 1 is split-K INSIDE the workgroup: each K-group has its own three-deep LDS ring (A rows 32 TI WM, B rows 32 TJ WN), the groups
 // walk their K ranges in lockstep (same barriers) and their partial sums meet through LDS at the end, added in K order -- fixed
-// order, bitwise reproducible, no slab round trip through HBM and no second launch.  That is what lets the matrix-DFT products fill
-// the chip without splitting K across workgroups: 512 x 2048 x 2048 as 512 workgroups of 64 x 32, 512 x 512 x 2048 as 256 of 32 x 32
-// (round 2: K split in 2 / 8 slabs + splitk_reduce_kernel, 6.2 + 5.3 us of config 4's 161).
+// order, bitwise reproducible, no slab round trip through HBM and no second launch.  Shipped: the eight-wave form for outputs of 256 ..
+// 511 tiles (config 4's first product, 512 x 2048 x 2048: 108.9 us against 108.2 + 6.2 for two slabs + splitk_reduce_kernel); smaller
+// outputs (its second product, 64 tiles) keep the slabs -- the 32 x 32 four-K-group form measured equal at K = 2048 and slower at 4096.
 // EPI = 1: the epilogue stores w |alpha c|^2 into (or adds it to) a REAL matrix instead of the complex result (the incoherent sum of
 // the polychromatic recipe: focus_dft + intensity + weighted accumulate without the 512^2 complex round trip).
 template <int TI, int TJ, int WM, int WN, int WK, bool AKF, bool BKF, int EPI>
@@ -633,7 +633,9 @@ static bool gemm_dma_plan(int64_t M, int64_t N, int64_t K, DmaPlan* out) {
 #ifdef PM_EXPERIMENTS
     else if ((wkm & 2) && t64 < want && 2 * t64 >= want && (K % 32) == 0) { p.tn = 32; p.wk = 2; }                   // 64 x 32, K halves
 #endif
+#ifdef PM_EXPERIMENTS     // equal to slabs + reduce at K = 2048 (36.4 vs 37.3 us), slower at K = 4096 (66 vs 62 us): tools/ builds only
     else if ((wkm & 4) && 2 * t64 < want && 4 * t64 >= pm_num_cus() && (K % 64) == 0) { p.tm = p.tn = 32; p.wk = 4; }
+#endif
     const int t = tuning().gemm_tile;
     if (t == 64) { p.tm = p.tn = 64; p.wk = 1; }
     else if (t == 128 && m128 && n128) { p.tm = p.tn = 128; p.wk = 1; }
@@ -797,7 +799,9 @@ static int cgemm_dma_run(int opA, int opB, int64_t M, int64_t N, int64_t K, doub
 #ifdef PM_EXPERIMENTS     // 64 x 32 tiles with two K-groups: 119 us against 108 + 6 for config 4's first product, tools/ builds only
     else if (p.wk == 2) PM_RUN(1, 1, 2, 1, 2);
 #endif
+#ifdef PM_EXPERIMENTS
     else if (p.wk == 4) PM_RUN(1, 1, 1, 1, 4);
+#endif
     else PM_RUN(1, 1, 2, 2, 1);
 #undef PM_RUN
     if (rc || p.S == 1) return rc;

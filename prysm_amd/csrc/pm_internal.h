@@ -98,8 +98,9 @@ struct Tuning {
     int gemm_dma_wgs = 512;   // ... 128 x 128 tiles when there are at least this many, else 64 x 64 (two or three workgroups per CU hide each
                               // other's barriers); K is split until the launch has this many workgroups.  Measured (profiles/r02/exp_gemm_shapes.log):
                               // config 4 pair 148.5 us at 512 with 64 x 64 tiles against 155.5 (128 x 128, 256) and 164.1 (64 x 64, 256)
-    int gemm_wk = 5;          // ... K split over wave groups INSIDE the workgroup when that fills the chip without slabs (cgemm.hip gemm_dma_plan):
-                              // bit 0 64 x 64 tiles with two K-groups (8 waves), bit 1 64 x 32 with two, bit 2 32 x 32 with four; 0: round 2's forms only
+    int gemm_wk = 1;          // ... K split over wave groups INSIDE the workgroup when that fills the chip without slabs (cgemm.hip gemm_dma_plan):
+                              // bit 0 64 x 64 tiles with two K-groups (8 waves); experiment builds: bit 1 64 x 32 with two, bit 2 32 x 32 with four;
+                              // 0: round 2's forms only.  Config 4 (profiles/r03/exp_gemm_forms.log): 160.5 us at 0, 153.0 at 1, 155.3 at 2, 155.9 at 4
     int gemm_tile = 0;        // force its tile edge (64 / 128); 0 = auto
     int gemm_bm = 64;         // rows of the GEMM workgroup tile (64 or 128)
     int gemm_bk = 0;          // 0 default K-tile depth, 32 doubles it
