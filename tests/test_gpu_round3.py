@@ -348,3 +348,34 @@ def test_fftdft_2048_to_512_K8192_vs_oracle(pa):
     assert rel_max(tonp(op(a)), ref) < 1e-9
     g = crandn(rng, (512, 512))
     assert rel_max(tonp(op.adjoint(g)), O.MDFT(x, y, fx, fy, norm=1.0 / 8192).adjoint(g)) < 1e-9
+
+
+# ----------------------------------------------------------------------------- lean middle pass: long columns, windows, crops
+
+@pytest.mark.parametrize('M,N,m_in', [(8192, 64, 8192), (8192, 32, 5000), (4096, 128, 4096), (4096, 64, 1000), (2048, 256, 777),
+                                      (1024, 512, 1024)])
+@pytest.mark.parametrize('dtype,tol', [(np.complex64, 2e-5), (np.complex128, 1e-11)])
+def test_fused_chain_lean_middle_pass_shapes(pa, M, N, m_in, dtype, tol):
+    """window(ifft2(fft2(pad(x)) H)) on tall arrays: the lean middle pass at 1024 ... 8192-point columns (512- and 1024-thread tiles),
+    zero-padded input windows (rows synthesised in the load), separable and full multipliers, conj H, a cropped output -- against
+    numpy in fp64"""
+    from prysm_amd import _ops
+    rng = np.random.default_rng(M + N + m_in)
+    x = crandn(rng, (m_in, N), dtype)
+    off = ((M - m_in + 1) // 2, 0)
+    P = np.zeros((M, N), np.complex128)
+    P[off[0]:off[0] + m_in] = x
+    F = np.fft.fft2(P)
+    hy, hx = np.exp(1j * rng.standard_normal(M)).astype(dtype), np.exp(1j * rng.standard_normal(N)).astype(dtype)
+    H = crandn(rng, (M, N), dtype)
+    xt = torch.from_numpy(x).cuda()
+    sc = 1.0 / (M * N)
+    # separable multiplier, full output
+    got = tonp(_ops.fft2_mul_ifft2(xt, scale=sc, mul=torch.from_numpy(hy).cuda(), mul_x=torch.from_numpy(hx).cuda(), shape=(M, N), in_off=off))
+    ref = np.fft.ifft2(F * np.outer(hy.astype(np.complex128), hx.astype(np.complex128)))
+    assert rel_max(got, ref) < tol
+    # full multiplier, conjugated, output cropped to the input window
+    got = tonp(_ops.fft2_mul_ifft2(xt, scale=sc, mul=torch.from_numpy(H).cuda(), mul_conj=True, shape=(M, N), in_off=off,
+                                   out_shape=(m_in, N), out_off=off))
+    ref = np.fft.ifft2(F * np.conj(H.astype(np.complex128)))[off[0]:off[0] + m_in]
+    assert rel_max(got, ref) < tol
