@@ -200,12 +200,8 @@ def _local_sum(amplitude, opd, wavelengths, weights, lo, hi, dx, efl, Q, focal_d
                 return first * w if w != 1.0 else first
             return focus_intensity(src, Q, out=acc, weight=w, synth=syn)
         ex = wf.prepare_executor(efl, focal_dx, samples, kind=kind)
-        if hasattr(ex, 'intensity'):       # matrix DFT: |.|^2 and the weighted accumulate in the second product's epilogue
-            return ex.intensity(wf.data, out=acc, weight=w)
-        E = wf.focus_dft(ex).data
-        if acc is None:
-            acc = torch.zeros(E.shape, dtype=L._REAL_OF[E.dtype], device=E.device)
-        return _ops.abs2(E, out=acc, weight=w)
+        # matrix DFT: |.|^2 and the weighted accumulate in the second product's epilogue; chirp-Z / FFT-DFT: composed
+        return wf.focus_dft_intensity(ex, out=acc, weight=w).data
 
     return _loop_sum(propagate, wavelengths, weights, lo, hi)
 

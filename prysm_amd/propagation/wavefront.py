@@ -380,6 +380,23 @@ class Wavefront:
         data = focus_dft(self.data, executor)
         return Wavefront(dx=executor.focal_dx, cmplx_field=data, wavelength=self.wavelength, space='psf')
 
+    def focus_dft_intensity(self, executor, out=None, weight=1.0):
+        """``self.focus_dft(executor).intensity`` with the modulus (and an optional weighted accumulate into `out`) in the epilogue of
+        the executor's last product -- no complex focal field in memory (MDFT executors: pm_cgemm_abs2; others compose).  The
+        counterpart of focus_intensity for the fixed-sampling focus; the polychromatic driver's variant M uses it per wavelength."""
+        if self.space != 'pupil':
+            raise ValueError('can only propagate from a pupil to psf plane')
+        if hasattr(executor, 'intensity'):
+            data = executor.intensity(self.data, out=out, weight=weight)
+        else:
+            E = focus_dft(self.data, executor)
+            if out is None:
+                data = _ops.abs2(E)
+                data = data if weight == 1.0 else data * weight
+            else:
+                data = _ops.abs2(E, out=out, weight=weight)
+        return RichData(data, executor.focal_dx, self.wavelength)
+
     def focus_dft_adjoint(self, executor):
         """Apply the adjoint of focus_dft (wavefront.py:698-718)."""
         if self.space != 'psf':

@@ -379,3 +379,28 @@ def test_fused_chain_lean_middle_pass_shapes(pa, M, N, m_in, dtype, tol):
                                    out_shape=(m_in, N), out_off=off))
     ref = np.fft.ifft2(F * np.conj(H.astype(np.complex128)))[off[0]:off[0] + m_in]
     assert rel_max(got, ref) < tol
+
+
+def test_wavefront_focus_dft_intensity(pa):
+    """Wavefront.focus_dft_intensity == focus_dft(...).intensity for the three executor kinds (the matrix DFT with the modulus in its
+    second product's epilogue), with and without a weighted accumulate"""
+    P = pa.propagation
+    rng = np.random.default_rng(5)
+    amp = (rng.random((256, 256)) > 0.3).astype(np.float32)
+    opd = (100 * rng.standard_normal((256, 256))).astype(np.float32)
+    prec = pa.config.precision
+    pa.config.precision = 32
+    try:
+        wf = P.Wavefront.from_amp_and_phase(amp, opd, 0.55, 0.04)
+        for kind in ('mdft', 'czt'):
+            ex = wf.prepare_executor(100.0, 1.0, 128, kind=kind)
+            want = tonp(wf.focus_dft(ex).intensity.data).astype(np.float64)
+            got = wf.focus_dft_intensity(ex)
+            assert got.dx == ex.focal_dx and rel_max(tonp(got.data), want) < 2e-5, kind
+            acc = torch.full((128, 128), 1.0, device='cuda')
+            wf.focus_dft_intensity(ex, out=acc, weight=0.5)
+            assert rel_max(tonp(acc), 1.0 + 0.5 * want) < 2e-5, kind
+    finally:
+        pa.config.precision = prec
+    with pytest.raises(ValueError):
+        P.Wavefront(np.ones((8, 8), complex), 0.5, 1.0, space='psf').focus_dft_intensity(None)
