@@ -19,7 +19,13 @@ After the timed region, outside of it and on every rank:
 * ``polychromatic``: BASELINE config 5 as ONE timed call of prysm_amd.polychromatic.polychromatic_psf -- 64
   wavelengths x 4096^2 fp32 sharded over the N ranks, |.|^2 accumulated per rank, one sum-reduce of the image to rank 0
   over RCCL -- variant F (FFT focus, Q = 1) and variant M (matrix-DFT focus 4096^2 -> 512^2 on MFMA), plus the
-  reduce of the 67 MB fp32 image on its own (``reduce_ms``).
+  reduce of the 67 MB fp32 image on its own in both root-only forms (``reduce_alone_ms``: one torch.distributed.reduce, and
+  all-to-all of slices + ordered local sum + gather); variant F with either form (``--reduce-method auto`` reports the
+  faster) and as a pipelined sequence of PSFs (PsfPipeline: frame k's reduce on a side stream under frame k + 1's
+  transforms); ``scaling_model``: what N = 2, 4, 8 should do, from this run's per-wavelength time.
+
+The headline line is complete before any of that starts; if the side measurements hang (their collectives meet RCCL on
+an N > 1 node for the first time in the driver's runs) a watchdog prints it without them after --extras-budget seconds.
 
 Rank 0 prints ONE JSON line.  ``roofline``: the dominant kernel (the slower of the two FFT passes), its duration
 measured with HIP events recorded between the kernels on the launch stream, in sequence; achieved = 2 N^2 s
