@@ -594,6 +594,15 @@ static bool plan_fused(const pm_fft2_desc* d, FusedPlan& p) {
     return true;
 }
 
+// Last row pass of the fused chains: streaming (non-temporal) stores -- the output is written once, in whole rows, and every line it does
+// not leave in the caches is a line of the intermediate that stays.  Measured (profiles/r03/exp_nt_rows.log, chain us without / with):
+// 4096^2 complex128 (256 MiB out) 344-347 / 320-321, padded 2048^2 -> 4096^2 complex128 343 / 326, 4096^2 complex64 (128 MiB) 167.7 /
+// 163.3, 2048^2 complex64 54.6 / 52.7, 2048^2 complex128 83.0 / 82.8.  Not beyond the Infinity Cache's size class (the two-pass
+// transform's column store lost 10 % with streaming stores at 512 MiB and 1 GiB, make_colstore).
+static int row_store_nt(size_t out_bytes) {
+    return tuning().nt_out >= 0 ? tuning().nt_out : ((out_bytes >= (size_t(24) << 20) && out_bytes < (size_t(384) << 20)) ? 1 : 0);
+}
+
 template <typename T>
 static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void* in, void* out, void* ws, hipStream_t st, int nb) {
     const int64_t M = d->in_y.n, N = d->in_x.n;
@@ -635,6 +644,7 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
         if (rc) return rc;
         RowLoadFold<T> rl{W1, plane, H, ltl, twM, 1, 0};
         RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), int(M), 1, T(d->scale), 1, to_map(d->out_y), 0, H};
+        rs.nt = row_store_nt(size_t(d->out_y.len) * size_t(d->out_x.len) * sizeof(cx<T>));
         return launch_row_unfold<T>(p.logn, rl, rs, twN, H, st, 1);
     }
     // pass A: forward row transforms of the stored input rows -> tiled W1
@@ -669,6 +679,7 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
     }
     RowLoadTiled<T> rl{W2, int(M), ltl, row0, nrun, 1, wstride};
     RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), nrun, 1, T(d->scale), 1, oy, d->out_bstride};
+    rs.nt = row_store_nt(size_t(p.nbatch) * size_t(d->out_y.len) * size_t(d->out_x.len) * sizeof(cx<T>));
     return launch_row_from_tiled<T>(p.logn, row_variant(d->dtype, p.logn), rl, rs, twN, nrun, st, nb);
 }
 
@@ -1160,6 +1171,7 @@ static int herm_conv_run(const pm_fft2_desc* d, const HermConvPlan& p, const voi
         RowLoadFold<T> rlf{W, plane, H, ltl, twm, 0, 0};
         RowStoreNat<T> rof{reinterpret_cast<cx<T>*>(out), d->out_ld / 2, AxisMap{int(n2), int(n2), 0, int(d->out_x.shift / 2)}, int(M), 1,
                            T(d->scale), 1, to_map(d->out_y), 0, H};
+        rof.nt = row_store_nt(size_t(M) * size_t(N) * sizeof(T));
         rcf = launch_row_c2r_fold<T>(p.logn - 1, rlf, rof, tw2, twn, H, st);
         return rcf < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: no folded half-spectrum row kernel for %lld points", (long long)N) : rcf;
     }
@@ -1176,6 +1188,7 @@ static int herm_conv_run(const pm_fft2_desc* d, const HermConvPlan& p, const voi
     RowLoadTiled<T> rl{W, int(M), ltl, 0, int(M), 0, 0};
     RowStoreNat<T> ro{reinterpret_cast<cx<T>*>(out), d->out_ld / 2, AxisMap{int(n2), int(n2), 0, int(d->out_x.shift / 2)}, int(M), 1,
                       T(d->scale), 1, to_map(d->out_y), 0, 0};
+    ro.nt = row_store_nt(size_t(M) * size_t(N) * sizeof(T));
     rc = launch_row_c2r<T>(p.logn - 1, rl, ro, tw2, twn, int(M), st);
     return rc < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: no half-spectrum row kernel for %lld points", (long long)N) : rc;
 }

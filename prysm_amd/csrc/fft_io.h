@@ -87,6 +87,7 @@ struct RowStoreNat {
     AxisMap ay;
     int64_t bstride;   // elements between consecutive fields of a batch (blockIdx.y); 0 / absent: one field
     int eoff;          // E > 1: sequence of slot e is unit*E + e (0) or unit + e*eoff (the pair (n, n + M/2) of an unfolded transform)
+    int nt;            // non-temporal stores (the output is written exactly once and is about the size of the Infinity Cache)
 };
 
 // row pass reading the tiled intermediate (third pass of the fused fft2 -> multiply -> ifft2)
@@ -513,7 +514,10 @@ PM_HD void store_rot(const RowStoreNat<typename C::T>& p, int blk, ThreadPos pos
             if (pp < lo || pp >= hi) continue;
             cx<T> val = cscale(v[e][m], p.scale);
             if (p.conj) val.y = -val.y;
-            row[pp] = val;
+            if (p.nt)
+                nt_store_cx(row + pp, val);
+            else
+                row[pp] = val;
         }
     }
 }
