@@ -107,14 +107,14 @@ __global__ void __launch_bounds__(C::NT) fft_row_c2r_kernel(const L lp, const Ro
     cx<T> v[C::E][C::P];
     const cx<T> wt = twn[pos.t];
     load<C>(lp, unit, pos, v);
-    // partner exchange: every sequence of the workgroup in natural order (one LDS region per slot e), then Z[(N2 - k) mod N2]
+    // partner exchange, one slot e at a time through the same LDS region (see fft_row_r2c_kernel): the sequences of the workgroup in
+    // natural order, then Z[(N2 - k) mod N2]
 #pragma unroll
-    for (int e = 0; e < C::E; ++e)
+    for (int e = 0; e < C::E; ++e) {
+        if (e > 0) __syncthreads();
 #pragma unroll
-        for (int m = 0; m < C::P; ++m) lds[e * C::LDS_ELEMS + lds_addr<C>(pos.bo, 0, pos.t + m * C::TPS)] = v[e][m];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < C::E; ++e)
+        for (int m = 0; m < C::P; ++m) lds[lds_addr<C>(pos.bo, 0, pos.t + m * C::TPS)] = v[e][m];
+        __syncthreads();
 #pragma unroll
         for (int m = 0; m < C::P; ++m) {
             const int k = pos.t + m * C::TPS;
@@ -123,13 +123,14 @@ __global__ void __launch_bounds__(C::NT) fft_row_c2r_kernel(const L lp, const Ro
             if (k == 0) {
                 zp = {z.x + z.y, z.x - z.y};       // X[0] and X[N/2] (both real) share column 0: E[0] + i O[0], doubled like the rest
             } else {
-                const cx<T> q = lds[e * C::LDS_ELEMS + lds_addr<C>(pos.bo, 0, N2 - k)];
+                const cx<T> q = lds[lds_addr<C>(pos.bo, 0, N2 - k)];
                 const cx<T> ev = {z.x + q.x, z.y - q.y};                                   // 2 E[k] = Z[k] + conj Z[N/2 - k]
                 const cx<T> od = cmulc(cx<T>{z.x - q.x, z.y + q.y}, cmul(wt, w32<T>(m)));    // 2 O[k] = (Z[k] - conj Z[N/2 - k]) conj W_N^k
                 zp = ev + mul_pi(od);
             }
             v[e][m] = {zp.x, -zp.y};
         }
+    }
     __syncthreads();     // the transform's exchange reuses this LDS
     if constexpr (C::E == 2 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
     else fft_run<C>(v, pos, pm_smem, tw);
@@ -171,7 +172,7 @@ template <typename T, int LOGN2, int VAR>
 int launch_row_c2r_one(const RowLoadTiled<T>& lp, const RowStoreNat<T>& sp, const cx<T>* tw, const cx<T>* twn, int nseq, hipStream_t st) {
     using C = typename RowCfgSel<T, LOGN2, VAR>::type;
     auto kern = fft_row_c2r_kernel<C, RowLoadTiled<T>>;
-    constexpr size_t part = size_t(C::E) * C::LDS_ELEMS * sizeof(cx<T>);
+    constexpr size_t part = size_t(C::LDS_ELEMS) * sizeof(cx<T>);
     constexpr size_t LDSB = C::LDS_BYTES > part ? C::LDS_BYTES : part;
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
@@ -207,7 +208,7 @@ template <typename T, int LOGN2>
 int launch_row_c2r_fold_one(const RowLoadFold<T>& lp, const RowStoreNat<T>& sp, const cx<T>* tw, const cx<T>* twn, int npairs, hipStream_t st) {
     using C = typename RowCfgSel<T, LOGN2, 4>::type;       // two rows per thread: the pair (n, n + M/2) the unfold rebuilds
     auto kern = fft_row_c2r_kernel<C, RowLoadFold<T>>;
-    constexpr size_t part = size_t(C::E) * C::LDS_ELEMS * sizeof(cx<T>);
+    constexpr size_t part = size_t(C::LDS_ELEMS) * sizeof(cx<T>);
     constexpr size_t LDSB = C::LDS_BYTES > part ? C::LDS_BYTES : part;
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));

@@ -59,13 +59,22 @@ __global__ void __launch_bounds__(C::NT) fft_row_r2c_kernel(const L lp, const R2
     else fft_run<C>(v, pos, pm_smem, tw);
     constexpr int N2 = C::N;          // complex points per row = N / 2
     const int tcm = (1 << sp.log_tc) - 1;
-    // partner exchange: every sequence of the workgroup in natural order (one LDS region per slot e), then read Z[(N2 - k) mod N2]
-    __syncthreads();
+    // partner exchange, ONE slot e at a time through the same LDS region: the sequences of the workgroup in natural order, then each
+    // thread combines its bins with Z[(N2 - k) mod N2] in place.  (Both slots at once doubled the kernel's LDS -- 69.6 KiB at 2048
+    // complex points with two rows per thread: two 256-thread workgroups per CU instead of four.)
 #pragma unroll
-    for (int e = 0; e < C::E; ++e)
+    for (int e = 0; e < C::E; ++e) {
+        __syncthreads();
 #pragma unroll
-        for (int m = 0; m < C::P; ++m) lds[e * C::LDS_ELEMS + lds_addr<C>(pos.bo, 0, pos.t + m * C::TPS)] = v[e][m];
-    __syncthreads();
+        for (int m = 0; m < C::P; ++m) lds[lds_addr<C>(pos.bo, 0, pos.t + m * C::TPS)] = v[e][m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) {
+            const int k = pos.t + m * C::TPS;
+            const cx<T> zp = lds[lds_addr<C>(pos.bo, 0, (N2 - k) & (N2 - 1))];
+            v[e][m] = r2c_combine(v[e][m], zp, cmul(wt, w32<T>(m)), k == 0);
+        }
+    }
     if constexpr (FOLD) {
         const int i = unit * C::BO + pos.bo;       // pair index = logical row of the lower half
         if (i >= sp.nseq) return;
@@ -74,10 +83,7 @@ __global__ void __launch_bounds__(C::NT) fft_row_r2c_kernel(const L lp, const R2
 #pragma unroll
         for (int m = 0; m < C::P; ++m) {
             const int k = pos.t + m * C::TPS;
-            const int pa = lds_addr<C>(pos.bo, 0, (N2 - k) & (N2 - 1));
-            const cx<T> w = cmul(wt, w32<T>(m));
-            const cx<T> x0 = r2c_combine(v[lo][m], lds[lo * C::LDS_ELEMS + pa], w, k == 0);
-            const cx<T> x1 = r2c_combine(v[hi][m], lds[hi * C::LDS_ELEMS + pa], w, k == 0);
+            const cx<T> x0 = v[lo][m], x1 = v[hi][m];
             const int64_t a = ((int64_t(k >> sp.log_tc) * sp.nseq + i) << sp.log_tc) + (k & tcm);
             sp.dst[a] = x0 + x1;
             sp.dst[a + sp.plane_stride] = cmul(x0 - x1, wi);
@@ -90,9 +96,8 @@ __global__ void __launch_bounds__(C::NT) fft_row_r2c_kernel(const L lp, const R2
 #pragma unroll
             for (int m = 0; m < C::P; ++m) {
                 const int k = pos.t + m * C::TPS;
-                const cx<T> zp = lds[e * C::LDS_ELEMS + lds_addr<C>(pos.bo, 0, (N2 - k) & (N2 - 1))];
                 const int64_t a = ((int64_t(k >> sp.log_tc) * sp.nseq + seq) << sp.log_tc) + (k & tcm);
-                sp.dst[a] = r2c_combine(v[e][m], zp, cmul(wt, w32<T>(m)), k == 0);
+                sp.dst[a] = v[e][m];
             }
         }
     }
@@ -293,9 +298,9 @@ template <typename T, int LOGN2, int VAR, bool FOLD>
 int launch_row_r2c_one(const RowLoadNat<T>& lp, const R2CRowStore<T>& sp, const cx<T>* tw, int nunits, int log_g, hipStream_t st) {
     using C = typename RowCfgSel<T, LOGN2, VAR>::type;
     auto kern = fft_row_r2c_kernel<C, RowLoadNat<T>, FOLD>;
-    // the partner exchange keeps every sequence of the workgroup in LDS (one region per slot e), also when the transform itself
-    // has a single stage
-    constexpr size_t part = size_t(C::E) * C::LDS_ELEMS * sizeof(cx<T>);
+    // the partner exchange keeps the sequences of the workgroup in LDS (one slot e at a time), also when the transform itself has a
+    // single stage
+    constexpr size_t part = size_t(C::LDS_ELEMS) * sizeof(cx<T>);
     constexpr size_t LDSB = C::LDS_BYTES > part ? C::LDS_BYTES : part;
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
