@@ -1205,7 +1205,8 @@ static bool spectral_fast(const pm_fft2_desc* d, const Fft2Plan& p) {
     if (d->dtype == PM_C128 && (p.logn > 11 || p.fold)) return false;
     return tuning().spectral > 1 && (d->flags & want) == want && !(d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY)) &&
            d->epilogue == PM_EPI_ABS2_ACCUM && d->batch <= 1 && d->mul_kind == PM_MUL_NONE && !p.r2c && !p.big_rn && !p.blue2d &&
-           p.logn >= 5 && p.logm >= (p.fold ? 6 : 5) && p.logm - (p.fold ? 1 : 0) <= 11 /* the accumulating column kernel spills beyond 2048-point tiles */ &&
+           p.logn >= 5 && p.logn <= 12 /* its row kernel spills hundreds of registers at 8192-point rows (two rows per thread + the packed map) */ &&
+           p.logm >= (p.fold ? 6 : 5) && p.logm - (p.fold ? 1 : 0) <= 11 /* the accumulating column kernel spills beyond 2048-point tiles */ &&
            p.tc != 0 && p.col_var == 0 && d->in_y.len > 0 && p.logn + p.logm < tuning().spectral_area_log;
 }
 static int spectral_group(int32_t count) {

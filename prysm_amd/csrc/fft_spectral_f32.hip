@@ -17,9 +17,7 @@ int launch_row_spectral<float>(int logn, int var, const RowLoadNat<float>& l, co
                                  : launch_row_spectral_one<T, 11, 0, S>(l, s, tw, nseq, log_g, w, st);
         case 12: return var == 4 ? launch_row_spectral_one<T, 12, 4, S>(l, s, tw, nseq, log_g, w, st)
                                  : launch_row_spectral_one<T, 12, 0, S>(l, s, tw, nseq, log_g, w, st);
-        case 13: return var == 4 ? launch_row_spectral_one<T, 13, 4, S>(l, s, tw, nseq, log_g, w, st)
-                                 : launch_row_spectral_one<T, 13, 0, S>(l, s, tw, nseq, log_g, w, st);
-        default: return -2;
+        default: return -2;     // 8192-point rows take the per-wavelength loop (capi.hip spectral_fast): this kernel spilled there
     }
 }
 
@@ -31,7 +29,6 @@ int launch_row_spectral_fold<float>(int logn, const RowLoadNat<float>& l, const 
     switch (logn) {
         case 11: return launch_row_spectral_one<T, 11, 4, S>(l, s, tw, npairs, 0, w, st);
         case 12: return launch_row_spectral_one<T, 12, 4, S>(l, s, tw, npairs, 0, w, st);
-        case 13: return launch_row_spectral_one<T, 13, 4, S>(l, s, tw, npairs, 0, w, st);
         default: return -2;
     }
 }
