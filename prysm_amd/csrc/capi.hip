@@ -125,6 +125,8 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("nt_out")) t.nt_out = v;
     else if (is("fold")) t.fold = v;
     else if (is("mixed_radix")) t.mixed_radix = v ? 1 : 0;
+    else if (is("mix")) t.mix = v < 0 ? 0 : (v > 2 ? 2 : v);
+    else if (is("mix_min")) t.mix_min = v < 18 ? 18 : v;
     else if (is("r2c")) t.r2c = v < 0 ? -1 : (v > 1 ? 2 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
     else if (is("colmul_mode")) t.colmul_mode = v;
@@ -205,6 +207,7 @@ struct Fft2Plan {
                           // Infinity Cache between the two passes, consecutive chunks reuse the same workspace
     bool fold;            // one radix-2 step of the column transform is taken in the row pass (RowStoreFold): the column
                           // pass then runs two planes of M/2-point tiles
+    bool mix_n, mix_m;    // the row / column transforms take the mixed-radix kernel (composite lengths, fft_mixed.hip)
     bool blue_n, blue_m;  // the row / column transforms take the Bluestein path (non-power-of-two lengths, bluestein.hip)
     size_t blue_off;      // its scratch sits behind the intermediates in the workspace (shared by the two passes)
     int big_rn, big_rm;   // power-of-two lengths above the engine's: radix of the extra step per axis (1 = none), 0 = not this path
@@ -309,6 +312,7 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
     p.big_rm = big_split(M);
     if (!(p.big_rn && p.big_rm && (p.big_rn > 1 || p.big_rm > 1)) || (d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY | PM_FLAG_SYNTH_INPUT)))
         p.big_rn = p.big_rm = 0;
+    p.mix_n = p.mix_m = false;
     if (p.big_rn) {   // [Z: R_n planes of M x N/R_n | F (and the pre-processed rows before it): the same size]
         p.tc = 0;
         p.fold = false;
@@ -318,6 +322,8 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
         p.ws_bytes = 2 * arr;
         return p;
     }
+    p.mix_n = p.logn < 0 && use_mix(N);
+    p.mix_m = p.logm < 0 && use_mix(M);
     p.blue_n = p.logn < 0 && use_blue(N);
     p.blue_m = p.logm < 0 && use_blue(M);
     p.blue_off = (p.ws_bytes + 255) & ~size_t(255);
@@ -481,7 +487,9 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
             DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), d->in_ld, 1, to_map(d->in_x), rows, conj,
                            (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
             int rc;
-            if (p.blue_n) {
+            if (p.mix_n) {
+                rc = mix_rows<T>(di, W, N, st);
+            } else if (p.blue_n) {
                 rc = blue_rows<T>(di, W, N, static_cast<char*>(ws) + p.blue_off, st);
             } else {
                 const cx<double>* tw = twiddles_f64(N, &err);
@@ -523,6 +531,7 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         return launch_col_nat<T>(p.logm, 0, cl, cs, tw, ntiles, 1, st);
     }
     DirectIn<T> di{W, 1, N, to_map(d->in_y), int(N), 0};   // sequence = column c at W[c], element stride N
+    if (p.mix_m) return mix_cols<T>(di, cs, st);
     if (p.blue_m) return blue_cols<T>(di, cs, static_cast<char*>(ws) + p.blue_off, st);
     const cx<double>* tw = twiddles_f64(M, &err);
     if (!tw) return err;
@@ -1047,6 +1056,7 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
             return launch_row_nat<T>(lg, row_variant(sizeof(T) == 4 ? PM_C64 : PM_C128, lg), lp, sp, tw, int(batch), 0, st);
         }
         DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), in_ld, 1, to_map(*ti), int(batch), conj};
+        if (use_mix(n)) return mix_rows<T>(di, nullptr, 0, st, &sp);
         if (blue_ws) return blue_rows<T>(di, nullptr, 0, blue_ws, st, &sp);
         const cx<double>* tw = twiddles_f64(n, &err);
         if (!tw) return err;
@@ -1074,6 +1084,7 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
         return launch_col_nat<T>(lg, tuning().col_var, cl, cs, tw, ntiles, 1, st);
     }
     DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), 1, in_ld, to_map(*ti), int(batch), conj};
+    if (use_mix(n)) return mix_cols<T>(di, cs, st);
     if (blue_ws) return blue_cols<T>(di, cs, blue_ws, st);
     const cx<double>* tw = twiddles_f64(n, &err);
     if (!tw) return err;
@@ -1297,6 +1308,7 @@ int pm_plan_prepare(int32_t dtype, int64_t n) {
         if (!ok) return err;
         if (engine_log2(n) >= 0 || !use_blue_long(n)) return 0;     // a mixed-radix length beside an awkward one still takes Bluestein
     }
+    if (use_mix(n)) return (dtype == PM_C64 ? (const void*)twiddles<float>(n, &err) : (const void*)twiddles<double>(n, &err)) ? 0 : err;
     if (use_blue_long(n)) {   // Bluestein tables of n and the twiddles of the convolution length (of its engine part when it is split)
         const int64_t mb = blue_conv_len(n), part = mb / big_split(mb);
         if (dtype == PM_C64) return (blue_tables<float>(n, &err) && twiddles<float>(mb, &err) && twiddles<float>(part, &err)) ? 0 : err;

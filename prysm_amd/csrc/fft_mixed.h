@@ -1,0 +1,384 @@
+// Composite lengths on their own factors: n = r0 r1 ... with every factor <= 16 (all lengths whose primes are <= 13: 1000, 3000,
+// 2592, 1001 ...) as ONE kernel per axis, in place of Bluestein's convolution of >= 2n - 1 points per axis (>= 4x the area in 2-D).
+// The reference reaches these lengths through scipy.fft / pocketfft, which factors them the same way (prysm/propagation/fft.py:24,
+// prysm/fttools.py:23-31, prysm/propagation/angular_spectrum.py:35-42).
+//
+// Algorithm: decimation in frequency, IN PLACE in LDS (a butterfly writes the slots it read, so one buffer serves any number of
+// butterflies per thread), one barrier per stage:
+//
+//     stage s works on blocks of L_s = n / (r0 .. r_{s-1}) points:  y[j + k L_s/r] = W_{L_s}^{jk} sum_m x[j + m L_s/r] W_r^{mk}
+//
+// after the last stage slot p = sum_s k_s L_{s+1} holds bin k0 + r0 k1 + r0 r1 k2 + ...  The first stage reads the caller's array
+// (window / rotation / real / conjugate: the DirectIn view) and the last one writes the destination, so the data crosses LDS
+// (stages - 1) times.  The last stage has no twiddles (the planner puts the largest factor there) and enumerates its butterflies by the
+// LOW digits of the bin index, so that adjacent lanes store adjacent bins.
+//
+// The factor of each stage is a run-time value (one kernel serves every length); the small DFTs are compile-time (switch over 2 .. 16).
+// Row mode: a workgroup holds `seqs` memory rows, lanes run along the row.  Column mode: `seqs` adjacent columns (a power of two),
+// lanes run across the columns first -- pieces of seqs elements per row of the array.
+//
+// Everything below the kernels is __host__ __device__ so that tools/emu_mix.cpp can run the index arithmetic on the CPU.
+#pragma once
+#include "bluestein.h"
+#include "fft_engine.h"
+#include "fft_io.h"
+
+namespace pm {
+
+constexpr int kMixMaxStages = 6;
+constexpr int kMixMaxN = 8192;
+constexpr int kMixMaxRadix = 16;
+
+// ---------------------------------------------------------------------------
+// compile-time roots of unity (octant reduction + Taylor series on [0, pi/4]; ~1 ulp)
+// ---------------------------------------------------------------------------
+constexpr double mix_sin_small(double x) {
+    double x2 = x * x, t = x, s = x;
+    for (int i = 1; i < 14; ++i) {
+        t *= -x2 / double((2 * i) * (2 * i + 1));
+        s += t;
+    }
+    return s;
+}
+constexpr double mix_cos_small(double x) {
+    double x2 = x * x, t = 1.0, s = 1.0;
+    for (int i = 1; i < 14; ++i) {
+        t *= -x2 / double((2 * i - 1) * (2 * i));
+        s += t;
+    }
+    return s;
+}
+// cos / sin of 2 pi num / den
+constexpr double mix_root(int num, int den, bool want_sin) {
+    const double quarter_pi = 0.78539816339744830961566084581988;
+    num %= den;
+    if (num < 0) num += den;
+    const int oct = (8 * num) / den, rem = 8 * num - oct * den;
+    const double r = quarter_pi * double(rem) / double(den), rc = quarter_pi * double(den - rem) / double(den);
+    double c = 0, s = 0;
+    switch (oct) {
+        case 0: c = mix_cos_small(r); s = mix_sin_small(r); break;
+        case 1: c = mix_sin_small(rc); s = mix_cos_small(rc); break;
+        case 2: c = -mix_sin_small(r); s = mix_cos_small(r); break;
+        case 3: c = -mix_cos_small(rc); s = mix_sin_small(rc); break;
+        case 4: c = -mix_cos_small(r); s = -mix_sin_small(r); break;
+        case 5: c = -mix_sin_small(rc); s = -mix_cos_small(rc); break;
+        case 6: c = mix_sin_small(r); s = -mix_cos_small(r); break;
+        default: c = mix_cos_small(rc); s = -mix_sin_small(rc); break;
+    }
+    return want_sin ? s : c;
+}
+template <int R>
+struct MixRootTab {
+    double c[R], s[R];
+    constexpr MixRootTab() : c{}, s{} {
+        for (int k = 0; k < R; ++k) {
+            c[k] = mix_root(k, R, false);
+            s[k] = mix_root(k, R, true);
+        }
+    }
+};
+template <int R>
+struct MixRoots {
+    static constexpr MixRootTab<R> tab{};
+};
+
+// ---------------------------------------------------------------------------
+// small DFTs beyond the engine's 2 / 4 / 8 / 16: odd primes by the symmetric half sums, composites by one Cooley-Tukey split with
+// compile-time twiddles.  Forward sign, natural order in and out.
+// ---------------------------------------------------------------------------
+template <typename T, int R>
+struct MixDft {
+    static PM_HD void run(cx<T>* a) { Dft<T, R>::run(a); }
+};
+
+template <typename T, int R>
+PM_HD void mix_dft_odd(cx<T>* a) {
+    constexpr int H = (R - 1) / 2;
+    cx<T> p[H + 1], q[H + 1];
+    cx<T> sum = a[0];
+#pragma unroll
+    for (int m = 1; m <= H; ++m) {
+        p[m] = a[m] + a[R - m];
+        q[m] = a[m] - a[R - m];
+        sum = sum + p[m];
+    }
+    const cx<T> x0 = a[0];
+    a[0] = sum;
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
+        cx<T> A = x0, B = {T(0), T(0)};
+#pragma unroll
+        for (int m = 1; m <= H; ++m) {
+            const T c = T(MixRoots<R>::tab.c[(m * k) % R]), s = T(MixRoots<R>::tab.s[(m * k) % R]);
+            A.x += p[m].x * c;
+            A.y += p[m].y * c;
+            B.x += q[m].x * s;
+            B.y += q[m].y * s;
+        }
+        a[k] = {A.x + B.y, A.y - B.x};
+        a[R - k] = {A.x - B.y, A.y + B.x};
+    }
+}
+template <typename T> struct MixDft<T, 3> { static PM_HD void run(cx<T>* a) { mix_dft_odd<T, 3>(a); } };
+template <typename T> struct MixDft<T, 5> { static PM_HD void run(cx<T>* a) { mix_dft_odd<T, 5>(a); } };
+template <typename T> struct MixDft<T, 7> { static PM_HD void run(cx<T>* a) { mix_dft_odd<T, 7>(a); } };
+template <typename T> struct MixDft<T, 11> { static PM_HD void run(cx<T>* a) { mix_dft_odd<T, 11>(a); } };
+template <typename T> struct MixDft<T, 13> { static PM_HD void run(cx<T>* a) { mix_dft_odd<T, 13>(a); } };
+
+// R = R1 R2, n = R2 n1 + n2, k = k1 + R1 k2
+template <typename T, int R1, int R2>
+PM_HD void mix_dft_ct(cx<T>* a) {
+    constexpr int R = R1 * R2;
+    cx<T> t[R1 > R2 ? R1 : R2];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) {
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) t[n1] = a[R2 * n1 + n2];
+        MixDft<T, R1>::run(t);
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            if (n2 * k1 % R != 0) {
+                const cx<T> w = {T(MixRoots<R>::tab.c[(n2 * k1) % R]), T(-MixRoots<R>::tab.s[(n2 * k1) % R])};
+                a[R2 * k1 + n2] = cmul(t[k1], w);
+            } else {
+                a[R2 * k1 + n2] = t[k1];
+            }
+        }
+    }
+    cx<T> o[R];
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) t[n2] = a[R2 * k1 + n2];
+        MixDft<T, R2>::run(t);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) o[k1 + R1 * k2] = t[k2];
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) a[k] = o[k];
+}
+template <typename T> struct MixDft<T, 6> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 3>(a); } };
+template <typename T> struct MixDft<T, 9> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 3, 3>(a); } };
+template <typename T> struct MixDft<T, 10> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 5>(a); } };
+template <typename T> struct MixDft<T, 12> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 4, 3>(a); } };
+template <typename T> struct MixDft<T, 14> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 7>(a); } };
+template <typename T> struct MixDft<T, 15> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 3, 5>(a); } };
+
+// ---------------------------------------------------------------------------
+// plan: factors (largest last), block lengths, exact division by multiply-high
+// ---------------------------------------------------------------------------
+struct MixPlan {
+    int n, nstage;
+    int radix[kMixMaxStages];
+    int len[kMixMaxStages + 1];     // len[s] = n / (radix[0] .. radix[s-1]); len[nstage] = 1
+    uint32_t mg_radix[kMixMaxStages];   // magic of radix[s]
+    uint32_t mg_sub[kMixMaxStages];     // magic of len[s + 1]
+    uint32_t mg_nb[kMixMaxStages];      // magic of n / radix[s] (butterflies of one sequence in stage s)
+    int seqs, log_seqs;             // sequences per workgroup (column mode: a power of two)
+    int npad;                       // LDS slots per sequence
+};
+
+// floor(a / d) for a d < 2^16 as (a * magic) >> 32, magic = floor(2^32 / d) + 1 (exact while a d < 2^32); d == 1: magic 0 = identity
+inline uint32_t mix_magic(int d) { return d <= 1 ? 0u : uint32_t((uint64_t(1) << 32) / uint64_t(d)) + 1u; }
+PM_HD int mix_div(int a, uint32_t magic) {
+    if (magic == 0) return a;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return int(__umulhi(uint32_t(a), magic));
+#else
+    return int((uint64_t(uint32_t(a)) * uint64_t(magic)) >> 32);
+#endif
+}
+
+PM_HD int mix_pad(int i) { return i + (i >> 4); }
+
+// fewest stages first, then the most even factors; returns false when n has a prime factor above 13 or needs more than kMixMaxStages
+inline bool mix_factor(int n, int* radix, int* nstage) {
+    if (n < 2 || n > kMixMaxN) return false;
+    int best[kMixMaxStages], cur[kMixMaxStages], bestn = kMixMaxStages + 1, bestmax = 0;
+    // depth-first over non-increasing factors
+    struct Rec {
+        static void go(int rem, int maxf, int depth, int* cur, int* best, int& bestn, int& bestmax) {
+            if (rem == 1) {
+                if (depth < bestn || (depth == bestn && cur[0] < bestmax)) {
+                    bestn = depth;
+                    bestmax = cur[0];
+                    for (int i = 0; i < depth; ++i) best[i] = cur[i];
+                }
+                return;
+            }
+            if (depth >= kMixMaxStages || depth + 1 > bestn) return;
+            for (int f = maxf; f >= 2; --f) {
+                if (rem % f) continue;
+                cur[depth] = f;
+                go(rem / f, f, depth + 1, cur, best, bestn, bestmax);
+            }
+        }
+    };
+    Rec::go(n, kMixMaxRadix, 0, cur, best, bestn, bestmax);
+    if (bestn > kMixMaxStages) return false;
+    // ascending: the largest factor runs last, where the twiddles are all one
+    for (int i = 0; i < bestn; ++i) radix[i] = best[bestn - 1 - i];
+    *nstage = bestn;
+    return true;
+}
+
+inline void mix_fill_plan(int n, const int* radix, int nstage, MixPlan& p) {
+    p = MixPlan{};
+    p.nstage = nstage;
+    for (int s = 0; s < nstage; ++s) p.radix[s] = radix[s];
+    p.n = n;
+    p.len[0] = n;
+    for (int s = 0; s < p.nstage; ++s) {
+        p.len[s + 1] = p.len[s] / p.radix[s];
+        p.mg_radix[s] = mix_magic(p.radix[s]);
+        p.mg_sub[s] = mix_magic(p.len[s + 1]);
+        p.mg_nb[s] = mix_magic(n / p.radix[s]);
+    }
+    p.npad = mix_pad(n) + 1;
+    p.seqs = 1;
+    p.log_seqs = 0;
+}
+inline bool mix_make_plan(int n, MixPlan& p) {
+    int radix[kMixMaxStages], nstage = 0;
+    if (!mix_factor(n, radix, &nstage) || nstage < 2) return false;
+    mix_fill_plan(n, radix, nstage, p);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// stages.  `tid` / `nt`: this thread and the threads of the workgroup; sl = sequence slot of the workgroup
+// ---------------------------------------------------------------------------
+template <bool COL>
+PM_HD int mix_addr(const MixPlan& p, int sl, int i) {
+    return COL ? ((mix_pad(i) << p.log_seqs) + sl) : (sl * p.npad + mix_pad(i));
+}
+template <bool COL>
+PM_HD void mix_split(const MixPlan& p, int b, uint32_t mg_nb, int nb, int& sl, int& j) {
+    if (COL) {
+        sl = b & (p.seqs - 1);
+        j = b >> p.log_seqs;
+    } else {
+        sl = mix_div(b, mg_nb);
+        j = b - sl * nb;
+    }
+}
+
+// first stage: caller's array -> LDS
+template <typename T, bool COL, int R, typename Fetch>
+PM_HD void mix_first(const MixPlan& p, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw, Fetch fetch) {
+    const int nb = p.len[1], total = p.seqs * nb;
+#pragma unroll 1
+    for (int b = tid; b < total; b += nt) {
+        int sl, j;
+        mix_split<COL>(p, b, p.mg_nb[0], nb, sl, j);
+        cx<T> a[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[k] = fetch(sl, j + k * nb);
+        MixDft<T, R>::run(a);
+        lds[mix_addr<COL>(p, sl, j)] = a[0];
+#pragma unroll
+        for (int k = 1; k < R; ++k) lds[mix_addr<COL>(p, sl, j + k * nb)] = cmul(a[k], tw[j * k]);
+    }
+}
+
+// middle stage s: LDS in place
+template <typename T, bool COL, int R>
+PM_HD void mix_mid(const MixPlan& p, int s, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw) {
+    const int nb = p.n / R, total = p.seqs * nb, sub = p.len[s + 1], L = p.len[s], tstep = p.n / L;
+#pragma unroll 1
+    for (int b = tid; b < total; b += nt) {
+        int sl, ja;
+        mix_split<COL>(p, b, p.mg_nb[s], nb, sl, ja);
+        const int blk = mix_div(ja, p.mg_sub[s]), j = ja - blk * sub, base = blk * L + j;
+        cx<T> a[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[k] = lds[mix_addr<COL>(p, sl, base + k * sub)];
+        MixDft<T, R>::run(a);
+        lds[mix_addr<COL>(p, sl, base)] = a[0];
+        const int tj = j * tstep;
+#pragma unroll
+        for (int k = 1; k < R; ++k) lds[mix_addr<COL>(p, sl, base + k * sub)] = cmul(a[k], tw[tj * k]);
+    }
+}
+
+// last stage: LDS -> destination; butterfly o (the low digits of the bin) produces bins o + k n / R
+template <typename T, bool COL, int R, typename Store>
+PM_HD void mix_last(const MixPlan& p, int tid, int nt, const cx<T>* lds, Store store) {
+    const int s = p.nstage - 1, nb = p.n / R, total = p.seqs * nb;
+#pragma unroll 1
+    for (int b = tid; b < total; b += nt) {
+        int sl, o;
+        mix_split<COL>(p, b, p.mg_nb[s], nb, sl, o);
+        int rem = o, pos = 0;
+        for (int i = 0; i < s; ++i) {
+            const int q = mix_div(rem, p.mg_radix[i]);
+            pos += (rem - q * p.radix[i]) * p.len[i + 1];
+            rem = q;
+        }
+        cx<T> a[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[k] = lds[mix_addr<COL>(p, sl, pos + k)];
+        MixDft<T, R>::run(a);
+#pragma unroll
+        for (int k = 0; k < R; ++k) store(sl, o + k * nb, a[k]);
+    }
+}
+
+#define PM_MIX_RADIX_SWITCH(r, CALL)                                                                                                     \
+    switch (r) {                                                                                                                         \
+        case 2: { constexpr int R = 2; CALL; } break;                                                                                    \
+        case 3: { constexpr int R = 3; CALL; } break;                                                                                    \
+        case 4: { constexpr int R = 4; CALL; } break;                                                                                    \
+        case 5: { constexpr int R = 5; CALL; } break;                                                                                    \
+        case 6: { constexpr int R = 6; CALL; } break;                                                                                    \
+        case 7: { constexpr int R = 7; CALL; } break;                                                                                    \
+        case 8: { constexpr int R = 8; CALL; } break;                                                                                    \
+        case 9: { constexpr int R = 9; CALL; } break;                                                                                    \
+        case 10: { constexpr int R = 10; CALL; } break;                                                                                  \
+        case 11: { constexpr int R = 11; CALL; } break;                                                                                  \
+        case 12: { constexpr int R = 12; CALL; } break;                                                                                  \
+        case 13: { constexpr int R = 13; CALL; } break;                                                                                  \
+        case 14: { constexpr int R = 14; CALL; } break;                                                                                  \
+        case 15: { constexpr int R = 15; CALL; } break;                                                                                  \
+        default: { constexpr int R = 16; CALL; } break;                                                                                  \
+    }
+
+// output of the row mode: natural rows (the intermediate of a 2-D transform) or the 1-D API's view (window / rotation, scale, conj)
+template <typename T>
+struct MixRowOut {
+    cx<T>* dst;
+    int64_t ld;
+    AxisMap ax;
+    T scale;
+    int conj;
+    int mapped;
+};
+
+template <typename T>
+PM_HD void mix_store_row(const MixRowOut<T>& o, int seq, int k, cx<T> v) {
+    if (o.mapped) {
+        const int q = o.ax.map(k);
+        if (q < 0) return;
+        v = cscale(v, o.scale);
+        if (o.conj) v.y = -v.y;
+        o.dst[int64_t(seq) * o.ld + q] = v;
+    } else {
+        o.dst[int64_t(seq) * o.ld + k] = v;
+    }
+}
+
+// one phase of the workgroup's work for thread `tid` (phase 0 = first stage, 1 .. nstage-2 = middle stages, nstage-1 = last stage);
+// the kernel puts a barrier between phases, the emulator runs every thread of a phase before the next one
+template <typename T, bool COL, typename Fetch, typename Store>
+PM_HD void mix_phase(const MixPlan& p, int phase, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw, Fetch fetch, Store store) {
+    if (phase == 0) {
+        PM_MIX_RADIX_SWITCH(p.radix[0], (mix_first<T, COL, R>(p, tid, nt, lds, tw, fetch)))
+    } else if (phase < p.nstage - 1) {
+        PM_MIX_RADIX_SWITCH(p.radix[phase], (mix_mid<T, COL, R>(p, phase, tid, nt, lds, tw)))
+    } else {
+        PM_MIX_RADIX_SWITCH(p.radix[phase], (mix_last<T, COL, R>(p, tid, nt, lds, store)))
+    }
+}
+
+}  // namespace pm

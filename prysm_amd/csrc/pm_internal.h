@@ -8,6 +8,8 @@
 
 namespace pm {
 
+bool mix_length(int64_t n);   // fft_mixed.hip: n (<= 8192) has a mixed-radix plan: at least two factors of at most 16 each
+
 // error plumbing (capi.hip)
 int fail(int code, const char* fmt, ...);
 inline int hip_rc(hipError_t e) { return int(e); }
@@ -48,6 +50,13 @@ template <typename T>
 int blue_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, void* scratch, hipStream_t st, const RowStoreNat<T>* o = nullptr);
 template <typename T>
 int blue_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, void* scratch, hipStream_t st);
+
+// Mixed-radix path (fft_mixed.hip): lengths up to 8192 whose prime factors are all <= 13, one kernel per axis with the data in LDS, no
+// scratch.  Same contracts as direct_rows / direct_rows_out (`o`) / direct_cols.
+template <typename T>
+int mix_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o = nullptr);
+template <typename T>
+int mix_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t st);
 
 // both axes at once (capi.hip blue2d_run): the chirp multiplies around ONE fused fft2 -> x (B1 (x) B2) -> ifft2 chain of size
 // MB1 x MB2 (the 2-D cyclic convolution with the separable chirp)
@@ -111,6 +120,9 @@ struct Tuning {
     int fold = -1;           // radix-2 step of the column transform folded into the row pass: -1 auto, 0 never, 1 wherever legal
     int blue_min = 96;        // shortest non-power-of-two length that takes the Bluestein path (shorter ones, and lengths
                              // above 4096, run on the direct O(n^2) kernel); 0 disables the path
+    int mix = 1;              // composite lengths (primes <= 13, up to 8192) on the mixed-radix kernel (fft_mixed.h) instead of Bluestein; 0: as in
+                              // round 2; 2: also the 3 / 5 / 7 x 2^k lengths of the radix-R step (bigfft.hip)
+    int mix_min = 32;         // ... from this length (shorter ones stay on the direct fp64-accumulating kernel)
     int blue_fuse = 1;        // both-axes form on engine lengths: chirp multiplies inside the chain's first load / last store (1)
                              // or as separate kernels around it (0)
     int blue_2d = 1;          // both axes on the Bluestein path: one fused fft2 x B ifft2 chain (1) or axis by axis (0)
@@ -166,6 +178,7 @@ inline int big_split(int64_t n) {
         return 0;
     }
     if (!tuning().mixed_radix || n < 96) return 0;
+    if (tuning().mix == 2 && n >= tuning().mix_min && mix_length(n)) return 0;    // the composite-length kernel takes these too
     for (int R = 3; R <= 7; R += 2) {
         if (n % R) continue;
         const int64_t q = n / R;
@@ -174,12 +187,18 @@ inline int big_split(int64_t n) {
     return 0;
 }
 
+// lengths the mixed-radix kernel takes: not a power of two (the engine's), not one of the radix-R lengths above when `big` says that
+// path owns them
+inline bool use_mix(int64_t n) {
+    return tuning().mix && n >= tuning().mix_min && n >= 2 && (n & (n - 1)) != 0 && mix_length(n);
+}
+
 // lengths the Bluestein path takes (bluestein.h): not a power of two, at least blue_min, and a convolution length
 // MB >= 2n - 1 that the engine runs as it is (use_blue: n <= 4096; the axis-by-axis form and pm_fft1_ws need that) or that
 // the big power-of-two path runs (use_blue_long: n <= 16384; only the both-axes form, two big transforms around the multiply)
 inline bool use_blue_long(int64_t n) {
     const int lo = tuning().blue_min;
-    return lo > 0 && n >= lo && n >= 2 && (n & (n - 1)) != 0 && n <= (int64_t(1) << 20) && big_split(blue_conv_len(n)) >= 1;
+    return lo > 0 && n >= lo && n >= 2 && (n & (n - 1)) != 0 && n <= (int64_t(1) << 20) && !use_mix(n) && big_split(blue_conv_len(n)) >= 1;
 }
 inline bool use_blue(int64_t n) { return use_blue_long(n) && big_split(blue_conv_len(n)) == 1; }
 // MIXED shapes with one axis the paths above cannot take alone (a length in (4096, 16384] that is not a power of two, or a
@@ -188,7 +207,7 @@ inline bool use_blue(int64_t n) { return use_blue_long(n) && big_split(blue_conv
 inline bool blue_reach(int64_t n) { return tuning().blue_min > 0 && n >= 2 && n <= (int64_t(1) << 20) && big_split(blue_conv_len(n)) >= 1; }
 inline bool blue_needs_both(int64_t n) {
     const bool pow2 = (n & (n - 1)) == 0;
-    if (!blue_reach(n)) return false;
+    if (!blue_reach(n) || use_mix(n)) return false;
     return pow2 ? big_split(n) > 1 : (n >= tuning().blue_min && !use_blue(n));
 }
 

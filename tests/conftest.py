@@ -33,6 +33,19 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture
+def bluestein_route():
+    """composite lengths go back to the round-2 routing (Bluestein / direct) for the duration of a test: the mixed-radix kernel
+    (csrc/fft_mixed.h) owns them by default"""
+    from prysm_amd import _lib
+    lib = _lib.load()
+    lib.pm_set_tuning(b'mix', 0)
+    try:
+        yield lib
+    finally:
+        lib.pm_set_tuning(b'mix', 1)
+
+
 @pytest.fixture(scope='session')
 def golden():
     def load(name):

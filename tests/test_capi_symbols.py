@@ -86,7 +86,29 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
         L.check(rc)
 
 
-def test_workspace_queries_of_the_bluestein_path(lib):
+def test_workspace_queries_of_the_mixed_radix_path(lib):
+    """composite lengths (primes <= 13, up to 8192) run in LDS on their own factors: no scratch beyond the natural intermediate, none for
+    the 1-D entry; lengths with a larger prime keep Bluestein's workspace"""
+    from prysm_amd import _lib as L
+    d = L.pm_fft2_desc()
+    d.dtype, d.direction = L.PM_C64, -1
+    d.in_y = d.in_x = d.out_y = d.out_x = L.pm_axis(1000, 1000, 0, 500)
+    d.in_ld = d.out_ld = 1000
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 1000 * 1000 * 8
+    d.in_y = d.out_y = L.pm_axis(3000, 3000, 0, 0)
+    d.dtype = L.PM_C128
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 3000 * 1000 * 16
+    d.in_y = d.out_y = L.pm_axis(6000, 6000, 0, 0)      # a length in (4096, 8192] no longer drags the other axis into a convolution
+    d.in_x = d.out_x = L.pm_axis(2048, 2048, 0, 0)
+    d.in_ld = d.out_ld = 2048
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 6000 * 2048 * 16
+    for n in (1000, 3000, 2592, 1001, 7000):
+        assert lib.pm_fft1_workspace(L.PM_C64, 1, 8, n) == 0 and lib.pm_fft1_workspace(L.PM_C128, 0, 8, n) == 0
+    assert lib.pm_fft1_workspace(L.PM_C64, 1, 8, 1009) > 0          # prime: Bluestein
+    assert lib.pm_fft1_workspace(L.PM_C64, 1, 8, 2 * 17 * 19) > 0   # primes above 13
+
+
+def test_workspace_queries_of_the_bluestein_path(lib, bluestein_route):
     """Lengths that are not powers of two: the workspace queries are pure host arithmetic (csrc/bluestein.h: MB = power of two >= 2n - 1)."""
     from prysm_amd import _lib as L
 

@@ -880,7 +880,7 @@ def test_numpy_operand_defers_to_wavefront_operators(pa):
 
 @pytest.mark.parametrize('shape,dtype', [((1000, 1000), np.complex64), ((300, 500), np.complex128), ((1000, 1024), np.complex64),
                                          ((1536, 9), np.complex128), ((97, 2000), np.complex64), ((4000, 130), np.complex128)])
-def test_bluestein_lengths(pa, shape, dtype):
+def test_bluestein_lengths(pa, bluestein_route, shape, dtype):
     """Lengths that are not powers of two (96 .. 4096) run on the FFT engine through Bluestein's identity (csrc/bluestein.hip):
     against numpy, against the direct O(n^2) kernel (tuning blue_min = 0), for the focus family (pad / shift / crop / inverse),
     real input, the |.|^2 epilogue and a stack."""
@@ -930,7 +930,7 @@ def test_bluestein_lengths(pa, shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', [np.complex64, np.complex128])
-def test_bluestein_fft1(pa, dtype):
+def test_bluestein_fft1(pa, bluestein_route, dtype):
     """pm_fft1_ws: batched 1-D transforms of non power-of-two length along either axis, zero padded to n, cropped output."""
     from prysm_amd import _ops
     rng = np.random.default_rng(77)
@@ -1026,7 +1026,7 @@ def test_big_16384_squared_separable_field(pa):
 
 @pytest.mark.parametrize('shape,dtype', [((40, 24), np.complex128), ((50, 50), np.complex64), ((24, 100), np.complex128),
                                          ((40, 16), np.complex128), ((64, 24), np.complex64), ((6, 40), np.complex128)])   # mixed shapes: native / split power of two / short axis beside a long one
-def test_long_bluestein_on_small_arrays(pa, shape, dtype):
+def test_long_bluestein_on_small_arrays(pa, bluestein_route, shape, dtype):
     """Lengths in (4096, 16384] that are not powers of two convolve at 16384 / 32768 points: chirp multiply, big transform with the
     chirp spectrum in its epilogue, big inverse with the crop, chirp multiply.  Run here on small arrays (native length 32, path
     from 20 points) against numpy: forward, inverse, windows, real input."""
@@ -1056,7 +1056,7 @@ def test_long_bluestein_on_small_arrays(pa, shape, dtype):
         lib.pm_set_tuning(b'blue_min', 96)
 
 
-def test_long_bluestein_5000(pa):
+def test_long_bluestein_5000(pa, bluestein_route):
     """unfocus of a 5000 x 4500 complex64 field (convolution at 16384 points) against numpy; timing of 8000^2 printed."""
     rng = np.random.default_rng(5000)
     x = crandn(rng, (5000, 4500), np.complex64)

@@ -404,3 +404,96 @@ def test_wavefront_focus_dft_intensity(pa):
         pa.config.precision = prec
     with pytest.raises(ValueError):
         P.Wavefront(np.ones((8, 8), complex), 0.5, 1.0, space='psf').focus_dft_intensity(None)
+
+
+# ----------------------------------------------------------------------------- composite lengths on their own factors (csrc/fft_mixed.h)
+
+@pytest.mark.parametrize('shape,dtype', [((1000, 1000), np.complex64), ((300, 500), np.complex128), ((1000, 1024), np.complex64),
+                                         ((1536, 45), np.complex128), ((77, 2000), np.complex64), ((4000, 130), np.complex128),
+                                         ((1001, 143), np.complex128), ((2592, 729), np.complex64), ((3000, 36), np.complex128),
+                                         ((250, 8190), np.complex64), ((6000, 40), np.complex128), ((3125, 343), np.complex128)])
+def test_composite_lengths_on_the_mixed_radix_kernel(pa, shape, dtype):
+    """lengths whose primes are all <= 13 (scipy.fft takes them natively: prysm/propagation/fft.py:24) run on one LDS-resident
+    mixed-radix kernel per axis: against numpy, against round 2's route (Bluestein / direct, knob mix = 0), for the focus family
+    (pad / shift / crop / inverse), real input, the |.|^2 epilogue and a stack"""
+    from prysm_amd import _lib, _ops
+    lib = _lib.load()
+    rng = np.random.default_rng(sum(shape))
+    tol = TOL32 if dtype == np.complex64 else TOL64
+    x = crandn(rng, shape, dtype)
+    want = np.fft.fft2(x.astype(np.complex128))
+    xd = torch.from_numpy(x).cuda()
+    got = _ops.fft2(xd, direction=-1, scale=1.0).cpu().numpy()
+    assert got.dtype == dtype and rel_max(got, want) < tol
+    try:
+        lib.pm_set_tuning(b'mix', 0)
+        old = _ops.fft2(xd, direction=-1, scale=1.0).cpu().numpy()
+    finally:
+        lib.pm_set_tuning(b'mix', 1)
+    assert rel_max(got, old) < 2 * tol
+    inv = _ops.fft2(torch.from_numpy(got).cuda(), direction=+1, scale=1.0 / (shape[0] * shape[1])).cpu().numpy()
+    assert rel_max(inv, x) < 2 * tol
+    if shape[0] * shape[1] <= 1100 * 1100:
+        small = x[:shape[0] // 2, :shape[1] // 2]
+        ref = O.focus(small.astype(np.complex128), 2)
+        assert rel_max(tonp(pa.propagation.focus(small, 2)), ref) < tol
+        assert rel_max(tonp(pa.propagation.focus_intensity(small, 2)), O.intensity(ref)) < 2 * tol
+        g = crandn(rng, ref.shape, dtype)
+        assert rel_max(tonp(pa.propagation.focus_adjoint(g, 2)), O.focus_adjoint(g.astype(np.complex128), 2)) < tol
+    assert rel_max(tonp(pa.propagation.unfocus(x, 1)), O.unfocus(x.astype(np.complex128), 1)) < tol
+    xr = np.ascontiguousarray(x.real)
+    assert rel_max(_ops.fft2(torch.from_numpy(xr).cuda(), direction=-1, scale=1.0).cpu().numpy(), np.fft.fft2(xr.astype(np.float64))) < tol
+    if shape[0] * shape[1] <= 1100 * 1100:
+        st = crandn(rng, (2,) + shape, dtype)
+        gs = _ops.fft2(torch.from_numpy(st).cuda(), direction=-1, scale=1.0).cpu().numpy()
+        assert max(rel_max(gs[b], np.fft.fft2(st[b].astype(np.complex128))) for b in range(2)) < tol
+
+
+@pytest.mark.parametrize('dtype', [np.complex64, np.complex128])
+def test_composite_lengths_fft1(pa, dtype):
+    """pm_fft1 on the mixed-radix kernel: both axes, zero padded to n, truncated, cropped and scaled outputs, odd batch extents"""
+    from prysm_amd import _ops
+    rng = np.random.default_rng(78)
+    tol = TOL32 if dtype == np.complex64 else TOL64
+    x = crandn(rng, (301, 1000), dtype)
+    xd = torch.from_numpy(x).cuda()
+    x128 = x.astype(np.complex128)
+    assert rel_max(_ops.fft1(xd, axis=1).cpu().numpy(), np.fft.fft(x128, axis=1)) < tol
+    assert rel_max(_ops.fft1(xd, n=315, axis=0).cpu().numpy(), np.fft.fft(x128, 315, axis=0)) < tol
+    assert rel_max(_ops.fft1(xd, n=1500, axis=1, direction=+1, scale=1 / 1500).cpu().numpy(), np.fft.ifft(x128, 1500, axis=1)) < tol
+    assert rel_max(_ops.fft1(xd, n=770, axis=0, out_len=100, out_off=30).cpu().numpy(), np.fft.fft(x128, 770, axis=0)[30:130]) < tol
+    assert rel_max(_ops.fft1(xd, n=600, axis=1).cpu().numpy(), np.fft.fft(x128, 600, axis=1)) < tol   # truncation
+    assert rel_max(_ops.fft1(xd, n=7000, axis=1, scale=0.5).cpu().numpy(), 0.5 * np.fft.fft(x128, 7000, axis=1)) < tol
+    for n in (18, 20, 24, 30, 35, 48, 54, 60, 63, 72, 80, 84, 90, 99, 108, 117, 165, 169, 182, 195, 210, 1331, 2197, 2401, 4095):
+        y = x128[:7, :min(n, 1000)]
+        assert rel_max(_ops.fft1(torch.from_numpy(y.astype(dtype)).cuda(), n=n, axis=1).cpu().numpy(), np.fft.fft(y.astype(dtype).astype(np.complex128), n, axis=1)) < tol, n
+
+
+def test_angular_spectrum_and_convolution_on_composite_grids(pa):
+    """free space on a 1000 x 1500 grid and an image-chain convolution on a 600 x 1000 one: every transform of the chains on the mixed-radix kernel"""
+    rng = np.random.default_rng(1001)
+    x = crandn(rng, (1000, 1500))
+    ref = O.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1)
+    assert rel_max(tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1)), ref) < TOL64
+    img = rng.standard_normal((600, 1000))
+    psf = rng.random((600, 1000))
+    want = np.fft.fftshift(np.fft.ifft2(np.fft.fft2(np.fft.ifftshift(img)) * np.fft.fft2(np.fft.ifftshift(psf)))).real
+    got = tonp(pa.convolution.conv(img, psf))
+    assert rel_max(got, want) < TOL64
+
+
+def test_focus_6000_on_the_mixed_radix_kernel(pa):
+    """a length in (4096, 8192]: round 2 convolved BOTH axes at 16384 points for these; now one kernel per axis (timing printed)"""
+    rng = np.random.default_rng(6000)
+    x = crandn(rng, (5000, 4500), np.complex64)
+    got = tonp(pa.propagation.unfocus(x, 1))
+    assert rel_max(got, O.unfocus(x.astype(np.complex128), 1)) < TOL32
+    xd = torch.from_numpy(crandn(rng, (8000, 8000), np.complex64)).cuda()
+    pa.propagation.focus(xd, 1)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    pa.propagation.focus(xd, 1)
+    ev1.record()
+    torch.cuda.synchronize()
+    print('focus 8000^2 complex64 (mixed radix): %.2f ms' % ev0.elapsed_time(ev1))

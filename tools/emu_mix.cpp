@@ -1,0 +1,86 @@
+// CPU emulation of the mixed-radix kernel's per-thread logic (prysm_amd/csrc/fft_mixed.h), test scaffolding like emu_fft.cpp: every
+// thread of a workgroup runs each phase in turn with a std::vector standing in for LDS, against a naive long-double DFT.
+// build: g++ -O2 -std=c++17 -I prysm_amd/csrc tools/emu_mix.cpp -o /tmp/emu_mix
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "fft_mixed.h"
+
+using namespace pm;
+typedef long double ld;
+typedef std::complex<ld> cld;
+
+template <typename T>
+static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift) {
+    MixPlan p;
+    if (!mix_make_plan(n, p)) return -1;
+    p.seqs = seqs;
+    p.log_seqs = 0;
+    while ((1 << p.log_seqs) < seqs) ++p.log_seqs;
+    const ld pi = acosl(-1.0L);
+    std::vector<cx<T>> tw(n);
+    for (int i = 0; i < n; ++i) tw[i] = {T(cosl(-2 * pi * i / n)), T(sinl(-2 * pi * i / n))};
+    std::mt19937 rng(n * 7 + nseq);
+    std::uniform_real_distribution<double> U(-1, 1);
+    // rows: x[seq][i]; cols: x[i][seq]
+    std::vector<cx<T>> x(size_t(n) * nseq), y(size_t(n) * nseq, cx<T>{T(0), T(0)});
+    for (auto& v : x) v = {T(U(rng)), T(U(rng))};
+    BlueIn<T> in{x.data(), col ? 1 : n, col ? nseq : 1, AxisMap{n, n, 0, shift}, 0, 0};
+    std::vector<cx<T>> lds(size_t(seqs) * p.npad + 64);
+    const int ngroups = (nseq + seqs - 1) / seqs;
+    for (int g = 0; g < ngroups; ++g) {
+        const int seq0 = g * seqs;
+        auto fetch = [&](int sl, int i) { return seq0 + sl < nseq ? blue_fetch(in, seq0 + sl, i) : cx<T>{T(0), T(0)}; };
+        auto store = [&](int sl, int k, cx<T> v) {
+            if (seq0 + sl >= nseq) return;
+            if (col) y[size_t(k) * nseq + seq0 + sl] = v; else y[size_t(seq0 + sl) * n + k] = v;
+        };
+        for (int ph = 0; ph < p.nstage; ++ph)
+            for (int tid = 0; tid < nt; ++tid) {
+                if (col) mix_phase<T, true>(p, ph, tid, nt, lds.data(), tw.data(), fetch, store);
+                else mix_phase<T, false>(p, ph, tid, nt, lds.data(), tw.data(), fetch, store);
+            }
+    }
+    double err = 0, ref = 0;
+    for (int s = 0; s < nseq; ++s) {
+        std::vector<cld> xs(n);
+        for (int i = 0; i < n; ++i) {
+            int q = i + shift; if (q >= n) q -= n;
+            const cx<T> v = col ? x[size_t(q) * nseq + s] : x[size_t(s) * n + q];
+            xs[i] = cld(v.x, v.y);
+        }
+        for (int k = 0; k < n; k += (n > 600 ? 37 : 1)) {
+            cld acc = 0;
+            for (int i = 0; i < n; ++i) { const ld a = -2 * pi * ld((int64_t(i) * k) % n) / n; acc += xs[i] * cld(cosl(a), sinl(a)); }
+            const cx<T> v = col ? y[size_t(k) * nseq + s] : y[size_t(s) * n + k];
+            err = std::max(err, double(std::abs(acc - cld(v.x, v.y))));
+            ref = std::max(ref, double(std::abs(acc)));
+        }
+    }
+    return err / ref;
+}
+
+int main() {
+    int bad = 0;
+    const int lens[] = {18, 20, 21, 30, 36, 45, 49, 60, 77, 90, 96, 100, 120, 121, 125, 143, 144, 169, 180, 243, 250, 256, 343, 360, 500, 625, 729, 1000,
+                        1001, 1331, 1500, 2187, 2310, 2592, 3000, 3125, 4000, 4096, 5000, 6561, 8000};
+    for (int n : lens) {
+        MixPlan p;
+        if (!mix_make_plan(n, p)) { printf("n=%d no plan\n", n); ++bad; continue; }
+        printf("n=%5d stages", n);
+        for (int s = 0; s < p.nstage; ++s) printf(" %d", p.radix[s]);
+        const double e1 = run_case<double>(n, 3, false, 2, 64, 0);
+        const double e2 = run_case<double>(n, 5, true, 4, 96, n / 2);
+        const double e3 = run_case<float>(n, 2, false, 1, 128, 1);
+        printf("  rows f64 %.2e  cols f64 %.2e  rows f32 %.2e\n", e1, e2, e3);
+        if (!(e1 < 1e-13) || !(e2 < 1e-13) || !(e3 < 2e-5)) { ++bad; printf("   ^^^ FAIL\n"); }
+    }
+    MixPlan q;
+    if (mix_make_plan(12, q) || mix_make_plan(17, q) || mix_make_plan(1024 * 17, q) || mix_make_plan(2 * 19, q)) { printf("planned an unsupported length\n"); ++bad; }
+    printf(bad ? "FAILED (%d)\n" : "all ok\n", bad);
+    return bad != 0;
+}

@@ -189,12 +189,13 @@ def fuzz_real_conv(ncases, rng, lib):
 def fuzz_fft1(ncases, rng, lib):
     """pm_fft1_ws through _ops.fft1: engine, direct, Bluestein, mixed-radix (3 / 5 / 7 x 2^k) and -- with the native length lowered --
     radix-2 / radix-4 lengths, both axes and directions, zero-padded inputs at an offset, windows of the bins, a scale."""
-    sizes = [2, 8, 64, 256, 1024, 4096, 3, 12, 36, 96, 100, 127, 160, 192, 224, 384, 640, 1000, 1536, 2560, 3584, 6144]
+    sizes = [2, 8, 64, 256, 1024, 4096, 3, 12, 36, 96, 100, 127, 160, 192, 224, 384, 640, 1000, 1536, 2560, 3584, 6144, 45, 250, 1001, 2592, 3000, 5000, 6000, 8190]
     nfail, worst = 0, 0.0
     for case in range(ncases):
         n = int(rng.choice(sizes))
         small = rng.random() < 0.3 and n in (64, 256)
         lib.pm_set_tuning(b'big_native_log', 5 if small else 13)      # 64 / 128 then take the radix-2 / radix-4 step; 256 goes direct
+        lib.pm_set_tuning(b'mix', 0 if rng.random() < 0.2 else 1)     # composite lengths: mostly their own kernel, sometimes round 2's routes
         if small:
             n = int(rng.choice([64, 128]))
         cdt = np.complex64 if rng.random() < 0.5 else np.complex128
@@ -226,6 +227,7 @@ def fuzz_fft1(ncases, rng, lib):
             nfail += 1
             print('fft1 case', case, 'FAIL err', err, (n, batch, ln, off, olen, ooff, axis, direction, cdt.__name__, small))
     lib.pm_set_tuning(b'big_native_log', 13)
+    lib.pm_set_tuning(b'mix', 1)
     print(f'fuzz_fft1: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
     return nfail
 
@@ -285,7 +287,8 @@ def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     lib = L.load()
-    sizes = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 3, 5, 9, 12, 20, 36, 100, 96, 127, 160, 200, 224, 384, 1000, 1536]   # engine, direct, Bluestein and mixed-radix lengths
+    sizes = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 3, 5, 9, 12, 20, 36, 100, 96, 127, 160, 200, 224, 384, 1000, 1536, 45, 77, 143, 250, 360, 729, 1001, 1250,
+             2592]   # engine, direct, Bluestein, radix-R step and mixed-radix (composite) lengths
     worst = 0.0
     nfail = 0
     for case in range(ncases):
@@ -314,10 +317,11 @@ def main():
         lib.pm_set_tuning(b'fold', fold)
         # routes of awkward lengths: with the native length lowered to 32 and the Bluestein path opened from 20 points, 64 / 128
         # take the radix-2 / radix-4 step of the 16384 / 32768-point path and 20 .. 64 the long both-axes Bluestein form
-        route = str(rng.choice(['default', 'default', 'small_native', 'unfused']))
+        route = str(rng.choice(['default', 'default', 'default', 'small_native', 'unfused', 'bluestein']))
         lib.pm_set_tuning(b'big_native_log', 5 if route == 'small_native' else 13)
         lib.pm_set_tuning(b'blue_min', 20 if route == 'small_native' else 96)
         lib.pm_set_tuning(b'blue_fuse', 0 if route == 'unfused' else 1)
+        lib.pm_set_tuning(b'mix', 0 if route in ('unfused', 'bluestein', 'small_native') else 1)   # composite lengths: their own kernel, or round 2's routes
         scale = float(rng.choice([1.0, 1.0 / np.sqrt(M * N)]))
         shp = (B, m, n) if B else (m, n)
         amp = None
@@ -363,7 +367,7 @@ def main():
         if not ok:
             nfail += 1
             print('case', case, 'FAIL err', err, (M, N, m, n, in_off, in_shift, (om, on), out_off, out_shift, direction, cdt.__name__, kind, B, epi, fold, route))
-    for key, val in ((b'fold', -1), (b'big_native_log', 13), (b'blue_min', 96), (b'blue_fuse', 1)):
+    for key, val in ((b'fold', -1), (b'big_native_log', 13), (b'blue_min', 96), (b'blue_fuse', 1), (b'mix', 1)):
         lib.pm_set_tuning(key, val)
     print(f'fuzz_fft2: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
     nfail += fuzz_fused(max(20, ncases // 2), rng, lib)
