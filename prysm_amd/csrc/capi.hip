@@ -127,6 +127,10 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("mixed_radix")) t.mixed_radix = v ? 1 : 0;
     else if (is("mix")) t.mix = v < 0 ? 0 : (v > 2 ? 2 : v);
     else if (is("mix_min")) t.mix_min = v < 18 ? 18 : v;
+    else if (is("mix_log_g")) t.mix_log_g = v;
+    else if (is("mix_seqs")) t.mix_seqs = v < 0 ? 0 : v;
+    else if (is("mix_tc")) t.mix_tc = v < 0 ? 0 : v;
+    else if (is("mix_nt")) t.mix_nt = v < 0 ? 0 : v;
     else if (is("r2c")) t.r2c = v < 0 ? -1 : (v > 1 ? 2 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
     else if (is("colmul_mode")) t.colmul_mode = v;

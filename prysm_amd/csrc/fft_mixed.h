@@ -1,4 +1,4 @@
-// Composite lengths on their own factors: n = r0 r1 ... with every factor <= 16 (all lengths whose primes are <= 13: 1000, 3000,
+// Composite lengths on their own factors: n = r0 r1 ... with every factor <= 32 (all lengths whose primes are <= 13: 1000, 3000,
 // 2592, 1001 ...) as ONE kernel per axis, in place of Bluestein's convolution of >= 2n - 1 points per axis (>= 4x the area in 2-D).
 // The reference reaches these lengths through scipy.fft / pocketfft, which factors them the same way (prysm/propagation/fft.py:24,
 // prysm/fttools.py:23-31, prysm/propagation/angular_spectrum.py:35-42).
@@ -13,7 +13,8 @@
 // (stages - 1) times.  The last stage has no twiddles (the planner puts the largest factor there) and enumerates its butterflies by the
 // LOW digits of the bin index, so that adjacent lanes store adjacent bins.
 //
-// The factor of each stage is a run-time value (one kernel serves every length); the small DFTs are compile-time (switch over 2 .. 16).
+// The factor of each stage is a run-time value (one kernel per class of largest factor -- 10, 16, 32 -- serves every length); the small
+// DFTs are compile-time (a switch over the factors of the class).
 // Row mode: a workgroup holds `seqs` memory rows, lanes run along the row.  Column mode: `seqs` adjacent columns (a power of two),
 // lanes run across the columns first -- pieces of seqs elements per row of the array.
 //
@@ -27,7 +28,9 @@ namespace pm {
 
 constexpr int kMixMaxStages = 6;
 constexpr int kMixMaxN = 8192;
-constexpr int kMixMaxRadix = 16;
+constexpr int kMixMaxRadix = 32;
+// factors with a small DFT below
+constexpr bool mix_radix_ok(int r) { return r >= 2 && r <= 32 && r != 17 && r != 19 && r != 23 && r != 29 && r != 31; }
 
 // ---------------------------------------------------------------------------
 // compile-time roots of unity (octant reduction + Taylor series on [0, pi/4]; ~1 ulp)
@@ -164,6 +167,17 @@ template <typename T> struct MixDft<T, 10> { static PM_HD void run(cx<T>* a) { m
 template <typename T> struct MixDft<T, 12> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 4, 3>(a); } };
 template <typename T> struct MixDft<T, 14> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 7>(a); } };
 template <typename T> struct MixDft<T, 15> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 3, 5>(a); } };
+template <typename T> struct MixDft<T, 18> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 9>(a); } };
+template <typename T> struct MixDft<T, 20> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 4, 5>(a); } };
+template <typename T> struct MixDft<T, 21> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 3, 7>(a); } };
+template <typename T> struct MixDft<T, 22> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 11>(a); } };
+template <typename T> struct MixDft<T, 24> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 8, 3>(a); } };
+template <typename T> struct MixDft<T, 25> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 5, 5>(a); } };
+template <typename T> struct MixDft<T, 26> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 13>(a); } };
+template <typename T> struct MixDft<T, 27> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 3, 9>(a); } };
+template <typename T> struct MixDft<T, 28> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 4, 7>(a); } };
+template <typename T> struct MixDft<T, 30> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 5, 6>(a); } };
+template <typename T> struct MixDft<T, 32> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 16>(a); } };
 
 // ---------------------------------------------------------------------------
 // plan: factors (largest last), block lengths, exact division by multiply-high
@@ -176,7 +190,7 @@ struct MixPlan {
     uint32_t mg_sub[kMixMaxStages];     // magic of len[s + 1]
     uint32_t mg_nb[kMixMaxStages];      // magic of n / radix[s] (butterflies of one sequence in stage s)
     int seqs, log_seqs;             // sequences per workgroup (column mode: a power of two)
-    int npad;                       // LDS slots per sequence
+    int maxr;                       // largest factor (selects the kernel class)
 };
 
 // floor(a / d) for a d < 2^16 as (a * magic) >> 32, magic = floor(2^32 / d) + 1 (exact while a d < 2^32); d == 1: magic 0 = identity
@@ -190,9 +204,7 @@ PM_HD int mix_div(int a, uint32_t magic) {
 #endif
 }
 
-PM_HD int mix_pad(int i) { return i + (i >> 4); }
-
-// fewest stages first, then the most even factors; returns false when n has a prime factor above 13 or needs more than kMixMaxStages
+// fewest stages first, then the smallest largest factor; returns false when n has a prime factor above 13 or needs more than kMixMaxStages
 inline bool mix_factor(int n, int* radix, int* nstage) {
     if (n < 2 || n > kMixMaxN) return false;
     int best[kMixMaxStages], cur[kMixMaxStages], bestn = kMixMaxStages + 1, bestmax = 0;
@@ -209,7 +221,7 @@ inline bool mix_factor(int n, int* radix, int* nstage) {
             }
             if (depth >= kMixMaxStages || depth + 1 > bestn) return;
             for (int f = maxf; f >= 2; --f) {
-                if (rem % f) continue;
+                if (rem % f || !mix_radix_ok(f)) continue;
                 cur[depth] = f;
                 go(rem / f, f, depth + 1, cur, best, bestn, bestmax);
             }
@@ -235,7 +247,7 @@ inline void mix_fill_plan(int n, const int* radix, int nstage, MixPlan& p) {
         p.mg_sub[s] = mix_magic(p.len[s + 1]);
         p.mg_nb[s] = mix_magic(n / p.radix[s]);
     }
-    p.npad = mix_pad(n) + 1;
+    p.maxr = radix[nstage - 1];
     p.seqs = 1;
     p.log_seqs = 0;
 }
@@ -249,9 +261,15 @@ inline bool mix_make_plan(int n, MixPlan& p) {
 // ---------------------------------------------------------------------------
 // stages.  `tid` / `nt`: this thread and the threads of the workgroup; sl = sequence slot of the workgroup
 // ---------------------------------------------------------------------------
+// LDS slot of point i of sequence slot sl, and the slot distance of `d` points (rows: [sl][i]; columns: [i][sl]).  No padding: lanes run
+// along i (or along sl first) with unit stride in every stage but the last, whose reads follow the digit-reversed order
 template <bool COL>
 PM_HD int mix_addr(const MixPlan& p, int sl, int i) {
-    return COL ? ((mix_pad(i) << p.log_seqs) + sl) : (sl * p.npad + mix_pad(i));
+    return COL ? ((i << p.log_seqs) + sl) : (sl * p.n + i);
+}
+template <bool COL>
+PM_HD int mix_step(const MixPlan& p, int d) {
+    return COL ? (d << p.log_seqs) : d;
 }
 template <bool COL>
 PM_HD void mix_split(const MixPlan& p, int b, uint32_t mg_nb, int nb, int& sl, int& j) {
@@ -276,9 +294,10 @@ PM_HD void mix_first(const MixPlan& p, int tid, int nt, cx<T>* lds, const cx<T>*
 #pragma unroll
         for (int k = 0; k < R; ++k) a[k] = fetch(sl, j + k * nb);
         MixDft<T, R>::run(a);
-        lds[mix_addr<COL>(p, sl, j)] = a[0];
+        const int a0 = mix_addr<COL>(p, sl, j), as = mix_step<COL>(p, nb);
+        lds[a0] = a[0];
 #pragma unroll
-        for (int k = 1; k < R; ++k) lds[mix_addr<COL>(p, sl, j + k * nb)] = cmul(a[k], tw[j * k]);
+        for (int k = 1; k < R; ++k) lds[a0 + k * as] = cmul(a[k], tw[j * k]);
     }
 }
 
@@ -291,14 +310,15 @@ PM_HD void mix_mid(const MixPlan& p, int s, int tid, int nt, cx<T>* lds, const c
         int sl, ja;
         mix_split<COL>(p, b, p.mg_nb[s], nb, sl, ja);
         const int blk = mix_div(ja, p.mg_sub[s]), j = ja - blk * sub, base = blk * L + j;
+        const int a0 = mix_addr<COL>(p, sl, base), as = mix_step<COL>(p, sub);
         cx<T> a[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) a[k] = lds[mix_addr<COL>(p, sl, base + k * sub)];
+        for (int k = 0; k < R; ++k) a[k] = lds[a0 + k * as];
         MixDft<T, R>::run(a);
-        lds[mix_addr<COL>(p, sl, base)] = a[0];
+        lds[a0] = a[0];
         const int tj = j * tstep;
 #pragma unroll
-        for (int k = 1; k < R; ++k) lds[mix_addr<COL>(p, sl, base + k * sub)] = cmul(a[k], tw[tj * k]);
+        for (int k = 1; k < R; ++k) lds[a0 + k * as] = cmul(a[k], tw[tj * k]);
     }
 }
 
@@ -316,32 +336,46 @@ PM_HD void mix_last(const MixPlan& p, int tid, int nt, const cx<T>* lds, Store s
             pos += (rem - q * p.radix[i]) * p.len[i + 1];
             rem = q;
         }
+        const int a0 = mix_addr<COL>(p, sl, pos), as = mix_step<COL>(p, 1);
         cx<T> a[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) a[k] = lds[mix_addr<COL>(p, sl, pos + k)];
+        for (int k = 0; k < R; ++k) a[k] = lds[a0 + k * as];
         MixDft<T, R>::run(a);
 #pragma unroll
         for (int k = 0; k < R; ++k) store(sl, o + k * nb, a[k]);
     }
 }
 
-#define PM_MIX_RADIX_SWITCH(r, CALL)                                                                                                     \
-    switch (r) {                                                                                                                         \
-        case 2: { constexpr int R = 2; CALL; } break;                                                                                    \
-        case 3: { constexpr int R = 3; CALL; } break;                                                                                    \
-        case 4: { constexpr int R = 4; CALL; } break;                                                                                    \
-        case 5: { constexpr int R = 5; CALL; } break;                                                                                    \
-        case 6: { constexpr int R = 6; CALL; } break;                                                                                    \
-        case 7: { constexpr int R = 7; CALL; } break;                                                                                    \
-        case 8: { constexpr int R = 8; CALL; } break;                                                                                    \
-        case 9: { constexpr int R = 9; CALL; } break;                                                                                    \
-        case 10: { constexpr int R = 10; CALL; } break;                                                                                  \
-        case 11: { constexpr int R = 11; CALL; } break;                                                                                  \
-        case 12: { constexpr int R = 12; CALL; } break;                                                                                  \
-        case 13: { constexpr int R = 13; CALL; } break;                                                                                  \
-        case 14: { constexpr int R = 14; CALL; } break;                                                                                  \
-        case 15: { constexpr int R = 15; CALL; } break;                                                                                  \
-        default: { constexpr int R = 16; CALL; } break;                                                                                  \
+// `MAXR` (a template parameter of the caller) bounds the factors a kernel class contains
+#define PM_MIX_RADIX_SWITCH(r, CALL) \
+    switch (r) { \
+        case 2: if constexpr (MAXR >= 2) { constexpr int R = 2; CALL; } break; \
+        case 3: if constexpr (MAXR >= 3) { constexpr int R = 3; CALL; } break; \
+        case 4: if constexpr (MAXR >= 4) { constexpr int R = 4; CALL; } break; \
+        case 5: if constexpr (MAXR >= 5) { constexpr int R = 5; CALL; } break; \
+        case 6: if constexpr (MAXR >= 6) { constexpr int R = 6; CALL; } break; \
+        case 7: if constexpr (MAXR >= 7) { constexpr int R = 7; CALL; } break; \
+        case 8: if constexpr (MAXR >= 8) { constexpr int R = 8; CALL; } break; \
+        case 9: if constexpr (MAXR >= 9) { constexpr int R = 9; CALL; } break; \
+        case 10: if constexpr (MAXR >= 10) { constexpr int R = 10; CALL; } break; \
+        case 11: if constexpr (MAXR >= 11) { constexpr int R = 11; CALL; } break; \
+        case 12: if constexpr (MAXR >= 12) { constexpr int R = 12; CALL; } break; \
+        case 13: if constexpr (MAXR >= 13) { constexpr int R = 13; CALL; } break; \
+        case 14: if constexpr (MAXR >= 14) { constexpr int R = 14; CALL; } break; \
+        case 15: if constexpr (MAXR >= 15) { constexpr int R = 15; CALL; } break; \
+        case 16: if constexpr (MAXR >= 16) { constexpr int R = 16; CALL; } break; \
+        case 18: if constexpr (MAXR >= 18) { constexpr int R = 18; CALL; } break; \
+        case 20: if constexpr (MAXR >= 20) { constexpr int R = 20; CALL; } break; \
+        case 21: if constexpr (MAXR >= 21) { constexpr int R = 21; CALL; } break; \
+        case 22: if constexpr (MAXR >= 22) { constexpr int R = 22; CALL; } break; \
+        case 24: if constexpr (MAXR >= 24) { constexpr int R = 24; CALL; } break; \
+        case 25: if constexpr (MAXR >= 25) { constexpr int R = 25; CALL; } break; \
+        case 26: if constexpr (MAXR >= 26) { constexpr int R = 26; CALL; } break; \
+        case 27: if constexpr (MAXR >= 27) { constexpr int R = 27; CALL; } break; \
+        case 28: if constexpr (MAXR >= 28) { constexpr int R = 28; CALL; } break; \
+        case 30: if constexpr (MAXR >= 30) { constexpr int R = 30; CALL; } break; \
+        case 32: if constexpr (MAXR >= 32) { constexpr int R = 32; CALL; } break; \
+        default: break; \
     }
 
 // output of the row mode: natural rows (the intermediate of a 2-D transform) or the 1-D API's view (window / rotation, scale, conj)
@@ -368,17 +402,37 @@ PM_HD void mix_store_row(const MixRowOut<T>& o, int seq, int k, cx<T> v) {
     }
 }
 
-// one phase of the workgroup's work for thread `tid` (phase 0 = first stage, 1 .. nstage-2 = middle stages, nstage-1 = last stage);
-// the kernel puts a barrier between phases, the emulator runs every thread of a phase before the next one
-template <typename T, bool COL, typename Fetch, typename Store>
-PM_HD void mix_phase(const MixPlan& p, int phase, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw, Fetch fetch, Store store) {
-    if (phase == 0) {
-        PM_MIX_RADIX_SWITCH(p.radix[0], (mix_first<T, COL, R>(p, tid, nt, lds, tw, fetch)))
-    } else if (phase < p.nstage - 1) {
-        PM_MIX_RADIX_SWITCH(p.radix[phase], (mix_mid<T, COL, R>(p, phase, tid, nt, lds, tw)))
-    } else {
-        PM_MIX_RADIX_SWITCH(p.radix[phase], (mix_last<T, COL, R>(p, tid, nt, lds, store)))
-    }
+// the phases of a workgroup's work for thread `tid`: first stage, middle stage `s` (1 .. nstage-2), last stage.  The kernel puts a barrier
+// between phases; the emulator runs every thread of a phase before the next one
+template <typename T, bool COL, int MAXR, typename Fetch>
+PM_HD void mix_run_first(const MixPlan& p, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw, Fetch fetch) {
+    PM_MIX_RADIX_SWITCH(p.radix[0], (mix_first<T, COL, R>(p, tid, nt, lds, tw, fetch)))
+}
+template <typename T, bool COL, int MAXR>
+PM_HD void mix_run_mid(const MixPlan& p, int s, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw) {
+    PM_MIX_RADIX_SWITCH(p.radix[s], (mix_mid<T, COL, R>(p, s, tid, nt, lds, tw)))
+}
+template <typename T, bool COL, int MAXR, typename Store>
+PM_HD void mix_run_last(const MixPlan& p, int tid, int nt, const cx<T>* lds, Store store) {
+    PM_MIX_RADIX_SWITCH(p.radix[p.nstage - 1], (mix_last<T, COL, R>(p, tid, nt, lds, store)))
+}
+
+// branch-free element of the DirectIn view: the load always happens (at element 0 of the sequence when the logical index falls outside the
+// stored window or the sequence does not exist -- `ok` false) and the value is selected afterwards, so the R loads of a butterfly issue
+// back to back
+template <typename T>
+PM_HD cx<T> mix_fetch(const BlueIn<T>& in, int seq, bool ok, int i) {
+    int q = in.ax.map(i);
+    ok = ok && q >= 0;
+    q = ok ? q : 0;
+    const int64_t at = int64_t(seq) * in.s_seq + int64_t(q) * in.s_i;
+    cx<T> x;
+    if (in.real)
+        x = {reinterpret_cast<const T*>(in.src)[at], T(0)};
+    else
+        x = reinterpret_cast<const cx<T>*>(in.src)[at];
+    if (in.conj) x.y = -x.y;
+    return ok ? x : cx<T>{T(0), T(0)};
 }
 
 }  // namespace pm

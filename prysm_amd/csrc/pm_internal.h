@@ -122,6 +122,8 @@ struct Tuning {
                              // above 4096, run on the direct O(n^2) kernel); 0 disables the path
     int mix = 1;              // composite lengths (primes <= 13, up to 8192) on the mixed-radix kernel (fft_mixed.h) instead of Bluestein; 0: as in
                               // round 2; 2: also the 3 / 5 / 7 x 2^k lengths of the radix-R step (bigfft.hip)
+    int mix_log_g = -1;       // ... its column pass: 2^this adjacent tiles per XCD (-1 auto: as many as share a 128 B line)
+    int mix_seqs = 0, mix_tc = 0, mix_nt = 0;   // ... force its rows per workgroup / columns per workgroup / threads per workgroup (0 = auto)
     int mix_min = 32;         // ... from this length (shorter ones stay on the direct fp64-accumulating kernel)
     int blue_fuse = 1;        // both-axes form on engine lengths: chirp multiplies inside the chain's first load / last store (1)
                              // or as separate kernels around it (0)

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <type_traits>
 #include <vector>
 
 #include "fft_mixed.h"
@@ -30,20 +31,23 @@ static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift) {
     std::vector<cx<T>> x(size_t(n) * nseq), y(size_t(n) * nseq, cx<T>{T(0), T(0)});
     for (auto& v : x) v = {T(U(rng)), T(U(rng))};
     BlueIn<T> in{x.data(), col ? 1 : n, col ? nseq : 1, AxisMap{n, n, 0, shift}, 0, 0};
-    std::vector<cx<T>> lds(size_t(seqs) * p.npad + 64);
+    std::vector<cx<T>> lds(size_t(seqs) * p.n + 64);
     const int ngroups = (nseq + seqs - 1) / seqs;
     for (int g = 0; g < ngroups; ++g) {
         const int seq0 = g * seqs;
-        auto fetch = [&](int sl, int i) { return seq0 + sl < nseq ? blue_fetch(in, seq0 + sl, i) : cx<T>{T(0), T(0)}; };
+        auto fetch = [&](int sl, int i) { const bool ok = seq0 + sl < nseq; return mix_fetch(in, ok ? seq0 + sl : seq0, ok, i); };
         auto store = [&](int sl, int k, cx<T> v) {
             if (seq0 + sl >= nseq) return;
             if (col) y[size_t(k) * nseq + seq0 + sl] = v; else y[size_t(seq0 + sl) * n + k] = v;
         };
-        for (int ph = 0; ph < p.nstage; ++ph)
-            for (int tid = 0; tid < nt; ++tid) {
-                if (col) mix_phase<T, true>(p, ph, tid, nt, lds.data(), tw.data(), fetch, store);
-                else mix_phase<T, false>(p, ph, tid, nt, lds.data(), tw.data(), fetch, store);
-            }
+        auto run = [&](auto colc) {
+            constexpr bool COL = decltype(colc)::value;
+            for (int tid = 0; tid < nt; ++tid) mix_run_first<T, COL, 32>(p, tid, nt, lds.data(), tw.data(), fetch);
+            for (int ph = 1; ph + 1 < p.nstage; ++ph)
+                for (int tid = 0; tid < nt; ++tid) mix_run_mid<T, COL, 32>(p, ph, tid, nt, lds.data(), tw.data());
+            for (int tid = 0; tid < nt; ++tid) mix_run_last<T, COL, 32>(p, tid, nt, lds.data(), store);
+        };
+        if (col) run(std::true_type{}); else run(std::false_type{});
     }
     double err = 0, ref = 0;
     for (int s = 0; s < nseq; ++s) {
@@ -66,8 +70,8 @@ static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift) {
 
 int main() {
     int bad = 0;
-    const int lens[] = {18, 20, 21, 30, 36, 45, 49, 60, 77, 90, 96, 100, 120, 121, 125, 143, 144, 169, 180, 243, 250, 256, 343, 360, 500, 625, 729, 1000,
-                        1001, 1331, 1500, 2187, 2310, 2592, 3000, 3125, 4000, 4096, 5000, 6561, 8000};
+    const int lens[] = {36, 40, 42, 44, 48, 50, 52, 54, 56, 60, 64, 45, 49, 60, 77, 90, 96, 100, 120, 121, 125, 143, 144, 169, 180, 243, 250, 256, 343, 360, 500, 625, 729, 1000,
+                        1001, 1331, 1500, 2187, 2310, 2592, 3000, 3125, 4000, 4004, 4096, 5000, 6000, 6561, 7000, 8000, 324, 400, 441, 484, 576, 625, 676, 729, 784, 900, 1024, 660, 780, 810, 840, 960};
     for (int n : lens) {
         MixPlan p;
         if (!mix_make_plan(n, p)) { printf("n=%d no plan\n", n); ++bad; continue; }
@@ -80,7 +84,7 @@ int main() {
         if (!(e1 < 1e-13) || !(e2 < 1e-13) || !(e3 < 2e-5)) { ++bad; printf("   ^^^ FAIL\n"); }
     }
     MixPlan q;
-    if (mix_make_plan(12, q) || mix_make_plan(17, q) || mix_make_plan(1024 * 17, q) || mix_make_plan(2 * 19, q)) { printf("planned an unsupported length\n"); ++bad; }
+    if (mix_make_plan(12, q) || mix_make_plan(32, q) || mix_make_plan(17, q) || mix_make_plan(1024 * 17, q) || mix_make_plan(2 * 19, q)) { printf("planned an unsupported length\n"); ++bad; }
     printf(bad ? "FAILED (%d)\n" : "all ok\n", bad);
     return bad != 0;
 }
