@@ -101,19 +101,19 @@ __global__ __launch_bounds__(512) void mix_cols_kernel(MixPlan p, BlueIn<T> in, 
     }
 }
 
-static constexpr size_t kMixLdsSoft = 80 * 1024, kMixLdsHard = 156 * 1024;
+static constexpr size_t kMixLdsHard = 156 * 1024;
 
 static inline int round_up64(int v) { return (v + 63) & ~63; }
 
 // threads of a workgroup: one butterfly per thread in the stage with the most butterflies, within [64, 512]
-static inline int mix_threads(const MixPlan& p) {
+static inline int mix_threads(const MixPlan& p, int cap = 512) {
     int rmin = kMixMaxRadix;
     for (int s = 0; s < p.nstage; ++s) rmin = p.radix[s] < rmin ? p.radix[s] : rmin;
     const int most = p.seqs * (p.n / rmin);
     int nt = round_up64(most);
     // several rounds per stage: even them out
-    if (nt > 512) {
-        const int rounds = (most + 511) / 512;
+    if (nt > cap) {
+        const int rounds = (most + cap - 1) / cap;
         nt = round_up64((most + rounds - 1) / rounds);
     }
     if (tuning().mix_nt > 0) nt = round_up64(tuning().mix_nt);
@@ -136,11 +136,13 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     const cx<T>* tw = twiddles<T>(n, &err);
     if (!tw) return err;
     const size_t per = size_t(p.n) * sizeof(cx<T>);
-    // rows per workgroup: as many as keep two workgroups on a CU, at least enough for 256 butterflies per stage of radix 16
-    int seqs = int(kMixLdsSoft / per);
-    if (seqs < 1) seqs = 1;
-    if (seqs > 16) seqs = 16;
-    while (seqs > 1 && (seqs - 1) * (n / 16) >= 256 && int64_t(nseq + seqs - 1) / seqs < 1024) --seqs;   // small arrays: more workgroups
+    // rows per workgroup: two (the twiddle and index work of a butterfly column is shared by nothing, but two rows give the 256 threads
+    // enough butterflies per stage), more for short rows (>= 2048 points per workgroup), within 64 KiB of LDS so that two or three
+    // workgroups share a CU and their load / transform / store phases overlap.  Measured (profiles/r03/exp_mix_sweep.log, us per pass):
+    // 3000-point rows complex64 57.8 at 2 rows x 256 threads against 86.5 (2 x 512) and 69.4 (4 x 512)
+    int seqs = (2048 + n - 1) / n;
+    if (seqs < 2) seqs = 2;
+    while (seqs > 1 && size_t(seqs) * per > size_t(64) * 1024) --seqs;
     if (tuning().mix_seqs > 0) seqs = tuning().mix_seqs;
     if (seqs > nseq) seqs = nseq;
     if (size_t(seqs) * per > kMixLdsHard) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d does not fit the LDS", n);
@@ -152,7 +154,7 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     auto launch = [&](auto kernel) {
         const int rc = mix_set_lds(kernel, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(kernel, dim3(groups), dim3(mix_threads(p)), lds, st, p, mix_in(in), nseq, ro, tw);
+        hipLaunchKernelGGL(kernel, dim3(groups), dim3(mix_threads(p, 256)), lds, st, p, mix_in(in), nseq, ro, tw);
         return int(hipGetLastError());
     };
     if (p.maxr <= 10) return launch(mix_rows_kernel<T, 10>);
@@ -170,11 +172,11 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     const cx<T>* tw = twiddles<T>(n, &err);
     if (!tw) return err;
     const size_t per = size_t(p.n) * sizeof(cx<T>);
-    // adjacent columns per workgroup (a power of two): two workgroups per CU if that leaves pieces of 64 B, else as wide as the LDS holds
-    const int full = int(128 / sizeof(cx<T>));      // a whole 128 B line
-    int tc = 1;
-    while (tc < full && size_t(2 * tc) * per <= kMixLdsSoft) tc *= 2;
-    while (size_t(tc) * sizeof(cx<T>) < 64 && size_t(2 * tc) * per <= kMixLdsHard) tc *= 2;
+    // adjacent columns per workgroup (a power of two): four (32 B pieces of complex64, 64 B of complex128; the tiles of one 128 B line run
+    // on one XCD, see log_g below), fewer when the LDS cannot hold four columns.  Measured (same log): 1000-point columns complex64 10.4 us
+    // at 4 against 12.9 at 8 (two workgroups per CU instead of four); 3000-point columns 78 at 4 (one workgroup per CU) against 102 at 2
+    int tc = 4;
+    while (tc > 1 && size_t(tc) * per > kMixLdsHard) tc /= 2;
     if (tuning().mix_tc > 0) {
         tc = 1;
         while (tc * 2 <= tuning().mix_tc) tc *= 2;

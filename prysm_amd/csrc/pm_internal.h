@@ -120,8 +120,9 @@ struct Tuning {
     int fold = -1;           // radix-2 step of the column transform folded into the row pass: -1 auto, 0 never, 1 wherever legal
     int blue_min = 96;        // shortest non-power-of-two length that takes the Bluestein path (shorter ones, and lengths
                              // above 4096, run on the direct O(n^2) kernel); 0 disables the path
-    int mix = 1;              // composite lengths (primes <= 13, up to 8192) on the mixed-radix kernel (fft_mixed.h) instead of Bluestein; 0: as in
-                              // round 2; 2: also the 3 / 5 / 7 x 2^k lengths of the radix-R step (bigfft.hip)
+    int mix = 1;              // composite lengths (primes <= 13, up to 8192) on the mixed-radix kernel (fft_mixed.h) instead of Bluestein and of
+                              // the radix-R step (profiles/r03/exp_mix.log: 1536^2 complex64 42 us against 61, 2560^2 104 against 119); 0: as in
+                              // round 2; 2: the 3 / 5 / 7 x 2^k lengths stay on the radix-R step (bigfft.hip)
     int mix_log_g = -1;       // ... its column pass: 2^this adjacent tiles per XCD (-1 auto: as many as share a 128 B line)
     int mix_seqs = 0, mix_tc = 0, mix_nt = 0;   // ... force its rows per workgroup / columns per workgroup / threads per workgroup (0 = auto)
     int mix_min = 32;         // ... from this length (shorter ones stay on the direct fp64-accumulating kernel)
@@ -180,7 +181,7 @@ inline int big_split(int64_t n) {
         return 0;
     }
     if (!tuning().mixed_radix || n < 96) return 0;
-    if (tuning().mix == 2 && n >= tuning().mix_min && mix_length(n)) return 0;    // the composite-length kernel takes these too
+    if (tuning().mix == 1 && n >= tuning().mix_min && mix_length(n)) return 0;    // the composite-length kernel takes these (up to 8192)
     for (int R = 3; R <= 7; R += 2) {
         if (n % R) continue;
         const int64_t q = n / R;

@@ -46,6 +46,19 @@ def bluestein_route():
         lib.pm_set_tuning(b'mix', 1)
 
 
+@pytest.fixture
+def radix_r_route():
+    """the lengths 3 / 5 / 7 x 2^k (up to 8192) go back to the radix-R step around engine transforms (csrc/bigfft.hip) for the duration
+    of a test: the mixed-radix kernel owns them by default"""
+    from prysm_amd import _lib
+    lib = _lib.load()
+    lib.pm_set_tuning(b'mix', 2)
+    try:
+        yield lib
+    finally:
+        lib.pm_set_tuning(b'mix', 1)
+
+
 @pytest.fixture(scope='session')
 def golden():
     def load(name):

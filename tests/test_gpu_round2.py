@@ -144,7 +144,7 @@ def test_packed_amp_opd_synthesis_equals_two_array_synthesis(pa):
 
 @pytest.mark.parametrize('shape', [(96, 160), (1536, 1536), (2560, 1024), (448, 1536), (3072, 5120)])
 @pytest.mark.parametrize('dtype', [np.complex64, np.complex128])
-def test_mixed_radix_lengths_vs_numpy(pa, shape, dtype):
+def test_mixed_radix_lengths_vs_numpy(pa, radix_r_route, shape, dtype):
     """lengths 3 / 5 / 7 x 2^k (Q = 1.5 pads, scipy's next_fast_len values) take one radix-R step around engine transforms instead of
     Bluestein's convolution at the next power of two above 2 n: same results as numpy, and as the Bluestein route (knob mixed_radix = 0)"""
     from prysm_amd import _lib
@@ -671,7 +671,7 @@ def test_polychromatic_psf_spectral_equals_loop_and_oracle(pa, n, Q):
 
 @pytest.mark.parametrize('cdtype', [np.complex64, np.complex128])
 @pytest.mark.parametrize('n', [96, 1536, 2560, 3584, 16384, 20480])
-def test_fft1_radix_r_lengths_vs_numpy(pa, n, cdtype):
+def test_fft1_radix_r_lengths_vs_numpy(pa, radix_r_route, n, cdtype):
     """pm_fft1 at the lengths that used to take Bluestein's detour (mixed radix) or the O(n^2) kernel (above 8192): both axes, both
     directions, zero padded inputs (numpy's fft(x, n)) and cropped outputs, odd and even batch extents"""
     from prysm_amd import _ops

@@ -43,7 +43,8 @@ def sweep(n, dt, axis, key, vals, extra=()):
 
 for dt in (torch.complex64, torch.complex128):
     for n in (1000, 3000, 4000):
-        for nt in (0, 128, 256, 512):
-            sweep(n, dt, 1, b'mix_seqs', [0, 1, 2, 4, 8], extra=((b'mix_nt', nt),))
-        for nt in (0, 256, 512):
-            sweep(n, dt, 0, b'mix_tc', [0, 1, 2, 4, 8, 16], extra=((b'mix_nt', nt),))
+        for nt in (0, 256):
+            sweep(n, dt, 1, b'mix_seqs', [0, 1, 2, 4], extra=((b'mix_nt', nt),))
+        for lg in (0, 1, 2, 3):
+            sweep(n, dt, 0, b'mix_tc', [0, 2, 4, 8], extra=((b'mix_log_g', lg),))
+lib.pm_set_tuning(b'mix_log_g', -1)

@@ -195,7 +195,7 @@ def fuzz_fft1(ncases, rng, lib):
         n = int(rng.choice(sizes))
         small = rng.random() < 0.3 and n in (64, 256)
         lib.pm_set_tuning(b'big_native_log', 5 if small else 13)      # 64 / 128 then take the radix-2 / radix-4 step; 256 goes direct
-        lib.pm_set_tuning(b'mix', 0 if rng.random() < 0.2 else 1)     # composite lengths: mostly their own kernel, sometimes round 2's routes
+        lib.pm_set_tuning(b'mix', int(rng.choice([0, 2, 1, 1, 1, 1])))     # composite lengths: mostly their own kernel, sometimes round 2's routes
         if small:
             n = int(rng.choice([64, 128]))
         cdt = np.complex64 if rng.random() < 0.5 else np.complex128
@@ -317,11 +317,11 @@ def main():
         lib.pm_set_tuning(b'fold', fold)
         # routes of awkward lengths: with the native length lowered to 32 and the Bluestein path opened from 20 points, 64 / 128
         # take the radix-2 / radix-4 step of the 16384 / 32768-point path and 20 .. 64 the long both-axes Bluestein form
-        route = str(rng.choice(['default', 'default', 'default', 'small_native', 'unfused', 'bluestein']))
+        route = str(rng.choice(['default', 'default', 'default', 'small_native', 'unfused', 'bluestein', 'radix_r']))
         lib.pm_set_tuning(b'big_native_log', 5 if route == 'small_native' else 13)
         lib.pm_set_tuning(b'blue_min', 20 if route == 'small_native' else 96)
         lib.pm_set_tuning(b'blue_fuse', 0 if route == 'unfused' else 1)
-        lib.pm_set_tuning(b'mix', 0 if route in ('unfused', 'bluestein', 'small_native') else 1)   # composite lengths: their own kernel, or round 2's routes
+        lib.pm_set_tuning(b'mix', 0 if route in ('unfused', 'bluestein', 'small_native') else (2 if route == 'radix_r' else 1))   # composite lengths: their own kernel, or round 2's routes
         scale = float(rng.choice([1.0, 1.0 / np.sqrt(M * N)]))
         shp = (B, m, n) if B else (m, n)
         amp = None
