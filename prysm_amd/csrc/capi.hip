@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "bluestein.h"
+#include "fft_mixed.h"
 #include "pm_internal.h"
 #include "fft_r2c_types.h"
 #include "fft_conv1_types.h"
@@ -73,6 +74,36 @@ static const cx<T>* table_get(int64_t n, int* err) {
 template <> const cx<float>* twiddles<float>(int64_t n, int* err) { return table_get<float>(n, err); }
 template <> const cx<double>* twiddles<double>(int64_t n, int* err) { return table_get<double>(n, err); }
 const cx<double>* twiddles_f64(int64_t n, int* err) { return table_get<double>(n, err); }
+
+// the mixed-radix plan of a composite length (fft_mixed.h) as the kernels read it, same cache, element-size key 1001
+bool mix_plan_for(int n, MixPlan& p);
+const MixPlan* mix_plan_dev(int n, int* err) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        *err = int(e);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(dev, 1001, int64_t(n));
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) return reinterpret_cast<const MixPlan*>(it->second);
+    MixPlan h;
+    if (!mix_plan_for(n, h)) {
+        *err = fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);
+        return nullptr;
+    }
+    void* d = nullptr;
+    e = hipMalloc(&d, sizeof(MixPlan));
+    if (e == hipSuccess) e = hipMemcpy(d, &h, sizeof(MixPlan), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (d) (void)hipFree(d);
+        *err = int(e);
+        return nullptr;
+    }
+    g_tables[key] = d;
+    return reinterpret_cast<const MixPlan*>(d);
+}
 
 // Bluestein tables [w (n) | B (MB)] of a non-power-of-two length n (bluestein.h), same cache, element-size key + 64
 template <typename T>
@@ -326,14 +357,16 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
         p.ws_bytes = 2 * arr;
         return p;
     }
-    p.mix_n = p.logn < 0 && use_mix(N);
-    p.mix_m = p.logm < 0 && use_mix(M);
-    p.blue_n = p.logn < 0 && use_blue(N);
-    p.blue_m = p.logm < 0 && use_blue(M);
+    // the mixed-radix kernel addresses with 32-bit offsets: arrays of 4 GiB and more plan without it
+    const bool mixfit = mix_fits(N, d->in_ld, es, false) && mix_fits(M, N, es, true) && mix_fits(M, d->out_ld, es, true);
+    p.mix_n = mixfit && p.logn < 0 && use_mix(N);
+    p.mix_m = mixfit && p.logm < 0 && use_mix(M);
+    p.blue_n = p.logn < 0 && use_blue(N, mixfit);
+    p.blue_m = p.logm < 0 && use_blue(M, mixfit);
     p.blue_off = (p.ws_bytes + 255) & ~size_t(255);
     const bool noflags = !(d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY | PM_FLAG_SYNTH_INPUT));
     p.blue2d = p.blue_n && p.blue_m && tuning().blue_2d && noflags;
-    p.blue_big = !p.blue2d && tuning().blue_2d && noflags && blue_reach(N) && blue_reach(M) && (blue_needs_both(N) || blue_needs_both(M)) &&
+    p.blue_big = !p.blue2d && tuning().blue_2d && noflags && blue_reach(N) && blue_reach(M) && (blue_needs_both(N, mixfit) || blue_needs_both(M, mixfit)) &&
                  (big_split(blue_conv_len(N)) > 1 || big_split(blue_conv_len(M)) > 1);
     if (p.blue_big) {   // [a (M x N) | c (M x N) | spectrum (MB1 x MB2) | workspace of the big transforms]
         p.blue2d = true;
@@ -1060,7 +1093,7 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
             return launch_row_nat<T>(lg, row_variant(sizeof(T) == 4 ? PM_C64 : PM_C128, lg), lp, sp, tw, int(batch), 0, st);
         }
         DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), in_ld, 1, to_map(*ti), int(batch), conj};
-        if (use_mix(n)) return mix_rows<T>(di, nullptr, 0, st, &sp);
+        if (use_mix(n) && mix_fits(n, in_ld, sizeof(cx<T>), false) && mix_fits(n, out_ld, sizeof(cx<T>), false)) return mix_rows<T>(di, nullptr, 0, st, &sp);
         if (blue_ws) return blue_rows<T>(di, nullptr, 0, blue_ws, st, &sp);
         const cx<double>* tw = twiddles_f64(n, &err);
         if (!tw) return err;
@@ -1088,7 +1121,7 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
         return launch_col_nat<T>(lg, tuning().col_var, cl, cs, tw, ntiles, 1, st);
     }
     DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), 1, in_ld, to_map(*ti), int(batch), conj};
-    if (use_mix(n)) return mix_cols<T>(di, cs, st);
+    if (use_mix(n) && mix_fits(n, in_ld, sizeof(cx<T>), true) && mix_fits(to->n, out_ld, sizeof(cx<T>), true)) return mix_cols<T>(di, cs, st);
     if (blue_ws) return blue_cols<T>(di, cs, blue_ws, st);
     const cx<double>* tw = twiddles_f64(n, &err);
     if (!tw) return err;
@@ -1312,7 +1345,10 @@ int pm_plan_prepare(int32_t dtype, int64_t n) {
         if (!ok) return err;
         if (engine_log2(n) >= 0 || !use_blue_long(n)) return 0;     // a mixed-radix length beside an awkward one still takes Bluestein
     }
-    if (use_mix(n)) return (dtype == PM_C64 ? (const void*)twiddles<float>(n, &err) : (const void*)twiddles<double>(n, &err)) ? 0 : err;
+    if (use_mix(n)) {
+        if (!mix_plan_dev(int(n), &err)) return err;
+        return (dtype == PM_C64 ? (const void*)twiddles<float>(n, &err) : (const void*)twiddles<double>(n, &err)) ? 0 : err;
+    }
     if (use_blue_long(n)) {   // Bluestein tables of n and the twiddles of the convolution length (of its engine part when it is split)
         const int64_t mb = blue_conv_len(n), part = mb / big_split(mb);
         if (dtype == PM_C64) return (blue_tables<float>(n, &err) && twiddles<float>(mb, &err) && twiddles<float>(part, &err)) ? 0 : err;

@@ -189,8 +189,13 @@ struct MixPlan {
     uint32_t mg_radix[kMixMaxStages];   // magic of radix[s]
     uint32_t mg_sub[kMixMaxStages];     // magic of len[s + 1]
     uint32_t mg_nb[kMixMaxStages];      // magic of n / radix[s] (butterflies of one sequence in stage s)
-    int seqs, log_seqs;             // sequences per workgroup (column mode: a power of two)
     int maxr;                       // largest factor (selects the kernel class)
+};
+// The kernels read the plan through a pointer to a device-resident copy (one per length, cached beside the twiddles): a plan passed by
+// value lands in scratch memory once the kernel is large (the compiler keeps the copy of the kernel argument), and its fields then sit in
+// VGPRs.  What varies per launch travels by value:
+struct MixShape {
+    int seqs, log_seqs;             // sequences per workgroup (column mode: a power of two)
 };
 
 // floor(a / d) for a d < 2^16 as (a * magic) >> 32, magic = floor(2^32 / d) + 1 (exact while a d < 2^32); d == 1: magic 0 = identity
@@ -248,8 +253,6 @@ inline void mix_fill_plan(int n, const int* radix, int nstage, MixPlan& p) {
         p.mg_nb[s] = mix_magic(n / p.radix[s]);
     }
     p.maxr = radix[nstage - 1];
-    p.seqs = 1;
-    p.log_seqs = 0;
 }
 inline bool mix_make_plan(int n, MixPlan& p) {
     int radix[kMixMaxStages], nstage = 0;
@@ -261,85 +264,133 @@ inline bool mix_make_plan(int n, MixPlan& p) {
 // ---------------------------------------------------------------------------
 // stages.  `tid` / `nt`: this thread and the threads of the workgroup; sl = sequence slot of the workgroup
 // ---------------------------------------------------------------------------
+// 24-bit multiply (full rate; the 32-bit one is quarter rate): both factors below 2^24, the low 32 bits of the product
+PM_HD uint32_t mix_mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
+// one complex element as ONE 8 / 16 byte access (cx<T> alone only promises the alignment of T)
+template <typename T>
+PM_HD cx<T> mix_ld(const cx<T>* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef T V __attribute__((ext_vector_type(2)));
+    const V w = *reinterpret_cast<const V*>(p);
+    return {w[0], w[1]};
+#else
+    return *p;
+#endif
+}
+template <typename T>
+PM_HD void mix_st(cx<T>* p, cx<T> v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef T V __attribute__((ext_vector_type(2)));
+    V w;
+    w[0] = v.x;
+    w[1] = v.y;
+    *reinterpret_cast<V*>(p) = w;
+#else
+    *p = v;
+#endif
+}
+
 // LDS slot of point i of sequence slot sl, and the slot distance of `d` points (rows: [sl][i]; columns: [i][sl]).  No padding: lanes run
 // along i (or along sl first) with unit stride in every stage but the last, whose reads follow the digit-reversed order
 template <bool COL>
-PM_HD int mix_addr(const MixPlan& p, int sl, int i) {
-    return COL ? ((i << p.log_seqs) + sl) : (sl * p.n + i);
+PM_HD int mix_addr(int n, MixShape sh, int sl, int i) {
+    return COL ? ((i << sh.log_seqs) + sl) : int(mix_mul24(uint32_t(sl), uint32_t(n)) + uint32_t(i));
 }
 template <bool COL>
-PM_HD int mix_step(const MixPlan& p, int d) {
-    return COL ? (d << p.log_seqs) : d;
+PM_HD int mix_step(MixShape sh, int d) {
+    return COL ? (d << sh.log_seqs) : d;
 }
 template <bool COL>
-PM_HD void mix_split(const MixPlan& p, int b, uint32_t mg_nb, int nb, int& sl, int& j) {
+PM_HD void mix_split(MixShape sh, int b, uint32_t mg_nb, int nb, int& sl, int& j) {
     if (COL) {
-        sl = b & (p.seqs - 1);
-        j = b >> p.log_seqs;
+        sl = b & (sh.seqs - 1);
+        j = b >> sh.log_seqs;
     } else {
         sl = mix_div(b, mg_nb);
-        j = b - sl * nb;
+        j = b - int(mix_mul24(uint32_t(sl), uint32_t(nb)));
     }
 }
 
 // first stage: caller's array -> LDS
 template <typename T, bool COL, int R, typename Fetch>
-PM_HD void mix_first(const MixPlan& p, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw, Fetch fetch) {
-    const int nb = p.len[1], total = p.seqs * nb;
+PM_HD void mix_first(const MixPlan& p, MixShape sh, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw, Fetch fetch) {
+    const int n = p.n, nb = p.len[1], total = sh.seqs * nb;
+    const uint32_t mg_nb0 = p.mg_nb[0];
 #pragma unroll 1
     for (int b = tid; b < total; b += nt) {
         int sl, j;
-        mix_split<COL>(p, b, p.mg_nb[0], nb, sl, j);
+        mix_split<COL>(sh, b, mg_nb0, nb, sl, j);
         cx<T> a[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) a[k] = fetch(sl, j + k * nb);
         MixDft<T, R>::run(a);
-        const int a0 = mix_addr<COL>(p, sl, j), as = mix_step<COL>(p, nb);
-        lds[a0] = a[0];
+        const int a0 = mix_addr<COL>(n, sh, sl, j), as = mix_step<COL>(sh, nb);
+        mix_st(lds + a0, a[0]);
 #pragma unroll
-        for (int k = 1; k < R; ++k) lds[a0 + k * as] = cmul(a[k], tw[j * k]);
+        for (int k = 1; k < R; ++k) mix_st(lds + a0 + k * as, cmul(a[k], mix_ld(tw + uint32_t(j) * uint32_t(k))));
     }
 }
 
 // middle stage s: LDS in place
 template <typename T, bool COL, int R>
-PM_HD void mix_mid(const MixPlan& p, int s, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw) {
-    const int nb = p.n / R, total = p.seqs * nb, sub = p.len[s + 1], L = p.len[s], tstep = p.n / L;
+PM_HD void mix_mid(const MixPlan& p, MixShape sh, int s, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw) {
+    const int n = p.n, nb = n / R, total = sh.seqs * nb, sub = p.len[s + 1], L = sub * R, tstep = n / L;
+    const uint32_t mg_nb = p.mg_nb[s], mg_sub = p.mg_sub[s];
 #pragma unroll 1
     for (int b = tid; b < total; b += nt) {
         int sl, ja;
-        mix_split<COL>(p, b, p.mg_nb[s], nb, sl, ja);
-        const int blk = mix_div(ja, p.mg_sub[s]), j = ja - blk * sub, base = blk * L + j;
-        const int a0 = mix_addr<COL>(p, sl, base), as = mix_step<COL>(p, sub);
+        mix_split<COL>(sh, b, mg_nb, nb, sl, ja);
+        const int blk = mix_div(ja, mg_sub), j = ja - int(mix_mul24(uint32_t(blk), uint32_t(sub))),
+                  base = int(mix_mul24(uint32_t(blk), uint32_t(L))) + j;
+        const int a0 = mix_addr<COL>(n, sh, sl, base), as = mix_step<COL>(sh, sub);
         cx<T> a[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) a[k] = lds[a0 + k * as];
+        for (int k = 0; k < R; ++k) a[k] = mix_ld(lds + a0 + k * as);
         MixDft<T, R>::run(a);
-        lds[a0] = a[0];
-        const int tj = j * tstep;
+        mix_st(lds + a0, a[0]);
+        const uint32_t tj = mix_mul24(uint32_t(j), uint32_t(tstep));
 #pragma unroll
-        for (int k = 1; k < R; ++k) lds[a0 + k * as] = cmul(a[k], tw[tj * k]);
+        for (int k = 1; k < R; ++k) mix_st(lds + a0 + k * as, cmul(a[k], mix_ld(tw + tj * uint32_t(k))));
     }
 }
 
 // last stage: LDS -> destination; butterfly o (the low digits of the bin) produces bins o + k n / R
 template <typename T, bool COL, int R, typename Store>
-PM_HD void mix_last(const MixPlan& p, int tid, int nt, const cx<T>* lds, Store store) {
-    const int s = p.nstage - 1, nb = p.n / R, total = p.seqs * nb;
+PM_HD void mix_last(const MixPlan& p, MixShape sh, int tid, int nt, const cx<T>* lds, Store store) {
+    const int n = p.n, s = p.nstage - 1, nb = n / R, total = sh.seqs * nb;
+    const uint32_t mg_nb = p.mg_nb[s];
+    // the digits of the butterfly index: factors, their reciprocals and the slot weights of the stages before the last (uniform values)
+    int rdx[kMixMaxStages - 1], wgt[kMixMaxStages - 1];
+    uint32_t mgr[kMixMaxStages - 1];
+#pragma unroll
+    for (int i = 0; i < kMixMaxStages - 1; ++i) {
+        rdx[i] = i < s ? p.radix[i] : 1;
+        wgt[i] = i < s ? p.len[i + 1] : 0;
+        mgr[i] = i < s ? p.mg_radix[i] : 0u;
+    }
 #pragma unroll 1
     for (int b = tid; b < total; b += nt) {
         int sl, o;
-        mix_split<COL>(p, b, p.mg_nb[s], nb, sl, o);
+        mix_split<COL>(sh, b, mg_nb, nb, sl, o);
         int rem = o, pos = 0;
-        for (int i = 0; i < s; ++i) {
-            const int q = mix_div(rem, p.mg_radix[i]);
-            pos += (rem - q * p.radix[i]) * p.len[i + 1];
-            rem = q;
+#pragma unroll
+        for (int i = 0; i < kMixMaxStages - 1; ++i) {
+            if (i < s) {
+                const int q = mix_div(rem, mgr[i]);
+                pos += int(mix_mul24(uint32_t(rem) - mix_mul24(uint32_t(q), uint32_t(rdx[i])), uint32_t(wgt[i])));
+                rem = q;
+            }
         }
-        const int a0 = mix_addr<COL>(p, sl, pos), as = mix_step<COL>(p, 1);
+        const int a0 = mix_addr<COL>(n, sh, sl, pos), as = mix_step<COL>(sh, 1);
         cx<T> a[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) a[k] = lds[a0 + k * as];
+        for (int k = 0; k < R; ++k) a[k] = mix_ld(lds + a0 + k * as);
         MixDft<T, R>::run(a);
 #pragma unroll
         for (int k = 0; k < R; ++k) store(sl, o + k * nb, a[k]);
@@ -405,34 +456,43 @@ PM_HD void mix_store_row(const MixRowOut<T>& o, int seq, int k, cx<T> v) {
 // the phases of a workgroup's work for thread `tid`: first stage, middle stage `s` (1 .. nstage-2), last stage.  The kernel puts a barrier
 // between phases; the emulator runs every thread of a phase before the next one
 template <typename T, bool COL, int MAXR, typename Fetch>
-PM_HD void mix_run_first(const MixPlan& p, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw, Fetch fetch) {
-    PM_MIX_RADIX_SWITCH(p.radix[0], (mix_first<T, COL, R>(p, tid, nt, lds, tw, fetch)))
+PM_HD void mix_run_first(const MixPlan& p, MixShape sh, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw, Fetch fetch) {
+    PM_MIX_RADIX_SWITCH(p.radix[0], (mix_first<T, COL, R>(p, sh, tid, nt, lds, tw, fetch)))
 }
 template <typename T, bool COL, int MAXR>
-PM_HD void mix_run_mid(const MixPlan& p, int s, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw) {
-    PM_MIX_RADIX_SWITCH(p.radix[s], (mix_mid<T, COL, R>(p, s, tid, nt, lds, tw)))
+PM_HD void mix_run_mid(const MixPlan& p, MixShape sh, int s, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw) {
+    PM_MIX_RADIX_SWITCH(p.radix[s], (mix_mid<T, COL, R>(p, sh, s, tid, nt, lds, tw)))
 }
 template <typename T, bool COL, int MAXR, typename Store>
-PM_HD void mix_run_last(const MixPlan& p, int tid, int nt, const cx<T>* lds, Store store) {
-    PM_MIX_RADIX_SWITCH(p.radix[p.nstage - 1], (mix_last<T, COL, R>(p, tid, nt, lds, store)))
+PM_HD void mix_run_last(const MixPlan& p, MixShape sh, int tid, int nt, const cx<T>* lds, Store store) {
+    PM_MIX_RADIX_SWITCH(p.radix[p.nstage - 1], (mix_last<T, COL, R>(p, sh, tid, nt, lds, store)))
 }
 
-// branch-free element of the DirectIn view: the load always happens (at element 0 of the sequence when the logical index falls outside the
-// stored window or the sequence does not exist -- `ok` false) and the value is selected afterwards, so the R loads of a butterfly issue
-// back to back
-template <typename T>
-PM_HD cx<T> mix_fetch(const BlueIn<T>& in, int seq, bool ok, int i) {
-    int q = in.ax.map(i);
-    ok = ok && q >= 0;
-    q = ok ? q : 0;
-    const int64_t at = int64_t(seq) * in.s_seq + int64_t(q) * in.s_i;
-    cx<T> x;
-    if (in.real)
-        x = {reinterpret_cast<const T*>(in.src)[at], T(0)};
-    else
-        x = reinterpret_cast<const cx<T>*>(in.src)[at];
-    if (in.conj) x.y = -x.y;
-    return ok ? x : cx<T>{T(0), T(0)};
-}
+// Branch-free element of the DirectIn view for the first stage: the load always happens (at element 0 of the workgroup's first sequence
+// when the logical index falls outside the stored window or the sequence does not exist) and the value is selected afterwards, so the
+// R loads of a butterfly issue back to back.  Offsets are 32-bit from a base that is uniform in the workgroup (the launcher checks that
+// they fit: fft_mixed_kernels.h mix_fits).  rows: element (sl, q) at base[sl pitch + q]; columns: at base[q pitch + sl].
+template <typename T, bool COL, bool REAL>
+struct MixFetch {
+    const void* base;
+    uint32_t pitch;
+    AxisMap ax;
+    T ysign;        // -1: conjugated input
+    int nvalid;     // sequences of this workgroup that exist
+    PM_HD cx<T> operator()(int sl, int i) const {
+        int q = ax.map(i);
+        const bool ok = sl < nvalid && q >= 0;
+        q = ok ? q : 0;
+        sl = ok ? sl : 0;
+        const uint32_t off = COL ? mix_mul24(uint32_t(q), pitch) + uint32_t(sl) : mix_mul24(uint32_t(sl), pitch) + uint32_t(q);
+        cx<T> x;
+        if (REAL)
+            x = {reinterpret_cast<const T*>(base)[off], T(0)};
+        else
+            x = mix_ld(reinterpret_cast<const cx<T>*>(base) + off);
+        x.y *= ysign;
+        return ok ? x : cx<T>{T(0), T(0)};
+    }
+};
 
 }  // namespace pm

@@ -1,20 +1,17 @@
-// Kernels and launch templates of the mixed-radix path (fft_mixed.h); instantiated per precision and direction in fft_mixed_*.hip so
-// that the four translation units compile in parallel.  Same contracts as direct_rows / direct_cols (dft_direct.hip) and blue_rows /
-// blue_cols (bluestein.hip), no scratch memory.
+// Kernels and launch templates of the mixed-radix path (fft_mixed.h); instantiated per precision, direction and kernel class in
+// fft_mixed_*.hip so that the translation units compile in parallel.  Same contracts as direct_rows / direct_cols (dft_direct.hip) and
+// blue_rows / blue_cols (bluestein.hip), no scratch memory.
 #pragma once
 #include "fft_mixed.h"
 #include "pm_internal.h"
 
 namespace pm {
 
-bool mix_plan_for(int n, MixPlan& p);   // fft_mixed.hip: the cached factorisation of n
+bool mix_plan_for(int n, MixPlan& p);                 // fft_mixed.hip: the cached factorisation of n
+const MixPlan* mix_plan_dev(int n, int* err);         // capi.hip: its device-resident copy (plan cache, beside the twiddles)
 
-template <typename T>
-static BlueIn<T> mix_in(const DirectIn<T>& in) {
-    return BlueIn<T>{in.src, in.s_seq, in.s_i, in.ax, in.conj, in.real};
-}
-
-// ColStoreNat element store (fft_io.h store_one) without the window test when the caller knows the view keeps every bin
+// ColStoreNat element store (fft_io.h store_one) with a 32-bit offset from the array base, and without the window test when the caller
+// knows the view keeps every bin
 template <bool CHECK, typename T>
 __device__ __forceinline__ void mix_store_col(const ColStoreNat<T>& p, int k, int c, cx<T> x) {
     const int qy = p.ay.map(k), qx = p.ax.map(c);
@@ -28,10 +25,11 @@ __device__ __forceinline__ void mix_store_col(const ColStoreNat<T>& p, int k, in
         const cx<T> h = cmul(p.mul[k], p.mul_x[c]);
         x = p.mul_conj ? cmulc(x, h) : cmul(x, h);
     }
+    const uint32_t off = mix_mul24(uint32_t(qy), uint32_t(p.ld)) + uint32_t(qx);
     if (p.epilogue == EPI_NONE) {
-        reinterpret_cast<cx<T>*>(p.dst)[int64_t(qy) * p.ld + qx] = x;
+        mix_st(reinterpret_cast<cx<T>*>(p.dst) + off, x);
     } else {
-        T* o = reinterpret_cast<T*>(p.dst) + int64_t(qy) * p.ld + qx;
+        T* o = reinterpret_cast<T*>(p.dst) + off;
         const T i2 = x.x * x.x + x.y * x.y;
         if (p.epilogue == EPI_ABS2)
             *o = i2;
@@ -41,63 +39,76 @@ __device__ __forceinline__ void mix_store_col(const ColStoreNat<T>& p, int k, in
 }
 
 template <typename T, int MAXR>
-__global__ __launch_bounds__(512) void mix_rows_kernel(MixPlan p, BlueIn<T> in, int nseq, MixRowOut<T> out, const cx<T>* __restrict__ tw) {
+__global__ __launch_bounds__(512) void mix_rows_kernel(const MixPlan* __restrict__ pp, MixShape sh, DirectIn<T> in, MixRowOut<T> out,
+                                                       const cx<T>* __restrict__ tw) {
+    const MixPlan& p = *pp;
     extern __shared__ __align__(16) char mix_smem[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(mix_smem);
-    const int seq0 = blockIdx.x * p.seqs, tid = threadIdx.x, nt = blockDim.x;
-    const bool full = seq0 + p.seqs <= nseq;
-    auto fetch = [&](int sl, int i) {
-        const bool ok = full || seq0 + sl < nseq;
-        return mix_fetch(in, ok ? seq0 + sl : seq0, ok, i);
-    };
-    mix_run_first<T, false, MAXR>(p, tid, nt, lds, tw, fetch);
+    const int seq0 = blockIdx.x * sh.seqs, tid = threadIdx.x, nt = blockDim.x;
+    const int nvalid = in.nseq - seq0 < sh.seqs ? in.nseq - seq0 : sh.seqs;
+    const T ysign = in.conj ? T(-1) : T(1);
+    if (in.real) {
+        const MixFetch<T, false, true> fetch{reinterpret_cast<const T*>(in.src) + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, ysign, nvalid};
+        mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+    } else {
+        const MixFetch<T, false, false> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, ysign, nvalid};
+        mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+    }
     __syncthreads();
-    for (int s = 1; s + 1 < p.nstage; ++s) {
-        mix_run_mid<T, false, MAXR>(p, s, tid, nt, lds, tw);
+    const int nstage = p.nstage;
+    for (int s = 1; s + 1 < nstage; ++s) {
+        mix_run_mid<T, false, MAXR>(p, sh, s, tid, nt, lds, tw);
         __syncthreads();
     }
-    if (full && !out.mapped) {
-        auto store = [&](int sl, int k, cx<T> v) { out.dst[int64_t(seq0 + sl) * out.ld + k] = v; };
-        mix_run_last<T, false, MAXR>(p, tid, nt, lds, store);
+    if (nvalid == sh.seqs && !out.mapped) {
+        cx<T>* dst0 = out.dst + int64_t(seq0) * out.ld;
+        const uint32_t ld = uint32_t(out.ld);
+        auto store = [&](int sl, int k, cx<T> v) { mix_st(dst0 + (mix_mul24(uint32_t(sl), ld) + uint32_t(k)), v); };
+        mix_run_last<T, false, MAXR>(p, sh, tid, nt, lds, store);
     } else {
         auto store = [&](int sl, int k, cx<T> v) {
-            if (seq0 + sl < nseq) mix_store_row(out, seq0 + sl, k, v);
+            if (sl < nvalid) mix_store_row(out, seq0 + sl, k, v);
         };
-        mix_run_last<T, false, MAXR>(p, tid, nt, lds, store);
+        mix_run_last<T, false, MAXR>(p, sh, tid, nt, lds, store);
     }
 }
 
 template <typename T, int MAXR>
-__global__ __launch_bounds__(512) void mix_cols_kernel(MixPlan p, BlueIn<T> in, int ncols, ColStoreNat<T> out, const cx<T>* __restrict__ tw,
-                                                       int log_g) {
+__global__ __launch_bounds__(512) void mix_cols_kernel(const MixPlan* __restrict__ pp, MixShape sh, DirectIn<T> in, ColStoreNat<T> out,
+                                                       const cx<T>* __restrict__ tw, int log_g) {
+    const MixPlan& p = *pp;
     extern __shared__ __align__(16) char mix_smem[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(mix_smem);
     // workgroups go round the 8 XCDs: slots s, s + 1 .. of ONE XCD take 2^log_g adjacent tiles, which share the 128 B lines of the rows
     // they read and write -- the lines then stay in that XCD's L2 instead of crossing the fabric once per tile
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int tile = ((slot >> log_g) << (log_g + 3)) + (xcd << log_g) + (slot & ((1 << log_g) - 1));
-    const int c0 = tile * p.seqs, tid = threadIdx.x, nt = blockDim.x;
-    if (c0 >= ncols) return;
-    const bool full = c0 + p.seqs <= ncols;
-    auto fetch = [&](int sl, int i) {
-        const bool ok = full || c0 + sl < ncols;
-        return mix_fetch(in, ok ? c0 + sl : c0, ok, i);
-    };
-    mix_run_first<T, true, MAXR>(p, tid, nt, lds, tw, fetch);
+    const int c0 = tile * sh.seqs, tid = threadIdx.x, nt = blockDim.x;
+    if (c0 >= in.nseq) return;
+    const int nvalid = in.nseq - c0 < sh.seqs ? in.nseq - c0 : sh.seqs;
+    const T ysign = in.conj ? T(-1) : T(1);
+    if (in.real) {
+        const MixFetch<T, true, true> fetch{reinterpret_cast<const T*>(in.src) + c0, uint32_t(in.s_i), in.ax, ysign, nvalid};
+        mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+    } else {
+        const MixFetch<T, true, false> fetch{in.src + c0, uint32_t(in.s_i), in.ax, ysign, nvalid};
+        mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+    }
     __syncthreads();
-    for (int s = 1; s + 1 < p.nstage; ++s) {
-        mix_run_mid<T, true, MAXR>(p, s, tid, nt, lds, tw);
+    const int nstage = p.nstage;
+    for (int s = 1; s + 1 < nstage; ++s) {
+        mix_run_mid<T, true, MAXR>(p, sh, s, tid, nt, lds, tw);
         __syncthreads();
     }
     const bool whole = out.ay.off == 0 && out.ay.len == out.ay.n && out.ax.off == 0 && out.ax.len == out.ax.n;
-    if (full && whole) {
+    if (nvalid == sh.seqs && whole) {
         auto store = [&](int sl, int k, cx<T> v) { mix_store_col<false>(out, k, c0 + sl, v); };
-        mix_run_last<T, true, MAXR>(p, tid, nt, lds, store);
+        mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
     } else {
         auto store = [&](int sl, int k, cx<T> v) {
-            if (c0 + sl < ncols) mix_store_col<true>(out, k, c0 + sl, v);
+            if (sl < nvalid) mix_store_col<true>(out, k, c0 + sl, v);
         };
-        mix_run_last<T, true, MAXR>(p, tid, nt, lds, store);
+        mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
     }
 }
 
@@ -105,11 +116,11 @@ static constexpr size_t kMixLdsHard = 156 * 1024;
 
 static inline int round_up64(int v) { return (v + 63) & ~63; }
 
-// threads of a workgroup: one butterfly per thread in the stage with the most butterflies, within [64, 512]
-static inline int mix_threads(const MixPlan& p, int cap = 512) {
+// threads of a workgroup: one butterfly per thread in the stage with the most butterflies, within [64, cap]
+static inline int mix_threads(const MixPlan& p, int seqs, int cap = 512) {
     int rmin = kMixMaxRadix;
     for (int s = 0; s < p.nstage; ++s) rmin = p.radix[s] < rmin ? p.radix[s] : rmin;
-    const int most = p.seqs * (p.n / rmin);
+    const int most = seqs * (p.n / rmin);
     int nt = round_up64(most);
     // several rounds per stage: even them out
     if (nt > cap) {
@@ -126,12 +137,38 @@ static int mix_set_lds(K kernel, size_t bytes) {
     return int(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
 }
 
+// one kernel class (largest factor <= MAXR); defined in fft_mixed_{rows,cols}_{f32,f64}[_big].hip
+template <typename T, int MAXR>
+int mix_rows_launch(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const MixRowOut<T>& ro, const cx<T>* tw, int groups, int nt, size_t lds, hipStream_t st);
+template <typename T, int MAXR>
+int mix_cols_launch(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const ColStoreNat<T>& out, const cx<T>* tw, int log_g, int groups, int nt, size_t lds,
+                    hipStream_t st);
+
+template <typename T, int MAXR>
+int mix_rows_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const MixRowOut<T>& ro, const cx<T>* tw, int groups, int nt, size_t lds,
+                         hipStream_t st) {
+    const int rc = mix_set_lds(mix_rows_kernel<T, MAXR>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((mix_rows_kernel<T, MAXR>), dim3(groups), dim3(nt), lds, st, p, sh, in, ro, tw);
+    return int(hipGetLastError());
+}
+template <typename T, int MAXR>
+int mix_cols_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const ColStoreNat<T>& out, const cx<T>* tw, int log_g, int groups, int nt,
+                         size_t lds, hipStream_t st) {
+    const int rc = mix_set_lds(mix_cols_kernel<T, MAXR>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((mix_cols_kernel<T, MAXR>), dim3(groups), dim3(nt), lds, st, p, sh, in, out, tw, log_g);
+    return int(hipGetLastError());
+}
+
 template <typename T>
 int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o) {
     const int n = in.ax.n, nseq = in.nseq;
     if (nseq <= 0 || n <= 0) return 0;
     MixPlan p;
     if (!mix_plan_for(n, p)) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);
+    if (in.s_i != 1 || !mix_fits(n, in.s_seq, sizeof(cx<T>), false) || !mix_fits(n, o ? o->ld : out_ld, sizeof(cx<T>), false))
+        return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: row pitch beyond 2^24 elements");
     int err = 0;
     const cx<T>* tw = twiddles<T>(n, &err);
     if (!tw) return err;
@@ -146,20 +183,16 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     if (tuning().mix_seqs > 0) seqs = tuning().mix_seqs;
     if (seqs > nseq) seqs = nseq;
     if (size_t(seqs) * per > kMixLdsHard) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d does not fit the LDS", n);
-    p.seqs = seqs;
+    const MixShape sh{seqs, 0};
+    const MixPlan* pd = mix_plan_dev(n, &err);
+    if (!pd) return err;
     const size_t lds = size_t(seqs) * per;
     MixRowOut<T> ro{out, out_ld, AxisMap{n, n, 0, 0}, T(1), 0, 0};
     if (o) ro = MixRowOut<T>{o->dst, o->ld, o->ax, o->scale, o->conj, 1};
-    const int groups = (nseq + seqs - 1) / seqs;
-    auto launch = [&](auto kernel) {
-        const int rc = mix_set_lds(kernel, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kernel, dim3(groups), dim3(mix_threads(p, 256)), lds, st, p, mix_in(in), nseq, ro, tw);
-        return int(hipGetLastError());
-    };
-    if (p.maxr <= 10) return launch(mix_rows_kernel<T, 10>);
-    if (p.maxr <= 16) return launch(mix_rows_kernel<T, 16>);
-    return launch(mix_rows_kernel<T, 32>);
+    const int groups = (nseq + seqs - 1) / seqs, nt = mix_threads(p, seqs, 256);
+    if (p.maxr <= 10) return mix_rows_launch<T, 10>(pd, sh, in, ro, tw, groups, nt, lds, st);
+    if (p.maxr <= 16) return mix_rows_launch<T, 16>(pd, sh, in, ro, tw, groups, nt, lds, st);
+    return mix_rows_launch<T, 32>(pd, sh, in, ro, tw, groups, nt, lds, st);
 }
 
 template <typename T>
@@ -168,6 +201,8 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     if (ncols <= 0 || n <= 0) return 0;
     MixPlan p;
     if (!mix_plan_for(n, p)) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);
+    if (in.s_seq != 1 || !mix_fits(n, in.s_i, sizeof(cx<T>), true) || !mix_fits(out.ay.n, out.ld, sizeof(cx<T>), true))
+        return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: the array does not fit 32-bit offsets");
     int err = 0;
     const cx<T>* tw = twiddles<T>(n, &err);
     if (!tw) return err;
@@ -183,25 +218,20 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     }
     while (tc > 1 && tc / 2 >= ncols) tc /= 2;
     if (size_t(tc) * per > kMixLdsHard) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d does not fit the LDS", n);
-    p.seqs = tc;
-    p.log_seqs = 0;
-    while ((1 << p.log_seqs) < tc) ++p.log_seqs;
+    MixShape sh{tc, 0};
+    while ((1 << sh.log_seqs) < tc) ++sh.log_seqs;
+    const MixPlan* pd = mix_plan_dev(n, &err);
+    if (!pd) return err;
     const size_t lds = size_t(tc) * per;
     // tiles that share a 128 B line run on one XCD (mix_cols_kernel): 2^log_g adjacent tiles, the grid padded to whole rounds of them
     int log_g = 0;
     while ((size_t(tc) << log_g) * sizeof(cx<T>) < 128 && log_g < 3) ++log_g;
     if (tuning().mix_log_g >= 0) log_g = tuning().mix_log_g > 4 ? 4 : tuning().mix_log_g;
     const int tiles = (ncols + tc - 1) / tc, round = 8 << log_g;
-    const int groups = (tiles + round - 1) / round * round;
-    auto launch = [&](auto kernel) {
-        const int rc = mix_set_lds(kernel, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kernel, dim3(groups), dim3(mix_threads(p)), lds, st, p, mix_in(in), ncols, out, tw, log_g);
-        return int(hipGetLastError());
-    };
-    if (p.maxr <= 10) return launch(mix_cols_kernel<T, 10>);
-    if (p.maxr <= 16) return launch(mix_cols_kernel<T, 16>);
-    return launch(mix_cols_kernel<T, 32>);
+    const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc);
+    if (p.maxr <= 10) return mix_cols_launch<T, 10>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
+    if (p.maxr <= 16) return mix_cols_launch<T, 16>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
+    return mix_cols_launch<T, 32>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
 }
 
 }  // namespace pm

@@ -192,6 +192,12 @@ inline int big_split(int64_t n) {
 
 // lengths the mixed-radix kernel takes: not a power of two (the engine's), not one of the radix-R lengths above when `big` says that
 // path owns them
+// ... its kernels address with 32-bit element offsets from a base that is uniform per workgroup and multiply indices by pitches with
+// the 24-bit multiplier: pitches below 2^24 elements, and in column mode (offset = point x pitch) the whole n x pitch array below 4 GiB
+inline bool mix_fits(int64_t n, int64_t pitch, size_t es, bool col) {
+    if (pitch < 0 || pitch >= (int64_t(1) << 24)) return false;
+    return !col || uint64_t(n) * uint64_t(pitch) * es < (uint64_t(1) << 32);
+}
 inline bool use_mix(int64_t n) {
     return tuning().mix && n >= tuning().mix_min && n >= 2 && (n & (n - 1)) != 0 && mix_length(n);
 }
@@ -199,19 +205,20 @@ inline bool use_mix(int64_t n) {
 // lengths the Bluestein path takes (bluestein.h): not a power of two, at least blue_min, and a convolution length
 // MB >= 2n - 1 that the engine runs as it is (use_blue: n <= 4096; the axis-by-axis form and pm_fft1_ws need that) or that
 // the big power-of-two path runs (use_blue_long: n <= 16384; only the both-axes form, two big transforms around the multiply)
-inline bool use_blue_long(int64_t n) {
+// (`mix` false: the caller found that the array does not fit the mixed-radix kernel's 32-bit offsets -- mix_fits -- and plans without it)
+inline bool use_blue_long(int64_t n, bool mix = true) {
     const int lo = tuning().blue_min;
-    return lo > 0 && n >= lo && n >= 2 && (n & (n - 1)) != 0 && n <= (int64_t(1) << 20) && !use_mix(n) && big_split(blue_conv_len(n)) >= 1;
+    return lo > 0 && n >= lo && n >= 2 && (n & (n - 1)) != 0 && n <= (int64_t(1) << 20) && !(mix && use_mix(n)) && big_split(blue_conv_len(n)) >= 1;
 }
-inline bool use_blue(int64_t n) { return use_blue_long(n) && big_split(blue_conv_len(n)) == 1; }
+inline bool use_blue(int64_t n, bool mix = true) { return use_blue_long(n, mix) && big_split(blue_conv_len(n)) == 1; }
 // MIXED shapes with one axis the paths above cannot take alone (a length in (4096, 16384] that is not a power of two, or a
 // 16384-point axis beside a non power of two): the both-axes form runs them with the OTHER axis convolved as well -- any length
 // from 2 whose convolution length the transforms reach (wasteful by the padding of that axis, but O(n log n))
 inline bool blue_reach(int64_t n) { return tuning().blue_min > 0 && n >= 2 && n <= (int64_t(1) << 20) && big_split(blue_conv_len(n)) >= 1; }
-inline bool blue_needs_both(int64_t n) {
+inline bool blue_needs_both(int64_t n, bool mix = true) {
     const bool pow2 = (n & (n - 1)) == 0;
-    if (!blue_reach(n) || use_mix(n)) return false;
-    return pow2 ? big_split(n) > 1 : (n >= tuning().blue_min && !use_blue(n));
+    if (!blue_reach(n) || (mix && use_mix(n))) return false;
+    return pow2 ? big_split(n) > 1 : (n >= tuning().blue_min && !use_blue(n, mix));
 }
 
 }  // namespace pm

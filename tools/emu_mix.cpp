@@ -19,9 +19,8 @@ template <typename T>
 static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift) {
     MixPlan p;
     if (!mix_make_plan(n, p)) return -1;
-    p.seqs = seqs;
-    p.log_seqs = 0;
-    while ((1 << p.log_seqs) < seqs) ++p.log_seqs;
+    MixShape sh{seqs, 0};
+    while ((1 << sh.log_seqs) < seqs) ++sh.log_seqs;
     const ld pi = acosl(-1.0L);
     std::vector<cx<T>> tw(n);
     for (int i = 0; i < n; ++i) tw[i] = {T(cosl(-2 * pi * i / n)), T(sinl(-2 * pi * i / n))};
@@ -35,17 +34,21 @@ static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift) {
     const int ngroups = (nseq + seqs - 1) / seqs;
     for (int g = 0; g < ngroups; ++g) {
         const int seq0 = g * seqs;
-        auto fetch = [&](int sl, int i) { const bool ok = seq0 + sl < nseq; return mix_fetch(in, ok ? seq0 + sl : seq0, ok, i); };
+        const cx<T>* base0 = x.data() + (col ? seq0 : size_t(seq0) * n);
+        const int nvalid = std::min(seqs, nseq - seq0);
+        MixFetch<T, true, false> fc{base0, uint32_t(nseq), in.ax, T(1), nvalid};
+        MixFetch<T, false, false> fr{base0, uint32_t(n), in.ax, T(1), nvalid};
+        auto fetch = [&](int sl, int i) { return col ? fc(sl, i) : fr(sl, i); };
         auto store = [&](int sl, int k, cx<T> v) {
             if (seq0 + sl >= nseq) return;
             if (col) y[size_t(k) * nseq + seq0 + sl] = v; else y[size_t(seq0 + sl) * n + k] = v;
         };
         auto run = [&](auto colc) {
             constexpr bool COL = decltype(colc)::value;
-            for (int tid = 0; tid < nt; ++tid) mix_run_first<T, COL, 32>(p, tid, nt, lds.data(), tw.data(), fetch);
+            for (int tid = 0; tid < nt; ++tid) mix_run_first<T, COL, 32>(p, sh, tid, nt, lds.data(), tw.data(), fetch);
             for (int ph = 1; ph + 1 < p.nstage; ++ph)
-                for (int tid = 0; tid < nt; ++tid) mix_run_mid<T, COL, 32>(p, ph, tid, nt, lds.data(), tw.data());
-            for (int tid = 0; tid < nt; ++tid) mix_run_last<T, COL, 32>(p, tid, nt, lds.data(), store);
+                for (int tid = 0; tid < nt; ++tid) mix_run_mid<T, COL, 32>(p, sh, ph, tid, nt, lds.data(), tw.data());
+            for (int tid = 0; tid < nt; ++tid) mix_run_last<T, COL, 32>(p, sh, tid, nt, lds.data(), store);
         };
         if (col) run(std::true_type{}); else run(std::false_type{});
     }
