@@ -70,7 +70,7 @@ def parse():
     ap.add_argument('--dtype', default='c64', choices=['c64', 'c128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-poly', action='store_true', help='only the headline loop (profiling runs)')
-    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192|padded|mtf|conv|adjoint|poly2048)')
+    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192|padded|composite|mtf|conv|adjoint|poly2048)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget for the CPU baseline sample')
     ap.add_argument('--reduce-method', default='auto', choices=['auto', 'reduce', 'a2a'],
                     help='how the polychromatic image reaches rank 0: one torch.distributed.reduce, or all-to-all of slices + ordered local '
@@ -226,6 +226,14 @@ def other_configs(only=''):
         x6 = torch.from_numpy(make_field(8192, np.complex64, 8192)).cuda()
         out['focus_8192_c64'] = _hbm_entry(_event_ms(lambda: P.focus(x6, 1), 20), 4 * 8192 ** 2 * 8)
         del x6
+    def sec_composite():   # lengths scipy factors natively (prysm/propagation/fft.py:24): the mixed-radix kernel (csrc/fft_mixed.h), 4 N^2 s bytes
+        for n, cdt, key in ((3000, np.complex64, 'focus_3000_c64_mixed_radix'), (1000, np.complex64, 'focus_1000_c64_mixed_radix'),
+                            (3000, np.complex128, 'focus_3000_c128_mixed_radix')):
+            xc = torch.from_numpy(make_field(n, cdt, n)).cuda()
+            out[key] = _hbm_entry(_event_ms(lambda: P.focus(xc, 1), 50), 4 * n ** 2 * xc.element_size(),
+                                  'composite length on its own factors (LDS-resident mixed radix, one kernel per axis); round 2 convolved these at '
+                                  'the next power of two above 2 N (Bluestein)')
+            del xc
     def sec_padded():    # the padded (Q = 2) cases reported separately, graded on 4 N^2 s of the TRANSFORM size although
         for npup, key in ((2048, 'focus_Q2_2048_to_4096_c64'), (1024, 'focus_Q2_1024_to_2048_c64')):     # the row pass skips the zero rows
             xp = torch.from_numpy(make_field(npup, np.complex64, npup + 7)).cuda()
@@ -330,7 +338,7 @@ def other_configs(only=''):
             del x4, ex
         finally:
             config.precision = prec
-    for key, fn in (('config2', sec_config2), ('config3', sec_config3), ('c128', sec_c128), ('n8192', sec_n8192), ('padded', sec_padded), ('mtf', sec_mtf), ('conv', sec_conv), ('adjoint', sec_adjoint), ('config4', sec_config4)):
+    for key, fn in (('config2', sec_config2), ('config3', sec_config3), ('c128', sec_c128), ('n8192', sec_n8192), ('padded', sec_padded), ('composite', sec_composite), ('mtf', sec_mtf), ('conv', sec_conv), ('adjoint', sec_adjoint), ('config4', sec_config4)):
         if not want(key):
             continue
         try:

@@ -34,14 +34,16 @@ def _next_power_of_2(n):
 def next_fast_len(n):
     """The next fast FFT size (prysm/fttools.py:23-31: scipy's next_fast_len, a power of two as the fallback).
 
-    Fast lengths here are what the device transforms without Bluestein's detour: powers of two up to 32768, and from 96 the
-    mixed-radix lengths 3 / 5 / 7 x 2^k with 2^k <= 8192 (one radix-3 / 5 / 7 step around engine transforms, csrc/bigfft.hip),
-    e.g. 2560 for 2559 where a power of two gives 4096.
+    Fast lengths here are powers of two up to 32768, and from 96 the lengths 3 / 5 / 7 x 2^k with 2^k <= 8192 (the mixed-radix kernel
+    up to 8192, one radix-3 / 5 / 7 step around engine transforms above: csrc/fft_mixed.h, csrc/bigfft.hip), e.g. 2560 for 2559
+    where a power of two gives 4096.
 
-    Trade-off (these are not scipy's values, which also admit 2^a 3^b 5^c ... lengths): an array padded to a mixed-radix length
-    transforms ~3x faster than through Bluestein but leaves the paths that need engine powers of two -- the fused
-    fft2 -> multiply -> ifft2 chain, pupil synthesis inside the row load, the Hermitian real-input path, grouped wavelengths --
-    for the composed / radix-R routes.  Callers that want those paths pad to a power of two (``1 << ceil(log2(n))``).
+    Trade-off (these are not scipy's values, which also admit 2^a 3^b 5^c ... lengths): composite lengths up to 8192 do run on their
+    own factors (the mixed-radix kernel, csrc/fft_mixed.h: 3000^2 complex64 in 110 us), but at about half the memory-bound rate of the
+    engine -- 4096^2 takes 99.5 us -- so the fastest length at or above n is still one of the lengths returned here.  A non power of
+    two also leaves the paths that need engine lengths -- the fused fft2 -> multiply -> ifft2 chain, pupil synthesis inside the row
+    load, the Hermitian real-input path, grouped wavelengths -- for the composed routes.  Callers that want those paths pad to a power
+    of two (``1 << ceil(log2(n))``).
     """
     n = int(n)
     best = _next_power_of_2(n)

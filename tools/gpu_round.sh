@@ -18,7 +18,7 @@ prof bench --steps 40 --warmup 5 --no-cpu-baseline --no-poly
 # the default bench line AFTER the PMC passes of the same sources: its roofline.traffic comes from the summary just collected
 cp $O/pmc_bench_summary.json $R/profiles/pmc_bench_summary.json
 ( timeout 900 python bench.py ) > $O/bench.log 2>&1
-for c in config2 config3 config4 c128 n8192 padded mtf conv adjoint poly2048; do prof $c --only $c; done
+for c in config2 config3 config4 c128 n8192 padded composite mtf conv adjoint poly2048; do prof $c --only $c; done
 ( cd /tmp && timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq_config4 -- python $R/bench.py --only config4 ) > $O/rocprof_sq_config4.log 2>&1
 python tools/pmc_clock.py $O/pmc_sq_config4 2>&1 | grep pm:: > $O/config4_mfma_busy.txt
 tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; tail -1 $O/bench.log | cut -c1-400; cat $O/pmc_bench_summary.txt; cat $O/config4_mfma_busy.txt
