@@ -2,6 +2,10 @@
 // fft_mixed_*.hip so that the translation units compile in parallel.  Same contracts as direct_rows / direct_cols (dft_direct.hip) and
 // blue_rows / blue_cols (bluestein.hip), no scratch memory.
 #pragma once
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "fft_mixed.h"
 #include "pm_internal.h"
 
@@ -131,10 +135,21 @@ static inline int mix_threads(const MixPlan& p, int seqs, int cap = 512) {
     return nt < 64 ? 64 : (nt > 512 ? 512 : nt);
 }
 
+// more than 64 KiB of dynamic LDS needs the kernel's limit raised: once per (kernel, device), to the most any launch asks for
 template <typename K>
 static int mix_set_lds(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
-    return int(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
+    const void* f = reinterpret_cast<const void*>(kernel);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& d : done)
+        if (d.first == f && d.second == dev) return 0;
+    const int rc = int(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(kMixLdsHard)));
+    if (rc == 0) done.emplace_back(f, dev);
+    return rc;
 }
 
 // one kernel class (largest factor <= MAXR); defined in fft_mixed_{rows,cols}_{f32,f64}[_big].hip
