@@ -162,6 +162,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("mix_seqs")) t.mix_seqs = v < 0 ? 0 : v;
     else if (is("mix_tc")) t.mix_tc = v < 0 ? 0 : v;
     else if (is("mix_nt")) t.mix_nt = v < 0 ? 0 : v;
+    else if (is("mix_ntc")) t.mix_ntc = v < 0 ? 0 : v;
     else if (is("r2c")) t.r2c = v < 0 ? -1 : (v > 1 ? 2 : v);
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
     else if (is("colmul_mode")) t.colmul_mode = v;

@@ -13,7 +13,7 @@
 // (stages - 1) times.  The last stage has no twiddles (the planner puts the largest factor there) and enumerates its butterflies by the
 // LOW digits of the bin index, so that adjacent lanes store adjacent bins.
 //
-// The factor of each stage is a run-time value (one kernel per class of largest factor -- 10, 16, 32 -- serves every length); the small
+// The factor of each stage is a run-time value (one kernel per class of largest factor -- 10, 16, 20, 32 -- serves every length); the small
 // DFTs are compile-time (a switch over the factors of the class).
 // Row mode: a workgroup holds `seqs` memory rows, lanes run along the row.  Column mode: `seqs` adjacent columns (a power of two),
 // lanes run across the columns first -- pieces of seqs elements per row of the array.

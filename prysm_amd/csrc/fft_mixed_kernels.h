@@ -121,7 +121,7 @@ static constexpr size_t kMixLdsHard = 156 * 1024;
 static inline int round_up64(int v) { return (v + 63) & ~63; }
 
 // threads of a workgroup: one butterfly per thread in the stage with the most butterflies, within [64, cap]
-static inline int mix_threads(const MixPlan& p, int seqs, int cap = 512) {
+static inline int mix_threads(const MixPlan& p, int seqs, int cap, int forced) {
     int rmin = kMixMaxRadix;
     for (int s = 0; s < p.nstage; ++s) rmin = p.radix[s] < rmin ? p.radix[s] : rmin;
     const int most = seqs * (p.n / rmin);
@@ -131,7 +131,7 @@ static inline int mix_threads(const MixPlan& p, int seqs, int cap = 512) {
         const int rounds = (most + cap - 1) / cap;
         nt = round_up64((most + rounds - 1) / rounds);
     }
-    if (tuning().mix_nt > 0) nt = round_up64(tuning().mix_nt);
+    if (forced > 0) nt = round_up64(forced);
     return nt < 64 ? 64 : (nt > 512 ? 512 : nt);
 }
 
@@ -152,7 +152,9 @@ static int mix_set_lds(K kernel, size_t bytes) {
     return rc;
 }
 
-// one kernel class (largest factor <= MAXR); defined in fft_mixed_{rows,cols}_{f32,f64}[_big].hip
+// one kernel class (largest factor <= MAXR: 10, 16, 20, 32); defined in fft_mixed_{rows,cols}_{f32,f64}[_mid|_big].hip.  Registers per
+// class, rows complex64 / complex128: 66 / 94, 94 / 176, 106 / 186, 171 / 256 with spills -- 3000 = 10 x 15 x 20 and 4000 = 10 x 20 x 20 are
+// why the class of 20 exists
 template <typename T, int MAXR>
 int mix_rows_launch(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const MixRowOut<T>& ro, const cx<T>* tw, int groups, int nt, size_t lds, hipStream_t st);
 template <typename T, int MAXR>
@@ -188,13 +190,13 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     const cx<T>* tw = twiddles<T>(n, &err);
     if (!tw) return err;
     const size_t per = size_t(p.n) * sizeof(cx<T>);
-    // rows per workgroup: two (the twiddle and index work of a butterfly column is shared by nothing, but two rows give the 256 threads
-    // enough butterflies per stage), more for short rows (>= 2048 points per workgroup), within 64 KiB of LDS so that two or three
-    // workgroups share a CU and their load / transform / store phases overlap.  Measured (profiles/r03/exp_mix_sweep.log, us per pass):
-    // 3000-point rows complex64 57.8 at 2 rows x 256 threads against 86.5 (2 x 512) and 69.4 (4 x 512)
-    int seqs = (2048 + n - 1) / n;
+    // rows per workgroup: two (256 threads then have enough butterflies per stage), more for short rows (about 2048 points per
+    // workgroup), within 48 KiB of LDS so that three workgroups share a CU and their load / transform / store phases overlap.  Measured
+    // (profiles/r03/exp_mix_sweep.log, 2-D transform, us): 1000^2 complex64 19.8 at 2 rows against 22.2 at 3; 4000^2 167 at 1 row
+    // (32 KiB) against 182 at 2; 3000^2 97 at 1 or 2 and 115 at 4; complex128 3000^2 206 at 1 against 219 at 2
+    int seqs = 2048 / n;
     if (seqs < 2) seqs = 2;
-    while (seqs > 1 && size_t(seqs) * per > size_t(64) * 1024) --seqs;
+    while (seqs > 1 && size_t(seqs) * per > size_t(48) * 1024) --seqs;
     if (tuning().mix_seqs > 0) seqs = tuning().mix_seqs;
     if (seqs > nseq) seqs = nseq;
     if (size_t(seqs) * per > kMixLdsHard) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d does not fit the LDS", n);
@@ -204,9 +206,10 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     const size_t lds = size_t(seqs) * per;
     MixRowOut<T> ro{out, out_ld, AxisMap{n, n, 0, 0}, T(1), 0, 0};
     if (o) ro = MixRowOut<T>{o->dst, o->ld, o->ax, o->scale, o->conj, 1};
-    const int groups = (nseq + seqs - 1) / seqs, nt = mix_threads(p, seqs, 256);
+    const int groups = (nseq + seqs - 1) / seqs, nt = mix_threads(p, seqs, 256, tuning().mix_nt);
     if (p.maxr <= 10) return mix_rows_launch<T, 10>(pd, sh, in, ro, tw, groups, nt, lds, st);
     if (p.maxr <= 16) return mix_rows_launch<T, 16>(pd, sh, in, ro, tw, groups, nt, lds, st);
+    if (p.maxr <= 20) return mix_rows_launch<T, 20>(pd, sh, in, ro, tw, groups, nt, lds, st);
     return mix_rows_launch<T, 32>(pd, sh, in, ro, tw, groups, nt, lds, st);
 }
 
@@ -243,9 +246,10 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     while ((size_t(tc) << log_g) * sizeof(cx<T>) < 128 && log_g < 3) ++log_g;
     if (tuning().mix_log_g >= 0) log_g = tuning().mix_log_g > 4 ? 4 : tuning().mix_log_g;
     const int tiles = (ncols + tc - 1) / tc, round = 8 << log_g;
-    const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc);
+    const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc, 512, tuning().mix_ntc);
     if (p.maxr <= 10) return mix_cols_launch<T, 10>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
     if (p.maxr <= 16) return mix_cols_launch<T, 16>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
+    if (p.maxr <= 20) return mix_cols_launch<T, 20>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
     return mix_cols_launch<T, 32>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
 }
 

@@ -124,7 +124,7 @@ struct Tuning {
                               // the radix-R step (profiles/r03/exp_mix.log: 1536^2 complex64 42 us against 61, 2560^2 104 against 119); 0: as in
                               // round 2; 2: the 3 / 5 / 7 x 2^k lengths stay on the radix-R step (bigfft.hip)
     int mix_log_g = -1;       // ... its column pass: 2^this adjacent tiles per XCD (-1 auto: as many as share a 128 B line)
-    int mix_seqs = 0, mix_tc = 0, mix_nt = 0;   // ... force its rows per workgroup / columns per workgroup / threads per workgroup (0 = auto)
+    int mix_seqs = 0, mix_tc = 0, mix_nt = 0, mix_ntc = 0;   // ... force its rows per workgroup / columns per workgroup / threads per workgroup of the row pass / of the column pass (0 = auto)
     int mix_min = 32;         // ... from this length (shorter ones stay on the direct fp64-accumulating kernel)
     int blue_fuse = 1;        // both-axes form on engine lengths: chirp multiplies inside the chain's first load / last store (1)
                              // or as separate kernels around it (0)

@@ -1,5 +1,4 @@
-"""Mixed-radix kernel: row pass and column pass timed alone (pm_fft1 along each axis of an n x n array) over the launch-shape knobs."""
-import sys
+"""Mixed-radix kernel: the 2-D transform (one row-pass and one column-pass kernel) over the launch-shape knobs, one knob at a time."""
 import torch
 from prysm_amd import _ops, _lib
 
@@ -22,29 +21,27 @@ def timed(fn, reps=20):
     return best
 
 
-def sweep(n, dt, axis, key, vals, extra=()):
+def sweep(n, dt, key, vals, extra=()):
     x = torch.randn(n, n, dtype=dt, device='cuda')
     res = []
+    for k2, v2 in extra:
+        lib.pm_set_tuning(k2, v2)
     for v in vals:
         lib.pm_set_tuning(key, v)
-        for k2, v2 in extra:
-            lib.pm_set_tuning(k2, v2)
         try:
-            t = timed(lambda: _ops.fft1(x, n, axis=axis))
+            t = timed(lambda: _ops.fft2(x, direction=-1, scale=1.0))
             res.append('%s=%d %.1f' % (key.decode(), v, t))
         except Exception as exc:
-            res.append('%s=%d EXC %s' % (key.decode(), v, repr(exc)[:60]))
-    lib.pm_set_tuning(key, 0)
+            res.append('%s=%d EXC %s' % (key.decode(), v, repr(exc)[:40]))
+    lib.pm_set_tuning(key, -1 if key == b'mix_log_g' else 0)
     for k2, _ in extra:
         lib.pm_set_tuning(k2, 0)
-    b = n * n * (8 if dt == torch.complex64 else 16)
-    print('SWEEP %s n=%d axis=%d %s: %s   (2 x bytes / 5 TB/s = %.1f us)' % ('c64' if dt == torch.complex64 else 'c128', n, axis, dict(extra), ' | '.join(res), 2 * b / 5e12 * 1e6))
+    print('SWEEP %s %d^2 %s: %s' % ('c64' if dt == torch.complex64 else 'c128', n, {k.decode(): v for k, v in extra}, ' | '.join(res)))
 
 
 for dt in (torch.complex64, torch.complex128):
-    for n in (1000, 3000, 4000):
-        for nt in (0, 256):
-            sweep(n, dt, 1, b'mix_seqs', [0, 1, 2, 4], extra=((b'mix_nt', nt),))
-        for lg in (0, 1, 2, 3):
-            sweep(n, dt, 0, b'mix_tc', [0, 2, 4, 8], extra=((b'mix_log_g', lg),))
-lib.pm_set_tuning(b'mix_log_g', -1)
+    for n in (1000, 2000, 3000, 4000, 6000):
+        sweep(n, dt, b'mix_seqs', [0, 1, 2, 3, 4])
+        sweep(n, dt, b'mix_seqs', [1, 2, 4], extra=((b'mix_nt', 128),))
+        sweep(n, dt, b'mix_tc', [0, 2, 4, 8])
+        sweep(n, dt, b'mix_tc', [2, 4], extra=((b'mix_ntc', 256),))
