@@ -51,8 +51,12 @@ __global__ __launch_bounds__(512) void mix_rows_kernel(const MixPlan* __restrict
     const int seq0 = blockIdx.x * sh.seqs, tid = threadIdx.x, nt = blockDim.x;
     const int nvalid = in.nseq - seq0 < sh.seqs ? in.nseq - seq0 : sh.seqs;
     const T ysign = in.conj ? T(-1) : T(1);
+    const bool whole = in.ax.off == 0 && in.ax.len == in.ax.n && nvalid == sh.seqs;
     if (in.real) {
         const MixFetch<T, false, true> fetch{reinterpret_cast<const T*>(in.src) + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, ysign, nvalid};
+        mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+    } else if (whole) {
+        const MixFetchWhole<T, false> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax.n, in.ax.shift, ysign};
         mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     } else {
         const MixFetch<T, false, false> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, ysign, nvalid};
@@ -91,8 +95,12 @@ __global__ __launch_bounds__(512) void mix_cols_kernel(const MixPlan* __restrict
     if (c0 >= in.nseq) return;
     const int nvalid = in.nseq - c0 < sh.seqs ? in.nseq - c0 : sh.seqs;
     const T ysign = in.conj ? T(-1) : T(1);
+    const bool whole_in = in.ax.off == 0 && in.ax.len == in.ax.n && nvalid == sh.seqs;
     if (in.real) {
         const MixFetch<T, true, true> fetch{reinterpret_cast<const T*>(in.src) + c0, uint32_t(in.s_i), in.ax, ysign, nvalid};
+        mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+    } else if (whole_in) {
+        const MixFetchWhole<T, true> fetch{in.src + c0, uint32_t(in.s_i), in.ax.n, in.ax.shift, ysign};
         mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     } else {
         const MixFetch<T, true, false> fetch{in.src + c0, uint32_t(in.s_i), in.ax, ysign, nvalid};

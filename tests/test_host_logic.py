@@ -70,6 +70,17 @@ def test_fft_engine_emulation():
     assert 'EMU OK' in out.stdout
 
 
+def test_mixed_radix_kernel_emulation():
+    """tools/emu_mix.cpp: the per-thread code of the mixed-radix kernel (csrc/fft_mixed.h: planner, every small DFT from 2 to 32, first /
+    middle / last stages, digit-reversed last stage, row and column layouts) run thread by thread against a long-double DFT"""
+    exe = '/tmp/pm_emu_mix_test'
+    subprocess.run(['g++', '-O2', '-std=c++17', '-I', os.path.join(ROOT, 'prysm_amd', 'csrc'),
+                    os.path.join(ROOT, 'tools', 'emu_mix.cpp'), '-o', exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert 'all ok' in out.stdout
+
+
 REF = '/root/reference'
 
 

@@ -38,7 +38,10 @@ static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift) {
         const int nvalid = std::min(seqs, nseq - seq0);
         MixFetch<T, true, false> fc{base0, uint32_t(nseq), in.ax, T(1), nvalid};
         MixFetch<T, false, false> fr{base0, uint32_t(n), in.ax, T(1), nvalid};
-        auto fetch = [&](int sl, int i) { return col ? fc(sl, i) : fr(sl, i); };
+        MixFetchWhole<T, true> wc{base0, uint32_t(nseq), n, shift, T(1)};
+        MixFetchWhole<T, false> wr{base0, uint32_t(n), n, shift, T(1)};
+        const bool whole = nvalid == seqs && (g % 2 == 0);     // alternate the two loaders over the groups
+        auto fetch = [&](int sl, int i) { return whole ? (col ? wc(sl, i) : wr(sl, i)) : (col ? fc(sl, i) : fr(sl, i)); };
         auto store = [&](int sl, int k, cx<T> v) {
             if (seq0 + sl >= nseq) return;
             if (col) y[size_t(k) * nseq + seq0 + sl] = v; else y[size_t(seq0 + sl) * n + k] = v;

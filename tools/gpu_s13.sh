@@ -1,5 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/s13; rm -rf $O; mkdir -p $O
-( PYTHONPATH=$R timeout 900 python tools/exp_mix_sweep.py 2>&1 | grep -E "SWEEP|Error|error" ) > $O/sweep.log 2>&1
-cat $O/sweep.log
+( timeout 900 python -m pytest tests/test_gpu_round3.py -x -q -m gpu -k "composite or mixed_radix_kernel" 2>&1 | tail -15 ) > $O/pytest_mix.log 2>&1
+( PYTHONPATH=$R timeout 600 python tools/exp_mix.py 2>&1 | grep -E "MIX|Error|error" ) > $O/exp_mix.log 2>&1
+tail -5 $O/pytest_mix.log; cat $O/exp_mix.log
