@@ -152,7 +152,7 @@ typedef struct pm_fft2_desc {
 
 /* Transform lengths (per axis): powers of two from 2 to 8192 run on the Stockham engine; composite lengths from 32 to 8192 whose prime
  * factors are all <= 13 (1000, 1536, 2592, 3000, 6000 ...: what scipy.fft factors natively) run on their own factors in one LDS-resident
- * mixed-radix kernel per axis with no scratch (3000^2 complex64: 110 us; arrays of 4 GiB and more keep the routes below); 16384 and
+ * mixed-radix kernel per axis with no scratch (3000^2 complex64: 95 us; arrays of 4 GiB and more keep the routes below); 16384 and
  * 32768 take one radix-2 / radix-4 step around engine transforms (16384^2 complex64: 4.3 ms), and so do 3 / 5 / 7 x 2^k above 8192
  * (10240, 12288 ...: radix 3 / 5 / 7) when the other axis is a power of two or such a length too; other lengths from 96 to 4096 (a prime
  * factor above 13: 997, 1009 ...) run on the engine through Bluestein's identity (chirp multiply, power-of-two convolution of length >= 2n - 1, chirp multiply;
