@@ -244,6 +244,9 @@ struct Fft2Plan {
     bool fold;            // one radix-2 step of the column transform is taken in the row pass (RowStoreFold): the column
                           // pass then runs two planes of M/2-point tiles
     bool mix_n, mix_m;    // the row / column transforms take the mixed-radix kernel (composite lengths, fft_mixed.hip)
+    int64_t w_ld;         // row pitch of the NATURAL intermediate (tc == 0), in elements: N, or N rounded up to whole 128 B lines when the
+                          // column pass is the mixed-radix kernel -- its 32 / 64 B pieces then share lines only inside one XCD group
+                          // (3000 complex64 columns: rows of 24000 B put every other row half a line off and the pass read 1.52x its bytes)
     bool blue_n, blue_m;  // the row / column transforms take the Bluestein path (non-power-of-two lengths, bluestein.hip)
     size_t blue_off;      // its scratch sits behind the intermediates in the workspace (shared by the two passes)
     int big_rn, big_rm;   // power-of-two lengths above the engine's: radix of the extra step per axis (1 = none), 0 = not this path
@@ -298,6 +301,7 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
     const size_t es = d->dtype == PM_C64 ? 8 : 16;
     const int64_t rows = d->in_y.len;   // only stored input rows are transformed in pass 1
     p.fold = false;
+    p.w_ld = N;
     p.r2c = allow_r2c && p.logn >= 0 && p.logm >= 0 && r2c_legal(d, p.logn, p.logm);
     if (p.r2c) {
         p.col_var = 0;
@@ -336,7 +340,11 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
     } else {
         p.tc = 0;
         p.log_k = 0;
-        p.ws_bytes = size_t(rows) * size_t(N) * es;
+        if (p.logm < 0 && use_mix(M)) {
+            const int64_t line = int64_t(128 / es);
+            p.w_ld = (N + line - 1) / line * line;
+        }
+        p.ws_bytes = size_t(rows) * size_t(p.w_ld) * es;
     }
     if (p.ws_bytes == 0) p.ws_bytes = es;
     p.nbatch = d->batch > 1 ? d->batch : 1;
@@ -359,7 +367,7 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
         return p;
     }
     // the mixed-radix kernel addresses with 32-bit offsets: arrays of 4 GiB and more plan without it
-    const bool mixfit = mix_fits(N, d->in_ld, es, false) && mix_fits(M, N, es, true) && mix_fits(M, d->out_ld, es, true);
+    const bool mixfit = mix_fits(N, d->in_ld, es, false) && mix_fits(M, p.w_ld, es, true) && mix_fits(M, d->out_ld, es, true);
     p.mix_n = mixfit && p.logn < 0 && use_mix(N);
     p.mix_m = mixfit && p.logm < 0 && use_mix(M);
     p.blue_n = p.logn < 0 && use_blue(N, mixfit);
@@ -517,7 +525,7 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
                 RowStoreTiled<T> sp{W, rows, ltc, wstride};
                 rc = launch_row_tiled<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, tuning().row_log_g, st, nb);
             } else {
-                RowStoreNat<T> sp{W, N, AxisMap{int(N), int(N), 0, 0}, rows, 0, T(1), 0, AxisMap{1, 1, 0, 0}};
+                RowStoreNat<T> sp{W, p.w_ld, AxisMap{int(N), int(N), 0, 0}, rows, 0, T(1), 0, AxisMap{1, 1, 0, 0}};
                 rc = launch_row_nat<T>(p.logn, row_variant(d->dtype, p.logn), lp, sp, tw, rows, 0, st);
             }
             if (rc) return rc;
@@ -526,13 +534,13 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
                            (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
             int rc;
             if (p.mix_n) {
-                rc = mix_rows<T>(di, W, N, st);
+                rc = mix_rows<T>(di, W, p.w_ld, st);
             } else if (p.blue_n) {
-                rc = blue_rows<T>(di, W, N, static_cast<char*>(ws) + p.blue_off, st);
+                rc = blue_rows<T>(di, W, p.w_ld, static_cast<char*>(ws) + p.blue_off, st);
             } else {
                 const cx<double>* tw = twiddles_f64(N, &err);
                 if (!tw) return err;
-                rc = direct_rows<T>(di, W, N, tw, st);
+                rc = direct_rows<T>(di, W, p.w_ld, tw, st);
             }
             if (rc) return rc;
         }
@@ -565,10 +573,10 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         }
         const int tc = col_tile_width_for(d->dtype, p.logm, 0);
         const int ntiles = int((N + tc - 1) / tc);
-        ColLoadNat<T> cl{W, N, to_map(d->in_y), int(N), 0, (N % 2 == 0) ? 1 : 0};
+        ColLoadNat<T> cl{W, p.w_ld, to_map(d->in_y), int(N), 0, (p.w_ld % 2 == 0) ? 1 : 0};
         return launch_col_nat<T>(p.logm, 0, cl, cs, tw, ntiles, 1, st);
     }
-    DirectIn<T> di{W, 1, N, to_map(d->in_y), int(N), 0};   // sequence = column c at W[c], element stride N
+    DirectIn<T> di{W, 1, p.w_ld, to_map(d->in_y), int(N), 0};   // sequence = column c at W[c], element stride = the pitch of the intermediate
     if (p.mix_m) return mix_cols<T>(di, cs, st);
     if (p.blue_m) return blue_cols<T>(di, cs, static_cast<char*>(ws) + p.blue_off, st);
     const cx<double>* tw = twiddles_f64(M, &err);

@@ -94,7 +94,7 @@ def test_workspace_queries_of_the_mixed_radix_path(lib):
     d.dtype, d.direction = L.PM_C64, -1
     d.in_y = d.in_x = d.out_y = d.out_x = L.pm_axis(1000, 1000, 0, 500)
     d.in_ld = d.out_ld = 1000
-    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 1000 * 1000 * 8
+    assert lib.pm_fft2_workspace(ctypes.byref(d)) == 1000 * 1008 * 8     # rows of the intermediate padded to whole 128 B lines
     d.in_y = d.out_y = L.pm_axis(3000, 3000, 0, 0)
     d.dtype = L.PM_C128
     assert lib.pm_fft2_workspace(ctypes.byref(d)) == 3000 * 1000 * 16
