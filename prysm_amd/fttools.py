@@ -39,7 +39,7 @@ def next_fast_len(n):
     where a power of two gives 4096.
 
     Trade-off (these are not scipy's values, which also admit 2^a 3^b 5^c ... lengths): composite lengths up to 8192 do run on their
-    own factors (the mixed-radix kernel, csrc/fft_mixed.h: 3000^2 complex64 in 95 us), but at a little over half the memory-bound rate
+    own factors (the mixed-radix kernel, csrc/fft_mixed.h: 3000^2 complex64 in 92 us), but at a little over half the memory-bound rate
     of the engine (2000^2 39 us against 32 us for 2048^2), so the lengths returned here remain the safe choice.  A non power of
     two also leaves the paths that need engine lengths -- the fused fft2 -> multiply -> ifft2 chain, pupil synthesis inside the row
     load, the Hermitian real-input path, grouped wavelengths -- for the composed routes.  Callers that want those paths pad to a power
