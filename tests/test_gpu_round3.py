@@ -497,3 +497,22 @@ def test_focus_6000_on_the_mixed_radix_kernel(pa):
     ev1.record()
     torch.cuda.synchronize()
     print('focus 8000^2 complex64 (mixed radix): %.2f ms' % ev0.elapsed_time(ev1))
+
+
+def test_otf_and_padded_focus_on_composite_grids(pa):
+    """the SURVEY 8(f) wrappers and a Q = 1.5 pad on composite grids: `mtf_from_psf` / `ptf_from_psf` of a real 600 x 1000 PSF (real input
+    read as it is by the mixed-radix first stage, centre normalisation and |.| / angle by the common epilogue) and
+    `Wavefront.focus(Q=1.5)` of a 1000^2 pupil (1500^2 transform with the pad in the load window)"""
+    rng = np.random.default_rng(600)
+    psf = rng.random((600, 1000)) + 0.01
+    F = np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(psf)))
+    F = F / F[300, 500]
+    assert rel_max(tonp(pa.otf.mtf_from_psf(psf, 1.0).data), np.abs(F)) < TOL64
+    got = tonp(pa.otf.ptf_from_psf(psf, 1.0).data)
+    big = np.abs(F) > 1e-3
+    assert np.max(np.abs(np.angle(np.exp(1j * (got - np.angle(F))))[big])) < 1e-8
+    x = crandn(rng, (1000, 1000), np.complex64)
+    ref = O.focus(x.astype(np.complex128), 1.5)
+    assert ref.shape == (1500, 1500)
+    assert rel_max(tonp(pa.propagation.focus(x, 1.5)), ref) < TOL32
+    assert rel_max(tonp(pa.propagation.focus_intensity(x, 1.5)), O.intensity(ref)) < 2 * TOL32
