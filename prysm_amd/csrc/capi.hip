@@ -75,9 +75,9 @@ template <> const cx<float>* twiddles<float>(int64_t n, int* err) { return table
 template <> const cx<double>* twiddles<double>(int64_t n, int* err) { return table_get<double>(n, err); }
 const cx<double>* twiddles_f64(int64_t n, int* err) { return table_get<double>(n, err); }
 
-// the mixed-radix plan of a composite length (fft_mixed.h) as the kernels read it, same cache, element-size key 1001
-bool mix_plan_for(int n, MixPlan& p);
-const MixPlan* mix_plan_dev(int n, int* err) {
+// the mixed-radix plan of a composite length (fft_mixed.h) as the kernels read it, same cache, element-size keys 1002 .. 1020 (the planner's cap on the largest factor)
+bool mix_plan_for(int n, size_t es, MixPlan& p);
+const MixPlan* mix_plan_dev(int n, size_t es, int* err) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) {
@@ -85,11 +85,11 @@ const MixPlan* mix_plan_dev(int n, int* err) {
         return nullptr;
     }
     std::lock_guard<std::mutex> lk(g_mu);
-    auto key = std::make_tuple(dev, 1001, int64_t(n));
+    auto key = std::make_tuple(dev, 1000 + tuning().mix_maxr + (es == 8 ? 100 : 0), int64_t(n));     // the plan follows the knob and the precision
     auto it = g_tables.find(key);
     if (it != g_tables.end()) return reinterpret_cast<const MixPlan*>(it->second);
     MixPlan h;
-    if (!mix_plan_for(n, h)) {
+    if (!mix_plan_for(n, es, h)) {
         *err = fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);
         return nullptr;
     }
@@ -158,6 +158,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("mixed_radix")) t.mixed_radix = v ? 1 : 0;
     else if (is("mix")) t.mix = v < 0 ? 0 : (v > 2 ? 2 : v);
     else if (is("mix_min")) t.mix_min = v < 18 ? 18 : v;
+    else if (is("mix_maxr")) t.mix_maxr = (v < 2 || v > 20) ? 20 : v;
     else if (is("mix_log_g")) t.mix_log_g = v;
     else if (is("mix_seqs")) t.mix_seqs = v < 0 ? 0 : v;
     else if (is("mix_tc")) t.mix_tc = v < 0 ? 0 : v;
@@ -1355,7 +1356,7 @@ int pm_plan_prepare(int32_t dtype, int64_t n) {
         if (engine_log2(n) >= 0 || !use_blue_long(n)) return 0;     // a mixed-radix length beside an awkward one still takes Bluestein
     }
     if (use_mix(n)) {
-        if (!mix_plan_dev(int(n), &err)) return err;
+        if (!mix_plan_dev(int(n), dtype == PM_C64 ? 8 : 16, &err)) return err;
         return (dtype == PM_C64 ? (const void*)twiddles<float>(n, &err) : (const void*)twiddles<double>(n, &err)) ? 0 : err;
     }
     if (use_blue_long(n)) {   // Bluestein tables of n and the twiddles of the convolution length (of its engine part when it is split)

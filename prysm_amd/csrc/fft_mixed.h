@@ -1,4 +1,4 @@
-// Composite lengths on their own factors: n = r0 r1 ... with every factor <= 32 (all lengths whose primes are <= 13: 1000, 3000,
+// Composite lengths on their own factors: n = r0 r1 ... with every factor <= 20 (all lengths whose primes are <= 13: 1000, 3000,
 // 2592, 1001 ...) as ONE kernel per axis, in place of Bluestein's convolution of >= 2n - 1 points per axis (>= 4x the area in 2-D).
 // The reference reaches these lengths through scipy.fft / pocketfft, which factors them the same way (prysm/propagation/fft.py:24,
 // prysm/fttools.py:23-31, prysm/propagation/angular_spectrum.py:35-42).
@@ -13,7 +13,7 @@
 // (stages - 1) times.  The last stage has no twiddles (the planner puts the largest factor there) and enumerates its butterflies by the
 // LOW digits of the bin index, so that adjacent lanes store adjacent bins.
 //
-// The factor of each stage is a run-time value (one kernel per class of largest factor -- 10, 16, 20, 32 -- serves every length); the small
+// The factor of each stage is a run-time value (one kernel per class of largest factor -- 10, 16, 20 -- serves every length); the small
 // DFTs are compile-time (a switch over the factors of the class).
 // Row mode: a workgroup holds `seqs` memory rows, lanes run along the row.  Column mode: `seqs` adjacent columns (a power of two),
 // lanes run across the columns first -- pieces of seqs elements per row of the array.
@@ -28,9 +28,11 @@ namespace pm {
 
 constexpr int kMixMaxStages = 6;
 constexpr int kMixMaxN = 8192;
-constexpr int kMixMaxRadix = 32;
-// factors with a small DFT below
-constexpr bool mix_radix_ok(int r) { return r >= 2 && r <= 32 && r != 17 && r != 19 && r != 23 && r != 29 && r != 31; }
+constexpr int kMixMaxRadix = 20;
+// factors with a small DFT below.  Factors up to 32 were built and measured (profiles/r03/exp_mix_maxr.log): the kernel class that contains
+// them needs 171 VGPRs (complex64) / 256 + spills (complex128) and lost to plans of one more stage in a leaner class at every length tried
+// (625 = 25 x 25: 22.2 us against 14.4 as 5 x 5 x 5 x 5; 5000^2 414 against 321; complex128 900^2 42.4 against 22.7)
+constexpr bool mix_radix_ok(int r) { return r >= 2 && r <= 20 && r != 17 && r != 19; }
 
 // ---------------------------------------------------------------------------
 // compile-time roots of unity (octant reduction + Taylor series on [0, pi/4]; ~1 ulp)
@@ -169,15 +171,6 @@ template <typename T> struct MixDft<T, 14> { static PM_HD void run(cx<T>* a) { m
 template <typename T> struct MixDft<T, 15> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 3, 5>(a); } };
 template <typename T> struct MixDft<T, 18> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 9>(a); } };
 template <typename T> struct MixDft<T, 20> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 4, 5>(a); } };
-template <typename T> struct MixDft<T, 21> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 3, 7>(a); } };
-template <typename T> struct MixDft<T, 22> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 11>(a); } };
-template <typename T> struct MixDft<T, 24> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 8, 3>(a); } };
-template <typename T> struct MixDft<T, 25> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 5, 5>(a); } };
-template <typename T> struct MixDft<T, 26> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 13>(a); } };
-template <typename T> struct MixDft<T, 27> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 3, 9>(a); } };
-template <typename T> struct MixDft<T, 28> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 4, 7>(a); } };
-template <typename T> struct MixDft<T, 30> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 5, 6>(a); } };
-template <typename T> struct MixDft<T, 32> { static PM_HD void run(cx<T>* a) { mix_dft_ct<T, 2, 16>(a); } };
 
 // ---------------------------------------------------------------------------
 // plan: factors (largest last), block lengths, exact division by multiply-high
@@ -209,31 +202,45 @@ PM_HD int mix_div(int a, uint32_t magic) {
 #endif
 }
 
-// fewest stages first, then the smallest largest factor; returns false when n has a prime factor above 13 or needs more than kMixMaxStages
-inline bool mix_factor(int n, int* radix, int* nstage) {
+// The plan of a length: among all factorisations into factors of the table above, the cheapest by a measured cost model -- stages x
+// weight of the kernel class the largest factor selects (10: 1, 16: 1.15, 20: `w20` = 1.3 for complex64, 1.4 for complex128: the leaner
+// classes keep more waves per SIMD, and e.g. complex128 3000 = 5 x 6 x 10 x 10 in the class of 10 runs in 189 us against 211 for
+// 10 x 15 x 20, while complex64 2000 = 10 x 10 x 20 keeps its three stages: 39.7 us against 44.0 -- profiles/r03/exp_mix_maxr*.log); above 4096 points (one workgroup per CU either
+// way: the LDS holds few sequences) the fewest stages win (6000 = 15 x 20 x 20: 516 us against 553 with four stages).  Ties go to the
+// smaller largest factor, then to the larger smallest one (fewer butterflies to index).  `maxr` caps the factors (tuning knob mix_maxr).  Returns false when n has a prime factor above 13.
+constexpr int mix_class_of(int maxr) { return maxr <= 10 ? 10 : (maxr <= 16 ? 16 : 20); }
+inline bool mix_factor(int n, int* radix, int* nstage, int maxr = kMixMaxRadix, double w20 = 1.4) {
     if (n < 2 || n > kMixMaxN) return false;
-    int best[kMixMaxStages], cur[kMixMaxStages], bestn = kMixMaxStages + 1, bestmax = 0;
+    int best[kMixMaxStages], cur[kMixMaxStages], bestn = 0, bestmax = 0, bestmin = 0;
+    double bestcost = 1e30;
+    const bool big = n > 4096;
     // depth-first over non-increasing factors
     struct Rec {
-        static void go(int rem, int maxf, int depth, int* cur, int* best, int& bestn, int& bestmax) {
+        static void go(int rem, int maxf, int depth, int* cur, int* best, int& bestn, int& bestmax, int& bestmin, double& bestcost, bool big, double w20) {
             if (rem == 1) {
-                if (depth < bestn || (depth == bestn && cur[0] < bestmax)) {
+                const int cls = mix_class_of(cur[0]);
+                const double w = big ? 1.0 : (cls == 10 ? 1.0 : (cls == 16 ? 1.15 : w20));
+                const double cost = depth * w;
+                const bool tie = cost < bestcost + 1e-9;
+                if (cost < bestcost - 1e-9 || (tie && cur[0] < bestmax) || (tie && cur[0] == bestmax && cur[depth - 1] > bestmin)) {
+                    bestcost = cost;
                     bestn = depth;
                     bestmax = cur[0];
+                    bestmin = cur[depth - 1];
                     for (int i = 0; i < depth; ++i) best[i] = cur[i];
                 }
                 return;
             }
-            if (depth >= kMixMaxStages || depth + 1 > bestn) return;
+            if (depth >= kMixMaxStages) return;
             for (int f = maxf; f >= 2; --f) {
                 if (rem % f || !mix_radix_ok(f)) continue;
                 cur[depth] = f;
-                go(rem / f, f, depth + 1, cur, best, bestn, bestmax);
+                go(rem / f, f, depth + 1, cur, best, bestn, bestmax, bestmin, bestcost, big, w20);
             }
         }
     };
-    Rec::go(n, kMixMaxRadix, 0, cur, best, bestn, bestmax);
-    if (bestn > kMixMaxStages) return false;
+    Rec::go(n, maxr < kMixMaxRadix ? maxr : kMixMaxRadix, 0, cur, best, bestn, bestmax, bestmin, bestcost, big, w20);
+    if (bestn == 0) return false;
     // ascending: the largest factor runs last, where the twiddles are all one
     for (int i = 0; i < bestn; ++i) radix[i] = best[bestn - 1 - i];
     *nstage = bestn;
@@ -417,15 +424,6 @@ PM_HD void mix_last(const MixPlan& p, MixShape sh, int tid, int nt, const cx<T>*
         case 16: if constexpr (MAXR >= 16) { constexpr int R = 16; CALL; } break; \
         case 18: if constexpr (MAXR >= 18) { constexpr int R = 18; CALL; } break; \
         case 20: if constexpr (MAXR >= 20) { constexpr int R = 20; CALL; } break; \
-        case 21: if constexpr (MAXR >= 21) { constexpr int R = 21; CALL; } break; \
-        case 22: if constexpr (MAXR >= 22) { constexpr int R = 22; CALL; } break; \
-        case 24: if constexpr (MAXR >= 24) { constexpr int R = 24; CALL; } break; \
-        case 25: if constexpr (MAXR >= 25) { constexpr int R = 25; CALL; } break; \
-        case 26: if constexpr (MAXR >= 26) { constexpr int R = 26; CALL; } break; \
-        case 27: if constexpr (MAXR >= 27) { constexpr int R = 27; CALL; } break; \
-        case 28: if constexpr (MAXR >= 28) { constexpr int R = 28; CALL; } break; \
-        case 30: if constexpr (MAXR >= 30) { constexpr int R = 30; CALL; } break; \
-        case 32: if constexpr (MAXR >= 32) { constexpr int R = 32; CALL; } break; \
         default: break; \
     }
 

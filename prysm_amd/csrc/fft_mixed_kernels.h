@@ -11,8 +11,8 @@
 
 namespace pm {
 
-bool mix_plan_for(int n, MixPlan& p);                 // fft_mixed.hip: the cached factorisation of n
-const MixPlan* mix_plan_dev(int n, int* err);         // capi.hip: its device-resident copy (plan cache, beside the twiddles)
+bool mix_plan_for(int n, size_t es, MixPlan& p);             // fft_mixed.hip: the cached factorisation of n for elements of es bytes
+const MixPlan* mix_plan_dev(int n, size_t es, int* err);     // capi.hip: its device-resident copy (plan cache, beside the twiddles)
 
 // ColStoreNat element store (fft_io.h store_one) with a 32-bit offset from the array base, and without the window test when the caller
 // knows the view keeps every bin
@@ -160,9 +160,9 @@ static int mix_set_lds(K kernel, size_t bytes) {
     return rc;
 }
 
-// one kernel class (largest factor <= MAXR: 10, 16, 20, 32); defined in fft_mixed_{rows,cols}_{f32,f64}[_mid|_big].hip.  Registers per
-// class, rows complex64 / complex128: 66 / 94, 94 / 176, 106 / 186, 171 / 256 with spills -- 3000 = 10 x 15 x 20 and 4000 = 10 x 20 x 20 are
-// why the class of 20 exists
+// one kernel class (largest factor <= MAXR: 10, 16, 20); defined in fft_mixed_{rows,cols}_{f32,f64}[_mid].hip.  Registers per class, rows
+// complex64 / complex128: 66 / 94, 94 / 176, 106 / 186.  (A class of factors up to 32 -- 171 / 256 + spills -- was built and lost to plans
+// with one more stage in a leaner class: fft_mixed.h mix_radix_ok.)
 template <typename T, int MAXR>
 int mix_rows_launch(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const MixRowOut<T>& ro, const cx<T>* tw, int groups, int nt, size_t lds, hipStream_t st);
 template <typename T, int MAXR>
@@ -191,7 +191,7 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     const int n = in.ax.n, nseq = in.nseq;
     if (nseq <= 0 || n <= 0) return 0;
     MixPlan p;
-    if (!mix_plan_for(n, p)) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);
+    if (!mix_plan_for(n, sizeof(cx<T>), p)) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);
     if (in.s_i != 1 || !mix_fits(n, in.s_seq, sizeof(cx<T>), false) || !mix_fits(n, o ? o->ld : out_ld, sizeof(cx<T>), false))
         return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: row pitch beyond 2^24 elements");
     int err = 0;
@@ -209,7 +209,7 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     if (seqs > nseq) seqs = nseq;
     if (size_t(seqs) * per > kMixLdsHard) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d does not fit the LDS", n);
     const MixShape sh{seqs, 0};
-    const MixPlan* pd = mix_plan_dev(n, &err);
+    const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
     const size_t lds = size_t(seqs) * per;
     MixRowOut<T> ro{out, out_ld, AxisMap{n, n, 0, 0}, T(1), 0, 0};
@@ -217,8 +217,7 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     const int groups = (nseq + seqs - 1) / seqs, nt = mix_threads(p, seqs, 256, tuning().mix_nt);
     if (p.maxr <= 10) return mix_rows_launch<T, 10>(pd, sh, in, ro, tw, groups, nt, lds, st);
     if (p.maxr <= 16) return mix_rows_launch<T, 16>(pd, sh, in, ro, tw, groups, nt, lds, st);
-    if (p.maxr <= 20) return mix_rows_launch<T, 20>(pd, sh, in, ro, tw, groups, nt, lds, st);
-    return mix_rows_launch<T, 32>(pd, sh, in, ro, tw, groups, nt, lds, st);
+    return mix_rows_launch<T, 20>(pd, sh, in, ro, tw, groups, nt, lds, st);
 }
 
 template <typename T>
@@ -226,7 +225,7 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     const int n = in.ax.n, ncols = in.nseq;
     if (ncols <= 0 || n <= 0) return 0;
     MixPlan p;
-    if (!mix_plan_for(n, p)) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);
+    if (!mix_plan_for(n, sizeof(cx<T>), p)) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);
     if (in.s_seq != 1 || !mix_fits(n, in.s_i, sizeof(cx<T>), true) || !mix_fits(out.ay.n, out.ld, sizeof(cx<T>), true))
         return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: the array does not fit 32-bit offsets");
     int err = 0;
@@ -246,7 +245,7 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     if (size_t(tc) * per > kMixLdsHard) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d does not fit the LDS", n);
     MixShape sh{tc, 0};
     while ((1 << sh.log_seqs) < tc) ++sh.log_seqs;
-    const MixPlan* pd = mix_plan_dev(n, &err);
+    const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
     const size_t lds = size_t(tc) * per;
     // tiles that share a 128 B line run on one XCD (mix_cols_kernel): 2^log_g adjacent tiles, the grid padded to whole rounds of them
@@ -257,8 +256,7 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc, 512, tuning().mix_ntc);
     if (p.maxr <= 10) return mix_cols_launch<T, 10>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
     if (p.maxr <= 16) return mix_cols_launch<T, 16>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
-    if (p.maxr <= 20) return mix_cols_launch<T, 20>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
-    return mix_cols_launch<T, 32>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
+    return mix_cols_launch<T, 20>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
 }
 
 }  // namespace pm

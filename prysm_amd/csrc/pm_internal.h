@@ -123,6 +123,7 @@ struct Tuning {
     int mix = 1;              // composite lengths (primes <= 13, up to 8192) on the mixed-radix kernel (fft_mixed.h) instead of Bluestein and of
                               // the radix-R step (profiles/r03/exp_mix.log: 1536^2 complex64 42 us against 61, 2560^2 104 against 119); 0: as in
                               // round 2; 2: the 3 / 5 / 7 x 2^k lengths stay on the radix-R step (bigfft.hip)
+    int mix_maxr = 20;        // ... plan within factors of at most this when the length allows (10 / 16 / 20: the kernel classes)
     int mix_log_g = -1;       // ... its column pass: 2^this adjacent tiles per XCD (-1 auto: as many as share a 128 B line)
     int mix_seqs = 0, mix_tc = 0, mix_nt = 0, mix_ntc = 0;   // ... force its rows per workgroup / columns per workgroup / threads per workgroup of the row pass / of the column pass (0 = auto)
     int mix_min = 32;         // ... from this length (shorter ones stay on the direct fp64-accumulating kernel)

@@ -48,10 +48,10 @@ static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift) {
         };
         auto run = [&](auto colc) {
             constexpr bool COL = decltype(colc)::value;
-            for (int tid = 0; tid < nt; ++tid) mix_run_first<T, COL, 32>(p, sh, tid, nt, lds.data(), tw.data(), fetch);
+            for (int tid = 0; tid < nt; ++tid) mix_run_first<T, COL, 20>(p, sh, tid, nt, lds.data(), tw.data(), fetch);
             for (int ph = 1; ph + 1 < p.nstage; ++ph)
-                for (int tid = 0; tid < nt; ++tid) mix_run_mid<T, COL, 32>(p, sh, ph, tid, nt, lds.data(), tw.data());
-            for (int tid = 0; tid < nt; ++tid) mix_run_last<T, COL, 32>(p, sh, tid, nt, lds.data(), store);
+                for (int tid = 0; tid < nt; ++tid) mix_run_mid<T, COL, 20>(p, sh, ph, tid, nt, lds.data(), tw.data());
+            for (int tid = 0; tid < nt; ++tid) mix_run_last<T, COL, 20>(p, sh, tid, nt, lds.data(), store);
         };
         if (col) run(std::true_type{}); else run(std::false_type{});
     }
@@ -90,7 +90,7 @@ int main() {
         if (!(e1 < 1e-13) || !(e2 < 1e-13) || !(e3 < 2e-5)) { ++bad; printf("   ^^^ FAIL\n"); }
     }
     MixPlan q;
-    if (mix_make_plan(12, q) || mix_make_plan(32, q) || mix_make_plan(17, q) || mix_make_plan(1024 * 17, q) || mix_make_plan(2 * 19, q)) { printf("planned an unsupported length\n"); ++bad; }
+    if (mix_make_plan(12, q) || mix_make_plan(16, q) || mix_make_plan(17, q) || mix_make_plan(1024 * 17, q) || mix_make_plan(2 * 19, q)) { printf("planned an unsupported length\n"); ++bad; }
     printf(bad ? "FAILED (%d)\n" : "all ok\n", bad);
     return bad != 0;
 }
