@@ -89,6 +89,31 @@ int main() {
         printf("  rows f64 %.2e  cols f64 %.2e  rows f32 %.2e\n", e1, e2, e3);
         if (!(e1 < 1e-13) || !(e2 < 1e-13) || !(e3 < 2e-5)) { ++bad; printf("   ^^^ FAIL\n"); }
     }
+    // the planner over every length: a plan exists exactly for the lengths whose primes are <= 13 and that need at least two factors; its
+    // factors multiply to n, are ascending, at most 20, and the block lengths / reciprocals are consistent
+    int planned = 0;
+    for (int n = 2; n <= kMixMaxN; ++n) {
+        int m = n;
+        for (int pr : {2, 3, 5, 7, 11, 13})
+            while (m % pr == 0) m /= pr;
+        const bool smooth = m == 1;
+        MixPlan pl;
+        const bool ok = mix_make_plan(n, pl);
+        if (ok != (smooth && !mix_radix_ok(n))) { printf("planner: n=%d smooth=%d planned=%d\n", n, int(smooth), int(ok)); ++bad; continue; }
+        if (!ok) continue;
+        ++planned;
+        long prod = 1;
+        bool good = pl.nstage >= 2 && pl.nstage <= kMixMaxStages && pl.len[0] == n && pl.len[pl.nstage] == 1;
+        for (int s = 0; s < pl.nstage; ++s) {
+            prod *= pl.radix[s];
+            good = good && mix_radix_ok(pl.radix[s]) && (s == 0 || pl.radix[s] >= pl.radix[s - 1]) && pl.len[s + 1] * pl.radix[s] == pl.len[s];
+            for (int a : {0, 1, pl.len[s] - 1, n - 1})
+                good = good && mix_div(a, pl.mg_radix[s]) == a / pl.radix[s] && mix_div(a, pl.mg_sub[s]) == a / pl.len[s + 1] &&
+                       mix_div(a, pl.mg_nb[s]) == a / (n / pl.radix[s]);
+        }
+        if (!good || prod != n || pl.maxr != pl.radix[pl.nstage - 1]) { printf("planner: bad plan for n=%d\n", n); ++bad; }
+    }
+    printf("planner: %d lengths planned\n", planned);
     MixPlan q;
     if (mix_make_plan(12, q) || mix_make_plan(16, q) || mix_make_plan(17, q) || mix_make_plan(1024 * 17, q) || mix_make_plan(2 * 19, q)) { printf("planned an unsupported length\n"); ++bad; }
     printf(bad ? "FAILED (%d)\n" : "all ok\n", bad);
