@@ -15,6 +15,7 @@
 #include "fft_r2c_types.h"
 #include "fft_conv1_types.h"
 #include "fft_spectral_types.h"
+#include "fft_spectral2.h"
 #include "fft_c2r_types.h"
 
 namespace pm {
@@ -171,6 +172,9 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("spectral")) t.spectral = v;
     else if (is("spectral_mode")) t.spectral_mode = v & 3;
     else if (is("spectral_area_log")) t.spectral_area_log = v;
+    else if (is("spectral2")) t.spectral2 = (v == 2 || v == 3 || v == 4) ? v : 0;
+    else if (is("spectral2_keep")) t.spectral2_keep = v ? 1 : 0;
+    else if (is("spectral2_min_log")) t.spectral2_min_log = v;
     else if (is("blue_min")) t.blue_min = v < 0 ? 0 : v;
     else if (is("blue_2d")) t.blue_2d = v ? 1 : 0;
     else if (is("blue_fuse")) t.blue_fuse = v ? 1 : 0;
@@ -1313,6 +1317,92 @@ static int fft2_spectral_group(const pm_fft2_desc* d, const Fft2Plan& p, const S
     return launch_col_spectral<T>(p.logm, cl, cs, twm, ntiles, sibling_log_g(p.log_k), w, st, 1);
 }
 
+// ---- the same in groups of 2 .. 4 wavelengths on the kernels that keep four waves per SIMD (fft_spectral2.h): complex64, rows of 1024 ..
+// 4096 samples, column tiles of 1024 / 2048 points (the planes of a folded 4096-row transform included), every bin of the output kept
+static bool spectral2_shape(const pm_fft2_desc* d, const Fft2Plan& p) {
+    const int want = PM_FLAG_SYNTH_INPUT | PM_FLAG_SYNTH_PACKED;
+    if (tuning().spectral2 < 2 || d->dtype != PM_C64) return false;
+    if ((d->flags & want) != want || (d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY))) return false;
+    if (d->epilogue != PM_EPI_ABS2_ACCUM || d->batch > 1 || d->mul_kind != PM_MUL_NONE) return false;
+    if (p.r2c || p.big_rn || p.blue2d || p.tc == 0 || p.col_var != 0) return false;
+    const int lt = p.logm - (p.fold ? 1 : 0);
+    if (p.logn < 10 || p.logn > 12 || lt < 10 || lt > 11 || p.logn + p.logm < tuning().spectral2_min_log) return false;
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    if (!(d->in_x.shift == 0 || d->in_x.shift == N / 2) || !(d->in_y.shift == 0 || d->in_y.shift == M / 2) || d->in_y.len <= 0) return false;
+    if (d->out_y.len != M || d->out_y.off != 0 || d->out_x.len != N || d->out_x.off != 0) return false;
+    if (!(d->out_y.shift == 0 || d->out_y.shift == M / 2) || (d->out_x.shift % p.tc) != 0 || (d->out_ld % 2) != 0) return false;
+    return int64_t(256) * d->out_ld * 8 < (int64_t(1) << 32) && d->in_ld < (int64_t(1) << 28);    // 32-bit per-thread byte offsets
+}
+
+static int fft2_spectral2_group(const pm_fft2_desc* d, const Fft2Plan& p, const Spectral& w, const void* in, void* out, void* ws, hipStream_t st) {
+    using T = float;
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    const int rows = int(d->in_y.len);
+    int err = 0;
+    cx<T>* W = reinterpret_cast<cx<T>*>(ws);
+    const cx<T>* tw = twiddles<T>(N, &err);
+    if (!tw) return err;
+    int ltl = 0;
+    while ((1 << ltl) < (p.tc << p.log_k)) ++ltl;
+    const int64_t tl = int64_t(1) << ltl, ntl = (N + tl - 1) / tl;
+    const int H = int(M / 2);
+    const bool keep = tuning().spectral2_keep != 0;
+    Sp2Row<T> gr{};
+    gr.src = reinterpret_cast<const cx<T>*>(in);
+    gr.ld = d->in_ld;
+    gr.off = int(d->in_x.off);
+    gr.len = int(d->in_x.len);
+    gr.rot = d->in_x.shift ? 8 : 0;
+    gr.nrows = rows;
+    // streaming loads of the map only when it is read once per group AND the group's intermediates are what the caches should hold
+    gr.nt = (tuning().nt_in >= 0 ? tuning().nt_in : 0) && (w.nb <= 2 || keep);
+    gr.dst = W;
+    gr.fstride = w.fstride;
+    gr.plane_stride = p.fold ? ntl * H * tl : 0;
+    gr.drows = p.fold ? H : rows;
+    gr.log_tl = ltl;
+    gr.swap = (p.fold && d->in_y.shift == M / 2) ? 1 : 0;
+    gr.twm = nullptr;
+    if (p.fold) {
+        gr.twm = twiddles<T>(M, &err);
+        if (!gr.twm) return err;
+    }
+    int rc = launch_row_spectral2(p.logn, p.fold, keep, gr, tw, w, st);
+    if (rc) return rc;
+    const int lt = p.logm - (p.fold ? 1 : 0);
+    const int64_t L = int64_t(1) << lt;
+    const cx<T>* twc = twiddles<T>(L, &err);
+    if (!twc) return err;
+    Sp2Col<T> gc{};
+    gc.src = W;
+    gc.fstride = w.fstride;
+    gc.plane_stride = gr.plane_stride;
+    gc.log_k = p.log_k;
+    gc.dst = reinterpret_cast<T*>(out);
+    gc.qshift = int(d->out_x.shift);
+    gc.ncols = int(N);
+    gc.s2 = T(d->scale) * T(d->scale);
+    if (p.fold) {
+        gc.nrows = H;
+        gc.off = 0;
+        gc.len = H;
+        gc.rot = 0;                 // the rotation of the input rows is the fold's swap
+        gc.ld = 2 * d->out_ld;      // plane y holds the output rows of parity y
+        gc.out_plane = d->out_ld;
+        gc.orot = d->out_y.shift ? 8 : 0;
+    } else {
+        gc.nrows = rows;
+        gc.off = int(d->in_y.off);
+        gc.len = int(d->in_y.len);
+        gc.rot = d->in_y.shift ? 8 : 0;
+        gc.ld = d->out_ld;
+        gc.out_plane = 0;
+        gc.orot = d->out_y.shift ? 8 : 0;
+    }
+    const int ntiles = int(N / p.tc);
+    return launch_col_spectral2(lt, gc, twc, ntiles, sibling_log_g(p.log_k), w, st, p.fold ? 2 : 1);
+}
+
 }  // namespace pm
 
 using namespace pm;
@@ -1402,7 +1492,12 @@ int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, s
 size_t pm_fft2_spectral_workspace(const pm_fft2_desc* d, int32_t count) {
     if (check_fft2(d) || count <= 0) return 0;
     const Fft2Plan p = plan_fft2(d);
-    return spectral_fast(d, p) ? p.ws_field * size_t(spectral_group(count)) : p.ws_bytes;
+    size_t need = spectral_fast(d, p) ? p.ws_field * size_t(spectral_group(count)) : p.ws_bytes;
+    if (spectral2_shape(d, p)) {    // whether the call takes those kernels also depends on the alignment of `out`: the query covers both
+        const size_t g2 = size_t(tuning().spectral2 < count ? tuning().spectral2 : count);
+        if (p.ws_field * g2 > need) need = p.ws_field * g2;
+    }
+    return need;
 }
 
 int pm_fft2_spectral(const pm_fft2_desc* d, int32_t count, const double* k, const double* weight, const void* in, void* out, void* workspace,
@@ -1419,6 +1514,24 @@ int pm_fft2_spectral(const pm_fft2_desc* d, int32_t count, const double* k, cons
     if (!workspace || workspace_bytes < need)
         return fail(PM_ERR_WORKSPACE, "pm_fft2_spectral: workspace of %zu bytes required, %zu given", need, workspace_bytes);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (spectral2_shape(d, p) && reinterpret_cast<uintptr_t>(out) % 8 == 0 && reinterpret_cast<uintptr_t>(in) % 8 == 0) {
+        const int g = tuning().spectral2;
+        const double two_pi = 2.0 * 3.14159265358979323846264338327950288;
+        for (int32_t b0 = 0; b0 < count; b0 += g) {
+            Spectral w{};
+            w.nb = count - b0 < g ? count - b0 : g;
+            w.fstride = int64_t(p.ws_field / sizeof(cx<float>));
+            w.mode = 0;
+            for (int i = 0; i < w.nb; ++i) {
+                w.w[i] = weight[b0 + i];
+                w.k2[i] = k[b0 + i] / two_pi;
+            }
+            rc = fft2_spectral2_group(d, p, w, in, out, workspace, st);
+            if (rc)
+                return rc == -2 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_spectral: internal: no lean grouped kernel for %lld x %lld", (long long)d->in_y.n, (long long)d->in_x.n) : rc;
+        }
+        return 0;
+    }
     if (!spectral_fast(d, p)) {     // the loop itself: one transform pair per wavelength
         pm_fft2_desc dd = *d;
         for (int32_t b = 0; b < count; ++b) {

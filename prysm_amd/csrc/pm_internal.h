@@ -138,6 +138,11 @@ struct Tuning {
                               // write 64 B pieces, direct and mirrored (MTF 4096^2 fp32 88.4 -> 81.4 us, fp64 176 -> 168; profiles/r02/exp_mtf_wide.log)
     int spectral = 8;         // pm_fft2_spectral: wavelengths per launch pair (fft_spectral.h; <= 8); 1: the plain loop of pm_fft2 calls
     int spectral_area_log = 24;   // ... for transforms of fewer than 2^this bins (capi.hip spectral_fast has the measurements)
+    int spectral2 = 4;        // ... groups of this many (2 .. 4) on the kernels that keep four waves per SIMD (fft_spectral2.h) where the shape
+                              // qualifies (complex64, rows of 1024 .. 4096 samples, every output bin kept); 0: round 3's forms only
+    int spectral2_keep = 0;   // ... groups of 3 / 4: the raw (amplitude, OPD) values stay in registers between the pairs (three waves per SIMD)
+                              // instead of being read again from L2 / Infinity Cache
+    int spectral2_min_log = 0;    // ... for transforms of at least 2^this bins
     int spectral_mode = 3;    // ... bit 0: its row pass keeps the packed map in registers, bit 1: its column pass accumulates in registers
     int colmul_mode = 3;      // middle pass of the fused chain at 2048-point column tiles (fft_kernels.h launch_col_mul_one): 3 lean addressing,
                               // two 512-thread workgroups per CU (126 VGPRs) where the pass qualifies (whole unrotated tiles, separable
