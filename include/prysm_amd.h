@@ -398,6 +398,13 @@ void pm_shutdown(void);            /* free cached tables */
  * defaults and measurements: struct Tuning in prysm_amd/csrc/pm_internal.h.  Also read once from the environment:
  * PM_TUNE="nt_in=1,fold=0". */
 int pm_set_tuning(const char* key, int32_t value);
+/* the same knob for the CALLING host thread only: its first call gives the thread a private copy of the process-wide values, which
+ * every later library call on that thread reads; pm_reset_tuning_local() returns the thread to the shared values.  This is the form
+ * to use when several host threads drive the library at once -- prysm's own advice for several pipelines / devices is one thread
+ * each (docs/source/how-tos/GPU and Exascale Computing.ipynb, file line 66) -- pm_set_tuning changes what every thread without a
+ * private copy sees. */
+int pm_set_tuning_local(const char* key, int32_t value);
+void pm_reset_tuning_local(void);
 /* time `reps` launches of each pass of the transform with hipEvents on `stream`; ms[0] = row pass,
  * ms[1] = column pass (average per launch).  Used by bench.py for the roofline object. */
 int pm_fft2_time_passes(const pm_fft2_desc* d, const void* in, void* out, void* workspace,

@@ -47,6 +47,8 @@ SIGNATURES = {
     'pm_plan_prepare': (c_i32, [c_i32, c_i64]),
     'pm_shutdown': (None, []),
     'pm_set_tuning': (c_i32, [ctypes.c_char_p, c_i32]),
+    'pm_set_tuning_local': (c_i32, [ctypes.c_char_p, c_i32]),
+    'pm_reset_tuning_local': (None, []),
     'pm_fft2_workspace': (c_sz, [ctypes.POINTER(pm_fft2_desc)]),
     'pm_fft2': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_vp, c_vp, c_vp, c_sz, c_vp]),
     'pm_fft2_spectral_workspace': (c_sz, [ctypes.POINTER(pm_fft2_desc), c_i32]),
@@ -244,6 +246,25 @@ def stream_ptr():
 
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class tuning_local:
+    """``with tuning_local(fold=0, mix=0): ...`` -- performance knobs for the CALLING THREAD only (pm_set_tuning_local), restored on
+    exit.  The process-wide pm_set_tuning is for start-up configuration; two threads driving the library at once (one pipeline per
+    thread, prysm's own advice) each take this."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        lib = load()
+        for k, v in self.knobs.items():
+            check(lib.pm_set_tuning_local(k.encode(), int(v)))
+        return self
+
+    def __exit__(self, *exc):
+        load().pm_reset_tuning_local()
+        return False
 
 
 _workspaces = {}

@@ -627,7 +627,6 @@ def cgemm_abs2(A, B, opA=0, opB=0, alpha=1.0, out=None, weight=1.0):
     else:
         if out.dtype != torch.float32 or tuple(out.shape) != (M, N) or out.stride(1) != 1 or out.device != A.device:
             raise ValueError('cgemm_abs2: `out` must be a float32 (M, N) image on the device of the operands')
-        _bump(out)
     nbytes = lib.pm_cgemm_workspace(L.code(A), M, N, K)
     ws = L.workspace(nbytes)
     rc = lib.pm_cgemm_abs2(L.code(A), opA, opB, M, N, K, float(alpha), L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out),
@@ -635,6 +634,8 @@ def cgemm_abs2(A, B, opA=0, opB=0, alpha=1.0, out=None, weight=1.0):
     if rc == L.PM_ERR_UNSUPPORTED:
         return None
     L.check(rc)
+    if acc:
+        _bump(out)      # written: caches keyed on (identity, version) must notice (not before the early return above: nothing was written)
     return out
 
 

@@ -181,7 +181,11 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("big_native_log")) t.big_native_log = v < 1 ? 1 : (v > kEngineMaxLog ? kEngineMaxLog : v);
 }
 
-Tuning& tuning() {
+// The process-wide defaults (PM_TUNE, pm_set_tuning) and, per host thread, an optional private copy (pm_set_tuning_local): the
+// reference's advice for several devices / pipelines is one pipeline per thread (GPU and Exascale Computing.ipynb, file line 66), and
+// two threads that pick different routes must not race on one struct.  Every entry point reads the knobs through tuning(), on the
+// calling thread.
+static Tuning& tuning_global() {
     static Tuning t = [] {
         Tuning x;
         const char* e = getenv("PM_TUNE");   // e.g. PM_TUNE="nt_in=1,fold=0"
@@ -196,6 +200,10 @@ Tuning& tuning() {
     }();
     return t;
 }
+static thread_local bool g_tune_local_on = false;
+static thread_local Tuning g_tune_local;
+
+Tuning& tuning() { return g_tune_local_on ? g_tune_local : tuning_global(); }
 
 int pm_num_cus() {
     static int cus[64] = {0};
@@ -359,6 +367,8 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
     // powers of two above the engine's longest transform: both axes powers of two, at least one split (big2d_run)
     p.big_rn = big_split(N);
     p.big_rm = big_split(M);
+    if (p.big_rn > 1 && !p.big_rm) p.big_rm = big_split(M, false);     // a composite length beside one that needs the split: both take it
+    if (p.big_rm > 1 && !p.big_rn) p.big_rn = big_split(N, false);
     if (!(p.big_rn && p.big_rm && (p.big_rn > 1 || p.big_rm > 1)) || (d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY | PM_FLAG_SYNTH_INPUT)))
         p.big_rn = p.big_rm = 0;
     p.mix_n = p.mix_m = false;
@@ -1429,9 +1439,24 @@ int pm_set_tuning(const char* key, int32_t value) {
     if (experiment_only(key, value))
         return fail(PM_ERR_UNSUPPORTED, "pm_set_tuning: %s = %d selects a variant this build does not contain (rebuild with -DPM_EXPERIMENTS)", key,
                     int(value));
-    tune_set(tuning(), key, strlen(key), value);
+    static std::mutex mu;      // writers of the process-wide defaults are serialised; a thread that needs its own values while others
+    std::lock_guard<std::mutex> lk(mu);     // run takes pm_set_tuning_local
+    tune_set(tuning_global(), key, strlen(key), value);
     return 0;
 }
+int pm_set_tuning_local(const char* key, int32_t value) {
+    if (!key) return fail(PM_ERR_ARG, "pm_set_tuning_local: null key");
+    if (experiment_only(key, value))
+        return fail(PM_ERR_UNSUPPORTED, "pm_set_tuning_local: %s = %d selects a variant this build does not contain (rebuild with -DPM_EXPERIMENTS)",
+                    key, int(value));
+    if (!g_tune_local_on) {
+        g_tune_local = tuning_global();     // the thread's copy starts from the defaults of this moment
+        g_tune_local_on = true;
+    }
+    tune_set(g_tune_local, key, strlen(key), value);
+    return 0;
+}
+void pm_reset_tuning_local(void) { g_tune_local_on = false; }
 const char* pm_last_error(void) { return g_err; }
 
 int pm_plan_prepare(int32_t dtype, int64_t n) {
@@ -1481,7 +1506,14 @@ int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, s
     if (rc) return rc;
     if (!in || !out) return fail(PM_ERR_ARG, "pm_fft2: null buffer");
     Fft2Plan p = plan_fft2(d);
-    if (p.r2c && reinterpret_cast<uintptr_t>(in) % (d->dtype == PM_C64 ? 8 : 16) != 0) p = plan_fft2(d, false);
+    if (p.r2c && reinterpret_cast<uintptr_t>(in) % (d->dtype == PM_C64 ? 8 : 16) != 0) {
+        // the Hermitian path reads the real array as pairs; the complex path that takes over has neither the centre normalisation nor
+        // the |.| / angle epilogues (check_fft2 accepted them on the strength of r2c_legal): refuse, do not run something else
+        if ((d->flags & PM_FLAG_NORM_DC) || d->epilogue == PM_EPI_ABS || d->epilogue == PM_EPI_ARG)
+            return fail(PM_ERR_UNSUPPORTED, "pm_fft2: PM_FLAG_NORM_DC / PM_EPI_ABS / PM_EPI_ARG read the real array as pairs; its base address "
+                        "must be aligned like a complex element (%d bytes)", d->dtype == PM_C64 ? 8 : 16);
+        p = plan_fft2(d, false);
+    }
     if (!workspace || workspace_bytes < p.ws_bytes)
         return fail(PM_ERR_WORKSPACE, "pm_fft2: workspace of %zu bytes required, %zu given", p.ws_bytes, workspace_bytes);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1606,41 +1638,39 @@ int pm_fft2_mul_ifft2(const pm_fft2_desc* d, const void* in, void* out, void* wo
 
 int pm_fft2_time_passes(const pm_fft2_desc* d, const void* in, void* out, void* workspace, size_t workspace_bytes,
                         int reps, double* ms, void* stream) {
-    // Per-kernel durations measured IN SEQUENCE (row pass, column pass, row pass, ...) with hipEvents
-    // recorded on the launch stream between the two kernels of every propagation, so cache state is the
-    // one the real back-to-back workload sees.  ms[0] = row pass, ms[1] = column pass, averages.
-    if (!ms || reps < 1 || reps > 256) return fail(PM_ERR_ARG, "pm_fft2_time_passes: reps must be in [1, 256]");
+    // Average duration of each of the two kernels of a propagation, HIP events on the launch stream.  Each pass is timed as ITS OWN
+    // back-to-back loop of `reps` launches between one pair of events (round 4; rounds 1 - 3 recorded an event between the two
+    // kernels of every propagation, which serialises them: row + column exceeded the step time by 7 %).  A loop of one
+    // kernel keeps the launch pipeline full exactly as the real alternating sequence does, so ms[0] + ms[1] = the step time within a
+    // few per cent; what it does not reproduce is the other pass's footprint in the caches (the row pass re-reads its input and
+    // rewrites the intermediate every launch, the column pass re-reads the intermediate) -- bench.py prints the ratio to the step time.
+    // ms[0] = row pass, ms[1] = column pass.
+    if (!ms || reps < 1 || reps > 4096) return fail(PM_ERR_ARG, "pm_fft2_time_passes: reps must be in [1, 4096]");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    std::vector<hipEvent_t> ev(size_t(reps) * 3);
+    hipEvent_t ev[4];
     for (auto& e : ev) {
         hipError_t he = hipEventCreate(&e);
         if (he != hipSuccess) return int(he);
     }
     pm_fft2_desc dd = *d;
-    const int32_t keep = d->flags & (PM_FLAG_REAL_INPUT | PM_FLAG_SYNTH_INPUT);
+    const int32_t keep = d->flags & (PM_FLAG_REAL_INPUT | PM_FLAG_SYNTH_INPUT | PM_FLAG_SYNTH_PACKED);
     dd.flags = keep;
     int rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);   // warm (also builds the plan)
-    for (int i = 0; i < reps && !rc; ++i) {
-        (void)hipEventRecord(ev[size_t(i) * 3 + 0], st);
-        dd.flags = keep | PM_FLAG_PASS1_ONLY;
-        rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
-        (void)hipEventRecord(ev[size_t(i) * 3 + 1], st);
-        dd.flags = keep | PM_FLAG_PASS2_ONLY;
-        if (!rc) rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
-        (void)hipEventRecord(ev[size_t(i) * 3 + 2], st);
+    for (int pass = 0; pass < 2 && !rc; ++pass) {
+        dd.flags = keep | (pass == 0 ? PM_FLAG_PASS1_ONLY : PM_FLAG_PASS2_ONLY);
+        for (int i = 0; i < 3 && !rc; ++i) rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
+        (void)hipEventRecord(ev[2 * pass], st);
+        for (int i = 0; i < reps && !rc; ++i) rc = pm_fft2(&dd, in, out, workspace, workspace_bytes, stream);
+        (void)hipEventRecord(ev[2 * pass + 1], st);
     }
     ms[0] = ms[1] = 0.0;
     if (!rc) {
-        (void)hipEventSynchronize(ev.back());
-        for (int i = 0; i < reps; ++i) {
-            float a = 0.f, b = 0.f;
-            (void)hipEventElapsedTime(&a, ev[size_t(i) * 3 + 0], ev[size_t(i) * 3 + 1]);
-            (void)hipEventElapsedTime(&b, ev[size_t(i) * 3 + 1], ev[size_t(i) * 3 + 2]);
-            ms[0] += double(a);
-            ms[1] += double(b);
+        (void)hipEventSynchronize(ev[3]);
+        for (int pass = 0; pass < 2; ++pass) {
+            float a = 0.f;
+            (void)hipEventElapsedTime(&a, ev[2 * pass], ev[2 * pass + 1]);
+            ms[pass] = double(a) / reps;
         }
-        ms[0] /= reps;
-        ms[1] /= reps;
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;

@@ -8,7 +8,7 @@
 
 namespace pm {
 
-bool mix_length(int64_t n);   // fft_mixed.hip: n (<= 8192) has a mixed-radix plan: at least two factors of at most 16 each
+bool mix_length(int64_t n);   // fft_mixed.hip: n (<= 8192) has a mixed-radix plan: at least two factors of at most 20 each
 
 // error plumbing (capi.hip)
 int fail(int code, const char* fmt, ...);
@@ -177,7 +177,9 @@ inline int engine_log2(int64_t n) {  // log2(n) if n is a power of two the engin
 
 // split n = R n' for the path of bigfft.hip (n' a power of two the engine transforms): R = 1 (native), 2 or 4 (powers of two above the
 // engine's longest transform), 3 / 5 / 7 (mixed-radix lengths from 96: 1536, 2560, 3584 ...); 0 = not a length this path takes
-inline int big_split(int64_t n) {
+// (`mix_owns` false: the OTHER axis needs this path -- 1536 x 16384, 6144 x 12288 -- so a length the composite-length kernel would
+// take alone keeps its radix-R step here; without it such shapes fell to the both-axes Bluestein form at 16384 x 32768)
+inline int big_split(int64_t n, bool mix_owns = true) {
     if (n < 2) return 0;
     const int64_t native = int64_t(1) << tuning().big_native_log;
     if ((n & (n - 1)) == 0) {
@@ -187,7 +189,7 @@ inline int big_split(int64_t n) {
         return 0;
     }
     if (!tuning().mixed_radix || n < 96) return 0;
-    if (tuning().mix == 1 && n >= tuning().mix_min && mix_length(n)) return 0;    // the composite-length kernel takes these (up to 8192)
+    if (mix_owns && tuning().mix == 1 && n >= tuning().mix_min && mix_length(n)) return 0;    // the composite-length kernel takes these (up to 8192)
     for (int R = 3; R <= 7; R += 2) {
         if (n % R) continue;
         const int64_t q = n / R;

@@ -236,13 +236,18 @@ class MDFT:
         epilogue of the second product (pm_cgemm_abs2) -- the complex focal field is not written.  Falls back to the composed form
         for shapes / precisions that kernel does not take."""
         a, Ex, Ey = self._cast(ary)
+        # the first product once; if the fused epilogue does not take this shape / precision (None), the second one is finished as a
+        # plain product + |.|^2 -- not by starting over with self(ary), which would run three products instead of two
         if not self._forward_left_first:
-            res = _ops.cgemm_abs2(Ey, _ops.cgemm(a, Ex, 0, 2), 0, 0, alpha=self.norm, out=out, weight=weight)
+            t = _ops.cgemm(a, Ex, 0, 2)
+            res = _ops.cgemm_abs2(Ey, t, 0, 0, alpha=self.norm, out=out, weight=weight)
+            E = _ops.cgemm(Ey, t, 0, 0, alpha=self.norm) if res is None else None
         else:
-            res = _ops.cgemm_abs2(_ops.cgemm(Ey, a, 0, 0), Ex, 0, 2, alpha=self.norm, out=out, weight=weight)
+            t = _ops.cgemm(Ey, a, 0, 0)
+            res = _ops.cgemm_abs2(t, Ex, 0, 2, alpha=self.norm, out=out, weight=weight)
+            E = _ops.cgemm(t, Ex, 0, 2, alpha=self.norm) if res is None else None
         if res is not None:
             return res
-        E = self(ary)
         if out is None:
             I = _ops.abs2(E)
             return I if weight == 1.0 else I * weight

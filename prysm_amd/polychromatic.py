@@ -30,19 +30,37 @@ def shard_bounds(n_items, rank, world_size):
 # tensors) packs them once instead of paying two extra sweeps of the pupil inside every call (6 % of an 8-wavelength share at 4096^2).
 # Identity, not address: a freed map's address is reused by the next one.  In-place torch ops bump the version; the library's own
 # `out=` writes do too (_ops._bump).
+# OPT-IN (`cache_pupil=True`), because the key cannot see every write: `t.data.copy_()` / `t.data.add_()`, DLPack or cupy aliases,
+# custom kernels and any raw-pointer write leave identity and version unchanged, and the cache would then hand back a STALE map.  The
+# contract of cache_pupil=True: between calls the two maps change only through torch in-place ops or this library's `out=` arguments --
+# or the caller calls clear_packed_pupil_cache().  Tensors without a version counter (torch.inference_mode) are never cached.
 _PACK_CACHE = []
 _PACK_CACHE_MAX = 4
 
 
+def clear_packed_pupil_cache():
+    """Forget every cached packed (amplitude, OPD) map (after a write the version counters cannot see)."""
+    del _PACK_CACHE[:]
+
+
 def _version(t):
-    return None if t is None else t._version
+    """torch's version counter of `t`; None for no tensor, -1 when it has none (inference tensors raise): never equal to a cached key."""
+    if t is None:
+        return None
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
 
 
-def packed_pupil(amp, opd, a_syn, o_syn):
-    """pack_amp_opd(a_syn, o_syn), cached on the identity + version of the caller's tensors `amp` / `opd`."""
+def packed_pupil(amp, opd, a_syn, o_syn, cache=False):
+    """pack_amp_opd(a_syn, o_syn); with `cache`, kept per identity + version of the caller's tensors `amp` / `opd` (see above)."""
     from . import _ops
-    for i, (ra, va, ro, vo, packed) in enumerate(_PACK_CACHE):
-        if (ra() if ra is not None else None) is amp and ro() is opd and va == _version(amp) and vo == _version(opd):
+    va, vo = _version(amp), _version(opd)
+    if not cache or va == -1 or vo == -1:
+        return _ops.pack_amp_opd(a_syn, o_syn)
+    for i, (ra, ca, ro, co, packed) in enumerate(_PACK_CACHE):
+        if (ra() if ra is not None else None) is amp and ro() is opd and ca == va and co == vo:
             if i:
                 _PACK_CACHE.insert(0, _PACK_CACHE.pop(i))
             return packed
@@ -134,7 +152,7 @@ def _fields_per_launch(shape, cdtype_bytes, Q, limit_bytes=1 << 30):
     return max(1, min(64, limit_bytes // per_field))
 
 
-def _local_sum(amplitude, opd, wavelengths, weights, lo, hi, dx, efl, Q, focal_dx, samples, kind, batched, spectral):
+def _local_sum(amplitude, opd, wavelengths, weights, lo, hi, dx, efl, Q, focal_dx, samples, kind, batched, spectral, cache_pupil=False):
     """sum_k w_k |E_k|^2 over this rank's wavelengths [lo, hi): the compute half of polychromatic_psf (no collective)."""
     from . import _lib as L
     from . import _ops
@@ -153,7 +171,7 @@ def _local_sum(amplitude, opd, wavelengths, weights, lo, hi, dx, efl, Q, focal_d
         # instead of two 4-byte ones from two arrays
         probe = Wavefront.from_amp_and_phase(amp, phs, float(wavelengths[0]), dx)._fusable(Q) if len(wavelengths) else None
         if probe is not None and len(wavelengths) > 1:
-            packed = packed_pupil(amp, phs, probe[0], probe[1])
+            packed = packed_pupil(amp, phs, probe[0], probe[1], cache_pupil)
     if Q is not None and batched is None:
         batched = (packed is None or not spectral) and math.ceil(amp.shape[-2] * Q) * math.ceil(amp.shape[-1] * Q) < 4096 * 4096
     if Q is not None and batched:
@@ -207,7 +225,7 @@ def _local_sum(amplitude, opd, wavelengths, weights, lo, hi, dx, efl, Q, focal_d
 
 
 def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, focal_dx=None, samples=None,
-                      kind='mdft', group=None, reduce_to_all=True, batched=None, reduce_method='reduce', spectral=True):
+                      kind='mdft', group=None, reduce_to_all=True, batched=None, reduce_method='reduce', spectral=True, cache_pupil=False):
     """Polychromatic PSF of a pupil (amplitude, OPD in nm) -- the how-to's recipe on N GPUs.
 
     Q given            : FFT focus per wavelength with the |.|^2 fused into the transform (multi-field throughput
@@ -224,12 +242,16 @@ def polychromatic_psf(amplitude, opd, wavelengths, weights, dx, efl, *, Q=None, 
     focal_dx + samples : per-wavelength fixed-sampling focus (prepare_executor + focus_dft, `kind`),
                          all wavelengths on one focal grid -- the variant of the how-to.
 
-    The (amplitude, OPD) maps are packed once per pair of tensors (packed_pupil), not once per call.  A process group of one
-    rank still runs its collective (same code path at every N); without a process group there is none.
+    cache_pupil        : keep the packed (amplitude, OPD) map of this pair of tensors for the next call (keyed on identity + torch's
+                         version counters; two sweeps of the pupil saved per call).  Off by default: a write the counters cannot see
+                         (`.data` ops, DLPack / cupy aliases, raw-pointer kernels) would be answered with a stale map -- see
+                         packed_pupil / clear_packed_pupil_cache.
+
+    A process group of one rank still runs its collective (same code path at every N); without a process group there is none.
     """
     use_dist, rank, world = _group_info(group)
     lo, hi = shard_bounds(len(wavelengths), rank, world)
-    acc = _local_sum(amplitude, opd, wavelengths, weights, lo, hi, dx, efl, Q, focal_dx, samples, kind, batched, spectral)
+    acc = _local_sum(amplitude, opd, wavelengths, weights, lo, hi, dx, efl, Q, focal_dx, samples, kind, batched, spectral, cache_pupil)
     return _reduce_image(acc, world, group, reduce_to_all, reduce_method, use_dist)
 
 
@@ -266,13 +288,14 @@ class PsfPipeline:
     """
 
     def __init__(self, wavelengths, weights, dx, efl, *, Q=None, focal_dx=None, samples=None, kind='mdft', group=None,
-                 reduce_to_all=False, batched=None, reduce_method='reduce', spectral=True, depth=2, propagate=None):
+                 reduce_to_all=False, batched=None, reduce_method='reduce', spectral=True, depth=2, propagate=None, cache_pupil=False):
         """propagate(amplitude, opd, wavelength, weight, acc) -> acc: optional replacement of the per-wavelength step (as in
-        incoherent_sum; the CPU tests inject the oracle here)."""
+        incoherent_sum; the CPU tests inject the oracle here).  cache_pupil: as in polychromatic_psf (frames that submit the SAME
+        two tensors pack them once)."""
         if len(wavelengths) != len(weights):
             raise ValueError('wavelengths and weights must have the same length')
         self.wavelengths, self.weights, self.dx, self.efl = list(wavelengths), list(weights), dx, efl
-        self.kw = dict(Q=Q, focal_dx=focal_dx, samples=samples, kind=kind, batched=batched, spectral=spectral)
+        self.kw = dict(Q=Q, focal_dx=focal_dx, samples=samples, kind=kind, batched=batched, spectral=spectral, cache_pupil=cache_pupil)
         self.group, self.reduce_to_all, self.reduce_method = group, reduce_to_all, reduce_method
         self.depth = max(1, int(depth))
         self._propagate = propagate

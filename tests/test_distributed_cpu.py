@@ -160,22 +160,33 @@ def test_psf_pipeline_frames_world2():
 
 
 def test_packed_pupil_cache_identity_and_version():
-    """packed_pupil: one pack per (amplitude, OPD) tensor pair; an in-place change (version bump) or a different tensor object
-    -- even one that would reuse the freed tensor's address -- misses"""
+    """packed_pupil(cache=True): one pack per (amplitude, OPD) tensor pair; an in-place change (version bump) or a different tensor
+    object -- even one that would reuse the freed tensor's address -- misses.  The cache is opt-in (a write the version
+    counter cannot see would be answered with a stale map); inference tensors have no counter and are never cached."""
     sys.path.insert(0, ROOT)
     from prysm_amd import polychromatic as pc
-    pc._PACK_CACHE.clear()
+    pc.clear_packed_pupil_cache()
     amp, opd = torch.ones(8, 8), torch.arange(64.0).reshape(8, 8)
-    p1 = pc.packed_pupil(amp, opd, amp, opd)
-    assert pc.packed_pupil(amp, opd, amp, opd) is p1
+    assert pc.packed_pupil(amp, opd, amp, opd) is not pc.packed_pupil(amp, opd, amp, opd) and not pc._PACK_CACHE   # default: no cache
+    p1 = pc.packed_pupil(amp, opd, amp, opd, True)
+    assert pc.packed_pupil(amp, opd, amp, opd, True) is p1
     opd.add_(1.0)                                   # rewritten in place: stale
-    p2 = pc.packed_pupil(amp, opd, amp, opd)
+    p2 = pc.packed_pupil(amp, opd, amp, opd, True)
     assert p2 is not p1 and torch.equal(p2.imag, opd)
     torch.autograd.graph.increment_version(opd)     # what the library's out= writes do (_ops._bump)
-    assert pc.packed_pupil(amp, opd, amp, opd) is not p2
+    assert pc.packed_pupil(amp, opd, amp, opd, True) is not p2
     opd2 = opd.clone()
-    assert pc.packed_pupil(amp, opd2, amp, opd2) is not pc.packed_pupil(amp, opd, amp, opd)
+    assert pc.packed_pupil(amp, opd2, amp, opd2, True) is not pc.packed_pupil(amp, opd, amp, opd, True)
     del opd2
     assert len(pc._PACK_CACHE) <= pc._PACK_CACHE_MAX
-    p3 = pc.packed_pupil(None, opd, None, opd)      # no amplitude map: unit amplitude
-    assert torch.equal(p3.real, torch.ones(8, 8)) and pc.packed_pupil(None, opd, None, opd) is p3
+    p3 = pc.packed_pupil(None, opd, None, opd, True)      # no amplitude map: unit amplitude
+    assert torch.equal(p3.real, torch.ones(8, 8)) and pc.packed_pupil(None, opd, None, opd, True) is p3
+    opd.data.add_(1.0)                              # invisible to the version counter: the documented limit of the opt-in cache ...
+    assert pc.packed_pupil(None, opd, None, opd, True) is p3
+    pc.clear_packed_pupil_cache()                   # ... and its remedy
+    p4 = pc.packed_pupil(None, opd, None, opd, True)
+    assert p4 is not p3 and torch.equal(p4.imag, opd)
+    with torch.inference_mode():                    # no version counter (t._version raises): packed every time, no crash
+        it = torch.arange(64.0).reshape(8, 8)
+        q1 = pc.packed_pupil(None, it, None, it, True)
+        assert pc.packed_pupil(None, it, None, it, True) is not q1 and torch.equal(q1.imag, it)

@@ -1,0 +1,229 @@
+"""GPU parity tests added in round 4:
+
+* the grouped-wavelength kernels that keep four waves per SIMD (csrc/fft_spectral2.h): groups of 2 / 3 / 4, raw values re-read or kept,
+  plain, padded (Q = 2), folded (4096-row) shapes, ragged last groups -- against the per-wavelength loop AND against numpy fp64;
+* per-thread tuning (pm_set_tuning_local): two host threads on two streams with different route knobs, results against numpy;
+* a misaligned real input with a Hermitian-only epilogue is refused (not silently run on the complex path);
+  MDFT.intensity's fallback finishes with ONE more product; a composite length beside a length that needs the radix-R split.
+
+Tolerances as in test_gpu_parity.py (max error / max magnitude against fp64): 1e-10 complex128, 5e-6 complex64 transforms.
+"""
+import ctypes
+import math
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_max
+from oracle import prysm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-10
+TOL32 = 5e-6
+
+
+@pytest.fixture(scope='module')
+def pa():
+    import prysm_amd
+    from prysm_amd import _lib
+    _lib.load()   # fails loudly when the HIP library is missing
+    assert torch.cuda.is_available()
+    return prysm_amd
+
+
+def tonp(x):
+    from prysm_amd.mathops import array_to_true_numpy
+    if hasattr(x, 'data') and not isinstance(x, (np.ndarray, torch.Tensor)):
+        x = x.data
+    return array_to_true_numpy(x)
+
+
+def crandn(rng, shape, dtype=np.complex128):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+
+
+# ----------------------------------------------------------------------------- grouped wavelengths, four waves per SIMD
+
+def _poly_numpy(amp, opd, ks, wts, Q):
+    """sum_b w_b |focus(amp exp(i k_b opd), Q)|^2 in fp64 (the how-to's loop: Polychromatic Propagation.ipynb cell 3)"""
+    acc = 0.0
+    for k, w in zip(ks, wts):
+        acc = acc + w * O.intensity(O.focus(amp.astype(np.float64) * np.exp(1j * k * opd.astype(np.float64)), Q))
+    return acc
+
+
+@pytest.mark.parametrize('shape,Q', [((1024, 1024), 1), ((512, 1024), 2), ((4096, 1024), 1), ((1024, 2048), 1)])
+def test_spectral2_groups_vs_loop_and_numpy(pa, shape, Q):
+    """pm_fft2_spectral on the round-4 kernels (tuning spectral2 = group size, spectral2_keep) for 7 wavelengths -- ragged last groups of
+    1 (groups of 2, 3) and 3 (groups of 4) -- against the loop of per-wavelength transform pairs (same arithmetic up to the
+    association of the sum) and against numpy fp64.  (4096, 1024) takes the fold: the row pairs meet through LDS."""
+    from prysm_amd import _lib, _ops
+    from prysm_amd.propagation import focus_intensity
+    lib = _lib.load()
+    rng = np.random.default_rng(shape[0] + Q)
+    amp = ((rng.random(shape) > 0.25) * rng.random(shape)).astype(np.float32)
+    opd = (40 * rng.standard_normal(shape)).astype(np.float32)
+    wl = np.linspace(0.5, 0.7, 7)
+    ks = [2 * math.pi / w / 1e3 for w in wl]
+    wts = list(np.linspace(0.5, 1.5, 7))
+    packed = _ops.pack_amp_opd(torch.from_numpy(amp).cuda(), torch.from_numpy(opd).cuda())
+    M, N = math.ceil(shape[0] * Q), math.ceil(shape[1] * Q)
+    ref = _poly_numpy(amp, opd, ks, wts, Q)
+
+    def run(**knobs):
+        acc = torch.full((M, N), 0.25, device='cuda', dtype=torch.float32)      # the call ADDS to what is there
+        with _lib.tuning_local(**knobs):
+            focus_intensity(packed, Q, out=acc, synth=('packed', ks[0]), spectral=(ks, wts))
+        return acc.cpu().numpy().astype(np.float64) - 0.25
+
+    loop = run(spectral=1, spectral2=0)
+    assert rel_max(loop, ref) < 2 * TOL32
+    for grp, keep in ((2, 0), (3, 0), (4, 0), (4, 1), (3, 1)):
+        got = run(spectral2=grp, spectral2_keep=keep)
+        assert rel_max(got, ref) < 2 * TOL32, (grp, keep)
+        assert rel_max(got, loop) < 1e-6, (grp, keep)
+    assert lib.pm_set_tuning_local(b'spectral2', 4) == 0
+    lib.pm_reset_tuning_local()
+
+
+def test_spectral2_default_route_config5_shape(pa):
+    """the default tuning sends BASELINE config 5's shape (4096^2 fp32 maps, Q = 1) through the grouped kernels; 5 wavelengths (a group
+    of 4 and a ragged 1) against the loop and numpy on a strip-checked image (numpy fp64 transforms of 4096^2 take seconds each)"""
+    from prysm_amd import _lib, _ops
+    from prysm_amd.propagation import focus_intensity
+    n = 4096
+    rng = np.random.default_rng(5)
+    ax = (np.arange(n) - n // 2) * (10.0 / n)
+    r = np.hypot(ax[None, :], ax[:, None])
+    amp = (r <= 5).astype(np.float32)
+    opd = (500.0 * (r / 5) ** 4 + 5 * rng.standard_normal((n, n))).astype(np.float32)
+    wl = np.linspace(0.5, 0.7, 5)
+    ks = [2 * math.pi / w / 1e3 for w in wl]
+    wts = [1.0, 0.5, 2.0, 1.5, 0.75]
+    packed = _ops.pack_amp_opd(torch.from_numpy(amp).cuda(), torch.from_numpy(opd).cuda())
+
+    def run(**knobs):
+        acc = torch.zeros((n, n), device='cuda', dtype=torch.float32)
+        with _lib.tuning_local(**knobs):
+            focus_intensity(packed, 1, out=acc, synth=('packed', ks[0]), spectral=(ks, wts))
+        return acc.cpu().numpy().astype(np.float64)
+
+    got = run()
+    loop = run(spectral=1, spectral2=0)
+    assert rel_max(got, loop) < 1e-6
+    ref = _poly_numpy(amp, opd, ks, wts, 1)
+    assert rel_max(got, ref) < 2 * TOL32
+
+
+# ----------------------------------------------------------------------------- per-thread tuning
+
+def test_two_threads_with_private_tuning(pa):
+    """two host threads, each on its own stream with its own route knobs (pm_set_tuning_local): thread A transforms a composite grid
+    on the mixed-radix kernel with the fold off, thread B the same grid through Bluestein (mix = 0) with the fold forced -- 30 rounds
+    each, interleaved by the scheduler; every result against numpy, and the process-wide values untouched afterwards"""
+    from prysm_amd import _lib, _ops
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    xa = crandn(rng, (600, 750), np.complex128)
+    xb = crandn(rng, (256, 2048), np.complex64)      # rows of 2048 samples: the forced fold is legal
+    wa, wb = np.fft.fft2(xa), np.fft.fft2(xb.astype(np.complex128))
+    errs, fails = {}, []
+
+    def worker(name, knobs):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st), _lib.tuning_local(**knobs):
+                da, db = torch.from_numpy(xa).cuda(), torch.from_numpy(xb).cuda()
+                worst = 0.0
+                for _ in range(30):
+                    ga = _ops.fft2(da, direction=-1, scale=1.0)
+                    gb = _ops.fft2(db, direction=-1, scale=1.0)
+                    st.synchronize()
+                    worst = max(worst, rel_max(ga.cpu().numpy(), wa) / TOL64, rel_max(gb.cpu().numpy(), wb) / TOL32)
+                errs[name] = worst
+        except Exception as exc:      # surfaced in the main thread
+            fails.append((name, repr(exc)))
+
+    ta = threading.Thread(target=worker, args=('A', dict(mix=1, fold=0)))
+    tb = threading.Thread(target=worker, args=('B', dict(mix=0, fold=1)))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not fails, fails
+    assert errs['A'] < 1.0 and errs['B'] < 1.0, errs
+    # the main thread never took a private copy: it still plans with the process-wide defaults (mix = 1: no Bluestein scratch)
+    got = _ops.fft2(torch.from_numpy(xa).cuda(), direction=-1, scale=1.0).cpu().numpy()
+    assert rel_max(got, wa) < TOL64
+    assert lib.pm_set_tuning_local(b'no_such_knob', 1) == 0      # unknown keys are ignored, as in pm_set_tuning
+    lib.pm_reset_tuning_local()
+
+
+# ----------------------------------------------------------------------------- ADVICE r3
+
+def test_misaligned_real_input_refuses_hermitian_epilogues(pa):
+    """a float32 field whose base address is 4 mod 8 cannot take the Hermitian path (it reads the array as pairs); the complex path has
+    no |.| / angle / centre normalisation, so PM_EPI_ABS, PM_EPI_ARG and PM_FLAG_NORM_DC are refused (rc = PM_ERR_UNSUPPORTED) instead
+    of returning accumulated |.|^2 with rc = 0; a plain spectrum of the same view still runs (complex path) and is right"""
+    from prysm_amd import _lib as L, _ops
+    lib = L.load()
+    n = 256
+    rng = np.random.default_rng(3)
+    base = torch.from_numpy(rng.random(n * n + 1).astype(np.float32)).cuda()
+    view = base[1:].view(n, n)              # 4 bytes past an 8-byte boundary
+    assert view.data_ptr() % 8 == 4
+    d = L.pm_fft2_desc()
+    d.dtype = L.PM_C64
+    d.direction = -1
+    d.scale = 1.0
+    d.weight = 1.0
+    d.in_y = d.in_x = d.out_y = d.out_x = _ops._axis(n, n, 0, 0)
+    d.in_ld = d.out_ld = n
+    d.flags = L.PM_FLAG_REAL_INPUT
+    nbytes = lib.pm_fft2_workspace(ctypes.byref(d))
+    ws = torch.empty(max(int(nbytes), 1) * 2, dtype=torch.uint8, device='cuda')
+    outr = torch.zeros((n, n), dtype=torch.float32, device='cuda')
+    for epi, flags in ((L.PM_EPI_ABS, 0), (L.PM_EPI_ARG, 0), (L.PM_EPI_ABS2, L.PM_FLAG_NORM_DC)):
+        d.epilogue = epi
+        d.flags = L.PM_FLAG_REAL_INPUT | flags
+        rc = lib.pm_fft2(ctypes.byref(d), view.data_ptr(), outr.data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr())
+        assert rc == L.PM_ERR_UNSUPPORTED, (epi, flags, rc)
+        assert float(outr.abs().max()) == 0.0
+    d.epilogue = L.PM_EPI_NONE
+    d.flags = L.PM_FLAG_REAL_INPUT
+    outc = torch.zeros((n, n), dtype=torch.complex64, device='cuda')
+    L.check(lib.pm_fft2(ctypes.byref(d), view.data_ptr(), outc.data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr()))
+    assert rel_max(outc.cpu().numpy(), np.fft.fft2(view.cpu().numpy().astype(np.float64))) < TOL32
+
+
+def test_mdft_intensity_fallback_finishes_with_one_product(pa, monkeypatch):
+    """MDFT.intensity on a shape / precision the fused |.|^2 epilogue does not take (complex128; 50 x 70 samples) must equal
+    |executor(x)|^2 and run TWO products, not three (the fallback used to start over with self(ary))"""
+    from prysm_amd import _ops
+    rng = np.random.default_rng(8)
+    x = crandn(rng, (96, 80))
+    ex = pa.propagation.prepare_executor(0.05, (96, 80), 1.0, (50, 70), O.HeNe, 100.0, kind='mdft')
+    calls = []
+    real = _ops.cgemm
+    monkeypatch.setattr(_ops, 'cgemm', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    acc = torch.full((50, 70), 2.0, dtype=torch.float64, device='cuda')
+    got = tonp(ex.intensity(torch.from_numpy(x).cuda(), out=acc, weight=0.5))
+    assert len(calls) == 2
+    ref = O.prepare_executor(0.05, (96, 80), 1.0, (50, 70), O.HeNe, 100.0)(x)
+    assert rel_max(got - 2.0, 0.5 * np.abs(ref) ** 2) < TOL64
+
+
+def test_composite_length_beside_a_split_length(pa):
+    """a composite length the mixed-radix kernel owns (96 = 3 * 32) beside a power of two that needs the radix-2 step (native length
+    lowered to 64: 128 splits) takes the radix-R path on BOTH axes (such shapes -- 1536 x 16384 at full size -- fell to the
+    both-axes Bluestein form); against numpy, both orientations and both precisions"""
+    from prysm_amd import _lib, _ops
+    rng = np.random.default_rng(21)
+    with _lib.tuning_local(big_native_log=6):
+        for shape in ((96, 128), (128, 96), (160, 256)):
+            for dtype, tol in ((np.complex64, TOL32), (np.complex128, TOL64)):
+                x = crandn(rng, shape, dtype)
+                got = _ops.fft2(torch.from_numpy(x).cuda(), direction=-1, scale=1.0).cpu().numpy()
+                assert rel_max(got, np.fft.fft2(x.astype(np.complex128))) < tol, (shape, dtype)
+                ref = O.focus(x.astype(np.complex128), 1)
+                assert rel_max(tonp(pa.propagation.focus(x, 1)), ref) < tol, (shape, dtype)
