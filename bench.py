@@ -209,7 +209,18 @@ def other_configs(only=''):
     def sec_config2():   # config 2: 2048^2 complex64 focus, 4 N^2 s bytes
         x2 = torch.from_numpy(make_field(2048, np.complex64, 2048)).cuda()
         out['config2_focus_2048_c64'] = _hbm_entry(_event_ms(lambda: P.focus(x2, 1), 100), 4 * 2048 ** 2 * 8)
-        del x2
+        # the same propagation as a SEQUENCE of independent fields alternating between two HIP streams (prysm_amd.graph.StreamRing):
+        # throughput of a wavelength / field-point loop at this size, where one launch pair alone is latency-bound
+        from prysm_amd.graph import StreamRing
+        ring, x2b, keep = StreamRing(2), x2.clone(), [None, None]
+
+        def pair():
+            keep[0] = ring.run(P.focus, x2, 1)
+            keep[1] = ring.run(P.focus, x2b, 1)
+            ring.join()
+        e2 = _hbm_entry(_event_ms(pair, 50) / 2, 4 * 2048 ** 2 * 8)
+        out['config2_focus_2048_c64']['two_streams'] = dict(e2, note='two independent 2048^2 fields per iteration, one per stream; ms per field')
+        del x2, x2b, keep
     def sec_config3():   # config 3: 4096^2 complex128 angular-spectrum step (fused 3 passes), graded on 8 N^2 s bytes
         x3 = torch.from_numpy(make_field(4096, np.complex128, 4096)).cuda()
         out['config3_angular_spectrum_4096_c128'] = _hbm_entry(

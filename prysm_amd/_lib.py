@@ -12,7 +12,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libprysm_amd.so')
+# PRYSM_AMD_LIB: another BUILD of the same library (tools/: the -DPM_EXPERIMENTS build in prysm_amd/alt/ for A/B measurements)
+LIB_PATH = os.environ.get('PRYSM_AMD_LIB') or os.path.join(_HERE, 'libprysm_amd.so')
 
 PM_C64, PM_C128, PM_F32, PM_F64, PM_BOOL = 0, 1, 2, 3, 4
 PM_EPI_NONE, PM_EPI_ABS2, PM_EPI_ABS2_ACCUM, PM_EPI_ABS, PM_EPI_ARG = 0, 1, 2, 3, 4

@@ -15,7 +15,9 @@
 #include "fft_r2c_types.h"
 #include "fft_conv1_types.h"
 #include "fft_spectral_types.h"
+#ifdef PM_EXPERIMENTS
 #include "fft_spectral2.h"
+#endif
 #include "fft_c2r_types.h"
 
 namespace pm {
@@ -1327,6 +1329,7 @@ static int fft2_spectral_group(const pm_fft2_desc* d, const Fft2Plan& p, const S
     return launch_col_spectral<T>(p.logm, cl, cs, twm, ntiles, sibling_log_g(p.log_k), w, st, 1);
 }
 
+#ifdef PM_EXPERIMENTS
 // ---- the same in groups of 2 .. 4 wavelengths on the kernels that keep four waves per SIMD (fft_spectral2.h): complex64, rows of 1024 ..
 // 4096 samples, column tiles of 1024 / 2048 points (the planes of a folded 4096-row transform included), every bin of the output kept
 static bool spectral2_shape(const pm_fft2_desc* d, const Fft2Plan& p) {
@@ -1413,6 +1416,8 @@ static int fft2_spectral2_group(const pm_fft2_desc* d, const Fft2Plan& p, const 
     return launch_col_spectral2(lt, gc, twc, ntiles, sibling_log_g(p.log_k), w, st, p.fold ? 2 : 1);
 }
 
+#endif   // PM_EXPERIMENTS
+
 }  // namespace pm
 
 using namespace pm;
@@ -1430,7 +1435,7 @@ static bool experiment_only(const char* key, int v) {
 #else
     auto is = [&](const char* k) { return !strcmp(key, k); };
     return (is("spectral_mode") && (v & 3) != 3) || (is("gemm_3m") && !v) || (is("gemm_bm") && v == 128) || (is("gemm_bk") && v == 32) ||
-           (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 6));
+           (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 6)) || (is("spectral2") && v != 0);
 #endif
 }
 
@@ -1525,10 +1530,12 @@ size_t pm_fft2_spectral_workspace(const pm_fft2_desc* d, int32_t count) {
     if (check_fft2(d) || count <= 0) return 0;
     const Fft2Plan p = plan_fft2(d);
     size_t need = spectral_fast(d, p) ? p.ws_field * size_t(spectral_group(count)) : p.ws_bytes;
+#ifdef PM_EXPERIMENTS
     if (spectral2_shape(d, p)) {    // whether the call takes those kernels also depends on the alignment of `out`: the query covers both
         const size_t g2 = size_t(tuning().spectral2 < count ? tuning().spectral2 : count);
         if (p.ws_field * g2 > need) need = p.ws_field * g2;
     }
+#endif
     return need;
 }
 
@@ -1546,6 +1553,7 @@ int pm_fft2_spectral(const pm_fft2_desc* d, int32_t count, const double* k, cons
     if (!workspace || workspace_bytes < need)
         return fail(PM_ERR_WORKSPACE, "pm_fft2_spectral: workspace of %zu bytes required, %zu given", need, workspace_bytes);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#ifdef PM_EXPERIMENTS     // groups of 2 .. 4 on the four-waves-per-SIMD kernels: lost to the loop at every size (profiles/r04/exp_spectral2.log)
     if (spectral2_shape(d, p) && reinterpret_cast<uintptr_t>(out) % 8 == 0 && reinterpret_cast<uintptr_t>(in) % 8 == 0) {
         const int g = tuning().spectral2;
         const double two_pi = 2.0 * 3.14159265358979323846264338327950288;
@@ -1564,6 +1572,7 @@ int pm_fft2_spectral(const pm_fft2_desc* d, int32_t count, const double* k, cons
         }
         return 0;
     }
+#endif
     if (!spectral_fast(d, p)) {     // the loop itself: one transform pair per wavelength
         pm_fft2_desc dd = *d;
         for (int32_t b = 0; b < count; ++b) {

@@ -1,4 +1,8 @@
 // Grouped-wavelength transform pair at four waves per SIMD, complex64 (kernels + explicit launchers; see fft_spectral2.h).
+// EXPERIMENT BUILD ONLY (-DPM_EXPERIMENTS, `make -C tools exp`): measured against the per-wavelength loop and round 3's groups of 8
+// on MI355X (profiles/r04/exp_spectral2.log) it lost at every size -- 4096^2: 109.0 us per wavelength in groups of 4 against 108.3 (loop)
+// and 106.1; 2048^2: 23.7 against 21.5 (groups of 8); 1024^2: 13.7 against 10.4 -- see DESIGN.md 3.3d for why fewer bytes did not buy time.
+#ifdef PM_EXPERIMENTS
 #include "fft_kernels.h"
 #include "fft_spectral2.h"
 
@@ -155,3 +159,4 @@ int launch_col_spectral2(int logm, const Sp2Col<float>& g, const cx<float>* tw, 
 }
 
 }  // namespace pm
+#endif   // PM_EXPERIMENTS

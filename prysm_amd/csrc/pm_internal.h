@@ -138,8 +138,10 @@ struct Tuning {
                               // write 64 B pieces, direct and mirrored (MTF 4096^2 fp32 88.4 -> 81.4 us, fp64 176 -> 168; profiles/r02/exp_mtf_wide.log)
     int spectral = 8;         // pm_fft2_spectral: wavelengths per launch pair (fft_spectral.h; <= 8); 1: the plain loop of pm_fft2 calls
     int spectral_area_log = 24;   // ... for transforms of fewer than 2^this bins (capi.hip spectral_fast has the measurements)
-    int spectral2 = 4;        // ... groups of this many (2 .. 4) on the kernels that keep four waves per SIMD (fft_spectral2.h) where the shape
-                              // qualifies (complex64, rows of 1024 .. 4096 samples, every output bin kept); 0: round 3's forms only
+    int spectral2 = 0;        // experiment builds: groups of this many (2 .. 4) on the kernels that keep four waves per SIMD (fft_spectral2.h) where
+                              // the shape qualifies (complex64, rows of 1024 .. 4096 samples, every output bin kept); 0: round 3's forms.
+                              // Measured (profiles/r04/exp_spectral2.log, us per wavelength: loop / groups of 8 / these in groups of 2, 4):
+                              // 4096^2 108.3 / 106.1 / 111.8, 109.0; 2048^2 39.6 / 21.5 / 28.0, 23.7; 1024^2 24.1 / 10.4 / 16.9, 13.7
     int spectral2_keep = 0;   // ... groups of 3 / 4: the raw (amplitude, OPD) values stay in registers between the pairs (three waves per SIMD)
                               // instead of being read again from L2 / Infinity Cache
     int spectral2_min_log = 0;    // ... for transforms of at least 2^this bins

@@ -51,3 +51,48 @@ class CapturedModel:
 def capture(fn, *example_inputs, warmup=2):
     """Capture fn(*example_inputs) into a hipGraph; returns the replayable model."""
     return CapturedModel(fn, *example_inputs, warmup=warmup)
+
+
+class StreamRing:
+    """Round-robin HIP streams for a SEQUENCE of independent propagations (the fields of a stack that does not fit one launch, the
+    wavelengths or field points of a model, one pipeline per thread as the reference advises -- GPU and Exascale Computing.ipynb).
+
+    One propagation is two dependent launches; at 2048^2 and below each launch is a single round of workgroups, so its tail (the last
+    workgroups storing) and the next launch's head (the first loads) leave most of the chip idle: 30.6 us per 2048^2 complex64
+    `focus` back to back on one stream, 26.3 us when consecutive calls alternate between two streams (tools/exp_two_streams.py,
+    profiles/r04/exp_two_streams.log).  Only while BOTH fields' arrays fit the 256 MiB Infinity Cache together: at 4096^2 two
+    streams evict each other's intermediates (95 -> 133 us) -- `worth_it(shape, dtype)` says which side of that a shape is on.
+
+        ring = StreamRing(2)
+        outs = [ring.run(P.focus, x, 1) for x in fields]     # each call on the next stream, after the work already queued for x
+        ring.join()                                           # the caller's stream now waits for every stream of the ring
+
+    Workspaces are per stream (_lib.workspace), outputs come from torch's stream-aware allocator; results are the same bits.
+    """
+
+    def __init__(self, n=2, device=None):
+        L.load()
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(n)))]
+        self._next = 0
+
+    @staticmethod
+    def worth_it(shape, dtype=torch.complex64, streams=2):
+        """True when `streams` concurrent propagations of this shape keep input + intermediate + output inside the Infinity Cache."""
+        m, n = shape[-2:]
+        return 3 * m * n * torch.empty((), dtype=dtype).element_size() * streams <= 200 << 20
+
+    def run(self, fn, *args, **kwargs):
+        s = self.streams[self._next]
+        self._next = (self._next + 1) % len(self.streams)
+        s.wait_stream(torch.cuda.current_stream())      # inputs produced on the caller's stream
+        with torch.cuda.stream(s):
+            out = fn(*args, **kwargs)
+        for t in args:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(s)
+        return out
+
+    def join(self):
+        cur = torch.cuda.current_stream()
+        for s in self.streams:
+            cur.wait_stream(s)

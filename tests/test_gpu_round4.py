@@ -63,6 +63,9 @@ def test_spectral2_groups_vs_loop_and_numpy(pa, shape, Q):
     from prysm_amd import _lib, _ops
     from prysm_amd.propagation import focus_intensity
     lib = _lib.load()
+    if lib.pm_set_tuning_local(b'spectral2', 4) != 0:
+        pytest.skip('kernels built with -DPM_EXPERIMENTS only (they lost to the loop: profiles/r04/exp_spectral2.log)')
+    lib.pm_reset_tuning_local()
     rng = np.random.default_rng(shape[0] + Q)
     amp = ((rng.random(shape) > 0.25) * rng.random(shape)).astype(np.float32)
     opd = (40 * rng.standard_normal(shape)).astype(np.float32)
@@ -79,21 +82,22 @@ def test_spectral2_groups_vs_loop_and_numpy(pa, shape, Q):
             focus_intensity(packed, Q, out=acc, synth=('packed', ks[0]), spectral=(ks, wts))
         return acc.cpu().numpy().astype(np.float64) - 0.25
 
-    loop = run(spectral=1, spectral2=0)
+    loop = run(spectral=1)
     assert rel_max(loop, ref) < 2 * TOL32
     for grp, keep in ((2, 0), (3, 0), (4, 0), (4, 1), (3, 1)):
         got = run(spectral2=grp, spectral2_keep=keep)
         assert rel_max(got, ref) < 2 * TOL32, (grp, keep)
         assert rel_max(got, loop) < 1e-6, (grp, keep)
-    assert lib.pm_set_tuning_local(b'spectral2', 4) == 0
-    lib.pm_reset_tuning_local()
 
 
-def test_spectral2_default_route_config5_shape(pa):
-    """the default tuning sends BASELINE config 5's shape (4096^2 fp32 maps, Q = 1) through the grouped kernels; 5 wavelengths (a group
-    of 4 and a ragged 1) against the loop and numpy on a strip-checked image (numpy fp64 transforms of 4096^2 take seconds each)"""
+def test_spectral_call_config5_shape_vs_numpy(pa):
+    """pm_fft2_spectral at BASELINE config 5's shape (4096^2 fp32 maps, Q = 1) on the default route and -- experiment builds -- in
+    groups of 4 on the round-4 kernels (a group of 4 and a ragged 1): 5 wavelengths against numpy fp64"""
     from prysm_amd import _lib, _ops
     from prysm_amd.propagation import focus_intensity
+    lib = _lib.load()
+    exp_build = lib.pm_set_tuning_local(b'spectral2', 4) == 0
+    lib.pm_reset_tuning_local()
     n = 4096
     rng = np.random.default_rng(5)
     ax = (np.arange(n) - n // 2) * (10.0 / n)
@@ -111,11 +115,13 @@ def test_spectral2_default_route_config5_shape(pa):
             focus_intensity(packed, 1, out=acc, synth=('packed', ks[0]), spectral=(ks, wts))
         return acc.cpu().numpy().astype(np.float64)
 
-    got = run()
-    loop = run(spectral=1, spectral2=0)
-    assert rel_max(got, loop) < 1e-6
     ref = _poly_numpy(amp, opd, ks, wts, 1)
-    assert rel_max(got, ref) < 2 * TOL32
+    loop = run(spectral=1)
+    assert rel_max(loop, ref) < 2 * TOL32
+    assert rel_max(run(), loop) < 1e-6
+    if exp_build:
+        got = run(spectral2=4)
+        assert rel_max(got, loop) < 1e-6 and rel_max(got, ref) < 2 * TOL32
 
 
 # ----------------------------------------------------------------------------- per-thread tuning

@@ -50,7 +50,7 @@ def main():
             def setk(**kw):
                 for k, v in kw.items():
                     assert lib.pm_set_tuning(k.encode(), v) == 0, k
-            setk(spectral=1, spectral2=0)
+            setk(spectral=1, spectral2=0)      # (needs the experiment build: prysm_amd/alt via PM_LIB, tools/Makefile `exp`)
             t0 = timeit(run, 3 if prof else 7)
             ref = acc.clone()
             print(f'n={n} Q={Q}: loop {t0 * 1e3 / nl:7.1f} us/wavelength', flush=True)
