@@ -214,12 +214,16 @@ def other_configs(only=''):
         from prysm_amd.graph import StreamRing
         ring, x2b, keep = StreamRing(2), x2.clone(), [None, None]
 
-        def pair():
-            keep[0] = ring.run(P.focus, x2, 1)
-            keep[1] = ring.run(P.focus, x2b, 1)
+        def sequence(k=100):       # 2 k propagations, free-running on the two streams, joined once at the end
+            for _ in range(k):
+                keep[0] = None
+                keep[0] = ring.run(P.focus, x2, 1)
+                keep[1] = None
+                keep[1] = ring.run(P.focus, x2b, 1)
             ring.join()
-        e2 = _hbm_entry(_event_ms(pair, 50) / 2, 4 * 2048 ** 2 * 8)
-        out['config2_focus_2048_c64']['two_streams'] = dict(e2, note='two independent 2048^2 fields per iteration, one per stream; ms per field')
+        e2 = _hbm_entry(_event_ms(sequence, 3, warm=1) / 200, 4 * 2048 ** 2 * 8)
+        out['config2_focus_2048_c64']['two_streams'] = dict(e2, note='a sequence of 200 independent 2048^2 propagations alternating between two HIP '
+                                                                     'streams (StreamRing), joined once at the end; ms per propagation')
         del x2, x2b, keep
     def sec_config3():   # config 3: 4096^2 complex128 angular-spectrum step (fused 3 passes), graded on 8 N^2 s bytes
         x3 = torch.from_numpy(make_field(4096, np.complex128, 4096)).cuda()
@@ -246,6 +250,24 @@ def other_configs(only=''):
                                   'composite length on its own factors (LDS-resident mixed radix, one kernel per axis); round 2 convolved these at '
                                   'the next power of two above 2 N (Bluestein)')
             del xc
+        # the free-space step on a composite grid (prysm/propagation/angular_spectrum.py:9-42 takes any size): three passes with the
+        # mixed-radix middle pass (round 4), graded like config 3 on 8 N^2 s; `composed_ms`: two pm_fft2 calls (rounds 1 - 3)
+        from prysm_amd import _lib as L_
+        for n, cdt, prec_, key in ((3000, np.complex128, 64, 'angular_spectrum_3000_c128_composite'), (3000, np.complex64, 32, 'angular_spectrum_3000_c64_composite')):
+            xa = torch.from_numpy(make_field(n, cdt, n + 1)).cuda()
+            prec0 = config.precision
+            config.precision = prec_
+            try:
+                e = _hbm_entry(_event_ms(lambda: P.angular_spectrum(xa, 0.6328, 0.01, 10.0, Q=1), 30), 8 * n ** 2 * xa.element_size(),
+                               'fft2 x H ifft2 on a 3000^2 grid: mixed-radix row pass, middle pass with the column resident in LDS (forward stages, '
+                               'x H, transposed stages), mixed-radix inverse row pass; graded on 8 N^2 s, moves 6 N^2 s')
+                with L_.tuning_local(mix_fused=0):
+                    e['composed_ms'] = _event_ms(lambda: P.angular_spectrum(xa, 0.6328, 0.01, 10.0, Q=1), 30)
+            finally:
+                config.precision = prec0
+            e['moved_frac_of_hbm_peak'] = 0.75 * e['frac_of_hbm_peak']
+            out[key] = e
+            del xa
     def sec_padded():    # the padded (Q = 2) cases reported separately, graded on 4 N^2 s of the TRANSFORM size although
         for npup, key in ((2048, 'focus_Q2_2048_to_4096_c64'), (1024, 'focus_Q2_1024_to_2048_c64')):     # the row pass skips the zero rows
             xp = torch.from_numpy(make_field(npup, np.complex64, npup + 7)).cuda()

@@ -211,18 +211,22 @@ def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_
     (PM_FLAG_REAL_OUTPUT: unpadded power-of-two sizes, a full multiplier), else `.real` of the complex result.
 
     Power-of-two transform sizes run the fused three-pass kernel chain (pm_fft2_mul_ifft2: the multiply and
-    both column transforms happen in registers); other sizes compose two pm_fft2 calls.
+    both column transforms happen in registers); so do composite grids whose column length has primes <= 13 (round 4: the middle
+    pass keeps the column in LDS through forward stages, multiplier and transposed stages); what is left composes two pm_fft2 calls.
     """
     lib = L.load()
     m, n = x.shape[-2:]
     M, N = (m, n) if shape is None else shape
-    # non power-of-two sizes compose two fused transforms (measured, profiles/r01/fused_as.log: the 3-pass chain
-    # wins at every engine size, e.g. 4096^2 complex128 448 vs 473 us, 2048^2 complex64 55 vs 75 us)
-    if not (_is_pow2_engine(M) and _is_pow2_engine(N)):
+    def composed():
+        # two fused transforms, the multiplier in the first one's column store (measured, profiles/r01/fused_as.log: the 3-pass chain wins
+        # at every engine size, e.g. 4096^2 complex128 448 vs 473 us, 2048^2 complex64 55 vs 75 us)
         F = fft2(x, direction=-1, scale=1.0, shape=shape, in_off=in_off, in_shift=in_shift, mul=mul, mul_x=mul_x,
                  mul_conj=mul_conj)
         r = fft2(F, direction=+1, scale=scale, out_shape=out_shape, out_off=out_off, out_shift=out_shift)
         return r.real if (real_out and not x.is_complex()) else r
+    pow2 = _is_pow2_engine(M) and _is_pow2_engine(N)
+    if not pow2 and x.dim() != 2:
+        return composed()
     d = L.pm_fft2_desc()
     x, (M, N), (om, on) = _fill_views(d, x, shape, in_off, in_shift, out_shape, out_off, out_shift)
     d.direction = -1
@@ -247,6 +251,10 @@ def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_
     if x.dim() == 3:
         d.out_bstride = out.stride(0) if out.shape[0] > 1 else om * d.out_ld
     nbytes = lib.pm_fft2_mul_ifft2_workspace(ctypes.byref(d))
+    if not nbytes and not pow2:
+        # not a shape of the composite-grid chain (a column length with a prime above 13, a Bluestein row length ...)
+        del out
+        return composed()
     ws = L.workspace(max(int(nbytes), 16))
     L.check(lib.pm_fft2_mul_ifft2(ctypes.byref(d), L.ptr(x), L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()))
     return out.real if (real_out and not x.is_complex()) else out

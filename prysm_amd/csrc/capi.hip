@@ -161,6 +161,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("mixed_radix")) t.mixed_radix = v ? 1 : 0;
     else if (is("mix")) t.mix = v < 0 ? 0 : (v > 2 ? 2 : v);
     else if (is("mix_min")) t.mix_min = v < 18 ? 18 : v;
+    else if (is("mix_fused")) t.mix_fused = v ? 1 : 0;
     else if (is("mix_maxr")) t.mix_maxr = (v < 2 || v > 20) ? 20 : v;
     else if (is("mix_log_g")) t.mix_log_g = v;
     else if (is("mix_seqs")) t.mix_seqs = v < 0 ? 0 : v;
@@ -634,13 +635,44 @@ struct FusedPlan {
     int64_t nbatch, chunk;       // fields, fields per launch triple
     size_t ws_bytes;             // total workspace
     bool fold;                   // radix-2 step of the column transforms folded into the first / last row pass
+    bool mixmid;                 // composite column length: natural intermediates of pitch w_ld, the mixed-radix middle pass (fft_mixed.h)
+    int64_t w_ld;
 };
+
+// Composite grids (round 4): the column length runs on its own factors with the column resident in LDS through forward stages, multiplier
+// and transposed stages (mix_cols_mul); the row passes are the engine's (a power-of-two row length) or the mixed-radix row kernel, on
+// NATURAL intermediates.  Three passes / 6 N^2 s bytes where two pm_fft2 calls move 8 N^2 s -- the reference takes any size through one
+// code path (prysm/propagation/angular_spectrum.py:9-42, prysm/convolution.py:9-31).  One field, complex output.
+static bool plan_fused_mix(const pm_fft2_desc* d, FusedPlan& p) {
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    const size_t es = d->dtype == PM_C64 ? 8 : 16;
+    if (!tuning().mix_fused || !use_mix(M) || !(p.logn >= 0 || use_mix(N)) || d->batch > 1) return false;
+    if (d->flags & (PM_FLAG_SYNTH_INPUT | PM_FLAG_SYNTH_PACKED | PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY | PM_FLAG_NORM_DC)) return false;
+    if (d->epilogue != PM_EPI_NONE || d->in_y.len <= 0) return false;
+    const int64_t line = int64_t(128 / es);
+    p.w_ld = (N + line - 1) / line * line;
+    if (!mix_fits(N, d->in_ld, es, false) || !mix_fits(M, p.w_ld, es, true) || !mix_fits(N, d->out_ld, es, false) || !mix_fits(N, p.w_ld, es, false))
+        return false;
+    p.mixmid = true;
+    p.fold = false;
+    p.tc = 0;
+    p.log_k = 0;
+    p.inplace = d->in_y.len == M;
+    p.w1_bytes = (size_t(d->in_y.len) * size_t(p.w_ld) * es + 255) & ~size_t(255);
+    p.w2_bytes = p.inplace ? 0 : ((size_t(M) * size_t(p.w_ld) * es + 255) & ~size_t(255));
+    p.nbatch = p.chunk = 1;
+    p.ws_bytes = p.w1_bytes + p.w2_bytes;
+    return true;
+}
 
 static bool plan_fused(const pm_fft2_desc* d, FusedPlan& p) {
     const int64_t M = d->in_y.n, N = d->in_x.n;
     p.logn = engine_log2(N);
     p.logm = engine_log2(M);
-    if (p.logn < 0 || p.logm < 0) return false;
+    p.mixmid = false;
+    p.w_ld = N;
+    if (p.logm < 0) return plan_fused_mix(d, p);
+    if (p.logn < 0) return false;
     const size_t es = d->dtype == PM_C64 ? 8 : 16;
     // fold (see fold_legal): here the output window is unconstrained -- the last row pass rebuilds whole rows
     p.fold = false;
@@ -753,6 +785,51 @@ static int fused_run_chunk(const pm_fft2_desc* d, const FusedPlan& p, const void
     RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), nrun, 1, T(d->scale), 1, oy, d->out_bstride};
     rs.nt = row_store_nt(size_t(p.nbatch) * size_t(d->out_y.len) * size_t(d->out_x.len) * sizeof(cx<T>));
     return launch_row_from_tiled<T>(p.logn, row_variant(d->dtype, p.logn), rl, rs, twN, nrun, st, nb);
+}
+
+// the composite-grid chain (plan_fused_mix)
+template <typename T>
+static int fused_mix_run(const pm_fft2_desc* d, const FusedPlan& p, const void* in, void* out, void* ws, hipStream_t st) {
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    cx<T>* W1 = reinterpret_cast<cx<T>*>(ws);
+    cx<T>* W2 = p.inplace ? W1 : reinterpret_cast<cx<T>*>(reinterpret_cast<char*>(ws) + p.w1_bytes);
+    // pass A: forward row transforms of the stored input rows -> natural W1 (the first pass of pm_fft2 on this shape)
+    pm_fft2_desc da = *d;
+    da.flags = (d->flags & PM_FLAG_REAL_INPUT) | PM_FLAG_PASS1_ONLY;
+    da.mul_kind = PM_MUL_NONE;
+    da.direction = -1;
+    da.batch = 0;
+    const Fft2Plan pa = plan_fft2(&da);
+    if (pa.tc != 0 || pa.w_ld != p.w_ld || pa.blue_n || pa.blue2d || pa.big_rn)
+        return fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: internal: the composite-grid chain and the transform planner disagree on %lld x %lld", (long long)M, (long long)N);
+    int rc = fft2_run_chunk<T>(&da, pa, in, out, W1, st, 1);
+    if (rc) return rc;
+    // pass B: column transform, x H, inverse column transform (unnormalised) with the columns resident in LDS -> natural W2, all M rows
+    DirectIn<T> di{W1, 1, p.w_ld, to_map(d->in_y), int(N), 0, 0};
+    MidMul<T> mm{d->mul_kind, d->mul_conj, reinterpret_cast<const cx<T>*>(d->mul), reinterpret_cast<const cx<T>*>(d->mul_x), d->mul_ld, int(N), 0, 0, 0, 0};
+    if ((rc = mix_cols_mul<T>(di, mm, W2, p.w_ld, st))) return rc;
+    // pass C: inverse row transforms (conj in, conj out) of the rows the output window keeps, scale applied here
+    int err = 0;
+    if (p.logn >= 0) {
+        const cx<T>* twN = twiddles<T>(N, &err);
+        if (!twN) return err;
+        RowLoadNat<T> lp{W2, p.w_ld, AxisMap{int(N), int(N), 0, 0}, int(M), 1, 0, 0};
+        RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out), d->out_ld, to_map(d->out_x), int(M), 1, T(d->scale), 1, to_map(d->out_y), 0};
+        rs.nt = row_store_nt(size_t(d->out_y.len) * size_t(d->out_x.len) * sizeof(cx<T>));
+        return launch_row_nat<T>(p.logn, row_variant(d->dtype, p.logn), lp, rs, twN, int(M), 0, st);
+    }
+    // the mixed-radix row kernel writes sequence s to memory row s: the kept positions [off, off + len) of the rotated rows are at most
+    // two runs of consecutive logical rows
+    const int64_t off = d->out_y.off, len = d->out_y.len, sh = d->out_y.shift;
+    const int64_t cut = sh > off ? (sh < off + len ? sh : off + len) : off;      // positions [off, cut) are logical rows p - sh + M
+    const int64_t runs[2][3] = {{off - sh + M, 0, cut - off}, {cut - sh, cut - off, off + len - cut}};     // first logical row, first memory row, count
+    for (const auto& r : runs) {
+        if (r[2] <= 0) continue;
+        DirectIn<T> ri{W2 + r[0] * p.w_ld, p.w_ld, 1, AxisMap{int(N), int(N), 0, 0}, int(r[2]), 1, 0};
+        RowStoreNat<T> rs{reinterpret_cast<cx<T>*>(out) + r[1] * d->out_ld, d->out_ld, to_map(d->out_x), int(r[2]), 1, T(d->scale), 0, AxisMap{1, 1, 0, 0}, 0};
+        if ((rc = mix_rows<T>(ri, nullptr, 0, st, &rs))) return rc;
+    }
+    return 0;
 }
 
 // ---------------------------------------------------------------- both axes not powers of two: 2-D Bluestein
@@ -961,6 +1038,7 @@ static int big2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, v
 
 template <typename T>
 static int fused_run(const pm_fft2_desc* d, const FusedPlan& p, const void* in, void* out, void* ws, hipStream_t st) {
+    if (p.mixmid) return fused_mix_run<T>(d, p, in, out, ws, st);
     for (int64_t b0 = 0; b0 < p.nbatch; b0 += p.chunk) {
         const int nb = int(p.nbatch - b0 < p.chunk ? p.nbatch - b0 : p.chunk);
         pm_fft2_desc dd = *d;
@@ -1635,8 +1713,9 @@ int pm_fft2_mul_ifft2(const pm_fft2_desc* d, const void* in, void* out, void* wo
     }
     FusedPlan p;
     if (!plan_fused(d, p))
-        return fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: both lengths must be powers of two <= 8192 (got %lld x %lld); "
-                    "compose two pm_fft2 calls instead", (long long)d->in_y.n, (long long)d->in_x.n);
+        return fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: takes powers of two <= 8192 on both axes, or (one field, complex output) a composite "
+                    "column length with primes <= 13 beside a row length of either kind (got %lld x %lld); compose two pm_fft2 calls instead",
+                    (long long)d->in_y.n, (long long)d->in_x.n);
     const size_t need = p.ws_bytes;
     if (!workspace || workspace_bytes < need)
         return fail(PM_ERR_WORKSPACE, "pm_fft2_mul_ifft2: workspace of %zu bytes required, %zu given", need, workspace_bytes);

@@ -404,6 +404,97 @@ PM_HD void mix_last(const MixPlan& p, MixShape sh, int tid, int nt, const cx<T>*
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// The TRANSPOSED stages: the same factorisation run backwards turns the digit-reversed slots the forward stages leave into a forward
+// DFT in NATURAL order.  F_n = P S_last .. S_0 (S_s = T_s F_R per block, P the digit reversal) and F_n is symmetric, so
+// F_n = S_0^T .. S_last^T P^T with S_s^T = F_R T_s: twiddle first, then the small DFT, on the slots the forward stage used.  The middle
+// pass of fft2 -> x H -> ifft2 on composite grids is forward stages, multiplier, transposed stages with the column resident in LDS
+// throughout (ifft = conj fft conj: the multiplier step stores conj(x h), the last transposed stage stores the conjugate).
+// ---------------------------------------------------------------------------
+// transposed middle stage s: LDS in place
+template <typename T, bool COL, int R>
+PM_HD void mix_mid_t(const MixPlan& p, MixShape sh, int s, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw) {
+    const int n = p.n, nb = n / R, total = sh.seqs * nb, sub = p.len[s + 1], L = sub * R, tstep = n / L;
+    const uint32_t mg_nb = p.mg_nb[s], mg_sub = p.mg_sub[s];
+#pragma unroll 1
+    for (int b = tid; b < total; b += nt) {
+        int sl, ja;
+        mix_split<COL>(sh, b, mg_nb, nb, sl, ja);
+        const int blk = mix_div(ja, mg_sub), j = ja - int(mix_mul24(uint32_t(blk), uint32_t(sub))),
+                  base = int(mix_mul24(uint32_t(blk), uint32_t(L))) + j;
+        const int a0 = mix_addr<COL>(n, sh, sl, base), as = mix_step<COL>(sh, sub);
+        const uint32_t tj = mix_mul24(uint32_t(j), uint32_t(tstep));
+        cx<T> a[R];
+        a[0] = mix_ld(lds + a0);
+#pragma unroll
+        for (int k = 1; k < R; ++k) a[k] = cmul(mix_ld(lds + a0 + k * as), mix_ld(tw + tj * uint32_t(k)));
+        MixDft<T, R>::run(a);
+#pragma unroll
+        for (int k = 0; k < R; ++k) mix_st(lds + a0 + k * as, a[k]);
+    }
+}
+
+// last forward stage, multiplier, last stage transposed (no twiddles either way): butterfly o holds bins o + k n / R in registers between
+// the two small DFTs -- no LDS round trip, no barrier.  mul(sl, bin, v) returns conj(v h(bin, column of sl)).
+template <typename T, bool COL, int R, typename Mul>
+PM_HD void mix_last_mul(const MixPlan& p, MixShape sh, int tid, int nt, cx<T>* lds, Mul mul) {
+    const int n = p.n, s = p.nstage - 1, nb = n / R, total = sh.seqs * nb;
+    const uint32_t mg_nb = p.mg_nb[s];
+    int rdx[kMixMaxStages - 1], wgt[kMixMaxStages - 1];
+    uint32_t mgr[kMixMaxStages - 1];
+#pragma unroll
+    for (int i = 0; i < kMixMaxStages - 1; ++i) {
+        rdx[i] = i < s ? p.radix[i] : 1;
+        wgt[i] = i < s ? p.len[i + 1] : 0;
+        mgr[i] = i < s ? p.mg_radix[i] : 0u;
+    }
+#pragma unroll 1
+    for (int b = tid; b < total; b += nt) {
+        int sl, o;
+        mix_split<COL>(sh, b, mg_nb, nb, sl, o);
+        int rem = o, pos = 0;
+#pragma unroll
+        for (int i = 0; i < kMixMaxStages - 1; ++i) {
+            if (i < s) {
+                const int q = mix_div(rem, mgr[i]);
+                pos += int(mix_mul24(uint32_t(rem) - mix_mul24(uint32_t(q), uint32_t(rdx[i])), uint32_t(wgt[i])));
+                rem = q;
+            }
+        }
+        const int a0 = mix_addr<COL>(n, sh, sl, pos), as = mix_step<COL>(sh, 1);
+        cx<T> a[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[k] = mix_ld(lds + a0 + k * as);
+        MixDft<T, R>::run(a);
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[k] = mul(sl, o + k * nb, a[k]);
+        MixDft<T, R>::run(a);
+#pragma unroll
+        for (int k = 0; k < R; ++k) mix_st(lds + a0 + k * as, a[k]);
+    }
+}
+
+// transposed first stage: LDS -> destination, natural order (point j + k n / R of sequence slot sl)
+template <typename T, bool COL, int R, typename Store>
+PM_HD void mix_first_t(const MixPlan& p, MixShape sh, int tid, int nt, const cx<T>* lds, const cx<T>* __restrict__ tw, Store store) {
+    const int n = p.n, nb = p.len[1], total = sh.seqs * nb;
+    const uint32_t mg_nb0 = p.mg_nb[0];
+#pragma unroll 1
+    for (int b = tid; b < total; b += nt) {
+        int sl, j;
+        mix_split<COL>(sh, b, mg_nb0, nb, sl, j);
+        const int a0 = mix_addr<COL>(n, sh, sl, j), as = mix_step<COL>(sh, nb);
+        cx<T> a[R];
+        a[0] = mix_ld(lds + a0);
+#pragma unroll
+        for (int k = 1; k < R; ++k) a[k] = cmul(mix_ld(lds + a0 + k * as), mix_ld(tw + uint32_t(j) * uint32_t(k)));
+        MixDft<T, R>::run(a);
+#pragma unroll
+        for (int k = 0; k < R; ++k) store(sl, j + k * nb, a[k]);
+    }
+}
+
 // `MAXR` (a template parameter of the caller) bounds the factors a kernel class contains
 #define PM_MIX_RADIX_SWITCH(r, CALL) \
     switch (r) { \
@@ -464,6 +555,19 @@ PM_HD void mix_run_mid(const MixPlan& p, MixShape sh, int s, int tid, int nt, cx
 template <typename T, bool COL, int MAXR, typename Store>
 PM_HD void mix_run_last(const MixPlan& p, MixShape sh, int tid, int nt, const cx<T>* lds, Store store) {
     PM_MIX_RADIX_SWITCH(p.radix[p.nstage - 1], (mix_last<T, COL, R>(p, sh, tid, nt, lds, store)))
+}
+
+template <typename T, bool COL, int MAXR>
+PM_HD void mix_run_mid_t(const MixPlan& p, MixShape sh, int s, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw) {
+    PM_MIX_RADIX_SWITCH(p.radix[s], (mix_mid_t<T, COL, R>(p, sh, s, tid, nt, lds, tw)))
+}
+template <typename T, bool COL, int MAXR, typename Mul>
+PM_HD void mix_run_last_mul(const MixPlan& p, MixShape sh, int tid, int nt, cx<T>* lds, Mul mul) {
+    PM_MIX_RADIX_SWITCH(p.radix[p.nstage - 1], (mix_last_mul<T, COL, R>(p, sh, tid, nt, lds, mul)))
+}
+template <typename T, bool COL, int MAXR, typename Store>
+PM_HD void mix_run_first_t(const MixPlan& p, MixShape sh, int tid, int nt, const cx<T>* lds, const cx<T>* __restrict__ tw, Store store) {
+    PM_MIX_RADIX_SWITCH(p.radix[0], (mix_first_t<T, COL, R>(p, sh, tid, nt, lds, tw, store)))
 }
 
 // Branch-free element of the DirectIn view for the first stage: the load always happens (at element 0 of the workgroup's first sequence

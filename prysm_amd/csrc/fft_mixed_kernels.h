@@ -81,9 +81,11 @@ __global__ __launch_bounds__(512) void mix_rows_kernel(const MixPlan* __restrict
     }
 }
 
-template <typename T, int MAXR>
-__global__ __launch_bounds__(512) void mix_cols_kernel(const MixPlan* __restrict__ pp, MixShape sh, DirectIn<T> in, ColStoreNat<T> out,
-                                                       const cx<T>* __restrict__ tw, int log_g) {
+// NTMAX: 512, or 1024 (128-register cap) for the classes whose register count allows it -- the column pass holds ONE workgroup per CU
+// from ~2000-point columns (four columns take most of the LDS), so the waves of that workgroup are all the latency hiding there is
+template <typename T, int MAXR, int NTMAX = 512>
+__global__ __launch_bounds__(NTMAX) void mix_cols_kernel(const MixPlan* __restrict__ pp, MixShape sh, DirectIn<T> in, ColStoreNat<T> out,
+                                                         const cx<T>* __restrict__ tw, int log_g) {
     const MixPlan& p = *pp;
     extern __shared__ __align__(16) char mix_smem[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(mix_smem);
@@ -124,6 +126,74 @@ __global__ __launch_bounds__(512) void mix_cols_kernel(const MixPlan* __restrict
     }
 }
 
+
+// Middle pass of fft2 -> x H -> ifft2 on a composite column length (fft_mixed.h, the transposed stages): a tile of adjacent columns of the
+// natural intermediate goes through forward stages, the multiplier and the transposed stages without leaving the LDS, and comes back as
+// the UNNORMALISED inverse column transform of (column spectrum x H) -- what the engine's middle pass (fft_kernels.h) leaves for the last
+// row pass.  2 nstage - 1 phases, one barrier between phases; may run in place (a workgroup reads its columns whole before it writes).
+template <typename T>
+struct MixMul {
+    int kind, conj;
+    const cx<T>* mul;       // MUL_FULL: mul[k * ld + c]; MUL_SEPARABLE: hy[k]
+    const cx<T>* mul_x;     // MUL_SEPARABLE: hx[c]
+    int64_t ld;
+    int ncols;
+};
+
+template <typename T, int MAXR, int NTMAX = 512>
+__global__ __launch_bounds__(NTMAX) void mix_cols_mul_kernel(const MixPlan* __restrict__ pp, MixShape sh, DirectIn<T> in, MixMul<T> mm, cx<T>* dst,
+                                                             uint32_t dst_pitch, const cx<T>* __restrict__ tw, int log_g) {
+    const MixPlan& p = *pp;
+    extern __shared__ __align__(16) char mix_smem[];
+    cx<T>* lds = reinterpret_cast<cx<T>*>(mix_smem);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = ((slot >> log_g) << (log_g + 3)) + (xcd << log_g) + (slot & ((1 << log_g) - 1));
+    const int c0 = tile * sh.seqs, tid = threadIdx.x, nt = blockDim.x;
+    if (c0 >= in.nseq) return;
+    const int nvalid = in.nseq - c0 < sh.seqs ? in.nseq - c0 : sh.seqs;
+    const bool whole_in = in.ax.off == 0 && in.ax.len == in.ax.n && nvalid == sh.seqs;
+    if (whole_in) {
+        const MixFetchWhole<T, true> fetch{in.src + c0, uint32_t(in.s_i), in.ax.n, in.ax.shift, T(1)};
+        mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+    } else {
+        const MixFetch<T, true, false> fetch{in.src + c0, uint32_t(in.s_i), in.ax, T(1), nvalid};
+        mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+    }
+    __syncthreads();
+    const int nstage = p.nstage;
+    for (int s = 1; s + 1 < nstage; ++s) {
+        mix_run_mid<T, true, MAXR>(p, sh, s, tid, nt, lds, tw);
+        __syncthreads();
+    }
+    if (mm.kind == MUL_FULL) {
+        auto mul = [&](int sl, int k, cx<T> v) {
+            const int c = sl < nvalid ? c0 + sl : c0;
+            const cx<T> h = mix_ld(mm.mul + (int64_t(k) * mm.ld + c));
+            const cx<T> r = mm.conj ? cmulc(v, h) : cmul(v, h);
+            return cx<T>{r.x, -r.y};
+        };
+        mix_run_last_mul<T, true, MAXR>(p, sh, tid, nt, lds, mul);
+    } else {
+        auto mul = [&](int sl, int k, cx<T> v) {
+            const int c = sl < nvalid ? c0 + sl : c0;
+            const cx<T> h = cmul(mix_ld(mm.mul + k), mix_ld(mm.mul_x + c));
+            const cx<T> r = mm.conj ? cmulc(v, h) : cmul(v, h);
+            return cx<T>{r.x, -r.y};
+        };
+        mix_run_last_mul<T, true, MAXR>(p, sh, tid, nt, lds, mul);
+    }
+    __syncthreads();
+    for (int s = nstage - 2; s >= 1; --s) {
+        mix_run_mid_t<T, true, MAXR>(p, sh, s, tid, nt, lds, tw);
+        __syncthreads();
+    }
+    cx<T>* d0 = dst + c0;
+    auto store = [&](int sl, int k, cx<T> v) {
+        if (sl < nvalid) mix_st(d0 + (mix_mul24(uint32_t(k), dst_pitch) + uint32_t(sl)), cx<T>{v.x, -v.y});
+    };
+    mix_run_first_t<T, true, MAXR>(p, sh, tid, nt, lds, tw, store);
+}
+
 static constexpr size_t kMixLdsHard = 156 * 1024;
 
 static inline int round_up64(int v) { return (v + 63) & ~63; }
@@ -140,8 +210,11 @@ static inline int mix_threads(const MixPlan& p, int seqs, int cap, int forced) {
         nt = round_up64((most + rounds - 1) / rounds);
     }
     if (forced > 0) nt = round_up64(forced);
-    return nt < 64 ? 64 : (nt > 512 ? 512 : nt);
+    const int hard = cap > 512 ? cap : 512;
+    return nt < 64 ? 64 : (nt > hard ? hard : nt);
 }
+// classes whose column kernel also exists for 1024-thread workgroups (128 registers per thread: complex64 94 .. 106, complex128 class of 10: 94)
+template <typename T> constexpr bool mix_cols_wide(int maxr_class) { return sizeof(T) == 4 || maxr_class <= 10; }
 
 // more than 64 KiB of dynamic LDS needs the kernel's limit raised: once per (kernel, device), to the most any launch asks for
 template <typename K>
@@ -180,6 +253,15 @@ int mix_rows_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, c
 template <typename T, int MAXR>
 int mix_cols_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const ColStoreNat<T>& out, const cx<T>* tw, int log_g, int groups, int nt,
                          size_t lds, hipStream_t st) {
+    if constexpr (mix_cols_wide<T>(MAXR)) {
+        if (nt > 512) {
+            const int rc = mix_set_lds(mix_cols_kernel<T, MAXR, 1024>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((mix_cols_kernel<T, MAXR, 1024>), dim3(groups), dim3(nt), lds, st, p, sh, in, out, tw, log_g);
+            return int(hipGetLastError());
+        }
+    }
+    if (nt > 512) nt = 512;
     const int rc = mix_set_lds(mix_cols_kernel<T, MAXR>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((mix_cols_kernel<T, MAXR>), dim3(groups), dim3(nt), lds, st, p, sh, in, out, tw, log_g);
@@ -253,10 +335,70 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     while ((size_t(tc) << log_g) * sizeof(cx<T>) < 128 && log_g < 3) ++log_g;
     if (tuning().mix_log_g >= 0) log_g = tuning().mix_log_g > 4 ? 4 : tuning().mix_log_g;
     const int tiles = (ncols + tc - 1) / tc, round = 8 << log_g;
-    const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc, 512, tuning().mix_ntc);
+    // threads: up to 512; the knob mix_ntc may ask for up to 1024 where that kernel exists
+    const int cls = mix_class_of(p.maxr);
+    const int cap = (tuning().mix_ntc > 512 && mix_cols_wide<T>(cls)) ? 1024 : 512;
+    const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc, cap, tuning().mix_ntc);
     if (p.maxr <= 10) return mix_cols_launch<T, 10>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
     if (p.maxr <= 16) return mix_cols_launch<T, 16>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
     return mix_cols_launch<T, 20>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
+}
+
+// the middle pass: one launcher per precision (fft_mixed_mid_f32.hip / _f64.hip hold its kernel classes)
+template <typename T, int MAXR>
+int mix_cols_mul_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const MixMul<T>& mm, cx<T>* dst, uint32_t pitch, const cx<T>* tw, int log_g,
+                             int groups, int nt, size_t lds, hipStream_t st) {
+    if constexpr (mix_cols_wide<T>(MAXR)) {
+        if (nt > 512) {
+            const int rc = mix_set_lds(mix_cols_mul_kernel<T, MAXR, 1024>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((mix_cols_mul_kernel<T, MAXR, 1024>), dim3(groups), dim3(nt), lds, st, p, sh, in, mm, dst, pitch, tw, log_g);
+            return int(hipGetLastError());
+        }
+    }
+    if (nt > 512) nt = 512;
+    const int rc = mix_set_lds(mix_cols_mul_kernel<T, MAXR>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((mix_cols_mul_kernel<T, MAXR>), dim3(groups), dim3(nt), lds, st, p, sh, in, mm, dst, pitch, tw, log_g);
+    return int(hipGetLastError());
+}
+
+template <typename T>
+int mix_cols_mul_impl(const DirectIn<T>& in, const MidMul<T>& m, cx<T>* dst, int64_t dst_pitch, hipStream_t st) {
+    const int n = in.ax.n, ncols = in.nseq;
+    if (ncols <= 0 || n <= 0) return 0;
+    MixPlan p;
+    if (!mix_plan_for(n, sizeof(cx<T>), p)) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);
+    if (in.s_seq != 1 || in.conj || in.real || !mix_fits(n, in.s_i, sizeof(cx<T>), true) || !mix_fits(n, dst_pitch, sizeof(cx<T>), true))
+        return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: the array does not fit 32-bit offsets");
+    int err = 0;
+    const cx<T>* tw = twiddles<T>(n, &err);
+    if (!tw) return err;
+    const size_t per = size_t(p.n) * sizeof(cx<T>);
+    int tc = 4;     // as mix_cols_impl
+    while (tc > 1 && size_t(tc) * per > kMixLdsHard) tc /= 2;
+    if (tuning().mix_tc > 0) {
+        tc = 1;
+        while (tc * 2 <= tuning().mix_tc) tc *= 2;
+    }
+    while (tc > 1 && tc / 2 >= ncols) tc /= 2;
+    if (size_t(tc) * per > kMixLdsHard) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d does not fit the LDS", n);
+    MixShape sh{tc, 0};
+    while ((1 << sh.log_seqs) < tc) ++sh.log_seqs;
+    const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
+    if (!pd) return err;
+    const size_t lds = size_t(tc) * per;
+    int log_g = 0;
+    while ((size_t(tc) << log_g) * sizeof(cx<T>) < 128 && log_g < 3) ++log_g;
+    if (tuning().mix_log_g >= 0) log_g = tuning().mix_log_g > 4 ? 4 : tuning().mix_log_g;
+    const int tiles = (ncols + tc - 1) / tc, round = 8 << log_g;
+    const int cls = mix_class_of(p.maxr);
+    const int cap = (tuning().mix_ntc > 512 && mix_cols_wide<T>(cls)) ? 1024 : 512;
+    const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc, cap, tuning().mix_ntc);
+    const MixMul<T> mm{m.kind, m.conj, m.mul, m.mul_x, m.ld, ncols};
+    if (p.maxr <= 10) return mix_cols_mul_launch_impl<T, 10>(pd, sh, in, mm, dst, uint32_t(dst_pitch), tw, log_g, groups, nt, lds, st);
+    if (p.maxr <= 16) return mix_cols_mul_launch_impl<T, 16>(pd, sh, in, mm, dst, uint32_t(dst_pitch), tw, log_g, groups, nt, lds, st);
+    return mix_cols_mul_launch_impl<T, 20>(pd, sh, in, mm, dst, uint32_t(dst_pitch), tw, log_g, groups, nt, lds, st);
 }
 
 }  // namespace pm

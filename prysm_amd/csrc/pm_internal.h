@@ -57,6 +57,10 @@ template <typename T>
 int mix_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o = nullptr);
 template <typename T>
 int mix_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t st);
+// middle pass of fft2 -> x H -> ifft2 on a composite column length: the columns of the natural intermediate `in` (sequence = column) come
+// back in dst[row * dst_pitch + column] as the unnormalised inverse column transform of (column spectrum x H); in place allowed
+template <typename T>
+int mix_cols_mul(const DirectIn<T>& in, const MidMul<T>& mm, cx<T>* dst, int64_t dst_pitch, hipStream_t st);
 
 // both axes at once (capi.hip blue2d_run): the chirp multiplies around ONE fused fft2 -> x (B1 (x) B2) -> ifft2 chain of size
 // MB1 x MB2 (the 2-D cyclic convolution with the separable chirp)
@@ -126,6 +130,7 @@ struct Tuning {
     int mix_maxr = 20;        // ... plan within factors of at most this when the length allows (10 / 16 / 20: the kernel classes)
     int mix_log_g = -1;       // ... its column pass: 2^this adjacent tiles per XCD (-1 auto: as many as share a 128 B line)
     int mix_seqs = 0, mix_tc = 0, mix_nt = 0, mix_ntc = 0;   // ... force its rows per workgroup / columns per workgroup / threads per workgroup of the row pass / of the column pass (0 = auto)
+    int mix_fused = 1;        // ... fft2 -> x H -> ifft2 on a composite column length as three passes with the mixed-radix middle pass (0: two pm_fft2)
     int mix_min = 32;         // ... from this length (shorter ones stay on the direct fp64-accumulating kernel)
     int blue_fuse = 1;        // both-axes form on engine lengths: chirp multiplies inside the chain's first load / last store (1)
                              // or as separate kernels around it (0)

@@ -233,3 +233,55 @@ def test_composite_length_beside_a_split_length(pa):
                 assert rel_max(got, np.fft.fft2(x.astype(np.complex128))) < tol, (shape, dtype)
                 ref = O.focus(x.astype(np.complex128), 1)
                 assert rel_max(tonp(pa.propagation.focus(x, 1)), ref) < tol, (shape, dtype)
+
+
+# ----------------------------------------------------------------------------- fused chain on composite grids
+
+@pytest.mark.parametrize('shape,dtype,tol', [((1000, 1500), np.complex128, TOL64), ((600, 750), np.complex64, TOL32),
+                                             ((1000, 1024), np.complex128, TOL64), ((360, 2048), np.complex64, TOL32),
+                                             ((105, 154), np.complex128, TOL64)])
+def test_angular_spectrum_on_composite_grids(pa, shape, dtype, tol):
+    """angular_spectrum / its adjoint / tf= on grids whose column length is composite (primes <= 13) -- three passes with the
+    mixed-radix middle pass (forward stages, x H, transposed stages in LDS) -- against the oracle and against the composed route
+    (two pm_fft2 calls, knob mix_fused = 0); row lengths composite and powers of two; Q = 1 and a padded Q = 2 input"""
+    from prysm_amd import _lib
+    rng = np.random.default_rng(shape[0] + shape[1])
+    prec = pa.config.precision
+    pa.config.precision = 32 if dtype == np.complex64 else 64
+    try:
+        x = crandn(rng, shape, dtype)
+        ref = O.angular_spectrum(x.astype(np.complex128), O.HeNe, 0.01, 10.0, Q=1)
+        got = tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1))
+        assert got.dtype == dtype and rel_max(got, ref) < tol
+        with _lib.tuning_local(mix_fused=0):
+            comp = tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1))
+        assert rel_max(comp, ref) < tol and rel_max(got, comp) < 2 * tol
+        # padded input (only the stored rows are transformed in the first pass; the middle pass synthesises the zero rows), and
+        # the adjoint: conj(H) and a crop of the rows / columns in the last pass
+        small = np.ascontiguousarray(x[:shape[0] // 2, :shape[1] // 2])
+        refq = O.angular_spectrum(small.astype(np.complex128), O.HeNe, 0.01, 10.0, Q=2)
+        assert rel_max(tonp(pa.propagation.angular_spectrum(small, O.HeNe, 0.01, 10.0, Q=2)), refq) < tol
+        refa = O.angular_spectrum_adjoint(x.astype(np.complex128), O.HeNe, 0.01, 10.0, Q=2)
+        assert rel_max(tonp(pa.propagation.angular_spectrum_adjoint(x, O.HeNe, 0.01, 10.0, Q=2)), refa) < tol
+        tf = O.angular_spectrum_transfer_function(shape, O.HeNe, 0.01, 7.0)
+        reft = O.angular_spectrum(x.astype(np.complex128), O.HeNe, 0.01, 7.0, Q=1, tf=tf)
+        assert rel_max(tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 7.0, Q=1, tf=tf.astype(dtype))), reft) < 2 * tol
+    finally:
+        pa.config.precision = prec
+
+
+@pytest.mark.parametrize('shape', [(300, 500), (375, 250), (96, 1000)])
+def test_conv_on_composite_grids(pa, shape):
+    """conv / apply_transfer_functions on composite grids: both rotations ride on the chain -- the input rotation in the first two passes'
+    loads, the output rotation as two runs of rows in the last pass -- complex and real objects, against the oracle"""
+    from prysm_amd import convolution as C
+    rng = np.random.default_rng(sum(shape))
+    o = crandn(rng, shape)
+    h = crandn(rng, shape)
+    assert rel_max(tonp(C.conv(o, h)), O.conv(o, h)) < 1e-9
+    orl = rng.standard_normal(shape)
+    assert rel_max(tonp(C.conv(orl, h)), O.conv(orl, h)) < 1e-9
+    tf = crandn(rng, shape)
+    assert rel_max(tonp(C.apply_transfer_functions(o, 1.0, [tf])), O.apply_transfer_functions(o, 1.0, [tf])) < 1e-9
+    assert rel_max(tonp(C.apply_transfer_functions(o.astype(np.complex64), 1.0, [tf.astype(np.complex64)], shift=True)),
+                   O.apply_transfer_functions(o, 1.0, [tf], shift=True)) < 2e-5

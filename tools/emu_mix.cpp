@@ -74,8 +74,85 @@ static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift) {
     return err / ref;
 }
 
+// the middle pass of fft2 -> x H -> ifft2 on a composite column length: forward stages, multiplier between the two small DFTs of the
+// last stage, transposed stages, conjugate on the way out == the unnormalised inverse transform of (fft(x) h) per column
+template <typename T>
+static double run_mid_case(int n, int nseq, bool col, int seqs, int nt) {
+    MixPlan p;
+    if (!mix_make_plan(n, p)) return -1;
+    MixShape sh{seqs, 0};
+    while ((1 << sh.log_seqs) < seqs) ++sh.log_seqs;
+    const ld pi = acosl(-1.0L);
+    std::vector<cx<T>> tw(n);
+    for (int i = 0; i < n; ++i) tw[i] = {T(cosl(-2 * pi * i / n)), T(sinl(-2 * pi * i / n))};
+    std::mt19937 rng(n * 5 + nseq);
+    std::uniform_real_distribution<double> U(-1, 1);
+    std::vector<cx<T>> x(size_t(n) * nseq), y(size_t(n) * nseq, cx<T>{T(0), T(0)}), h(size_t(n) * nseq);
+    for (auto& v : x) v = {T(U(rng)), T(U(rng))};
+    for (auto& v : h) v = {T(U(rng)), T(U(rng))};       // h[bin][seq] (cols) or h[seq][bin] (rows)
+    std::vector<cx<T>> lds(size_t(seqs) * p.n + 64);
+    const int ngroups = (nseq + seqs - 1) / seqs;
+    for (int g = 0; g < ngroups; ++g) {
+        const int seq0 = g * seqs;
+        const cx<T>* base0 = x.data() + (col ? seq0 : size_t(seq0) * n);
+        const int nvalid = std::min(seqs, nseq - seq0);
+        MixFetch<T, true, false> fc{base0, uint32_t(nseq), AxisMap{n, n, 0, 0}, T(1), nvalid};
+        MixFetch<T, false, false> fr{base0, uint32_t(n), AxisMap{n, n, 0, 0}, T(1), nvalid};
+        auto fetch = [&](int sl, int i) { return col ? fc(sl, i) : fr(sl, i); };
+        auto mul = [&](int sl, int k, cx<T> v) {
+            const int sq = seq0 + sl < nseq ? seq0 + sl : 0;
+            const cx<T> hh = col ? h[size_t(k) * nseq + sq] : h[size_t(sq) * n + k];
+            const cx<T> r = cmul(v, hh);
+            return cx<T>{r.x, -r.y};
+        };
+        auto store = [&](int sl, int k, cx<T> v) {
+            if (seq0 + sl >= nseq) return;
+            v.y = -v.y;
+            if (col) y[size_t(k) * nseq + seq0 + sl] = v; else y[size_t(seq0 + sl) * n + k] = v;
+        };
+        auto run = [&](auto colc) {
+            constexpr bool COL = decltype(colc)::value;
+            for (int tid = 0; tid < nt; ++tid) mix_run_first<T, COL, 20>(p, sh, tid, nt, lds.data(), tw.data(), fetch);
+            for (int ph = 1; ph + 1 < p.nstage; ++ph)
+                for (int tid = 0; tid < nt; ++tid) mix_run_mid<T, COL, 20>(p, sh, ph, tid, nt, lds.data(), tw.data());
+            for (int tid = 0; tid < nt; ++tid) mix_run_last_mul<T, COL, 20>(p, sh, tid, nt, lds.data(), mul);
+            for (int ph = p.nstage - 2; ph >= 1; --ph)
+                for (int tid = 0; tid < nt; ++tid) mix_run_mid_t<T, COL, 20>(p, sh, ph, tid, nt, lds.data(), tw.data());
+            for (int tid = 0; tid < nt; ++tid) mix_run_first_t<T, COL, 20>(p, sh, tid, nt, lds.data(), tw.data(), store);
+        };
+        if (col) run(std::true_type{}); else run(std::false_type{});
+    }
+    double err = 0, ref = 0;
+    for (int s = 0; s < nseq; ++s) {
+        std::vector<cld> X(n), Y(n);
+        for (int k = 0; k < n; ++k) {
+            cld acc = 0;
+            for (int i = 0; i < n; ++i) {
+                const cx<T> v = col ? x[size_t(i) * nseq + s] : x[size_t(s) * n + i];
+                const ld a = -2 * pi * ld((int64_t(i) * k) % n) / n;
+                acc += cld(v.x, v.y) * cld(cosl(a), sinl(a));
+            }
+            const cx<T> hh = col ? h[size_t(k) * nseq + s] : h[size_t(s) * n + k];
+            X[k] = acc * cld(hh.x, hh.y);
+        }
+        for (int i = 0; i < n; i += (n > 300 ? 29 : 1)) {
+            cld acc = 0;
+            for (int k = 0; k < n; ++k) { const ld a = 2 * pi * ld((int64_t(i) * k) % n) / n; acc += X[k] * cld(cosl(a), sinl(a)); }
+            const cx<T> v = col ? y[size_t(i) * nseq + s] : y[size_t(s) * n + i];
+            err = std::max(err, double(std::abs(acc - cld(v.x, v.y))));
+            ref = std::max(ref, double(std::abs(acc)));
+        }
+    }
+    return err / ref;
+}
+
 int main() {
     int bad = 0;
+    for (int n : {36, 60, 100, 125, 180, 243, 360, 1000, 1001, 1536, 2310, 3000}) {
+        const double m1 = run_mid_case<double>(n, 5, true, 4, 96), m2 = run_mid_case<double>(n, 3, false, 2, 64), m3 = run_mid_case<float>(n, 6, true, 2, 128);
+        printf("middle pass n=%5d  cols f64 %.2e  rows f64 %.2e  cols f32 %.2e\n", n, m1, m2, m3);
+        if (!(m1 < 1e-12) || !(m2 < 1e-12) || !(m3 < 2e-5)) { ++bad; printf("   ^^^ FAIL\n"); }
+    }
     const int lens[] = {36, 40, 42, 44, 48, 50, 52, 54, 56, 60, 64, 45, 49, 60, 77, 90, 96, 100, 120, 121, 125, 143, 144, 169, 180, 243, 250, 256, 343, 360, 500, 625, 729, 1000,
                         1001, 1331, 1500, 2187, 2310, 2592, 3000, 3125, 4000, 4004, 4096, 5000, 6000, 6561, 7000, 8000, 324, 400, 441, 484, 576, 625, 676, 729, 784, 900, 1024, 660, 780, 810, 840, 960};
     for (int n : lens) {
