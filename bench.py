@@ -214,7 +214,8 @@ def other_configs(only=''):
         from prysm_amd.graph import StreamRing
         ring, x2b, keep = StreamRing(2), x2.clone(), [None, None]
 
-        def sequence(k=100):       # 2 k propagations, free-running on the two streams, joined once at the end
+        def sequence(k=100):       # 2 k propagations, free-running on the two streams, forked / joined once
+            ring.fork()
             for _ in range(k):
                 keep[0] = None
                 keep[0] = ring.run(P.focus, x2, 1)

@@ -68,7 +68,8 @@ enum {
                              * synthesised while the row pass loads it -- Wavefront.from_amp_and_phase
                              * (prysm/propagation/wavefront.py:58-79) fused into focus: the complex pupil never exists in
                              * memory.  `in` is float for PM_C64, double for PM_C128 (fp64 sincospi per sample: 4096^2 329 -> 255 us
-                             * against synthesis + transform); power-of-two row lengths only (PM_ERR_UNSUPPORTED otherwise). */
+                             * against synthesis + transform).  Row lengths: powers of two (the engine's row loader) and composites of primes
+                             * <= 13 up to 8192 (the mixed-radix row kernel's first stage, round 4); PM_ERR_UNSUPPORTED otherwise. */
     PM_FLAG_SYNTH_PACKED = 32, /* with PM_FLAG_SYNTH_INPUT: `in` holds (amplitude, OPD) float / double PAIRS (in_ld in pairs), synth_amp is ignored.
                              * One 8-byte load per element instead of two 4-byte loads from two arrays: a loop over wavelengths packs
                              * its two maps once (the polychromatic recipe: 133 -> 101 us per wavelength at 4096^2) */

@@ -64,10 +64,23 @@ def _fill_mul(d, x, mul, mul_x, mul_conj, keep):
     d.mul_conj = 1 if mul_conj else 0
 
 
+def _is_mix_length(n):
+    """lengths the mixed-radix kernel takes (csrc/fft_mixed.h): 32 .. 8192, not a power of two, primes <= 13"""
+    if n < 32 or n > 8192 or (n & (n - 1)) == 0:
+        return False
+    for p in (2, 3, 5, 7, 11, 13):
+        while n % p == 0:
+            n //= p
+    return n == 1
+
+
 def synth_supported(opd, amp, N):
     """Whether pm_fft2 can synthesise amp * exp(i k opd) while loading (PM_FLAG_SYNTH_INPUT): a 2-D float32 / float64 OPD map
-    (complex64 / complex128 transform), power-of-two row length, real / bool amplitude."""
-    if opd.dim() != 2 or opd.dtype not in (torch.float32, torch.float64) or not _is_pow2_engine(N):
+    (complex64 / complex128 transform), a row length that is a power of two or (round 4) a composite of primes <= 13 -- the two row
+    kernels whose loaders synthesise --, real / bool amplitude."""
+    if opd.dim() != 2 or opd.dtype not in (torch.float32, torch.float64) or not (_is_pow2_engine(N) or _is_mix_length(N)):
+        return False
+    if not _is_pow2_engine(N) and opd.stride(0) >= 1 << 24:
         return False
     return amp is None or (amp.dtype in _AMP_CODE and amp.dim() == 2 and amp.shape == opd.shape and amp.stride(-1) == 1)
 
@@ -529,13 +542,33 @@ def quadratic_phase(x, y, c, cdtype):
     return out
 
 
-def as_tf_vectors(shape, wvl, dx, z, cdtype):
+# (shape, wavelength, dx, z, dtype, device, stream) -> (hy, hx): a model that steps the same distance again and again (a time series,
+# the planes of a relay, an optimiser's forward passes) re-uses the two vectors instead of re-synthesising them (one launch of 5 us
+# against a 320 us step at 4096^2 complex128 -- and nothing at all to wait for at small sizes, where the launch is the cost).  The key
+# is scalars only, so nothing can go stale; the values are READ-ONLY by contract (angular_spectrum never hands them out).  Keyed on
+# the stream because the vectors are produced on it: another stream would have to wait for that work.
+_AS_TF_CACHE = {}
+_AS_TF_CACHE_MAX = 16
+
+
+def as_tf_vectors(shape, wvl, dx, z, cdtype, cache=True):
     lib = L.load()
     rows, cols = shape
+    key = (int(rows), int(cols), float(wvl), float(dx), float(z), cdtype, L._cur_dev(), L._cur_stream())
+    if cache and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        cache = False       # tensors made during a graph capture live in the graph's pool: never handed to eager code
+    if cache:
+        hit = _AS_TF_CACHE.get(key)
+        if hit is not None:
+            return hit
     hy = torch.empty(rows, dtype=cdtype, device=L.device())
     hx = torch.empty(cols, dtype=cdtype, device=L.device())
     L.check(lib.pm_as_tf_vectors(L._COMPLEX_CODE[cdtype], rows, cols, float(wvl), float(dx), float(z), L.ptr(hy),
                                  L.ptr(hx), L.stream_ptr()))
+    if cache:
+        if len(_AS_TF_CACHE) >= _AS_TF_CACHE_MAX:
+            _AS_TF_CACHE.pop(next(iter(_AS_TF_CACHE)))
+        _AS_TF_CACHE[key] = (hy, hx)
     return hy, hx
 
 

@@ -550,6 +550,20 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         } else {
             DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), d->in_ld, 1, to_map(d->in_x), rows, conj,
                            (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
+            if (d->flags & PM_FLAG_SYNTH_INPUT) {     // the mixed-radix row kernel synthesises the pupil in its first stage's loads
+                if (!p.mix_n)
+                    return fail(PM_ERR_UNSUPPORTED, "pm_fft2: PM_FLAG_SYNTH_INPUT: rows of %lld samples do not run on a kernel that synthesises the "
+                                "pupil while loading (synthesise it with pm_pupil_synth first)", (long long)N);
+                di.synth = (d->flags & PM_FLAG_SYNTH_PACKED) ? 3 : 2;
+                di.real = 0;
+                di.conj = 0;
+                di.amp = d->synth_amp;
+                di.amp_kind = !d->synth_amp ? 0 : (d->synth_amp_dtype == PM_F32 ? 1 : (d->synth_amp_dtype == PM_F64 ? 2 : 3));
+                di.amp_ld = d->synth_amp_ld;
+                di.k2 = d->synth_k / (2.0 * 3.14159265358979323846264338327950288);
+                if (di.amp && !mix_fits(N, di.amp_ld, sizeof(cx<T>), false))
+                    return fail(PM_ERR_UNSUPPORTED, "pm_fft2: PM_FLAG_SYNTH_INPUT: amplitude pitch beyond 2^24 elements");
+            }
             int rc;
             if (p.mix_n) {
                 rc = mix_rows<T>(di, W, p.w_ld, st);
@@ -1074,8 +1088,9 @@ static int check_fft2(const pm_fft2_desc* d) {
         return fail(PM_ERR_ARG, "pm_fft2: PM_FLAG_SYNTH_PACKED qualifies PM_FLAG_SYNTH_INPUT");
     if (d->flags & PM_FLAG_SYNTH_INPUT) {
         if (d->direction != -1) return fail(PM_ERR_ARG, "pm_fft2: PM_FLAG_SYNTH_INPUT is a forward transform");
-        if (engine_log2(d->in_x.n) < 0 || d->batch > 1)
-            return fail(PM_ERR_UNSUPPORTED, "pm_fft2: PM_FLAG_SYNTH_INPUT needs a power-of-two row length and no batch");
+        if ((engine_log2(d->in_x.n) < 0 && !use_mix(d->in_x.n)) || d->batch > 1)
+            return fail(PM_ERR_UNSUPPORTED, "pm_fft2: PM_FLAG_SYNTH_INPUT needs a row length that is a power of two or a composite with primes "
+                        "<= 13 (the kernels whose loaders synthesise the pupil), and no batch");
         if (d->synth_amp && d->synth_amp_dtype != PM_F32 && d->synth_amp_dtype != PM_F64 && d->synth_amp_dtype != PM_BOOL)
             return fail(PM_ERR_ARG, "pm_fft2: synth_amp_dtype");
         if (d->synth_amp && d->synth_amp_ld < d->in_x.len) return fail(PM_ERR_ARG, "pm_fft2: synth_amp_ld < row length");

@@ -615,4 +615,35 @@ struct MixFetch {
     }
 };
 
+// ... and the pupil synthesised while loading (rows only): amp exp(2 pi i k2 opd) from packed (amplitude, OPD) pairs or from the OPD map
+// and a separate amplitude array (Wavefront.from_amp_and_phase, prysm/propagation/wavefront.py:58-79) -- the complex pupil of a composite
+// grid is never written to memory either
+template <typename T, bool PACKED>
+struct MixFetchSynth {
+    const void* base;       // packed pairs (cx<T>) or the OPD map (T), at the workgroup's first row
+    uint32_t pitch;
+    AxisMap ax;
+    int nvalid;
+    double k2;
+    const void* amp;        // !PACKED: amplitude array at the workgroup's first row (or null: unit amplitude)
+    int amp_kind;
+    uint32_t amp_pitch;
+    PM_HD cx<T> operator()(int sl, int i) const {
+        int q = ax.map(i);
+        const bool ok = sl < nvalid && q >= 0;
+        q = ok ? q : 0;
+        sl = ok ? sl : 0;
+        const uint32_t off = mix_mul24(uint32_t(sl), pitch) + uint32_t(q);
+        cx<T> x;
+        if (PACKED) {
+            const cx<T> ao = mix_ld(reinterpret_cast<const cx<T>*>(base) + off);
+            x = synth_value<T>(ao.y, ao.x, k2);
+        } else {
+            const T a = synth_amp<T>(amp, amp_kind, int64_t(mix_mul24(uint32_t(sl), amp_pitch) + uint32_t(q)));
+            x = synth_value<T>(reinterpret_cast<const T*>(base)[off], a, k2);
+        }
+        return ok ? x : cx<T>{T(0), T(0)};
+    }
+};
+
 }  // namespace pm

@@ -42,7 +42,9 @@ __device__ __forceinline__ void mix_store_col(const ColStoreNat<T>& p, int k, in
     }
 }
 
-template <typename T, int MAXR>
+// SYNTH: the instantiation whose first stage synthesises the pupil (in.synth); kept apart because the fp64 sincospi of the complex128 form
+// costs 40 registers that the plain kernel of the class of 10 does not have to pay (94 -> 134 VGPRs, five waves per SIMD -> three)
+template <typename T, int MAXR, bool SYNTH = false>
 __global__ __launch_bounds__(512) void mix_rows_kernel(const MixPlan* __restrict__ pp, MixShape sh, DirectIn<T> in, MixRowOut<T> out,
                                                        const cx<T>* __restrict__ tw) {
     const MixPlan& p = *pp;
@@ -52,7 +54,16 @@ __global__ __launch_bounds__(512) void mix_rows_kernel(const MixPlan* __restrict
     const int nvalid = in.nseq - seq0 < sh.seqs ? in.nseq - seq0 : sh.seqs;
     const T ysign = in.conj ? T(-1) : T(1);
     const bool whole = in.ax.off == 0 && in.ax.len == in.ax.n && nvalid == sh.seqs;
-    if (in.real) {
+    if (SYNTH && in.synth == 3) {
+        const MixFetchSynth<T, true> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, nvalid, in.k2, nullptr, 0, 0u};
+        mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+    } else if (SYNTH && in.synth == 2) {
+        const char* a0 = reinterpret_cast<const char*>(in.amp);
+        if (a0) a0 += int64_t(seq0) * in.amp_ld * (in.amp_kind == 1 ? 4 : (in.amp_kind == 2 ? 8 : 1));
+        const MixFetchSynth<T, false> fetch{reinterpret_cast<const T*>(in.src) + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, nvalid, in.k2,
+                                            a0, a0 ? in.amp_kind : 0, uint32_t(in.amp_ld)};
+        mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+    } else if (in.real) {
         const MixFetch<T, false, true> fetch{reinterpret_cast<const T*>(in.src) + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, ysign, nvalid};
         mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     } else if (whole) {
@@ -245,6 +256,12 @@ int mix_cols_launch(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const 
 template <typename T, int MAXR>
 int mix_rows_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const MixRowOut<T>& ro, const cx<T>* tw, int groups, int nt, size_t lds,
                          hipStream_t st) {
+    if (in.synth) {
+        const int rc = mix_set_lds(mix_rows_kernel<T, MAXR, true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((mix_rows_kernel<T, MAXR, true>), dim3(groups), dim3(nt), lds, st, p, sh, in, ro, tw);
+        return int(hipGetLastError());
+    }
     const int rc = mix_set_lds(mix_rows_kernel<T, MAXR>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL((mix_rows_kernel<T, MAXR>), dim3(groups), dim3(nt), lds, st, p, sh, in, ro, tw);
@@ -335,10 +352,15 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     while ((size_t(tc) << log_g) * sizeof(cx<T>) < 128 && log_g < 3) ++log_g;
     if (tuning().mix_log_g >= 0) log_g = tuning().mix_log_g > 4 ? 4 : tuning().mix_log_g;
     const int tiles = (ncols + tc - 1) / tc, round = 8 << log_g;
-    // threads: up to 512; the knob mix_ntc may ask for up to 1024 where that kernel exists
+    // threads: one butterfly per thread of the busiest stage up to 512 -- and 1024 where the tile takes more than half the LDS (ONE
+    // workgroup per CU: its waves are all the latency hiding there is) and the kernel class has the 1024-thread form.  Measured
+    // (profiles/r04/exp_mix_ntc.log, 2-D transform us at 512 / 1024 threads): complex64 3000^2 95.1 / 84.8, 4000^2 162.4 / 158.2,
+    // complex128 3000^2 189.4 / 180.4, 2000^2 66.1 / 62.6; with two workgroups per CU it loses (complex64 2000^2 40.0 / 44.5, 1536^2 34.5 / 37.7)
     const int cls = mix_class_of(p.maxr);
-    const int cap = (tuning().mix_ntc > 512 && mix_cols_wide<T>(cls)) ? 1024 : 512;
-    const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc, cap, tuning().mix_ntc);
+    const bool one_wg = lds > size_t(80) * 1024 && mix_cols_wide<T>(cls);
+    const int forced = tuning().mix_ntc > 0 ? tuning().mix_ntc : (one_wg ? 1024 : 0);
+    const int cap = (forced > 512 && mix_cols_wide<T>(cls)) ? 1024 : 512;
+    const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc, cap, forced);
     if (p.maxr <= 10) return mix_cols_launch<T, 10>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
     if (p.maxr <= 16) return mix_cols_launch<T, 16>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
     return mix_cols_launch<T, 20>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
@@ -393,8 +415,10 @@ int mix_cols_mul_impl(const DirectIn<T>& in, const MidMul<T>& m, cx<T>* dst, int
     if (tuning().mix_log_g >= 0) log_g = tuning().mix_log_g > 4 ? 4 : tuning().mix_log_g;
     const int tiles = (ncols + tc - 1) / tc, round = 8 << log_g;
     const int cls = mix_class_of(p.maxr);
-    const int cap = (tuning().mix_ntc > 512 && mix_cols_wide<T>(cls)) ? 1024 : 512;
-    const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc, cap, tuning().mix_ntc);
+    const bool one_wg = lds > size_t(80) * 1024 && mix_cols_wide<T>(cls);      // as mix_cols_impl
+    const int forced = tuning().mix_ntc > 0 ? tuning().mix_ntc : (one_wg ? 1024 : 0);
+    const int cap = (forced > 512 && mix_cols_wide<T>(cls)) ? 1024 : 512;
+    const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc, cap, forced);
     const MixMul<T> mm{m.kind, m.conj, m.mul, m.mul_x, m.ld, ncols};
     if (p.maxr <= 10) return mix_cols_mul_launch_impl<T, 10>(pd, sh, in, mm, dst, uint32_t(dst_pitch), tw, log_g, groups, nt, lds, st);
     if (p.maxr <= 16) return mix_cols_mul_launch_impl<T, 16>(pd, sh, in, mm, dst, uint32_t(dst_pitch), tw, log_g, groups, nt, lds, st);

@@ -28,6 +28,14 @@ struct DirectIn {
     int nseq;
     int conj;
     int real;   // src is a REAL array (T): strides count real elements
+    // PUPIL SYNTHESIS on the fly (mixed-radix rows only, round 4): the element is amp exp(2 pi i k2 opd), as in the engine's row loader
+    // (fft_io.h RowLoadNat).  synth 3: src holds packed (amplitude, OPD) pairs; 2: src is the real OPD map (strides in real elements)
+    // and the amplitude comes from `amp` (amp_kind 0 unit, 1 float, 2 double, 3 bool / uint8; amp_ld elements between its rows)
+    int synth;
+    const void* amp;
+    int amp_kind;
+    int64_t amp_ld;
+    double k2;
 };
 // rows: out[seq*ld + k] (natural complex intermediate, k in [0,n))
 template <typename T>

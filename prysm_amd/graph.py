@@ -64,8 +64,12 @@ class StreamRing:
     streams evict each other's intermediates (95 -> 133 us) -- `worth_it(shape, dtype)` says which side of that a shape is on.
 
         ring = StreamRing(2)
-        outs = [ring.run(P.focus, x, 1) for x in fields]     # each call on the next stream, after the work already queued for x
+        ring.fork()                                           # every stream of the ring waits for what the caller's stream has queued
+        outs = [ring.run(P.focus, x, 1) for x in fields]     # each call on the next stream
         ring.join()                                           # the caller's stream now waits for every stream of the ring
+
+    fork / join are the only synchronisation (one event each way per stream): a wait per call would cost more host time than a 2048^2
+    propagation takes on the device.  Inputs must come from before the fork (or from the same stream of the ring).
 
     Workspaces are per stream (_lib.workspace), outputs come from torch's stream-aware allocator; results are the same bits.
     """
@@ -81,16 +85,16 @@ class StreamRing:
         m, n = shape[-2:]
         return 3 * m * n * torch.empty((), dtype=dtype).element_size() * streams <= 200 << 20
 
+    def fork(self):
+        cur = torch.cuda.current_stream()
+        for s in self.streams:
+            s.wait_stream(cur)
+
     def run(self, fn, *args, **kwargs):
         s = self.streams[self._next]
         self._next = (self._next + 1) % len(self.streams)
-        s.wait_stream(torch.cuda.current_stream())      # inputs produced on the caller's stream
         with torch.cuda.stream(s):
-            out = fn(*args, **kwargs)
-        for t in args:
-            if isinstance(t, torch.Tensor) and t.is_cuda:
-                t.record_stream(s)
-        return out
+            return fn(*args, **kwargs)
 
     def join(self):
         cur = torch.cuda.current_stream()

@@ -28,7 +28,7 @@ def angular_spectrum_transfer_function(samples, wvl, dx, z):
     """
     if isinstance(samples, int):
         samples = (samples, samples)
-    hy, hx = _ops.as_tf_vectors(tuple(samples), wvl, dx, z, _cdtype())
+    hy, hx = _ops.as_tf_vectors(tuple(samples), wvl, dx, z, _cdtype(), cache=False)
     return _ops.outer(hy, hx)
 
 

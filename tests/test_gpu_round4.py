@@ -285,3 +285,33 @@ def test_conv_on_composite_grids(pa, shape):
     assert rel_max(tonp(C.apply_transfer_functions(o, 1.0, [tf])), O.apply_transfer_functions(o, 1.0, [tf])) < 1e-9
     assert rel_max(tonp(C.apply_transfer_functions(o.astype(np.complex64), 1.0, [tf.astype(np.complex64)], shift=True)),
                    O.apply_transfer_functions(o, 1.0, [tf], shift=True)) < 2e-5
+
+
+# ----------------------------------------------------------------------------- pupil synthesis inside the mixed-radix row kernel
+
+@pytest.mark.parametrize('shape,Q', [((600, 750), 1), ((500, 500), 1.5), ((1000, 1536), 1), ((300, 400), 2)])
+def test_pupil_synthesis_in_the_load_on_composite_grids(pa, shape, Q):
+    """Wavefront.from_amp_and_phase(...).focus() / .focus_intensity() and the polychromatic driver on grids whose (padded) row length is a
+    composite of primes <= 13: the pupil is synthesised by the first stage of the mixed-radix row kernel (the lazy wavefront never
+    materialises it), float32 and float64 maps, float / bool / no amplitude, packed maps through the wavelength loop -- vs the oracle"""
+    from prysm_amd.polychromatic import polychromatic_psf
+    rng = np.random.default_rng(int(shape[0] * Q))
+    ampf = (rng.random(shape) * (rng.random(shape) > 0.2)).astype(np.float32)
+    ampb = rng.random(shape) > 0.3
+    for rd, tol in ((np.float32, 1e-5), (np.float64, TOL64)):
+        opd = (150 * rng.standard_normal(shape)).astype(rd)
+        for amp in (ampf.astype(rd), ampb, None):
+            a64 = np.ones(shape) if amp is None else amp.astype(np.float64)
+            pref = O.focus(O.from_amp_and_phase(a64, opd.astype(np.float64), O.HeNe), Q)
+            wf = pa.propagation.Wavefront.from_amp_and_phase(amp if amp is not None else np.ones(shape, dtype=rd), opd, O.HeNe, 0.04)
+            assert wf._fusable(Q) is not None
+            got = tonp(wf.focus(100.0, Q=Q).data)
+            assert wf._data is None                    # never materialised
+            assert rel_max(got, pref) < tol, (rd, None if amp is None else amp.dtype)
+            I = tonp(wf.focus_intensity(100.0, Q=Q).data)
+            assert rel_max(I, O.intensity(pref)) < 2 * tol
+    opd = (150 * rng.standard_normal(shape)).astype(np.float32)
+    wv, wt = np.linspace(0.5, 0.7, 5), np.linspace(1.0, 2.0, 5)
+    poly = tonp(polychromatic_psf(ampf, opd, wv, wt, 0.04, 100.0, Q=Q))
+    pw = sum(w * O.intensity(O.focus(O.from_amp_and_phase(ampf.astype(np.float64), opd.astype(np.float64), float(l)), Q)) for l, w in zip(wv, wt))
+    assert poly.dtype == np.float32 and rel_max(poly, pw) < 2e-5
