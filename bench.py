@@ -251,6 +251,12 @@ def other_configs(only=''):
                                   'composite length on its own factors (LDS-resident mixed radix, one kernel per axis); round 2 convolved these at '
                                   'the next power of two above 2 N (Bluestein)')
             del xc
+        # 6006 = 6 x 7 x 11 x 13 (the mixed-radix kernel as it is) and 10000 = 2 x 5000 (round 4: one radix-2 step around
+        # mixed-radix sub-transforms; rounds 1 - 3 convolved it at 32768 points per axis)
+        for n, key in ((6006, 'focus_6006_c64_mixed_radix'), (10000, 'focus_10000_c64_radix2_x_mixed_radix')):
+            xc = torch.from_numpy(make_field(n, np.complex64, n)).cuda()
+            out[key] = _hbm_entry(_event_ms(lambda: P.focus(xc, 1), 10, warm=2), 4 * n ** 2 * xc.element_size())
+            del xc
         # the free-space step on a composite grid (prysm/propagation/angular_spectrum.py:9-42 takes any size): three passes with the
         # mixed-radix middle pass (round 4), graded like config 3 on 8 N^2 s; `composed_ms`: two pm_fft2 calls (rounds 1 - 3)
         from prysm_amd import _lib as L_

@@ -368,10 +368,17 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
     p.chunk = batch_chunk(p.nbatch, p.ws_field);
     if (p.nbatch > 1) p.ws_bytes = p.ws_field * size_t(p.chunk);
     // powers of two above the engine's longest transform: both axes powers of two, at least one split (big2d_run)
-    p.big_rn = big_split(N);
-    p.big_rm = big_split(M);
-    if (p.big_rn > 1 && !p.big_rm) p.big_rm = big_split(M, false);     // a composite length beside one that needs the split: both take it
-    if (p.big_rm > 1 && !p.big_rn) p.big_rn = big_split(N, false);
+    p.big_rn = big_split2d(N);
+    p.big_rm = big_split2d(M);
+    if (p.big_rn > 1 && !p.big_rm) p.big_rm = big_split2d(M, false);     // a composite length beside one that needs the split: both take it
+    if (p.big_rm > 1 && !p.big_rn) p.big_rn = big_split2d(N, false);
+    if (p.big_rn && p.big_rm) {     // sub-transforms on the mixed-radix kernel address with 32-bit offsets
+        const int64_t np_ = N / p.big_rn, mp_ = M / p.big_rm;
+        const bool mixn = engine_log2(np_) < 0, mixm = engine_log2(mp_) < 0;
+        if ((mixn && !(mix_fits(np_, np_, es, false) && (p.big_rn > 1 || mix_fits(np_, d->in_ld, es, false)))) ||
+            (mixm && !mix_fits(mp_, int64_t(p.big_rm) * np_, es, true)))
+            p.big_rn = p.big_rm = 0;
+    }
     if (!(p.big_rn && p.big_rm && (p.big_rn > 1 || p.big_rm > 1)) || (d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY | PM_FLAG_SYNTH_INPUT)))
         p.big_rn = p.big_rm = 0;
     p.mix_n = p.mix_m = false;
@@ -980,16 +987,17 @@ static int big2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, v
     const int64_t M = d->in_y.n, N = d->in_x.n;
     const int Rn = p.big_rn, Rm = p.big_rm;
     const int np = int(N / Rn), mp = int(M / Rm);
-    const int lgn = engine_log2(np), lgm = engine_log2(mp);
-    if (lgn < 0 || lgm < 0) return fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: big split %d x %d of %lld x %lld", Rm, Rn, (long long)M, (long long)N);
+    const int lgn = engine_log2(np), lgm = engine_log2(mp);      // < 0: that sub-transform runs on the mixed-radix kernel (big_split2d)
+    if ((lgn < 0 && !use_mix(np)) || (lgm < 0 && !use_mix(mp)))
+        return fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: big split %d x %d of %lld x %lld", Rm, Rn, (long long)M, (long long)N);
     const int dt = d->dtype;
     const int conj = d->direction > 0 ? 1 : 0;
     int err = 0;
     const size_t arr = (size_t(M) * size_t(N) * sizeof(cx<T>) + 255) & ~size_t(255);
     cx<T>* Z = reinterpret_cast<cx<T>*>(ws);
     cx<T>* F = reinterpret_cast<cx<T>*>(static_cast<char*>(ws) + arr);
-    const cx<T>* twn = twiddles<T>(np, &err);
-    if (!twn) return err;
+    const cx<T>* twn = lgn >= 0 ? twiddles<T>(np, &err) : nullptr;
+    if (lgn >= 0 && !twn) return err;
     const cx<T>* twm = twiddles<T>(mp, &err);
     if (!twm) return err;
     int rc;
@@ -1001,9 +1009,32 @@ static int big2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, v
         cx<T>* Y = F;   // dead before the column stage writes F
         if ((rc = big_pre_rows<T>(bi, int(M), np, Rn, Y, twN, st))) return rc;
         const int nseq = Rn * int(M);
-        RowLoadNat<T> lp{Y, np, AxisMap{np, np, 0, 0}, nseq, 0, 0};
-        RowStoreNat<T> sp{Z, np, AxisMap{np, np, 0, 0}, nseq, 0, T(1), 0, AxisMap{1, 1, 0, 0}};
-        if ((rc = launch_row_nat<T>(lgn, row_variant(dt, lgn), lp, sp, twn, nseq, 0, st))) return rc;
+        if (lgn < 0) {
+            DirectIn<T> ri{Y, np, 1, AxisMap{np, np, 0, 0}, nseq, 0, 0};
+            if ((rc = mix_rows<T>(ri, Z, np, st))) return rc;
+        } else {
+            RowLoadNat<T> lp{Y, np, AxisMap{np, np, 0, 0}, nseq, 0, 0};
+            RowStoreNat<T> sp{Z, np, AxisMap{np, np, 0, 0}, nseq, 0, T(1), 0, AxisMap{1, 1, 0, 0}};
+            if ((rc = launch_row_nat<T>(lgn, row_variant(dt, lgn), lp, sp, twn, nseq, 0, st))) return rc;
+        }
+    } else if (lgn < 0) {
+        // a composite row length as it is (beside a column length that needs the step): the mixed-radix row kernel writes sequence s to
+        // memory row s, so the stored rows go out as the (at most two) runs of consecutive LOGICAL rows they are
+        const int rows = int(d->in_y.len);
+        if (rows < M) {
+            hipError_t e = hipMemsetAsync(Z, 0, size_t(M) * size_t(N) * sizeof(cx<T>), st);
+            if (e != hipSuccess) return int(e);
+        }
+        const int64_t c = ((d->in_y.off - d->in_y.shift) % M + M) % M;      // stored row q is logical row (q + c) mod M
+        const int64_t n1 = rows < M - c ? rows : M - c;
+        const int64_t runs[2][3] = {{0, c, n1}, {n1, 0, rows - n1}};       // first stored row, first logical row, count
+        const size_t ies = (d->flags & PM_FLAG_REAL_INPUT) ? sizeof(T) : sizeof(cx<T>);
+        for (const auto& r : runs) {
+            if (r[2] <= 0) continue;
+            DirectIn<T> ri{reinterpret_cast<const cx<T>*>(static_cast<const char*>(in) + size_t(r[0]) * size_t(d->in_ld) * ies), d->in_ld, 1, to_map(d->in_x),
+                           int(r[2]), conj, (d->flags & PM_FLAG_REAL_INPUT) ? 1 : 0};
+            if ((rc = mix_rows<T>(ri, Z + r[1] * N, N, st))) return rc;
+        }
     } else {
         const int rows = int(d->in_y.len);
         if (rows < M) {
@@ -1025,6 +1056,23 @@ static int big2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, v
     const int vec = (sizeof(T) != 4 || np % 2 == 0) ? 1 : 0;
     const int64_t plane = int64_t(mp) * np;
     for (int m = 0; m < Rn; ++m) {
+        if (lgm < 0) {      // the sub-lattices r, r + R_m, ... one launch each on the mixed-radix column kernel
+            for (int r = 0; r < Rm; ++r) {
+                DirectIn<T> ci{Z + int64_t(m) * M * np + int64_t(r) * np, 1, int64_t(Rm) * np, AxisMap{mp, mp, 0, 0}, np, 0, 0};
+                ColStoreNat<T> cs{};
+                cs.dst = F + (int64_t(m) * Rm + r) * plane;
+                cs.ld = np;
+                cs.ay = AxisMap{mp, mp, 0, 0};
+                cs.ax = AxisMap{np, np, 0, 0};
+                cs.epilogue = EPI_NONE;
+                cs.scale = T(1);
+                cs.weight = T(1);
+                cs.mul_kind = MUL_NONE;
+                cs.vec_ok = vec;
+                if ((rc = mix_cols<T>(ci, cs, st))) return rc;
+            }
+            continue;
+        }
         ColLoadNat<T> cl{Z + int64_t(m) * M * np, int64_t(Rm) * np, AxisMap{mp, mp, 0, 0}, np, 0, vec, int64_t(np)};
         ColStoreNat<T> cs{};
         cs.dst = F + int64_t(m) * Rm * plane;
@@ -1567,6 +1615,13 @@ int pm_plan_prepare(int32_t dtype, int64_t n) {
                                         : (twiddles<double>(n, &err) && twiddles<double>(part, &err));
         if (!ok) return err;
         if (engine_log2(n) >= 0 || !use_blue_long(n)) return 0;     // a mixed-radix length beside an awkward one still takes Bluestein
+    }
+    if (big_split(n) == 0 && big_split2d(n) > 1) {     // a composite above 8192 (2-D transforms): the tables of n and of its mixed-radix cofactor
+        const int64_t part = n / big_split2d(n);
+        const bool ok = dtype == PM_C64 ? (twiddles<float>(n, &err) && twiddles<float>(part, &err)) : (twiddles<double>(n, &err) && twiddles<double>(part, &err));
+        if (!ok) return err;
+        if (engine_log2(part) < 0 && !mix_plan_dev(int(part), dtype == PM_C64 ? 8 : 16, &err)) return err;
+        return 0;
     }
     if (use_mix(n)) {
         if (!mix_plan_dev(int(n), dtype == PM_C64 ? 8 : 16, &err)) return err;

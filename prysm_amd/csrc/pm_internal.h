@@ -213,6 +213,24 @@ inline int big_split(int64_t n, bool mix_owns = true) {
     return 0;
 }
 
+// ... and for the 2-D transform (capi.hip big2d_run) the sub-transforms of length n / R may also run on the mixed-radix kernel (round 4):
+// composites ABOVE 8192 whose cofactor of 2, 3, 4, 5 or 7 is a length either kernel takes -- 10000 = 2 x 5000, 9000 = 2 x 4500,
+// 12000 = 2 x 6000, 20000 = 4 x 5000 -- which used to convolve at 32768 points per axis (Bluestein); and, beside an axis that needs the
+// step (`mix_owns` false), a composite length up to 8192 as it is (R = 1).  pm_fft1's big path keeps big_split (engine sub-transforms).
+inline int big_split2d(int64_t n, bool mix_owns = true) {
+    const int r = big_split(n, mix_owns);
+    if (r) return r;
+    if (!tuning().mix || !tuning().mixed_radix) return 0;
+    if (n <= (int64_t(1) << kEngineMaxLog)) return (!mix_owns && n >= tuning().mix_min && mix_length(n)) ? 1 : 0;
+    for (int R : {2, 3, 4, 5, 7}) {
+        if (n % R) continue;
+        const int64_t q = n / R;
+        if (q > (int64_t(1) << kEngineMaxLog)) continue;
+        if (engine_log2(q) >= 0 || (q >= tuning().mix_min && mix_length(q))) return R;
+    }
+    return 0;
+}
+
 // lengths the mixed-radix kernel takes: not a power of two (the engine's), not one of the radix-R lengths above when `big` says that
 // path owns them
 // ... its kernels address with 32-bit element offsets from a base that is uniform per workgroup and multiply indices by pitches with

@@ -315,3 +315,25 @@ def test_pupil_synthesis_in_the_load_on_composite_grids(pa, shape, Q):
     poly = tonp(polychromatic_psf(ampf, opd, wv, wt, 0.04, 100.0, Q=Q))
     pw = sum(w * O.intensity(O.focus(O.from_amp_and_phase(ampf.astype(np.float64), opd.astype(np.float64), float(l)), Q)) for l, w in zip(wv, wt))
     assert poly.dtype == np.float32 and rel_max(poly, pw) < 2e-5
+
+
+# ----------------------------------------------------------------------------- composites above 8192
+
+@pytest.mark.parametrize('shape', [(10000, 96), (96, 10000), (9000, 3000), (12000, 128), (64, 20000)])
+def test_composite_lengths_above_8192(pa, shape):
+    """lengths above 8192 whose cofactor of 2 .. 7 is a composite the mixed-radix kernel takes (10000 = 2 x 5000, 9000 = 2 x 4500,
+    12000 = 2 x 6000, 20000 = 4 x 5000) run as one radix-R step around mixed-radix sub-transforms instead of a Bluestein convolution at
+    32768 points -- beside short composite / power-of-two axes; fft2, ifft2 and the focus family (rotations, pad window) vs numpy"""
+    from prysm_amd import _ops
+    rng = np.random.default_rng(sum(shape))
+    for dtype, tol in ((np.complex64, TOL32), (np.complex128, TOL64)):
+        x = crandn(rng, shape, dtype)
+        xd = torch.from_numpy(x).cuda()
+        assert rel_max(_ops.fft2(xd, direction=-1, scale=1.0).cpu().numpy(), np.fft.fft2(x.astype(np.complex128))) < tol, dtype
+        M, N = shape
+        assert rel_max(_ops.fft2(xd, direction=+1, scale=1.0 / (M * N)).cpu().numpy(), np.fft.ifft2(x.astype(np.complex128))) < tol
+        assert rel_max(tonp(pa.propagation.focus(x, 1)), O.focus(x.astype(np.complex128), 1)) < tol
+    small = crandn(rng, (shape[0] // 2, shape[1] // 2), np.complex128)
+    assert rel_max(tonp(pa.propagation.focus(small, 2)), O.focus(small, 2)) < TOL64
+    xr = rng.standard_normal(shape)
+    assert rel_max(_ops.fft2(torch.from_numpy(xr).cuda(), direction=-1, scale=1.0).cpu().numpy(), np.fft.fft2(xr)) < TOL64
