@@ -162,6 +162,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("mix")) t.mix = v < 0 ? 0 : (v > 2 ? 2 : v);
     else if (is("mix_min")) t.mix_min = v < 18 ? 18 : v;
     else if (is("mix_fused")) t.mix_fused = v ? 1 : 0;
+    else if (is("two_units")) t.two_units = v & 3;
     else if (is("mix_maxr")) t.mix_maxr = (v < 2 || v > 20) ? 20 : v;
     else if (is("mix_log_g")) t.mix_log_g = v;
     else if (is("mix_seqs")) t.mix_seqs = v < 0 ? 0 : v;
@@ -207,6 +208,10 @@ static thread_local bool g_tune_local_on = false;
 static thread_local Tuning g_tune_local;
 
 Tuning& tuning() { return g_tune_local_on ? g_tune_local : tuning_global(); }
+
+#ifdef PM_EXPERIMENTS
+int pm_two_units() { return tuning().two_units; }
+#endif
 
 int pm_num_cus() {
     static int cus[64] = {0};
@@ -1576,7 +1581,7 @@ static bool experiment_only(const char* key, int v) {
 #else
     auto is = [&](const char* k) { return !strcmp(key, k); };
     return (is("spectral_mode") && (v & 3) != 3) || (is("gemm_3m") && !v) || (is("gemm_bm") && v == 128) || (is("gemm_bk") && v == 32) ||
-           (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 6)) || (is("spectral2") && v != 0);
+           (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 6)) || (is("spectral2") && v != 0) || (is("two_units") && v != 0);
 #endif
 }
 

@@ -62,6 +62,38 @@ __global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp, cons
     store<C>(spb, unit, pos, v);
 }
 
+#ifdef PM_EXPERIMENTS
+// TWO units per workgroup (half the grid), the second unit's loads issued before the first unit's transform and
+// stores.  Both passes of a 2048^2 transform are single-round launches (8 row workgroups per CU, one column tile per CU), so a plain
+// workgroup has nothing to overlap its own phases with; this form gives it a second unit.  Knob two_units (bit 0 rows, bit 1 columns);
+// measured in profiles/r04/exp_cfg2_two_units.log.
+template <typename C, bool COL, int VAR, typename L, typename S>
+__global__ void __launch_bounds__(C::NT) fft_kernel_2u(const L lp, const S sp, const cx<typename C::T>* __restrict__ tw, const int log_g) {
+    extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+    const ThreadPos pos = thread_pos<C>(threadIdx.x);
+    int u0 = group_remap(2 * blockIdx.x, 2 * gridDim.x, log_g), u1 = group_remap(2 * blockIdx.x + 1, 2 * gridDim.x, log_g);
+    if (COL) {
+        u0 = u0 * C::BO + pos.bo;
+        u1 = u1 * C::BO + pos.bo;
+    }
+    cx<typename C::T> v[C::E][C::P], vn[C::E][C::P];
+    const L lpb = at_batch(lp, blockIdx.y);
+    const S spb = at_batch(sp, blockIdx.y);
+    load<C>(lpb, u0, pos, v);
+    load<C>(lpb, u1, pos, vn);      // in flight under the first unit's transform and stores
+    if constexpr (VAR != 5 && C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
+    else fft_run<C>(v, pos, pm_smem, tw);
+    store<C>(spb, u0, pos, v);
+    __syncthreads();
+    ThreadPos p2 = pos;
+    asm volatile("" : "+v"(p2.t), "+v"(p2.cl), "+v"(p2.bo));
+    if constexpr (VAR != 5 && C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(vn, p2, pm_smem, tw);
+    else fft_run<C>(vn, p2, pm_smem, tw);
+    store<C>(spb, u1, pos, vn);
+}
+int pm_two_units();     // capi.hip: the knob
+#endif
+
 // Fused spectral-multiply column pass: forward transform, multiply by H, inverse transform -- all on the
 // registers of the workgroup (the engine returns natural order, so the inverse starts where the forward ended);
 // reads the tiled intermediate of the row pass and writes a tiled buffer for the inverse row pass.  This is the
@@ -490,6 +522,19 @@ int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, 
     const int per_wg = C::BO * (COL ? 1 : C::E);     // row mode: a thread owns E consecutive rows
     const int grid = (units + per_wg - 1) / per_wg;
     if (grid <= 0 || nbatch <= 0) return 0;
+#ifdef PM_EXPERIMENTS
+    if constexpr (LOGN == 11 && sizeof(T) == 4) {
+        if ((pm_two_units() & (COL ? 2 : 1)) && grid % 2 == 0) {
+            auto k2 = fft_kernel_2u<C, COL, VAR, L, S>;
+            if (LDSB > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
+                if (e != hipSuccess) return int(e);
+            }
+            hipLaunchKernelGGL(k2, dim3(grid / 2, nbatch), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
+            return int(hipGetLastError());
+        }
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
     return int(hipGetLastError());
 }
