@@ -162,6 +162,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("mix")) t.mix = v < 0 ? 0 : (v > 2 ? 2 : v);
     else if (is("mix_min")) t.mix_min = v < 18 ? 18 : v;
     else if (is("mix_fused")) t.mix_fused = v ? 1 : 0;
+    else if (is("mix_pad")) t.mix_pad = v ? 1 : 0;
     else if (is("two_units")) t.two_units = v & 3;
     else if (is("mix_maxr")) t.mix_maxr = (v < 2 || v > 20) ? 20 : v;
     else if (is("mix_log_g")) t.mix_log_g = v;

@@ -189,7 +189,15 @@ struct MixPlan {
 // VGPRs.  What varies per launch travels by value:
 struct MixShape {
     int seqs, log_seqs;             // sequences per workgroup (column mode: a power of two)
+    // LDS slots of a sequence (round 4): point p sits in slot p + pad1 (p / len[2]) + pad0 (p / len[1]) -- a few unused slots after
+    // every block of the first two levels.  Unpadded, the last stage reads at the digit-reversed strides len[1], len[2] (300 and 20
+    // elements at 3000 = 10 x 15 x 20: only 8 distinct bank pairs for 32 lanes, a 4-way conflict on every read) and the middle stages
+    // cross short blocks inside a lane group: SQ_LDS_BANK_CONFLICT was 32 % (columns) to 56 % (rows) of the LDS cycles
+    // (profiles/r03/exp_mix_pmc.txt).  s0 / s1: slot strides of the first two digits, npad: slots per sequence.  The host picks the
+    // pads per (plan, precision, mode, sequences per workgroup) with a model of the LDS banks (fft_mixed.hip mix_pick_pads).
+    int pad0, pad1, s0, s1, npad;
 };
+inline void mix_shape_pads(const MixPlan& p, MixShape& sh, int c0, int c1);
 
 // floor(a / d) for a d < 2^16 as (a * magic) >> 32, magic = floor(2^32 / d) + 1 (exact while a d < 2^32); d == 1: magic 0 = identity
 inline uint32_t mix_magic(int d) { return d <= 1 ? 0u : uint32_t((uint64_t(1) << 32) / uint64_t(d)) + 1u; }
@@ -268,6 +276,16 @@ inline bool mix_make_plan(int n, MixPlan& p) {
     return true;
 }
 
+inline void mix_shape_pads(const MixPlan& p, MixShape& sh, int c0, int c1) {
+    const int L1 = p.len[1], L2 = p.nstage >= 3 ? p.len[2] : 1;
+    if (p.nstage < 3) c1 = 0;
+    sh.pad0 = c0;
+    sh.pad1 = c1;
+    sh.s1 = L2 + c1;
+    sh.s0 = L1 + c1 * (L1 / L2) + c0;
+    sh.npad = p.radix[0] * sh.s0;
+}
+
 // ---------------------------------------------------------------------------
 // stages.  `tid` / `nt`: this thread and the threads of the workgroup; sl = sequence slot of the workgroup
 // ---------------------------------------------------------------------------
@@ -306,8 +324,21 @@ PM_HD void mix_st(cx<T>* p, cx<T> v) {
 // LDS slot of point i of sequence slot sl, and the slot distance of `d` points (rows: [sl][i]; columns: [i][sl]).  No padding: lanes run
 // along i (or along sl first) with unit stride in every stage but the last, whose reads follow the digit-reversed order
 template <bool COL>
-PM_HD int mix_addr(int n, MixShape sh, int sl, int i) {
-    return COL ? ((i << sh.log_seqs) + sl) : int(mix_mul24(uint32_t(sl), uint32_t(n)) + uint32_t(i));
+PM_HD int mix_addr(int, MixShape sh, int sl, int slot) {
+    return COL ? ((slot << sh.log_seqs) + sl) : int(mix_mul24(uint32_t(sl), uint32_t(sh.npad)) + uint32_t(slot));
+}
+// slot of point j < len[1] (first stage: the digit-0 term k s0 is added by the caller)
+PM_HD int mix_slot_low(const MixPlan& p, MixShape sh, int j) {
+    return sh.pad1 ? j + int(mix_mul24(uint32_t(sh.pad1), uint32_t(mix_div(j, p.mg_sub[1])))) : j;
+}
+// slot of the first point blk L + j (j < sub) of a butterfly of stage s >= 1, and the slot distance of its points
+PM_HD int mix_slot_mid(const MixPlan& p, MixShape sh, int s, int blk, int j, int L) {
+    if (s == 1) return int(mix_mul24(uint32_t(blk), uint32_t(sh.s0))) + j;        // blk is digit 0, the points are a digit-1 apart
+    const int b0 = int(mix_mul24(uint32_t(blk), uint32_t(L))) + j;                // all points inside one block of len[2]
+    int r = b0;
+    if (sh.pad1) r += int(mix_mul24(uint32_t(sh.pad1), uint32_t(mix_div(b0, p.mg_sub[1]))));
+    if (sh.pad0) r += int(mix_mul24(uint32_t(sh.pad0), uint32_t(mix_div(b0, p.mg_sub[0]))));
+    return r;
 }
 template <bool COL>
 PM_HD int mix_step(MixShape sh, int d) {
@@ -337,7 +368,7 @@ PM_HD void mix_first(const MixPlan& p, MixShape sh, int tid, int nt, cx<T>* lds,
 #pragma unroll
         for (int k = 0; k < R; ++k) a[k] = fetch(sl, j + k * nb);
         MixDft<T, R>::run(a);
-        const int a0 = mix_addr<COL>(n, sh, sl, j), as = mix_step<COL>(sh, nb);
+        const int a0 = mix_addr<COL>(n, sh, sl, mix_slot_low(p, sh, j)), as = mix_step<COL>(sh, sh.s0);
         mix_st(lds + a0, a[0]);
 #pragma unroll
         for (int k = 1; k < R; ++k) mix_st(lds + a0 + k * as, cmul(a[k], mix_ld(tw + uint32_t(j) * uint32_t(k))));
@@ -353,9 +384,8 @@ PM_HD void mix_mid(const MixPlan& p, MixShape sh, int s, int tid, int nt, cx<T>*
     for (int b = tid; b < total; b += nt) {
         int sl, ja;
         mix_split<COL>(sh, b, mg_nb, nb, sl, ja);
-        const int blk = mix_div(ja, mg_sub), j = ja - int(mix_mul24(uint32_t(blk), uint32_t(sub))),
-                  base = int(mix_mul24(uint32_t(blk), uint32_t(L))) + j;
-        const int a0 = mix_addr<COL>(n, sh, sl, base), as = mix_step<COL>(sh, sub);
+        const int blk = mix_div(ja, mg_sub), j = ja - int(mix_mul24(uint32_t(blk), uint32_t(sub)));
+        const int a0 = mix_addr<COL>(n, sh, sl, mix_slot_mid(p, sh, s, blk, j, L)), as = mix_step<COL>(sh, s == 1 ? sh.s1 : sub);
         cx<T> a[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) a[k] = mix_ld(lds + a0 + k * as);
@@ -378,7 +408,7 @@ PM_HD void mix_last(const MixPlan& p, MixShape sh, int tid, int nt, const cx<T>*
 #pragma unroll
     for (int i = 0; i < kMixMaxStages - 1; ++i) {
         rdx[i] = i < s ? p.radix[i] : 1;
-        wgt[i] = i < s ? p.len[i + 1] : 0;
+        wgt[i] = i < s ? (i == 0 ? sh.s0 : (i == 1 ? sh.s1 : p.len[i + 1])) : 0;      // slot strides of the digits (MixShape)
         mgr[i] = i < s ? p.mg_radix[i] : 0u;
     }
 #pragma unroll 1
@@ -421,9 +451,8 @@ PM_HD void mix_mid_t(const MixPlan& p, MixShape sh, int s, int tid, int nt, cx<T
     for (int b = tid; b < total; b += nt) {
         int sl, ja;
         mix_split<COL>(sh, b, mg_nb, nb, sl, ja);
-        const int blk = mix_div(ja, mg_sub), j = ja - int(mix_mul24(uint32_t(blk), uint32_t(sub))),
-                  base = int(mix_mul24(uint32_t(blk), uint32_t(L))) + j;
-        const int a0 = mix_addr<COL>(n, sh, sl, base), as = mix_step<COL>(sh, sub);
+        const int blk = mix_div(ja, mg_sub), j = ja - int(mix_mul24(uint32_t(blk), uint32_t(sub)));
+        const int a0 = mix_addr<COL>(n, sh, sl, mix_slot_mid(p, sh, s, blk, j, L)), as = mix_step<COL>(sh, s == 1 ? sh.s1 : sub);
         const uint32_t tj = mix_mul24(uint32_t(j), uint32_t(tstep));
         cx<T> a[R];
         a[0] = mix_ld(lds + a0);
@@ -446,7 +475,7 @@ PM_HD void mix_last_mul(const MixPlan& p, MixShape sh, int tid, int nt, cx<T>* l
 #pragma unroll
     for (int i = 0; i < kMixMaxStages - 1; ++i) {
         rdx[i] = i < s ? p.radix[i] : 1;
-        wgt[i] = i < s ? p.len[i + 1] : 0;
+        wgt[i] = i < s ? (i == 0 ? sh.s0 : (i == 1 ? sh.s1 : p.len[i + 1])) : 0;      // slot strides of the digits (MixShape)
         mgr[i] = i < s ? p.mg_radix[i] : 0u;
     }
 #pragma unroll 1
@@ -484,7 +513,7 @@ PM_HD void mix_first_t(const MixPlan& p, MixShape sh, int tid, int nt, const cx<
     for (int b = tid; b < total; b += nt) {
         int sl, j;
         mix_split<COL>(sh, b, mg_nb0, nb, sl, j);
-        const int a0 = mix_addr<COL>(n, sh, sl, j), as = mix_step<COL>(sh, nb);
+        const int a0 = mix_addr<COL>(n, sh, sl, mix_slot_low(p, sh, j)), as = mix_step<COL>(sh, sh.s0);
         cx<T> a[R];
         a[0] = mix_ld(lds + a0);
 #pragma unroll

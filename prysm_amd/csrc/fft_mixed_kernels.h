@@ -12,6 +12,7 @@
 namespace pm {
 
 bool mix_plan_for(int n, size_t es, MixPlan& p);             // fft_mixed.hip: the cached factorisation of n for elements of es bytes
+void mix_pick_pads(const MixPlan& p, size_t es, bool col, MixShape& sh);     // fft_mixed.hip: the LDS padding of this launch shape (bank model)
 const MixPlan* mix_plan_dev(int n, size_t es, int* err);     // capi.hip: its device-resident copy (plan cache, beside the twiddles)
 
 // ColStoreNat element store (fft_io.h store_one) with a 32-bit offset from the array base, and without the window test when the caller
@@ -307,10 +308,11 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     if (tuning().mix_seqs > 0) seqs = tuning().mix_seqs;
     if (seqs > nseq) seqs = nseq;
     if (size_t(seqs) * per > kMixLdsHard) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d does not fit the LDS", n);
-    const MixShape sh{seqs, 0};
+    MixShape sh{seqs, 0};
+    mix_pick_pads(p, sizeof(cx<T>), false, sh);
     const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
-    const size_t lds = size_t(seqs) * per;
+    const size_t lds = size_t(seqs) * size_t(sh.npad) * sizeof(cx<T>);
     MixRowOut<T> ro{out, out_ld, AxisMap{n, n, 0, 0}, T(1), 0, 0};
     if (o) ro = MixRowOut<T>{o->dst, o->ld, o->ax, o->scale, o->conj, 1};
     const int groups = (nseq + seqs - 1) / seqs, nt = mix_threads(p, seqs, 256, tuning().mix_nt);
@@ -344,9 +346,10 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     if (size_t(tc) * per > kMixLdsHard) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d does not fit the LDS", n);
     MixShape sh{tc, 0};
     while ((1 << sh.log_seqs) < tc) ++sh.log_seqs;
+    mix_pick_pads(p, sizeof(cx<T>), true, sh);
     const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
-    const size_t lds = size_t(tc) * per;
+    const size_t lds = size_t(tc) * size_t(sh.npad) * sizeof(cx<T>);
     // tiles that share a 128 B line run on one XCD (mix_cols_kernel): 2^log_g adjacent tiles, the grid padded to whole rounds of them
     int log_g = 0;
     while ((size_t(tc) << log_g) * sizeof(cx<T>) < 128 && log_g < 3) ++log_g;
@@ -407,9 +410,10 @@ int mix_cols_mul_impl(const DirectIn<T>& in, const MidMul<T>& m, cx<T>* dst, int
     if (size_t(tc) * per > kMixLdsHard) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d does not fit the LDS", n);
     MixShape sh{tc, 0};
     while ((1 << sh.log_seqs) < tc) ++sh.log_seqs;
+    mix_pick_pads(p, sizeof(cx<T>), true, sh);
     const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
-    const size_t lds = size_t(tc) * per;
+    const size_t lds = size_t(tc) * size_t(sh.npad) * sizeof(cx<T>);
     int log_g = 0;
     while ((size_t(tc) << log_g) * sizeof(cx<T>) < 128 && log_g < 3) ++log_g;
     if (tuning().mix_log_g >= 0) log_g = tuning().mix_log_g > 4 ? 4 : tuning().mix_log_g;

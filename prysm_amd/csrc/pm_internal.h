@@ -138,6 +138,7 @@ struct Tuning {
     int mix_maxr = 20;        // ... plan within factors of at most this when the length allows (10 / 16 / 20: the kernel classes)
     int mix_log_g = -1;       // ... its column pass: 2^this adjacent tiles per XCD (-1 auto: as many as share a 128 B line)
     int mix_seqs = 0, mix_tc = 0, mix_nt = 0, mix_ntc = 0;   // ... force its rows per workgroup / columns per workgroup / threads per workgroup of the row pass / of the column pass (0 = auto)
+    int mix_pad = 1;          // ... LDS slots padded after the blocks of the first two levels, pads chosen by a bank model (fft_mixed.hip mix_pick_pads); 0: none
     int mix_fused = 1;        // ... fft2 -> x H -> ifft2 on a composite column length as three passes with the mixed-radix middle pass (0: two pm_fft2)
     int mix_min = 32;         // ... from this length (shorter ones stay on the direct fp64-accumulating kernel)
     int blue_fuse = 1;        // both-axes form on engine lengths: chirp multiplies inside the chain's first load / last store (1)

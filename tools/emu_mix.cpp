@@ -16,11 +16,12 @@ typedef long double ld;
 typedef std::complex<ld> cld;
 
 template <typename T>
-static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift) {
+static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift, int c0 = 0, int c1 = 0) {
     MixPlan p;
     if (!mix_make_plan(n, p)) return -1;
     MixShape sh{seqs, 0};
     while ((1 << sh.log_seqs) < seqs) ++sh.log_seqs;
+    mix_shape_pads(p, sh, c0, c1);
     const ld pi = acosl(-1.0L);
     std::vector<cx<T>> tw(n);
     for (int i = 0; i < n; ++i) tw[i] = {T(cosl(-2 * pi * i / n)), T(sinl(-2 * pi * i / n))};
@@ -30,7 +31,7 @@ static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift) {
     std::vector<cx<T>> x(size_t(n) * nseq), y(size_t(n) * nseq, cx<T>{T(0), T(0)});
     for (auto& v : x) v = {T(U(rng)), T(U(rng))};
     BlueIn<T> in{x.data(), col ? 1 : n, col ? nseq : 1, AxisMap{n, n, 0, shift}, 0, 0};
-    std::vector<cx<T>> lds(size_t(seqs) * p.n + 64);
+    std::vector<cx<T>> lds(size_t(seqs) * sh.npad + 64);
     const int ngroups = (nseq + seqs - 1) / seqs;
     for (int g = 0; g < ngroups; ++g) {
         const int seq0 = g * seqs;
@@ -77,11 +78,12 @@ static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift) {
 // the middle pass of fft2 -> x H -> ifft2 on a composite column length: forward stages, multiplier between the two small DFTs of the
 // last stage, transposed stages, conjugate on the way out == the unnormalised inverse transform of (fft(x) h) per column
 template <typename T>
-static double run_mid_case(int n, int nseq, bool col, int seqs, int nt) {
+static double run_mid_case(int n, int nseq, bool col, int seqs, int nt, int c0 = 0, int c1 = 0) {
     MixPlan p;
     if (!mix_make_plan(n, p)) return -1;
     MixShape sh{seqs, 0};
     while ((1 << sh.log_seqs) < seqs) ++sh.log_seqs;
+    mix_shape_pads(p, sh, c0, c1);
     const ld pi = acosl(-1.0L);
     std::vector<cx<T>> tw(n);
     for (int i = 0; i < n; ++i) tw[i] = {T(cosl(-2 * pi * i / n)), T(sinl(-2 * pi * i / n))};
@@ -90,7 +92,7 @@ static double run_mid_case(int n, int nseq, bool col, int seqs, int nt) {
     std::vector<cx<T>> x(size_t(n) * nseq), y(size_t(n) * nseq, cx<T>{T(0), T(0)}), h(size_t(n) * nseq);
     for (auto& v : x) v = {T(U(rng)), T(U(rng))};
     for (auto& v : h) v = {T(U(rng)), T(U(rng))};       // h[bin][seq] (cols) or h[seq][bin] (rows)
-    std::vector<cx<T>> lds(size_t(seqs) * p.n + 64);
+    std::vector<cx<T>> lds(size_t(seqs) * sh.npad + 64);
     const int ngroups = (nseq + seqs - 1) / seqs;
     for (int g = 0; g < ngroups; ++g) {
         const int seq0 = g * seqs;
@@ -149,7 +151,8 @@ static double run_mid_case(int n, int nseq, bool col, int seqs, int nt) {
 int main() {
     int bad = 0;
     for (int n : {36, 60, 100, 125, 180, 243, 360, 1000, 1001, 1536, 2310, 3000}) {
-        const double m1 = run_mid_case<double>(n, 5, true, 4, 96), m2 = run_mid_case<double>(n, 3, false, 2, 64), m3 = run_mid_case<float>(n, 6, true, 2, 128);
+        // (the second and third with padded LDS slots: MixShape pad0 / pad1)
+        const double m1 = run_mid_case<double>(n, 5, true, 4, 96), m2 = run_mid_case<double>(n, 3, false, 2, 64, 3, 2), m3 = run_mid_case<float>(n, 6, true, 2, 128, 1, 4);
         printf("middle pass n=%5d  cols f64 %.2e  rows f64 %.2e  cols f32 %.2e\n", n, m1, m2, m3);
         if (!(m1 < 1e-12) || !(m2 < 1e-12) || !(m3 < 2e-5)) { ++bad; printf("   ^^^ FAIL\n"); }
     }
@@ -160,8 +163,8 @@ int main() {
         if (!mix_make_plan(n, p)) { printf("n=%d no plan\n", n); ++bad; continue; }
         printf("n=%5d stages", n);
         for (int s = 0; s < p.nstage; ++s) printf(" %d", p.radix[s]);
-        const double e1 = run_case<double>(n, 3, false, 2, 64, 0);
-        const double e2 = run_case<double>(n, 5, true, 4, 96, n / 2);
+        const double e1 = run_case<double>(n, 3, false, 2, 64, 0, n % 7, n % 3);      // padded LDS slots, pads varying with the length
+        const double e2 = run_case<double>(n, 5, true, 4, 96, n / 2, n % 5, n % 4);
         const double e3 = run_case<float>(n, 2, false, 1, 128, 1);
         printf("  rows f64 %.2e  cols f64 %.2e  rows f32 %.2e\n", e1, e2, e3);
         if (!(e1 < 1e-13) || !(e2 < 1e-13) || !(e3 < 2e-5)) { ++bad; printf("   ^^^ FAIL\n"); }
