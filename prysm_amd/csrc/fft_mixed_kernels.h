@@ -43,6 +43,12 @@ __device__ __forceinline__ void mix_store_col(const ColStoreNat<T>& p, int k, in
     }
 }
 
+// LDS layout of the row mode (round 4): the sequences of the workgroup INTERLEAVED, [point][sequence] with lanes across the sequences first
+// -- the column mode's layout and lane order (template argument COL = true of the stage functions) on top of the row mode's global
+// addressing (the Fetch / Store functors).  With [sequence][point] the lanes of a wave ran along ONE sequence and met the digit-reversed
+// strides of the last stage and the short blocks of the middle stages in every 32-lane group (bank conflicts on 56 % of the LDS cycles at
+// 3000 points, 34 % with the best padding); interleaved, a group covers 16 (8, 4) consecutive points of 2 (4, 8) rows.  A wave's global
+// accesses become 2 (4, 8) contiguous runs instead of one -- still whole 256 B / 128 B / 64 B pieces.  Rows per workgroup: a power of two.
 // SYNTH: the instantiation whose first stage synthesises the pupil (in.synth); kept apart because the fp64 sincospi of the complex128 form
 // costs 40 registers that the plain kernel of the class of 10 does not have to pay (94 -> 134 VGPRs, five waves per SIMD -> three)
 template <typename T, int MAXR, bool SYNTH = false>
@@ -57,39 +63,39 @@ __global__ __launch_bounds__(512) void mix_rows_kernel(const MixPlan* __restrict
     const bool whole = in.ax.off == 0 && in.ax.len == in.ax.n && nvalid == sh.seqs;
     if (SYNTH && in.synth == 3) {
         const MixFetchSynth<T, true> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, nvalid, in.k2, nullptr, 0, 0u};
-        mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+        mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     } else if (SYNTH && in.synth == 2) {
         const char* a0 = reinterpret_cast<const char*>(in.amp);
         if (a0) a0 += int64_t(seq0) * in.amp_ld * (in.amp_kind == 1 ? 4 : (in.amp_kind == 2 ? 8 : 1));
         const MixFetchSynth<T, false> fetch{reinterpret_cast<const T*>(in.src) + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, nvalid, in.k2,
                                             a0, a0 ? in.amp_kind : 0, uint32_t(in.amp_ld)};
-        mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+        mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     } else if (in.real) {
         const MixFetch<T, false, true> fetch{reinterpret_cast<const T*>(in.src) + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, ysign, nvalid};
-        mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+        mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     } else if (whole) {
         const MixFetchWhole<T, false> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax.n, in.ax.shift, ysign};
-        mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+        mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     } else {
         const MixFetch<T, false, false> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, ysign, nvalid};
-        mix_run_first<T, false, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+        mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     }
     __syncthreads();
     const int nstage = p.nstage;
     for (int s = 1; s + 1 < nstage; ++s) {
-        mix_run_mid<T, false, MAXR>(p, sh, s, tid, nt, lds, tw);
+        mix_run_mid<T, true, MAXR>(p, sh, s, tid, nt, lds, tw);
         __syncthreads();
     }
     if (nvalid == sh.seqs && !out.mapped) {
         cx<T>* dst0 = out.dst + int64_t(seq0) * out.ld;
         const uint32_t ld = uint32_t(out.ld);
         auto store = [&](int sl, int k, cx<T> v) { mix_st(dst0 + (mix_mul24(uint32_t(sl), ld) + uint32_t(k)), v); };
-        mix_run_last<T, false, MAXR>(p, sh, tid, nt, lds, store);
+        mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
     } else {
         auto store = [&](int sl, int k, cx<T> v) {
             if (sl < nvalid) mix_store_row(out, seq0 + sl, k, v);
         };
-        mix_run_last<T, false, MAXR>(p, sh, tid, nt, lds, store);
+        mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
     }
 }
 
@@ -306,10 +312,16 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     if (seqs < 2) seqs = 2;
     while (seqs > 1 && size_t(seqs) * per > size_t(48) * 1024) --seqs;
     if (tuning().mix_seqs > 0) seqs = tuning().mix_seqs;
-    if (seqs > nseq) seqs = nseq;
+    while (seqs > 1 && seqs / 2 >= nseq) seqs /= 2;
+    {   // a power of two: the rows of a workgroup are interleaved in LDS (mix_rows_kernel)
+        int pw = 1;
+        while (pw * 2 <= seqs) pw *= 2;
+        seqs = pw;
+    }
     if (size_t(seqs) * per > kMixLdsHard) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d does not fit the LDS", n);
     MixShape sh{seqs, 0};
-    mix_pick_pads(p, sizeof(cx<T>), false, sh);
+    while ((1 << sh.log_seqs) < seqs) ++sh.log_seqs;
+    mix_pick_pads(p, sizeof(cx<T>), true, sh);
     const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
     const size_t lds = size_t(seqs) * size_t(sh.npad) * sizeof(cx<T>);
