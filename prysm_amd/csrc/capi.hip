@@ -164,6 +164,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("mix_fused")) t.mix_fused = v ? 1 : 0;
     else if (is("mix_pad")) t.mix_pad = v ? 1 : 0;
     else if (is("two_units")) t.two_units = v & 3;
+    else if (is("engine_p8")) t.engine_p8 = v & 7;
     else if (is("mix_maxr")) t.mix_maxr = (v < 2 || v > 20) ? 20 : v;
     else if (is("mix_log_g")) t.mix_log_g = v;
     else if (is("mix_seqs")) t.mix_seqs = v < 0 ? 0 : v;
@@ -212,6 +213,7 @@ Tuning& tuning() { return g_tune_local_on ? g_tune_local : tuning_global(); }
 
 #ifdef PM_EXPERIMENTS
 int pm_two_units() { return tuning().two_units; }
+int pm_engine_p8() { return tuning().engine_p8; }
 #endif
 
 int pm_num_cus() {
@@ -1582,7 +1584,7 @@ static bool experiment_only(const char* key, int v) {
 #else
     auto is = [&](const char* k) { return !strcmp(key, k); };
     return (is("spectral_mode") && (v & 3) != 3) || (is("gemm_3m") && !v) || (is("gemm_bm") && v == 128) || (is("gemm_bk") && v == 32) ||
-           (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 6)) || (is("spectral2") && v != 0) || (is("two_units") && v != 0);
+           (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 6)) || (is("spectral2") && v != 0) || (is("two_units") && v != 0) || (is("engine_p8") && v != 0);
 #endif
 }
 

@@ -31,12 +31,14 @@ namespace pm {
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
 constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
 
-template <typename T_, int LOGN_, int CI_, int E_, int BO_, int COMP_>
+// LOGPMAX_: log2 of the most points a thread holds per sequence -- 4 (16 points, radix-16 stages: everything the library ships) or 3
+// (8 points, radix-8 stages: the lighter-wave engine of round 4's experiment build)
+template <typename T_, int LOGN_, int CI_, int E_, int BO_, int COMP_, int LOGPMAX_ = 4>
 struct FftCfg {
     using T = T_;
     static constexpr int LOGN = LOGN_;
     static constexpr int N = 1 << LOGN_;
-    static constexpr int P = N >= 16 ? 16 : N;          // points per thread per sequence
+    static constexpr int P = N >= (1 << LOGPMAX_) ? (1 << LOGPMAX_) : N;          // points per thread per sequence
     static constexpr int LOGP = ilog2(P);
     static constexpr int TPS = N / P;                    // threads per sequence
     static constexpr int CI = CI_;                       // sequences interleaved over adjacent lanes
@@ -286,8 +288,8 @@ template <typename C>
 struct LdsType {
     using type = cx<typename C::T>;
 };
-template <typename T, int L, int CI, int E, int BO>
-struct LdsType<FftCfg<T, L, CI, E, BO, 2>> {
+template <typename T, int L, int CI, int E, int BO, int LP>
+struct LdsType<FftCfg<T, L, CI, E, BO, 2, LP>> {
     using type = T;
 };
 

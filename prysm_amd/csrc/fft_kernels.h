@@ -92,6 +92,23 @@ __global__ void __launch_bounds__(C::NT) fft_kernel_2u(const L lp, const S sp, c
     store<C>(spb, u1, pos, vn);
 }
 int pm_two_units();     // capi.hip: the knob
+// Round 4's second experiment: the engine with EIGHT points per thread (radix-8 stages, FftCfg LOGPMAX = 3) for the two passes of the
+// folded 4096^2 complex64 transform -- half the registers per thread, twice the waves, three exchanges instead of two.
+// MINW: minimum waves per SIMD the register allocation leaves room for.
+template <typename C, bool COL, typename L, typename S, int MINW>
+__global__ void __launch_bounds__(C::NT, MINW) fft_kernel_p8(const L lp, const S sp, const cx<typename C::T>* __restrict__ tw, const int log_g) {
+    extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+    const ThreadPos pos = thread_pos<C>(threadIdx.x);
+    int unit = group_remap(blockIdx.x, gridDim.x, log_g);
+    if (COL) unit = unit * C::BO + pos.bo;
+    cx<typename C::T> v[C::E][C::P];
+    const L lpb = at_batch(lp, blockIdx.y);
+    const S spb = at_batch(sp, blockIdx.y);
+    load<C>(lpb, unit, pos, v);
+    fft_run_pipe2<C>(v, pos, pm_smem, tw);
+    store<C>(spb, unit, pos, v);
+}
+int pm_engine_p8();     // capi.hip: the knob (bit 0 rows, bit 1 columns)
 #endif
 
 // Fused spectral-multiply column pass: forward transform, multiply by H, inverse transform -- all on the
@@ -523,6 +540,16 @@ int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, 
     const int grid = (units + per_wg - 1) / per_wg;
     if (grid <= 0 || nbatch <= 0) return 0;
 #ifdef PM_EXPERIMENTS
+    if constexpr (COL && LOGN == 11 && sizeof(T) == 4 && VAR == 0) {
+        if (pm_engine_p8() & 2) {       // 8 columns x 2048 rows by 1024 threads of 8 points
+            using C8 = FftCfg<T, 11, 4, 2, 1, 1, 3>;
+            auto k8 = (pm_engine_p8() & 4) ? fft_kernel_p8<C8, true, L, S, 8> : fft_kernel_p8<C8, true, L, S, 4>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, int(C8::LDS_BYTES));
+            if (e != hipSuccess) return int(e);
+            hipLaunchKernelGGL(k8, dim3(units, nbatch), dim3(C8::NT), C8::LDS_BYTES, st, lp, sp, tw, log_g);
+            return int(hipGetLastError());
+        }
+    }
     if constexpr (LOGN == 11 && sizeof(T) == 4) {
         if ((pm_two_units() & (COL ? 2 : 1)) && grid % 2 == 0) {
             auto k2 = fft_kernel_2u<C, COL, VAR, L, S>;
@@ -545,6 +572,19 @@ template <typename T, int LOGN>
 int launch_fold_one(const RowLoadNat<T>& lp, const RowStoreFold<T>& sp, const cx<T>* tw, int npairs, int log_g, hipStream_t st,
                     int nbatch) {
     using C = typename RowCfgSel<T, LOGN, 4>::type;
+#ifdef PM_EXPERIMENTS
+    if constexpr (LOGN == 12 && sizeof(T) == 4) {
+        if (pm_engine_p8() & 1) {       // a row pair by 512 threads of 8 points
+            using C8 = FftCfg<T, 12, 1, 2, 1, 1, 3>;
+            auto k8 = (pm_engine_p8() & 4) ? fft_kernel_p8<C8, false, RowLoadNat<T>, RowStoreFold<T>, 8> : fft_kernel_p8<C8, false, RowLoadNat<T>, RowStoreFold<T>, 4>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, int(C8::LDS_BYTES));
+            if (e != hipSuccess) return int(e);
+            if (npairs <= 0 || nbatch <= 0) return 0;
+            hipLaunchKernelGGL(k8, dim3(npairs, nbatch), dim3(C8::NT), C8::LDS_BYTES, st, lp, sp, tw, log_g);
+            return int(hipGetLastError());
+        }
+    }
+#endif
     auto kern = fft_kernel<C, false, 4, RowLoadNat<T>, RowStoreFold<T>>;
     constexpr size_t LDSB = C::LDS_BYTES;
     if (LDSB > 48 * 1024) {

@@ -166,6 +166,8 @@ struct Tuning {
                               // a 128-VGPR cap (spills), 2 persistent prefetching workgroups (twiddles / hy in LDS).  Measured
                               // (profiles/r03/exp_colmul.log, us, modes 0 / 1 / 2 / 3): middle pass of config 3 159.1 / 198.1 / 135.7 / 115.4;
                               // chain 4096^2 complex128 383 / 430 / 365 / 355, complex64 186 / 176 / 175 / 165, 2048^2 complex128 90 / 94 / 86 / 81
+    int engine_p8 = 0;        // experiment builds: the radix-8 engine (8 points per thread) for the folded 4096^2 complex64 transform: bit 0 its row pass,
+                              // bit 1 its column pass, bit 2 a 64-register cap (eight waves per SIMD) instead of 128
     int two_units = 0;        // experiment builds: two units per workgroup in the passes of a 2048-point complex64 transform (bit 0 rows, bit 1 columns)
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)

@@ -83,9 +83,9 @@ static void report(const char* what, double err, double tol) {
 }
 
 // --- 1-D row transform, natural in / natural out, with zero-pad + shift maps -------------
-template <typename T, int LOGN, int BO, int COMP, int E = 1>
+template <typename T, int LOGN, int BO, int COMP, int E = 1, int LOGP = 4>
 static void test_row(int nseq, int in_len, int in_off, int in_shift, int out_shift, bool inverse) {
-    using C = FftCfg<T, LOGN, 1, E, BO, COMP>;
+    using C = FftCfg<T, LOGN, 1, E, BO, COMP, LOGP>;
     const int N = C::N;
     std::mt19937 rng(LOGN * 131 + nseq);
     std::normal_distribution<double> nd;
@@ -117,8 +117,8 @@ static void test_row(int nseq, int in_len, int in_off, int in_shift, int out_shi
         }
     }
     char buf[128];
-    snprintf(buf, sizeof buf, "row %s N=%d BO=%d COMP=%d E=%d nseq=%d len=%d off=%d sh=%d/%d %s",
-             sizeof(T) == 4 ? "c64" : "c128", N, BO, COMP, E, nseq, in_len, in_off, in_shift, out_shift,
+    snprintf(buf, sizeof buf, "row %s N=%d BO=%d COMP=%d E=%d P=%d nseq=%d len=%d off=%d sh=%d/%d %s",
+             sizeof(T) == 4 ? "c64" : "c128", N, BO, COMP, E, C::P, nseq, in_len, in_off, in_shift, out_shift,
              inverse ? "inv" : "fwd");
     report(buf, err / nrm, sizeof(T) == 4 ? 2e-6 : 1e-14);
 }
@@ -913,6 +913,11 @@ int main() {
     test_row<double, 8, 16, 1>(5, 256, 0, 128, 128, false);
     test_row<double, 12, 1, 2>(2, 4096, 0, 0, 0, true);
     test_row<double, 10, 4, 2>(5, 700, 162, 512, 0, false);
+    // eight points per thread (radix-8 stages: round 4's experiment engine): 8^4, 8^3 x 4, 8^2 x 2, two rows per thread, rotations
+    test_row<float, 12, 1, 1, 2, 3>(3, 4096, 0, 2048, 2048, false);
+    test_row<float, 11, 1, 1, 2, 3>(5, 2000, 24, 1024, 0, true);
+    test_row<float, 7, 4, 1, 1, 3>(9, 128, 0, 64, 64, false);
+    test_row<double, 10, 1, 2, 1, 3>(3, 1024, 0, 0, 512, false);
     // two rows per thread (row pass variant 4): odd row counts leave a half-filled last pair
     test_row<float, 12, 1, 1, 2>(3, 4096, 0, 2048, 2048, false);
     test_row<float, 11, 2, 1, 2>(7, 2000, 24, 1024, 0, true);
