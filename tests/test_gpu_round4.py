@@ -337,3 +337,40 @@ def test_composite_lengths_above_8192(pa, shape):
     assert rel_max(tonp(pa.propagation.focus(small, 2)), O.focus(small, 2)) < TOL64
     xr = rng.standard_normal(shape)
     assert rel_max(_ops.fft2(torch.from_numpy(xr).cuda(), direction=-1, scale=1.0).cpu().numpy(), np.fft.fft2(xr)) < TOL64
+
+
+# ----------------------------------------------------------------------------- small host-side additions
+
+def test_stream_ring_sequence_matches_one_stream(pa):
+    """prysm_amd.graph.StreamRing: a sequence of independent propagations alternating between two HIP streams gives, bit for bit, what
+    one stream gives (per-stream workspaces, stream-aware allocator), and join() orders the caller's stream behind all of them"""
+    from prysm_amd.graph import StreamRing
+    rng = np.random.default_rng(4)
+    fields = [torch.from_numpy(crandn(rng, (512, 512), np.complex64)).cuda() for _ in range(6)]
+    want = [pa.propagation.focus(f, 2).clone() for f in fields]
+    torch.cuda.synchronize()
+    ring = StreamRing(2)
+    ring.fork()
+    outs = [ring.run(pa.propagation.focus, f, 2) for f in fields]
+    ring.join()
+    total = sum(o.abs().sum() for o in outs)        # consumed on the caller's stream, after the join
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, w) for o, w in zip(outs, want)) and float(total) > 0
+    assert StreamRing.worth_it((2048, 2048)) and not StreamRing.worth_it((4096, 4096))
+
+
+def test_transfer_function_vectors_are_cached_per_scalars(pa):
+    """angular_spectrum re-uses the two transfer-function vectors of (shape, wavelength, dx, z): same tensors on a repeat, new ones for
+    another distance, results right either way; the materialised transfer function never hands cached storage out"""
+    from prysm_amd import _ops
+    rng = np.random.default_rng(6)
+    x = crandn(rng, (256, 256))
+    a = _ops.as_tf_vectors((256, 256), O.HeNe, 0.01, 10.0, torch.complex128)
+    b = _ops.as_tf_vectors((256, 256), O.HeNe, 0.01, 10.0, torch.complex128)
+    c = _ops.as_tf_vectors((256, 256), O.HeNe, 0.01, 11.0, torch.complex128)
+    assert a[0] is b[0] and a[1] is b[1] and c[0] is not a[0]
+    for z in (10.0, 11.0, 10.0):
+        assert rel_max(tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, z, Q=1)), O.angular_spectrum(x, O.HeNe, 0.01, z, Q=1)) < TOL64
+    tf = pa.propagation.angular_spectrum_transfer_function((256, 256), O.HeNe, 0.01, 10.0)
+    assert rel_max(tonp(tf), O.angular_spectrum_transfer_function((256, 256), O.HeNe, 0.01, 10.0)) < TOL64
+    assert len(_ops._AS_TF_CACHE) <= _ops._AS_TF_CACHE_MAX

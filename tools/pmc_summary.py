@@ -26,7 +26,7 @@ def short(n):
         return 'cgemm_' + ('f32' if '<float' in n else 'f64')
     if 'splitk' in n:
         return 'splitk_reduce'
-    m = re.search(r'FftCfg<(\w+), (\d+), (\d+), (\d+), (\d+), (\d+)>', n)
+    m = re.search(r'FftCfg<(\w+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?>', n)      # (+ the points-per-thread argument, round 4)
     if m:
         kind = 'row_pass' if 'RowLoad' in n else 'column_pass'
         if 'c2r' in n:
