@@ -69,7 +69,7 @@ enum {
                              * (prysm/propagation/wavefront.py:58-79) fused into focus: the complex pupil never exists in
                              * memory.  `in` is float for PM_C64, double for PM_C128 (fp64 sincospi per sample: 4096^2 329 -> 255 us
                              * against synthesis + transform).  Row lengths: powers of two (the engine's row loader) and composites of primes
-                             * <= 13 up to 8192 (the mixed-radix row kernel's first stage, round 4); PM_ERR_UNSUPPORTED otherwise. */
+                             * <= 19 up to 8192 (the mixed-radix row kernel's first stage, round 4); PM_ERR_UNSUPPORTED otherwise. */
     PM_FLAG_SYNTH_PACKED = 32, /* with PM_FLAG_SYNTH_INPUT: `in` holds (amplitude, OPD) float / double PAIRS (in_ld in pairs), synth_amp is ignored.
                              * One 8-byte load per element instead of two 4-byte loads from two arrays: a loop over wavelengths packs
                              * its two maps once (the polychromatic recipe: 133 -> 101 us per wavelength at 4096^2) */
@@ -152,13 +152,13 @@ typedef struct pm_fft2_desc {
 } pm_fft2_desc;
 
 /* Transform lengths (per axis): powers of two from 2 to 8192 run on the Stockham engine; composite lengths from 32 to 8192 whose prime
- * factors are all <= 13 (1000, 1536, 2592, 3000, 6000 ...: what scipy.fft factors natively) run on their own factors in one LDS-resident
+ * factors are all <= 19 (1000, 1020, 1536, 2592, 3000, 6000 ...: what scipy.fft factors natively) run on their own factors in one LDS-resident
  * mixed-radix kernel per axis with no scratch (3000^2 complex64: 87 us; arrays of 4 GiB and more keep the routes below); 16384 and
  * 32768 take one radix-2 / radix-4 step around engine transforms (16384^2 complex64: 4.3 ms), and so do 3 / 5 / 7 x 2^k above 8192
  * (10240, 12288 ...: radix 3 / 5 / 7) and -- round 4 -- composites above 8192 whose cofactor of 2, 3, 4, 5 or 7 is a length the mixed-radix
  * kernel takes (10000 = 2 x 5000, 9000, 12000, 20000 ...: 10000^2 complex64 1.9 ms), when the other axis is a power of two, such a length
  * or a composite the mixed-radix kernel takes; other lengths from 96 to 4096 (a prime
- * factor above 13: 997, 1009 ...) run on the engine through Bluestein's identity (chirp multiply, power-of-two convolution of length >= 2n - 1, chirp multiply;
+ * factor above 19: 997, 1009 ...) run on the engine through Bluestein's identity (chirp multiply, power-of-two convolution of length >= 2n - 1, chirp multiply;
  * when both axes are such lengths the 2-D convolution is ONE fused fft2 x B ifft2 chain, and that form reaches 16384 per axis by
  * convolving at 16384 / 32768 points: 8000^2 complex64 8.6 ms); shorter lengths, and other lengths
  * up to 32768, run on a direct O(n^2) kernel with fp64 accumulation.  Anything else is PM_ERR_UNSUPPORTED.  The reference
@@ -190,7 +190,7 @@ int pm_fft2_spectral(const pm_fft2_desc* d, int32_t count, const double* k, cons
  * Replaces fft.ifft2(fft.fft2(field) * tf) of angular_spectrum / angular_spectrum_adjoint
  * (prysm/propagation/angular_spectrum.py:35,41-42,76) and the fft2 * fft2 -> ifft2 core of convolution.conv
  * (prysm/convolution.py:27-30).  Transform lengths: powers of two <= 8192 on both axes, or (round 4: one field, complex output) a COLUMN
- * length from 32 to 8192 whose primes are <= 13 beside a row length of either kind -- the middle pass then keeps each column in LDS through
+ * length from 32 to 8192 whose primes are <= 19 beside a row length of either kind -- the middle pass then keeps each column in LDS through
  * the forward stages of its factorisation, the multiplier and the same stages transposed (csrc/fft_mixed.h; angular spectrum 3000^2
  * complex128: 281 us against 369 for two pm_fft2 calls).  PM_ERR_UNSUPPORTED (workspace query: 0) otherwise: the caller composes two
  * pm_fft2 calls.  Uses the fields of pm_fft2_desc: dtype, scale (applied

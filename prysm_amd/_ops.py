@@ -65,10 +65,10 @@ def _fill_mul(d, x, mul, mul_x, mul_conj, keep):
 
 
 def _is_mix_length(n):
-    """lengths the mixed-radix kernel takes (csrc/fft_mixed.h): 32 .. 8192, not a power of two, primes <= 13"""
+    """lengths the mixed-radix kernel takes (csrc/fft_mixed.h): 32 .. 8192, not a power of two, primes <= 19"""
     if n < 32 or n > 8192 or (n & (n - 1)) == 0:
         return False
-    for p in (2, 3, 5, 7, 11, 13):
+    for p in (2, 3, 5, 7, 11, 13, 17, 19):
         while n % p == 0:
             n //= p
     return n == 1
@@ -76,7 +76,7 @@ def _is_mix_length(n):
 
 def synth_supported(opd, amp, N):
     """Whether pm_fft2 can synthesise amp * exp(i k opd) while loading (PM_FLAG_SYNTH_INPUT): a 2-D float32 / float64 OPD map
-    (complex64 / complex128 transform), a row length that is a power of two or (round 4) a composite of primes <= 13 -- the two row
+    (complex64 / complex128 transform), a row length that is a power of two or (round 4) a composite of primes <= 19 -- the two row
     kernels whose loaders synthesise --, real / bool amplitude."""
     if opd.dim() != 2 or opd.dtype not in (torch.float32, torch.float64) or not (_is_pow2_engine(N) or _is_mix_length(N)):
         return False
@@ -224,7 +224,7 @@ def fft2_mul_ifft2(x, *, scale, mul, mul_x=None, mul_conj=False, shape=None, in_
     (PM_FLAG_REAL_OUTPUT: unpadded power-of-two sizes, a full multiplier), else `.real` of the complex result.
 
     Power-of-two transform sizes run the fused three-pass kernel chain (pm_fft2_mul_ifft2: the multiply and
-    both column transforms happen in registers); so do composite grids whose column length has primes <= 13 (round 4: the middle
+    both column transforms happen in registers); so do composite grids whose column length has primes <= 19 (round 4: the middle
     pass keeps the column in LDS through forward stages, multiplier and transposed stages); what is left composes two pm_fft2 calls.
     """
     lib = L.load()

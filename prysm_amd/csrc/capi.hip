@@ -1146,7 +1146,7 @@ static int check_fft2(const pm_fft2_desc* d) {
         if (d->direction != -1) return fail(PM_ERR_ARG, "pm_fft2: PM_FLAG_SYNTH_INPUT is a forward transform");
         if ((engine_log2(d->in_x.n) < 0 && !use_mix(d->in_x.n)) || d->batch > 1)
             return fail(PM_ERR_UNSUPPORTED, "pm_fft2: PM_FLAG_SYNTH_INPUT needs a row length that is a power of two or a composite with primes "
-                        "<= 13 (the kernels whose loaders synthesise the pupil), and no batch");
+                        "<= 19 (the kernels whose loaders synthesise the pupil), and no batch");
         if (d->synth_amp && d->synth_amp_dtype != PM_F32 && d->synth_amp_dtype != PM_F64 && d->synth_amp_dtype != PM_BOOL)
             return fail(PM_ERR_ARG, "pm_fft2: synth_amp_dtype");
         if (d->synth_amp && d->synth_amp_ld < d->in_x.len) return fail(PM_ERR_ARG, "pm_fft2: synth_amp_ld < row length");
@@ -1792,7 +1792,7 @@ int pm_fft2_mul_ifft2(const pm_fft2_desc* d, const void* in, void* out, void* wo
     FusedPlan p;
     if (!plan_fused(d, p))
         return fail(PM_ERR_UNSUPPORTED, "pm_fft2_mul_ifft2: takes powers of two <= 8192 on both axes, or (one field, complex output) a composite "
-                    "column length with primes <= 13 beside a row length of either kind (got %lld x %lld); compose two pm_fft2 calls instead",
+                    "column length with primes <= 19 beside a row length of either kind (got %lld x %lld); compose two pm_fft2 calls instead",
                     (long long)d->in_y.n, (long long)d->in_x.n);
     const size_t need = p.ws_bytes;
     if (!workspace || workspace_bytes < need)

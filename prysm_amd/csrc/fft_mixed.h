@@ -1,4 +1,4 @@
-// Composite lengths on their own factors: n = r0 r1 ... with every factor <= 20 (all lengths whose primes are <= 13: 1000, 3000,
+// Composite lengths on their own factors: n = r0 r1 ... with every factor <= 20 (all lengths whose primes are <= 19: 1000, 3000,
 // 2592, 1001 ...) as ONE kernel per axis, in place of Bluestein's convolution of >= 2n - 1 points per axis (>= 4x the area in 2-D).
 // The reference reaches these lengths through scipy.fft / pocketfft, which factors them the same way (prysm/propagation/fft.py:24,
 // prysm/fttools.py:23-31, prysm/propagation/angular_spectrum.py:35-42).
@@ -32,7 +32,9 @@ constexpr int kMixMaxRadix = 20;
 // factors with a small DFT below.  Factors up to 32 were built and measured (profiles/r03/exp_mix_maxr.log): the kernel class that contains
 // them needs 171 VGPRs (complex64) / 256 + spills (complex128) and lost to plans of one more stage in a leaner class at every length tried
 // (625 = 25 x 25: 22.2 us against 14.4 as 5 x 5 x 5 x 5; 5000^2 414 against 321; complex128 900^2 42.4 against 22.7)
-constexpr bool mix_radix_ok(int r) { return r >= 2 && r <= 20 && r != 17 && r != 19; }
+// (17 and 19 -- round 4 -- by the symmetric half sums like the other odd primes: O(R^2), but lengths such as 1020 = 3 x 4 x 5 x 17 or 1900 = 19 x 10 x 10 leave Bluestein's
+// convolution for it; the class of 20 holds them at no extra registers in complex64)
+constexpr bool mix_radix_ok(int r) { return r >= 2 && r <= 20; }
 
 // ---------------------------------------------------------------------------
 // compile-time roots of unity (octant reduction + Taylor series on [0, pi/4]; ~1 ulp)
@@ -130,6 +132,8 @@ template <typename T> struct MixDft<T, 5> { static PM_HD void run(cx<T>* a) { mi
 template <typename T> struct MixDft<T, 7> { static PM_HD void run(cx<T>* a) { mix_dft_odd<T, 7>(a); } };
 template <typename T> struct MixDft<T, 11> { static PM_HD void run(cx<T>* a) { mix_dft_odd<T, 11>(a); } };
 template <typename T> struct MixDft<T, 13> { static PM_HD void run(cx<T>* a) { mix_dft_odd<T, 13>(a); } };
+template <typename T> struct MixDft<T, 17> { static PM_HD void run(cx<T>* a) { mix_dft_odd<T, 17>(a); } };
+template <typename T> struct MixDft<T, 19> { static PM_HD void run(cx<T>* a) { mix_dft_odd<T, 19>(a); } };
 
 // R = R1 R2, n = R2 n1 + n2, k = k1 + R1 k2
 template <typename T, int R1, int R2>
@@ -215,7 +219,7 @@ PM_HD int mix_div(int a, uint32_t magic) {
 // classes keep more waves per SIMD, and e.g. complex128 3000 = 5 x 6 x 10 x 10 in the class of 10 runs in 189 us against 211 for
 // 10 x 15 x 20, while complex64 2000 = 10 x 10 x 20 keeps its three stages: 39.7 us against 44.0 -- profiles/r03/exp_mix_maxr*.log); above 4096 points (one workgroup per CU either
 // way: the LDS holds few sequences) the fewest stages win (6000 = 15 x 20 x 20: 516 us against 553 with four stages).  Ties go to the
-// smaller largest factor, then to the larger smallest one (fewer butterflies to index).  `maxr` caps the factors (tuning knob mix_maxr).  Returns false when n has a prime factor above 13.
+// smaller largest factor, then to the larger smallest one (fewer butterflies to index).  `maxr` caps the factors (tuning knob mix_maxr).  Returns false when n has a prime factor above 19.
 constexpr int mix_class_of(int maxr) { return maxr <= 10 ? 10 : (maxr <= 16 ? 16 : 20); }
 inline bool mix_factor(int n, int* radix, int* nstage, int maxr = kMixMaxRadix, double w20 = 1.4) {
     if (n < 2 || n > kMixMaxN) return false;
@@ -542,6 +546,8 @@ PM_HD void mix_first_t(const MixPlan& p, MixShape sh, int tid, int nt, const cx<
         case 14: if constexpr (MAXR >= 14) { constexpr int R = 14; CALL; } break; \
         case 15: if constexpr (MAXR >= 15) { constexpr int R = 15; CALL; } break; \
         case 16: if constexpr (MAXR >= 16) { constexpr int R = 16; CALL; } break; \
+        case 17: if constexpr (MAXR >= 20) { constexpr int R = 17; CALL; } break; \
+        case 19: if constexpr (MAXR >= 20) { constexpr int R = 19; CALL; } break; \
         case 18: if constexpr (MAXR >= 18) { constexpr int R = 18; CALL; } break; \
         case 20: if constexpr (MAXR >= 20) { constexpr int R = 20; CALL; } break; \
         default: break; \

@@ -135,7 +135,9 @@ void mix_pick_pads(const MixPlan& p, size_t es, bool col, MixShape& sh) {
     if (!tuning().mix_pad) return;
     static std::mutex mu;
     static std::map<std::tuple<int, int, int, int, int>, std::pair<int, int>> cache;
-    const auto key = std::make_tuple(p.n, int(es), int(col), sh.seqs, p.nstage * 100 + p.radix[0]);
+    int plan_id = p.nstage;      // the factorisation follows the knob mix_maxr: the pads belong to the plan, not just to the length
+    for (int s = 0; s < p.nstage; ++s) plan_id = plan_id * 21 + p.radix[s];
+    const auto key = std::make_tuple(p.n, int(es), int(col), sh.seqs, plan_id);
     {
         std::lock_guard<std::mutex> lk(mu);
         const auto it = cache.find(key);

@@ -59,7 +59,7 @@ int blue_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, void* scratch, 
 template <typename T>
 int blue_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, void* scratch, hipStream_t st);
 
-// Mixed-radix path (fft_mixed.hip): lengths up to 8192 whose prime factors are all <= 13, one kernel per axis with the data in LDS, no
+// Mixed-radix path (fft_mixed.hip): lengths up to 8192 whose prime factors are all <= 19 (<= 13 until round 4), one kernel per axis with the data in LDS, no
 // scratch.  Same contracts as direct_rows / direct_rows_out (`o`) / direct_cols.
 template <typename T>
 int mix_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o = nullptr);
@@ -132,7 +132,7 @@ struct Tuning {
     int fold = -1;           // radix-2 step of the column transform folded into the row pass: -1 auto, 0 never, 1 wherever legal
     int blue_min = 96;        // shortest non-power-of-two length that takes the Bluestein path (shorter ones, and lengths
                              // above 4096, run on the direct O(n^2) kernel); 0 disables the path
-    int mix = 1;              // composite lengths (primes <= 13, up to 8192) on the mixed-radix kernel (fft_mixed.h) instead of Bluestein and of
+    int mix = 1;              // composite lengths (primes <= 19, up to 8192) on the mixed-radix kernel (fft_mixed.h) instead of Bluestein and of
                               // the radix-R step (profiles/r03/exp_mix.log: 1536^2 complex64 42 us against 61, 2560^2 104 against 119); 0: as in
                               // round 2; 2: the 3 / 5 / 7 x 2^k lengths stay on the radix-R step (bigfft.hip)
     int mix_maxr = 20;        // ... plan within factors of at most this when the length allows (10 / 16 / 20: the kernel classes)

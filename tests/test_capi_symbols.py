@@ -105,7 +105,8 @@ def test_workspace_queries_of_the_mixed_radix_path(lib):
     for n in (1000, 3000, 2592, 1001, 7000):
         assert lib.pm_fft1_workspace(L.PM_C64, 1, 8, n) == 0 and lib.pm_fft1_workspace(L.PM_C128, 0, 8, n) == 0
     assert lib.pm_fft1_workspace(L.PM_C64, 1, 8, 1009) > 0          # prime: Bluestein
-    assert lib.pm_fft1_workspace(L.PM_C64, 1, 8, 2 * 17 * 19) > 0   # primes above 13
+    assert lib.pm_fft1_workspace(L.PM_C64, 1, 8, 2 * 17 * 19) == 0  # round 4: 17 and 19 are radices of the mixed-radix kernel
+    assert lib.pm_fft1_workspace(L.PM_C64, 1, 8, 2 * 23 * 29) > 0   # primes above 19: Bluestein
 
 
 def test_workspace_queries_of_the_bluestein_path(lib, bluestein_route):

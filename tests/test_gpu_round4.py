@@ -374,3 +374,20 @@ def test_transfer_function_vectors_are_cached_per_scalars(pa):
     tf = pa.propagation.angular_spectrum_transfer_function((256, 256), O.HeNe, 0.01, 10.0)
     assert rel_max(tonp(tf), O.angular_spectrum_transfer_function((256, 256), O.HeNe, 0.01, 10.0)) < TOL64
     assert len(_ops._AS_TF_CACHE) <= _ops._AS_TF_CACHE_MAX
+
+
+@pytest.mark.parametrize('shape', [(1020, 1900), (323, 380), (272, 4913), (2048, 1020)])
+def test_lengths_with_the_primes_17_and_19(pa, shape):
+    """radices 17 and 19 in the mixed-radix kernel (round 4): 1020 = 6 x 10 x 17, 1900 = 10 x 10 x 19, 323 = 17 x 19, 4913 = 17^3 no longer
+    convolve through Bluestein; fft2 / ifft2 / focus in both precisions and the fused chain (column lengths 1020, 323) vs numpy"""
+    from prysm_amd import _ops
+    rng = np.random.default_rng(sum(shape))
+    M, N = shape
+    for dtype, tol in ((np.complex64, TOL32), (np.complex128, TOL64)):
+        x = crandn(rng, shape, dtype)
+        xd = torch.from_numpy(x).cuda()
+        assert rel_max(_ops.fft2(xd, direction=-1, scale=1.0).cpu().numpy(), np.fft.fft2(x.astype(np.complex128))) < tol, dtype
+        assert rel_max(_ops.fft2(xd, direction=+1, scale=1.0 / (M * N)).cpu().numpy(), np.fft.ifft2(x.astype(np.complex128))) < tol
+        assert rel_max(tonp(pa.propagation.focus(x, 1)), O.focus(x.astype(np.complex128), 1)) < tol
+    x = crandn(rng, shape)
+    assert rel_max(tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1)), O.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1)) < TOL64

@@ -159,7 +159,7 @@ int main() {
         if (!(m1 < 1e-12) || !(m2 < 1e-12) || !(m3 < 2e-5)) { ++bad; printf("   ^^^ FAIL\n"); }
     }
     const int lens[] = {36, 40, 42, 44, 48, 50, 52, 54, 56, 60, 64, 45, 49, 60, 77, 90, 96, 100, 120, 121, 125, 143, 144, 169, 180, 243, 250, 256, 343, 360, 500, 625, 729, 1000,
-                        1001, 1331, 1500, 2187, 2310, 2592, 3000, 3125, 4000, 4004, 4096, 5000, 6000, 6561, 7000, 8000, 324, 400, 441, 484, 576, 625, 676, 729, 784, 900, 1024, 660, 780, 810, 840, 960};
+                        1001, 1331, 1500, 272, 323, 380, 1020, 1900, 4913, 6137, 2187, 2310, 2592, 3000, 3125, 4000, 4004, 4096, 5000, 6000, 6561, 7000, 8000, 324, 400, 441, 484, 576, 625, 676, 729, 784, 900, 1024, 660, 780, 810, 840, 960};
     for (int n : lens) {
         MixPlan p;
         if (!mix_make_plan(n, p)) { printf("n=%d no plan\n", n); ++bad; continue; }
@@ -171,12 +171,12 @@ int main() {
         printf("  rows f64 %.2e  cols f64 %.2e  rows f32 %.2e\n", e1, e2, e3);
         if (!(e1 < 1e-13) || !(e2 < 1e-13) || !(e3 < 2e-5)) { ++bad; printf("   ^^^ FAIL\n"); }
     }
-    // the planner over every length: a plan exists exactly for the lengths whose primes are <= 13 and that need at least two factors; its
+    // the planner over every length: a plan exists exactly for the lengths whose primes are <= 19 and that need at least two factors; its
     // factors multiply to n, are ascending, at most 20, and the block lengths / reciprocals are consistent
     int planned = 0;
     for (int n = 2; n <= kMixMaxN; ++n) {
         int m = n;
-        for (int pr : {2, 3, 5, 7, 11, 13})
+        for (int pr : {2, 3, 5, 7, 11, 13, 17, 19})
             while (m % pr == 0) m /= pr;
         const bool smooth = m == 1;
         MixPlan pl;
@@ -197,7 +197,7 @@ int main() {
     }
     printf("planner: %d lengths planned\n", planned);
     MixPlan q;
-    if (mix_make_plan(12, q) || mix_make_plan(16, q) || mix_make_plan(17, q) || mix_make_plan(1024 * 17, q) || mix_make_plan(2 * 19, q)) { printf("planned an unsupported length\n"); ++bad; }
+    if (mix_make_plan(12, q) || mix_make_plan(16, q) || mix_make_plan(17, q) || mix_make_plan(1024 * 17, q) || mix_make_plan(2 * 23, q) || !mix_make_plan(2 * 19, q)) { printf("planned an unsupported length\n"); ++bad; }
     printf(bad ? "FAILED (%d)\n" : "all ok\n", bad);
     return bad != 0;
 }

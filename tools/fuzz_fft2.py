@@ -33,12 +33,16 @@ def window(F, out_shape, out_off, out_shift):
 
 def fuzz_fused(ncases, rng, lib):
     """window(ifft2(fft2(pad(x)) * H)) * scale: fused 3-pass chain (powers of two) or two-call composition."""
-    sizes = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 12, 20, 100]
+    # (round 4: composite column lengths -- 96, 100, 323 = 17 x 19, 360, 1000, 1020, 1536 -- take the three-pass chain with the mixed-radix
+    # middle pass; the knobs mix_fused / mix_pad flip between it and the composition, padded and unpadded LDS slots)
+    sizes = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 12, 20, 100, 96, 323, 360, 1000, 1020, 1536]
     nfail, worst = 0, 0.0
     for case in range(ncases):
         big = rng.random() < 0.2
         M = int(rng.choice([2048, 4096] if big else sizes))
         N = int(rng.choice([2048, 4096] if big else sizes))
+        lib.pm_set_tuning(b'mix_fused', int(rng.random() < 0.8))
+        lib.pm_set_tuning(b'mix_pad', int(rng.random() < 0.7))
         if M * N > (1 << 23):
             N = 2048
         cdt = np.complex64 if rng.random() < 0.5 else np.complex128
@@ -93,7 +97,8 @@ def fuzz_fused(ncases, rng, lib):
         if not err < tol:
             nfail += 1
             print('fused case', case, 'FAIL err', err, (M, N, m, n, in_off, in_shift, (om, on), out_off, out_shift, cdt.__name__, B, sep, per_field, conj, fold))
-    lib.pm_set_tuning(b'fold', -1)
+    for key, val in ((b'fold', -1), (b'mix_fused', 1), (b'mix_pad', 1)):
+        lib.pm_set_tuning(key, val)
     print(f'fuzz_fused: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
     return nfail
 
@@ -288,7 +293,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     lib = L.load()
     sizes = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 3, 5, 9, 12, 20, 36, 100, 96, 127, 160, 200, 224, 384, 1000, 1536, 45, 77, 143, 250, 360, 729, 1001, 1250,
-             2592]   # engine, direct, Bluestein, radix-R step and mixed-radix (composite) lengths
+             2592, 323, 1020, 1900]   # engine, direct, Bluestein, radix-R step and mixed-radix (composite; round 4: primes 17 / 19 too) lengths
     worst = 0.0
     nfail = 0
     for case in range(ncases):
@@ -298,6 +303,9 @@ def main():
         if M * N > (1 << 23):
             N = 2048 if M == 8192 else N
             M = min(M, 4096) if N == 4096 else M
+        if rng.random() < 0.04:     # round 4: a composite above 8192 beside a short axis (one radix-R step around mixed-radix sub-transforms)
+            M, N = (int(rng.choice([9000, 10000, 12000])), int(rng.choice([64, 96, 100]))) if rng.random() < 0.5 else (int(rng.choice([64, 100])), int(rng.choice([10000, 20000])))
+        lib.pm_set_tuning(b'mix_pad', int(rng.random() < 0.7))
         cdt = np.complex64 if rng.random() < 0.5 else np.complex128
         rdt = np.float32 if cdt == np.complex64 else np.float64
         m = M if rng.random() < 0.6 else int(rng.integers(1, M + 1))
@@ -332,7 +340,7 @@ def main():
             x = rng.standard_normal(shp).astype(rdt)
             xs = x.astype(cdt)
         else:
-            if cdt != np.complex64 or B or (N & (N - 1)) or N < 2 or N > 8192:
+            if cdt != np.complex64 or B or not (((N & (N - 1)) == 0 and 2 <= N <= 8192) or (_ops._is_mix_length(N) and route in ('default', 'radix_r'))):
                 kind = 'real'
                 x = rng.standard_normal(shp).astype(rdt)
                 xs = x.astype(cdt)
@@ -367,7 +375,7 @@ def main():
         if not ok:
             nfail += 1
             print('case', case, 'FAIL err', err, (M, N, m, n, in_off, in_shift, (om, on), out_off, out_shift, direction, cdt.__name__, kind, B, epi, fold, route))
-    for key, val in ((b'fold', -1), (b'big_native_log', 13), (b'blue_min', 96), (b'blue_fuse', 1), (b'mix', 1)):
+    for key, val in ((b'fold', -1), (b'big_native_log', 13), (b'blue_min', 96), (b'blue_fuse', 1), (b'mix', 1), (b'mix_pad', 1)):
         lib.pm_set_tuning(key, val)
     print(f'fuzz_fft2: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
     nfail += fuzz_fused(max(20, ncases // 2), rng, lib)
