@@ -164,6 +164,9 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("mix_fused")) t.mix_fused = v ? 1 : 0;
     else if (is("mix_pad")) t.mix_pad = v ? 1 : 0;
     else if (is("two_units")) t.two_units = v & 3;
+    else if (is("mix_ablate")) t.mix_ablate = v & 15;
+    else if (is("mix_pers")) t.mix_pers = v != 0;
+    else if (is("mix_stagger")) t.mix_stagger = v < 0 ? 0 : (v > 64 ? 64 : v);
     else if (is("engine_p8")) t.engine_p8 = v & 7;
     else if (is("mix_maxr")) t.mix_maxr = (v < 2 || v > 20) ? 20 : v;
     else if (is("mix_log_g")) t.mix_log_g = v;
@@ -1584,7 +1587,8 @@ static bool experiment_only(const char* key, int v) {
 #else
     auto is = [&](const char* k) { return !strcmp(key, k); };
     return (is("spectral_mode") && (v & 3) != 3) || (is("gemm_3m") && !v) || (is("gemm_bm") && v == 128) || (is("gemm_bk") && v == 32) ||
-           (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 6)) || (is("spectral2") && v != 0) || (is("two_units") && v != 0) || (is("engine_p8") && v != 0);
+           (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 6)) || (is("spectral2") && v != 0) || (is("two_units") && v != 0) || (is("engine_p8") && v != 0) ||
+           (is("mix_ablate") && v != 0) || (is("mix_pers") && v != 0);
 #endif
 }
 

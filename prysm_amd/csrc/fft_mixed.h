@@ -200,7 +200,20 @@ struct MixShape {
     // (profiles/r03/exp_mix_pmc.txt).  s0 / s1: slot strides of the first two digits, npad: slots per sequence.  The host picks the
     // pads per (plan, precision, mode, sequences per workgroup) with a model of the LDS banks (fft_mixed.hip mix_pick_pads).
     int pad0, pad1, s0, s1, npad;
+    // start-up stagger (knob mix_stagger): the workgroups of the first wave of the launch (index < first_round) wait 0 .. 7 x stagger x
+    // 512 cycles by a hash of their index, so that the load / butterfly / store phases of the workgroups of a CU -- which otherwise
+    // start together and stay in step -- overlap
+    int stagger, first_round;
+    int pers_tiles;     // > 0: the persistent column kernel (fft_mixed_kernels.h mix_cols_pers_kernel) over this many tiles
+#ifdef PM_EXPERIMENTS
+    int ablate;     // timing experiments only (results are wrong): 1 no global loads, 2 no twiddle loads, 4 no global stores, 8 no butterflies
+#endif
 };
+#ifdef PM_EXPERIMENTS
+#define PM_MIX_ABLATE(sh, bit) (((sh).ablate & (bit)) != 0)
+#else
+#define PM_MIX_ABLATE(sh, bit) false
+#endif
 inline void mix_shape_pads(const MixPlan& p, MixShape& sh, int c0, int c1);
 
 // floor(a / d) for a d < 2^16 as (a * magic) >> 32, magic = floor(2^32 / d) + 1 (exact while a d < 2^32); d == 1: magic 0 = identity
@@ -359,24 +372,118 @@ PM_HD void mix_split(MixShape sh, int b, uint32_t mg_nb, int nb, int& sl, int& j
     }
 }
 
+// The twiddles w^k, k = 1 .. R-1, of one butterfly (w = tw[idx], a root of unity of the transform length): one table load each for
+// w, w^4 and w^16 and at most three complex products for the rest (w^2 = w w, w^3 = w^2 w, w^8 = w^4 w^4, w^12 = w^8 w^4,
+// w^(4b+a) = w^(4b) w^a, w^(16+a) = w^16 w^a) instead of R - 1 loads.  The loads, not the butterflies, were what the stages waited on:
+// a wave's twiddle load touches up to 32 different 128 B lines (lane stride 8 k tstep bytes), one tag lookup each, and a stage issued
+// R - 1 of them per butterfly -- with them switched off a 3000-point row kernel ran 15 us of 62 faster, without the butterflies only 6
+// (profiles/r04/exp_mix_ablate.log).  A product costs one rounding of the table's accuracy; three of them stay far inside the parity bar.
+template <typename T, int R>
+struct MixTw {
+    cx<T> lo[4], hi[5];
+    // the table loads on their own (a stage that has other loads in flight issues them together), then the products
+    struct Raw { cx<T> w1, w4, w16; };
+    static PM_HD Raw load(const cx<T>* __restrict__ tw, uint32_t idx) {
+        Raw r;
+        r.w1 = mix_ld(tw + idx);
+        r.w4 = R > 4 ? mix_ld(tw + 4u * idx) : r.w1;
+        r.w16 = R > 16 ? mix_ld(tw + 16u * idx) : r.w1;
+        return r;
+    }
+    PM_HD explicit MixTw(const Raw& r) {
+        lo[0] = hi[0] = cx<T>{T(1), T(0)};
+        lo[1] = r.w1;
+        hi[1] = r.w4;
+        hi[4] = r.w16;
+        if (R > 2) lo[2] = cmul(lo[1], lo[1]);
+        if (R > 3) lo[3] = cmul(lo[2], lo[1]);
+        if (R > 8) hi[2] = cmul(hi[1], hi[1]);
+        if (R > 12) hi[3] = cmul(hi[2], hi[1]);
+    }
+    PM_HD MixTw(const cx<T>* __restrict__ tw, uint32_t idx) : MixTw(load(tw, idx)) {}
+    PM_HD cx<T> operator()(int k) const {     // k is a constant after unrolling
+        if (k < 4) return lo[k];
+        if ((k & 3) == 0) return hi[k >> 2];
+        return k < 16 ? cmul(hi[k >> 2], lo[k & 3]) : cmul(hi[4], lo[k - 16]);
+    }
+};
+
 // first stage: caller's array -> LDS
-template <typename T, bool COL, int R, typename Fetch>
+// (a Fetch with a finish() member returns the raw load from operator() and does its arithmetic in finish(): the loads of a trip then
+// issue back to back)
+template <typename F, typename T> PM_HD auto mix_finish(const F& f, cx<T> x, int) -> decltype(f.finish(x)) { return f.finish(x); }
+template <typename F, typename T> PM_HD cx<T> mix_finish(const F&, cx<T> x, long) { return x; }
+template <typename T>
+constexpr int mix_first_unroll(int r) {
+    return sizeof(T) == 4 ? (r <= 10 ? 3 : (r <= 16 ? 2 : 1)) : (r <= 10 ? 2 : 1);
+}
+template <typename T, bool COL, int R, int UCAP, typename Fetch>
 PM_HD void mix_first(const MixPlan& p, MixShape sh, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw, Fetch fetch) {
+    const int n = p.n, nb = p.len[1], total = sh.seqs * nb;
+    const uint32_t mg_nb0 = p.mg_nb[0];
+    // U butterflies of a thread per trip, all their loads issued before the first butterfly: a workgroup's trips are serial round trips to
+    // memory (3000-point rows: 600 butterflies of 10 on 256 threads, three trips, while the workgroups of a CU run in step and nobody
+    // computes), so the small factors take up to three at once -- within 32 complex64 / 20 complex128 elements in registers
+    constexpr int U = mix_first_unroll<T>(R) < UCAP ? mix_first_unroll<T>(R) : UCAP;     // UCAP: 1 in the 1024-thread column kernels (128 registers)
+#pragma unroll 1
+    for (int b0 = tid; b0 < total; b0 += U * nt) {
+        cx<T> a[U][R];
+        typename MixTw<T, R>::Raw wr[U];
+        int sl[U], j[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sl[u] = j[u] = 0;
+            if (b0 + u * nt < total) {
+                mix_split<COL>(sh, b0 + u * nt, mg_nb0, nb, sl[u], j[u]);
+                wr[u] = MixTw<T, R>::load(tw, PM_MIX_ABLATE(sh, 2) ? 0u : uint32_t(j[u]));
+#pragma unroll
+                for (int k = 0; k < R; ++k) a[u][k] = PM_MIX_ABLATE(sh, 1) ? cx<T>{T(j[u] + k), T(sl[u])} : fetch(sl[u], j[u] + k * nb);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (b0 + u * nt < total) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) a[u][k] = mix_finish(fetch, a[u][k], 0);
+                if (!PM_MIX_ABLATE(sh, 8)) MixDft<T, R>::run(a[u]);
+                const int a0 = mix_addr<COL>(n, sh, sl[u], mix_slot_low(p, sh, j[u])), as = mix_step<COL>(sh, sh.s0);
+                mix_st(lds + a0, a[u][0]);
+                const MixTw<T, R> w(wr[u]);
+#pragma unroll
+                for (int k = 1; k < R; ++k) mix_st(lds + a0 + k * as, cmul(a[u][k], w(k)));
+            }
+        }
+    }
+}
+
+// first stage on a sequence that is already in LDS at its slots (the persistent column kernel copies the tile in): point j + k nb sits
+// in slot slot_low(j) + k s0, which is also where the stage leaves digit k -- in place, like a middle stage
+template <typename T, bool COL, int R>
+PM_HD void mix_first_lds(const MixPlan& p, MixShape sh, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw) {
     const int n = p.n, nb = p.len[1], total = sh.seqs * nb;
     const uint32_t mg_nb0 = p.mg_nb[0];
 #pragma unroll 1
     for (int b = tid; b < total; b += nt) {
         int sl, j;
         mix_split<COL>(sh, b, mg_nb0, nb, sl, j);
+        const typename MixTw<T, R>::Raw wr = MixTw<T, R>::load(tw, uint32_t(j));
+        const int a0 = mix_addr<COL>(n, sh, sl, mix_slot_low(p, sh, j)), as = mix_step<COL>(sh, sh.s0);
         cx<T> a[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) a[k] = fetch(sl, j + k * nb);
+        for (int k = 0; k < R; ++k) a[k] = mix_ld(lds + a0 + k * as);
         MixDft<T, R>::run(a);
-        const int a0 = mix_addr<COL>(n, sh, sl, mix_slot_low(p, sh, j)), as = mix_step<COL>(sh, sh.s0);
         mix_st(lds + a0, a[0]);
+        const MixTw<T, R> w(wr);
 #pragma unroll
-        for (int k = 1; k < R; ++k) mix_st(lds + a0 + k * as, cmul(a[k], mix_ld(tw + uint32_t(j) * uint32_t(k))));
+        for (int k = 1; k < R; ++k) mix_st(lds + a0 + k * as, cmul(a[k], w(k)));
     }
+}
+// LDS slot of point i of a sequence (any i < n): the copy-in of the persistent column kernel
+PM_HD int mix_slot_of(const MixPlan& p, MixShape sh, int i) {
+    int r = i;
+    if (sh.pad1) r += int(mix_mul24(uint32_t(sh.pad1), uint32_t(mix_div(i, p.mg_sub[1]))));
+    if (sh.pad0) r += int(mix_mul24(uint32_t(sh.pad0), uint32_t(mix_div(i, p.mg_sub[0]))));
+    return r;
 }
 
 // middle stage s: LDS in place
@@ -390,14 +497,15 @@ PM_HD void mix_mid(const MixPlan& p, MixShape sh, int s, int tid, int nt, cx<T>*
         mix_split<COL>(sh, b, mg_nb, nb, sl, ja);
         const int blk = mix_div(ja, mg_sub), j = ja - int(mix_mul24(uint32_t(blk), uint32_t(sub)));
         const int a0 = mix_addr<COL>(n, sh, sl, mix_slot_mid(p, sh, s, blk, j, L)), as = mix_step<COL>(sh, s == 1 ? sh.s1 : sub);
+        const typename MixTw<T, R>::Raw wr = MixTw<T, R>::load(tw, PM_MIX_ABLATE(sh, 2) ? 0u : mix_mul24(uint32_t(j), uint32_t(tstep)));
         cx<T> a[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) a[k] = mix_ld(lds + a0 + k * as);
-        MixDft<T, R>::run(a);
+        if (!PM_MIX_ABLATE(sh, 8)) MixDft<T, R>::run(a);
         mix_st(lds + a0, a[0]);
-        const uint32_t tj = mix_mul24(uint32_t(j), uint32_t(tstep));
+        const MixTw<T, R> w(wr);
 #pragma unroll
-        for (int k = 1; k < R; ++k) mix_st(lds + a0 + k * as, cmul(a[k], mix_ld(tw + tj * uint32_t(k))));
+        for (int k = 1; k < R; ++k) mix_st(lds + a0 + k * as, cmul(a[k], w(k)));
     }
 }
 
@@ -432,9 +540,10 @@ PM_HD void mix_last(const MixPlan& p, MixShape sh, int tid, int nt, const cx<T>*
         cx<T> a[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) a[k] = mix_ld(lds + a0 + k * as);
-        MixDft<T, R>::run(a);
+        if (!PM_MIX_ABLATE(sh, 8)) MixDft<T, R>::run(a);
 #pragma unroll
-        for (int k = 0; k < R; ++k) store(sl, o + k * nb, a[k]);
+        for (int k = 0; k < R; ++k)
+            if (!PM_MIX_ABLATE(sh, 4) || a[k].x == T(-12345.678)) store(sl, o + k * nb, a[k]);
     }
 }
 
@@ -457,11 +566,11 @@ PM_HD void mix_mid_t(const MixPlan& p, MixShape sh, int s, int tid, int nt, cx<T
         mix_split<COL>(sh, b, mg_nb, nb, sl, ja);
         const int blk = mix_div(ja, mg_sub), j = ja - int(mix_mul24(uint32_t(blk), uint32_t(sub)));
         const int a0 = mix_addr<COL>(n, sh, sl, mix_slot_mid(p, sh, s, blk, j, L)), as = mix_step<COL>(sh, s == 1 ? sh.s1 : sub);
-        const uint32_t tj = mix_mul24(uint32_t(j), uint32_t(tstep));
+        const MixTw<T, R> w(tw, mix_mul24(uint32_t(j), uint32_t(tstep)));
         cx<T> a[R];
         a[0] = mix_ld(lds + a0);
 #pragma unroll
-        for (int k = 1; k < R; ++k) a[k] = cmul(mix_ld(lds + a0 + k * as), mix_ld(tw + tj * uint32_t(k)));
+        for (int k = 1; k < R; ++k) a[k] = cmul(mix_ld(lds + a0 + k * as), w(k));
         MixDft<T, R>::run(a);
 #pragma unroll
         for (int k = 0; k < R; ++k) mix_st(lds + a0 + k * as, a[k]);
@@ -518,10 +627,11 @@ PM_HD void mix_first_t(const MixPlan& p, MixShape sh, int tid, int nt, const cx<
         int sl, j;
         mix_split<COL>(sh, b, mg_nb0, nb, sl, j);
         const int a0 = mix_addr<COL>(n, sh, sl, mix_slot_low(p, sh, j)), as = mix_step<COL>(sh, sh.s0);
+        const MixTw<T, R> w(tw, uint32_t(j));
         cx<T> a[R];
         a[0] = mix_ld(lds + a0);
 #pragma unroll
-        for (int k = 1; k < R; ++k) a[k] = cmul(mix_ld(lds + a0 + k * as), mix_ld(tw + uint32_t(j) * uint32_t(k)));
+        for (int k = 1; k < R; ++k) a[k] = cmul(mix_ld(lds + a0 + k * as), w(k));
         MixDft<T, R>::run(a);
 #pragma unroll
         for (int k = 0; k < R; ++k) store(sl, j + k * nb, a[k]);
@@ -579,9 +689,13 @@ PM_HD void mix_store_row(const MixRowOut<T>& o, int seq, int k, cx<T> v) {
 
 // the phases of a workgroup's work for thread `tid`: first stage, middle stage `s` (1 .. nstage-2), last stage.  The kernel puts a barrier
 // between phases; the emulator runs every thread of a phase before the next one
-template <typename T, bool COL, int MAXR, typename Fetch>
+template <typename T, bool COL, int MAXR, int UCAP = 1, typename Fetch>
 PM_HD void mix_run_first(const MixPlan& p, MixShape sh, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw, Fetch fetch) {
-    PM_MIX_RADIX_SWITCH(p.radix[0], (mix_first<T, COL, R>(p, sh, tid, nt, lds, tw, fetch)))
+    PM_MIX_RADIX_SWITCH(p.radix[0], (mix_first<T, COL, R, UCAP>(p, sh, tid, nt, lds, tw, fetch)))
+}
+template <typename T, bool COL, int MAXR>
+PM_HD void mix_run_first_lds(const MixPlan& p, MixShape sh, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw) {
+    PM_MIX_RADIX_SWITCH(p.radix[0], (mix_first_lds<T, COL, R>(p, sh, tid, nt, lds, tw)))
 }
 template <typename T, bool COL, int MAXR>
 PM_HD void mix_run_mid(const MixPlan& p, MixShape sh, int s, int tid, int nt, cx<T>* lds, const cx<T>* __restrict__ tw) {
@@ -621,10 +735,9 @@ struct MixFetchWhole {
         int q = i + shift;
         q = q >= n ? q - n : q;
         const uint32_t off = COL ? mix_mul24(uint32_t(q), pitch) + uint32_t(sl) : mix_mul24(uint32_t(sl), pitch) + uint32_t(q);
-        cx<T> x = mix_ld(base + off);
-        x.y *= ysign;
-        return x;
+        return mix_ld(base + off);      // raw: finish() applies the conjugation once every load of the trip is in flight
     }
+    PM_HD cx<T> finish(cx<T> x) const { return cx<T>{x.x, x.y * ysign}; }
 };
 
 template <typename T, bool COL, bool REAL>
@@ -648,6 +761,7 @@ struct MixFetch {
         x.y *= ysign;
         return ok ? x : cx<T>{T(0), T(0)};
     }
+    PM_HD cx<T> finish(cx<T> x) const { return x; }
 };
 
 // ... and the pupil synthesised while loading (rows only): amp exp(2 pi i k2 opd) from packed (amplitude, OPD) pairs or from the OPD map
@@ -679,6 +793,7 @@ struct MixFetchSynth {
         }
         return ok ? x : cx<T>{T(0), T(0)};
     }
+    PM_HD cx<T> finish(cx<T> x) const { return x; }
 };
 
 }  // namespace pm

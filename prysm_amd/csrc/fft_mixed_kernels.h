@@ -43,6 +43,32 @@ __device__ __forceinline__ void mix_store_col(const ColStoreNat<T>& p, int k, in
     }
 }
 
+// ... and the store of the plain 2-D transform -- every bin kept (rotations only), no multiplier, complex output, a full tile: the
+// element's row is one add and one unsigned min (k + shift wrapped), its column depends on the butterfly only, the offset is one 24-bit
+// multiply-add.  The general form above costs ~25 vector instructions and six uniform branches PER ELEMENT inside the unrolled butterfly
+// (the last stage of a column kernel of the class of 20 came to 80 instructions per sample against 17 in the row kernel).
+template <typename T>
+struct MixColStoreWhole {
+    cx<T>* dst;
+    uint32_t ld;
+    int ny, sy, nx, sx;      // lengths and rotations of the output rows / columns (AxisMap n, shift)
+    T sr, si;                // scale, and -scale for a conjugated output
+    int c0;
+    __device__ __forceinline__ void operator()(int sl, int k, cx<T> v) const {
+        const uint32_t qy0 = uint32_t(k + sy), qy1 = qy0 - uint32_t(ny), qy = qy0 < qy1 ? qy0 : qy1;
+        const uint32_t qx0 = uint32_t(c0 + sl + sx), qx1 = qx0 - uint32_t(nx), qx = qx0 < qx1 ? qx0 : qx1;
+        mix_st(dst + (mix_mul24(qy, ld) + qx), cx<T>{v.x * sr, v.y * si});
+    }
+};
+
+// start-up stagger (MixShape::stagger)
+__device__ __forceinline__ void mix_stagger_delay(MixShape sh) {
+    if (sh.stagger > 0 && int(blockIdx.x) < sh.first_round) {
+        const unsigned h = (blockIdx.x * 2654435761u) >> 29;
+        for (unsigned i = 0; i < h * unsigned(sh.stagger); ++i) __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 // LDS layout of the row mode (round 4): the sequences of the workgroup INTERLEAVED, [point][sequence] with lanes across the sequences first
 // -- the column mode's layout and lane order (template argument COL = true of the stage functions) on top of the row mode's global
 // addressing (the Fetch / Store functors).  With [sequence][point] the lanes of a wave ran along ONE sequence and met the digit-reversed
@@ -75,7 +101,7 @@ __global__ __launch_bounds__(512) void mix_rows_kernel(const MixPlan* __restrict
         mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     } else if (whole) {
         const MixFetchWhole<T, false> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax.n, in.ax.shift, ysign};
-        mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
+        mix_run_first<T, true, MAXR, 3>(p, sh, tid, nt, lds, tw, fetch);
     } else {
         const MixFetch<T, false, false> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, ysign, nvalid};
         mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
@@ -115,6 +141,7 @@ __global__ __launch_bounds__(NTMAX) void mix_cols_kernel(const MixPlan* __restri
     if (c0 >= in.nseq) return;
     const int nvalid = in.nseq - c0 < sh.seqs ? in.nseq - c0 : sh.seqs;
     const T ysign = in.conj ? T(-1) : T(1);
+    mix_stagger_delay(sh);
     const bool whole_in = in.ax.off == 0 && in.ax.len == in.ax.n && nvalid == sh.seqs;
     if (in.real) {
         const MixFetch<T, true, true> fetch{reinterpret_cast<const T*>(in.src) + c0, uint32_t(in.s_i), in.ax, ysign, nvalid};
@@ -133,7 +160,11 @@ __global__ __launch_bounds__(NTMAX) void mix_cols_kernel(const MixPlan* __restri
         __syncthreads();
     }
     const bool whole = out.ay.off == 0 && out.ay.len == out.ay.n && out.ax.off == 0 && out.ax.len == out.ax.n;
-    if (nvalid == sh.seqs && whole) {
+    if (nvalid == sh.seqs && whole && out.mul_kind == MUL_NONE && out.epilogue == EPI_NONE) {
+        const MixColStoreWhole<T> store{reinterpret_cast<cx<T>*>(out.dst), uint32_t(out.ld), out.ay.n, out.ay.shift, out.ax.n, out.ax.shift,
+                                        out.scale, out.conj ? -out.scale : out.scale, c0};
+        mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
+    } else if (nvalid == sh.seqs && whole) {
         auto store = [&](int sl, int k, cx<T> v) { mix_store_col<false>(out, k, c0 + sl, v); };
         mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
     } else {
@@ -144,6 +175,92 @@ __global__ __launch_bounds__(NTMAX) void mix_cols_kernel(const MixPlan* __restri
     }
 }
 
+
+#ifdef PM_EXPERIMENTS
+// The column pass as PERSISTENT workgroups (round 4; experiment build -- it lost: complex64 3000^2 77.2 -> 83.0 us, 3600^2 106 -> 115,
+// complex128 2000^2 64.6 -> 70.4, only 4000^2 128 -> 126, profiles/r04/exp_mix_pers.log -- the wait for the prefetched pieces also waits
+// for the last stage's stores, which share the counter, and 512-thread workgroups hide less): where a tile fills the LDS there is one workgroup per CU, and with one tile per
+// workgroup the CU loads (nothing to compute), computes (memory idle) and stores in turn -- 3000-point complex64 columns: 3.9 us + 6.4 us +
+// 3.9 us per tile, and every CU in the same phase at the same time.  Here a workgroup walks over tiles: the loads of the NEXT tile are
+// issued before the last stage of this one, as 16 B pieces held in registers (PRE per thread: the whole tile), and land while the last stage
+// runs; the stores of the last stage drain under the next tile's first stages.  The tile is copied into its LDS slots and the first stage
+// runs in place (mix_first_lds), so the prefetch does not depend on the factorisation.  Needs whole tiles (ncols a multiple of the tile), a
+// complex input whose view keeps every element, 16 B aligned rows, and an output view that keeps every bin.
+// 512 threads: the prefetched tile is 12 - 20 pieces = 48 - 80 registers per thread on top of the last stage's, which a 1024-thread
+// workgroup (128 registers) spills -- and a spilled prefetch register is a wait for its load.
+template <typename T, int MAXR, int PRE>
+__global__ __launch_bounds__(512) void mix_cols_pers_kernel(const MixPlan* __restrict__ pp, MixShape sh, DirectIn<T> in, ColStoreNat<T> out,
+                                                              const cx<T>* __restrict__ tw, int log_g, int groups) {
+    const MixPlan& p = *pp;
+    extern __shared__ __align__(16) char mix_smem[];
+    cx<T>* lds = reinterpret_cast<cx<T>*>(mix_smem);
+    typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
+    constexpr int EPV = 8 / int(sizeof(T));                 // complex elements per 16 B piece: 2 (complex64) or 1 (complex128)
+    const int tid = threadIdx.x, nt = blockDim.x, n = p.n;
+    const int log_upr = sh.log_seqs - (EPV == 2 ? 1 : 0);   // pieces per row of the tile (a power of two)
+    const int nu = n << log_upr;                            // pieces of a tile
+    const T ysign = in.conj ? T(-1) : T(1);
+    const uint32_t pitch = uint32_t(in.s_i);
+    auto tile_of = [&](int vb) {
+        const int xcd = vb & 7, slot = vb >> 3;
+        return ((slot >> log_g) << (log_g + 3)) + (xcd << log_g) + (slot & ((1 << log_g) - 1));
+    };
+    V pre[PRE];
+    auto prefetch = [&](int tile) {
+        const cx<T>* base = in.src + tile * sh.seqs;
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+            const int u = tid + q * nt;
+            if (u < nu) {
+                const int i = u >> log_upr, part = u & ((1 << log_upr) - 1);
+                const uint32_t r0 = uint32_t(i + in.ax.shift), r1 = r0 - uint32_t(n), r = r0 < r1 ? r0 : r1;
+                pre[q] = *reinterpret_cast<const V*>(base + (mix_mul24(r, pitch) + uint32_t(part * EPV)));
+            }
+        }
+    };
+    auto copy_in = [&]() {
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+            const int u = tid + q * nt;
+            if (u < nu) {
+                const int i = u >> log_upr, part = u & ((1 << log_upr) - 1);
+                V v = pre[q];
+                if (EPV == 2) { v[1] *= ysign; v[3] *= ysign; } else { v[1] *= ysign; }
+                *reinterpret_cast<V*>(lds + ((mix_slot_of(p, sh, i) << sh.log_seqs) + part * EPV)) = v;
+            }
+        }
+    };
+    const int nstage = p.nstage;
+    const bool lean = out.mul_kind == MUL_NONE && out.epilogue == EPI_NONE;
+    bool have = false;
+    for (int vb = blockIdx.x; vb < groups; vb += gridDim.x) {
+        const int tile = tile_of(vb);
+        if (tile >= sh.pers_tiles) continue;
+        if (!have) prefetch(tile);
+        copy_in();
+        __syncthreads();
+        mix_run_first_lds<T, true, MAXR>(p, sh, tid, nt, lds, tw);
+        __syncthreads();
+        for (int s = 1; s + 1 < nstage; ++s) {
+            mix_run_mid<T, true, MAXR>(p, sh, s, tid, nt, lds, tw);
+            __syncthreads();
+        }
+        const int nvb = vb + int(gridDim.x), ntile = nvb < groups ? tile_of(nvb) : sh.pers_tiles;
+        have = ntile < sh.pers_tiles;
+        if (have) prefetch(ntile);
+        const int c0 = tile * sh.seqs;
+        if (lean) {
+            const MixColStoreWhole<T> store{reinterpret_cast<cx<T>*>(out.dst), uint32_t(out.ld), out.ay.n, out.ay.shift, out.ax.n, out.ax.shift,
+                                            out.scale, out.conj ? -out.scale : out.scale, c0};
+            mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
+        } else {
+            auto store = [&](int sl, int k, cx<T> v) { mix_store_col<false>(out, k, c0 + sl, v); };
+            mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
+        }
+        __syncthreads();
+    }
+}
+#endif
 
 // Middle pass of fft2 -> x H -> ifft2 on a composite column length (fft_mixed.h, the transposed stages): a tile of adjacent columns of the
 // natural intermediate goes through forward stages, the multiplier and the transposed stages without leaving the LDS, and comes back as
@@ -215,14 +332,22 @@ __global__ __launch_bounds__(NTMAX) void mix_cols_mul_kernel(const MixPlan* __re
 static constexpr size_t kMixLdsHard = 156 * 1024;
 
 static inline int round_up64(int v) { return (v + 63) & ~63; }
+// workgroups that start together when the launch begins (256 CUs; LDS and the 32 wave slots of a CU bound the workgroups per CU)
+static inline int mix_first_round(size_t lds, int nt) {
+    const int by_lds = lds ? int(size_t(160) * 1024 / lds) : 8, by_waves = 2048 / (nt < 64 ? 64 : nt);
+    const int per_cu = by_lds < by_waves ? by_lds : by_waves;
+    return 256 * (per_cu < 1 ? 1 : per_cu);
+}
 
 // threads of a workgroup: one butterfly per thread in the stage with the most butterflies, within [64, cap]
-static inline int mix_threads(const MixPlan& p, int seqs, int cap, int forced) {
+static inline int mix_threads(const MixPlan& p, int seqs, int cap, int forced, bool even = true) {
     int rmin = kMixMaxRadix;
     for (int s = 0; s < p.nstage; ++s) rmin = p.radix[s] < rmin ? p.radix[s] : rmin;
     const int most = seqs * (p.n / rmin);
     int nt = round_up64(most);
-    // several rounds per stage: even them out
+    // several rounds per stage: even them out (not in the row kernel, whose first stage takes its trips at once: 3000-point rows 75.4 us at
+    // 256 threads against 78.3 at 192, profiles/r04/exp_mix_shape.log)
+    if (nt > cap && !even) nt = cap;
     if (nt > cap) {
         const int rounds = (most + cap - 1) / cap;
         nt = round_up64((most + rounds - 1) / rounds);
@@ -277,6 +402,24 @@ int mix_rows_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, c
 template <typename T, int MAXR>
 int mix_cols_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const ColStoreNat<T>& out, const cx<T>* tw, int log_g, int groups, int nt,
                          size_t lds, hipStream_t st) {
+#ifdef PM_EXPERIMENTS
+    if (sh.pers_tiles > 0) {
+        // 16 B pieces per thread: 12 cover a 96 KiB tile on 512 threads, 16 a 128 KiB one (more would spill)
+        nt = 512;
+        const int pieces = int((lds + size_t(nt) * 16 - 1) / (size_t(nt) * 16));
+        const int grid = groups < 256 ? groups : 256;
+        if (pieces <= 12) {
+            const int rc = mix_set_lds(mix_cols_pers_kernel<T, MAXR, 12>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((mix_cols_pers_kernel<T, MAXR, 12>), dim3(grid), dim3(nt), lds, st, p, sh, in, out, tw, log_g, groups);
+        } else {
+            const int rc = mix_set_lds(mix_cols_pers_kernel<T, MAXR, 16>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL((mix_cols_pers_kernel<T, MAXR, 16>), dim3(grid), dim3(nt), lds, st, p, sh, in, out, tw, log_g, groups);
+        }
+        return int(hipGetLastError());
+    }
+#endif
     if constexpr (mix_cols_wide<T>(MAXR)) {
         if (nt > 512) {
             const int rc = mix_set_lds(mix_cols_kernel<T, MAXR, 1024>, lds);
@@ -308,8 +451,9 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     // workgroup), within 48 KiB of LDS so that three workgroups share a CU and their load / transform / store phases overlap.  Measured
     // (profiles/r03/exp_mix_sweep.log, 2-D transform, us): 1000^2 complex64 19.8 at 2 rows against 22.2 at 3; 4000^2 167 at 1 row
     // (32 KiB) against 182 at 2; 3000^2 97 at 1 or 2 and 115 at 4; complex128 3000^2 206 at 1 against 219 at 2
-    int seqs = 2048 / n;
-    if (seqs < 2) seqs = 2;
+    // ... and again after round 4's changes (profiles/r04/exp_mix_shape.log, 1 / 2 rows at 256 threads): 3000^2 75.4 / 80.0, 4000^2 126.0 /
+    // 144.9, complex128 3000^2 165.7 / 193.0, 2000^2 38.4 / 37.5, 1000^2 17.9 / 18.2 -- one row from 1024 points (more workgroups per CU)
+    int seqs = n >= 1024 ? 1 : 2048 / n;
     while (seqs > 1 && size_t(seqs) * per > size_t(48) * 1024) --seqs;
     if (tuning().mix_seqs > 0) seqs = tuning().mix_seqs;
     while (seqs > 1 && seqs / 2 >= nseq) seqs /= 2;
@@ -322,12 +466,17 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     MixShape sh{seqs, 0};
     while ((1 << sh.log_seqs) < seqs) ++sh.log_seqs;
     mix_pick_pads(p, sizeof(cx<T>), true, sh);
+#ifdef PM_EXPERIMENTS
+    sh.ablate = tuning().mix_ablate;
+#endif
+    sh.stagger = tuning().mix_stagger;
     const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
     const size_t lds = size_t(seqs) * size_t(sh.npad) * sizeof(cx<T>);
     MixRowOut<T> ro{out, out_ld, AxisMap{n, n, 0, 0}, T(1), 0, 0};
     if (o) ro = MixRowOut<T>{o->dst, o->ld, o->ax, o->scale, o->conj, 1};
-    const int groups = (nseq + seqs - 1) / seqs, nt = mix_threads(p, seqs, 256, tuning().mix_nt);
+    const int groups = (nseq + seqs - 1) / seqs, nt = mix_threads(p, seqs, 256, tuning().mix_nt, false);
+    sh.stagger = 0;
     if (p.maxr <= 10) return mix_rows_launch<T, 10>(pd, sh, in, ro, tw, groups, nt, lds, st);
     if (p.maxr <= 16) return mix_rows_launch<T, 16>(pd, sh, in, ro, tw, groups, nt, lds, st);
     return mix_rows_launch<T, 20>(pd, sh, in, ro, tw, groups, nt, lds, st);
@@ -349,6 +498,9 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     // on one XCD, see log_g below), fewer when the LDS cannot hold four columns.  Measured (same log): 1000-point columns complex64 10.4 us
     // at 4 against 12.9 at 8 (two workgroups per CU instead of four); 3000-point columns 78 at 4 (one workgroup per CU) against 102 at 2
     int tc = 4;
+    // ... eight columns of complex64 (whole 64 B pieces) where four would leave the LDS half empty and eight fit: 2000^2 35.2 us against 37.6
+    // (complex128 1000^2, the same bytes: 25.0 against 23.6 -- stays at four)
+    if (sizeof(T) == 4 && per > size_t(10) * 1024 && 8 * per <= kMixLdsHard) tc = 8;
     while (tc > 1 && size_t(tc) * per > kMixLdsHard) tc /= 2;
     if (tuning().mix_tc > 0) {
         tc = 1;
@@ -359,6 +511,10 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     MixShape sh{tc, 0};
     while ((1 << sh.log_seqs) < tc) ++sh.log_seqs;
     mix_pick_pads(p, sizeof(cx<T>), true, sh);
+#ifdef PM_EXPERIMENTS
+    sh.ablate = tuning().mix_ablate;
+#endif
+    sh.stagger = tuning().mix_stagger;
     const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
     const size_t lds = size_t(tc) * size_t(sh.npad) * sizeof(cx<T>);
@@ -376,6 +532,15 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     const int forced = tuning().mix_ntc > 0 ? tuning().mix_ntc : (one_wg ? 1024 : 0);
     const int cap = (forced > 512 && mix_cols_wide<T>(cls)) ? 1024 : 512;
     const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc, cap, forced);
+    sh.first_round = mix_first_round(lds, nt);
+    // the stagger is for one workgroup per CU and several rounds of them (MixShape::stagger).  Measured, column kernel only, 2-D transform us
+    // at 0 / 4 / 8 units (profiles/r04/exp_mix_stagger.log): complex64 3000^2 75.4 / 74.3 / 76.6, 4000^2 131.2 / 129.7 / 127.6, complex128
+    // 3000^2 167.1 / 166.4 / 160.8, 2000^2 62.7 / 59.6 / 65.3; a single round only pays the delay (complex64 2000^2 35.6 / 38.3 / 43.6)
+    if (lds <= size_t(80) * 1024 || tiles <= sh.first_round) sh.stagger = 0;
+    // persistent workgroups (mix_cols_pers_kernel) where a CU holds one tile: more tiles than CUs, whole tiles, a plain complex input
+    const bool whole_in = !in.real && in.ax.off == 0 && in.ax.len == in.ax.n, whole_out = out.ay.off == 0 && out.ay.len == out.ay.n && out.ax.off == 0 && out.ax.len == out.ax.n;
+    const bool aligned = (reinterpret_cast<uintptr_t>(in.src) & 15) == 0 && ((size_t(in.s_i) * sizeof(cx<T>)) & 15) == 0 && size_t(tc) * sizeof(cx<T>) >= 16;
+    if (tuning().mix_pers && lds > size_t(80) * 1024 && lds <= size_t(128) * 1024 && tiles > 256 && ncols % tc == 0 && whole_in && whole_out && aligned && out.bstride == 0) sh.pers_tiles = tiles;
     if (p.maxr <= 10) return mix_cols_launch<T, 10>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
     if (p.maxr <= 16) return mix_cols_launch<T, 16>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
     return mix_cols_launch<T, 20>(pd, sh, in, out, tw, log_g, groups, nt, lds, st);
@@ -423,6 +588,10 @@ int mix_cols_mul_impl(const DirectIn<T>& in, const MidMul<T>& m, cx<T>* dst, int
     MixShape sh{tc, 0};
     while ((1 << sh.log_seqs) < tc) ++sh.log_seqs;
     mix_pick_pads(p, sizeof(cx<T>), true, sh);
+#ifdef PM_EXPERIMENTS
+    sh.ablate = tuning().mix_ablate;
+#endif
+    sh.stagger = tuning().mix_stagger;
     const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
     const size_t lds = size_t(tc) * size_t(sh.npad) * sizeof(cx<T>);

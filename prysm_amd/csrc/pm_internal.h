@@ -168,6 +168,9 @@ struct Tuning {
                               // chain 4096^2 complex128 383 / 430 / 365 / 355, complex64 186 / 176 / 175 / 165, 2048^2 complex128 90 / 94 / 86 / 81
     int engine_p8 = 0;        // experiment builds: the radix-8 engine (8 points per thread) for the folded 4096^2 complex64 transform: bit 0 its row pass,
                               // bit 1 its column pass, bit 2 a 64-register cap (eight waves per SIMD) instead of 128
+    int mix_pers = 0;         // experiment builds: its column pass as persistent workgroups with the next tile prefetched where a CU holds one tile (mix_cols_pers_kernel)
+    int mix_stagger = 4;      // ... start-up stagger of the column kernel's workgroups in units of 512 cycles x 0 .. 7 where a CU holds one tile (fft_mixed.h MixShape::stagger); 0 = off
+    int mix_ablate = 0;       // experiment builds: timing-only ablations of the mixed-radix kernels (fft_mixed.h MixShape::ablate; results are wrong)
     int two_units = 0;        // experiment builds: two units per workgroup in the passes of a 2048-point complex64 transform (bit 0 rows, bit 1 columns)
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)

@@ -42,14 +42,21 @@ static double run_case(int n, int nseq, bool col, int seqs, int nt, int shift, i
         MixFetchWhole<T, true> wc{base0, uint32_t(nseq), n, shift, T(1)};
         MixFetchWhole<T, false> wr{base0, uint32_t(n), n, shift, T(1)};
         const bool whole = nvalid == seqs && (g % 2 == 0);     // alternate the two loaders over the groups
-        auto fetch = [&](int sl, int i) { return whole ? (col ? wc(sl, i) : wr(sl, i)) : (col ? fc(sl, i) : fr(sl, i)); };
+        auto fetch = [&](int sl, int i) { return whole ? (col ? wc.finish(wc(sl, i)) : wr.finish(wr(sl, i))) : (col ? fc(sl, i) : fr(sl, i)); };
         auto store = [&](int sl, int k, cx<T> v) {
             if (seq0 + sl >= nseq) return;
             if (col) y[size_t(k) * nseq + seq0 + sl] = v; else y[size_t(seq0 + sl) * n + k] = v;
         };
         auto run = [&](auto colc) {
             constexpr bool COL = decltype(colc)::value;
-            for (int tid = 0; tid < nt; ++tid) mix_run_first<T, COL, 20>(p, sh, tid, nt, lds.data(), tw.data(), fetch);
+            if (COL && col && nvalid == seqs && (g % 4 == 1 || g % 4 == 2)) {
+                // the persistent column kernel's way in: the tile copied to its LDS slots, then the first stage in place
+                for (int i = 0; i < n; ++i)
+                    for (int sl = 0; sl < seqs; ++sl) lds[(size_t(mix_slot_of(p, sh, i)) << sh.log_seqs) + sl] = wc.finish(wc(sl, i));
+                for (int tid = 0; tid < nt; ++tid) mix_run_first_lds<T, COL, 20>(p, sh, tid, nt, lds.data(), tw.data());
+            } else {
+                for (int tid = 0; tid < nt; ++tid) mix_run_first<T, COL, 20, 3>(p, sh, tid, nt, lds.data(), tw.data(), fetch);
+            }
             for (int ph = 1; ph + 1 < p.nstage; ++ph)
                 for (int tid = 0; tid < nt; ++tid) mix_run_mid<T, COL, 20>(p, sh, ph, tid, nt, lds.data(), tw.data());
             for (int tid = 0; tid < nt; ++tid) mix_run_last<T, COL, 20>(p, sh, tid, nt, lds.data(), store);
