@@ -43,10 +43,42 @@ struct ColCfgSel {
     using type = FftCfg<T, LOGN, CI, E, BO, COMP>;
 };
 
+// log_g with the start-up stagger of fft_kernel packed above it: bits 8-15 the units, bits 16+ the workgroups per CU (those that start with
+// the launch = 256 CUs x that); no stagger for a launch of a single round
+int pm_fft_stagger(int pass);       // capi.hip: the knobs fft_stagger (row kernels) / fft_stagger_col (column kernels) / fft_stagger_mid
+static inline int engine_log_g(int log_g, int grid, size_t lds_bytes, int nt, int pass) {      // pass: 0 rows, 1 columns, 2 the middle pass of a fused chain, 3 / 4 the real-input row / Hermitian column kernels (fft_r2c.h)
+    const int by_lds = lds_bytes ? int(size_t(160) * 1024 / lds_bytes) : 8, by_waves = 2048 / nt;
+    const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
+    if (grid <= 256 * per_cu) return log_g;
+    // auto (knob < 0): 8 units where a CU holds one workgroup, 1 where it holds more (they already overlap each other).  Measured
+    // (profiles/r04/exp_fft_stagger.log, 2-D transform us without / with): 4096^2 complex64 93.5 / 92.8 (95.4 / 93.7 on another box),
+    // complex128 210.3 / 206.0, 8192^2 complex64 493 / 474, complex128 1033 / 1013; twice the units already lose (4096^2 complex128 220)
+    int stg = pm_fft_stagger(pass);
+    // (two column workgroups per CU: 93.4 against 93.3 without -- nothing; the Hermitian column kernel, one 1024-thread workgroup per CU:
+    // 8192^2 real input 357 -> 344 us at 8 and 338 at 16 on one box, 392 -> 385 at 8 and 391 at 16 on another -- exp_mtf_stagger*.log;
+    // the real-input row kernel: nothing at any setting)
+    if (stg < 0) stg = pass == 3 ? 0 : (per_cu == 1 ? 8 : (pass == 0 ? 1 : 0));
+    if (stg == 0) return log_g;
+    return log_g | ((stg & 255) << 8) | (per_cu << 16);
+}
+
+__device__ __forceinline__ int engine_stagger(int log_g_packed) {
+    const int stg = (log_g_packed >> 8) & 255;
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;     // dispatch order: x first
+    if (stg && int(lin) < ((log_g_packed >> 16) << 8)) {
+        const unsigned h = (lin * 2654435761u) >> 29;
+        for (unsigned i = 0; i < h * unsigned(stg); ++i) __builtin_amdgcn_s_sleep(8);
+    }
+    return log_g_packed & 255;
+}
+
 template <typename C, bool COL, int VAR, typename L, typename S>
-__global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp, const cx<typename C::T>* __restrict__ tw, const int log_g) {
+__global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp, const cx<typename C::T>* __restrict__ tw, const int log_g_packed) {
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
+    // start-up stagger (knob fft_stagger, packed above the group shift by engine_log_g): the workgroups that start with the launch wait
+    // 0 .. 7 x units x 512 cycles by a hash of their index, so that the load / transform / store phases of a CU's workgroups overlap
+    const int log_g = engine_stagger(log_g_packed);
     int unit = group_remap(blockIdx.x, gridDim.x, log_g);
     if (COL) unit = unit * C::BO + pos.bo;
     cx<typename C::T> v[C::E][C::P];
@@ -363,10 +395,11 @@ __global__ void __launch_bounds__(C::NT, 1)
 template <typename C, int KIND, typename S = ColStoreTiled<typename C::T>>
 __global__ void __launch_bounds__(C::NT, 4)
     fft_col_mul_lean_kernel(const ColLoadTiled<typename C::T> lp0, const MidMul<typename C::T> mp0, const S sp0,
-                            const cx<typename C::T>* __restrict__ tw, const int log_g) {
+                            const cx<typename C::T>* __restrict__ tw, const int log_g_packed) {
     using T = typename C::T;
     static_assert(C::BO == 1, "one tile per workgroup");
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
+    const int log_g = engine_stagger(log_g_packed);
     constexpr int TC = C::CI * C::E, ES = int(sizeof(cx<T>));
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
     const auto lp = at_batch(lp0, blockIdx.y);
@@ -485,7 +518,7 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& 
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    int(C::LDS_BYTES));
                 if (e != hipSuccess) return int(e);
-                hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), C::LDS_BYTES, st, lp, mp, sp, tw, log_g);
+                hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), C::LDS_BYTES, st, lp, mp, sp, tw, engine_log_g(log_g, grid, C::LDS_BYTES, C::NT, 2));
                 return int(hipGetLastError());
             }
         }
@@ -562,7 +595,7 @@ int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, 
         }
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
+    hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), LDSB, st, lp, sp, tw, engine_log_g(log_g, grid, LDSB, C::NT, COL ? 1 : 0));
     return int(hipGetLastError());
 }
 
@@ -593,7 +626,7 @@ int launch_fold_one(const RowLoadNat<T>& lp, const RowStoreFold<T>& sp, const cx
     }
     const int grid = (npairs + C::BO - 1) / C::BO;
     if (grid <= 0 || nbatch <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
+    hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), LDSB, st, lp, sp, tw, engine_log_g(log_g, grid, LDSB, C::NT, 0));
     return int(hipGetLastError());
 }
 template <typename T>

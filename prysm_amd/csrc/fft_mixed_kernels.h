@@ -286,6 +286,7 @@ __global__ __launch_bounds__(NTMAX) void mix_cols_mul_kernel(const MixPlan* __re
     const int c0 = tile * sh.seqs, tid = threadIdx.x, nt = blockDim.x;
     if (c0 >= in.nseq) return;
     const int nvalid = in.nseq - c0 < sh.seqs ? in.nseq - c0 : sh.seqs;
+    mix_stagger_delay(sh);
     const bool whole_in = in.ax.off == 0 && in.ax.len == in.ax.n && nvalid == sh.seqs;
     if (whole_in) {
         const MixFetchWhole<T, true> fetch{in.src + c0, uint32_t(in.s_i), in.ax.n, in.ax.shift, T(1)};
@@ -604,6 +605,8 @@ int mix_cols_mul_impl(const DirectIn<T>& in, const MidMul<T>& m, cx<T>* dst, int
     const int forced = tuning().mix_ntc > 0 ? tuning().mix_ntc : (one_wg ? 1024 : 0);
     const int cap = (forced > 512 && mix_cols_wide<T>(cls)) ? 1024 : 512;
     const int groups = (tiles + round - 1) / round * round, nt = mix_threads(p, tc, cap, forced);
+    sh.first_round = mix_first_round(lds, nt);
+    if (lds <= size_t(80) * 1024 || tiles <= sh.first_round) sh.stagger = 0;     // as mix_cols_impl
     const MixMul<T> mm{m.kind, m.conj, m.mul, m.mul_x, m.ld, ncols};
     if (p.maxr <= 10) return mix_cols_mul_launch_impl<T, 10>(pd, sh, in, mm, dst, uint32_t(dst_pitch), tw, log_g, groups, nt, lds, st);
     if (p.maxr <= 16) return mix_cols_mul_launch_impl<T, 16>(pd, sh, in, mm, dst, uint32_t(dst_pitch), tw, log_g, groups, nt, lds, st);

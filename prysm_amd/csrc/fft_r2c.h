@@ -43,8 +43,9 @@ PM_HD cx<T> w32(int m) {
 
 template <typename C, typename L, bool FOLD>
 __global__ void __launch_bounds__(C::NT) fft_row_r2c_kernel(const L lp, const R2CRowStore<typename C::T> sp,
-                                                            const cx<typename C::T>* __restrict__ tw, const int log_g) {
+                                                            const cx<typename C::T>* __restrict__ tw, const int log_g_packed) {
     using T = typename C::T;
+    const int log_g = engine_stagger(log_g_packed);
     static_assert(C::COMP == 1 && C::CI == 1, "row mode, complex exchange");
     static_assert(!FOLD || C::E == 2, "the fold pairs the two rows of a thread");
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
@@ -203,8 +204,9 @@ PM_HD void herm_store_fast(const HermStore<typename C::T>& p, int col0, ThreadPo
 
 template <typename C, int EPI>
 __global__ void __launch_bounds__(C::NT) fft_col_herm_kernel(const ColLoadTiled<typename C::T> lp0, const HermStore<typename C::T> sp0,
-                                                            const cx<typename C::T>* __restrict__ tw, const int log_g) {
+                                                            const cx<typename C::T>* __restrict__ tw, const int log_g_packed) {
     using T = typename C::T;
+    const int log_g = engine_stagger(log_g_packed);
     constexpr int TC = C::CI * C::E;
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
@@ -309,7 +311,7 @@ int launch_row_r2c_one(const RowLoadNat<T>& lp, const R2CRowStore<T>& sp, const 
     const int per_wg = C::BO * (FOLD ? 1 : C::E);    // units: rows, or row PAIRS of a folded transform
     const int grid = (nunits + per_wg - 1) / per_wg;
     if (grid <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), LDSB, st, lp, sp, tw, engine_log_g(log_g, grid, LDSB, C::NT, 3));
     return int(hipGetLastError());
 }
 
@@ -360,7 +362,7 @@ int launch_col_herm_epi(const ColLoadTiled<T>& lp, const HermStore<T>& sp, const
     }
     const int grid = (ntiles + C::BO - 1) / C::BO;
     if (grid <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(grid, sp.plane >= 0 ? 2 : 1), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
+    hipLaunchKernelGGL(kern, dim3(grid, sp.plane >= 0 ? 2 : 1), dim3(C::NT), LDSB, st, lp, sp, tw, engine_log_g(log_g, grid * (sp.plane >= 0 ? 2 : 1), LDSB, C::NT, 4));
     return int(hipGetLastError());
 }
 

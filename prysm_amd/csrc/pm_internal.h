@@ -168,6 +168,7 @@ struct Tuning {
                               // chain 4096^2 complex128 383 / 430 / 365 / 355, complex64 186 / 176 / 175 / 165, 2048^2 complex128 90 / 94 / 86 / 81
     int engine_p8 = 0;        // experiment builds: the radix-8 engine (8 points per thread) for the folded 4096^2 complex64 transform: bit 0 its row pass,
                               // bit 1 its column pass, bit 2 a 64-register cap (eight waves per SIMD) instead of 128
+    int fft_stagger = -1, fft_stagger_col = -1, fft_stagger_mid = 0, fft_stagger_r2c = 0, fft_stagger_herm = -1;    // start-up stagger of the engine's plain row / column kernels (fft_kernels.h engine_log_g), units of 512 cycles x 0 .. 7; 0 = off, -1 = auto
     int mix_pers = 0;         // experiment builds: its column pass as persistent workgroups with the next tile prefetched where a CU holds one tile (mix_cols_pers_kernel)
     int mix_stagger = 4;      // ... start-up stagger of the column kernel's workgroups in units of 512 cycles x 0 .. 7 where a CU holds one tile (fft_mixed.h MixShape::stagger); 0 = off
     int mix_ablate = 0;       // experiment builds: timing-only ablations of the mixed-radix kernels (fft_mixed.h MixShape::ablate; results are wrong)
