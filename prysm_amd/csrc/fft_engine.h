@@ -154,6 +154,16 @@ struct Dft<T, 16> {
 // remaining W^((4a+b) b0) are products (one extra rounding).  They depend on the thread slot only, not on
 // the sequence.
 // ---------------------------------------------------------------------------
+// which configurations take W and W^4 from the table and form the other four twiddles of a butterfly as products (PM_TW_TABLE: none)
+template <typename C>
+constexpr bool tw_powers() {
+#ifdef PM_TW_TABLE
+    return false;
+#else
+    return !(sizeof(typename C::T) == 4 && C::LOGN == 12 && C::CI == 1);
+#endif
+}
+
 template <typename C, int S>
 struct StageTw {
     static constexpr int R = C::radix(S), Q = C::P / R;
@@ -172,10 +182,17 @@ PM_HD void load_stage_tw(StageTw<C, S>& w, int t, const cx<typename C::T>* __res
             if constexpr (R == 2) {
                 w.wb[q][1] = tw[base];
             } else {
+                if constexpr (!tw_powers<C>()) {
 #pragma unroll
-                for (int a = 1; a < R / 4; ++a) w.wa[q][a] = tw[4 * a * base];
+                    for (int a = 1; a < R / 4; ++a) w.wa[q][a] = tw[4 * a * base];
 #pragma unroll
-                for (int b = 1; b < 4; ++b) w.wb[q][b] = tw[b * base];
+                    for (int b = 1; b < 4; ++b) w.wb[q][b] = tw[b * base];
+                } else {
+                // W and W^4 only; stage_compute forms W^2, W^3, W^8, W^12 (stage_tw_powers): in the last stage of a 4096-point transform the
+                // lanes' W^8 and W^12 entries are 32 and 48 different 128 B lines per wave-load, against 4 for W
+                if constexpr (R / 4 > 1) w.wa[q][1] = tw[4 * base];
+                w.wb[q][1] = tw[base];
+                }
             }
         }
     }
@@ -196,18 +213,34 @@ PM_HD void stage_compute(cx<typename C::T> (&v)[C::E][C::P], const StageTw<C, S>
 #pragma unroll
                 for (int e = E0; e < E1; ++e) v[e][Q + q] = cmul(v[e][Q + q], w.wb[q][1]);
             } else {
+                // the twiddles of this butterfly: W^b (b < 4) and W^(4a) (a < R/4); the loader brought W and W^4, the other powers are two
+                // or four complex products here (PM_TW_TABLE: all six from the table, as until round 4)
+                cx<T> wa[4], wb[4];
+                wb[1] = w.wb[q][1];
+                if constexpr (R / 4 > 1) wa[1] = w.wa[q][1];
+                if constexpr (!tw_powers<C>()) {
+                    wb[2] = w.wb[q][2];
+                    wb[3] = w.wb[q][3];
+                    if constexpr (R / 4 > 2) wa[2] = w.wa[q][2];
+                    if constexpr (R / 4 > 3) wa[3] = w.wa[q][3];
+                } else {
+                    wb[2] = cmul(wb[1], wb[1]);
+                    wb[3] = cmul(wb[2], wb[1]);
+                    if constexpr (R / 4 > 2) wa[2] = cmul(wa[1], wa[1]);
+                    if constexpr (R / 4 > 3) wa[3] = cmul(wa[2], wa[1]);
+                }
 #pragma unroll
                 for (int a = 1; a < R / 4; ++a) {
 #pragma unroll
-                    for (int e = E0; e < E1; ++e) v[e][(4 * a) * Q + q] = cmul(v[e][(4 * a) * Q + q], w.wa[q][a]);
+                    for (int e = E0; e < E1; ++e) v[e][(4 * a) * Q + q] = cmul(v[e][(4 * a) * Q + q], wa[a]);
                 }
 #pragma unroll
                 for (int b = 1; b < 4; ++b) {
 #pragma unroll
-                    for (int e = E0; e < E1; ++e) v[e][b * Q + q] = cmul(v[e][b * Q + q], w.wb[q][b]);
+                    for (int e = E0; e < E1; ++e) v[e][b * Q + q] = cmul(v[e][b * Q + q], wb[b]);
 #pragma unroll
                     for (int a = 1; a < R / 4; ++a) {
-                        const cx<T> wab = cmul(w.wa[q][a], w.wb[q][b]);
+                        const cx<T> wab = cmul(wa[a], wb[b]);
 #pragma unroll
                         for (int e = E0; e < E1; ++e)
                             v[e][(4 * a + b) * Q + q] = cmul(v[e][(4 * a + b) * Q + q], wab);
