@@ -234,17 +234,17 @@ PM_HD int mix_div(int a, uint32_t magic) {
 // way: the LDS holds few sequences) the fewest stages win (6000 = 15 x 20 x 20: 516 us against 553 with four stages).  Ties go to the
 // smaller largest factor, then to the larger smallest one (fewer butterflies to index).  `maxr` caps the factors (tuning knob mix_maxr).  Returns false when n has a prime factor above 19.
 constexpr int mix_class_of(int maxr) { return maxr <= 10 ? 10 : (maxr <= 16 ? 16 : 20); }
-inline bool mix_factor(int n, int* radix, int* nstage, int maxr = kMixMaxRadix, double w20 = 1.4) {
+inline bool mix_factor(int n, int* radix, int* nstage, int maxr = kMixMaxRadix, double w20 = 1.4, double w16 = 1.15) {
     if (n < 2 || n > kMixMaxN) return false;
     int best[kMixMaxStages], cur[kMixMaxStages], bestn = 0, bestmax = 0, bestmin = 0;
     double bestcost = 1e30;
     const bool big = n > 4096;
     // depth-first over non-increasing factors
     struct Rec {
-        static void go(int rem, int maxf, int depth, int* cur, int* best, int& bestn, int& bestmax, int& bestmin, double& bestcost, bool big, double w20) {
+        static void go(int rem, int maxf, int depth, int* cur, int* best, int& bestn, int& bestmax, int& bestmin, double& bestcost, bool big, double w20, double w16) {
             if (rem == 1) {
                 const int cls = mix_class_of(cur[0]);
-                const double w = big ? 1.0 : (cls == 10 ? 1.0 : (cls == 16 ? 1.15 : w20));
+                const double w = big ? 1.0 : (cls == 10 ? 1.0 : (cls == 16 ? w16 : w20));
                 const double cost = depth * w;
                 const bool tie = cost < bestcost + 1e-9;
                 if (cost < bestcost - 1e-9 || (tie && cur[0] < bestmax) || (tie && cur[0] == bestmax && cur[depth - 1] > bestmin)) {
@@ -260,11 +260,11 @@ inline bool mix_factor(int n, int* radix, int* nstage, int maxr = kMixMaxRadix, 
             for (int f = maxf; f >= 2; --f) {
                 if (rem % f || !mix_radix_ok(f)) continue;
                 cur[depth] = f;
-                go(rem / f, f, depth + 1, cur, best, bestn, bestmax, bestmin, bestcost, big, w20);
+                go(rem / f, f, depth + 1, cur, best, bestn, bestmax, bestmin, bestcost, big, w20, w16);
             }
         }
     };
-    Rec::go(n, maxr < kMixMaxRadix ? maxr : kMixMaxRadix, 0, cur, best, bestn, bestmax, bestmin, bestcost, big, w20);
+    Rec::go(n, maxr < kMixMaxRadix ? maxr : kMixMaxRadix, 0, cur, best, bestn, bestmax, bestmin, bestcost, big, w20, w16);
     if (bestn == 0) return false;
     // ascending: the largest factor runs last, where the twiddles are all one
     for (int i = 0; i < bestn; ++i) radix[i] = best[bestn - 1 - i];
