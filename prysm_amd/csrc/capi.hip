@@ -170,6 +170,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("fft_stagger_herm")) t.fft_stagger_herm = v < 0 ? -1 : (v > 64 ? 64 : v);
     else if (is("fft_stagger_mid")) t.fft_stagger_mid = v < 0 ? -1 : (v > 64 ? 64 : v);
     else if (is("fft_stagger_col")) t.fft_stagger_col = v < 0 ? -1 : (v > 64 ? 64 : v);
+    else if (is("mix_fold")) t.mix_fold = v != 0;
     else if (is("mix_pers")) t.mix_pers = v != 0;
     else if (is("mix_stagger")) t.mix_stagger = v < 0 ? 0 : (v > 64 ? 64 : v);
     else if (is("engine_p8")) t.engine_p8 = v & 7;
@@ -280,6 +281,7 @@ struct Fft2Plan {
     bool fold;            // one radix-2 step of the column transform is taken in the row pass (RowStoreFold): the column
                           // pass then runs two planes of M/2-point tiles
     bool mix_n, mix_m;    // the row / column transforms take the mixed-radix kernel (composite lengths, fft_mixed.hip)
+    bool mix_fold;        // ... with one radix-2 step of the column transform folded into the row pass (MixRowOut fold_h): half-length column tiles
     int64_t w_ld;         // row pitch of the NATURAL intermediate (tc == 0), in elements: N, or N rounded up to whole 128 B lines when the
                           // column pass is the mixed-radix kernel -- its 32 / 64 B pieces then share lines only inside one XCD group
                           // (3000 complex64 columns: rows of 24000 B put every other row half a line off and the pass read 1.52x its bytes)
@@ -401,7 +403,7 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
     }
     if (!(p.big_rn && p.big_rm && (p.big_rn > 1 || p.big_rm > 1)) || (d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY | PM_FLAG_SYNTH_INPUT)))
         p.big_rn = p.big_rm = 0;
-    p.mix_n = p.mix_m = false;
+    p.mix_n = p.mix_m = p.mix_fold = false;
     if (p.big_rn) {   // [Z: R_n planes of M x N/R_n | F (and the pre-processed rows before it): the same size]
         p.tc = 0;
         p.fold = false;
@@ -415,6 +417,22 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
     const bool mixfit = mix_fits(N, d->in_ld, es, false) && mix_fits(M, p.w_ld, es, true) && mix_fits(M, d->out_ld, es, true);
     p.mix_n = mixfit && p.logn < 0 && use_mix(N);
     p.mix_m = mixfit && p.logm < 0 && use_mix(M);
+    // FOLD on composite grids (round 4; knob mix_fold, experiment builds only -- measured slower, fft_mixed.h MixRowOut): where four columns of M points fill a CU's LDS the column kernel runs one workgroup per CU, whose
+    // load / butterfly / store phases nothing overlaps (fft_mixed_kernels.h).  With the radix-2 step of the column transform taken by the
+    // row pass (rows in pairs (g, g + M/2)) the column tiles are half as tall and two or three workgroups share a CU.  Needs every row
+    // stored, rotations of 0 or M/2 on the way in and an even one on the way out, no multiplier, one field.
+    {
+        const int64_t H = M / 2;
+        // the tile the unfolded column pass would take (mix_cols_impl: four columns, eight of mid-size complex64, fewer when they do not fit)
+        const size_t per = size_t(M) * es, hard = size_t(156) * 1024;
+        size_t tc0 = (es == 8 && per > size_t(10) * 1024 && 8 * per <= hard) ? 8 : 4;
+        while (tc0 > 1 && tc0 * per > hard) tc0 /= 2;
+        p.mix_fold = tuning().mix_fold && p.mix_n && p.mix_m && (M % 2) == 0 && use_mix(H) && tc0 * per > size_t(80) * 1024 &&
+                     d->in_y.len == M && d->in_y.off == 0 && (d->in_y.shift == 0 || d->in_y.shift == H) && d->out_y.len == M && d->out_y.off == 0 &&
+                     (d->out_y.shift % 2) == 0 && d->mul_kind == PM_MUL_NONE &&
+                     !(d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY)) && mix_fits(N, H * d->in_ld, es, false) &&
+                     (!(d->flags & PM_FLAG_SYNTH_INPUT) || !d->synth_amp || mix_fits(N, H * d->synth_amp_ld, es, false));
+    }
     p.blue_n = p.logn < 0 && use_blue(N, mixfit);
     p.blue_m = p.logm < 0 && use_blue(M, mixfit);
     p.blue_off = (p.ws_bytes + 255) & ~size_t(255);
@@ -592,7 +610,12 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
                     return fail(PM_ERR_UNSUPPORTED, "pm_fft2: PM_FLAG_SYNTH_INPUT: amplitude pitch beyond 2^24 elements");
             }
             int rc;
-            if (p.mix_n) {
+            if (p.mix_n && p.mix_fold) {
+                const cx<T>* twm = twiddles<T>(M, &err);
+                if (!twm) return err;
+                const MixFold<T> mf{int(M / 2), d->in_y.shift == M / 2 ? 1 : 0, twm};
+                rc = mix_rows<T>(di, W, p.w_ld, st, nullptr, &mf);
+            } else if (p.mix_n) {
                 rc = mix_rows<T>(di, W, p.w_ld, st);
             } else if (p.blue_n) {
                 rc = blue_rows<T>(di, W, p.w_ld, static_cast<char*>(ws) + p.blue_off, st);
@@ -634,6 +657,22 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         const int ntiles = int((N + tc - 1) / tc);
         ColLoadNat<T> cl{W, p.w_ld, to_map(d->in_y), int(N), 0, (p.w_ld % 2 == 0) ? 1 : 0};
         return launch_col_nat<T>(p.logm, 0, cl, cs, tw, ntiles, 1, st);
+    }
+    if (p.mix_m && p.mix_fold) {
+        // two planes of M/2-point column transforms: plane b holds the output rows 2 k + b -- the output seen with a doubled leading
+        // dimension, plane 1 one row further (as the engine's fold above)
+        const int H = int(M / 2);
+        const size_t oes = d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T);
+        for (int b = 0; b < 2; ++b) {
+            DirectIn<T> dp{W + int64_t(b) * H * p.w_ld, 1, p.w_ld, AxisMap{H, H, 0, 0}, int(N), 0};
+            ColStoreNat<T> cp = cs;
+            cp.dst = static_cast<char*>(cs.dst) + size_t(b) * size_t(d->out_ld) * oes;
+            cp.ld = 2 * d->out_ld;
+            cp.ay = AxisMap{H, H, 0, int(d->out_y.shift / 2)};
+            const int rc = mix_cols<T>(dp, cp, st);
+            if (rc) return rc;
+        }
+        return 0;
     }
     DirectIn<T> di{W, 1, p.w_ld, to_map(d->in_y), int(N), 0};   // sequence = column c at W[c], element stride = the pitch of the intermediate
     if (p.mix_m) return mix_cols<T>(di, cs, st);
@@ -1597,7 +1636,7 @@ static bool experiment_only(const char* key, int v) {
     auto is = [&](const char* k) { return !strcmp(key, k); };
     return (is("spectral_mode") && (v & 3) != 3) || (is("gemm_3m") && !v) || (is("gemm_bm") && v == 128) || (is("gemm_bk") && v == 32) ||
            (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 6)) || (is("spectral2") && v != 0) || (is("two_units") && v != 0) || (is("engine_p8") && v != 0) ||
-           (is("mix_ablate") && v != 0) || (is("mix_pers") && v != 0);
+           (is("mix_ablate") && v != 0) || (is("mix_pers") && v != 0) || (is("mix_fold") && v != 0);
 #endif
 }
 

@@ -672,6 +672,14 @@ struct MixRowOut {
     T scale;
     int conj;
     int mapped;
+    // FOLD (round 4, experiment builds: it measured SLOWER than the unfolded pair of passes -- 3000^2 complex64 78.9 -> 87.7 us, 4000^2 126 -> 143,
+    // complex128 3000^2 175 -> 199, profiles/r04/exp_mix_fold.log: two rows per workgroup cost the row pass more than the half-height tiles give
+    // the column pass; the engine's RowStoreFold on composite lengths): the workgroup's two rows are (g, g + fold_h) of an array of 2 fold_h
+    // rows, and what is stored is one radix-2 decimation-in-frequency step of the COLUMN transform -- plane 0 row g = y[g] + y[g + H],
+    // plane 1 row g = (y[g] - y[g + H]) W_M^g (planes fold_h rows apart); the column pass then runs H-point tiles, half the LDS each.
+    // fold_tw[g] = W_M^g; fold_swap: the input rows are rotated by H, so the two rows of the pair trade places (plane 1 changes sign)
+    int fold_h, fold_swap;
+    const cx<T>* fold_tw;
 };
 
 template <typename T>

@@ -83,27 +83,34 @@ __global__ __launch_bounds__(512) void mix_rows_kernel(const MixPlan* __restrict
     const MixPlan& p = *pp;
     extern __shared__ __align__(16) char mix_smem[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(mix_smem);
-    const int seq0 = blockIdx.x * sh.seqs, tid = threadIdx.x, nt = blockDim.x;
-    const int nvalid = in.nseq - seq0 < sh.seqs ? in.nseq - seq0 : sh.seqs;
+    // the rows of the workgroup: seqs consecutive ones, or (FOLD, experiment builds) the pair (g, g + H)
+#ifdef PM_EXPERIMENTS
+    const bool fold = out.fold_h > 0;
+#else
+    constexpr bool fold = false;
+#endif
+    const int seq0 = fold ? int(blockIdx.x) : int(blockIdx.x) * sh.seqs, tid = threadIdx.x, nt = blockDim.x;
+    const int nvalid = fold ? 2 : (in.nseq - seq0 < sh.seqs ? in.nseq - seq0 : sh.seqs);
+    const uint32_t rpitch = fold ? uint32_t(out.fold_h) * uint32_t(in.s_seq) : uint32_t(in.s_seq);
     const T ysign = in.conj ? T(-1) : T(1);
     const bool whole = in.ax.off == 0 && in.ax.len == in.ax.n && nvalid == sh.seqs;
     if (SYNTH && in.synth == 3) {
-        const MixFetchSynth<T, true> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, nvalid, in.k2, nullptr, 0, 0u};
+        const MixFetchSynth<T, true> fetch{in.src + int64_t(seq0) * in.s_seq, rpitch, in.ax, nvalid, in.k2, nullptr, 0, 0u};
         mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     } else if (SYNTH && in.synth == 2) {
         const char* a0 = reinterpret_cast<const char*>(in.amp);
         if (a0) a0 += int64_t(seq0) * in.amp_ld * (in.amp_kind == 1 ? 4 : (in.amp_kind == 2 ? 8 : 1));
-        const MixFetchSynth<T, false> fetch{reinterpret_cast<const T*>(in.src) + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, nvalid, in.k2,
-                                            a0, a0 ? in.amp_kind : 0, uint32_t(in.amp_ld)};
+        const MixFetchSynth<T, false> fetch{reinterpret_cast<const T*>(in.src) + int64_t(seq0) * in.s_seq, rpitch, in.ax, nvalid, in.k2,
+                                            a0, a0 ? in.amp_kind : 0, fold ? uint32_t(out.fold_h) * uint32_t(in.amp_ld) : uint32_t(in.amp_ld)};
         mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     } else if (in.real) {
-        const MixFetch<T, false, true> fetch{reinterpret_cast<const T*>(in.src) + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, ysign, nvalid};
+        const MixFetch<T, false, true> fetch{reinterpret_cast<const T*>(in.src) + int64_t(seq0) * in.s_seq, rpitch, in.ax, ysign, nvalid};
         mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     } else if (whole) {
-        const MixFetchWhole<T, false> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax.n, in.ax.shift, ysign};
+        const MixFetchWhole<T, false> fetch{in.src + int64_t(seq0) * in.s_seq, rpitch, in.ax.n, in.ax.shift, ysign};
         mix_run_first<T, true, MAXR, 3>(p, sh, tid, nt, lds, tw, fetch);
     } else {
-        const MixFetch<T, false, false> fetch{in.src + int64_t(seq0) * in.s_seq, uint32_t(in.s_seq), in.ax, ysign, nvalid};
+        const MixFetch<T, false, false> fetch{in.src + int64_t(seq0) * in.s_seq, rpitch, in.ax, ysign, nvalid};
         mix_run_first<T, true, MAXR>(p, sh, tid, nt, lds, tw, fetch);
     }
     __syncthreads();
@@ -112,6 +119,21 @@ __global__ __launch_bounds__(512) void mix_rows_kernel(const MixPlan* __restrict
         mix_run_mid<T, true, MAXR>(p, sh, s, tid, nt, lds, tw);
         __syncthreads();
     }
+#ifdef PM_EXPERIMENTS
+    if (fold) {
+        // lanes 2 m and 2 m + 1 hold the same bin of the two rows (the rows are interleaved, lanes across them first)
+        cx<T> wf = out.fold_tw[seq0];
+        if (out.fold_swap) wf = cx<T>{-wf.x, -wf.y};
+        cx<T>* d0 = out.dst + int64_t(seq0) * out.ld;
+        cx<T>* d1 = d0 + int64_t(out.fold_h) * out.ld;
+        auto store = [&](int sl, int k, cx<T> v) {
+            const cx<T> o = {__shfl_xor(v.x, 1), __shfl_xor(v.y, 1)};
+            const cx<T> r = sl == 0 ? cx<T>{v.x + o.x, v.y + o.y} : cmul(cx<T>{o.x - v.x, o.y - v.y}, wf);
+            mix_st((sl == 0 ? d0 : d1) + k, r);
+        };
+        mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
+    } else
+#endif
     if (nvalid == sh.seqs && !out.mapped) {
         cx<T>* dst0 = out.dst + int64_t(seq0) * out.ld;
         const uint32_t ld = uint32_t(out.ld);
@@ -437,9 +459,12 @@ int mix_cols_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, c
 }
 
 template <typename T>
-int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o) {
+int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o, const MixFold<T>* fold) {
     const int n = in.ax.n, nseq = in.nseq;
     if (nseq <= 0 || n <= 0) return 0;
+    if (fold && (o || nseq != 2 * fold->H || !mix_fits(n, int64_t(fold->H) * in.s_seq, sizeof(cx<T>), false) ||
+                 (in.amp && !mix_fits(n, int64_t(fold->H) * in.amp_ld, sizeof(cx<T>), false))))
+        return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: folded row pass on a shape it does not take");
     MixPlan p;
     if (!mix_plan_for(n, sizeof(cx<T>), p)) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);
     if (in.s_i != 1 || !mix_fits(n, in.s_seq, sizeof(cx<T>), false) || !mix_fits(n, o ? o->ld : out_ld, sizeof(cx<T>), false))
@@ -458,6 +483,7 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     while (seqs > 1 && size_t(seqs) * per > size_t(48) * 1024) --seqs;
     if (tuning().mix_seqs > 0) seqs = tuning().mix_seqs;
     while (seqs > 1 && seqs / 2 >= nseq) seqs /= 2;
+    if (fold) seqs = 2;
     {   // a power of two: the rows of a workgroup are interleaved in LDS (mix_rows_kernel)
         int pw = 1;
         while (pw * 2 <= seqs) pw *= 2;
@@ -474,9 +500,14 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
     const size_t lds = size_t(seqs) * size_t(sh.npad) * sizeof(cx<T>);
-    MixRowOut<T> ro{out, out_ld, AxisMap{n, n, 0, 0}, T(1), 0, 0};
-    if (o) ro = MixRowOut<T>{o->dst, o->ld, o->ax, o->scale, o->conj, 1};
-    const int groups = (nseq + seqs - 1) / seqs, nt = mix_threads(p, seqs, 256, tuning().mix_nt, false);
+    MixRowOut<T> ro{out, out_ld, AxisMap{n, n, 0, 0}, T(1), 0, 0, 0, 0, nullptr};
+    if (o) ro = MixRowOut<T>{o->dst, o->ld, o->ax, o->scale, o->conj, 1, 0, 0, nullptr};
+    if (fold) {
+        ro.fold_h = fold->H;
+        ro.fold_swap = fold->swap;
+        ro.fold_tw = fold->tw;
+    }
+    const int groups = fold ? fold->H : (nseq + seqs - 1) / seqs, nt = mix_threads(p, seqs, 256, tuning().mix_nt, false);
     sh.stagger = 0;
     if (p.maxr <= 10) return mix_rows_launch<T, 10>(pd, sh, in, ro, tw, groups, nt, lds, st);
     if (p.maxr <= 16) return mix_rows_launch<T, 16>(pd, sh, in, ro, tw, groups, nt, lds, st);

@@ -61,8 +61,15 @@ int blue_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, void* scratch, h
 
 // Mixed-radix path (fft_mixed.hip): lengths up to 8192 whose prime factors are all <= 19 (<= 13 until round 4), one kernel per axis with the data in LDS, no
 // scratch.  Same contracts as direct_rows / direct_rows_out (`o`) / direct_cols.
+// `fold` (round 4): the rows are taken in pairs (g, g + H) of an array of 2 H rows and the intermediate holds one radix-2 step of the
+// column transform (two planes of H rows, fft_mixed.h MixRowOut): tw = the device table of W_M^g (M = 2 H), swap = rows rotated by H
 template <typename T>
-int mix_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o = nullptr);
+struct MixFold {
+    int H, swap;
+    const cx<T>* tw;
+};
+template <typename T>
+int mix_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o = nullptr, const MixFold<T>* fold = nullptr);
 template <typename T>
 int mix_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t st);
 // middle pass of fft2 -> x H -> ifft2 on a composite column length: the columns of the natural intermediate `in` (sequence = column) come
@@ -169,6 +176,8 @@ struct Tuning {
     int engine_p8 = 0;        // experiment builds: the radix-8 engine (8 points per thread) for the folded 4096^2 complex64 transform: bit 0 its row pass,
                               // bit 1 its column pass, bit 2 a 64-register cap (eight waves per SIMD) instead of 128
     int fft_stagger = -1, fft_stagger_col = -1, fft_stagger_mid = 0, fft_stagger_r2c = 0, fft_stagger_herm = -1;    // start-up stagger of the engine's plain row / column kernels (fft_kernels.h engine_log_g), units of 512 cycles x 0 .. 7; 0 = off, -1 = auto
+    int mix_fold = 0;         // experiment builds: a radix-2 step of a composite column transform folded into the mixed-radix row pass where the whole column's tile would
+                              // take a CU's LDS (capi.hip plan_fft2 mix_fold)
     int mix_pers = 0;         // experiment builds: its column pass as persistent workgroups with the next tile prefetched where a CU holds one tile (mix_cols_pers_kernel)
     int mix_stagger = 4;      // ... start-up stagger of the column kernel's workgroups in units of 512 cycles x 0 .. 7 where a CU holds one tile (fft_mixed.h MixShape::stagger); 0 = off
     int mix_ablate = 0;       // experiment builds: timing-only ablations of the mixed-radix kernels (fft_mixed.h MixShape::ablate; results are wrong)

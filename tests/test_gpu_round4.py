@@ -391,3 +391,29 @@ def test_lengths_with_the_primes_17_and_19(pa, shape):
         assert rel_max(tonp(pa.propagation.focus(x, 1)), O.focus(x.astype(np.complex128), 1)) < tol
     x = crandn(rng, shape)
     assert rel_max(tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1)), O.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1)) < TOL64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('direction', [-1, +1])
+def test_mixed_radix_fold_experiment(pa, direction):
+    """The radix-2 step of a composite column transform folded into the mixed-radix row pass (knob mix_fold; experiment builds only -- it
+    measured slower and is not shipped, profiles/r04/exp_mix_fold.log): same result as numpy for the focus view and the |.|^2 epilogue."""
+    from prysm_amd import _lib, _ops
+    lib = _lib.load()
+    if lib.pm_set_tuning_local(b'mix_fold', 1) != 0:
+        lib.pm_reset_tuning_local()
+        pytest.skip('product build: the folded mixed-radix row pass is compiled into experiment builds only')
+    try:
+        n = 1500
+        rng = np.random.default_rng(5)
+        x = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))).astype(np.complex128)
+        xt = torch.from_numpy(x).cuda()
+        h = n // 2
+        got = _ops.fft2(xt, direction=direction, scale=1.0 / n, in_shift=(h, h), out_shift=(h, h)).cpu().numpy()
+        f = np.fft.fft2 if direction < 0 else (lambda a: np.fft.ifft2(a) * a.size)
+        ref = np.fft.fftshift(f(np.fft.ifftshift(x))) / n
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+        i2 = _ops.fft2(xt, direction=direction, scale=1.0 / n, in_shift=(h, h), out_shift=(h, h), epilogue=_lib.PM_EPI_ABS2).cpu().numpy()
+        assert np.abs(i2 - np.abs(ref) ** 2).max() <= 1e-12 * (np.abs(ref) ** 2).max()
+    finally:
+        lib.pm_reset_tuning_local()
