@@ -165,11 +165,11 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("mix_pad")) t.mix_pad = v ? 1 : 0;
     else if (is("two_units")) t.two_units = v & 3;
     else if (is("mix_ablate")) t.mix_ablate = v & 15;
-    else if (is("fft_stagger")) t.fft_stagger = v < 0 ? -1 : (v > 64 ? 64 : v);
-    else if (is("fft_stagger_r2c")) t.fft_stagger_r2c = v < 0 ? 0 : (v > 64 ? 64 : v);
-    else if (is("fft_stagger_herm")) t.fft_stagger_herm = v < 0 ? -1 : (v > 64 ? 64 : v);
+    else if (is("fft_stagger")) t.fft_stagger = v < 0 ? -1 : (v > 164 ? 164 : v);
+    else if (is("fft_stagger_r2c")) t.fft_stagger_r2c = v < 0 ? 0 : (v > 164 ? 164 : v);
+    else if (is("fft_stagger_herm")) t.fft_stagger_herm = v < 0 ? -1 : (v > 164 ? 164 : v);
     else if (is("fft_stagger_mid")) t.fft_stagger_mid = v < 0 ? -1 : (v > 64 ? 64 : v);
-    else if (is("fft_stagger_col")) t.fft_stagger_col = v < 0 ? -1 : (v > 64 ? 64 : v);
+    else if (is("fft_stagger_col")) t.fft_stagger_col = v < 0 ? -1 : (v > 164 ? 164 : v);
     else if (is("mix_fold")) t.mix_fold = v != 0;
     else if (is("mix_pers")) t.mix_pers = v != 0;
     else if (is("mix_stagger")) t.mix_stagger = v < 0 ? 0 : (v > 64 ? 64 : v);

@@ -49,11 +49,13 @@ int pm_fft_stagger(int pass);       // capi.hip: the knobs fft_stagger (row kern
 static inline int engine_log_g(int log_g, int grid, size_t lds_bytes, int nt, int pass) {      // pass: 0 rows, 1 columns, 2 the middle pass of a fused chain, 3 / 4 the real-input row / Hermitian column kernels (fft_r2c.h)
     const int by_lds = lds_bytes ? int(size_t(160) * 1024 / lds_bytes) : 8, by_waves = 2048 / nt;
     const int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
-    if (grid <= 256 * per_cu) return log_g;
+    int stg = pm_fft_stagger(pass);
+    const bool force = stg >= 100;      // experiments: 100 + units staggers a single-round launch too (several workgroups per CU only)
+    if (force) stg -= 100;
+    if (grid <= 256 * per_cu && !(force && per_cu > 1)) return log_g;
     // auto (knob < 0): 8 units where a CU holds one workgroup, 1 where it holds more (they already overlap each other).  Measured
     // (profiles/r04/exp_fft_stagger.log, 2-D transform us without / with): 4096^2 complex64 93.5 / 92.8 (95.4 / 93.7 on another box),
     // complex128 210.3 / 206.0, 8192^2 complex64 493 / 474, complex128 1033 / 1013; twice the units already lose (4096^2 complex128 220)
-    int stg = pm_fft_stagger(pass);
     // (two column workgroups per CU: 93.4 against 93.3 without -- nothing; the Hermitian column kernel, one 1024-thread workgroup per CU:
     // 8192^2 real input 357 -> 344 us at 8 and 338 at 16 on one box, 392 -> 385 at 8 and 391 at 16 on another -- exp_mtf_stagger*.log;
     // the real-input row kernel: nothing at any setting)
