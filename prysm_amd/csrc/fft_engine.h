@@ -84,6 +84,17 @@ PM_HD void dft4(cx<T>& a0, cx<T>& a1, cx<T>& a2, cx<T>& a3) {
     a3 = d02 - m;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PM_PACKED_F32)
+// complex64 on packed fp32 instructions (pm_common.h): 8 instructions per radix-4 butterfly instead of 16
+__device__ __forceinline__ void dft4(cx<float>& a0, cx<float>& a1, cx<float>& a2, cx<float>& a3) {
+    const cx<float> s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    a0 = s02 + s13;
+    a2 = s02 - s13;
+    a1 = add_mi(d02, d13);
+    a3 = sub_mi(d02, d13);
+}
+#endif
+
 template <typename T, int R>
 struct Dft;
 
@@ -106,9 +117,22 @@ struct Dft<T, 8> {
         dft4(a[0], a[2], a[4], a[6]);  // even samples -> E[k] in a[0],a[2],a[4],a[6]
         dft4(a[1], a[3], a[5], a[7]);  // odd samples  -> O[k] in a[1],a[3],a[5],a[7]
         cx<T> o0 = a[1];
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PM_PACKED_F32)
+        cx<T> o1, o2, o3;
+        if constexpr (sizeof(T) == 4) {
+            o1 = cmul_k(a[3], r, -r);
+            o2 = cmul_k(a[5], T(0), T(-1));
+            o3 = cmul_k(a[7], -r, -r);
+        } else {
+            o1 = cx<T>{r * (a[3].x + a[3].y), r * (a[3].y - a[3].x)};
+            o2 = mul_mi(a[5]);
+            o3 = cx<T>{r * (a[7].y - a[7].x), -r * (a[7].x + a[7].y)};
+        }
+#else
         cx<T> o1 = {r * (a[3].x + a[3].y), r * (a[3].y - a[3].x)};    // * w8^1
         cx<T> o2 = mul_mi(a[5]);                                        // * w8^2
         cx<T> o3 = {r * (a[7].y - a[7].x), -r * (a[7].x + a[7].y)};   // * w8^3
+#endif
         cx<T> e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
         a[0] = e0 + o0; a[4] = e0 - o0;
         a[1] = e1 + o1; a[5] = e1 - o1;
@@ -125,6 +149,20 @@ struct Dft<T, 16> {
 #pragma unroll
         for (int n2 = 0; n2 < 4; ++n2) dft4(a[n2], a[n2 + 4], a[n2 + 8], a[n2 + 12]);
         // step 2: b[n2][k1] *= w16^(n2 k1)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PM_PACKED_F32)
+        if constexpr (sizeof(T) == 4) {
+            a[5] = cmul_k(a[5], c1, -s1);
+            a[9] = cmul_k(a[9], r, -r);
+            a[13] = cmul_k(a[13], s1, -c1);
+            a[6] = cmul_k(a[6], r, -r);
+            a[10] = cmul_k(a[10], T(0), T(-1));
+            a[14] = cmul_k(a[14], -r, -r);
+            a[7] = cmul_k(a[7], s1, -c1);
+            a[11] = cmul_k(a[11], -r, -r);
+            a[15] = cmul_k(a[15], -c1, s1);
+        } else
+#endif
+        {
         a[5] = cmul(a[5], cx<T>{c1, -s1});     // n2=1,k1=1 : w^1
         a[9] = cmul(a[9], cx<T>{r, -r});       // n2=1,k1=2 : w^2
         a[13] = cmul(a[13], cx<T>{s1, -c1});   // n2=1,k1=3 : w^3
@@ -134,6 +172,7 @@ struct Dft<T, 16> {
         a[7] = cmul(a[7], cx<T>{s1, -c1});     // n2=3,k1=1 : w^3
         a[11] = cmul(a[11], cx<T>{-r, -r});    // n2=3,k1=2 : w^6
         a[15] = cmul(a[15], cx<T>{-c1, s1});   // n2=3,k1=3 : w^9
+        }
         // step 3: DFT-4 over n2 for each k1; a[4 k1 + k2] = X[k1 + 4 k2]
 #pragma unroll
         for (int k1 = 0; k1 < 4; ++k1) dft4(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);

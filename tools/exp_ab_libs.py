@@ -51,6 +51,18 @@ for dt, n, reps in ((torch.complex64, 4096, 40), (torch.complex64, 2048, 60), (t
     o = torch.empty_like(x)
     res.append('focus %s %d: %.1f' % ('c64' if dt == torch.complex64 else 'c128', n, timed(lambda: P.focus(x, 1), reps)))
     del x, o
+for n in (3000, 1000, 2000):
+    x = torch.randn(n, n, dtype=torch.complex64, device='cuda')
+    res.append('focus c64 %d: %.1f' % (n, timed(lambda: P.focus(x, 1), 20)))
+    del x
+obj = torch.rand(4096, 4096, dtype=torch.float32, device='cuda')
+H = torch.randn(4096, 4096, dtype=torch.complex64, device='cuda')
+try:
+    from prysm_amd import convolution as CV
+    res.append('conv real 4096: %.1f' % timed(lambda: CV.conv(obj, H, transfer_function=True) if 'transfer_function' in CV.conv.__code__.co_varnames else CV.conv(obj, H), 10))
+except Exception as e:
+    res.append('conv n/a')
+del obj, H
 x = torch.randn(4096, 4096, dtype=torch.complex128, device='cuda')
 res.append('AS c128 4096: %.1f' % timed(lambda: P.angular_spectrum(x, 0.6328, 0.01, 10.0, Q=1), 15))
 del x
