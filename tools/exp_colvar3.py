@@ -1,5 +1,7 @@
 """32 B column tiles (col_var 3: four complex64 / two complex128 columns on 256 threads) for 2048-point columns: a 2048^2 transform then
-has 512 / 1024 column workgroups instead of one per CU.  focus time in us per (col_var, log_k), and agreement with the default tiling."""
+has 512 / 1024 column workgroups instead of one per CU.  focus time in us per (col_var, log_k), and agreement with the default tiling.
+The variant measured no faster (profiles/r04/exp_colvar3.log) and was removed again: to repeat the measurement, re-add `VAR == 3` to
+ColCfgSel / launch_fft (fft_kernels.h) and col_tile_width_for (pm_internal.h) as in commit 805cf35's successor."""
 import torch
 from prysm_amd import _ops, _lib, propagation as P
 lib = _lib.load()
