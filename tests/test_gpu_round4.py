@@ -417,3 +417,27 @@ def test_mixed_radix_fold_experiment(pa, direction):
         assert np.abs(i2 - np.abs(ref) ** 2).max() <= 1e-12 * (np.abs(ref) ** 2).max()
     finally:
         lib.pm_reset_tuning_local()
+
+
+@pytest.mark.gpu
+def test_start_up_stagger_changes_timing_only(pa):
+    """The start-up stagger (engine: fft_stagger / fft_stagger_col, 100 + units forces it on single-round launches; mixed-radix column
+    kernel: mix_stagger) delays workgroups of the first round by a hash of their index and must not change a bit of any result."""
+    from prysm_amd import _lib, _ops
+    lib = _lib.load()
+    g = torch.Generator(device='cuda').manual_seed(11)
+    cases = [((4096, 4096), torch.complex64), ((2048, 2048), torch.complex64), ((1024, 4096), torch.complex128), ((3000, 3000), torch.complex64)]
+    try:
+        for shape, dt in cases:
+            rdt = torch.float32 if dt == torch.complex64 else torch.float64
+            x = torch.complex(torch.randn(shape, device='cuda', dtype=rdt, generator=g), torch.randn(shape, device='cuda', dtype=rdt, generator=g))
+            h = (shape[0] // 2, shape[1] // 2)
+            outs = []
+            for r, c, m in ((0, 0, 0), (3, 5, 9), (108, 104, 1)):
+                assert lib.pm_set_tuning_local(b'fft_stagger', r) == 0
+                assert lib.pm_set_tuning_local(b'fft_stagger_col', c) == 0
+                assert lib.pm_set_tuning_local(b'mix_stagger', m) == 0
+                outs.append(_ops.fft2(x, direction=-1, scale=1.0, in_shift=h, out_shift=h))
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), shape
+    finally:
+        lib.pm_reset_tuning_local()
