@@ -105,6 +105,27 @@ def make_field(n, cdtype, seed):
     return x
 
 
+def plain_copy_pair_ms(x, reps=50):
+    """Two dependent device-to-device copies of the field, in -> workspace -> out (torch's copy kernel): what the data movement of a
+    two-pass transform costs on this box with no arithmetic at all -- the practical ceiling the step is compared with (round 4)."""
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    for _ in range(5):
+        y.copy_(x)
+        z.copy_(y)
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            y.copy_(x)
+            z.copy_(y)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / reps
+        best = t if best is None or t < best else best
+    return best
+
+
 def kernel_pass_times(x, n, reps=100):
     """Average duration (ms) of the row pass and of the column pass: each pass as its own back-to-back loop of `reps` launches between
     one pair of HIP events on the launch stream (pm_fft2_time_passes)."""
@@ -686,6 +707,7 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
         p1, p2 = kernel_pass_times(x, n)
+        two_copies_ms = plain_copy_pair_ms(x)
         dom, dom_ms = ('row_pass', p1) if p1 >= p2 else ('column_pass', p2)
         alg_bytes_kernel = 2.0 * n * n * es           # one pass reads N^2 s and writes N^2 s
         achieved = alg_bytes_kernel / (dom_ms * 1e-3) / 1e9
@@ -709,9 +731,11 @@ def main():
                          'traffic': traffic, 'traffic_unit': 'bytes per launch',
                          'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': alg_bytes_kernel,
                          'row_pass_ms': p1, 'column_pass_ms': p2, 'passes_over_step': (p1 + p2) / ms_step,
+                         'two_plain_copies_ms': two_copies_ms, 'step_over_two_plain_copies': ms_step / two_copies_ms,
                          'note': '2*N^2*s algorithmic bytes per pass / average HIP-event duration of that pass, each pass timed as its own '
                                  'back-to-back loop of 100 launches on the launch stream (pm_fft2_time_passes); passes_over_step = '
-                                 '(row + column) / ms_per_step'},
+                                 '(row + column) / ms_per_step; two_plain_copies_ms = torch copies in -> ws -> out of the same field, '
+                                 'measured in this run'},
             'prewarm_ms': PREWARM_MS,
         }
 
