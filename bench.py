@@ -61,6 +61,58 @@ F32_MFMA_PEAK_TF = 157.3
 N_WAVELENGTHS = 64      # BASELINE config 5
 
 
+def _slim(o):
+    """the line without its prose: every 'note' / 'workload' string below the top level (they are documented once, in DESIGN.md 5
+    "Keys of the bench line") and floats at six significant digits -- the driver keeps the last 2000 characters of the output"""
+    if isinstance(o, dict):
+        return {k: (v if k == 'config' else _slim(v)) for k, v in o.items() if k not in ('note', 'workload') or not isinstance(v, str)}
+    if isinstance(o, list):
+        return [_slim(v) for v in o]
+    if isinstance(o, float):
+        return float(f'{o:.6g}')
+    return o
+
+
+def _summary(line):
+    """The numbers a reader of the stored tail needs, as the LAST key of the line (flat, short names, ms unless named otherwise)."""
+    def get(path, d=line):
+        for k in path.split('/'):
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return float(f'{d:.4g}') if isinstance(d, float) else d
+    oc = 'other_configs/'
+    pairs = {
+        'psfs_per_s': get('value'), 'ms': get('ms_per_step'), 'row_ms': get('roofline/row_pass_ms'), 'col_ms': get('roofline/column_pass_ms'),
+        'frac': get('roofline/frac'), 'two_copies_ms': get('roofline/two_plain_copies_ms'), 'n2048_per_s': get('n2048/value'),
+        'psf_variant_ms': get('psf_variant/ms_per_psf'),
+        'c2_ms': get(oc + 'config2_focus_2048_c64/ms'), 'c2_two_streams_ms': get(oc + 'config2_focus_2048_c64/two_streams/ms'),
+        'c2_sequence_ms': get(oc + 'config2_focus_2048_c64/sequence_block/ms'), 'f1000_sequence_ms': get(oc + 'focus_1000_c64_sequence_block/ms'),
+        'c3_ms': get(oc + 'config3_angular_spectrum_4096_c128/ms'), 'c3_moved_frac': get(oc + 'config3_angular_spectrum_4096_c128/moved_frac_of_hbm_peak'),
+        'c4_ms': get(oc + 'config4_mdft_2048_to_512_c64/ms'), 'c4_build_ms': get(oc + 'config4_mdft_2048_to_512_c64/prepare_executor_ms'),
+        'c4_frac_mfma': get(oc + 'config4_mdft_2048_to_512_c64/frac_of_f32_mfma_peak'),
+        'c128_4096_ms': get(oc + 'focus_4096_c128/ms'), 'c64_8192_ms': get(oc + 'focus_8192_c64/ms'),
+        'mtf_4096_ms': get(oc + 'mtf_from_psf_4096_f32/ms'), 'conv_4096_ms': get(oc + 'conv_real_4096_f32/ms'),
+        'f3000_c64_ms': get(oc + 'focus_3000_c64_mixed_radix/ms'), 'f3000_c128_ms': get(oc + 'focus_3000_c128_mixed_radix/ms'),
+        'f1000_c64_ms': get(oc + 'focus_1000_c64_mixed_radix/ms'),
+        'c5F_psf_ms': get('polychromatic/variant_F_fft_focus/psf_ms'), 'c5F_ms_per_wvl': get('polychromatic/variant_F_fft_focus/per_wavelength_ms_per_gpu'),
+        'c5F_psf_ms_by_reduce': get('polychromatic/variant_F_fft_focus/psf_ms_by_reduce_method'),
+        'c5F_pipelined_ms': get('polychromatic/variant_F_fft_focus/pipelined_ms_per_psf'), 'c5M_psf_ms': get('polychromatic/variant_M_mdft_512/psf_ms'), 'c5M_czt_psf_ms': get('polychromatic/variant_M_czt_512/psf_ms'),
+        'reduce_method': get('polychromatic/reduce_method'), 'reduce_alone_ms': get('polychromatic/reduce_alone_ms'),
+        'model_eff8_a2a': get('polychromatic/scaling_model/per_N/8/efficiency_single_shot/a2a'),
+        'model_eff8_reduce': get('polychromatic/scaling_model/per_N/8/efficiency_single_shot/reduce'),
+        'c5_2048_us_per_wvl': get('polychromatic_2048/spectral_groups/per_wavelength_us_per_gpu'),
+        'cpu_1core_per_s': get('cpu_baseline/value'), 'cpu_allcores_per_s': get('cpu_baseline/tuned/value'), 'cpu': get('cpu_baseline/host/cpu'),
+    }
+    return {k: v for k, v in pairs.items() if v is not None}
+
+
+def emit(line):
+    out = _slim(line)
+    out['summary'] = _summary(out)
+    print(json.dumps(out), flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -72,7 +124,7 @@ def parse():
     ap.add_argument('--no-poly', action='store_true', help='only the headline loop (profiling runs)')
     ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192|padded|composite|mtf|conv|adjoint|poly2048)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget for the CPU baseline sample')
-    ap.add_argument('--reduce-method', default='auto', choices=['auto', 'reduce', 'a2a'],
+    ap.add_argument('--reduce-method', default='auto', choices=['auto', 'reduce', 'a2a', 'rs'],
                     help='how the polychromatic image reaches rank 0: one torch.distributed.reduce, or all-to-all of slices + ordered local '
                          'sum + gather (one message per xGMI link); auto = whichever reduces the 67 MB image faster in this run')
     ap.add_argument('--extras-budget', type=float, default=900.0,
@@ -246,7 +298,25 @@ def other_configs(only=''):
         e2 = _hbm_entry(_event_ms(sequence, 3, warm=1) / 200, 4 * 2048 ** 2 * 8)
         out['config2_focus_2048_c64']['two_streams'] = dict(e2, note='a sequence of 200 independent 2048^2 propagations alternating between two HIP '
                                                                      'streams (StreamRing), joined once at the end; ms per propagation')
-        del x2, x2b, keep
+        # ... and the same loop written as plain calls inside a prysm_amd.graph.sequence() block (round 5): the block picks the streams
+        from prysm_amd import graph as G
+
+        def block(xa, xb, k=100):
+            with G.sequence():
+                for _ in range(k):
+                    keep[0] = None
+                    keep[0] = P.focus(xa, 1)
+                    keep[1] = None
+                    keep[1] = P.focus(xb, 1)
+        e3 = _hbm_entry(_event_ms(lambda: block(x2, x2b), 3, warm=1) / 200, 4 * 2048 ** 2 * 8)
+        out['config2_focus_2048_c64']['sequence_block'] = dict(e3, note='the same 200 propagations as plain P.focus calls inside `with graph.sequence():`')
+        del x2, x2b
+        xa = torch.from_numpy(make_field(1000, np.complex64, 1000)).cuda()
+        xb = xa.clone()
+        one = _hbm_entry(_event_ms(lambda: P.focus(xa, 1), 100), 4 * 1000 ** 2 * 8)
+        e4 = _hbm_entry(_event_ms(lambda: block(xa, xb), 3, warm=1) / 200, 4 * 1000 ** 2 * 8)
+        out['focus_1000_c64_sequence_block'] = dict(e4, one_stream_ms=one['ms'], note='1000^2 complex64 (mixed-radix kernels): plain calls in a sequence() block')
+        del xa, xb, keep
     def sec_config3():   # config 3: 4096^2 complex128 angular-spectrum step (fused 3 passes), graded on 8 N^2 s bytes
         x3 = torch.from_numpy(make_field(4096, np.complex128, 4096)).cuda()
         out['config3_angular_spectrum_4096_c128'] = _hbm_entry(
@@ -369,9 +439,13 @@ def other_configs(only=''):
             x4 = torch.from_numpy(make_field(2048, np.complex64, 2048)).cuda()
             ex = P.prepare_executor(10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0)
             ms = _event_ms(lambda: P.focus_dft(x4, ex), 50)
+            # the executor BUILD (two basis matrices on the device, the reference's one-off cost per grid and
+            # wavelength) timed apart from its application
+            build_ms = _event_ms(lambda: P.prepare_executor(10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0), 20)
             fl = 8 * 512 * 2048 * (2048 + 512)
             out['config4_mdft_2048_to_512_c64'] = {
-                'ms': ms, 'algorithmic_TFLOPs': fl / (ms * 1e-3) / 1e12, 'frac_of_f32_mfma_peak': fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                'ms': ms, 'prepare_executor_ms': build_ms, 'algorithmic_TFLOPs': fl / (ms * 1e-3) / 1e12,
+                'frac_of_f32_mfma_peak': fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
                 'bound': 'mfma', 'note': 'two complex GEMMs on v_mfma_f32_32x32x2_f32; peak 157.3 TFLOP/s (MI355X_MICROARCH.md)'}
             if not only:
                 # the same focal grid by the chirp-Z executor (prysm/fttools.py:235-389), for comparison
@@ -423,8 +497,16 @@ def cpu_baseline(n, cdtype, budget_s):
         O.focus(x, 1)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
+    import scipy
+    model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as fh:
+            model = next((ln.split(':', 1)[1].strip() for ln in fh if ln.startswith('model name')), 'unknown')
+    except OSError:
+        pass
     out = {
         'value': 1.0 / med, 'unit': 'propagations/s', 'cores': 1, 'kind': 'port',
+        'host': {'cpu': model, 'logical_cores': os.cpu_count(), 'numpy': np.__version__, 'scipy': scipy.__version__},
         'sample': f'{len(times)} x oracle.focus({n}x{n} {np.dtype(cdtype).name}, Q=1), median {med * 1e3:.1f} ms, '
                   f'min {min(times) * 1e3:.1f} ms; scipy.fft workers=1 (as prysm ships), host has {os.cpu_count()} cores',
     }
@@ -524,9 +606,10 @@ def polychromatic_config5(ranks, n, reduce_ms, method='auto', reps=3, frames=6):
     wts = np.ones(N_WAVELENGTHS)
     dx = 10.0 / n
     if method == 'auto':
-        method = 'a2a' if (ranks.world > 1 and reduce_ms['a2a'] < reduce_ms['reduce']) else 'reduce'
+        method = min(('reduce', 'a2a', 'rs'), key=lambda m: reduce_ms.get(m, 1e9)) if ranks.world > 1 else 'reduce'
     forms = {'reduce': 'torch.distributed.reduce(SUM) of the real image to rank 0 (RCCL over xGMI)',
-             'a2a': 'all_to_all_single of image slices + ordered local sum (pm_sum_modes) + gather to rank 0 (RCCL over xGMI)'}
+             'a2a': 'all_to_all_single of image slices + ordered local sum (pm_sum_modes) + gather into the root image (RCCL over xGMI)',
+             'rs': 'reduce_scatter_tensor + gather into the root image (RCCL over xGMI)'}
     res = {'wavelengths': N_WAVELENGTHS, 'wavelengths_per_gpu': math.ceil(N_WAVELENGTHS / ranks.world), 'pupil': f'{n}x{n} fp32',
            'reduce_method': method if ranks.world > 1 else 'none (one rank)',
            'reduce': forms[method] if ranks.world > 1 else 'none (one rank)'}
@@ -557,9 +640,11 @@ def polychromatic_config5(ranks, n, reduce_ms, method='auto', reps=3, frames=6):
 
         res['variant_F_fft_focus'] = entry(timed_median(var_f, reps))
         if ranks.world > 1:     # the other reduce form on the same call, for the record
-            other = 'reduce' if method == 'a2a' else 'a2a'
-            res['variant_F_fft_focus']['psf_ms_by_reduce_method'] = {method: res['variant_F_fft_focus']['psf_ms'],
-                                                                     other: timed_median(lambda: var_f(other), reps) * 1e3}
+            by = {method: res['variant_F_fft_focus']['psf_ms']}
+            for other in ('reduce', 'a2a', 'rs'):
+                if other != method:
+                    by[other] = timed_median(lambda o=other: var_f(o), reps) * 1e3
+            res['variant_F_fft_focus']['psf_ms_by_reduce_method'] = by
         # pipelined: a sequence of PSFs (frames of a time series / forward passes of an optimiser), one in flight behind the next
         pipe = PsfPipeline(wvls, wts, dx, 100.0, Q=1, reduce_to_all=False, reduce_method=method, depth=2, cache_pupil=True)
 
@@ -626,11 +711,11 @@ def reduce_alone_ms(ranks, n):
     """The one data-path collective on its own, both root-only forms: sum-reduce of an n^2 fp32 image to rank 0 (median of 5) as
     ONE torch.distributed.reduce and as all-to-all of slices + ordered local sum + gather (polychromatic._reduce_image)."""
     if ranks.world == 1:
-        return {'reduce': 0.0, 'a2a': 0.0}
+        return {'reduce': 0.0, 'a2a': 0.0, 'rs': 0.0}
     from prysm_amd.polychromatic import _reduce_image
     img = torch.ones((n, n), dtype=torch.float32, device='cuda')
     out = {}
-    for method in ('reduce', 'a2a'):
+    for method in ('reduce', 'a2a', 'rs'):
         fn = lambda: _reduce_image(img, ranks.world, None, False, method, True)   # noqa: E731
         fn()   # warm
         ts = sorted(ranks.timed(fn) for _ in range(5))
@@ -747,7 +832,7 @@ def main():
         if rank == 0 and not printed.is_set():
             printed.set()
             line['extras'] = f'not finished within --extras-budget {args.extras_budget:.0f} s; headline only'
-            print(json.dumps(line), flush=True)
+            emit(line)
         os._exit(0)
 
     dog = threading.Timer(args.extras_budget + (0.0 if rank == 0 else 5.0), give_up)
@@ -767,7 +852,7 @@ def main():
             red = reduce_alone_ms(ranks, n)
             extra['polychromatic'] = polychromatic_config5(ranks, n, red, args.reduce_method)
             extra['polychromatic']['reduce_alone_ms'] = red
-            extra['reduce_ms'] = red['a2a'] if extra['polychromatic']['reduce_method'] == 'a2a' else red['reduce']
+            extra['reduce_ms'] = red.get(extra['polychromatic']['reduce_method'], red['reduce'])
             f = extra['polychromatic']['variant_F_fft_focus']
             t1 = f['per_wavelength_ms_per_gpu'] * N_WAVELENGTHS      # this run's compute rate scaled to one GPU's 64 wavelengths
             extra['polychromatic']['scaling_model'] = scaling_model(
@@ -780,7 +865,7 @@ def main():
                 if rank == 0:
                     printed.set()
                     line.update(extra)
-                    print(json.dumps(line), flush=True)
+                    emit(line)
                 os._exit(0 if rank == 0 else 1)
 
     if rank == 0:
@@ -807,7 +892,7 @@ def main():
                 line['cpu_baseline'] = {'error': repr(exc)}
         if not printed.is_set():
             printed.set()
-            print(json.dumps(line), flush=True)
+            emit(line)
     dog.cancel()
     if world > 1:
         dist.barrier()

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PM_VERSION 106 /* 0.1.0 */
+#define PM_VERSION 107 /* 0.1.0 */
 
 /* dtype codes */
 enum { PM_C64 = 0, PM_C128 = 1, PM_F32 = 2, PM_F64 = 3, PM_BOOL = 4 };
@@ -411,6 +411,14 @@ int pm_set_tuning(const char* key, int32_t value);
  * private copy sees. */
 int pm_set_tuning_local(const char* key, int32_t value);
 void pm_reset_tuning_local(void);
+/* Which route does this descriptor take?  Writes ONE line into buf (n >= 64 bytes; longer lines are cut) that names the planner's
+ * decisions for op = 0 (pm_fft2) or op = 1 (pm_fft2_mul_ifft2) under the calling thread's knobs: the route ("engine", "engine-fold",
+ * "hermitian[-fold]", "natural-mixed", "natural", "radix-step", "bluestein-2d[-big]"; "fused", "fused-composite", "hermitian-chain",
+ * "composed"), the kernel class of each axis ("stockham", "mixed-radix", "bluestein", "direct"), tile width, layout and workspace
+ * bytes.  Host logic only -- no device is touched, so a table of shapes can be pinned to its routes on a machine without a GPU
+ * (the reference reaches every size through one scipy call, prysm/fttools.py:23-31; here a shape that slips to a slow route
+ * should fail a test, not a benchmark).  Returns 0, or the error pm_fft2 would return for an invalid descriptor. */
+int pm_plan_explain(const pm_fft2_desc* d, int32_t op, char* buf, size_t n);
 /* time `reps` launches of each pass of the transform with hipEvents on `stream`; ms[0] = row pass,
  * ms[1] = column pass (average per launch).  Used by bench.py for the roofline object. */
 int pm_fft2_time_passes(const pm_fft2_desc* d, const void* in, void* out, void* workspace,

@@ -6,6 +6,7 @@ device memory and streams; all arithmetic on the hot path happens in the HIP
 kernels behind this binding.
 """
 import ctypes
+import threading
 import os
 
 import numpy as np
@@ -50,6 +51,7 @@ SIGNATURES = {
     'pm_set_tuning': (c_i32, [ctypes.c_char_p, c_i32]),
     'pm_set_tuning_local': (c_i32, [ctypes.c_char_p, c_i32]),
     'pm_reset_tuning_local': (None, []),
+    'pm_plan_explain': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_i32, ctypes.c_char_p, c_sz]),
     'pm_fft2_workspace': (c_sz, [ctypes.POINTER(pm_fft2_desc)]),
     'pm_fft2': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_vp, c_vp, c_vp, c_sz, c_vp]),
     'pm_fft2_spectral_workspace': (c_sz, [ctypes.POINTER(pm_fft2_desc), c_i32]),
@@ -252,19 +254,43 @@ def ptr(t):
 class tuning_local:
     """``with tuning_local(fold=0, mix=0): ...`` -- performance knobs for the CALLING THREAD only (pm_set_tuning_local), restored on
     exit.  The process-wide pm_set_tuning is for start-up configuration; two threads driving the library at once (one pipeline per
-    thread, prysm's own advice) each take this."""
+    thread, prysm's own advice) each take this.
+
+    Blocks nest: the library keeps ONE private copy of the knobs per thread and can only reset it as a whole, so this class keeps the
+    thread's stack of open blocks and re-applies the outer ones when an inner block ends (or fails to start -- a knob the build
+    refuses leaves nothing half-applied).  Knobs set by direct pm_set_tuning_local calls are outside that stack and are lost at the
+    first exit."""
+
+    _tls = threading.local()
 
     def __init__(self, **knobs):
         self.knobs = knobs
 
+    @classmethod
+    def _replay(cls, lib):
+        lib.pm_reset_tuning_local()
+        for outer in getattr(cls._tls, 'stack', []):
+            for k, v in outer.items():
+                lib.pm_set_tuning_local(k.encode(), int(v))
+
     def __enter__(self):
         lib = load()
-        for k, v in self.knobs.items():
-            check(lib.pm_set_tuning_local(k.encode(), int(v)))
+        try:
+            for k, v in self.knobs.items():
+                check(lib.pm_set_tuning_local(k.encode(), int(v)))
+        except Exception:
+            self._replay(lib)
+            raise
+        if not hasattr(self._tls, 'stack'):
+            self._tls.stack = []
+        self._tls.stack.append(dict(self.knobs))
         return self
 
     def __exit__(self, *exc):
-        load().pm_reset_tuning_local()
+        stack = getattr(self._tls, 'stack', [])
+        if stack:
+            stack.pop()
+        self._replay(load())
         return False
 
 

@@ -5,10 +5,12 @@ torch's current stream.  No arithmetic happens in Python.
 """
 import ctypes
 import math
+import threading
 
 import torch
 
 from . import _lib as L
+from .graph import sequenced
 
 
 # The kernels write through raw pointers, which torch's version counters do not see: a caller-supplied `out=` tensor is marked
@@ -104,9 +106,31 @@ def _check_out(out, x, oshape, odt):
         raise ValueError('fft2: the last axis of `out` must be contiguous')
 
 
-def fft2(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
-         out_shape=None, out_off=(0, 0), out_shift=(0, 0), epilogue=L.PM_EPI_NONE,
-         mul=None, mul_x=None, mul_conj=False, out=None, weight=1.0, flags=0, synth=None, spectral=None):
+def fft2(x, *, synth=None, spectral=None, **kw):
+    """Fused 2-D transform (pm_fft2); see _fft2_call for the arguments.
+
+    synth (pupil synthesis inside the row pass) is a property of the ROUTE the library's planner picks -- this module's
+    synth_supported() restates the planner's test without its inputs (the mix / mix_min knobs, a tuning_local block, workspace
+    limits), so it can say yes where the planner then says PM_ERR_UNSUPPORTED.  When that happens for a single 2-D field the pupil
+    is materialised (pm_pupil_synth, what the call would have cost before the fusion existed) and the transform runs on it:
+    a disagreement costs time, never an exception."""
+    if synth is None or spectral is not None or x.dim() != 2:
+        return _fft2_call(x, synth=synth, spectral=spectral, **kw)
+    try:
+        return _fft2_call(x, synth=synth, **kw)
+    except NotImplementedError:
+        cdt = L._COMPLEX_OF[x.dtype] if not x.is_complex() else x.dtype
+        if isinstance(synth[0], str):       # ('packed', k): (amplitude, OPD) pairs
+            pairs = torch.view_as_real(x)
+            field = pupil_synth(pairs[..., 0].contiguous(), pairs[..., 1].contiguous(), synth[1], cdt)
+        else:
+            field = pupil_synth(synth[0], x, synth[1], cdt)
+        return _fft2_call(field, **kw)
+
+
+def _fft2_call(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0),
+               out_shape=None, out_off=(0, 0), out_shift=(0, 0), epilogue=L.PM_EPI_NONE,
+               mul=None, mul_x=None, mul_conj=False, out=None, weight=1.0, flags=0, synth=None, spectral=None):
     """Fused 2-D transform (pm_fft2).
 
     x          : (m, n) complex tensor, or a (B, m, n) stack transformed in one launch pair; each field sits at
@@ -549,6 +573,18 @@ def quadratic_phase(x, y, c, cdtype):
 # the stream because the vectors are produced on it: another stream would have to wait for that work.
 _AS_TF_CACHE = {}
 _AS_TF_CACHE_MAX = 16
+_AS_TF_LOCK = threading.Lock()      # one pipeline per host thread is the advertised use: lookups, inserts and evictions are serialised
+
+
+def clear_tf_cache(stream=None):
+    """Forget the cached transfer-function vectors -- all of them, or those made on one stream (its raw handle): a destroyed stream's
+    handle can be handed out again, and a new stream with an old handle must not find vectors it never waited for."""
+    with _AS_TF_LOCK:
+        if stream is None:
+            _AS_TF_CACHE.clear()
+        else:
+            for k in [k for k in _AS_TF_CACHE if k[-1] == stream]:
+                _AS_TF_CACHE.pop(k, None)
 
 
 def as_tf_vectors(shape, wvl, dx, z, cdtype, cache=True):
@@ -558,7 +594,8 @@ def as_tf_vectors(shape, wvl, dx, z, cdtype, cache=True):
     if cache and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         cache = False       # tensors made during a graph capture live in the graph's pool: never handed to eager code
     if cache:
-        hit = _AS_TF_CACHE.get(key)
+        with _AS_TF_LOCK:
+            hit = _AS_TF_CACHE.get(key)
         if hit is not None:
             return hit
     hy = torch.empty(rows, dtype=cdtype, device=L.device())
@@ -566,9 +603,10 @@ def as_tf_vectors(shape, wvl, dx, z, cdtype, cache=True):
     L.check(lib.pm_as_tf_vectors(L._COMPLEX_CODE[cdtype], rows, cols, float(wvl), float(dx), float(z), L.ptr(hy),
                                  L.ptr(hx), L.stream_ptr()))
     if cache:
-        if len(_AS_TF_CACHE) >= _AS_TF_CACHE_MAX:
-            _AS_TF_CACHE.pop(next(iter(_AS_TF_CACHE)))
-        _AS_TF_CACHE[key] = (hy, hx)
+        with _AS_TF_LOCK:
+            while len(_AS_TF_CACHE) >= _AS_TF_CACHE_MAX:
+                _AS_TF_CACHE.pop(next(iter(_AS_TF_CACHE)), None)
+            _AS_TF_CACHE[key] = (hy, hx)
     return hy, hx
 
 
@@ -682,3 +720,12 @@ def cgemm_abs2(A, B, opA=0, opB=0, alpha=1.0, out=None, weight=1.0):
 
 def ceil_half(d):
     return math.ceil(d / 2)
+
+
+# Inside a ``prysm_amd.graph.sequence()`` block every array-level entry point asks the block for its stream (independent calls alternate
+# between the streams of a ring, dependent ones follow their producer); outside of one the wrapper is one thread-local read.
+for _name in ('fft2', 'pack_amp_opd', 'fft2_mul_ifft2', 'fft1', 'czt_vectors', 'czt_axis', 'fft1_ramp', 'cmul', 'rmul', 'scale_sep', 'abs2',
+              'abs_arg', 'sum_modes', 'encircled_energy', 'encircled_energy_adjoint', 'spline_prefilter', 'sample_map', 'pupil_synth',
+              'quadratic_phase', 'as_tf_vectors', 'outer', 'embed', 'pad_index', 'mdft_basis', 'mdft_basis_grid', 'cgemm', 'cgemm_abs2'):
+    globals()[_name] = sequenced(globals()[_name])
+del _name

@@ -147,6 +147,8 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("log_k")) t.log_k = v > 12 ? 12 : v;   // < 0: auto; log2(N / tile width) makes the intermediate natural (row-major)
     else if (is("row_log_g")) t.row_log_g = v < 0 ? 0 : (v > 3 ? 3 : v);
     else if (is("row_var")) t.row_var = v;
+    else if (is("row_cap")) t.row_cap = v ? 1 : 0;
+    else if (is("stagger_group")) t.stagger_group = v ? 1 : 0;
     else if (is("gemm_bk")) t.gemm_bk = v;
     else if (is("gemm_bm")) t.gemm_bm = v;
     else if (is("gemm_dma")) t.gemm_dma = v ? 1 : 0;
@@ -228,6 +230,9 @@ int pm_fft_stagger(int pass) {
 int pm_two_units() { return tuning().two_units; }
 int pm_engine_p8() { return tuning().engine_p8; }
 #endif
+
+int pm_row_cap() { return tuning().row_cap; }
+int pm_stagger_group() { return tuning().stagger_group; }
 
 int pm_num_cus() {
     static int cus[64] = {0};
@@ -733,6 +738,16 @@ static bool plan_fused_mix(const pm_fft2_desc* d, FusedPlan& p) {
     p.w_ld = (N + line - 1) / line * line;
     if (!mix_fits(N, d->in_ld, es, false) || !mix_fits(M, p.w_ld, es, true) || !mix_fits(N, d->out_ld, es, false) || !mix_fits(N, p.w_ld, es, false))
         return false;
+    {   // pass A is the first pass of pm_fft2 on this shape (fused_mix_run): its planner must take the same natural intermediate, or the
+        // query below would promise a chain the run then refuses
+        pm_fft2_desc da = *d;
+        da.flags = (d->flags & PM_FLAG_REAL_INPUT) | PM_FLAG_PASS1_ONLY;
+        da.mul_kind = PM_MUL_NONE;
+        da.direction = -1;
+        da.batch = 0;
+        const Fft2Plan pa = plan_fft2(&da);
+        if (pa.tc != 0 || pa.w_ld != p.w_ld || pa.blue_n || pa.blue2d || pa.big_rn) return false;
+    }
     p.mixmid = true;
     p.fold = false;
     p.tc = 0;
@@ -1732,6 +1747,52 @@ int pm_fft2(const pm_fft2_desc* d, const void* in, void* out, void* workspace, s
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == PM_C64) return fft2_run<float>(d, p, in, out, workspace, st);
     return fft2_run<double>(d, p, in, out, workspace, st);
+}
+
+// One line that says which route a descriptor takes -- the planner's decisions (plan_fft2 / plan_fused / herm_conv_plan under the
+// calling thread's tuning knobs) in words.  Host logic only: callable without a GPU, so the routes of a table of shapes are pinned by
+// a CPU test (tests/test_host_logic.py) and a shape that falls to a slow route shows up there and not as a timing.
+static const char* axis_route(bool engine, bool mix, bool blue) { return engine ? "stockham" : (mix ? "mixed-radix" : (blue ? "bluestein" : "direct")); }
+int pm_plan_explain(const pm_fft2_desc* d, int32_t op, char* buf, size_t n) {
+    if (!buf || n < 64) return fail(PM_ERR_ARG, "pm_plan_explain: a buffer of at least 64 bytes is required");
+    buf[0] = 0;
+    int rc = check_fft2(d);
+    if (rc) return rc;
+    const long long M = d->in_y.n, N = d->in_x.n;
+    const char* dt = d->dtype == PM_C64 ? "c64" : "c128";
+    if (op == 1) {
+        if (d->flags & PM_FLAG_REAL_OUTPUT) {
+            HermConvPlan hp;
+            if (!herm_conv_plan(d, hp)) { snprintf(buf, n, "fft2_mul_ifft2 %lldx%lld %s: route=unsupported (real output needs the Hermitian chain)", M, N, dt); return 0; }
+            snprintf(buf, n, "fft2_mul_ifft2 %lldx%lld %s: route=hermitian-chain passes=3 ws=%zu", M, N, dt, hp.ws_bytes);
+            return 0;
+        }
+        FusedPlan p;
+        if (!plan_fused(d, p)) { snprintf(buf, n, "fft2_mul_ifft2 %lldx%lld %s: route=composed (two fft2 calls)", M, N, dt); return 0; }
+        snprintf(buf, n, "fft2_mul_ifft2 %lldx%lld %s: route=%s passes=3 rows=%s mid=%s%s ws=%zu", M, N, dt, p.mixmid ? "fused-composite" : "fused",
+                 axis_route(p.logn >= 0, !(p.logn >= 0), false), p.mixmid ? "mixed-radix-resident" : "stockham-pair", p.fold ? " fold" : "", p.ws_bytes);
+        return 0;
+    }
+    if (op != 0) return fail(PM_ERR_ARG, "pm_plan_explain: op must be 0 (pm_fft2) or 1 (pm_fft2_mul_ifft2)");
+    const Fft2Plan p = plan_fft2(d);
+    if (p.big_rn) {
+        const long long np_ = N / p.big_rn, mp_ = M / p.big_rm;
+        snprintf(buf, n, "fft2 %lldx%lld %s: route=radix-step rows=%dx%s(%lld) cols=%dx%s(%lld) ws=%zu", M, N, dt, p.big_rn,
+                 engine_log2(np_) >= 0 ? "stockham" : "mixed-radix", np_, p.big_rm, engine_log2(mp_) >= 0 ? "stockham" : "mixed-radix", mp_, p.ws_bytes);
+    } else if (p.blue2d) {
+        snprintf(buf, n, "fft2 %lldx%lld %s: route=%s conv=%lldx%lld ws=%zu", M, N, dt, p.blue_big ? "bluestein-2d-big" : "bluestein-2d",
+                 (long long)blue_conv_len(M), (long long)blue_conv_len(N), p.ws_bytes);
+    } else if (p.r2c) {
+        snprintf(buf, n, "fft2 %lldx%lld %s: route=hermitian%s rows=stockham-r2c(%lld) cols=stockham(%lld%s) tile=%d log_k=%d ws=%zu", M, N, dt,
+                 p.fold ? "-fold" : "", N / 2, p.fold ? M / 2 : M, p.fold ? "x2" : "", p.tc, p.log_k, p.ws_bytes);
+    } else {
+        const bool en = p.logn >= 0, em = p.logm >= 0;
+        snprintf(buf, n, "fft2 %lldx%lld %s: route=%s rows=%s(%lld) cols=%s(%lld%s) tile=%d log_k=%d chunk=%lld ws=%zu", M, N, dt,
+                 (en && em) ? (p.fold ? "engine-fold" : "engine") : ((p.mix_n || !p.blue_n) && (p.mix_m || !p.blue_m) && (p.mix_n || p.mix_m) ? "natural-mixed" : "natural"),
+                 axis_route(en, p.mix_n, p.blue_n), N, axis_route(em, p.mix_m, p.blue_m), p.fold ? M / 2 : M, p.fold ? "x2" : "", p.tc, p.log_k,
+                 (long long)p.chunk, p.ws_bytes);
+    }
+    return 0;
 }
 
 size_t pm_fft2_spectral_workspace(const pm_fft2_desc* d, int32_t count) {

@@ -20,6 +20,8 @@
 //
 // All functions are __host__ __device__: tools/emu_fft.cpp runs them on the CPU.
 #pragma once
+#include <type_traits>
+
 #include "fft_engine.h"
 
 namespace pm {
@@ -373,6 +375,9 @@ template <typename T> PM_HD ColStoreNat<T> at_batch(ColStoreNat<T> p, int b) {
 // ------------------------------------------------------------------ row mode
 // FULL: the window covers the whole axis and the sequence exists -> no per-element predicates at all
 // MODE: 0 complex input, 1 real input, 2 pupil synthesis (real OPD + amplitude)
+// (p.nt stays a runtime test inside the unrolled loop: every load then sits in a basic block of its own behind a scalar branch, which
+// looks wasteful and is what keeps the sixteen 64-bit addresses from being formed -- and held -- all at once: as a template argument
+// the row kernels grew by 12 - 40 registers and several lost a workgroup per CU, round 5, tools/kernel_table.py)
 template <typename C, int ROT, bool FULL = false, int MODE = 0>
 PM_HD void load_rot(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos,
                     cx<typename C::T> (&v)[C::E][C::P]) {
@@ -445,28 +450,48 @@ PM_HD void load(const RowLoadNat<typename C::T>& p, int blk, ThreadPos pos, cx<t
     else load_sel<C, 0>(p, blk, pos, v);
 }
 
+// Addresses of the tiled intermediate for row kernels.  Column c = t + m TPS of stored row `row` sits at element
+//     (((c >> ltc) * nrows + row) << ltc) + (c & tcm),         TL = 1 << ltc the layout tile width, tcm = TL - 1.
+// TPS and TL are powers of two, so whichever is larger the address splits into a per-thread part and a part that depends on the register
+// slot m only (no carry between them: TL <= TPS makes (m TPS) & tcm zero, TL > TPS makes t + ((m TPS) & tcm) stay below TL):
+//     thread:  (((t >> ltc) * nrows + row) << ltc) + (t & tcm)                     -> ONE 32-bit byte offset (vector register)
+//     slot:    ((((m TPS) >> ltc) * nrows) << ltc) + ((m TPS) & tcm)               -> uniform, scalar registers
+// The general form computed a 64-bit product, two 64-bit shifts and three 64-bit adds per point in vector registers -- 18 integer
+// instructions beside the 8 floating-point ones of a fold (round 5; the row + fold kernel of the headline issued twice the VALU
+// work of the column kernel, profiles/r04/headline_sq_counters.txt).  Byte offsets fit 32 bits: a slot's rows end below
+// TPS * nrows * sizeof(complex) <= 512 * 8192 * 16 B.
+template <typename C>
+struct TiledRowAddr {
+    using T = typename C::T;
+    static constexpr int ES = int(sizeof(cx<T>));
+    uint32_t voff;      // bytes
+    int ltc, nrows;
+    PM_HD TiledRowAddr(int t, int row, int ltc_, int nrows_) : ltc(ltc_), nrows(nrows_) {
+        const int tcm = (1 << ltc) - 1;
+        voff = uint32_t((((t >> ltc) * nrows + row) << ltc) + (t & tcm)) * uint32_t(ES);
+    }
+    PM_HD int64_t slot(int m) const {   // bytes, uniform
+        const int mt = m * C::TPS, tcm = (1 << ltc) - 1;
+        return ((int64_t(mt >> ltc) * nrows << ltc) + (mt & tcm)) * ES;
+    }
+    template <typename P> PM_HD P* at(P* base, int m) const {
+        typedef typename std::conditional<std::is_const<P>::value, const char, char>::type B;
+        return reinterpret_cast<P*>(reinterpret_cast<B*>(base) + slot(m) + voff);
+    }
+};
+
 template <typename C>
 PM_HD void store(const RowStoreTiled<typename C::T>& p, int blk, ThreadPos pos,
                  const cx<typename C::T> (&v)[C::E][C::P]) {
-    const int tcm = (1 << p.log_tc) - 1;
 #pragma unroll
     for (int e = 0; e < C::E; ++e) {
         const int seq = (blk * C::BO + pos.bo) * C::E + e;
         if (seq >= p.nseq) continue;
-        // element (seq, c) -> ((c >> ltc) * nseq + seq) << ltc  +  (c & tcm); c = t + m*TPS
-        if (C::TPS > tcm) {
-            // TPS is a multiple of the tile width: tile index and in-tile column separate cleanly
-            const int64_t base = ((int64_t(pos.t >> p.log_tc) * p.nseq + seq) << p.log_tc) + (pos.t & tcm);
-            const int64_t step = int64_t(C::TPS >> p.log_tc) * p.nseq << p.log_tc;
+        const TiledRowAddr<C> A(pos.t, seq, p.log_tc, p.nseq);
 #pragma unroll
-            for (int m = 0; m < C::P; ++m) p.dst[base + m * step] = v[e][m];
-        } else {
-#pragma unroll
-            for (int m = 0; m < C::P; ++m) {
-                const int c = pos.t + m * C::TPS;
-                const int64_t a = ((int64_t(c >> p.log_tc) * p.nseq + seq) << p.log_tc) + (c & tcm);
-                p.dst[a] = v[e][m];
-            }
+        for (int m = 0; m < C::P; ++m) {
+            *A.at(p.dst, m) = v[e][m];
+            if ((m & 3) == 3) PM_SCHED_FENCE();     // four slot bases (scalar register pairs) at a time: all sixteen spill scalars into vector registers
         }
     }
 }
@@ -478,17 +503,19 @@ PM_HD void store(const RowStoreFold<typename C::T>& p, int blk, ThreadPos pos,
     static_assert(C::E == 2, "the fold pairs the two rows of a thread");
     const int i = blk * C::BO + pos.bo;       // pair index = logical row of the lower half
     if (i >= p.npairs) return;
-    const cx<T> w = p.twm[i];
-    const int tcm = (1 << p.log_tc) - 1;
-    const int lo = p.swap ? 1 : 0, hi = lo ^ 1;
+    // rows that came in rotated by M/2 (swap): register set 0 holds the UPPER row of the pair -- the sum does not care and the
+    // difference changes sign, which the twiddle absorbs (a runtime select of the register sets cost four v_cndmask per point)
+    cx<T> w = p.twm[i];
+    if (p.swap) w = {-w.x, -w.y};
+    const TiledRowAddr<C> A(pos.t, i, p.log_tc, p.npairs);
+    cx<T>* const d1 = p.dst + p.plane_stride;
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
-        const int c = pos.t + m * C::TPS;
-        const int64_t a = ((int64_t(c >> p.log_tc) * p.npairs + i) << p.log_tc) + (c & tcm);
-        const cx<T> s = {v[lo][m].x + v[hi][m].x, v[lo][m].y + v[hi][m].y};
-        const cx<T> d = {v[lo][m].x - v[hi][m].x, v[lo][m].y - v[hi][m].y};
-        p.dst[a] = s;
-        p.dst[a + p.plane_stride] = cmul(d, w);
+        const cx<T> s = {v[0][m].x + v[1][m].x, v[0][m].y + v[1][m].y};
+        const cx<T> d = {v[0][m].x - v[1][m].x, v[0][m].y - v[1][m].y};
+        *A.at(p.dst, m) = s;
+        *A.at(d1, m) = cmul(d, w);
+        if ((m & 3) == 3) PM_SCHED_FENCE();     // or the products of all sixteen points are formed (and held) before the first store
     }
 }
 
@@ -538,20 +565,18 @@ template <typename C>
 PM_HD void load(const RowLoadTiled<typename C::T>& p, int blk, ThreadPos pos, cx<typename C::T> (&v)[C::E][C::P]) {
     using T = typename C::T;
     static_assert(C::CI == 1, "row mode");
-    const int tlm = (1 << p.log_tl) - 1;
 #pragma unroll
     for (int e = 0; e < C::E; ++e) {
         const int seq = (blk * C::BO + pos.bo) * C::E + e;
         const bool ok = seq < p.nseq;
-        const int q = p.row0 + (ok ? seq : 0);
+        const TiledRowAddr<C> A(pos.t, p.row0 + (ok ? seq : 0), p.log_tl, p.nrows);
 #pragma unroll
         for (int m = 0; m < C::P; ++m) {
-            const int c = pos.t + m * C::TPS;
-            const int64_t a = ((int64_t(c >> p.log_tl) * p.nrows + q) << p.log_tl) + (c & tlm);
             cx<T> val = {T(0), T(0)};
-            if (ok) val = p.src[a];
+            if (ok) val = *A.at(p.src, m);
             if (p.conj) val.y = -val.y;
             v[e][m] = val;
+            if ((m & 3) == 3) PM_SCHED_FENCE();
         }
     }
 }
@@ -582,16 +607,15 @@ PM_HD void load(const RowLoadFold<typename C::T>& p, int blk, ThreadPos pos, cx<
     static_assert(C::CI == 1 && C::E == 2, "the unfold rebuilds the two rows of a thread");
     const int n = blk * C::BO + pos.bo;
     const bool ok = n < p.npairs;
-    const int tlm = (1 << p.log_tl) - 1;
     const cx<T> w = p.twm[ok ? n : 0];
+    const TiledRowAddr<C> A(pos.t, ok ? n : 0, p.log_tl, p.npairs);
+    const cx<T>* const s1 = p.src + p.plane_stride;
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
-        const int c = pos.t + m * C::TPS;
-        const int64_t a = ((int64_t(c >> p.log_tl) * p.npairs + (ok ? n : 0)) << p.log_tl) + (c & tlm);
         cx<T> a0 = {T(0), T(0)}, a1 = {T(0), T(0)};
         if (ok) {
-            a0 = p.src[a];
-            a1 = p.src[a + p.plane_stride];
+            a0 = *A.at(p.src, m);
+            a1 = *A.at(s1, m);
         }
         const cx<T> b = cmulc(a1, w);      // conj(W_M^n) A1[n]
         cx<T> lo = {a0.x + b.x, a0.y + b.y}, hi = {a0.x - b.x, a0.y - b.y};
@@ -601,6 +625,7 @@ PM_HD void load(const RowLoadFold<typename C::T>& p, int blk, ThreadPos pos, cx<
         }
         v[0][m] = lo;
         v[1][m] = hi;
+        if ((m & 3) == 3) PM_SCHED_FENCE();
     }
 }
 

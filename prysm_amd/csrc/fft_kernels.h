@@ -45,6 +45,7 @@ struct ColCfgSel {
 
 // log_g with the start-up stagger of fft_kernel packed above it: bits 8-15 the units, bits 16+ the workgroups per CU (those that start with
 // the launch = 256 CUs x that); no stagger for a launch of a single round
+int pm_stagger_group();             // capi.hip: the knob stagger_group
 int pm_fft_stagger(int pass);       // capi.hip: the knobs fft_stagger (row kernels) / fft_stagger_col (column kernels) / fft_stagger_mid
 static inline int engine_log_g(int log_g, int grid, size_t lds_bytes, int nt, int pass) {      // pass: 0 rows, 1 columns, 2 the middle pass of a fused chain, 3 / 4 the real-input row / Hermitian column kernels (fft_r2c.h)
     const int by_lds = lds_bytes ? int(size_t(160) * 1024 / lds_bytes) : 8, by_waves = 2048 / nt;
@@ -61,21 +62,41 @@ static inline int engine_log_g(int log_g, int grid, size_t lds_bytes, int nt, in
     // the real-input row kernel: nothing at any setting)
     if (stg < 0) stg = pass == 3 ? 0 : (per_cu == 1 ? 8 : (pass == 0 ? 1 : 0));
     if (stg == 0) return log_g;
-    return log_g | ((stg & 255) << 8) | (per_cu << 16);
+    // bit 30 (knob stagger_group, column kernels): the delay is hashed from the SIBLING GROUP of a workgroup (the 2^log_g
+    // workgroups group_remap puts on one XCD with adjacent tiles) instead of from the workgroup -- siblings then stay in step, and the
+    // 64 B pieces they write into the same 128 B lines (the mirrored half: one element off alignment) can meet in that XCD's L2
+    return log_g | ((stg & 255) << 8) | ((per_cu & 255) << 16) | ((pass != 0 && pass != 3 && pm_stagger_group()) ? (1 << 30) : 0);
 }
 
 __device__ __forceinline__ int engine_stagger(int log_g_packed) {
     const int stg = (log_g_packed >> 8) & 255;
-    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;     // dispatch order: x first
-    if (stg && int(lin) < ((log_g_packed >> 16) << 8)) {
+    unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;     // dispatch order: x first
+    if (stg && int(lin) < (((log_g_packed >> 16) & 255) << 8)) {
+        if (log_g_packed & (1 << 30)) lin = ((lin >> 3) >> (log_g_packed & 255)) * 8 + (lin & 7);
         const unsigned h = (lin * 2654435761u) >> 29;
         for (unsigned i = 0; i < h * unsigned(stg); ++i) __builtin_amdgcn_s_sleep(8);
     }
     return log_g_packed & 255;
 }
 
+// Minimum waves per SIMD the register allocation must leave room for (the second __launch_bounds__ argument of hipcc).  The paired
+// rows of a folded transform (VAR 4, E = 2) are the kernels that sit at a register boundary: complex64 fits four 256-thread
+// workgroups per CU at 128 VGPRs; complex128 (128 registers of data alone) fits three at 168 for rows up to 4096 points only with
+// spills (VAR 6, knob row_cap) and otherwise runs two per CU.
+template <typename C, bool COL, int VAR, typename S>
+constexpr int fft_kernel_min_waves() {
+    constexpr bool chirp = std::is_same<S, RowStoreChirp<typename C::T>>::value;     // (the Bluestein chain's last pass: 141 - 149 registers, left alone)
+    if (!COL && (VAR == 4 || VAR == 6) && C::E == 2 && !chirp) {
+        if (sizeof(typename C::T) == 4) return 4;
+        return (VAR == 6 && C::LOGN <= 12) ? 3 : 1;      // VAR 6: VAR 4 under the cap (knob row_cap)
+    }
+    // complex64 column tiles of 512 threads: two workgroups per CU need 128 registers (the allocation sits at 128 - 130)
+    if (COL && sizeof(typename C::T) == 4 && C::NT == 512 && C::LDS_BYTES <= 80 * 1024) return 4;
+    return 1;
+}
+
 template <typename C, bool COL, int VAR, typename L, typename S>
-__global__ void __launch_bounds__(C::NT) fft_kernel(const L lp, const S sp, const cx<typename C::T>* __restrict__ tw, const int log_g_packed) {
+__global__ void __launch_bounds__(C::NT, (fft_kernel_min_waves<C, COL, VAR, S>())) fft_kernel(const L lp, const S sp, const cx<typename C::T>* __restrict__ tw, const int log_g_packed) {
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
     // start-up stagger (knob fft_stagger, packed above the group shift by engine_log_g): the workgroups that start with the launch wait
@@ -483,6 +504,7 @@ __global__ void __launch_bounds__(C::NT, 4)
 }
 
 int pm_num_cus();   // capi.hip: compute units of the current device (cached)
+int pm_row_cap();   // capi.hip: the knob row_cap
 
 // mode (tuning colmul_mode; 512-thread tiles = 2048-point columns only): 0 one tile per workgroup, 1 the same under a 128-VGPR cap
 // (two workgroups per CU), 2 persistent workgroups that prefetch the next tile (fft_col_mul_pf_kernel)
@@ -621,6 +643,9 @@ int launch_fold_one(const RowLoadNat<T>& lp, const RowStoreFold<T>& sp, const cx
     }
 #endif
     auto kern = fft_kernel<C, false, 4, RowLoadNat<T>, RowStoreFold<T>>;
+    if constexpr (sizeof(T) == 8 && LOGN <= 12) {
+        if (pm_row_cap()) kern = fft_kernel<C, false, 6, RowLoadNat<T>, RowStoreFold<T>>;
+    }
     constexpr size_t LDSB = C::LDS_BYTES;
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
@@ -647,6 +672,9 @@ template <typename T, int LOGN>
 int launch_unfold_one(const RowLoadFold<T>& lp, const RowStoreNat<T>& sp, const cx<T>* tw, int npairs, hipStream_t st, int nbatch) {
     using C = typename RowCfgSel<T, LOGN, 4>::type;
     auto kern = fft_kernel<C, false, 4, RowLoadFold<T>, RowStoreNat<T>>;
+    if constexpr (sizeof(T) == 8 && LOGN <= 12) {
+        if (pm_row_cap()) kern = fft_kernel<C, false, 6, RowLoadFold<T>, RowStoreNat<T>>;
+    }
     constexpr size_t LDSB = C::LDS_BYTES;
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));

@@ -59,7 +59,6 @@ __global__ void __launch_bounds__(C::NT) fft_row_r2c_kernel(const L lp, const R2
     if constexpr (C::E == 2 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
     else fft_run<C>(v, pos, pm_smem, tw);
     constexpr int N2 = C::N;          // complex points per row = N / 2
-    const int tcm = (1 << sp.log_tc) - 1;
     // partner exchange, ONE slot e at a time through the same LDS region: the sequences of the workgroup in natural order, then each
     // thread combines its bins with Z[(N2 - k) mod N2] in place.  (Both slots at once doubled the kernel's LDS -- 69.6 KiB at 2048
     // complex points with two rows per thread: two 256-thread workgroups per CU instead of four.)
@@ -76,29 +75,31 @@ __global__ void __launch_bounds__(C::NT) fft_row_r2c_kernel(const L lp, const R2
             v[e][m] = r2c_combine(v[e][m], zp, cmul(wt, w32<T>(m)), k == 0);
         }
     }
+    // stores: the lean addressing of the tiled intermediate (fft_io.h TiledRowAddr)
     if constexpr (FOLD) {
         const int i = unit * C::BO + pos.bo;       // pair index = logical row of the lower half
         if (i >= sp.nseq) return;
-        const cx<T> wi = sp.twm[i];
-        const int lo = sp.swap ? 1 : 0, hi = lo ^ 1;
+        cx<T> wi = sp.twm[i];
+        if (sp.swap) wi = {-wi.x, -wi.y};          // rows rotated by M/2: the difference changes sign (store(RowStoreFold))
+        const TiledRowAddr<C> A(pos.t, i, sp.log_tc, sp.nseq);
+        cx<T>* const d1 = sp.dst + sp.plane_stride;
 #pragma unroll
         for (int m = 0; m < C::P; ++m) {
-            const int k = pos.t + m * C::TPS;
-            const cx<T> x0 = v[lo][m], x1 = v[hi][m];
-            const int64_t a = ((int64_t(k >> sp.log_tc) * sp.nseq + i) << sp.log_tc) + (k & tcm);
-            sp.dst[a] = x0 + x1;
-            sp.dst[a + sp.plane_stride] = cmul(x0 - x1, wi);
+            const cx<T> x0 = v[0][m], x1 = v[1][m];
+            *A.at(sp.dst, m) = x0 + x1;
+            *A.at(d1, m) = cmul(x0 - x1, wi);
+            if ((m & 3) == 3) PM_SCHED_FENCE();
         }
     } else {
 #pragma unroll
         for (int e = 0; e < C::E; ++e) {
             const int seq = (unit * C::BO + pos.bo) * C::E + e;
             if (seq >= sp.nseq) continue;
+            const TiledRowAddr<C> A(pos.t, seq, sp.log_tc, sp.nseq);
 #pragma unroll
             for (int m = 0; m < C::P; ++m) {
-                const int k = pos.t + m * C::TPS;
-                const int64_t a = ((int64_t(k >> sp.log_tc) * sp.nseq + seq) << sp.log_tc) + (k & tcm);
-                sp.dst[a] = v[e][m];
+                *A.at(sp.dst, m) = v[e][m];
+                if ((m & 3) == 3) PM_SCHED_FENCE();
             }
         }
     }

@@ -10,6 +10,14 @@
 #define PM_HD inline
 #endif
 
+// a fence for the instruction scheduler (device code; nothing on the host emulators): keeps unrolled batches apart so that the
+// products of sixteen points are not all formed -- and held in registers -- before the first store
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PM_SCHED_FENCE() ((void)0)
+#endif
+
 namespace pm {
 
 template <typename T>

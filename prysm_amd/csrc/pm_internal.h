@@ -182,6 +182,9 @@ struct Tuning {
     int mix_stagger = 4;      // ... start-up stagger of the column kernel's workgroups in units of 512 cycles x 0 .. 7 where a CU holds one tile (fft_mixed.h MixShape::stagger); 0 = off
     int mix_ablate = 0;       // experiment builds: timing-only ablations of the mixed-radix kernels (fft_mixed.h MixShape::ablate; results are wrong)
     int two_units = 0;        // experiment builds: two units per workgroup in the passes of a 2048-point complex64 transform (bit 0 rows, bit 1 columns)
+    int row_cap = 0;          // complex128 paired rows of a folded transform (up to 4096 points): 1 = the kernel built under a 168-register cap, three
+                              // 256-thread workgroups per CU instead of two (fft_kernels.h fft_kernel_min_waves; it spills ~20 - 60 registers)
+    int stagger_group = 0;    // column kernels: the start-up stagger hashed per sibling group instead of per workgroup (fft_kernels.h engine_log_g)
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)
 };

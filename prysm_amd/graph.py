@@ -7,6 +7,9 @@ hipGraph on ROCm) and replayed with one launch: the 21 us of Python + ctypes iss
 fields of 1024^2 and below, disappears.  This is the MI355X answer to the reference's advice of fusing work to
 amortise launch overhead (docs: GPU and Exascale Computing.ipynb).
 """
+import functools
+import threading
+
 import torch
 
 from . import _lib as L
@@ -53,6 +56,27 @@ def capture(fn, *example_inputs, warmup=2):
     return CapturedModel(fn, *example_inputs, warmup=warmup)
 
 
+def _tensors_of(obj, out):
+    """device tensors reachable from a result: a tensor, a sequence / dict of results, an object that holds its array in `data`
+    (Wavefront -- not materialising a lazy one --, RichData)"""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            out.append(obj)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _tensors_of(o, out)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _tensors_of(o, out)
+    elif obj is not None and not isinstance(obj, (int, float, complex, str, bytes)):
+        d = getattr(obj, '__dict__', None)
+        if d:
+            t = d.get('_data', d.get('data'))
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                out.append(t)
+    return out
+
+
 class StreamRing:
     """Round-robin HIP streams for a SEQUENCE of independent propagations (the fields of a stack that does not fit one launch, the
     wavelengths or field points of a model, one pipeline per thread as the reference advises -- GPU and Exascale Computing.ipynb).
@@ -64,12 +88,19 @@ class StreamRing:
     streams evict each other's intermediates (95 -> 133 us) -- `worth_it(shape, dtype)` says which side of that a shape is on.
 
         ring = StreamRing(2)
-        ring.fork()                                           # every stream of the ring waits for what the caller's stream has queued
-        outs = [ring.run(P.focus, x, 1) for x in fields]     # each call on the next stream
+        outs = [ring.run(P.focus, x, 1) for x in fields]     # each call on the next stream (the first run of a batch forks)
         ring.join()                                           # the caller's stream now waits for every stream of the ring
 
-    fork / join are the only synchronisation (one event each way per stream): a wait per call would cost more host time than a 2048^2
-    propagation takes on the device.  Inputs must come from before the fork (or from the same stream of the ring).
+    Synchronisation is one event each way per stream and per BATCH, not per call (a wait per call would cost more host time than a
+    2048^2 propagation takes on the device):
+      * fork() orders every stream of the ring behind what the caller's stream has queued; the first run() after a join() (or after
+        construction) forks by itself, so "loop {run ...; join; consume}" is ordered in both directions on every trip.  Inputs made
+        on the caller's stream AFTER that fork need another fork() (or must come from the same stream of the ring).
+      * join() orders the caller's stream behind every stream of the ring.
+      * every result tensor of run() is noted as "also used on the caller's stream" (Tensor.record_stream) the moment it is made: it
+        was allocated on a ring stream, and without that note torch's caching allocator would hand its block to the next run() on
+        that stream as soon as the caller dropped the tensor -- while the caller's stream could still have reads of it queued
+        (ADVICE r4).  With the note, a dropped block is reusable once the caller's stream has passed the point of the drop.
 
     Workspaces are per stream (_lib.workspace), outputs come from torch's stream-aware allocator; results are the same bits.
     """
@@ -78,6 +109,7 @@ class StreamRing:
         L.load()
         self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(n)))]
         self._next = 0
+        self._forked = False      # a batch is open: the ring's streams are ordered behind the caller's stream
 
     @staticmethod
     def worth_it(shape, dtype=torch.complex64, streams=2):
@@ -89,14 +121,146 @@ class StreamRing:
         cur = torch.cuda.current_stream()
         for s in self.streams:
             s.wait_stream(cur)
+        self._forked = True
 
-    def run(self, fn, *args, **kwargs):
+    def next_stream(self):
         s = self.streams[self._next]
         self._next = (self._next + 1) % len(self.streams)
+        return s
+
+    def run_on(self, s, fn, *args, **kwargs):
+        """fn(*args, **kwargs) on stream `s` of the ring; its result tensors are recorded on the caller's stream"""
+        if not self._forked:
+            self.fork()
+        cur = torch.cuda.current_stream()
         with torch.cuda.stream(s):
-            return fn(*args, **kwargs)
+            out = fn(*args, **kwargs)
+        for t in _tensors_of(out, []):
+            t.record_stream(cur)
+        return out
+
+    def run(self, fn, *args, **kwargs):
+        return self.run_on(self.next_stream(), fn, *args, **kwargs)
 
     def join(self):
         cur = torch.cuda.current_stream()
         for s in self.streams:
             cur.wait_stream(s)
+        self._forked = False
+
+
+_seq_state = threading.local()
+
+
+def active_sequence():
+    """the Sequence the calling thread is inside of, or None"""
+    return getattr(_seq_state, 'seq', None)
+
+
+class Sequence:
+    """``with prysm_amd.graph.sequence(): ...`` around an UNMODIFIED loop of Wavefront / propagation calls: consecutive calls that do
+    not depend on each other run on alternating HIP streams (a StreamRing), calls that do depend stay on their producer's stream.
+
+        with graph.sequence() as seq:
+            psfs = [P.Wavefront.from_amp_and_phase(amp, opd, wvl, dx).focus(efl, Q=2).intensity for opd in opds]
+        # here the caller's stream is ordered behind all of it
+
+    What prysm users write for small fields (prysm/propagation/wavefront.py:478-504 in a loop over wavelengths or field points;
+    prysm/x/polarization.py:478-553 is the reference's own batch precedent) gets the two-stream overlap of StreamRing without
+    being restructured into stacks or ring.run(...) calls: 2048^2 complex64 `focus` 29.6 -> 26.6 us per field, and the smaller the
+    field the more there is to hide.
+
+    How: every array-level entry point of the library (prysm_amd._ops, and Wavefront arithmetic) asks `dispatch` for its stream.  A
+    call whose tensor arguments were all made before the block (or on the host) takes the next stream of the ring; a call that
+    reads a tensor produced inside the block runs on the stream that produced it (same-stream order IS the dependence), waiting for
+    any other producers it reads from.  Leaving the block joins.  The results are bit-identical to the one-stream run: same
+    kernels, per-stream workspaces.
+
+    Inputs made by plain torch operations on the caller's stream inside the block (amp.to(dtype), a mask built in the loop) are
+    waited for when the caller's stream is not idle at the call.  The one rule: RESULTS must not be read by plain torch operations
+    or copied to the host before the block ends (or seq.join()) -- Wavefront arithmetic, .intensity / .phase and prysm_amd's own
+    host conversions (array_to_true_numpy, Wavefront.__array__) are part of the library and do the right thing.
+    """
+
+    def __init__(self, streams=2, device=None):
+        self.ring = StreamRing(streams, device)
+        self._producer = {}       # storage pointer of a tensor made inside the block -> its stream
+        self._depth = 0
+        self._prev = None
+
+    def __enter__(self):
+        self._prev = active_sequence()
+        if self._prev is not None:
+            raise RuntimeError('prysm_amd.graph.sequence() blocks do not nest')
+        _seq_state.seq = self
+        self.ring.fork()
+        return self
+
+    def __exit__(self, *exc):
+        _seq_state.seq = None
+        self.join()
+        return False
+
+    def fork(self):
+        self.ring.fork()
+
+    def join(self):
+        self.ring.join()
+        self._producer.clear()
+
+    def _known(self, tensors):
+        return sum(1 for t in tensors if t.untyped_storage().data_ptr() in self._producer)
+
+    def dispatch(self, fn, args, kwargs):
+        """run fn(*args, **kwargs) on the stream the data dependences pick; nested library calls run inside the outer call's stream"""
+        if self._depth:
+            return fn(*args, **kwargs)
+        ins = _tensors_of(args, [])
+        if kwargs:
+            _tensors_of(kwargs, ins)
+        s = None
+        others = None
+        for t in ins:
+            ps = self._producer.get(t.untyped_storage().data_ptr())
+            if ps is None or ps is s:
+                continue
+            if s is None:
+                s = ps
+            else:
+                others = (others or []) + [ps]
+        fresh = s is None or len(ins) > self._known(ins)
+        if s is None:
+            s = self.ring.next_stream()
+        if others:
+            for o in others:
+                s.wait_stream(o)
+        if fresh:
+            # an input that was not made inside the block: from before it (ordered by the fork) or from a plain torch operation on the
+            # caller's stream since (amp.to(dtype), a mask built in the loop).  If the caller's stream is not idle, wait for it.
+            cur = torch.cuda.current_stream()
+            if not cur.query():
+                s.wait_stream(cur)
+        self._depth += 1
+        try:
+            out = self.ring.run_on(s, fn, *args, **kwargs)
+        finally:
+            self._depth -= 1
+        for t in _tensors_of(out, []):
+            self._producer[t.untyped_storage().data_ptr()] = s
+        return out
+
+
+def sequence(streams=2, device=None):
+    """Context manager: independent propagations inside the block alternate between `streams` HIP streams (see Sequence)."""
+    return Sequence(streams, device)
+
+
+def sequenced(fn):
+    """decorator of the library's array-level entry points: inside a sequence() block the call goes through Sequence.dispatch"""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        seq = getattr(_seq_state, 'seq', None)
+        if seq is None:
+            return fn(*args, **kwargs)
+        return seq.dispatch(fn, args, kwargs)
+    return wrapper

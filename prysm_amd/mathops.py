@@ -32,6 +32,10 @@ def array_to_true_numpy(*args):
     """
     if len(args) == 0:
         return
+    from .graph import active_sequence
+    seq = active_sequence()
+    if seq is not None:
+        seq.join()      # inside a graph.sequence() block the results live on the ring's streams: a host copy waits for them first
     out = []
     for arg in args:
         if isinstance(arg, _scalar_types) or isinstance(arg, _np.ndarray):

@@ -11,6 +11,7 @@ sum-reduce of the real image (RCCL over xGMI; `backend="nccl"` is RCCL on ROCm) 
 incoherent sum.  One process per GPU; world size 1 needs no process group.
 """
 import math
+import threading
 import weakref
 
 import torch
@@ -36,11 +37,13 @@ def shard_bounds(n_items, rank, world_size):
 # or the caller calls clear_packed_pupil_cache().  Tensors without a version counter (torch.inference_mode) are never cached.
 _PACK_CACHE = []
 _PACK_CACHE_MAX = 4
+_PACK_LOCK = threading.Lock()
 
 
 def clear_packed_pupil_cache():
     """Forget every cached packed (amplitude, OPD) map (after a write the version counters cannot see)."""
-    del _PACK_CACHE[:]
+    with _PACK_LOCK:
+        del _PACK_CACHE[:]
 
 
 def _version(t):
@@ -59,15 +62,21 @@ def packed_pupil(amp, opd, a_syn, o_syn, cache=False):
     va, vo = _version(amp), _version(opd)
     if not cache or va == -1 or vo == -1:
         return _ops.pack_amp_opd(a_syn, o_syn)
-    for i, (ra, ca, ro, co, packed) in enumerate(_PACK_CACHE):
-        if (ra() if ra is not None else None) is amp and ro() is opd and ca == va and co == vo:
-            if i:
-                _PACK_CACHE.insert(0, _PACK_CACHE.pop(i))
-            return packed
+    # ... and per STREAM: the map is packed by work queued on the current stream, and a reader on another stream (StreamRing, one
+    # pipeline per thread) would not be ordered behind it
+    from . import _lib as L
+    st = L._cur_stream() if opd.is_cuda else 0
+    with _PACK_LOCK:
+        for i, (ra, ca, ro, co, ps, packed) in enumerate(_PACK_CACHE):
+            if (ra() if ra is not None else None) is amp and ro() is opd and ca == va and co == vo and ps == st:
+                if i:
+                    _PACK_CACHE.insert(0, _PACK_CACHE.pop(i))
+                return packed
     packed = _ops.pack_amp_opd(a_syn, o_syn)
-    _PACK_CACHE.insert(0, (None if amp is None else weakref.ref(amp), _version(amp), weakref.ref(opd), _version(opd), packed))
-    del _PACK_CACHE[_PACK_CACHE_MAX:]
-    _PACK_CACHE[:] = [e for e in _PACK_CACHE if (e[0] is None or e[0]() is not None) and e[2]() is not None]
+    with _PACK_LOCK:
+        _PACK_CACHE.insert(0, (None if amp is None else weakref.ref(amp), _version(amp), weakref.ref(opd), _version(opd), st, packed))
+        del _PACK_CACHE[_PACK_CACHE_MAX:]
+        _PACK_CACHE[:] = [e for e in _PACK_CACHE if (e[0] is None or e[0]() is not None) and e[2]() is not None]
     return packed
 
 
@@ -78,6 +87,29 @@ def _group_info(group):
     return use, (dist.get_rank(group) if use else 0), (dist.get_world_size(group) if use else 1)
 
 
+_SCRATCH = {}
+
+
+def _scratch(tag, shape, dtype, device):
+    """A receive buffer kept between calls, per (use, shape, dtype, device, stream): the reduce sits on the critical path of every image, and
+    a fresh 67 MB allocation per call (plus a torch.cat of as much at the root) was an extra sweep of the image inside it.
+    Stream-ordered like _lib.workspace: one image's collective and the next one's are queued on the same stream."""
+    st = 0
+    if device.type == 'cuda':
+        from . import _lib as L
+        st = L._cur_stream()
+    key = (tag, tuple(shape), dtype, device, st)
+    t = _SCRATCH.get(key)
+    if t is None:
+        if len(_SCRATCH) >= 8:
+            _SCRATCH.clear()
+        t = _SCRATCH[key] = torch.empty(shape, dtype=dtype, device=device)
+    return t
+
+
+REDUCE_METHODS = ('reduce', 'a2a', 'rs')
+
+
 def _reduce_image(acc, world, group, reduce_to_all, method='reduce', use_dist=None):
     """The one data-path collective: sum-reduce of the real image over the ranks (RCCL; gloo in the CPU tests).
 
@@ -86,9 +118,15 @@ def _reduce_image(acc, world, group, reduce_to_all, method='reduce', use_dist=No
                               scratch afterwards (gloo and RCCL both leave partial sums in them).
     root only, 'a2a'        : the fully connected xGMI form of SURVEY 8(e): every rank sends slice j of its image to rank j
                               (one all-to-all, 7 distinct links per GPU), sums the `world` slices it received in rank order
-                              (pm_sum_modes: fixed order, bitwise reproducible) and the first rank gathers the reduced slices.
-                              Needs numel % world == 0; falls back to 'reduce' otherwise.
+                              (pm_sum_modes: fixed order, bitwise reproducible whatever the transport does) and the first rank
+                              gathers the reduced slices STRAIGHT INTO the slices of its image (no list of parts, no concatenation).
+    root only, 'rs'         : the same exchange as ONE library collective, reduce_scatter_tensor (RCCL picks ring or direct by
+                              size), then the same gather.  The order of the additions is the library's: reproducible on a fixed
+                              topology, not bit-equal to 'a2a'.
+    'a2a' and 'rs' need numel % world == 0 and a contiguous image; they fall back to 'reduce' otherwise.
     """
+    if method not in REDUCE_METHODS:
+        raise ValueError(f'reduce_method must be one of {REDUCE_METHODS}, got {method!r}')
     if use_dist is None:
         use_dist = world > 1
     if not use_dist:
@@ -97,21 +135,25 @@ def _reduce_image(acc, world, group, reduce_to_all, method='reduce', use_dist=No
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
         return acc
     root = dist.get_global_rank(group, 0) if group is not None else 0
-    if method == 'a2a' and acc.numel() % world == 0 and acc.is_contiguous():
-        from . import _ops
+    if method in ('a2a', 'rs') and acc.numel() % world == 0 and acc.is_contiguous():
         per = acc.numel() // world
         send = acc.view(world, per)
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=group)
-        if acc.is_cuda:
-            part = _ops.sum_modes(recv.view(world, 1, per), [1.0] * world).view(per)
+        if method == 'rs':
+            part = _scratch('rs', (per,), acc.dtype, acc.device)
+            dist.reduce_scatter_tensor(part, acc.view(-1), op=dist.ReduceOp.SUM, group=group)
         else:
-            part = recv.sum(0)
+            recv = _scratch('a2a', (world, per), acc.dtype, acc.device)
+            dist.all_to_all_single(recv, send, group=group)
+            if acc.is_cuda:
+                from . import _ops
+                part = _ops.sum_modes(recv.view(world, 1, per), [1.0] * world, out=_scratch('a2a_part', (1, per), acc.dtype, acc.device)).view(per)
+            else:
+                part = _scratch('a2a_part', (per,), acc.dtype, acc.device)
+                torch.sum(recv, 0, out=part)       # rank order, one pass
         me = dist.get_rank()
-        parts = [torch.empty_like(part) for _ in range(world)] if me == root else None
-        dist.gather(part, parts, dst=root, group=group)
-        if me == root:
-            torch.cat(parts, out=acc.view(-1))
+        # the root receives slice j of the reduced image from rank j directly in acc[j * per : (j + 1) * per] (its own send data there is
+        # spent: the exchange above has completed in stream order)
+        dist.gather(part, [send[j] for j in range(world)] if me == root else None, dst=root, group=group)
         return acc
     dist.reduce(acc, dst=root, op=dist.ReduceOp.SUM, group=group)
     return acc

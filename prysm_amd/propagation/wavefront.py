@@ -14,6 +14,7 @@ import torch
 
 from .. import _lib as L
 from .. import _ops
+from ..graph import sequenced
 from .._richdata import RichData
 from ._kernels import phase_prefix
 from .fft import (
@@ -86,7 +87,11 @@ class Wavefront:
 
     def __array__(self, dtype=None, copy=None):
         """numpy conversion = the field (keeps np.asarray(wavefront) from building an object array)."""
-        a = self.data.detach().cpu().numpy() if isinstance(self.data, torch.Tensor) else np.asarray(self.data)
+        if isinstance(self.data, torch.Tensor):
+            from ..mathops import array_to_true_numpy
+            a = array_to_true_numpy(self.data)      # (joins an open graph.sequence() block first)
+        else:
+            a = np.asarray(self.data)
         return a.astype(dtype) if dtype is not None else a
 
     def _fusable(self, Q):
@@ -154,6 +159,7 @@ class Wavefront:
         return coeff * torch.sum(rsq * _ops.cmul(L_bar, screen, conj_b=True).imag)
 
     @property
+    @sequenced
     def intensity(self):
         """Intensity, abs(w)^2 (wavefront.py:146-151)."""
         data = self.data
@@ -165,16 +171,19 @@ class Wavefront:
         return RichData(out, self.dx, self.wavelength)
 
     @property
+    @sequenced
     def phase(self):
         """Phase, angle(w)."""
         return RichData(torch.angle(self.data), self.dx, self.wavelength)
 
     @property
+    @sequenced
     def real(self):
         """re(w)."""
         return RichData(self.data.real if self.data.is_complex() else self.data, self.dx, self.wavelength)
 
     @property
+    @sequenced
     def imag(self):
         """im(w)."""
         return RichData(self.data.imag if self.data.is_complex() else torch.zeros_like(self.data), self.dx,
@@ -234,6 +243,7 @@ class Wavefront:
             return self
         return Wavefront(cropped, self.wavelength, self.dx, self.space)
 
+    @sequenced
     def __numerical_operation__(self, other, op, reverse=False):
         """Apply an operation to this wavefront with another piece of data (wavefront.py:360-383)."""
         func = getattr(operator, op)

@@ -35,7 +35,7 @@ for batched in (True, False):
     got = tonp(polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2, batched=batched))
     worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))
 # root-only results: one reduce, and the all-to-all of slices + ordered local sum + gather
-for method in ('reduce', 'a2a'):
+for method in ('reduce', 'a2a', 'rs'):
     got = polychromatic_psf(amp, opd, wvls, wts, dx, 100.0, Q=2, batched=False, reduce_to_all=False, reduce_method=method)
     if rank == 0:
         worst = max(worst, float(np.abs(tonp(got) - want).max() / np.abs(want).max()))
@@ -61,7 +61,7 @@ for sc in set(scales):
     o2 = O.hopkins_w040(r / 5, sc)
     wantf[sc] = O.sum_of_2d_modes(np.asarray([O.intensity(O.focus(O.from_amp_and_phase(amp, o2, float(w)), 2)) for w in wvls]), wts)
 amp_t = torch.from_numpy(amp).cuda()
-for kw in (dict(reduce_to_all=True), dict(reduce_method='reduce'), dict(reduce_method='a2a')):
+for kw in (dict(reduce_to_all=True), dict(reduce_method='reduce'), dict(reduce_method='a2a'), dict(reduce_method='rs')):
     pipe = PsfPipeline(wvls, wts, dx, 100.0, Q=2, batched=False, depth=2, **kw)
     pend = [pipe.submit(amp_t, torch.from_numpy(O.hopkins_w040(r / 5, sc)).cuda()) for sc in scales]
     imgs = [p.result() for p in pend]

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     for s in declared_symbols():
         assert hasattr(lib, s), f'{s} declared in prysm_amd.h but not exported'
         assert s in _lib.SIGNATURES, f'{s} has no ctypes signature in prysm_amd/_lib.py'
-    assert lib.pm_version() == 106
+    assert lib.pm_version() == 107
 
 
 def test_argument_errors_are_reported_without_a_gpu(lib):
@@ -186,3 +186,121 @@ def test_product_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in re.sub(r'""".*?"""', '', src, flags=re.S), f
+
+
+# ----------------------------------------------------------------------------- routes (pm_plan_explain: host logic, no GPU)
+
+def _route(lib, m, n, dt='c64', op=0, Q=None, real=False, mul=False, epi=0, batch=0, synth=False):
+    from prysm_amd import _lib as L
+    d = L.pm_fft2_desc()
+    d.dtype, d.direction = (L.PM_C64 if dt == 'c64' else L.PM_C128), -1
+    if Q:
+        d.in_y = L.pm_axis(m, m // Q, (m - m // Q) // 2, m // 2)
+        d.in_x = L.pm_axis(n, n // Q, (n - n // Q) // 2, n // 2)
+        d.in_ld = n // Q
+    else:
+        d.in_y, d.in_x, d.in_ld = L.pm_axis(m, m, 0, m // 2), L.pm_axis(n, n, 0, n // 2), n
+    d.out_y, d.out_x, d.out_ld = L.pm_axis(m, m, 0, m // 2), L.pm_axis(n, n, 0, n // 2), n
+    if real:
+        d.flags |= L.PM_FLAG_REAL_INPUT
+    if synth:
+        d.flags |= L.PM_FLAG_SYNTH_INPUT
+    d.epilogue = epi
+    if mul:
+        d.mul_kind, d.mul, d.mul_x = L.PM_MUL_SEPARABLE, 16, 16
+    if batch:
+        d.batch, d.in_bstride, d.out_bstride = batch, m * n, m * n
+    buf = ctypes.create_string_buffer(256)
+    L.check(lib.pm_plan_explain(ctypes.byref(d), op, buf, 256))
+    return buf.value.decode()
+
+
+# (arguments of _route, substrings the line must contain): the routes of round 5.  A change of the planner that moves a shape shows up
+# here, on the CPU box -- the 1536 x 16384 row is the routing bug ADVICE r3 found with a stopwatch.
+ROUTES = [
+    ((4096, 4096), ['route=engine-fold', 'rows=stockham(4096)', 'cols=stockham(2048x2)', 'tile=8', 'log_k=7', 'ws=134217728']),
+    ((4096, 4096, 'c128'), ['route=engine-fold', 'cols=stockham(2048x2)', 'log_k=2', 'ws=268435456']),
+    ((8192, 8192), ['route=engine-fold', 'rows=stockham(8192)', 'cols=stockham(4096x2)', 'log_k=3']),
+    ((8192, 8192, 'c128'), ['route=engine-fold', 'cols=stockham(4096x2)']),
+    ((2048, 2048), ['route=engine ', 'rows=stockham(2048)', 'cols=stockham(2048)', 'ws=33554432']),
+    ((1024, 1024), ['route=engine ', 'log_k=1']),
+    ((512, 512, 'c128'), ['route=engine ']),
+    ((64, 16), ['route=engine ', 'rows=stockham(16)', 'cols=stockham(64)']),
+    ((2048, 8192), ['route=engine ', 'rows=stockham(8192)', 'cols=stockham(2048)']),
+    ((8192, 2048), ['route=engine-fold', 'cols=stockham(4096x2)']),
+    ((16384, 16384), ['route=radix-step', 'rows=2xstockham(8192)', 'cols=2xstockham(8192)']),
+    ((32768, 4096), ['route=radix-step', 'cols=4xstockham(8192)', 'rows=1xstockham(4096)']),
+    ((1536, 16384), ['route=radix-step', 'rows=2xstockham(8192)', 'cols=3xstockham(512)']),
+    ((6144, 12288), ['route=radix-step', 'rows=3xstockham(4096)', 'cols=3xstockham(2048)']),
+    ((10000, 10000), ['route=radix-step', 'rows=2xmixed-radix(5000)', 'cols=2xmixed-radix(5000)']),
+    ((9000, 12000), ['route=radix-step', 'rows=2xmixed-radix(6000)', 'cols=2xmixed-radix(4500)']),
+    ((20000, 4096), ['route=radix-step', 'cols=4xmixed-radix(5000)']),
+    ((3000, 3000), ['route=natural-mixed', 'rows=mixed-radix(3000)', 'cols=mixed-radix(3000)', 'ws=72192000']),
+    ((3000, 3000, 'c128'), ['route=natural-mixed', 'rows=mixed-radix(3000)']),
+    ((1000, 1000), ['route=natural-mixed', 'ws=8064000']),
+    ((6006, 6006), ['route=natural-mixed', 'cols=mixed-radix(6006)']),
+    ((1020, 1900), ['route=natural-mixed', 'rows=mixed-radix(1900)', 'cols=mixed-radix(1020)']),
+    ((323, 380), ['route=natural-mixed', 'rows=mixed-radix(380)', 'cols=mixed-radix(323)']),
+    ((4096, 3000), ['route=natural-mixed', 'rows=mixed-radix(3000)', 'cols=stockham(4096)']),
+    ((3000, 4096), ['route=natural-mixed', 'rows=stockham(4096)', 'cols=mixed-radix(3000)']),
+    ((1536, 1536), ['route=natural-mixed', 'rows=mixed-radix(1536)']),
+    ((36, 36), ['route=natural-mixed']),
+    ((24, 24), ['route=natural ', 'rows=direct(24)', 'cols=direct(24)']),
+    ((997, 997), ['route=bluestein-2d', 'conv=2048x2048']),
+    ((2018, 2018), ['route=bluestein-2d', 'conv=4096x4096']),
+    ((1024, 1009), ['route=natural ', 'rows=bluestein(1009)', 'cols=stockham(1024)']),
+    ((4099, 4099), ['route=bluestein-2d-big', 'conv=16384x16384']),
+]
+ROUTES_KW = [
+    (dict(m=4096, n=4096, Q=2), ['route=engine ', 'cols=stockham(4096)', 'log_k=2', 'ws=67108864']),      # padded: unfolded, stored rows only
+    (dict(m=4096, n=4096, real=True, epi=3), ['route=hermitian-fold', 'rows=stockham-r2c(2048)', 'cols=stockham(2048x2)', 'tile=16']),
+    (dict(m=8192, n=8192, real=True, epi=3), ['route=hermitian-fold', 'rows=stockham-r2c(4096)', 'cols=stockham(4096x2)', 'tile=8']),
+    (dict(m=2048, n=2048, real=True), ['route=engine ']),               # a plain spectrum of a small real field stays on the complex path
+    (dict(m=4096, n=4096, real=True), ['route=hermitian-fold']),
+    (dict(m=3000, n=3000, real=True), ['route=natural-mixed']),         # composite grids: no Hermitian path yet (the real array is read by the complex kernels)
+    (dict(m=1024, n=1024, batch=100), ['route=engine ', 'chunk=16', 'ws=134217728']),
+    (dict(m=4096, n=4096, synth=True), ['route=engine-fold']),
+    (dict(m=3000, n=3000, synth=True), ['rows=mixed-radix(3000)']),
+    (dict(m=4096, n=4096, dt='c128', op=1, mul=True), ['route=fused ', 'passes=3', 'mid=stockham-pair fold', 'ws=268435456']),
+    (dict(m=4096, n=4096, dt='c64', op=1, mul=True), ['route=fused ', 'fold']),
+    (dict(m=2048, n=2048, dt='c128', op=1, mul=True), ['route=fused ', 'mid=stockham-pair ws=']),
+    (dict(m=3000, n=3000, dt='c128', op=1, mul=True), ['route=fused-composite', 'mid=mixed-radix-resident']),
+    (dict(m=3000, n=4096, dt='c64', op=1, mul=True), ['route=fused-composite', 'rows=stockham']),
+    (dict(m=997, n=997, op=1, mul=True), ['route=composed']),
+    (dict(m=4096, n=3000, op=1, mul=True), ['route=composed']),          # a composite ROW length beside engine columns: two transforms
+]
+
+
+def test_routes_of_a_table_of_shapes(lib):
+    for args, want in ROUTES:
+        line = _route(lib, *args)
+        assert all(w in line for w in want), (args, line)
+    for kw, want in ROUTES_KW:
+        line = _route(lib, **kw)
+        assert all(w in line for w in want), (kw, line)
+    from prysm_amd import _lib as L
+    d = L.pm_fft2_desc()
+    d.dtype = 9
+    buf = ctypes.create_string_buffer(256)
+    assert lib.pm_plan_explain(ctypes.byref(d), 0, buf, 256) == L.PM_ERR_ARG
+    assert lib.pm_plan_explain(ctypes.byref(d), 0, buf, 8) == L.PM_ERR_ARG
+
+
+def test_routes_follow_the_knobs_and_tuning_local_nests(lib):
+    """leaving an inner tuning_local block used to discard the outer block's knobs; a block that fails to start (a knob the
+    product build refuses) must leave nothing half-applied"""
+    from prysm_amd import _lib as L
+    assert 'mixed-radix' in _route(lib, 1000, 1000) and 'engine-fold' in _route(lib, 4096, 4096)
+    with L.tuning_local(mix=0):
+        assert 'bluestein' in _route(lib, 1000, 1000)
+        with L.tuning_local(fold=0):
+            assert 'bluestein' in _route(lib, 1000, 1000) and 'route=engine ' in _route(lib, 4096, 4096)
+        assert 'bluestein' in _route(lib, 1000, 1000) and 'engine-fold' in _route(lib, 4096, 4096)
+        with pytest.raises(NotImplementedError):
+            with L.tuning_local(fold=0, spectral2=3):
+                pass
+        assert 'bluestein' in _route(lib, 1000, 1000) and 'engine-fold' in _route(lib, 4096, 4096)
+    assert 'mixed-radix' in _route(lib, 1000, 1000)
+    with L.tuning_local(log_k=0):
+        assert 'log_k=0' in _route(lib, 4096, 4096)
+    assert 'log_k=7' in _route(lib, 4096, 4096)

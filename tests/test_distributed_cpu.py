@@ -9,6 +9,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -101,9 +102,26 @@ def test_incoherent_sum_all_to_all_reduce_world2():
     np.testing.assert_allclose(res[0], ref, rtol=1e-12, atol=1e-12 * ref.max())
 
 
+def test_incoherent_sum_reduce_scatter_world2_and_3():
+    """root-only result through reduce_scatter_tensor + the gather into the slices of the root's image (round 5): the 64 x 64 image in two
+    slices over 2 ranks; over 3 ranks it does not divide and the call must fall back to the plain reduce"""
+    res, ref = _run(False, method='rs')
+    np.testing.assert_allclose(res[0], ref, rtol=1e-12, atol=1e-12 * ref.max())
+    res, ref = _run(False, method='rs', world=3)
+    np.testing.assert_allclose(res[0], ref, rtol=1e-12, atol=1e-12 * ref.max())
+
+
+def test_reduce_method_names_are_checked():
+    sys.path.insert(0, ROOT)
+    from prysm_amd.polychromatic import _reduce_image, REDUCE_METHODS
+    assert REDUCE_METHODS == ('reduce', 'a2a', 'rs')
+    with pytest.raises(ValueError):
+        _reduce_image(torch.zeros(4, 4), 1, None, False, method='ring')
+
+
 def test_incoherent_sum_subgroup_without_global_rank0():
     """dist.reduce's dst is a GLOBAL rank; a group [1, 2] must reduce to global rank 1"""
-    for method in ('reduce', 'a2a'):
+    for method in ('reduce', 'a2a', 'rs'):
         res, ref = _run(False, method=method, world=3, sub=True)
         np.testing.assert_allclose(res[1], ref, rtol=1e-12, atol=1e-12 * ref.max())
 
@@ -142,7 +160,7 @@ def test_psf_pipeline_frames_world2():
     r, _ = O.cart_to_polar(x, y)
     amp = O.circle(5, r)
     wvls, wts = np.linspace(0.5, 0.7, 5), np.linspace(1.0, 2.0, 5)
-    for method in ('reduce', 'a2a'):
+    for method in ('reduce', 'a2a', 'rs'):
         ctx = mp.get_context('spawn')
         q = ctx.Queue()
         port = _free_port()

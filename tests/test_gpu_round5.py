@@ -1,0 +1,273 @@
+"""GPU parity tests added in round 5:
+
+* the lean addressing of the tiled intermediate (fft_io.h TiledRowAddr) on every layout: layout tiles narrower AND wider than a
+  thread group (knob log_k), folded and unfolded, both precisions, the real-input row pass -- against numpy fp64;
+* the complex128 paired-row kernels under the register cap (knob row_cap) against the uncapped ones, bit for bit;
+* prysm_amd.graph.sequence(): an unmodified loop of Wavefront code on alternating streams, bit-equal to the one-stream run and
+  equal to the oracle; StreamRing batches that re-use inputs (results recorded on the caller's stream at join);
+* pupil synthesis in the load with a planner that says no (tuning_local(mix=0)): the pupil is materialised, nothing raises;
+* nested tuning_local blocks; the packed-pupil cache is per stream;
+* the three root-only reduce forms on a process group of one rank (RCCL).
+
+Tolerances as in test_gpu_parity.py (max error / max magnitude against fp64): 1e-10 complex128, 5e-6 complex64 transforms.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_max
+from oracle import prysm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-10
+TOL32 = 5e-6
+
+
+@pytest.fixture(scope='module')
+def pa():
+    import prysm_amd
+    from prysm_amd import _lib
+    _lib.load()   # fails loudly when the HIP library is missing
+    assert torch.cuda.is_available()
+    return prysm_amd
+
+
+def tonp(x):
+    from prysm_amd.mathops import array_to_true_numpy
+    if hasattr(x, 'data') and not isinstance(x, (np.ndarray, torch.Tensor)):
+        x = x.data
+    return array_to_true_numpy(x)
+
+
+def crandn(rng, shape, dtype=np.complex128):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+
+
+# ----------------------------------------------------------------------------- lean addressing of the tiled intermediate
+
+@pytest.mark.parametrize('shape,dtype', [((4096, 4096), np.complex64), ((4096, 2048), np.complex128), ((256, 4096), np.complex64),
+                                         ((512, 256), np.complex128), ((64, 16), np.complex64), ((2048, 8192), np.complex64)])
+@pytest.mark.parametrize('log_k', [-1, 0, 3, 7])
+def test_tiled_intermediate_layouts_vs_numpy(pa, shape, dtype, log_k):
+    """focus / unfocus with the layout tile of the intermediate from one column tile (log_k 0: narrower than every thread group) to
+    1024 columns (log_k 7: wider than the 128 .. 512 threads of a row): the per-thread offset + per-slot uniform base of round 5 must
+    land every element where the column pass reads it"""
+    from prysm_amd import _lib
+    P = pa.propagation
+    rng = np.random.default_rng(shape[0] + shape[1] + log_k)
+    x = crandn(rng, shape, dtype)
+    tol = TOL64 if dtype == np.complex128 else TOL32
+    with _lib.tuning_local(log_k=log_k):
+        assert rel_max(tonp(P.focus(x, 1)), O.focus(x.astype(np.complex128), 1)) < tol
+        assert rel_max(tonp(P.unfocus(x, 1)), O.unfocus(x.astype(np.complex128), 1)) < tol
+        if shape[0] >= 256:     # the padded (unfolded, zero rows skipped) form
+            small = x[:shape[0] // 2, :shape[1] // 2]
+            assert rel_max(tonp(P.focus(small, 2)), O.focus(small.astype(np.complex128), 2)) < tol
+
+
+@pytest.mark.parametrize('shape,dtype', [((4096, 4096), np.complex128), ((2048, 4096), np.complex128), ((4096, 2048), np.complex128)])
+def test_fused_chain_layouts_and_row_cap(pa, shape, dtype):
+    """the folded 3-pass chain (fold store, plane column passes, unfold load -- all three on the lean addressing) at two layouts, and the
+    paired complex128 rows built under the 168-register cap (knob row_cap) against the uncapped kernels: the same bits"""
+    from prysm_amd import _lib
+    P = pa.propagation
+    rng = np.random.default_rng(sum(shape))
+    x = crandn(rng, shape, dtype)
+    want = O.angular_spectrum(x, O.HeNe, 0.01, 25.0, Q=1)
+    got = {}
+    for log_k in (-1, 0, 5):
+        for cap in (0, 1):
+            with _lib.tuning_local(log_k=log_k, row_cap=cap):
+                got[log_k, cap] = P.angular_spectrum(x, O.HeNe, 0.01, 25.0, Q=1)
+                f = P.focus(x, 1)
+            assert rel_max(tonp(got[log_k, cap]), want) < TOL64
+            assert rel_max(tonp(f), O.focus(x, 1)) < TOL64
+    assert all(torch.equal(got[-1, 0], g) for g in got.values())
+
+
+@pytest.mark.parametrize('n', [4096, 2048, 512])
+def test_real_input_rows_on_the_lean_store(pa, n):
+    """the Hermitian path's row pass (fft_r2c.h) writes the tiled intermediate through the same addressing, folded from 1024 rows"""
+    from prysm_amd import otf
+    rng = np.random.default_rng(n)
+    psf = (rng.random((n, n)) + 0.01).astype(np.float32)
+    F = np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(psf.astype(np.float64))))
+    want = np.abs(F / F[n // 2, n // 2])
+    for log_k in (-1, 0, 6):
+        from prysm_amd import _lib
+        with _lib.tuning_local(log_k=log_k):
+            assert np.max(np.abs(tonp(otf.mtf_from_psf(psf, 1.0).data) - want)) < 5e-6
+
+
+# ----------------------------------------------------------------------------- sequences of independent propagations
+
+def _seven_planes(P, amp, opd, wvl):
+    """a small relay written as plain Wavefront code: pupil -> focus -> stop -> back -> free space -> focus -> intensity"""
+    wf = P.Wavefront.from_amp_and_phase(amp, opd, wvl, 0.04)
+    psf = wf.focus(100.0, Q=1)
+    back = psf.unfocus(100.0, Q=1)
+    back = back * P.Wavefront(amp.to(back.data.dtype), wvl, back.dx)
+    moved = back.free_space(dz=5.0, Q=1)
+    return moved.focus(100.0, Q=1).intensity.data
+
+
+@pytest.mark.parametrize('n,rdt', [(512, torch.float32), (1000, torch.float32), (256, torch.float64)])
+def test_sequence_block_matches_one_stream(pa, n, rdt):
+    """graph.sequence(): a loop over wavelengths of a seven-plane chain written as plain Wavefront code -- independent chains alternate
+    between two streams, the dependent steps of one chain follow their producer; the block's results are, bit for bit, the
+    one-stream results, the oracle's numbers, and they are safe to consume on the caller's stream after the block"""
+    from prysm_amd import graph
+    P = pa.propagation
+    g = torch.Generator(device='cuda').manual_seed(n)
+    amp = (torch.rand((n, n), device='cuda', generator=g) > 0.3).to(rdt)
+    opd = torch.randn((n, n), device='cuda', generator=g, dtype=rdt) * 30
+    wvls = [0.5 + 0.03 * i for i in range(6)]
+    want = [_seven_planes(P, amp, opd, w).clone() for w in wvls]
+    torch.cuda.synchronize()
+    with graph.sequence() as seq:
+        outs = [_seven_planes(P, amp, opd, w) for w in wvls]
+        streams_used = {id(s) for s in seq._producer.values()}
+    total = sum(o.sum() for o in outs)          # consumed on the caller's stream right after the block
+    torch.cuda.synchronize()
+    assert len(streams_used) == 2
+    assert all(torch.equal(o, w) for o, w in zip(outs, want)) and float(total) > 0
+    # and the chain itself against the oracle (first wavelength)
+    a, o = amp.double().cpu().numpy(), opd.double().cpu().numpy()
+    f = O.focus(O.from_amp_and_phase(a, o, wvls[0]), 1)
+    b = O.unfocus(f, 1) * a
+    m = O.angular_spectrum(b, wvls[0], 0.04, 5.0, Q=1)
+    ref = O.intensity(O.focus(m, 1))
+    assert rel_max(tonp(outs[0]), ref) < (4e-5 if rdt == torch.float32 else 1e-9)
+    assert graph.active_sequence() is None
+    with pytest.raises(RuntimeError):
+        with graph.sequence():
+            with graph.sequence():
+                pass
+    assert graph.active_sequence() is None
+
+
+def test_sequence_accumulator_and_host_conversion(pa):
+    """an `out=` accumulator makes consecutive calls dependent (they follow the accumulator's stream), and a host conversion inside
+    the block joins first"""
+    from prysm_amd import graph
+    P = pa.propagation
+    rng = np.random.default_rng(5)
+    fields = [torch.from_numpy(crandn(rng, (256, 256), np.complex64)).cuda() for _ in range(5)]
+    acc = torch.zeros((256, 256), dtype=torch.float32, device='cuda')
+    with graph.sequence() as seq:
+        for f in fields:
+            P.focus_intensity(f, 1, out=acc, weight=0.5)
+        assert len({id(s) for s in seq._producer.values()}) == 1
+        inside = tonp(acc)          # joins, then copies
+    want = sum(0.5 * O.intensity(O.focus(tonp(f).astype(np.complex128), 1)) for f in fields)
+    assert rel_max(inside, want) < 4e-5 and rel_max(tonp(acc), want) < 4e-5
+
+
+def test_stream_ring_batches_reuse_inputs(pa):
+    """'fork once; loop {run ...; join; consume; drop}' -- the first run of every batch forks and every result is recorded
+    on the caller's stream, so a dropped result's block cannot be handed to the next batch while the caller's reads are queued"""
+    from prysm_amd.graph import StreamRing
+    rng = np.random.default_rng(9)
+    fields = [torch.from_numpy(crandn(rng, (1024, 1024), np.complex64)).cuda() for _ in range(4)]
+    want = [pa.propagation.focus(f, 1).abs().sum().item() for f in fields]
+    ring = StreamRing(2)
+    for trip in range(6):
+        outs = [ring.run(pa.propagation.focus, f, 1) for f in fields]
+        ring.join()
+        assert not ring._forked
+        sums = [o.abs().sum() for o in outs]        # queued on the caller's stream
+        del outs                                     # the blocks go back to the allocator while those reads may still be queued
+        got = [s.item() for s in sums]
+        assert np.allclose(got, want, rtol=1e-6)
+
+
+# ----------------------------------------------------------------------------- planner / host agreements
+
+def test_synthesis_falls_back_when_the_planner_refuses(pa):
+    """_ops.synth_supported restates the planner's test without its inputs; with mix = 0 in a tuning_local block a 1000-wide
+    lazy pupil is not a row length whose kernel synthesises -- the call used to raise, now the pupil is materialised"""
+    from prysm_amd import _lib
+    P = pa.propagation
+    rng = np.random.default_rng(12)
+    amp = (rng.random((300, 1000)) > 0.3).astype(np.float32)
+    opd = (50 * rng.standard_normal((300, 1000))).astype(np.float32)
+    want = O.focus(O.from_amp_and_phase(amp.astype(np.float64), opd.astype(np.float64), 0.6328), 1)
+    wf = P.Wavefront.from_amp_and_phase(amp, opd, 0.6328, 0.04)
+    assert rel_max(tonp(wf.focus(100.0, Q=1).data), want) < 2e-5          # mixed-radix rows synthesise
+    with _lib.tuning_local(mix=0):
+        wf2 = P.Wavefront.from_amp_and_phase(amp, opd, 0.6328, 0.04)
+        assert rel_max(tonp(wf2.focus(100.0, Q=1).data), want) < 2e-5     # Bluestein rows do not: materialised
+        assert rel_max(tonp(wf2.focus_intensity(100.0, Q=1).data), O.intensity(want)) < 4e-5
+
+
+def test_tuning_local_blocks_nest(pa):
+    """the inner block's exit used to discard the outer block's knobs"""
+    from prysm_amd import _lib
+    lib = _lib.load()
+
+    def route(n):
+        d = _lib.pm_fft2_desc()
+        d.dtype, d.direction = _lib.PM_C64, -1
+        d.in_y = d.in_x = d.out_y = d.out_x = _lib.pm_axis(n, n, 0, 0)
+        d.in_ld = d.out_ld = n
+        buf = ctypes.create_string_buffer(256)
+        _lib.check(lib.pm_plan_explain(ctypes.byref(d), 0, buf, 256))
+        return buf.value.decode()
+    assert 'mixed-radix' in route(1000) and 'engine-fold' in route(4096)
+    with _lib.tuning_local(mix=0):
+        assert 'mixed-radix' not in route(1000)
+        with _lib.tuning_local(fold=0):
+            assert 'mixed-radix' not in route(1000) and 'engine-fold' not in route(4096)
+        assert 'mixed-radix' not in route(1000) and 'engine-fold' in route(4096)      # the outer block survives the inner exit
+        with pytest.raises(NotImplementedError):
+            with _lib.tuning_local(fold=1, spectral2=3):       # refused by the product build: nothing of the block may stick
+                pass
+        assert 'mixed-radix' not in route(1000) and 'engine-fold' in route(4096)
+    assert 'mixed-radix' in route(1000)
+
+
+def test_packed_pupil_cache_is_per_stream(pa):
+    from prysm_amd import polychromatic as pc
+    amp = torch.ones((64, 64), device='cuda')
+    opd = torch.randn((64, 64), device='cuda')
+    pc.clear_packed_pupil_cache()
+    a = pc.packed_pupil(amp, opd, amp, opd, cache=True)
+    assert pc.packed_pupil(amp, opd, amp, opd, cache=True) is a
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        b = pc.packed_pupil(amp, opd, amp, opd, cache=True)
+        assert b is not a and pc.packed_pupil(amp, opd, amp, opd, cache=True) is b
+    torch.cuda.current_stream().wait_stream(s)
+    assert torch.equal(a, b)
+    pc.clear_packed_pupil_cache()
+
+
+def test_root_only_reduce_forms_on_a_one_rank_group(pa):
+    """'reduce', 'a2a' and 'rs' on RCCL with a process group of one rank: every collective of the 8-GPU path executes here
+    (all_to_all_single, reduce_scatter_tensor, gather into views of the image), twice (the receive buffers are kept)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from prysm_amd.polychromatic import _reduce_image
+    if dist.is_initialized():
+        pytest.skip('a process group is already up in this process')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        img = torch.rand((512, 512), device='cuda')
+        for method in ('reduce', 'a2a', 'rs'):
+            for _ in range(2):
+                acc = img.clone()
+                out = _reduce_image(acc, 1, None, False, method=method, use_dist=True)
+                torch.cuda.synchronize()
+                assert out is acc and torch.equal(out, img)
+    finally:
+        dist.destroy_process_group()
