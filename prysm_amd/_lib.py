@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PRYSM_AMD_LIB: another BUILD of the same library (tools/: the -DPM_EXPERIMENTS build in prysm_amd/alt/ for A/B measurements)
+# PRYSM_AMD_LIB: another BUILD of the same library (tools/exp_ab_libs.py: two builds -- e.g. two commits -- against each other on one box)
 LIB_PATH = os.environ.get('PRYSM_AMD_LIB') or os.path.join(_HERE, 'libprysm_amd.so')
 
 PM_C64, PM_C128, PM_F32, PM_F64, PM_BOOL = 0, 1, 2, 3, 4
@@ -114,8 +114,14 @@ def load():
             f'{LIB_PATH} is missing: build it with `make -C prysm_amd/csrc -j8` (or '
             '`python -c "import __graft_entry__ as g; g.build()"`).  prysm_amd has no CPU fallback.')
     lib = ctypes.CDLL(LIB_PATH)
+    other_build = bool(os.environ.get('PRYSM_AMD_LIB'))
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)   # AttributeError here = the library does not export a declared symbol
+        try:
+            fn = getattr(lib, name)   # AttributeError here = the library does not export a declared symbol
+        except AttributeError:
+            if other_build:           # an OLDER build under test (tools/exp_ab_libs.py): it may predate an entry point; calling it raises
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = lib
@@ -172,7 +178,7 @@ def device():
 
 
 # torch.cuda.current_stream() / current_device() build Python objects and re-check the runtime on every call (~6 us of the ~21 us a
-# small propagation costs on the host, tools/exp_host_profile.py); the raw accessors return the same integers
+# small propagation costs on the host, experiments/scripts/exp_host_profile.py); the raw accessors return the same integers
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 _raw_device = getattr(torch._C, '_cuda_getDevice', None)
 

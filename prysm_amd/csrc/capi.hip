@@ -15,9 +15,6 @@
 #include "fft_r2c_types.h"
 #include "fft_conv1_types.h"
 #include "fft_spectral_types.h"
-#ifdef PM_EXPERIMENTS
-#include "fft_spectral2.h"
-#endif
 #include "fft_c2r_types.h"
 
 namespace pm {
@@ -147,7 +144,6 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("log_k")) t.log_k = v > 12 ? 12 : v;   // < 0: auto; log2(N / tile width) makes the intermediate natural (row-major)
     else if (is("row_log_g")) t.row_log_g = v < 0 ? 0 : (v > 3 ? 3 : v);
     else if (is("row_var")) t.row_var = v;
-    else if (is("row_cap")) t.row_cap = v ? 1 : 0;
     else if (is("stagger_group")) t.stagger_group = v ? 1 : 0;
     else if (is("gemm_bk")) t.gemm_bk = v;
     else if (is("gemm_bm")) t.gemm_bm = v;
@@ -226,12 +222,7 @@ int pm_fft_stagger(int pass) {
     const Tuning& t = tuning();
     return pass == 2 ? t.fft_stagger_mid : (pass == 1 ? t.fft_stagger_col : (pass == 3 ? t.fft_stagger_r2c : (pass == 4 ? t.fft_stagger_herm : t.fft_stagger)));
 }
-#ifdef PM_EXPERIMENTS
-int pm_two_units() { return tuning().two_units; }
-int pm_engine_p8() { return tuning().engine_p8; }
-#endif
 
-int pm_row_cap() { return tuning().row_cap; }
 int pm_stagger_group() { return tuning().stagger_group; }
 
 int pm_num_cus() {
@@ -1544,94 +1535,6 @@ static int fft2_spectral_group(const pm_fft2_desc* d, const Fft2Plan& p, const S
     return launch_col_spectral<T>(p.logm, cl, cs, twm, ntiles, sibling_log_g(p.log_k), w, st, 1);
 }
 
-#ifdef PM_EXPERIMENTS
-// ---- the same in groups of 2 .. 4 wavelengths on the kernels that keep four waves per SIMD (fft_spectral2.h): complex64, rows of 1024 ..
-// 4096 samples, column tiles of 1024 / 2048 points (the planes of a folded 4096-row transform included), every bin of the output kept
-static bool spectral2_shape(const pm_fft2_desc* d, const Fft2Plan& p) {
-    const int want = PM_FLAG_SYNTH_INPUT | PM_FLAG_SYNTH_PACKED;
-    if (tuning().spectral2 < 2 || d->dtype != PM_C64) return false;
-    if ((d->flags & want) != want || (d->flags & (PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY))) return false;
-    if (d->epilogue != PM_EPI_ABS2_ACCUM || d->batch > 1 || d->mul_kind != PM_MUL_NONE) return false;
-    if (p.r2c || p.big_rn || p.blue2d || p.tc == 0 || p.col_var != 0) return false;
-    const int lt = p.logm - (p.fold ? 1 : 0);
-    if (p.logn < 10 || p.logn > 12 || lt < 10 || lt > 11 || p.logn + p.logm < tuning().spectral2_min_log) return false;
-    const int64_t M = d->in_y.n, N = d->in_x.n;
-    if (!(d->in_x.shift == 0 || d->in_x.shift == N / 2) || !(d->in_y.shift == 0 || d->in_y.shift == M / 2) || d->in_y.len <= 0) return false;
-    if (d->out_y.len != M || d->out_y.off != 0 || d->out_x.len != N || d->out_x.off != 0) return false;
-    if (!(d->out_y.shift == 0 || d->out_y.shift == M / 2) || (d->out_x.shift % p.tc) != 0 || (d->out_ld % 2) != 0) return false;
-    return int64_t(256) * d->out_ld * 8 < (int64_t(1) << 32) && d->in_ld < (int64_t(1) << 28);    // 32-bit per-thread byte offsets
-}
-
-static int fft2_spectral2_group(const pm_fft2_desc* d, const Fft2Plan& p, const Spectral& w, const void* in, void* out, void* ws, hipStream_t st) {
-    using T = float;
-    const int64_t M = d->in_y.n, N = d->in_x.n;
-    const int rows = int(d->in_y.len);
-    int err = 0;
-    cx<T>* W = reinterpret_cast<cx<T>*>(ws);
-    const cx<T>* tw = twiddles<T>(N, &err);
-    if (!tw) return err;
-    int ltl = 0;
-    while ((1 << ltl) < (p.tc << p.log_k)) ++ltl;
-    const int64_t tl = int64_t(1) << ltl, ntl = (N + tl - 1) / tl;
-    const int H = int(M / 2);
-    const bool keep = tuning().spectral2_keep != 0;
-    Sp2Row<T> gr{};
-    gr.src = reinterpret_cast<const cx<T>*>(in);
-    gr.ld = d->in_ld;
-    gr.off = int(d->in_x.off);
-    gr.len = int(d->in_x.len);
-    gr.rot = d->in_x.shift ? 8 : 0;
-    gr.nrows = rows;
-    // streaming loads of the map only when it is read once per group AND the group's intermediates are what the caches should hold
-    gr.nt = (tuning().nt_in >= 0 ? tuning().nt_in : 0) && (w.nb <= 2 || keep);
-    gr.dst = W;
-    gr.fstride = w.fstride;
-    gr.plane_stride = p.fold ? ntl * H * tl : 0;
-    gr.drows = p.fold ? H : rows;
-    gr.log_tl = ltl;
-    gr.swap = (p.fold && d->in_y.shift == M / 2) ? 1 : 0;
-    gr.twm = nullptr;
-    if (p.fold) {
-        gr.twm = twiddles<T>(M, &err);
-        if (!gr.twm) return err;
-    }
-    int rc = launch_row_spectral2(p.logn, p.fold, keep, gr, tw, w, st);
-    if (rc) return rc;
-    const int lt = p.logm - (p.fold ? 1 : 0);
-    const int64_t L = int64_t(1) << lt;
-    const cx<T>* twc = twiddles<T>(L, &err);
-    if (!twc) return err;
-    Sp2Col<T> gc{};
-    gc.src = W;
-    gc.fstride = w.fstride;
-    gc.plane_stride = gr.plane_stride;
-    gc.log_k = p.log_k;
-    gc.dst = reinterpret_cast<T*>(out);
-    gc.qshift = int(d->out_x.shift);
-    gc.ncols = int(N);
-    gc.s2 = T(d->scale) * T(d->scale);
-    if (p.fold) {
-        gc.nrows = H;
-        gc.off = 0;
-        gc.len = H;
-        gc.rot = 0;                 // the rotation of the input rows is the fold's swap
-        gc.ld = 2 * d->out_ld;      // plane y holds the output rows of parity y
-        gc.out_plane = d->out_ld;
-        gc.orot = d->out_y.shift ? 8 : 0;
-    } else {
-        gc.nrows = rows;
-        gc.off = int(d->in_y.off);
-        gc.len = int(d->in_y.len);
-        gc.rot = d->in_y.shift ? 8 : 0;
-        gc.ld = d->out_ld;
-        gc.out_plane = 0;
-        gc.orot = d->out_y.shift ? 8 : 0;
-    }
-    const int ntiles = int(N / p.tc);
-    return launch_col_spectral2(lt, gc, twc, ntiles, sibling_log_g(p.log_k), w, st, p.fold ? 2 : 1);
-}
-
-#endif   // PM_EXPERIMENTS
 
 }  // namespace pm
 
@@ -1641,24 +1544,20 @@ extern "C" {
 
 int pm_version(void) { return PM_VERSION; }
 
-// Variants that measured slower are compiled only with -DPM_EXPERIMENTS (tools/ A/B builds): the product library refuses the knob
-// values that would select them instead of silently running something else.
+// Variants that measured slower were built behind -DPM_EXPERIMENTS through round 4 and left the sources in round 5 (experiments/README.md
+// has the list, the logs and the patch that brings them back): the library refuses the knob values that selected them instead of
+// silently running something else.
 static bool experiment_only(const char* key, int v) {
-#ifdef PM_EXPERIMENTS
-    (void)key; (void)v;
-    return false;
-#else
     auto is = [&](const char* k) { return !strcmp(key, k); };
     return (is("spectral_mode") && (v & 3) != 3) || (is("gemm_3m") && !v) || (is("gemm_bm") && v == 128) || (is("gemm_bk") && v == 32) ||
            (is("colmul_mode") && (v == 1 || v == 2)) || (is("gemm_wk") && (v & 6)) || (is("spectral2") && v != 0) || (is("two_units") && v != 0) || (is("engine_p8") && v != 0) ||
            (is("mix_ablate") && v != 0) || (is("mix_pers") && v != 0) || (is("mix_fold") && v != 0);
-#endif
 }
 
 int pm_set_tuning(const char* key, int32_t value) {
     if (!key) return fail(PM_ERR_ARG, "pm_set_tuning: null key");
     if (experiment_only(key, value))
-        return fail(PM_ERR_UNSUPPORTED, "pm_set_tuning: %s = %d selects a variant this build does not contain (rebuild with -DPM_EXPERIMENTS)", key,
+        return fail(PM_ERR_UNSUPPORTED, "pm_set_tuning: %s = %d selects a variant that lost its measurement and is no longer in the library (experiments/README.md)", key,
                     int(value));
     static std::mutex mu;      // writers of the process-wide defaults are serialised; a thread that needs its own values while others
     std::lock_guard<std::mutex> lk(mu);     // run takes pm_set_tuning_local
@@ -1668,7 +1567,7 @@ int pm_set_tuning(const char* key, int32_t value) {
 int pm_set_tuning_local(const char* key, int32_t value) {
     if (!key) return fail(PM_ERR_ARG, "pm_set_tuning_local: null key");
     if (experiment_only(key, value))
-        return fail(PM_ERR_UNSUPPORTED, "pm_set_tuning_local: %s = %d selects a variant this build does not contain (rebuild with -DPM_EXPERIMENTS)",
+        return fail(PM_ERR_UNSUPPORTED, "pm_set_tuning_local: %s = %d selects a variant that lost its measurement and is no longer in the library (experiments/README.md)",
                     key, int(value));
     if (!g_tune_local_on) {
         g_tune_local = tuning_global();     // the thread's copy starts from the defaults of this moment
@@ -1799,12 +1698,6 @@ size_t pm_fft2_spectral_workspace(const pm_fft2_desc* d, int32_t count) {
     if (check_fft2(d) || count <= 0) return 0;
     const Fft2Plan p = plan_fft2(d);
     size_t need = spectral_fast(d, p) ? p.ws_field * size_t(spectral_group(count)) : p.ws_bytes;
-#ifdef PM_EXPERIMENTS
-    if (spectral2_shape(d, p)) {    // whether the call takes those kernels also depends on the alignment of `out`: the query covers both
-        const size_t g2 = size_t(tuning().spectral2 < count ? tuning().spectral2 : count);
-        if (p.ws_field * g2 > need) need = p.ws_field * g2;
-    }
-#endif
     return need;
 }
 
@@ -1822,26 +1715,6 @@ int pm_fft2_spectral(const pm_fft2_desc* d, int32_t count, const double* k, cons
     if (!workspace || workspace_bytes < need)
         return fail(PM_ERR_WORKSPACE, "pm_fft2_spectral: workspace of %zu bytes required, %zu given", need, workspace_bytes);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#ifdef PM_EXPERIMENTS     // groups of 2 .. 4 on the four-waves-per-SIMD kernels: lost to the loop at every size (profiles/r04/exp_spectral2.log)
-    if (spectral2_shape(d, p) && reinterpret_cast<uintptr_t>(out) % 8 == 0 && reinterpret_cast<uintptr_t>(in) % 8 == 0) {
-        const int g = tuning().spectral2;
-        const double two_pi = 2.0 * 3.14159265358979323846264338327950288;
-        for (int32_t b0 = 0; b0 < count; b0 += g) {
-            Spectral w{};
-            w.nb = count - b0 < g ? count - b0 : g;
-            w.fstride = int64_t(p.ws_field / sizeof(cx<float>));
-            w.mode = 0;
-            for (int i = 0; i < w.nb; ++i) {
-                w.w[i] = weight[b0 + i];
-                w.k2[i] = k[b0 + i] / two_pi;
-            }
-            rc = fft2_spectral2_group(d, p, w, in, out, workspace, st);
-            if (rc)
-                return rc == -2 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2_spectral: internal: no lean grouped kernel for %lld x %lld", (long long)d->in_y.n, (long long)d->in_x.n) : rc;
-        }
-        return 0;
-    }
-#endif
     if (!spectral_fast(d, p)) {     // the loop itself: one transform pair per wavelength
         pm_fft2_desc dd = *d;
         for (int32_t b = 0; b < count; ++b) {

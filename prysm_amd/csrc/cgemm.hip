@@ -301,7 +301,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // One operand tile (ROWS rows x 16 k, ROWS = 64 or 128) in LDS, filled by LDS-DMA (global_load_lds_dwordx4: no staging
 // registers, no ds_write -- the eight ds_write_b128 per thread and K-tile of a register-staged version cost the MFMA stream
-// 1600 of its 6144 cycles, tools/exp_mfma2.cpp).  A DMA piece lands lane-linear (wave-uniform base + 16 B x lane), so the image is:
+// 1600 of its 6144 cycles, experiments/scripts/exp_mfma2.cpp).  A DMA piece lands lane-linear (wave-uniform base + 16 B x lane), so the image is:
 //   KFAST (memory [row][k]):  [row][8 slots of 16 B], slot = kpair ^ ((row >> 1) & 7) -- the swizzle is applied to the SOURCE
 //                             address of each lane and again when reading; 16-byte fragment reads of the 16-lane LDS groups are
 //                             conflict-free.  Piece j = rows 8 j .. 8 j + 7.
@@ -630,12 +630,6 @@ static bool gemm_dma_plan(int64_t M, int64_t N, int64_t K, DmaPlan* out) {
     const int wkm = tuning().gemm_wk;     // bit 0: 64 x 64 with two K-groups (8 waves), bit 1: 64 x 32 with two, bit 2: 32 x 32 with four
     if (m128 && n128 && (M / 128) * (N / 128) >= want) p.tm = p.tn = 128;
     else if ((wkm & 1) && t64 < want && 2 * t64 >= want && (K % 32) == 0) p.wk = 2;                                  // 64 x 64, K halves
-#ifdef PM_EXPERIMENTS
-    else if ((wkm & 2) && t64 < want && 2 * t64 >= want && (K % 32) == 0) { p.tn = 32; p.wk = 2; }                   // 64 x 32, K halves
-#endif
-#ifdef PM_EXPERIMENTS     // equal to slabs + reduce at K = 2048 (36.4 vs 37.3 us), slower at K = 4096 (66 vs 62 us): tools/ builds only
-    else if ((wkm & 4) && 2 * t64 < want && 4 * t64 >= pm_num_cus() && (K % 64) == 0) { p.tm = p.tn = 32; p.wk = 4; }
-#endif
     const int t = tuning().gemm_tile;
     if (t == 64) { p.tm = p.tn = 64; p.wk = 1; }
     else if (t == 128 && m128 && n128) { p.tm = p.tn = 128; p.wk = 1; }
@@ -693,16 +687,7 @@ int cgemm_ws_bm(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha,
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB)); \
         hipLaunchKernelGGL(kern, grid, dim3(256), LDSB, st, cA, cB, M, N, K, ksplit, al, A, lda, B, ldb, out, ldo, slab);  \
     }
-#ifdef PM_EXPERIMENTS     // the four-chain complex product (knob gemm_3m = 0): tools/ builds only
-#define PM_GEMM_3M_OR_4(AK, BK_)     \
-    if (tuning().gemm_3m) {          \
-        PM_GEMM_(AK, BK_, true)      \
-    } else {                         \
-        PM_GEMM_(AK, BK_, false)     \
-    }
-#else
 #define PM_GEMM_3M_OR_4(AK, BK_) PM_GEMM_(AK, BK_, true)
-#endif
 #define PM_GEMM(AK, BK_)                     \
     {                                        \
         PM_GEMM_3M_OR_4(AK, BK_)             \
@@ -737,11 +722,6 @@ int cgemm_ws_bm(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha,
 template <typename T, int BK>
 int cgemm_ws_bk(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, const cx<T>* A, int64_t lda,
                 const cx<T>* B, int64_t ldb, cx<T>* C, int64_t ldc, void* ws, size_t ws_bytes, hipStream_t st) {
-#ifdef PM_EXPERIMENTS     // 128-row tiles of the register-staged kernel (knob gemm_bm): measured no better, tools/ builds only
-    if constexpr (sizeof(T) == 4) {   // fp64: 16x16 MFMA tiles, four per wave along M would spill
-        if (gemm_bm(M) == 128) return cgemm_ws_bm<T, BK, 128>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
-    }
-#endif
     return cgemm_ws_bm<T, BK, 64>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
 }
 
@@ -796,12 +776,6 @@ static int cgemm_dma_run(int opA, int opB, int64_t M, int64_t N, int64_t K, doub
              : cgemm_dma_launch<TI, TJ, WM, WN, WK, 0>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st, none)
     if (p.tm == 128) PM_RUN(2, 2, 2, 2, 1);
     else if (p.wk == 2 && p.tn == 64) PM_RUN(1, 1, 2, 2, 2);
-#ifdef PM_EXPERIMENTS     // 64 x 32 tiles with two K-groups: 119 us against 108 + 6 for config 4's first product, tools/ builds only
-    else if (p.wk == 2) PM_RUN(1, 1, 2, 1, 2);
-#endif
-#ifdef PM_EXPERIMENTS
-    else if (p.wk == 4) PM_RUN(1, 1, 1, 1, 4);
-#endif
     else PM_RUN(1, 1, 2, 2, 1);
 #undef PM_RUN
     if (rc || p.S == 1) return rc;
@@ -826,11 +800,6 @@ int cgemm_ws(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha, co
     }
     // K-tile depth: 16 (fp32) / 8 (fp64) = 33 KiB of LDS, 4 workgroups per CU; tuning gemm_bk = 32 / 16 doubles it
     // (66.5 KiB, 2 per CU, half the barriers per flop)
-#ifdef PM_EXPERIMENTS
-    const int bk = tuning().gemm_bk;
-    if (sizeof(T) == 4 && bk == 32) return cgemm_ws_bk<T, 32>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
-    if (sizeof(T) == 8 && bk == 32) return cgemm_ws_bk<T, 16>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
-#endif
     if (sizeof(T) == 4) return cgemm_ws_bk<T, 16>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
     return cgemm_ws_bk<T, 8>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
 }

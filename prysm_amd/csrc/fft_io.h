@@ -309,7 +309,7 @@ template <typename T> inline void nt_store_s(T* p, T v) { *p = v; }
 
 // amp * exp(2 pi i * turns): the phase is reduced to [-0.5, 0.5] turns in fp64 (OPD * k reaches thousands of radians),
 // then the hardware sine / cosine (argument in revolutions; measured max abs error 1.3e-7 on that interval,
-// tools/exp_hwsin.cpp) for float, sincospi for double.
+// experiments/scripts/exp_hwsin.cpp) for float, sincospi for double.
 template <typename T>
 PM_HD cx<T> synth_value(T opd, T a, double k2) {
     const double turns = double(opd) * k2;

@@ -81,15 +81,13 @@ __device__ __forceinline__ int engine_stagger(int log_g_packed) {
 
 // Minimum waves per SIMD the register allocation must leave room for (the second __launch_bounds__ argument of hipcc).  The paired
 // rows of a folded transform (VAR 4, E = 2) are the kernels that sit at a register boundary: complex64 fits four 256-thread
-// workgroups per CU at 128 VGPRs; complex128 (128 registers of data alone) fits three at 168 for rows up to 4096 points only with
-// spills (VAR 6, knob row_cap) and otherwise runs two per CU.
+// workgroups per CU at 128 VGPRs.  complex128 (128 registers of data alone) runs two per CU at 182 - 215 registers; a build under a
+// 168-register cap (three per CU) spills 24 - 186 registers and was measured in round 5: 4096^2 focus 201 -> 289 us,
+// angular spectrum 305 -> 404 us, 2048^2 unchanged (profiles/r05/exp_knob_row_cap.log) -- not built any more.
 template <typename C, bool COL, int VAR, typename S>
 constexpr int fft_kernel_min_waves() {
     constexpr bool chirp = std::is_same<S, RowStoreChirp<typename C::T>>::value;     // (the Bluestein chain's last pass: 141 - 149 registers, left alone)
-    if (!COL && (VAR == 4 || VAR == 6) && C::E == 2 && !chirp) {
-        if (sizeof(typename C::T) == 4) return 4;
-        return (VAR == 6 && C::LOGN <= 12) ? 3 : 1;      // VAR 6: VAR 4 under the cap (knob row_cap)
-    }
+    if (!COL && VAR == 4 && C::E == 2 && !chirp) return sizeof(typename C::T) == 4 ? 4 : 1;
     // complex64 column tiles of 512 threads: two workgroups per CU need 128 registers (the allocation sits at 128 - 130)
     if (COL && sizeof(typename C::T) == 4 && C::NT == 512 && C::LDS_BYTES <= 80 * 1024) return 4;
     return 1;
@@ -117,54 +115,6 @@ __global__ void __launch_bounds__(C::NT, (fft_kernel_min_waves<C, COL, VAR, S>()
     store<C>(spb, unit, pos, v);
 }
 
-#ifdef PM_EXPERIMENTS
-// TWO units per workgroup (half the grid), the second unit's loads issued before the first unit's transform and
-// stores.  Both passes of a 2048^2 transform are single-round launches (8 row workgroups per CU, one column tile per CU), so a plain
-// workgroup has nothing to overlap its own phases with; this form gives it a second unit.  Knob two_units (bit 0 rows, bit 1 columns);
-// measured in profiles/r04/exp_cfg2_two_units.log.
-template <typename C, bool COL, int VAR, typename L, typename S>
-__global__ void __launch_bounds__(C::NT) fft_kernel_2u(const L lp, const S sp, const cx<typename C::T>* __restrict__ tw, const int log_g) {
-    extern __shared__ __attribute__((aligned(16))) char pm_smem[];
-    const ThreadPos pos = thread_pos<C>(threadIdx.x);
-    int u0 = group_remap(2 * blockIdx.x, 2 * gridDim.x, log_g), u1 = group_remap(2 * blockIdx.x + 1, 2 * gridDim.x, log_g);
-    if (COL) {
-        u0 = u0 * C::BO + pos.bo;
-        u1 = u1 * C::BO + pos.bo;
-    }
-    cx<typename C::T> v[C::E][C::P], vn[C::E][C::P];
-    const L lpb = at_batch(lp, blockIdx.y);
-    const S spb = at_batch(sp, blockIdx.y);
-    load<C>(lpb, u0, pos, v);
-    load<C>(lpb, u1, pos, vn);      // in flight under the first unit's transform and stores
-    if constexpr (VAR != 5 && C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
-    else fft_run<C>(v, pos, pm_smem, tw);
-    store<C>(spb, u0, pos, v);
-    __syncthreads();
-    ThreadPos p2 = pos;
-    asm volatile("" : "+v"(p2.t), "+v"(p2.cl), "+v"(p2.bo));
-    if constexpr (VAR != 5 && C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(vn, p2, pm_smem, tw);
-    else fft_run<C>(vn, p2, pm_smem, tw);
-    store<C>(spb, u1, pos, vn);
-}
-int pm_two_units();     // capi.hip: the knob
-// Round 4's second experiment: the engine with EIGHT points per thread (radix-8 stages, FftCfg LOGPMAX = 3) for the two passes of the
-// folded 4096^2 complex64 transform -- half the registers per thread, twice the waves, three exchanges instead of two.
-// MINW: minimum waves per SIMD the register allocation leaves room for.
-template <typename C, bool COL, typename L, typename S, int MINW>
-__global__ void __launch_bounds__(C::NT, MINW) fft_kernel_p8(const L lp, const S sp, const cx<typename C::T>* __restrict__ tw, const int log_g) {
-    extern __shared__ __attribute__((aligned(16))) char pm_smem[];
-    const ThreadPos pos = thread_pos<C>(threadIdx.x);
-    int unit = group_remap(blockIdx.x, gridDim.x, log_g);
-    if (COL) unit = unit * C::BO + pos.bo;
-    cx<typename C::T> v[C::E][C::P];
-    const L lpb = at_batch(lp, blockIdx.y);
-    const S spb = at_batch(sp, blockIdx.y);
-    load<C>(lpb, unit, pos, v);
-    fft_run_pipe2<C>(v, pos, pm_smem, tw);
-    store<C>(spb, unit, pos, v);
-}
-int pm_engine_p8();     // capi.hip: the knob (bit 0 rows, bit 1 columns)
-#endif
 
 // Fused spectral-multiply column pass: forward transform, multiply by H, inverse transform -- all on the
 // registers of the workgroup (the engine returns natural order, so the inverse starts where the forward ended);
@@ -289,127 +239,6 @@ __device__ __forceinline__ void pf_store(const ColStoreTiledCrop<typename C::T>&
     }
 }
 
-#ifdef PM_EXPERIMENTS
-// The same pass as a PERSISTENT workgroup that prefetches: one 512-thread workgroup per CU walks its tiles and issues the loads of
-// tile t + 1 into a second register set BEFORE the two transforms of tile t, so HBM reads are in flight under the butterflies and
-// the stores of tile t drain under the transforms of tile t + 1.  The one-tile-per-workgroup form above runs ONE workgroup per CU at
-// 2048-point complex128 tiles (184 VGPRs) and did load -> FFT -> x H -> IFFT -> store strictly in sequence: 156.6 us for 536.9 MB
-// = 0.43 of the HBM roofline with PMC traffic 1.01x (config 3's middle pass).  Registers: 2 x 64 for the two
-// tiles + the transform's own ~60, inside the 256 a two-waves-per-SIMD kernel owns.  Virtual block vb = blockIdx.x + k gridDim.x
-// keeps vb % 8 = the XCD of the physical block (gridDim.x is a multiple of 8), so group_remap's sibling tiles still meet in one L2.
-// Host-checked: every tile exists and is read whole and unrotated (the folded chain's planes).  Addresses are ONE uniform 64-bit
-// base per register slot (scalar registers) + ONE 32-bit per-thread byte offset: with the generic loaders the compiler hoisted
-// the 16 + 16 + 16 per-slot 64-bit vector addresses of load / multiplier / store out of the tile loop (96 VGPRs, hundreds of
-// spills beside the second register set).  The multiplier kind is a template argument.
-// v *= hy[k] hx[c], then conjugate (the separable case of mid_multiply_conj_kind); hy from the workgroup's LDS copy
-template <typename C>
-__device__ __forceinline__ void pf_multiply_conj(const cx<typename C::T>* hyl, const cx<typename C::T> (&hx)[C::E], int conj, ThreadPos pos,
-                                                 cx<typename C::T> (&v)[C::E][C::P]) {
-    using T = typename C::T;
-#pragma unroll
-    for (int m = 0; m < C::P; ++m) {
-        const cx<T> hy = hyl[pos.t + m * C::TPS];
-#pragma unroll
-        for (int e = 0; e < C::E; ++e) {
-            const cx<T> h = cmul(hy, hx[e]);
-            const cx<T> x = conj ? cmulc(v[e][m], h) : cmul(v[e][m], h);
-            v[e][m] = {x.x, -x.y};
-        }
-    }
-}
-
-// LDS: [exchange fabric C::LDS_BYTES | twiddle table W_N^k, N entries | hy of this plane, N entries].  Every load the two transforms
-// and the multiply need comes from LDS (lgkmcnt), because the vector memory counter is IN ORDER on gfx9: a twiddle fetched from
-// global memory after the prefetch was issued could only be waited for by waiting for the whole prefetch.  The only vector-memory
-// operations inside the tile loop are the prefetch (next tile + its hx) and the stores.
-template <typename C>
-struct PfLds {
-    static constexpr size_t TW_OFF = (C::LDS_BYTES + 255) & ~size_t(255);
-    static constexpr size_t HY_OFF = TW_OFF + size_t(C::N) * sizeof(cx<typename C::T>);
-    static constexpr size_t BYTES = HY_OFF + size_t(C::N) * sizeof(cx<typename C::T>);
-};
-
-template <typename C, typename S = ColStoreTiled<typename C::T>>
-__global__ void __launch_bounds__(C::NT, 1)
-    fft_col_mul_pf_kernel(const ColLoadTiled<typename C::T> lp0, const MidMul<typename C::T> mp0, const S sp0,
-                          const cx<typename C::T>* __restrict__ tw, const int log_g, const int nvb) {
-    using T = typename C::T;
-    static_assert(C::BO == 1, "one tile per workgroup");
-    extern __shared__ __attribute__((aligned(16))) char pm_smem[];
-    constexpr int TC = C::CI * C::E;
-    const ThreadPos pos = thread_pos<C>(threadIdx.x);
-    const auto lp = at_batch(lp0, blockIdx.y);
-    const auto mp = at_batch(mp0, blockIdx.y);
-    const auto sp = at_batch(sp0, blockIdx.y);
-    const PfAddr<C> A(pos, lp.log_k);
-    cx<T>* const twl = reinterpret_cast<cx<T>*>(pm_smem + PfLds<C>::TW_OFF);
-    cx<T>* const hyl = reinterpret_cast<cx<T>*>(pm_smem + PfLds<C>::HY_OFF);
-    {
-        const int ys = mp.ystep > 1 ? mp.ystep : 1;
-        for (int i = threadIdx.x; i < C::N; i += C::NT) {
-            twl[i] = tw[i];
-            hyl[i] = mp.mul[int64_t(i) * ys];
-        }
-    }
-    cx<T> v[C::E][C::P], vn[C::E][C::P], hx[C::E], hxn[C::E];
-    int vb = blockIdx.x;
-    int unit = group_remap(vb, nvb, log_g);
-    pf_load<C>(lp, unit, A, v);
-#pragma unroll
-    for (int e = 0; e < C::E; ++e) hx[e] = mp.mul_x[unit * TC + pos.cl * C::E + e];
-    // The first tile must have ARRIVED before the loop (an opaque use of its registers): the compiler's s_waitcnt pass places ONE
-    // static wait where a tile's registers are first read, and that point is reached from the loop's back edge too -- if the first
-    // tile could still be pending there, the wait it needs (everything but the newest loads) would also apply in every later trip,
-    // where the newest loads are the prefetch: the prefetch would be drained before each transform.
-#pragma unroll
-    for (int e = 0; e < C::E; ++e)
-#pragma unroll
-        for (int m = 0; m < C::P; ++m) asm volatile("" : "+v"(v[e][m].x), "+v"(v[e][m].y));
-#pragma unroll
-    for (int e = 0; e < C::E; ++e) asm volatile("" : "+v"(hx[e].x), "+v"(hx[e].y));
-    __syncthreads();   // the tables are in LDS
-    for (;;) {
-        const int vb2 = vb + int(gridDim.x);
-        const bool more = vb2 < nvb;       // uniform over the workgroup
-        int unit2 = 0;
-        if (more) {
-            unit2 = group_remap(vb2, nvb, log_g);
-            pf_load<C>(lp, unit2, A, vn);   // in flight until the copy below
-#pragma unroll
-            for (int e = 0; e < C::E; ++e) hxn[e] = mp.mul_x[unit2 * TC + pos.cl * C::E + e];
-        }
-        // opaque copies of the slot, per tile and per transform: twiddles and the separable multiplier depend only on the slot, so
-        // the compiler would hoist their loads out of the tile loop (and CSE them across the two transforms) and hold ~130
-        // registers of them beside the two tiles
-        ThreadPos pos1 = pos;
-        asm volatile("" : "+v"(pos1.t), "+v"(pos1.cl), "+v"(pos1.bo));
-        if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos1, pm_smem, twl);
-        else fft_run<C>(v, pos1, pm_smem, twl);
-        pf_multiply_conj<C>(hyl, hx, mp.conj, pos1, v);
-        __syncthreads();   // LDS of the forward exchange is reused by the inverse
-        ThreadPos pos2 = pos;
-        asm volatile("" : "+v"(pos2.t), "+v"(pos2.cl), "+v"(pos2.bo));
-        if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos2, pm_smem, twl);
-        else fft_run<C>(v, pos2, pm_smem, twl);
-#pragma unroll
-        for (int e = 0; e < C::E; ++e)
-#pragma unroll
-            for (int m = 0; m < C::P; ++m) v[e][m].y = -v[e][m].y;
-        pf_store<C>(sp, unit, A, v);
-        if (!more) break;
-#pragma unroll
-        for (int e = 0; e < C::E; ++e) {
-            hx[e] = hxn[e];
-#pragma unroll
-            for (int m = 0; m < C::P; ++m) v[e][m] = vn[e][m];
-        }
-        unit = unit2;
-        vb = vb2;
-        __syncthreads();   // the next forward exchange reuses the LDS the inverse has just read
-    }
-}
-
-#endif   // PM_EXPERIMENTS
 
 // Mode 3: one tile per workgroup like mode 0, but built to fit TWO 512-thread workgroups per CU (128 VGPRs) without spilling: the
 // lean addressing of the persistent kernel (one uniform base + one 32-bit offset per stream instead of 16 vector addresses each),
@@ -504,7 +333,6 @@ __global__ void __launch_bounds__(C::NT, 4)
 }
 
 int pm_num_cus();   // capi.hip: compute units of the current device (cached)
-int pm_row_cap();   // capi.hip: the knob row_cap
 
 // mode (tuning colmul_mode; 512-thread tiles = 2048-point columns only): 0 one tile per workgroup, 1 the same under a 128-VGPR cap
 // (two workgroups per CU), 2 persistent workgroups that prefetch the next tile (fft_col_mul_pf_kernel)
@@ -515,23 +343,6 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& 
     const int grid = (ntiles + C::BO - 1) / C::BO;
     if (grid <= 0) return 0;
     if constexpr (C::BO == 1 && C::NT >= 512) {
-#ifdef PM_EXPERIMENTS     // the persistent prefetching form: 135.7 us against 115.4 for the lean two-per-CU form below; tools/ builds only
-        if (mode == 2 && C::NT == 512 && std::is_same<S, ColStoreTiled<T>>::value) {
-            // physical blocks: one per CU over all planes, a multiple of 8 << log_g so that siblings stay siblings
-            const int unit8 = 8 << log_g;
-            int gx = pm_num_cus() / (nbatch > 0 ? nbatch : 1);
-            gx = gx / unit8 * unit8;
-            const bool whole = lp.ay.off == 0 && lp.ay.len == C::N && lp.ay.shift == 0 && lp.ntiles == grid * C::BO && sp.ntiles == lp.ntiles;
-            if (gx >= unit8 && grid % unit8 == 0 && grid > gx && whole && mp.kind == MUL_SEPARABLE && mp.ncols >= grid * C::CI * C::E) {
-                auto kern = fft_col_mul_pf_kernel<C, S>;
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   int(PfLds<C>::BYTES));
-                if (e != hipSuccess) return int(e);
-                hipLaunchKernelGGL(kern, dim3(gx, nbatch), dim3(C::NT), PfLds<C>::BYTES, st, lp, mp, sp, tw, log_g, grid);
-                return int(hipGetLastError());
-            }
-        }
-#endif
         if (mode == 3) {
             // an unrotated window of stored rows (zero padding around it is synthesised), every tile present
             const bool whole = lp.ay.shift == 0 && lp.ay.n == C::N && lp.ntiles == grid * C::BO && sp.ntiles == lp.ntiles;
@@ -546,16 +357,6 @@ int launch_col_mul_one(const ColLoadTiled<T>& lp, const MidMul<T>& mp, const S& 
                 return int(hipGetLastError());
             }
         }
-#ifdef PM_EXPERIMENTS     // spills 45 registers and loses (198 vs 159 us): tools/ builds only
-        if (mode == 1 && C::NT == 512 && std::is_same<S, ColStoreTiled<T>>::value) {
-            auto kern = fft_col_mul_kernel<C, S, 4>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               int(C::LDS_BYTES));
-            if (e != hipSuccess) return int(e);
-            hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), C::LDS_BYTES, st, lp, mp, sp, tw, log_g);
-            return int(hipGetLastError());
-        }
-#endif
     }
     auto kern = fft_col_mul_kernel<C, S>;
     if (C::LDS_BYTES > 48 * 1024) {
@@ -596,29 +397,6 @@ int launch_one(const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, 
     const int per_wg = C::BO * (COL ? 1 : C::E);     // row mode: a thread owns E consecutive rows
     const int grid = (units + per_wg - 1) / per_wg;
     if (grid <= 0 || nbatch <= 0) return 0;
-#ifdef PM_EXPERIMENTS
-    if constexpr (COL && LOGN == 11 && sizeof(T) == 4 && VAR == 0) {
-        if (pm_engine_p8() & 2) {       // 8 columns x 2048 rows by 1024 threads of 8 points
-            using C8 = FftCfg<T, 11, 4, 2, 1, 1, 3>;
-            auto k8 = (pm_engine_p8() & 4) ? fft_kernel_p8<C8, true, L, S, 8> : fft_kernel_p8<C8, true, L, S, 4>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, int(C8::LDS_BYTES));
-            if (e != hipSuccess) return int(e);
-            hipLaunchKernelGGL(k8, dim3(units, nbatch), dim3(C8::NT), C8::LDS_BYTES, st, lp, sp, tw, log_g);
-            return int(hipGetLastError());
-        }
-    }
-    if constexpr (LOGN == 11 && sizeof(T) == 4) {
-        if ((pm_two_units() & (COL ? 2 : 1)) && grid % 2 == 0) {
-            auto k2 = fft_kernel_2u<C, COL, VAR, L, S>;
-            if (LDSB > 48 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
-                if (e != hipSuccess) return int(e);
-            }
-            hipLaunchKernelGGL(k2, dim3(grid / 2, nbatch), dim3(C::NT), LDSB, st, lp, sp, tw, log_g);
-            return int(hipGetLastError());
-        }
-    }
-#endif
     hipLaunchKernelGGL(kern, dim3(grid, nbatch), dim3(C::NT), LDSB, st, lp, sp, tw, engine_log_g(log_g, grid, LDSB, C::NT, COL ? 1 : 0));
     return int(hipGetLastError());
 }
@@ -629,23 +407,7 @@ template <typename T, int LOGN>
 int launch_fold_one(const RowLoadNat<T>& lp, const RowStoreFold<T>& sp, const cx<T>* tw, int npairs, int log_g, hipStream_t st,
                     int nbatch) {
     using C = typename RowCfgSel<T, LOGN, 4>::type;
-#ifdef PM_EXPERIMENTS
-    if constexpr (LOGN == 12 && sizeof(T) == 4) {
-        if (pm_engine_p8() & 1) {       // a row pair by 512 threads of 8 points
-            using C8 = FftCfg<T, 12, 1, 2, 1, 1, 3>;
-            auto k8 = (pm_engine_p8() & 4) ? fft_kernel_p8<C8, false, RowLoadNat<T>, RowStoreFold<T>, 8> : fft_kernel_p8<C8, false, RowLoadNat<T>, RowStoreFold<T>, 4>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, int(C8::LDS_BYTES));
-            if (e != hipSuccess) return int(e);
-            if (npairs <= 0 || nbatch <= 0) return 0;
-            hipLaunchKernelGGL(k8, dim3(npairs, nbatch), dim3(C8::NT), C8::LDS_BYTES, st, lp, sp, tw, log_g);
-            return int(hipGetLastError());
-        }
-    }
-#endif
     auto kern = fft_kernel<C, false, 4, RowLoadNat<T>, RowStoreFold<T>>;
-    if constexpr (sizeof(T) == 8 && LOGN <= 12) {
-        if (pm_row_cap()) kern = fft_kernel<C, false, 6, RowLoadNat<T>, RowStoreFold<T>>;
-    }
     constexpr size_t LDSB = C::LDS_BYTES;
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
@@ -672,9 +434,6 @@ template <typename T, int LOGN>
 int launch_unfold_one(const RowLoadFold<T>& lp, const RowStoreNat<T>& sp, const cx<T>* tw, int npairs, hipStream_t st, int nbatch) {
     using C = typename RowCfgSel<T, LOGN, 4>::type;
     auto kern = fft_kernel<C, false, 4, RowLoadFold<T>, RowStoreNat<T>>;
-    if constexpr (sizeof(T) == 8 && LOGN <= 12) {
-        if (pm_row_cap()) kern = fft_kernel<C, false, 6, RowLoadFold<T>, RowStoreNat<T>>;
-    }
     constexpr size_t LDSB = C::LDS_BYTES;
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));

@@ -205,15 +205,8 @@ struct MixShape {
     // start together and stay in step -- overlap
     int stagger, first_round;
     int pers_tiles;     // > 0: the persistent column kernel (fft_mixed_kernels.h mix_cols_pers_kernel) over this many tiles
-#ifdef PM_EXPERIMENTS
-    int ablate;     // timing experiments only (results are wrong): 1 no global loads, 2 no twiddle loads, 4 no global stores, 8 no butterflies
-#endif
 };
-#ifdef PM_EXPERIMENTS
-#define PM_MIX_ABLATE(sh, bit) (((sh).ablate & (bit)) != 0)
-#else
 #define PM_MIX_ABLATE(sh, bit) false
-#endif
 inline void mix_shape_pads(const MixPlan& p, MixShape& sh, int c0, int c1);
 
 // floor(a / d) for a d < 2^16 as (a * magic) >> 32, magic = floor(2^32 / d) + 1 (exact while a d < 2^32); d == 1: magic 0 = identity

@@ -29,13 +29,7 @@ struct MixFactors {
 };
 // es: bytes per element (8: complex64, 16: complex128) -- the weight of the class of 20 differs (fft_mixed.h mix_factor)
 static const MixFactors& mix_factors(int maxr = kMixMaxRadix, size_t es = 16) {
-#ifdef PM_EXPERIMENTS     // the class weights of the planner from the environment (percent), read once: tools/exp_mix_weights.py
-    static const double w20d = getenv("PM_MIX_W20D") ? atof(getenv("PM_MIX_W20D")) / 100 : 1.4, w20s = getenv("PM_MIX_W20S") ? atof(getenv("PM_MIX_W20S")) / 100 : 1.3,
-                        w16 = getenv("PM_MIX_W16") ? atof(getenv("PM_MIX_W16")) / 100 : 1.15;
-    static const MixFactors f20d(20, w20d, w16), f20s(20, w20s, w16), f16(16, 1.4, w16), f10(10, 1.4);
-#else
     static const MixFactors f20d(20, 1.4), f20s(20, 1.3), f16(16, 1.4), f10(10, 1.4);
-#endif
     return maxr <= 10 ? f10 : (maxr <= 16 ? f16 : (es == 8 ? f20s : f20d));
 }
 

@@ -84,11 +84,7 @@ __global__ __launch_bounds__(512) void mix_rows_kernel(const MixPlan* __restrict
     extern __shared__ __align__(16) char mix_smem[];
     cx<T>* lds = reinterpret_cast<cx<T>*>(mix_smem);
     // the rows of the workgroup: seqs consecutive ones, or (FOLD, experiment builds) the pair (g, g + H)
-#ifdef PM_EXPERIMENTS
-    const bool fold = out.fold_h > 0;
-#else
     constexpr bool fold = false;
-#endif
     const int seq0 = fold ? int(blockIdx.x) : int(blockIdx.x) * sh.seqs, tid = threadIdx.x, nt = blockDim.x;
     const int nvalid = fold ? 2 : (in.nseq - seq0 < sh.seqs ? in.nseq - seq0 : sh.seqs);
     const uint32_t rpitch = fold ? uint32_t(out.fold_h) * uint32_t(in.s_seq) : uint32_t(in.s_seq);
@@ -119,21 +115,6 @@ __global__ __launch_bounds__(512) void mix_rows_kernel(const MixPlan* __restrict
         mix_run_mid<T, true, MAXR>(p, sh, s, tid, nt, lds, tw);
         __syncthreads();
     }
-#ifdef PM_EXPERIMENTS
-    if (fold) {
-        // lanes 2 m and 2 m + 1 hold the same bin of the two rows (the rows are interleaved, lanes across them first)
-        cx<T> wf = out.fold_tw[seq0];
-        if (out.fold_swap) wf = cx<T>{-wf.x, -wf.y};
-        cx<T>* d0 = out.dst + int64_t(seq0) * out.ld;
-        cx<T>* d1 = d0 + int64_t(out.fold_h) * out.ld;
-        auto store = [&](int sl, int k, cx<T> v) {
-            const cx<T> o = {__shfl_xor(v.x, 1), __shfl_xor(v.y, 1)};
-            const cx<T> r = sl == 0 ? cx<T>{v.x + o.x, v.y + o.y} : cmul(cx<T>{o.x - v.x, o.y - v.y}, wf);
-            mix_st((sl == 0 ? d0 : d1) + k, r);
-        };
-        mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
-    } else
-#endif
     if (nvalid == sh.seqs && !out.mapped) {
         cx<T>* dst0 = out.dst + int64_t(seq0) * out.ld;
         const uint32_t ld = uint32_t(out.ld);
@@ -198,91 +179,6 @@ __global__ __launch_bounds__(NTMAX) void mix_cols_kernel(const MixPlan* __restri
 }
 
 
-#ifdef PM_EXPERIMENTS
-// The column pass as PERSISTENT workgroups (round 4; experiment build -- it lost: complex64 3000^2 77.2 -> 83.0 us, 3600^2 106 -> 115,
-// complex128 2000^2 64.6 -> 70.4, only 4000^2 128 -> 126, profiles/r04/exp_mix_pers.log -- the wait for the prefetched pieces also waits
-// for the last stage's stores, which share the counter, and 512-thread workgroups hide less): where a tile fills the LDS there is one workgroup per CU, and with one tile per
-// workgroup the CU loads (nothing to compute), computes (memory idle) and stores in turn -- 3000-point complex64 columns: 3.9 us + 6.4 us +
-// 3.9 us per tile, and every CU in the same phase at the same time.  Here a workgroup walks over tiles: the loads of the NEXT tile are
-// issued before the last stage of this one, as 16 B pieces held in registers (PRE per thread: the whole tile), and land while the last stage
-// runs; the stores of the last stage drain under the next tile's first stages.  The tile is copied into its LDS slots and the first stage
-// runs in place (mix_first_lds), so the prefetch does not depend on the factorisation.  Needs whole tiles (ncols a multiple of the tile), a
-// complex input whose view keeps every element, 16 B aligned rows, and an output view that keeps every bin.
-// 512 threads: the prefetched tile is 12 - 20 pieces = 48 - 80 registers per thread on top of the last stage's, which a 1024-thread
-// workgroup (128 registers) spills -- and a spilled prefetch register is a wait for its load.
-template <typename T, int MAXR, int PRE>
-__global__ __launch_bounds__(512) void mix_cols_pers_kernel(const MixPlan* __restrict__ pp, MixShape sh, DirectIn<T> in, ColStoreNat<T> out,
-                                                              const cx<T>* __restrict__ tw, int log_g, int groups) {
-    const MixPlan& p = *pp;
-    extern __shared__ __align__(16) char mix_smem[];
-    cx<T>* lds = reinterpret_cast<cx<T>*>(mix_smem);
-    typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
-    constexpr int EPV = 8 / int(sizeof(T));                 // complex elements per 16 B piece: 2 (complex64) or 1 (complex128)
-    const int tid = threadIdx.x, nt = blockDim.x, n = p.n;
-    const int log_upr = sh.log_seqs - (EPV == 2 ? 1 : 0);   // pieces per row of the tile (a power of two)
-    const int nu = n << log_upr;                            // pieces of a tile
-    const T ysign = in.conj ? T(-1) : T(1);
-    const uint32_t pitch = uint32_t(in.s_i);
-    auto tile_of = [&](int vb) {
-        const int xcd = vb & 7, slot = vb >> 3;
-        return ((slot >> log_g) << (log_g + 3)) + (xcd << log_g) + (slot & ((1 << log_g) - 1));
-    };
-    V pre[PRE];
-    auto prefetch = [&](int tile) {
-        const cx<T>* base = in.src + tile * sh.seqs;
-#pragma unroll
-        for (int q = 0; q < PRE; ++q) {
-            const int u = tid + q * nt;
-            if (u < nu) {
-                const int i = u >> log_upr, part = u & ((1 << log_upr) - 1);
-                const uint32_t r0 = uint32_t(i + in.ax.shift), r1 = r0 - uint32_t(n), r = r0 < r1 ? r0 : r1;
-                pre[q] = *reinterpret_cast<const V*>(base + (mix_mul24(r, pitch) + uint32_t(part * EPV)));
-            }
-        }
-    };
-    auto copy_in = [&]() {
-#pragma unroll
-        for (int q = 0; q < PRE; ++q) {
-            const int u = tid + q * nt;
-            if (u < nu) {
-                const int i = u >> log_upr, part = u & ((1 << log_upr) - 1);
-                V v = pre[q];
-                if (EPV == 2) { v[1] *= ysign; v[3] *= ysign; } else { v[1] *= ysign; }
-                *reinterpret_cast<V*>(lds + ((mix_slot_of(p, sh, i) << sh.log_seqs) + part * EPV)) = v;
-            }
-        }
-    };
-    const int nstage = p.nstage;
-    const bool lean = out.mul_kind == MUL_NONE && out.epilogue == EPI_NONE;
-    bool have = false;
-    for (int vb = blockIdx.x; vb < groups; vb += gridDim.x) {
-        const int tile = tile_of(vb);
-        if (tile >= sh.pers_tiles) continue;
-        if (!have) prefetch(tile);
-        copy_in();
-        __syncthreads();
-        mix_run_first_lds<T, true, MAXR>(p, sh, tid, nt, lds, tw);
-        __syncthreads();
-        for (int s = 1; s + 1 < nstage; ++s) {
-            mix_run_mid<T, true, MAXR>(p, sh, s, tid, nt, lds, tw);
-            __syncthreads();
-        }
-        const int nvb = vb + int(gridDim.x), ntile = nvb < groups ? tile_of(nvb) : sh.pers_tiles;
-        have = ntile < sh.pers_tiles;
-        if (have) prefetch(ntile);
-        const int c0 = tile * sh.seqs;
-        if (lean) {
-            const MixColStoreWhole<T> store{reinterpret_cast<cx<T>*>(out.dst), uint32_t(out.ld), out.ay.n, out.ay.shift, out.ax.n, out.ax.shift,
-                                            out.scale, out.conj ? -out.scale : out.scale, c0};
-            mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
-        } else {
-            auto store = [&](int sl, int k, cx<T> v) { mix_store_col<false>(out, k, c0 + sl, v); };
-            mix_run_last<T, true, MAXR>(p, sh, tid, nt, lds, store);
-        }
-        __syncthreads();
-    }
-}
-#endif
 
 // Middle pass of fft2 -> x H -> ifft2 on a composite column length (fft_mixed.h, the transposed stages): a tile of adjacent columns of the
 // natural intermediate goes through forward stages, the multiplier and the transposed stages without leaving the LDS, and comes back as
@@ -425,24 +321,6 @@ int mix_rows_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, c
 template <typename T, int MAXR>
 int mix_cols_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, const ColStoreNat<T>& out, const cx<T>* tw, int log_g, int groups, int nt,
                          size_t lds, hipStream_t st) {
-#ifdef PM_EXPERIMENTS
-    if (sh.pers_tiles > 0) {
-        // 16 B pieces per thread: 12 cover a 96 KiB tile on 512 threads, 16 a 128 KiB one (more would spill)
-        nt = 512;
-        const int pieces = int((lds + size_t(nt) * 16 - 1) / (size_t(nt) * 16));
-        const int grid = groups < 256 ? groups : 256;
-        if (pieces <= 12) {
-            const int rc = mix_set_lds(mix_cols_pers_kernel<T, MAXR, 12>, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL((mix_cols_pers_kernel<T, MAXR, 12>), dim3(grid), dim3(nt), lds, st, p, sh, in, out, tw, log_g, groups);
-        } else {
-            const int rc = mix_set_lds(mix_cols_pers_kernel<T, MAXR, 16>, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL((mix_cols_pers_kernel<T, MAXR, 16>), dim3(grid), dim3(nt), lds, st, p, sh, in, out, tw, log_g, groups);
-        }
-        return int(hipGetLastError());
-    }
-#endif
     if constexpr (mix_cols_wide<T>(MAXR)) {
         if (nt > 512) {
             const int rc = mix_set_lds(mix_cols_kernel<T, MAXR, 1024>, lds);
@@ -493,9 +371,6 @@ int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t
     MixShape sh{seqs, 0};
     while ((1 << sh.log_seqs) < seqs) ++sh.log_seqs;
     mix_pick_pads(p, sizeof(cx<T>), true, sh);
-#ifdef PM_EXPERIMENTS
-    sh.ablate = tuning().mix_ablate;
-#endif
     sh.stagger = tuning().mix_stagger;
     const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
@@ -543,9 +418,6 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     MixShape sh{tc, 0};
     while ((1 << sh.log_seqs) < tc) ++sh.log_seqs;
     mix_pick_pads(p, sizeof(cx<T>), true, sh);
-#ifdef PM_EXPERIMENTS
-    sh.ablate = tuning().mix_ablate;
-#endif
     sh.stagger = tuning().mix_stagger;
     const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;
@@ -620,9 +492,6 @@ int mix_cols_mul_impl(const DirectIn<T>& in, const MidMul<T>& m, cx<T>* dst, int
     MixShape sh{tc, 0};
     while ((1 << sh.log_seqs) < tc) ++sh.log_seqs;
     mix_pick_pads(p, sizeof(cx<T>), true, sh);
-#ifdef PM_EXPERIMENTS
-    sh.ablate = tuning().mix_ablate;
-#endif
     sh.stagger = tuning().mix_stagger;
     const MixPlan* pd = mix_plan_dev(n, sizeof(cx<T>), &err);
     if (!pd) return err;

@@ -136,11 +136,7 @@ template <typename T, int LOGN, int VAR, typename S>
 int launch_row_spectral_one(const RowLoadNat<T>& lp, const S& sp, const cx<T>* tw, int units, int log_g, const Spectral& w,
                             hipStream_t st) {
     using C = typename RowCfgSel<T, LOGN, VAR>::type;
-#ifdef PM_EXPERIMENTS     // the forms that lost (profiles/r02/exp_spectral.log) are built for tools/ only
-    auto kern = (w.mode & 1) ? fft_row_spectral_kernel<C, VAR, S, true> : fft_row_spectral_kernel<C, VAR, S, false>;
-#else
     auto kern = fft_row_spectral_kernel<C, VAR, S, true>;
-#endif
     constexpr size_t LDSB = C::LDS_BYTES;
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
@@ -158,11 +154,7 @@ template <typename T, int LOGM>
 int launch_col_spectral_one(const ColLoadTiled<T>& lp, const ColStoreNat<T>& sp, const cx<T>* tw, int ntiles, int log_g,
                             const Spectral& w, hipStream_t st, int nplanes) {
     using C = typename ColCfgSel<T, LOGM, 0>::type;
-#ifdef PM_EXPERIMENTS
-    auto kern = (w.mode & 2) ? fft_col_spectral_kernel<C, true> : fft_col_spectral_kernel<C, false>;
-#else
     auto kern = fft_col_spectral_kernel<C, true>;
-#endif
     constexpr size_t LDSB = C::LDS_BYTES;
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));

@@ -127,7 +127,7 @@ struct Tuning {
                               // other's barriers); K is split until the launch has this many workgroups.  Measured (profiles/r02/exp_gemm_shapes.log):
                               // config 4 pair 148.5 us at 512 with 64 x 64 tiles against 155.5 (128 x 128, 256) and 164.1 (64 x 64, 256)
     int gemm_wk = 1;          // ... K split over wave groups INSIDE the workgroup when that fills the chip without slabs (cgemm.hip gemm_dma_plan):
-                              // bit 0 64 x 64 tiles with two K-groups (8 waves); experiment builds: bit 1 64 x 32 with two, bit 2 32 x 32 with four;
+                              // bit 0 64 x 64 tiles with two K-groups (8 waves); removed in round 5 (experiments/README.md; the value is refused): bit 1 64 x 32 with two, bit 2 32 x 32 with four;
                               // 0: round 2's forms only.  Config 4 (profiles/r03/exp_gemm_forms.log): 160.5 us at 0, 153.0 at 1, 155.3 at 2, 155.9 at 4
     int gemm_tile = 0;        // force its tile edge (64 / 128); 0 = auto
     int gemm_bm = 64;         // rows of the GEMM workgroup tile (64 or 128)
@@ -159,7 +159,7 @@ struct Tuning {
                               // write 64 B pieces, direct and mirrored (MTF 4096^2 fp32 88.4 -> 81.4 us, fp64 176 -> 168; profiles/r02/exp_mtf_wide.log)
     int spectral = 8;         // pm_fft2_spectral: wavelengths per launch pair (fft_spectral.h; <= 8); 1: the plain loop of pm_fft2 calls
     int spectral_area_log = 24;   // ... for transforms of fewer than 2^this bins (capi.hip spectral_fast has the measurements)
-    int spectral2 = 0;        // experiment builds: groups of this many (2 .. 4) on the kernels that keep four waves per SIMD (fft_spectral2.h) where
+    int spectral2 = 0;        // removed in round 5 (experiments/README.md; the value is refused): groups of this many (2 .. 4) on the kernels that keep four waves per SIMD (fft_spectral2.h) where
                               // the shape qualifies (complex64, rows of 1024 .. 4096 samples, every output bin kept); 0: round 3's forms.
                               // Measured (profiles/r04/exp_spectral2.log, us per wavelength: loop / groups of 8 / these in groups of 2, 4):
                               // 4096^2 108.3 / 106.1 / 111.8, 109.0; 2048^2 39.6 / 21.5 / 28.0, 23.7; 1024^2 24.1 / 10.4 / 16.9, 13.7
@@ -169,21 +169,19 @@ struct Tuning {
     int spectral_mode = 3;    // ... bit 0: its row pass keeps the packed map in registers, bit 1: its column pass accumulates in registers
     int colmul_mode = 3;      // middle pass of the fused chain at 2048-point column tiles (fft_kernels.h launch_col_mul_one): 3 lean addressing,
                               // two 512-thread workgroups per CU (126 VGPRs) where the pass qualifies (whole unrotated tiles, separable
-                              // multiplier), else 0 = one tile per workgroup (184 VGPRs, one per CU); experiment builds: 1 the generic kernel under
+                              // multiplier), else 0 = one tile per workgroup (184 VGPRs, one per CU); removed in round 5 (experiments/README.md; the value is refused): 1 the generic kernel under
                               // a 128-VGPR cap (spills), 2 persistent prefetching workgroups (twiddles / hy in LDS).  Measured
                               // (profiles/r03/exp_colmul.log, us, modes 0 / 1 / 2 / 3): middle pass of config 3 159.1 / 198.1 / 135.7 / 115.4;
                               // chain 4096^2 complex128 383 / 430 / 365 / 355, complex64 186 / 176 / 175 / 165, 2048^2 complex128 90 / 94 / 86 / 81
-    int engine_p8 = 0;        // experiment builds: the radix-8 engine (8 points per thread) for the folded 4096^2 complex64 transform: bit 0 its row pass,
+    int engine_p8 = 0;        // removed in round 5 (experiments/README.md; the value is refused): the radix-8 engine (8 points per thread) for the folded 4096^2 complex64 transform: bit 0 its row pass,
                               // bit 1 its column pass, bit 2 a 64-register cap (eight waves per SIMD) instead of 128
     int fft_stagger = -1, fft_stagger_col = -1, fft_stagger_mid = 0, fft_stagger_r2c = 0, fft_stagger_herm = -1;    // start-up stagger of the engine's plain row / column kernels (fft_kernels.h engine_log_g), units of 512 cycles x 0 .. 7; 0 = off, -1 = auto
-    int mix_fold = 0;         // experiment builds: a radix-2 step of a composite column transform folded into the mixed-radix row pass where the whole column's tile would
+    int mix_fold = 0;         // removed in round 5 (experiments/README.md; the value is refused): a radix-2 step of a composite column transform folded into the mixed-radix row pass where the whole column's tile would
                               // take a CU's LDS (capi.hip plan_fft2 mix_fold)
-    int mix_pers = 0;         // experiment builds: its column pass as persistent workgroups with the next tile prefetched where a CU holds one tile (mix_cols_pers_kernel)
+    int mix_pers = 0;         // removed in round 5 (experiments/README.md; the value is refused): its column pass as persistent workgroups with the next tile prefetched where a CU holds one tile (mix_cols_pers_kernel)
     int mix_stagger = 4;      // ... start-up stagger of the column kernel's workgroups in units of 512 cycles x 0 .. 7 where a CU holds one tile (fft_mixed.h MixShape::stagger); 0 = off
-    int mix_ablate = 0;       // experiment builds: timing-only ablations of the mixed-radix kernels (fft_mixed.h MixShape::ablate; results are wrong)
-    int two_units = 0;        // experiment builds: two units per workgroup in the passes of a 2048-point complex64 transform (bit 0 rows, bit 1 columns)
-    int row_cap = 0;          // complex128 paired rows of a folded transform (up to 4096 points): 1 = the kernel built under a 168-register cap, three
-                              // 256-thread workgroups per CU instead of two (fft_kernels.h fft_kernel_min_waves; it spills ~20 - 60 registers)
+    int mix_ablate = 0;       // removed in round 5 (experiments/README.md; the value is refused): timing-only ablations of the mixed-radix kernels (fft_mixed.h MixShape::ablate; results are wrong)
+    int two_units = 0;        // removed in round 5 (experiments/README.md; the value is refused): two units per workgroup in the passes of a 2048-point complex64 transform (bit 0 rows, bit 1 columns)
     int stagger_group = 0;    // column kernels: the start-up stagger hashed per sibling group instead of per workgroup (fft_kernels.h engine_log_g)
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)

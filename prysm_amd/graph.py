@@ -83,7 +83,7 @@ class StreamRing:
 
     One propagation is two dependent launches; at 2048^2 and below each launch is a single round of workgroups, so its tail (the last
     workgroups storing) and the next launch's head (the first loads) leave most of the chip idle: 30.6 us per 2048^2 complex64
-    `focus` back to back on one stream, 26.3 us when consecutive calls alternate between two streams (tools/exp_two_streams.py,
+    `focus` back to back on one stream, 26.3 us when consecutive calls alternate between two streams (experiments/scripts/exp_two_streams.py,
     profiles/r04/exp_two_streams.log).  Only while BOTH fields' arrays fit the 256 MiB Infinity Cache together: at 4096^2 two
     streams evict each other's intermediates (95 -> 133 us) -- `worth_it(shape, dtype)` says which side of that a shape is on.
 

@@ -599,7 +599,7 @@ def test_spectral_call_equals_the_wavelength_loop(pa, m, n, Q, count):
         for group in (1, 2, 3, 8):
             for mode in (0, 1, 2, 3):
                 assert lib.pm_set_tuning(b'spectral', group) == 0
-                if lib.pm_set_tuning(b'spectral_mode', mode) != 0:     # forms 0 - 2 lost and are built with -DPM_EXPERIMENTS only
+                if lib.pm_set_tuning(b'spectral_mode', mode) != 0:     # forms 0 - 2 lost their measurements and left the library (experiments/README.md)
                     assert mode != 3
                     continue
                 got = torch.full((M, N), 0.0, device='cuda')

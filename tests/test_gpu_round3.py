@@ -46,7 +46,7 @@ def crandn(rng, shape, dtype=np.complex128):
 
 # ----------------------------------------------------------------------------- fused chain: the three middle-pass forms
 
-@pytest.mark.parametrize('mode', [0, 1, 2, 3])
+@pytest.mark.parametrize('mode', [0, 3])      # (1 and 2 lost their measurements and left the library in round 5: experiments/README.md)
 @pytest.mark.parametrize('n,dtype,tol', [(4096, np.complex128, TOL64), (4096, np.complex64, TOL32), (2048, np.complex128, TOL64),
                                          (2048, np.complex64, TOL32)])
 def test_angular_spectrum_middle_pass_forms(pa, mode, n, dtype, tol):
@@ -56,8 +56,7 @@ def test_angular_spectrum_middle_pass_forms(pa, mode, n, dtype, tol):
     lib = _lib.load()
     rng = np.random.default_rng(n + mode)
     x = crandn(rng, (n, n), dtype)
-    if lib.pm_set_tuning(b'colmul_mode', mode) != 0:
-        pytest.skip('form built with -DPM_EXPERIMENTS only')
+    assert lib.pm_set_tuning(b'colmul_mode', mode) == 0
     prec = pa.config.precision
     pa.config.precision = 32 if dtype == np.complex64 else 64
     try:
@@ -70,7 +69,7 @@ def test_angular_spectrum_middle_pass_forms(pa, mode, n, dtype, tol):
     assert rel_max(got, ref) < tol
 
 
-@pytest.mark.parametrize('mode', [0, 1, 2, 3])
+@pytest.mark.parametrize('mode', [0, 3])
 def test_angular_spectrum_tf_and_adjoint_middle_pass_forms(pa, mode):
     """tf= (a full multiplier: the persistent form declines it and the call must still be right) and the adjoint (conj H) at 4096^2"""
     from prysm_amd import _lib
@@ -78,8 +77,7 @@ def test_angular_spectrum_tf_and_adjoint_middle_pass_forms(pa, mode):
     rng = np.random.default_rng(77 + mode)
     x = crandn(rng, (4096, 4096))
     tf = O.angular_spectrum_transfer_function((4096, 4096), O.HeNe, 0.01, 10.0)
-    if lib.pm_set_tuning(b'colmul_mode', mode) != 0:
-        pytest.skip('form built with -DPM_EXPERIMENTS only')
+    assert lib.pm_set_tuning(b'colmul_mode', mode) == 0
     try:
         got_tf = tonp(pa.propagation.angular_spectrum(x, O.HeNe, 0.01, 10.0, Q=1, tf=tf))
         got_adj = tonp(pa.propagation.angular_spectrum_adjoint(x, O.HeNe, 0.01, 10.0, Q=1))
@@ -188,7 +186,7 @@ def test_cgemm_in_workgroup_k_split_all_ops(pa, M, N, K):
         At, Bt = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
         got = tonp(_ops.cgemm(At, Bt, opA, opB, alpha=0.5))
         assert rel_max(got, 0.5 * ref) < TOL32_MDFT, (opA, opB)
-        for form in (0, 2, 4, 7):     # round 2's slabs; the 64 x 32 / 32 x 32 forms and all of them together (experiment builds)
+        for form in (0, 2):     # round 2's slabs (0); 2 = a form that left the library in round 5 and must be refused, not run
             if lib.pm_set_tuning(b'gemm_wk', form) != 0:
                 continue
             try:

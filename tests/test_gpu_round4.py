@@ -55,48 +55,17 @@ def _poly_numpy(amp, opd, ks, wts, Q):
     return acc
 
 
-@pytest.mark.parametrize('shape,Q', [((1024, 1024), 1), ((512, 1024), 2), ((4096, 1024), 1), ((1024, 2048), 1)])
-def test_spectral2_groups_vs_loop_and_numpy(pa, shape, Q):
-    """pm_fft2_spectral on the round-4 kernels (tuning spectral2 = group size, spectral2_keep) for 7 wavelengths -- ragged last groups of
-    1 (groups of 2, 3) and 3 (groups of 4) -- against the loop of per-wavelength transform pairs (same arithmetic up to the
-    association of the sum) and against numpy fp64.  (4096, 1024) takes the fold: the row pairs meet through LDS."""
-    from prysm_amd import _lib, _ops
-    from prysm_amd.propagation import focus_intensity
-    lib = _lib.load()
-    if lib.pm_set_tuning_local(b'spectral2', 4) != 0:
-        pytest.skip('kernels built with -DPM_EXPERIMENTS only (they lost to the loop: profiles/r04/exp_spectral2.log)')
-    lib.pm_reset_tuning_local()
-    rng = np.random.default_rng(shape[0] + Q)
-    amp = ((rng.random(shape) > 0.25) * rng.random(shape)).astype(np.float32)
-    opd = (40 * rng.standard_normal(shape)).astype(np.float32)
-    wl = np.linspace(0.5, 0.7, 7)
-    ks = [2 * math.pi / w / 1e3 for w in wl]
-    wts = list(np.linspace(0.5, 1.5, 7))
-    packed = _ops.pack_amp_opd(torch.from_numpy(amp).cuda(), torch.from_numpy(opd).cuda())
-    M, N = math.ceil(shape[0] * Q), math.ceil(shape[1] * Q)
-    ref = _poly_numpy(amp, opd, ks, wts, Q)
-
-    def run(**knobs):
-        acc = torch.full((M, N), 0.25, device='cuda', dtype=torch.float32)      # the call ADDS to what is there
-        with _lib.tuning_local(**knobs):
-            focus_intensity(packed, Q, out=acc, synth=('packed', ks[0]), spectral=(ks, wts))
-        return acc.cpu().numpy().astype(np.float64) - 0.25
-
-    loop = run(spectral=1)
-    assert rel_max(loop, ref) < 2 * TOL32
-    for grp, keep in ((2, 0), (3, 0), (4, 0), (4, 1), (3, 1)):
-        got = run(spectral2=grp, spectral2_keep=keep)
-        assert rel_max(got, ref) < 2 * TOL32, (grp, keep)
-        assert rel_max(got, loop) < 1e-6, (grp, keep)
+# (test_spectral2_groups_vs_loop_and_numpy went with the kernels it tested: the grouped-wavelength kernels at four waves per SIMD lost to
+# the loop at every size -- profiles/r04/exp_spectral2.log -- and left the library in round 5; experiments/README.md)
 
 
 def test_spectral_call_config5_shape_vs_numpy(pa):
-    """pm_fft2_spectral at BASELINE config 5's shape (4096^2 fp32 maps, Q = 1) on the default route and -- experiment builds -- in
-    groups of 4 on the round-4 kernels (a group of 4 and a ragged 1): 5 wavelengths against numpy fp64"""
+    """pm_fft2_spectral at BASELINE config 5's shape (4096^2 fp32 maps, Q = 1) on the default route: 5 wavelengths against numpy fp64
+    and against the loop; the knob of the removed grouped kernels is refused"""
     from prysm_amd import _lib, _ops
     from prysm_amd.propagation import focus_intensity
     lib = _lib.load()
-    exp_build = lib.pm_set_tuning_local(b'spectral2', 4) == 0
+    assert lib.pm_set_tuning_local(b'spectral2', 4) == _lib.PM_ERR_UNSUPPORTED
     lib.pm_reset_tuning_local()
     n = 4096
     rng = np.random.default_rng(5)
@@ -119,9 +88,6 @@ def test_spectral_call_config5_shape_vs_numpy(pa):
     loop = run(spectral=1)
     assert rel_max(loop, ref) < 2 * TOL32
     assert rel_max(run(), loop) < 1e-6
-    if exp_build:
-        got = run(spectral2=4)
-        assert rel_max(got, loop) < 1e-6 and rel_max(got, ref) < 2 * TOL32
 
 
 # ----------------------------------------------------------------------------- per-thread tuning
@@ -394,27 +360,17 @@ def test_lengths_with_the_primes_17_and_19(pa, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('direction', [-1, +1])
-def test_mixed_radix_fold_experiment(pa, direction):
-    """The radix-2 step of a composite column transform folded into the mixed-radix row pass (knob mix_fold; experiment builds only -- it
-    measured slower and is not shipped, profiles/r04/exp_mix_fold.log): same result as numpy for the focus view and the |.|^2 epilogue."""
-    from prysm_amd import _lib, _ops
+def test_knobs_of_removed_variants_are_refused(pa):
+    """the variants that lost their measurements left the library in round 5 (experiments/README.md): their knob values answer
+    PM_ERR_UNSUPPORTED -- nothing else runs in their place -- and the shipped values are still accepted"""
+    from prysm_amd import _lib
     lib = _lib.load()
-    if lib.pm_set_tuning_local(b'mix_fold', 1) != 0:
-        lib.pm_reset_tuning_local()
-        pytest.skip('product build: the folded mixed-radix row pass is compiled into experiment builds only')
     try:
-        n = 1500
-        rng = np.random.default_rng(5)
-        x = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))).astype(np.complex128)
-        xt = torch.from_numpy(x).cuda()
-        h = n // 2
-        got = _ops.fft2(xt, direction=direction, scale=1.0 / n, in_shift=(h, h), out_shift=(h, h)).cpu().numpy()
-        f = np.fft.fft2 if direction < 0 else (lambda a: np.fft.ifft2(a) * a.size)
-        ref = np.fft.fftshift(f(np.fft.ifftshift(x))) / n
-        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
-        i2 = _ops.fft2(xt, direction=direction, scale=1.0 / n, in_shift=(h, h), out_shift=(h, h), epilogue=_lib.PM_EPI_ABS2).cpu().numpy()
-        assert np.abs(i2 - np.abs(ref) ** 2).max() <= 1e-12 * (np.abs(ref) ** 2).max()
+        for key, v in ((b'mix_fold', 1), (b'mix_pers', 1), (b'two_units', 1), (b'engine_p8', 1), (b'spectral2', 2), (b'colmul_mode', 1),
+                       (b'colmul_mode', 2), (b'gemm_wk', 2), (b'gemm_3m', 0), (b'mix_ablate', 1), (b'spectral_mode', 0)):
+            assert lib.pm_set_tuning_local(key, v) == _lib.PM_ERR_UNSUPPORTED, key
+        for key, v in ((b'colmul_mode', 3), (b'colmul_mode', 0), (b'gemm_wk', 1), (b'spectral_mode', 3), (b'stagger_group', 1)):
+            assert lib.pm_set_tuning_local(key, v) == 0, key
     finally:
         lib.pm_reset_tuning_local()
 
@@ -434,6 +390,7 @@ def test_start_up_stagger_changes_timing_only(pa):
             h = (shape[0] // 2, shape[1] // 2)
             outs = []
             for r, c, m in ((0, 0, 0), (3, 5, 9), (108, 104, 1)):
+                assert lib.pm_set_tuning_local(b'stagger_group', 1 if m == 9 else 0) == 0
                 assert lib.pm_set_tuning_local(b'fft_stagger', r) == 0
                 assert lib.pm_set_tuning_local(b'fft_stagger_col', c) == 0
                 assert lib.pm_set_tuning_local(b'mix_stagger', m) == 0

@@ -1,6 +1,6 @@
 """Interleaved A/B of ONE tuning knob on a list of workloads (us per call, best of a few timed loops per setting per round):
 
-    python tools/exp_knob_ab.py row_cap 0,1 focus/c128/4096 as/c128/4096 focus/c128/2048 [rounds]
+    python tools/exp_knob_ab.py stagger_group 0,1 focus/c64/8192 mtf/f32/4096 as/c128/4096 [rounds]
 
 workloads: focus/<c64|c128>/<n>[/Q]  unfocus/...  as/<c64|c128>/<n>  mtf/<f32|f64>/<n>"""
 import sys
