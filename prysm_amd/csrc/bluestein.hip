@@ -179,7 +179,7 @@ int blue_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, void* scratch, h
         cs.dst = b;
         cs.ay = AxisMap{mb, mb, 0, 0};
         cs.conj = 0;
-        const int rc = launch_col_nat<T>(lg, tuning().col_var, cl, cs, tw, ntiles, 1, st);
+        const int rc = launch_col_nat<T>(lg, 0, cl, cs, tw, ntiles, 1, st);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(blue_mul_cols_kernel<T>, grid_for(int64_t(mb) * ncols), dim3(256), 0, st, b, ncols, mb, bf);
@@ -188,7 +188,7 @@ int blue_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, void* scratch, h
         cs.dst = a;
         cs.ay = AxisMap{mb, n, 0, 0};
         cs.conj = 1;
-        const int rc = launch_col_nat<T>(lg, tuning().col_var, cl, cs, tw, ntiles, 1, st);
+        const int rc = launch_col_nat<T>(lg, 0, cl, cs, tw, ntiles, 1, st);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(blue_post_cols_kernel<T>, grid_for(int64_t(n) * ncols), dim3(256), 0, st, a, n, ncols, w, out);

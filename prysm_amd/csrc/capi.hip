@@ -145,6 +145,7 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("row_log_g")) t.row_log_g = v < 0 ? 0 : (v > 3 ? 3 : v);
     else if (is("row_var")) t.row_var = v;
     else if (is("stagger_group")) t.stagger_group = v ? 1 : 0;
+    else if (is("col_log_g")) t.col_log_g = v;
     else if (is("gemm_bk")) t.gemm_bk = v;
     else if (is("gemm_bm")) t.gemm_bm = v;
     else if (is("gemm_dma")) t.gemm_dma = v ? 1 : 0;
@@ -237,7 +238,11 @@ int pm_num_cus() {
 }
 
 // sibling group of column-pass workgroups: the tiles of one layout-tile row, at most 8
-static int sibling_log_g(int log_k) { return log_k < 1 ? 1 : (log_k > 3 ? 3 : log_k); }
+// (knob col_log_g >= 0 overrides: up to 2^5 = the 32 workgroups an XCD's CUs hold at one per CU -- experiments of round 5)
+static int sibling_log_g(int log_k) {
+    if (tuning().col_log_g >= 0) return tuning().col_log_g > 5 ? 5 : tuning().col_log_g;
+    return log_k < 1 ? 1 : (log_k > 3 ? 3 : log_k);
+}
 
 static AxisMap to_map(const pm_axis& a) { return AxisMap{int(a.n), int(a.len), int(a.off), int(a.shift)}; }
 
@@ -361,7 +366,11 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
             const int f = tuning().fold;
             p.fold = f > 0 || (f < 0 && p.logm >= 12);
         }
-        p.col_var = tuning().col_var >= 0 ? tuning().col_var : ((p.fold && d->dtype == PM_C128 && p.logm == 12) ? 2 : 0);
+        {   // 128 B tiles exist for 2048-point complex128 tiles only (fft_kernels.h launch_fft): the knob can switch them off or, for an
+            // unfolded 2048-row transform, on -- nothing else
+            const bool want2 = tuning().col_var >= 0 ? tuning().col_var == 2 : (p.fold && p.logm == 12);
+            p.col_var = (want2 && d->dtype == PM_C128 && (p.fold ? p.logm - 1 : p.logm) == 11) ? 2 : 0;
+        }
         p.tc = col_tile_width_for(d->dtype, p.fold ? p.logm - 1 : p.logm, p.col_var);
         p.log_k = tuning().log_k >= 0 ? tuning().log_k : (N >= 8192 ? 3 : (N >= 4096 ? 2 : 1));   // auto: >= 256 B pieces from 4096 columns
         // folded 4096^2 complex64 (intermediate = 128 MiB, inside the Infinity Cache): 8 KiB row pieces measured 95.0 vs 97.8 us
@@ -1150,7 +1159,7 @@ static int big2d_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, v
         cs.mul_kind = MUL_NONE;
         cs.vec_ok = vec;
         cs.bstride = plane;
-        if ((rc = launch_col_nat<T>(lgm, tuning().col_var, cl, cs, twm, ntiles, 1, st, Rm))) return rc;
+        if ((rc = launch_col_nat<T>(lgm, 0, cl, cs, twm, ntiles, 1, st, Rm))) return rc;
     }
     // ---- combine the sub-lattices, un-interleave the row split, common epilogue
     const cx<T>* twM = twm;
@@ -1302,7 +1311,7 @@ static int fft1_big(int conj, int axis, int64_t batch, const pm_axis* ti, const 
         cs.weight = T(1);
         cs.mul_kind = MUL_NONE;
         cs.vec_ok = vec_f;
-        if ((rc = launch_col_nat<T>(lg, tuning().col_var, cl, cs, twp, ntiles, 1, st, 1))) return rc;
+        if ((rc = launch_col_nat<T>(lg, 0, cl, cs, twp, ntiles, 1, st, 1))) return rc;
     }
     return big_finish<T>(F, np, nb, R, 1, twN, o, st);
 }
@@ -1350,7 +1359,7 @@ static int fft1_run(int direction, int axis, int64_t batch, const pm_axis* ti, c
         const int ntiles = int((batch + tc - 1) / tc);
         const int vec = (sizeof(T) != 4 || ((in_ld % 2 == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0))) ? 1 : 0;
         ColLoadNat<T> cl{reinterpret_cast<const cx<T>*>(in), in_ld, to_map(*ti), int(batch), conj, vec};
-        return launch_col_nat<T>(lg, tuning().col_var, cl, cs, tw, ntiles, 1, st);
+        return launch_col_nat<T>(lg, 0, cl, cs, tw, ntiles, 1, st);
     }
     DirectIn<T> di{reinterpret_cast<const cx<T>*>(in), 1, in_ld, to_map(*ti), int(batch), conj};
     if (use_mix(n) && mix_fits(n, in_ld, sizeof(cx<T>), true) && mix_fits(to->n, out_ld, sizeof(cx<T>), true)) return mix_cols<T>(di, cs, st);

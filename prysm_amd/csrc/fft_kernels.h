@@ -455,19 +455,29 @@ int launch_unfold_impl(int logn, const RowLoadFold<T>& lp, const RowStoreNat<T>&
     }
 }
 
+// The row-pass tiling per length and precision (what pm_internal.h row_variant() returns; measured in rounds 1 - 2): only THAT one is
+// built.  Until round 5 every length from 2048 points carried all four tilings of both precisions for the knob row_var -- 12 dead
+// kernel families per loader / storer pair, 7 MB of the library.
+template <typename T, int LOGN>
+constexpr int built_row_var() {
+    if (sizeof(T) == 4) return LOGN >= 12 ? 4 : (LOGN == 11 ? 5 : 0);
+    return LOGN == 11 ? 1 : 0;
+}
+
 template <typename T, bool COL, typename L, typename S>
 int launch_fft(int logn, int var, const L& lp, const S& sp, const cx<T>* tw, int units, int log_g, hipStream_t st, int nbatch) {
     switch (logn) {
 #define PM_CASE(k) \
     case k:        \
         return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st, nbatch);
-// lengths with more than one tiling (see RowCfgSel / ColCfgSel)
+// lengths with more than one tiling (see RowCfgSel / ColCfgSel): rows take the built one; columns the 128 B tiles (var 2) for
+// 2048-point complex128 tiles, else the 64 B tiles
 #define PM_CASEV(k)                                                                                              \
     case k:                                                                                                      \
-        if (!COL && var == 1) return launch_one<T, COL, k, (COL ? 0 : 1), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
-        if (!COL && var == 4) return launch_one<T, COL, k, (COL ? 0 : 4), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
-        if (!COL && var == 5) return launch_one<T, COL, k, (COL ? 0 : 5), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
-        if (COL && var == 2 && k == 11) return launch_one<T, COL, k, (COL ? 2 : 0), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        if constexpr (!COL) return launch_one<T, COL, k, (COL ? 0 : built_row_var<T, k>()), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        if constexpr (COL && k == 11 && sizeof(T) == 8) {                                                        \
+            if (var == 2) return launch_one<T, COL, k, (COL ? 2 : 0), L, S>(lp, sp, tw, units, log_g, st, nbatch); \
+        }                                                                                                        \
         return launch_one<T, COL, k, 0, L, S>(lp, sp, tw, units, log_g, st, nbatch);
         PM_CASE(1) PM_CASE(2) PM_CASE(3) PM_CASE(4) PM_CASE(5) PM_CASE(6) PM_CASE(7)
         PM_CASE(8) PM_CASE(9) PM_CASE(10) PM_CASEV(11) PM_CASEV(12) PM_CASEV(13)

@@ -203,12 +203,22 @@ PM_HD void herm_store_fast(const HermStore<typename C::T>& p, int col0, ThreadPo
     }
 }
 
+// LDS of the Hermitian column kernel: [exchange fabric of the transform | partner exchange of the packed column (same region)] then, 16-byte
+// aligned behind both, one double per wave for the DC sum
+template <typename C>
+constexpr size_t herm_dc_offset() {
+    constexpr size_t part = size_t(C::BO) * C::N * sizeof(cx<typename C::T>);
+    constexpr size_t need = C::LDS_BYTES > part ? C::LDS_BYTES : part;
+    return (need + 15) & ~size_t(15);
+}
+
 template <typename C, int EPI>
 __global__ void __launch_bounds__(C::NT) fft_col_herm_kernel(const ColLoadTiled<typename C::T> lp0, const HermStore<typename C::T> sp0,
                                                             const cx<typename C::T>* __restrict__ tw, const int log_g_packed) {
     using T = typename C::T;
     const int log_g = engine_stagger(log_g_packed);
     constexpr int TC = C::CI * C::E;
+    constexpr size_t DC_OFF = herm_dc_offset<C>();
     extern __shared__ __attribute__((aligned(16))) char pm_smem[];
     const ThreadPos pos = thread_pos<C>(threadIdx.x);
     const int unit = group_remap(blockIdx.x, gridDim.x, log_g) * C::BO + pos.bo;
@@ -222,25 +232,29 @@ __global__ void __launch_bounds__(C::NT) fft_col_herm_kernel(const ColLoadTiled<
     }
     load<C>(lp, unit, pos, v);
     T s = sp.scale;
+    // F[0][0] = sum over rows of X_row[0] (real), the same value, bit for bit, in every workgroup (strided partial sums per thread,
+    // each wave reduced in registers in a fixed order, the wave sums through LDS).  Round 5: the wave sums go to a slot BEHIND the
+    // exchange fabric before the transform and are read after it -- the transform's own barriers publish them, where the
+    // reduction used to sit between the loads and the transform with two barriers of its own (2.1 of the pass's 39 us,
+    // experiments/wave_spec/ws_bench.hip).
+    constexpr int NW = (C::NT + 63) / 64;
+    double* const red = reinterpret_cast<double*>(pm_smem + DC_OFF);
     if (sp.norm_dc) {
-        // F[0][0] = sum over rows of X_row[0] (real), the same value, bit for bit, in every workgroup
-        // (strided partial sums per thread, each wave reduced in registers in a fixed order, the wave sums through LDS)
-        double* red = reinterpret_cast<double*>(pm_smem);
         double acc = 0.0;
         for (int q = threadIdx.x; q < sp.nrows_w; q += C::NT) acc += double(sp.w0[int64_t(q) * sp.w0_stride].x);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
-        constexpr int NW = (C::NT + 63) / 64;
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        double dc = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) dc += red[w];
-        __syncthreads();     // the exchange of the transform reuses this LDS
-        s = T(double(sp.scale) / dc);
+        if constexpr (C::NSTAGE < 2) __syncthreads();     // a single-stage transform has no barrier of its own
     }
     if constexpr (C::E == 2 && C::COMP == 1 && C::NSTAGE > 1) fft_run_pipe2<C>(v, pos, pm_smem, tw);
     else fft_run<C>(v, pos, pm_smem, tw);
+    if (sp.norm_dc) {
+        double dc = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dc += red[w];
+        s = T(double(sp.scale) / dc);
+    }
     const int n2 = sp.N / 2;
     const int col0 = unit * TC + pos.cl * C::E;
     // Column 0 carries X[0] + i X[N/2] of two real columns: its transform C separates as F0[u] = (C[u] + conj C[M - u]) / 2,
@@ -353,10 +367,7 @@ template <typename T, int LOGM, int EPI, int VAR = 0>
 int launch_col_herm_epi(const ColLoadTiled<T>& lp, const HermStore<T>& sp, const cx<T>* tw, int ntiles, int log_g, hipStream_t st) {
     using C = typename ColCfgSel<T, LOGM, VAR>::type;
     auto kern = fft_col_herm_kernel<C, EPI>;
-    constexpr size_t red = size_t(C::NT) * sizeof(double);                  // the DC reduction
-    constexpr size_t part = size_t(C::BO) * C::N * sizeof(cx<T>);           // the partner exchange of the packed column
-    constexpr size_t need = red > part ? red : part;
-    constexpr size_t LDSB = C::LDS_BYTES > need ? C::LDS_BYTES : need;
+    constexpr size_t LDSB = herm_dc_offset<C>() + size_t((C::NT + 63) / 64) * sizeof(double);     // fabric / partner exchange, then the wave sums
     if (LDSB > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(LDSB));
         if (e != hipSuccess) return int(e);

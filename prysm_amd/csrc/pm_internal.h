@@ -114,8 +114,8 @@ inline int col_tile_width_for(int dtype, int logm, int var) {
 struct Tuning {
     int col_var = -1;   // column-pass tiling (ColCfgSel): 0 64 B tiles, 2 128 B tiles for 2048-point columns, -1 auto (2 for the planes of a
                         // folded 4096-row complex128 transform)
-    int row_var = -1;   // row-pass tiling (RowCfgSel): 0 plain, 1 half-LDS (re / im exchanged separately), 4 two rows per thread, 5 one row
-                        // per workgroup, -1 auto (row_variant() below)
+    int row_var = -1;   // (ignored since round 5) row-pass tiling (RowCfgSel): 0 plain, 1 half-LDS (re / im exchanged separately), 4 two rows per
+                        // thread, 5 one row per workgroup: the measured best per length and precision is the one that is built (row_variant() below)
     // non-temporal input loads / output stores: 0 off, 1 on, -1 auto (by array size vs the 256 MiB
     // Infinity Cache: measured on MI355X, streaming hints pay once the arrays no longer fit beside the
     // intermediate -- input from ~128 MiB, output from ~256 MiB; they cost a few % below that)
@@ -182,6 +182,7 @@ struct Tuning {
     int mix_stagger = 4;      // ... start-up stagger of the column kernel's workgroups in units of 512 cycles x 0 .. 7 where a CU holds one tile (fft_mixed.h MixShape::stagger); 0 = off
     int mix_ablate = 0;       // removed in round 5 (experiments/README.md; the value is refused): timing-only ablations of the mixed-radix kernels (fft_mixed.h MixShape::ablate; results are wrong)
     int two_units = 0;        // removed in round 5 (experiments/README.md; the value is refused): two units per workgroup in the passes of a 2048-point complex64 transform (bit 0 rows, bit 1 columns)
+    int col_log_g = -1;       // sibling group of column-pass workgroups: 2^this adjacent tiles on one XCD back to back (-1: from the layout, capi.hip sibling_log_g)
     int stagger_group = 0;    // column kernels: the start-up stagger hashed per sibling group instead of per workgroup (fft_kernels.h engine_log_g)
     int batch_ws_mib = 128;   // batched transforms: fields per launch pair are chosen so their intermediates take
                              // at most this many MiB (measured best at 128; they should survive in the Infinity Cache between the passes)
@@ -189,8 +190,7 @@ struct Tuning {
 Tuning& tuning();
 // measured on MI355X (profiles/r01/sweep*.log): the half-LDS variant wins for complex128 rows of 2048 points (24.6 vs 30.5 us)
 inline int row_variant(int dtype, int logn) {
-    const int v = tuning().row_var;
-    if (v >= 0) return v;
+    // (the knob row_var is accepted and ignored since round 5: one tiling per length and precision is built, fft_kernels.h built_row_var)
     // two rows per thread (variant 4) for complex64 from 4096 points: 53.5 -> 51.4 us at 4096^2, 226 -> 207 us at 8192^2;
     // it loses for complex128 (register pressure) and makes no difference at 2048
     if (dtype == PM_C64 && logn >= 12) return 4;

@@ -157,6 +157,12 @@ def active_sequence():
     return getattr(_seq_state, 'seq', None)
 
 
+def _key(t):
+    """identity of the memory a tensor lives in: the data pointer of its base (views share their base's producer)"""
+    b = t._base
+    return (t if b is None else b).data_ptr()
+
+
 class Sequence:
     """``with prysm_amd.graph.sequence(): ...`` around an UNMODIFIED loop of Wavefront / propagation calls: consecutive calls that do
     not depend on each other run on alternating HIP streams (a StreamRing), calls that do depend stay on their producer's stream.
@@ -167,8 +173,8 @@ class Sequence:
 
     What prysm users write for small fields (prysm/propagation/wavefront.py:478-504 in a loop over wavelengths or field points;
     prysm/x/polarization.py:478-553 is the reference's own batch precedent) gets the two-stream overlap of StreamRing without
-    being restructured into stacks or ring.run(...) calls: 2048^2 complex64 `focus` 29.6 -> 26.6 us per field, and the smaller the
-    field the more there is to hide.
+    being restructured into stacks or ring.run(...) calls (DESIGN.md 3.4 has the measurements; below ~1500^2 the host's ~18 us per
+    call is the limit either way and stacks / graph.capture remain the tools).
 
     How: every array-level entry point of the library (prysm_amd._ops, and Wavefront arithmetic) asks `dispatch` for its stream.  A
     call whose tensor arguments were all made before the block (or on the host) takes the next stream of the ring; a call that
@@ -177,21 +183,37 @@ class Sequence:
     kernels, per-stream workspaces.
 
     Inputs made by plain torch operations on the caller's stream inside the block (amp.to(dtype), a mask built in the loop) are
-    waited for when the caller's stream is not idle at the call.  The one rule: RESULTS must not be read by plain torch operations
-    or copied to the host before the block ends (or seq.join()) -- Wavefront arithmetic, .intensity / .phase and prysm_amd's own
-    host conversions (array_to_true_numpy, Wavefront.__array__) are part of the library and do the right thing.
+    waited for when the caller's stream is not idle the first time the block sees them.  The one rule: RESULTS must not be read by
+    plain torch operations or copied to the host before the block ends (or seq.join()) -- Wavefront arithmetic, .intensity /
+    .phase and prysm_amd's own host conversions (array_to_true_numpy, Wavefront.__array__) are part of the library and do the
+    right thing.
+
+    The dispatch is on the host's critical path (a 2048^2 propagation is 26 us of device time): streams are switched through the raw
+    setter, tensors are identified by data pointer, and an input is checked against the caller's stream once, not per call.
     """
 
     def __init__(self, streams=2, device=None):
         self.ring = StreamRing(streams, device)
-        self._producer = {}       # storage pointer of a tensor made inside the block -> its stream
+        self._producer = {}       # data pointer of a tensor made inside the block -> its stream
+        self._checked = set()     # data pointers of outside inputs already ordered behind the caller's stream
         self._depth = 0
-        self._prev = None
+        self._caller = None
+        self._set = getattr(torch._C, '_cuda_setStream', None)
+        self._ids = {}            # id(stream) -> the three integers of the raw setter
+
+    def _switch(self, s):
+        if self._set is None:
+            torch.cuda.set_stream(s)
+            return
+        ids = self._ids.get(id(s))
+        if ids is None:
+            ids = self._ids[id(s)] = (s.stream_id, s.device_index, s.device_type)
+        self._set(stream_id=ids[0], device_index=ids[1], device_type=ids[2])
 
     def __enter__(self):
-        self._prev = active_sequence()
-        if self._prev is not None:
+        if active_sequence() is not None:
             raise RuntimeError('prysm_amd.graph.sequence() blocks do not nest')
+        self._caller = torch.cuda.current_stream()
         _seq_state.seq = self
         self.ring.fork()
         return self
@@ -203,13 +225,12 @@ class Sequence:
 
     def fork(self):
         self.ring.fork()
+        self._checked.clear()
 
     def join(self):
         self.ring.join()
         self._producer.clear()
-
-    def _known(self, tensors):
-        return sum(1 for t in tensors if t.untyped_storage().data_ptr() in self._producer)
+        self._checked.clear()
 
     def dispatch(self, fn, args, kwargs):
         """run fn(*args, **kwargs) on the stream the data dependences pick; nested library calls run inside the outer call's stream"""
@@ -218,35 +239,49 @@ class Sequence:
         ins = _tensors_of(args, [])
         if kwargs:
             _tensors_of(kwargs, ins)
+        prod, checked = self._producer, self._checked
         s = None
         others = None
+        fresh = None
         for t in ins:
-            ps = self._producer.get(t.untyped_storage().data_ptr())
-            if ps is None or ps is s:
-                continue
-            if s is None:
-                s = ps
-            else:
-                others = (others or []) + [ps]
-        fresh = s is None or len(ins) > self._known(ins)
+            k = _key(t)
+            ps = prod.get(k)
+            if ps is None:
+                if k not in checked:
+                    fresh = (fresh or []) + [k]
+                    for r in self.ring.streams:      # allocated elsewhere, read on the ring: its block must not be recycled under those reads
+                        t.record_stream(r)
+            elif ps is not s:
+                if s is None:
+                    s = ps
+                else:
+                    others = (others or []) + [ps]
         if s is None:
             s = self.ring.next_stream()
+        if not self.ring._forked:
+            self.ring.fork()
         if others:
             for o in others:
                 s.wait_stream(o)
         if fresh:
-            # an input that was not made inside the block: from before it (ordered by the fork) or from a plain torch operation on the
-            # caller's stream since (amp.to(dtype), a mask built in the loop).  If the caller's stream is not idle, wait for it.
-            cur = torch.cuda.current_stream()
-            if not cur.query():
-                s.wait_stream(cur)
-        self._depth += 1
+            # inputs that were not made inside the block: from before it (ordered by the fork) or from a plain torch operation on the
+            # caller's stream since (amp.to(dtype), a mask built in the loop).  If the caller's stream is not idle, EVERY ring stream waits
+            # for it once; after that the tensor counts as ordered.
+            if not self._caller.query():
+                for r in self.ring.streams:
+                    r.wait_stream(self._caller)
+            checked.update(fresh)
+        self._depth = 1
+        self._switch(s)
         try:
-            out = self.ring.run_on(s, fn, *args, **kwargs)
+            out = fn(*args, **kwargs)
         finally:
-            self._depth -= 1
+            self._switch(self._caller)
+            self._depth = 0
+        caller = self._caller
         for t in _tensors_of(out, []):
-            self._producer[t.untyped_storage().data_ptr()] = s
+            t.record_stream(caller)
+            prod[_key(t)] = s
         return out
 
 
