@@ -88,6 +88,7 @@ def _summary(line):
         'psf_variant_ms': get('psf_variant/ms_per_psf'),
         'c2_ms': get(oc + 'config2_focus_2048_c64/ms'), 'c2_two_streams_ms': get(oc + 'config2_focus_2048_c64/two_streams/ms'),
         'c2_sequence_ms': get(oc + 'config2_focus_2048_c64/sequence_block/ms'), 'f1000_sequence_ms': get(oc + 'focus_1000_c64_sequence_block/ms'),
+        'c128_2048_ms': get(oc + 'focus_2048_c128_sequence_block/one_stream_ms'), 'c128_2048_sequence_ms': get(oc + 'focus_2048_c128_sequence_block/ms'),
         'c3_ms': get(oc + 'config3_angular_spectrum_4096_c128/ms'), 'c3_moved_frac': get(oc + 'config3_angular_spectrum_4096_c128/moved_frac_of_hbm_peak'),
         'c4_ms': get(oc + 'config4_mdft_2048_to_512_c64/ms'), 'c4_build_ms': get(oc + 'config4_mdft_2048_to_512_c64/prepare_executor_ms'),
         'c4_frac_mfma': get(oc + 'config4_mdft_2048_to_512_c64/frac_of_f32_mfma_peak'),
@@ -311,6 +312,13 @@ def other_configs(only=''):
         e3 = _hbm_entry(_event_ms(lambda: block(x2, x2b), 3, warm=1) / 200, 4 * 2048 ** 2 * 8)
         out['config2_focus_2048_c64']['sequence_block'] = dict(e3, note='the same 200 propagations as plain P.focus calls inside `with graph.sequence():`')
         del x2, x2b
+        # where the block pays: device time per call above the host's ~25 us and arrays that still share the Infinity Cache
+        xc = torch.from_numpy(make_field(2048, np.complex128, 2048)).cuda()
+        xd = xc.clone()
+        one128 = _hbm_entry(_event_ms(lambda: P.focus(xc, 1), 60), 4 * 2048 ** 2 * 16)
+        e5 = _hbm_entry(_event_ms(lambda: block(xc, xd, 50), 3, warm=1) / 100, 4 * 2048 ** 2 * 16)
+        out['focus_2048_c128_sequence_block'] = dict(e5, one_stream_ms=one128['ms'], note='2048^2 complex128: plain calls in a sequence() block')
+        del xc, xd
         xa = torch.from_numpy(make_field(1000, np.complex64, 1000)).cuda()
         xb = xa.clone()
         one = _hbm_entry(_event_ms(lambda: P.focus(xa, 1), 100), 4 * 1000 ** 2 * 8)

@@ -345,7 +345,8 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
     if (p.r2c) {
         p.col_var = 0;
         p.tc = col_tile_width_for(d->dtype, p.logm, 0);
-        p.log_k = tuning().log_k >= 0 ? tuning().log_k : 2;
+        // layout tiles of 8 column tiles: mtf_from_psf 4096^2 fp32 73.6 -> 72.0 us against 4 (profiles/r05/exp_layout_sweep.log)
+        p.log_k = tuning().log_k >= 0 ? tuning().log_k : 3;
         // fold (one radix-2 step of the column transform in the row pass, as in the complex path): half-length column tiles, two
         // workgroups per CU whose load / transform / store phases overlap -- here from 1024-point columns, because the Hermitian
         // column pass has only half the tiles to fill the chip with
@@ -560,7 +561,12 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
             ColLoadTiled<T> cl{W, H, AxisMap{H, H, 0, 0}, ntiles, p.log_k, plane};
             HermStore<T> hs{out, 2 * d->out_ld, AxisMap{H, H, 0, int(d->out_y.shift / 2)}, to_map(d->out_x), H, int(N), d->epilogue,
                             T(d->scale), T(d->weight), (d->flags & PM_FLAG_NORM_DC) ? 1 : 0, W, tl, H, 0, d->out_ld, fast, p.col_var == 2 ? 1 : 0};
-            return launch_col_herm<T>(p.logm - 1, cl, hs, twh, ntiles, sibling_log_g(p.log_k), st);
+            // several rounds of one-workgroup-per-CU tiles (8192^2: 1024 of them): ALL 32 workgroups an XCD holds take adjacent tiles,
+            // so a row of the output is written 2 KiB at a time -- mtf_from_psf 8192^2 fp32 391 -> 373 us (exp_layout_sweep.log)
+            int lg = sibling_log_g(p.log_k);
+            if (tuning().col_log_g < 0 && 2 * ntiles > 2 * pm_num_cus())
+                for (lg = 5; lg > 3 && ntiles % (8 << lg); --lg) {}
+            return launch_col_herm<T>(p.logm - 1, cl, hs, twh, ntiles, lg, st);
         }
         ColLoadTiled<T> cl{W, int(M), to_map(d->in_y), ntiles, p.log_k, 0};
         HermStore<T> hs{out, d->out_ld, to_map(d->out_y), to_map(d->out_x), int(M), int(N), d->epilogue, T(d->scale), T(d->weight),

@@ -9,6 +9,7 @@ amortise launch overhead (docs: GPU and Exascale Computing.ipynb).
 """
 import functools
 import threading
+import weakref
 
 import torch
 
@@ -96,11 +97,12 @@ class StreamRing:
       * fork() orders every stream of the ring behind what the caller's stream has queued; the first run() after a join() (or after
         construction) forks by itself, so "loop {run ...; join; consume}" is ordered in both directions on every trip.  Inputs made
         on the caller's stream AFTER that fork need another fork() (or must come from the same stream of the ring).
-      * join() orders the caller's stream behind every stream of the ring.
-      * every result tensor of run() is noted as "also used on the caller's stream" (Tensor.record_stream) the moment it is made: it
-        was allocated on a ring stream, and without that note torch's caching allocator would hand its block to the next run() on
-        that stream as soon as the caller dropped the tensor -- while the caller's stream could still have reads of it queued
-        (ADVICE r4).  With the note, a dropped block is reusable once the caller's stream has passed the point of the drop.
+      * join() orders the caller's stream behind every stream of the ring and notes every result of the batch that is STILL ALIVE as
+        "also used on the caller's stream" (Tensor.record_stream): it was allocated on a ring stream, and without that note torch's
+        caching allocator would hand its block to a later run() on that stream as soon as the caller dropped the tensor -- while
+        the caller's stream could still have reads of it queued.  A result dropped BEFORE the join was never read by
+        the caller; one dropped after it is covered by the note; and the next batch forks before it reuses anything.  (Per result
+        this costs a weak reference in run() and one record_stream at the join -- not a call on the critical path of every run().)
 
     Workspaces are per stream (_lib.workspace), outputs come from torch's stream-aware allocator; results are the same bits.
     """
@@ -110,6 +112,7 @@ class StreamRing:
         self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(n)))]
         self._next = 0
         self._forked = False      # a batch is open: the ring's streams are ordered behind the caller's stream
+        self._made = []           # weak references to the results of the open batch
 
     @staticmethod
     def worth_it(shape, dtype=torch.complex64, streams=2):
@@ -132,12 +135,15 @@ class StreamRing:
         """fn(*args, **kwargs) on stream `s` of the ring; its result tensors are recorded on the caller's stream"""
         if not self._forked:
             self.fork()
-        cur = torch.cuda.current_stream()
         with torch.cuda.stream(s):
             out = fn(*args, **kwargs)
-        for t in _tensors_of(out, []):
-            t.record_stream(cur)
+        self.note(out)
         return out
+
+    def note(self, out):
+        made = self._made
+        for t in _tensors_of(out, []):
+            made.append(weakref.ref(t))
 
     def run(self, fn, *args, **kwargs):
         return self.run_on(self.next_stream(), fn, *args, **kwargs)
@@ -146,6 +152,11 @@ class StreamRing:
         cur = torch.cuda.current_stream()
         for s in self.streams:
             cur.wait_stream(s)
+        for r in self._made:
+            t = r()
+            if t is not None:
+                t.record_stream(cur)
+        self._made = []
         self._forked = False
 
 
@@ -263,6 +274,9 @@ class Sequence:
         if others:
             for o in others:
                 s.wait_stream(o)
+            for t in ins:                   # made on another ring stream, read on this one: its block must outlive these reads
+                if prod.get(_key(t)) not in (None, s):
+                    t.record_stream(s)
         if fresh:
             # inputs that were not made inside the block: from before it (ordered by the fork) or from a plain torch operation on the
             # caller's stream since (amp.to(dtype), a mask built in the loop).  If the caller's stream is not idle, EVERY ring stream waits
@@ -278,9 +292,11 @@ class Sequence:
         finally:
             self._switch(self._caller)
             self._depth = 0
-        caller = self._caller
+        made = self.ring._made
+        if len(made) > 4096:                # a long block: forget the results that are gone already
+            made[:] = [r for r in made if r() is not None]
         for t in _tensors_of(out, []):
-            t.record_stream(caller)
+            made.append(weakref.ref(t))     # recorded on the caller's stream at the join if still alive (StreamRing.join)
             prod[_key(t)] = s
         return out
 
