@@ -389,6 +389,17 @@ int pm_cgemm_abs2(int32_t dtype, int32_t opA, int32_t opB, int64_t M, int64_t N,
                   size_t workspace_bytes, void* stream);
 
 /* --- housekeeping ------------------------------------------------------------------------- */
+/* Real-input 2-D spectrum on ANY even width (round 5; prysm/otf.py:28-33 transform_psf, :62-135 the centre-normalised MTF / PTF / OTF
+ * take any size through scipy): the real M x N array IS an M x N/2 complex array z[r][j] = x[r][2j] + i x[r][2j+1]; transform that
+ * with pm_fft2 (forward, no rotations -- half the work, on whatever route its lengths take) and hand the result `zf` to this sweep,
+ * which untangles F = fft2(x) from it, applies the rotation of the INPUT by (in_shift_y, in_shift_x) samples as a phase, divides by
+ * F[0][0] (norm_dc; real: the sum of the samples), multiplies by `scale`, takes the epilogue (PM_EPI_NONE complex out, PM_EPI_ABS,
+ * PM_EPI_ABS2, PM_EPI_ARG real out) and writes all M x N bins rotated by (out_shift_y, out_shift_x).  Lengths the library's own
+ * Hermitian path takes (powers of two, PM_FLAG_REAL_INPUT in pm_fft2) do not need it. */
+int pm_r2c_untangle(int32_t dtype, int64_t M, int64_t N, const void* zf, int64_t zf_ld, int64_t in_shift_y, int64_t in_shift_x,
+                    int64_t out_shift_y, int64_t out_shift_x, int32_t epilogue, int32_t norm_dc, double scale, void* out, int64_t out_ld,
+                    void* stream);
+
 int pm_version(void);
 const char* pm_last_error(void);   /* thread-local message for the last negative return */
 int pm_plan_prepare(int32_t dtype, int64_t n);   /* build + cache the tables of a transform length now (twiddles; for a length on the

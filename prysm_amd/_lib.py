@@ -52,6 +52,7 @@ SIGNATURES = {
     'pm_set_tuning_local': (c_i32, [ctypes.c_char_p, c_i32]),
     'pm_reset_tuning_local': (None, []),
     'pm_plan_explain': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_i32, ctypes.c_char_p, c_sz]),
+    'pm_r2c_untangle': (c_i32, [c_i32, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_f64, c_vp, c_i64, c_vp]),
     'pm_fft2_workspace': (c_sz, [ctypes.POINTER(pm_fft2_desc)]),
     'pm_fft2': (c_i32, [ctypes.POINTER(pm_fft2_desc), c_vp, c_vp, c_vp, c_sz, c_vp]),
     'pm_fft2_spectral_workspace': (c_sz, [ctypes.POINTER(pm_fft2_desc), c_i32]),

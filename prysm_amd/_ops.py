@@ -228,6 +228,33 @@ def _fft2_call(x, *, direction, scale, shape=None, in_off=(0, 0), in_shift=(0, 0
     return out
 
 
+def real_pairs_ok(x):
+    """Whether a real 2-D array can be read as rows of complex pairs (fft2_real): float32 / float64, contiguous rows of EVEN length, even
+    row pitch, base address aligned like a complex element."""
+    return (isinstance(x, torch.Tensor) and not x.is_complex() and x.dim() == 2 and x.dtype in (torch.float32, torch.float64) and
+            x.shape[1] >= 2 and x.shape[1] % 2 == 0 and x.shape[0] >= 1 and x.stride(1) == 1 and (x.stride(0) % 2 == 0 or x.shape[0] == 1) and
+            x.data_ptr() % (2 * x.element_size()) == 0)
+
+
+def fft2_real(x, *, scale=1.0, in_shift=(0, 0), out_shift=(0, 0), epilogue=L.PM_EPI_NONE, norm_dc=False):
+    """fft2 of a REAL (M, N) array, N even, on any lengths: the array read as (M, N/2) complex pairs, one half-size pm_fft2 on whatever
+    route those lengths take, and one untangling sweep (pm_r2c_untangle) that also applies the input rotation, the optional division by
+    the DC bin, `scale`, the epilogue (complex, |.|, |.|^2, angle) and the output rotation.  What the library's Hermitian path does for
+    powers of two, for every other size (1000^2, 3000^2, 1536 x 2000 ...): prysm/otf.py:28-33, 62-135."""
+    lib = L.load()
+    if not real_pairs_ok(x):
+        raise ValueError('fft2_real: a real float32 / float64 2-D array with contiguous rows of even length is required')
+    M, N = x.shape
+    z = torch.view_as_complex(x.as_strided((M, N // 2, 2), (x.stride(0) if M > 1 else N, 2, 1)))
+    zf = _fft2_call(z, direction=-1, scale=1.0)
+    cdt = zf.dtype
+    out = torch.empty((M, N), dtype=cdt if epilogue == L.PM_EPI_NONE else L._REAL_OF[cdt], device=x.device)
+    L.check(lib.pm_r2c_untangle(L._COMPLEX_CODE[cdt], M, N, L.ptr(zf), zf.stride(0), int(in_shift[0]) % M, int(in_shift[1]) % N,
+                                int(out_shift[0]) % M, int(out_shift[1]) % N, int(epilogue), 1 if norm_dc else 0, float(scale),
+                                L.ptr(out), out.stride(0), L.stream_ptr()))
+    return out
+
+
 def pack_amp_opd(amp, opd):
     """(amplitude, OPD) pairs in the OPD map's precision as a complex tensor -- the input of fft2(..., synth=('packed', k)).  A loop
     over wavelengths packs its two maps once and then reads ONE element per sample in every transform."""
@@ -724,7 +751,7 @@ def ceil_half(d):
 
 # Inside a ``prysm_amd.graph.sequence()`` block every array-level entry point asks the block for its stream (independent calls alternate
 # between the streams of a ring, dependent ones follow their producer); outside of one the wrapper is one thread-local read.
-for _name in ('fft2', 'pack_amp_opd', 'fft2_mul_ifft2', 'fft1', 'czt_vectors', 'czt_axis', 'fft1_ramp', 'cmul', 'rmul', 'scale_sep', 'abs2',
+for _name in ('fft2', 'fft2_real', 'pack_amp_opd', 'fft2_mul_ifft2', 'fft1', 'czt_vectors', 'czt_axis', 'fft1_ramp', 'cmul', 'rmul', 'scale_sep', 'abs2',
               'abs_arg', 'sum_modes', 'encircled_energy', 'encircled_energy_adjoint', 'spline_prefilter', 'sample_map', 'pupil_synth',
               'quadratic_phase', 'as_tf_vectors', 'outer', 'embed', 'pad_index', 'mdft_basis', 'mdft_basis_grid', 'cgemm', 'cgemm_abs2'):
     globals()[_name] = sequenced(globals()[_name])

@@ -467,7 +467,121 @@ using namespace pm;
 
 #define PM_STREAM(s) reinterpret_cast<hipStream_t>(s)
 
+// ---------------------------------------------------------------- real-input 2-D spectrum from the transform of the packed array
+// A real M x N array (N even) read as M x N/2 complex numbers z[r][j] = x[r][2j] + i x[r][2j+1] costs nothing to form -- it is the same
+// memory -- and its 2-D transform Zf (any route of pm_fft2: engine, mixed-radix, Bluestein) is half the work of transforming x as
+// complex.  One sweep untangles it:
+//     A = Zf[u][k],  B = conj Zf[(M - u) % M][(N/2 - k) % (N/2)]
+//     F[u][k] = (A + B) / 2 + W_N^k (A - B) / (2i),        k = 0 .. N/2 - 1;      F[u][N/2] = (A0 + B0) / 2 - (A0 - B0) / (2i) at k = 0
+// and F[(M - u) % M][N - k] = conj F[u][k] fills the other half.  Rotations of the INPUT by (sy, sx) samples (ifftshift) are phases
+// here -- conj(W_M^(u sy) W_N^(k sx)), signs for half a length -- because the packed view cannot rotate by an odd number of samples;
+// rotations of the OUTPUT are index maps.  Optional division by F[0][0] = Re Zf[0][0] + Im Zf[0][0] (the sum of all samples: real)
+// and the |.|, |.|^2, angle epilogues of the Hermitian path: otf.mtf_from_psf / ptf_from_psf / otf_from_psf on ANY even width
+// (prysm/otf.py:28-33, 62-135 take any size through scipy) in one half-size transform + this sweep.
+template <typename T, int EPI>
+__device__ __forceinline__ void untangle_put(void* out, int64_t ldo, int64_t qy, int64_t qx, cx<T> f) {
+    const int64_t at = qy * ldo + qx;
+    if constexpr (EPI == PM_EPI_NONE) reinterpret_cast<cx<T>*>(out)[at] = f;
+    else if constexpr (EPI == PM_EPI_ABS) reinterpret_cast<T*>(out)[at] = sqrt(f.x * f.x + f.y * f.y);
+    else if constexpr (EPI == PM_EPI_ABS2) reinterpret_cast<T*>(out)[at] = f.x * f.x + f.y * f.y;
+    else reinterpret_cast<T*>(out)[at] = atan2(f.y, f.x);
+}
+
+template <typename T, int EPI>
+__global__ void r2c_untangle_kernel(int64_t M, int64_t N, const cx<T>* __restrict__ zf, int64_t ldz, const cx<T>* __restrict__ twn,
+                                    const cx<T>* __restrict__ twm, int64_t isy, int64_t isx, int64_t osy, int64_t osx, int norm_dc, T scale,
+                                    void* out, int64_t ldo) {
+    const int64_t n2 = N / 2;
+    const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;      // 0 .. N/2 inclusive
+    if (k > n2) return;
+    T s = scale;
+    if (norm_dc) {
+        const cx<T> z0 = zf[0];
+        s = scale / (z0.x + z0.y);
+    }
+    const int64_t ka = k == n2 ? 0 : k, kb = ka == 0 ? 0 : n2 - ka;
+    const cx<T> w = k == n2 ? cx<T>{T(-1), T(0)} : twn[k];                  // W_N^k
+    // phase of the input rotation along x: conj(W_N^(k isx mod N))
+    cx<T> px = {T(1), T(0)};
+    if (2 * isx == N) {                          // half a length (ifftshift of an even axis): a sign
+        if (k & 1) px.x = T(-1);
+    } else if (isx) {
+        const cx<T> t = twn[(k * isx) % N];
+        px = {t.x, -t.y};
+    }
+    const bool half_y = 2 * isy == M;
+    int64_t qx = k + osx;
+    if (qx >= N) qx -= N;
+    int64_t qxm = (k == 0 || k == n2) ? -1 : N - k + osx;
+    if (qxm >= N) qxm -= N;
+    for (int64_t u = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; u < M; u += int64_t(gridDim.y) * blockDim.y) {
+        const int64_t um = u == 0 ? 0 : M - u;
+        const cx<T> a = zf[u * ldz + ka];
+        const cx<T> bz = zf[um * ldz + kb];
+        const cx<T> b = {bz.x, -bz.y};
+        const cx<T> xe = {T(0.5) * (a.x + b.x), T(0.5) * (a.y + b.y)};
+        const cx<T> d = {T(0.5) * (a.x - b.x), T(0.5) * (a.y - b.y)};
+        cx<T> f = xe + cmul(w, mul_mi(d));                                  // (A - B) / (2i) = -i (A - B) / 2
+        cx<T> ph = px;
+        if (half_y) {
+            if (u & 1) ph = {-px.x, -px.y};
+        } else if (isy) {
+            const cx<T> t = twm[(u * isy) % M];
+            ph = cmul(px, cx<T>{t.x, -t.y});
+        }
+        f = cscale(cmul(f, ph), s);
+        int64_t qy = u + osy;
+        if (qy >= M) qy -= M;
+        untangle_put<T, EPI>(out, ldo, qy, qx, f);
+        if (qxm >= 0) {
+            int64_t qym = um + osy;
+            if (qym >= M) qym -= M;
+            untangle_put<T, EPI>(out, ldo, qym, qxm, cx<T>{f.x, -f.y});
+        }
+    }
+}
+
+template <typename T>
+static int r2c_untangle_launch(int64_t M, int64_t N, const void* zf, int64_t ldz, int64_t isy, int64_t isx, int64_t osy, int64_t osx, int epi,
+                               int norm_dc, double scale, void* out, int64_t ldo, hipStream_t st) {
+    int err = 0;
+    const cx<T>* twn = twiddles<T>(N, &err);
+    if (!twn) return err;
+    const cx<T>* twm = isy ? twiddles<T>(M, &err) : twn;
+    if (!twm) return err;
+    dim3 block(64, 4);
+    int64_t gy = (M + 3) / 4;
+    if (gy > 16384) gy = 16384;
+    dim3 grid((unsigned)((N / 2 + 1 + 63) / 64), (unsigned)gy);
+#define PM_UNT(E)                                                                                                                      \
+    hipLaunchKernelGGL((r2c_untangle_kernel<T, E>), grid, block, 0, st, M, N, (const cx<T>*)zf, ldz, twn, twm, isy, isx, osy, osx, norm_dc, \
+                       T(scale), out, ldo)
+    switch (epi) {
+        case PM_EPI_NONE: PM_UNT(PM_EPI_NONE); break;
+        case PM_EPI_ABS: PM_UNT(PM_EPI_ABS); break;
+        case PM_EPI_ABS2: PM_UNT(PM_EPI_ABS2); break;
+        case PM_EPI_ARG: PM_UNT(PM_EPI_ARG); break;
+        default: return fail(PM_ERR_ARG, "pm_r2c_untangle: epilogue must be PM_EPI_NONE, PM_EPI_ABS, PM_EPI_ABS2 or PM_EPI_ARG");
+    }
+#undef PM_UNT
+    return int(hipGetLastError());
+}
+
 extern "C" {
+
+int pm_r2c_untangle(int32_t dtype, int64_t M, int64_t N, const void* zf, int64_t zf_ld, int64_t in_shift_y, int64_t in_shift_x,
+                    int64_t out_shift_y, int64_t out_shift_x, int32_t epilogue, int32_t norm_dc, double scale, void* out, int64_t out_ld,
+                    void* stream) {
+    if (!zf || !out || M < 1 || N < 2 || (N % 2) || zf_ld < N / 2 || out_ld < N) return fail(PM_ERR_ARG, "pm_r2c_untangle: bad argument (N must be even)");
+    if (in_shift_y < 0 || in_shift_y >= M || in_shift_x < 0 || in_shift_x >= N || out_shift_y < 0 || out_shift_y >= M || out_shift_x < 0 ||
+        out_shift_x >= N)
+        return fail(PM_ERR_ARG, "pm_r2c_untangle: shifts must lie in [0, length)");
+    if (dtype == PM_C64)
+        return r2c_untangle_launch<float>(M, N, zf, zf_ld, in_shift_y, in_shift_x, out_shift_y, out_shift_x, epilogue, norm_dc, scale, out, out_ld, PM_STREAM(stream));
+    if (dtype == PM_C128)
+        return r2c_untangle_launch<double>(M, N, zf, zf_ld, in_shift_y, in_shift_x, out_shift_y, out_shift_x, epilogue, norm_dc, scale, out, out_ld, PM_STREAM(stream));
+    return fail(PM_ERR_ARG, "pm_r2c_untangle: dtype must be PM_C64 or PM_C128");
+}
 
 int pm_cmul(int32_t dtype, int32_t op, int64_t rows, int64_t cols, const void* a, int64_t a_ld, const void* b,
             int64_t b_ld, void* out, int64_t out_ld, void* stream) {

@@ -205,6 +205,7 @@ class Sequence:
 
     def __init__(self, streams=2, device=None):
         self.ring = StreamRing(streams, device)
+        self.cache_budget = 200 << 20      # bytes of the 256 MiB Infinity Cache the concurrent propagations may claim
         self._producer = {}       # data pointer of a tensor made inside the block -> its stream
         self._checked = set()     # data pointers of outside inputs already ordered behind the caller's stream
         self._depth = 0
@@ -268,7 +269,14 @@ class Sequence:
                 else:
                     others = (others or []) + [ps]
         if s is None:
-            s = self.ring.next_stream()
+            # an independent call: the next stream of the ring -- unless its arrays are too large for two propagations to share the
+            # Infinity Cache (StreamRing.worth_it: input + intermediate + output per stream), where two streams evict each other's
+            # intermediates (2048^2 complex128: 47 -> 54 us per call; 4096^2 complex64: 95 -> 133) and everything stays on stream 0
+            big = 0
+            for t in ins:
+                nb = t.numel() * t.element_size()
+                big = nb if nb > big else big
+            s = self.ring.next_stream() if 3 * big * len(self.ring.streams) <= self.cache_budget else self.ring.streams[0]
         if not self.ring._forked:
             self.ring.fork()
         if others:

@@ -39,7 +39,10 @@ def transform_psf(psf, dx=None):
     x = L.as_field(psf)          # a real PSF is read as it is (PM_FLAG_REAL_INPUT): no complex copy, half the bytes in pass 1
     M, N = x.shape
     shift = (M // 2, N // 2)
-    data = _ops.fft2(x, direction=-1, scale=1.0, in_shift=shift, out_shift=shift)
+    if not x.is_complex() and not _hermitian_ok(x) and _ops.real_pairs_ok(x) and M * N >= 1 << 18:
+        data = _ops.fft2_real(x, in_shift=shift, out_shift=shift)      # sizes off the engine: half-size transform + untangle (round 5)
+    else:
+        data = _ops.fft2(x, direction=-1, scale=1.0, in_shift=shift, out_shift=shift)
     df = 1000 / (data.shape[0] * dx)  # cy/um to cy/mm
     return data, df
 
@@ -60,9 +63,13 @@ def _fused_from_psf(psf, dx, epilogue):
     if x.is_complex() or x.dim() != 2:
         return None
     M, N = x.shape
-    if not _hermitian_ok(x):
-        return None
     shift = (M // 2, N // 2)
+    if not _hermitian_ok(x):
+        # any other size with an even width (1000^2, 3000^2 ...): the array as complex pairs, a half-size transform on its own route and
+        # one untangling sweep with the same normalisation and epilogue (round 5, _ops.fft2_real)
+        if _ops.real_pairs_ok(x) and x.is_cuda:
+            return _ops.fft2_real(x, scale=1.0, in_shift=shift, out_shift=shift, epilogue=epilogue, norm_dc=True), 1000 / (M * dx)
+        return None
     try:
         data = _ops.fft2(x, direction=-1, scale=1.0, in_shift=shift, out_shift=shift, epilogue=epilogue, flags=L.PM_FLAG_NORM_DC)
     except NotImplementedError:      # the predicate above mirrors the library's (capi.hip r2c_legal); kept as the backstop

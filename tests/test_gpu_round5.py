@@ -164,6 +164,25 @@ def test_sequence_accumulator_and_host_conversion(pa):
     assert rel_max(inside, want) < 4e-5 and rel_max(tonp(acc), want) < 4e-5
 
 
+def test_sequence_keeps_large_fields_on_one_stream(pa):
+    """two propagations whose arrays cannot share the Infinity Cache (2048^2 complex128: 3 x 64 MB each) stay on one stream of the ring
+    -- two streams measured 47 -> 54 us per call there --, smaller ones alternate; the same bits either way"""
+    from prysm_amd import graph
+    P = pa.propagation
+    g = torch.Generator(device='cuda').manual_seed(3)
+    big = [torch.randn((2048, 2048), device='cuda', generator=g, dtype=torch.float64).to(torch.complex128) for _ in range(2)]
+    small = [torch.randn((1024, 1024), device='cuda', generator=g, dtype=torch.float32).to(torch.complex64) for _ in range(2)]
+    want = [P.focus(x, 1).clone() for x in big + small]
+    with graph.sequence() as seq:
+        got_big = [P.focus(x, 1) for x in big]
+        n_big = len({id(s) for s in seq._producer.values()})
+        got_small = [P.focus(x, 1) for x in small]
+        n_all = len({id(s) for s in seq._producer.values()})
+    torch.cuda.synchronize()
+    assert n_big == 1 and n_all == 2
+    assert all(torch.equal(a, b) for a, b in zip(got_big + got_small, want))
+
+
 def test_stream_ring_batches_reuse_inputs(pa):
     """'fork once; loop {run ...; join; consume; drop}' -- the first run of every batch forks and every result is recorded
     on the caller's stream, so a dropped result's block cannot be handed to the next batch while the caller's reads are queued"""
@@ -269,3 +288,69 @@ def test_root_only_reduce_forms_on_a_one_rank_group(pa):
                 assert out is acc and torch.equal(out, img)
     finally:
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------- real inputs on any even width
+
+@pytest.mark.parametrize('shape,rdt', [((1000, 1000), np.float32), ((3000, 3000), np.float32), ((1001, 1000), np.float64), ((300, 1536), np.float64),
+                                       ((64, 64), np.float32), ((1, 30), np.float64), ((997, 2018), np.float32), ((2048, 1000), np.float64)])
+def test_fft2_real_on_any_even_width_vs_numpy(pa, shape, rdt):
+    """_ops.fft2_real: the real array read as complex pairs, a half-size pm_fft2 (mixed-radix, engine, Bluestein or direct -- whatever
+    the lengths take) and pm_r2c_untangle; plain and centred (ifftshift in / fftshift out), complex output and the three real
+    epilogues, with and without the division by the DC bin -- against numpy fp64"""
+    from prysm_amd import _lib, _ops
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    x = (rng.random(shape) + 0.05).astype(rdt)
+    xt = torch.from_numpy(x).cuda()
+    x64 = x.astype(np.float64)
+    M, N = shape
+    tol = 1e-10 if rdt == np.float64 else 2e-5
+    plain = np.fft.fft2(x64)
+    assert rel_max(tonp(_ops.fft2_real(xt)), plain) < tol
+    sh = (M // 2, N // 2)
+    cen = np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(x64)))
+    got = tonp(_ops.fft2_real(xt, in_shift=sh, out_shift=sh))
+    assert got.dtype == (np.complex128 if rdt == np.float64 else np.complex64) and rel_max(got, cen) < tol
+    nrm = cen / cen[M // 2, N // 2]
+    assert rel_max(tonp(_ops.fft2_real(xt, in_shift=sh, out_shift=sh, norm_dc=True)), nrm) < tol
+    assert rel_max(tonp(_ops.fft2_real(xt, in_shift=sh, out_shift=sh, norm_dc=True, epilogue=_lib.PM_EPI_ABS)), np.abs(nrm)) < tol
+    assert rel_max(tonp(_ops.fft2_real(xt, in_shift=sh, out_shift=sh, scale=0.5, epilogue=_lib.PM_EPI_ABS2)), np.abs(0.5 * cen) ** 2) < 2 * tol
+    ang = tonp(_ops.fft2_real(xt, in_shift=sh, out_shift=sh, norm_dc=True, epilogue=_lib.PM_EPI_ARG))
+    strong = np.abs(nrm) > 1e-3 * np.abs(nrm).max()          # the angle of a bin at rounding level is noise in any implementation
+    dphi = np.angle(np.exp(1j * (ang - np.angle(nrm))))
+    assert np.max(np.abs(dphi[strong])) < (1e-8 if rdt == np.float64 else 2e-3)
+    # a view into a wider array (row pitch != width) and an odd width refused
+    wide = torch.zeros((M, N + 6), dtype=xt.dtype, device='cuda')
+    wide[:, 2:N + 2] = xt
+    assert rel_max(tonp(_ops.fft2_real(wide[:, 2:N + 2])), plain) < tol
+    if N > 2:
+        assert not _ops.real_pairs_ok(xt[:, :N - 1])
+        with pytest.raises(ValueError):
+            _ops.fft2_real(xt[:, :N - 1])
+
+
+@pytest.mark.parametrize('n,rdt', [(1000, np.float32), (3000, np.float32), (1500, np.float64)])
+def test_mtf_ptf_otf_on_composite_grids(pa, n, rdt):
+    """prysm/otf.py on a real PSF whose size is not a power of two: one half-size transform + the untangling sweep with the
+    normalisation and |.| / angle fused (no elementwise torch sweeps), equal to the reference's formula in fp64"""
+    from prysm_amd import otf
+    rng = np.random.default_rng(n)
+    yy, xx = np.mgrid[:n, :n] - n // 2
+    psf = (np.exp(-(xx ** 2 + yy ** 2) / (2 * 9.0 ** 2)) + 0.02 * rng.random((n, n))).astype(rdt)
+    F = np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(psf.astype(np.float64))))
+    nrm = F / F[n // 2, n // 2]
+    tol = 1e-10 if rdt == np.float64 else 2e-5
+    m = otf.mtf_from_psf(psf, 1.0)
+    assert tuple(m.data.shape) == (n, n) and not m.data.is_complex() and abs(m.dx - 1000 / n) < 1e-12
+    assert np.max(np.abs(tonp(m.data) - np.abs(nrm))) < tol
+    o = otf.otf_from_psf(psf, 1.0)
+    assert np.max(np.abs(tonp(o.data) - nrm)) < tol
+    p = tonp(otf.ptf_from_psf(psf, 1.0).data)
+    strong = np.abs(nrm) > 1e-3
+    assert np.max(np.abs(np.angle(np.exp(1j * (p - np.angle(nrm))))[strong])) < (1e-8 if rdt == np.float64 else 2e-3)
+    mm, pp, oo = otf.mtf_ptf_otf_from_psf(psf, 1.0)
+    assert np.max(np.abs(tonp(mm.data) - np.abs(nrm))) < tol and np.max(np.abs(tonp(oo.data) - nrm)) < tol
+    data, df = otf.transform_psf(psf, 1.0)
+    assert rel_max(tonp(data), F) < tol and abs(df - 1000 / n) < 1e-12
+    mtf2, raw = otf.mtf_from_psf(psf, 1.0, return_more=True)      # the composed route still answers return_more
+    assert np.max(np.abs(tonp(mtf2.data) - np.abs(nrm))) < tol and rel_max(tonp(raw), F) < tol

@@ -2,7 +2,7 @@
 
     python tools/exp_knob_ab.py stagger_group 0,1 focus/c64/8192 mtf/f32/4096 as/c128/4096 [rounds]
 
-workloads: focus/<c64|c128>/<n>[/Q]  unfocus/...  as/<c64|c128>/<n>  mtf/<f32|f64>/<n>"""
+workloads: focus/<c64|c128>/<n>[/Q]  unfocus/...  as/<c64|c128>/<n>  mtf/<f32|f64>/<n>  mdft/<c64|c128>/<n>"""
 import sys
 
 import torch
@@ -41,6 +41,12 @@ def make(spec):
     if kind == 'as':
         x = torch.randn(n, n, dtype=cd, device='cuda')
         return (lambda: P.angular_spectrum(x, 0.6328, 0.01, 10.0, Q=1)), reps
+    if kind == 'mdft':     # config 4: matrix-DFT focus n^2 -> 512^2 (two complex GEMMs on MFMA)
+        from prysm_amd.conf import config
+        config.precision = 32 if dt == 'c64' else 64
+        x = torch.randn(n, n, dtype=cd, device='cuda')
+        ex = P.prepare_executor(10 / n, (n, n), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0)
+        return (lambda: P.focus_dft(x, ex)), 30
     if kind == 'mtf':
         psf = torch.rand(n, n, dtype=cd, device='cuda') + 0.01
         return (lambda: otf.mtf_from_psf(psf, 1.0)), reps
