@@ -94,7 +94,8 @@ def _summary(line):
         'c4_ms': get(oc + 'config4_mdft_2048_to_512_c64/ms'), 'c4_build_ms': get(oc + 'config4_mdft_2048_to_512_c64/prepare_executor_ms'),
         'c4_frac_mfma': get(oc + 'config4_mdft_2048_to_512_c64/frac_of_f32_mfma_peak'),
         'c128_4096_ms': get(oc + 'focus_4096_c128/ms'), 'c64_8192_ms': get(oc + 'focus_8192_c64/ms'),
-        'mtf_4096_ms': get(oc + 'mtf_from_psf_4096_f32/ms'), 'conv_4096_ms': get(oc + 'conv_real_4096_f32/ms'),
+        'mtf_4096_ms': get(oc + 'mtf_from_psf_4096_f32/ms'), 'mtf_3000_ms': get(oc + 'mtf_from_psf_3000_f32/ms'),
+        'mtf_3000_composed_ms': get(oc + 'mtf_from_psf_3000_f32/composed_ms'), 'conv_4096_ms': get(oc + 'conv_real_4096_f32/ms'),
         'f3000_c64_ms': get(oc + 'focus_3000_c64_mixed_radix/ms'), 'f3000_c128_ms': get(oc + 'focus_3000_c128_mixed_radix/ms'),
         'f1000_c64_ms': get(oc + 'focus_1000_c64_mixed_radix/ms'),
         'c5F_psf_ms': get('polychromatic/variant_F_fft_focus/psf_ms'), 'c5F_ms_per_wvl': get('polychromatic/variant_F_fft_focus/per_wavelength_ms_per_gpu'),
@@ -409,6 +410,14 @@ def other_configs(only=''):
                                         'note': 'fused: real-input (Hermitian) transform, N/2 columns, DC normalisation + abs in the store; composed '
                                                 '(return_more=True): complex spectrum + division + abs as separate device sweeps'}
         del psf
+        # the same on a composite grid (round 5): half-size transform on the mixed-radix kernels + one untangling sweep with the
+        # normalisation and |.| fused (_ops.fft2_real); graded on 12 B per sample (4 read, 8 intermediate ... the transform moves 16 + 8)
+        psf3 = torch.rand(3000, 3000, dtype=torch.float32, device='cuda') + 0.01
+        ms3 = _event_ms(lambda: otf.mtf_from_psf(psf3, 1.0), 30)
+        ms3c = _event_ms(lambda: otf.mtf_from_psf(psf3, 1.0, return_more=True), 10)
+        out['mtf_from_psf_3000_f32'] = {'ms': ms3, 'composed_ms': ms3c,
+                                        'note': 'real 3000^2 PSF: (3000 x 1500) complex transform + pm_r2c_untangle; composed = return_more=True'}
+        del psf3
     def sec_conv():      # a real 4096^2 fp32 object through a transfer function (apply_transfer_functions: the image-chain
         from prysm_amd import _ops     # step after the PSF) -- half spectra end to end against the complex chain on the same arrays
         obj = torch.rand(4096, 4096, dtype=torch.float32, device='cuda')

@@ -82,8 +82,9 @@ def kernels(path):
 
 
 def occupancy(k):
-    """waves per SIMD the unified register file (512 per lane, allocation granule 8) leaves room for, at most 8"""
-    regs = k['vgpr'] + k['agpr']
+    """waves per SIMD the unified register file (512 per lane, allocation granule 8) leaves room for, at most 8 (on gfx90a and later the
+    code object's .vgpr_count is the unified total: it already includes the accumulation registers)"""
+    regs = k['vgpr']
     regs = max(8, (regs + 7) // 8 * 8)
     return min(8, 512 // regs)
 
@@ -113,12 +114,12 @@ def main(argv):
     for n in sorted(set(a) | set(b)):
         if n not in a:
             k = b[n]
-            print('NEW      %4d vgpr %4d spill occ %d wg/CU %d  %s' % (k['vgpr'] + k['agpr'], k['spill'], occupancy(k), wgs_per_cu_by_regs(k), short(n)))
+            print('NEW      %4d vgpr %4d spill occ %d wg/CU %d  %s' % (k['vgpr'], k['spill'], occupancy(k), wgs_per_cu_by_regs(k), short(n)))
         elif n not in b:
             print('GONE     %s' % short(n))
         else:
             x, y = a[n], b[n]
-            if (x['vgpr'] + x['agpr'], x['spill'], x['scratch']) != (y['vgpr'] + y['agpr'], y['spill'], y['scratch']):
+            if (x['vgpr'], x['spill'], x['scratch']) != (y['vgpr'], y['spill'], y['scratch']):
                 tag = 'same-occ'
                 if wgs_per_cu_by_regs(y) < wgs_per_cu_by_regs(x) or y['spill'] > x['spill']:
                     tag = 'WORSE'
@@ -126,7 +127,7 @@ def main(argv):
                 elif wgs_per_cu_by_regs(y) > wgs_per_cu_by_regs(x) or y['spill'] < x['spill']:
                     tag = 'better'
                 print('%-8s %4d -> %4d vgpr  %4d -> %4d spill  wg/CU %d -> %d  %s' % (
-                    tag, x['vgpr'] + x['agpr'], y['vgpr'] + y['agpr'], x['spill'], y['spill'], wgs_per_cu_by_regs(x), wgs_per_cu_by_regs(y), short(n)))
+                    tag, x['vgpr'], y['vgpr'], x['spill'], y['spill'], wgs_per_cu_by_regs(x), wgs_per_cu_by_regs(y), short(n)))
     print('%d kernels before, %d after, %d worse' % (len(a), len(b), worse))
     return 0
 
