@@ -151,7 +151,6 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("gemm_dma")) t.gemm_dma = v ? 1 : 0;
     else if (is("gemm_dma_wgs")) t.gemm_dma_wgs = v < 1 ? 1 : v;
     else if (is("gemm_tile")) t.gemm_tile = (v == 64 || v == 128) ? v : 0;
-    else if (is("gemm_seam")) t.gemm_seam = v ? 1 : 0;
     else if (is("gemm_3m")) t.gemm_3m = v ? 1 : 0;
     else if (is("gemm_wk")) t.gemm_wk = v & 7;
     else if (is("gemm_min_wgs")) t.gemm_min_wgs = v < 1 ? 1 : v;

@@ -18,10 +18,6 @@
 //    64 x 64 tiles with masked edges.
 // When the output has too few tiles for 256 CUs, K is split into slabs reduced by a second small kernel in a FIXED order --
 // deterministic, unlike atomics.
-#include <map>
-#include <mutex>
-#include <utility>
-
 #include "pm_internal.h"
 
 namespace pm {
@@ -359,8 +355,7 @@ template <int TI, int TJ, int WM, int WN, int WK, bool AKF, bool BKF, int EPI>
 __global__ void __launch_bounds__(64 * WM * WN * WK) cgemm_dma_kernel(int conjA, int conjB, int ntm, int ntn, int64_t K, int64_t ksplit, float alpha,
                                                        const cx<float>* __restrict__ A, int64_t lda, const cx<float>* __restrict__ B,
                                                        int64_t ldb, cx<float>* __restrict__ C, int64_t ldc, int64_t slab_stride,
-                                                       float weight, int accumulate, int* __restrict__ seam, int nslab,
-                                                       cx<float>* __restrict__ Cfin, int64_t ldf, float alpha_fin) {
+                                                       float weight, int accumulate) {
     static_assert(WM * WN * WK == 4 || WM * WN * WK == 8, "four waves, or eight: two K-groups of the 2 x 2 arrangement");
     constexpr int BK = 16, BM = 32 * TI * WM, BN = 32 * TJ * WN, NBUF = 3, NWS = WM * WN;
     constexpr int ABYTES = BM * 128, BBYTES = BN * 128, SGBYTES = NBUF * (ABYTES + BBYTES);
@@ -574,38 +569,6 @@ __global__ void __launch_bounds__(64 * WM * WN * WK) cgemm_dma_kernel(int conjA,
                     Cout[orow * ldc + ocol] = {cr, ci};
                 }
             }
-    // Split-K seam INSIDE the launch (round 5): the K-slabs of a tile are separate workgroups that park their partial tiles in the
-    // workspace; the LAST of them to arrive (one counter per tile, device scope) adds the slabs in slab order -- fixed order, bitwise
-    // reproducible whichever workgroup it is -- scales and stores the tile, and puts the counter back to zero for the next call.  The
-    // separate reduce launch this replaces cost the 512 x 512 x 2048 product of config 4 a 5 us kernel and the gap before it.
-    if constexpr (EPI == 0 && WK == 1) {       // (slabs are only planned for the forms without K-groups: every wave is still here)
-        if (seam != nullptr) {
-            int* const flag = reinterpret_cast<int*>(pm_gemm_smem);
-            __threadfence();                       // this workgroup's partial tile is visible device-wide before it is counted
-            __syncthreads();
-            if (tid == 0) *flag = atomicAdd(seam + rr, 1) == nslab - 1 ? 1 : 0;
-            __syncthreads();
-            if (*flag == 0) return;
-            __threadfence();                       // the other slabs' tiles, written on other XCDs, are read from memory, not from a stale L2 line
-            if (tid == 0) seam[rr] = 0;
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t orow = m0 + wr * 32 * TI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const int64_t ocol = n0 + wc * 32 * TJ + j * 32 + row;
-                        float sr = 0.f, si = 0.f;
-                        for (int sl = 0; sl < nslab; ++sl) {
-                            const cx<float> v = C[int64_t(sl) * slab_stride + orow * ldc + ocol];
-                            sr += v.x;
-                            si += v.y;
-                        }
-                        Cfin[orow * ldf + ocol] = {sr * alpha_fin, si * alpha_fin};
-                    }
-        }
-    }
 }
 
 template <typename T>
@@ -762,52 +725,16 @@ int cgemm_ws_bk(int opA, int opB, int64_t M, int64_t N, int64_t K, double alpha,
     return cgemm_ws_bm<T, BK, 64>(opA, opB, M, N, K, alpha, A, lda, B, ldb, C, ldc, ws, ws_bytes, st);
 }
 
-// Tile counters of the in-launch split-K seam: one zeroed array of kSeamTiles ints per (device, stream), allocated at the first split
-// product on that stream (a blocking hipMalloc + hipMemset, like the twiddle tables: warm a stream up before capturing a hipGraph on
-// it) and left at zero by every launch that used it.  Per stream because two streams may run split products at once.
-constexpr int kSeamTiles = 4096;
-static int* seam_counters(hipStream_t st, int* err) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, int*> tab;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) {
-        *err = int(e);
-        return nullptr;
-    }
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = tab.find({dev, st});
-    if (it != tab.end()) return it->second;
-    int* d = nullptr;
-    e = hipMalloc(&d, kSeamTiles * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(d, 0, kSeamTiles * sizeof(int));
-    if (e != hipSuccess) {
-        if (d) (void)hipFree(d);
-        *err = int(e);
-        return nullptr;
-    }
-    tab[{dev, st}] = d;
-    return d;
-}
-
 struct DmaEpi {
     int kind;          // 0 complex result, 1 real |.|^2 (pm_cgemm_abs2)
     float weight;
     int accumulate;
 };
 
-// the in-launch seam of a split product: the tile counters (self-resetting), where the finished tiles go and their scale
-struct DmaSeam {
-    int* counters = nullptr;
-    cx<float>* C = nullptr;
-    int64_t ldc = 0;
-    float alpha = 1.f;
-};
-
 template <int TI, int TJ, int WM, int WN, int WK, int EPI>
 static int cgemm_dma_launch(bool akf, bool bkf, int cA, int cB, int ntm, int ntn, int S, int64_t K, int64_t ksplit, float al,
                             const cx<float>* A, int64_t lda, const cx<float>* B, int64_t ldb, cx<float>* out, int64_t ldo, int64_t slab,
-                            hipStream_t st, const DmaEpi& ep, const DmaSeam& sm = DmaSeam{}) {
+                            hipStream_t st, const DmaEpi& ep) {
     constexpr int RING = 3 * (32 * TI * WM + 32 * TJ * WN) * 128 * WK;
     constexpr int RED = WK > 1 ? (WK - 1) * WM * WN * TI * TJ * 48 * 64 * 4 : 0;
     constexpr int LDSB = RING > RED ? RING : RED;
@@ -817,7 +744,7 @@ static int cgemm_dma_launch(bool akf, bool bkf, int cA, int cB, int ntm, int ntn
         if (LDSB > 48 * 1024)                                                                                                         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);         \
         hipLaunchKernelGGL(kern, dim3(unsigned(ntm * ntn * S)), dim3(64 * WM * WN * WK), LDSB, st, cA, cB, ntm, ntn, K, ksplit, al, A, lda, B, ldb, out, \
-                           ldo, slab, ep.weight, ep.accumulate, sm.counters, S, sm.C, sm.ldc, sm.alpha);                             \
+                           ldo, slab, ep.weight, ep.accumulate);                                                                      \
     }
     if (akf && bkf) PM_GD(true, true)
     else if (akf) PM_GD(true, false)
@@ -842,27 +769,16 @@ static int cgemm_dma_run(int opA, int opB, int64_t M, int64_t N, int64_t K, doub
     const int64_t ldo = p.S > 1 ? N : ldc, slab = p.S > 1 ? M * N : 0;
     const float al = p.S > 1 ? 1.f : float(alpha);
     const DmaEpi none{0, 1.f, 0};
-    // split products with a complex result finish inside the launch (the last slab of a tile to arrive adds them up: cgemm_dma_kernel);
-    // knob gemm_seam = 0: the separate reduce launch, as until round 4 (and always for the |.|^2 epilogue, whose accumulate reads C)
-    DmaSeam sm;
-    if (p.S > 1 && ep.kind == 0 && tuning().gemm_seam && ntm * ntn <= kSeamTiles) {
-        int err = 0;
-        sm.counters = seam_counters(st, &err);
-        if (!sm.counters) return err;
-        sm.C = C;
-        sm.ldc = ldc;
-        sm.alpha = float(alpha);
-    }
     int rc;
 #define PM_RUN(TI, TJ, WM, WN, WK)                                                                                                            \
     rc = (ep.kind == 1 && p.S == 1)                                                                                                           \
              ? cgemm_dma_launch<TI, TJ, WM, WN, WK, 1>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st, ep) \
-             : cgemm_dma_launch<TI, TJ, WM, WN, WK, 0>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st, none, sm)
+             : cgemm_dma_launch<TI, TJ, WM, WN, WK, 0>(akf, bkf, cA, cB, ntm, ntn, p.S, K, p.ksplit, al, A, lda, B, ldb, out, ldo, slab, st, none)
     if (p.tm == 128) PM_RUN(2, 2, 2, 2, 1);
     else if (p.wk == 2 && p.tn == 64) PM_RUN(1, 1, 2, 2, 2);
     else PM_RUN(1, 1, 2, 2, 1);
 #undef PM_RUN
-    if (rc || p.S == 1 || sm.counters) return rc;
+    if (rc || p.S == 1) return rc;
     const int64_t total = M * N;
     if (ep.kind == 1)
         hipLaunchKernelGGL(splitk_reduce_abs2_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, p.S, float(alpha),

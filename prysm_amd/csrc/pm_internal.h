@@ -129,8 +129,6 @@ struct Tuning {
     int gemm_wk = 1;          // ... K split over wave groups INSIDE the workgroup when that fills the chip without slabs (cgemm.hip gemm_dma_plan):
                               // bit 0 64 x 64 tiles with two K-groups (8 waves); removed in round 5 (experiments/README.md; the value is refused): bit 1 64 x 32 with two, bit 2 32 x 32 with four;
                               // 0: round 2's forms only.  Config 4 (profiles/r03/exp_gemm_forms.log): 160.5 us at 0, 153.0 at 1, 155.3 at 2, 155.9 at 4
-    int gemm_seam = 1;        // ... split products finish inside the launch: the last K-slab of a tile to arrive adds the slabs in order (0: the
-                              // separate reduce launch of rounds 2 - 4)
     int gemm_tile = 0;        // force its tile edge (64 / 128); 0 = auto
     int gemm_bm = 64;         // rows of the GEMM workgroup tile (64 or 128)
     int gemm_bk = 0;          // 0 default K-tile depth, 32 doubles it

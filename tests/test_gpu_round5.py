@@ -354,40 +354,3 @@ def test_mtf_ptf_otf_on_composite_grids(pa, n, rdt):
     assert rel_max(tonp(data), F) < tol and abs(df - 1000 / n) < 1e-12
     mtf2, raw = otf.mtf_from_psf(psf, 1.0, return_more=True)      # the composed route still answers return_more
     assert np.max(np.abs(tonp(mtf2.data) - np.abs(nrm))) < tol and rel_max(tonp(raw), F) < tol
-
-
-# ----------------------------------------------------------------------------- split products that finish inside the launch
-
-@pytest.mark.parametrize('M,N,K', [(512, 512, 2048), (64, 128, 4096), (256, 64, 1024), (512, 512, 512)])
-def test_cgemm_split_k_seam_equals_the_reduce_launch(pa, M, N, K):
-    """complex64 products whose K is split into slabs (small outputs): the last slab of a tile to arrive adds the slabs in slab order
-    inside the launch (round 5, knob gemm_seam) -- bit for bit what the separate reduce launch wrote, equal to numpy, reproducible
-    call after call (the tile counters return to zero), on two streams at once, and for all four operand layouts"""
-    from prysm_amd import _lib, _ops
-    lib = _lib.load()
-    rng = np.random.default_rng(M + N + K)
-    for opA, opB in ((0, 0), (2, 3), (1, 2)):
-        A = crandn(rng, (K, M) if opA & 2 else (M, K), np.complex64)
-        B = crandn(rng, (N, K) if opB & 2 else (K, N), np.complex64)
-
-        def op(a, o):
-            a = a.T if o & 2 else a
-            return a.conj() if o & 1 else a
-        ref = op(A.astype(np.complex128), opA) @ op(B.astype(np.complex128), opB)
-        At, Bt = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
-        try:
-            assert lib.pm_set_tuning(b'gemm_seam', 0) == 0
-            old = _ops.cgemm(At, Bt, opA, opB, alpha=0.25)
-            assert lib.pm_set_tuning(b'gemm_seam', 1) == 0
-            new = [_ops.cgemm(At, Bt, opA, opB, alpha=0.25) for _ in range(3)]
-            s2 = torch.cuda.Stream()
-            s2.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s2):
-                other = [_ops.cgemm(At, Bt, opA, opB, alpha=0.25) for _ in range(3)]
-            also = [_ops.cgemm(At, Bt, opA, opB, alpha=0.25) for _ in range(3)]
-            torch.cuda.current_stream().wait_stream(s2)
-            torch.cuda.synchronize()
-        finally:
-            lib.pm_set_tuning(b'gemm_seam', 1)
-        assert rel_max(tonp(old), 0.25 * ref) < 3e-5
-        assert all(torch.equal(old, g) for g in new + other + also), (opA, opB)
