@@ -312,6 +312,19 @@ template <typename T> inline void nt_store_s(T* p, T v) { *p = v; }
 // experiments/scripts/exp_hwsin.cpp) for float, sincospi for double.
 template <typename T>
 PM_HD cx<T> synth_value(T opd, T a, double k2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (sizeof(T) == 4) {
+        // fp32 OPD map: the product opd * k2 carried as TWO floats (the rounding error of the first product is exact in an FMA; k2's
+        // low part adds the bits a float k2 lacks), reduced to [-0.5, 0.5] turns by an exact subtraction -- 3e-8 turns of error, below
+        // the hardware sine's 1.3e-7, in six fp32 instructions where the fp64 form took five at half rate plus two conversions
+        // (round 5: the synthesising row pass of the wavelength loop is VALU co-limited)
+        const float khi = float(k2), klo = float(k2 - double(khi));
+        const float th = opd * khi;
+        const float tl = __builtin_fmaf(opd, klo, __builtin_fmaf(opd, khi, -th));
+        const float rf = (th - __builtin_rintf(th)) + tl;
+        return {a * __builtin_amdgcn_cosf(rf), a * __builtin_amdgcn_sinf(rf)};
+    }
+#endif
     const double turns = double(opd) * k2;
     const double r = turns - rint(turns);
 #if defined(__HIP_DEVICE_COMPILE__)

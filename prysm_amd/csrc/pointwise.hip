@@ -487,57 +487,76 @@ __device__ __forceinline__ void untangle_put(void* out, int64_t ldo, int64_t qy,
     else reinterpret_cast<T*>(out)[at] = atan2(f.y, f.x);
 }
 
+// One thread takes the PAIR of packed bins a = Zf[u][k], b = Zf[(M - u) % M][(N/2 - k) % (N/2)] for k = 0 .. N/4: every element of Zf is
+// read once (the first form read each twice: 86 MB for a 36 MB array, profiles/r05), and the pair yields two bins of F --
+// F[u][k] from (A, B) = (a, conj b) with W_N^k, F[(M - u) % M][N/2 - k] from (b, conj a) with W_N^(N/2 - k) = -conj W_N^k -- each stored with
+// its conjugate mirror image: four coalesced stores per thread.  Column k = 0 also yields the Nyquist column N/2.
+template <typename T, int EPI>
+struct UntangleOut {
+    int64_t M, N, isy, isx, osy, osx, ldo;
+    const cx<T>* twn;
+    const cx<T>* twm;
+    T s;
+    void* out;
+    // F[u][k] (0 <= k <= N/2) through the input-rotation phase, the scale, the epilogue and the output rotation, with its mirror image
+    __device__ __forceinline__ void emit(int64_t u, int64_t k, cx<T> f) const {
+        cx<T> ph = {T(1), T(0)};
+        if (2 * isx == N) {                          // half a length (ifftshift of an even axis): a sign
+            if (k & 1) ph.x = T(-1);
+        } else if (isx) {
+            const cx<T> t = twn[(k * isx) % N];
+            ph = {t.x, -t.y};
+        }
+        if (2 * isy == M) {
+            if (u & 1) ph = {-ph.x, -ph.y};
+        } else if (isy) {
+            const cx<T> t = twm[(u * isy) % M];
+            ph = cmul(ph, cx<T>{t.x, -t.y});
+        }
+        f = cscale(cmul(f, ph), s);
+        int64_t qy = u + osy, qx = k + osx;
+        if (qy >= M) qy -= M;
+        if (qx >= N) qx -= N;
+        untangle_put<T, EPI>(out, ldo, qy, qx, f);
+        if (k != 0 && 2 * k != N) {
+            int64_t qym = (u == 0 ? 0 : M - u) + osy, qxm = N - k + osx;
+            if (qym >= M) qym -= M;
+            if (qxm >= N) qxm -= N;
+            untangle_put<T, EPI>(out, ldo, qym, qxm, cx<T>{f.x, -f.y});
+        }
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ cx<T> untangle_bin(cx<T> a, cx<T> bconj, cx<T> w) {      // (A + B) / 2 + W (A - B) / (2i)
+    const cx<T> xe = {T(0.5) * (a.x + bconj.x), T(0.5) * (a.y + bconj.y)};
+    const cx<T> d = {T(0.5) * (a.x - bconj.x), T(0.5) * (a.y - bconj.y)};
+    return xe + cmul(w, mul_mi(d));
+}
+
 template <typename T, int EPI>
 __global__ void r2c_untangle_kernel(int64_t M, int64_t N, const cx<T>* __restrict__ zf, int64_t ldz, const cx<T>* __restrict__ twn,
                                     const cx<T>* __restrict__ twm, int64_t isy, int64_t isx, int64_t osy, int64_t osx, int norm_dc, T scale,
                                     void* out, int64_t ldo) {
     const int64_t n2 = N / 2;
-    const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;      // 0 .. N/2 inclusive
-    if (k > n2) return;
+    const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;      // 0 .. N/4 inclusive
+    if (k > n2 / 2) return;
     T s = scale;
     if (norm_dc) {
         const cx<T> z0 = zf[0];
         s = scale / (z0.x + z0.y);
     }
-    const int64_t ka = k == n2 ? 0 : k, kb = ka == 0 ? 0 : n2 - ka;
-    const cx<T> w = k == n2 ? cx<T>{T(-1), T(0)} : twn[k];                  // W_N^k
-    // phase of the input rotation along x: conj(W_N^(k isx mod N))
-    cx<T> px = {T(1), T(0)};
-    if (2 * isx == N) {                          // half a length (ifftshift of an even axis): a sign
-        if (k & 1) px.x = T(-1);
-    } else if (isx) {
-        const cx<T> t = twn[(k * isx) % N];
-        px = {t.x, -t.y};
-    }
-    const bool half_y = 2 * isy == M;
-    int64_t qx = k + osx;
-    if (qx >= N) qx -= N;
-    int64_t qxm = (k == 0 || k == n2) ? -1 : N - k + osx;
-    if (qxm >= N) qxm -= N;
+    const UntangleOut<T, EPI> o{M, N, isy, isx, osy, osx, ldo, twn, twm, s, out};
+    const int64_t kb = k == 0 ? 0 : n2 - k;
+    const cx<T> w = twn[k];                                                 // W_N^k; W_N^kb = -conj(W_N^k)
     for (int64_t u = int64_t(blockIdx.y) * blockDim.y + threadIdx.y; u < M; u += int64_t(gridDim.y) * blockDim.y) {
         const int64_t um = u == 0 ? 0 : M - u;
-        const cx<T> a = zf[u * ldz + ka];
-        const cx<T> bz = zf[um * ldz + kb];
-        const cx<T> b = {bz.x, -bz.y};
-        const cx<T> xe = {T(0.5) * (a.x + b.x), T(0.5) * (a.y + b.y)};
-        const cx<T> d = {T(0.5) * (a.x - b.x), T(0.5) * (a.y - b.y)};
-        cx<T> f = xe + cmul(w, mul_mi(d));                                  // (A - B) / (2i) = -i (A - B) / 2
-        cx<T> ph = px;
-        if (half_y) {
-            if (u & 1) ph = {-px.x, -px.y};
-        } else if (isy) {
-            const cx<T> t = twm[(u * isy) % M];
-            ph = cmul(px, cx<T>{t.x, -t.y});
-        }
-        f = cscale(cmul(f, ph), s);
-        int64_t qy = u + osy;
-        if (qy >= M) qy -= M;
-        untangle_put<T, EPI>(out, ldo, qy, qx, f);
-        if (qxm >= 0) {
-            int64_t qym = um + osy;
-            if (qym >= M) qym -= M;
-            untangle_put<T, EPI>(out, ldo, qym, qxm, cx<T>{f.x, -f.y});
-        }
+        const cx<T> a = zf[u * ldz + k];
+        const cx<T> b = zf[um * ldz + kb];
+        const cx<T> ac = {a.x, -a.y}, bc = {b.x, -b.y};
+        o.emit(u, k, untangle_bin(a, bc, w));
+        if (k == 0) o.emit(u, n2, untangle_bin(a, bc, cx<T>{T(-1), T(0)}));           // the Nyquist column: W_N^(N/2) = -1
+        else if (kb != k) o.emit(um, kb, untangle_bin(b, ac, cx<T>{-w.x, w.y}));
     }
 }
 
@@ -552,7 +571,7 @@ static int r2c_untangle_launch(int64_t M, int64_t N, const void* zf, int64_t ldz
     dim3 block(64, 4);
     int64_t gy = (M + 3) / 4;
     if (gy > 16384) gy = 16384;
-    dim3 grid((unsigned)((N / 2 + 1 + 63) / 64), (unsigned)gy);
+    dim3 grid((unsigned)((N / 4 + 1 + 63) / 64), (unsigned)gy);
 #define PM_UNT(E)                                                                                                                      \
     hipLaunchKernelGGL((r2c_untangle_kernel<T, E>), grid, block, 0, st, M, N, (const cx<T>*)zf, ldz, twn, twm, isy, isx, osy, osx, norm_dc, \
                        T(scale), out, ldo)
