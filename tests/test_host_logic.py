@@ -312,3 +312,40 @@ def test_hermitian_path_predicate():
     assert not _hermitian_ok(big[:, 1:65])                                  # base address one float off a complex boundary
     assert _hermitian_ok(big[:, 2:66])
     assert not _hermitian_ok(torch.zeros(64, 131)[:, :64])                  # odd leading dimension
+
+
+def test_untangle_formula_of_the_real_input_route():
+    """The algebra pm_r2c_untangle implements (csrc/pointwise.hip), restated in numpy: the 2-D transform of a real M x N array from
+    the transform of its M x N/2 complex-pair view -- pairs of packed bins (u, k) <-> (-u, N/2 - k), the Nyquist column from k = 0,
+    the other half by conjugate symmetry, the input rotation as a phase -- against numpy's fft2, on even / odd heights and widths whose
+    halves are even and odd"""
+    rng = np.random.default_rng(3)
+    for M, N in ((8, 16), (7, 10), (5, 6), (1, 2), (12, 4), (9, 30)):
+        x = rng.random((M, N))
+        n2 = N // 2
+        zf = np.fft.fft2(x[:, 0::2] + 1j * x[:, 1::2])
+        F = np.zeros((M, N), dtype=np.complex128)
+        wN = np.exp(-2j * np.pi * np.arange(N) / N)
+        for u in range(M):
+            um = (M - u) % M
+            for k in range(n2 // 2 + 1):
+                kb = (n2 - k) % n2
+                a, b = zf[u, k], zf[um, kb]
+
+                def bin_(A, Bc, w):
+                    return (A + Bc) / 2 + w * (A - Bc) / 2j
+                f1 = bin_(a, np.conj(b), wN[k])
+                F[u, k] = f1
+                if k != 0:
+                    F[um, N - k] = np.conj(f1)
+                if k == 0:
+                    F[u, n2] = bin_(a, np.conj(b), -1.0)
+                elif kb != k:
+                    f2 = bin_(b, np.conj(a), -np.conj(wN[k]))
+                    F[um, kb] = f2
+                    F[u, N - kb] = np.conj(f2)
+        assert np.allclose(F, np.fft.fft2(x), atol=1e-12 * N * M)
+        # rotation of the input by (sy, sx) samples = the phase conj(W_M^(u sy) W_N^(k sx))
+        sy, sx = M // 2, 3 % N
+        ph = np.exp(2j * np.pi * (np.arange(M)[:, None] * sy / M + np.arange(N)[None, :] * sx / N))
+        assert np.allclose(F * ph, np.fft.fft2(np.roll(x, (-sy, -sx), axis=(0, 1))), atol=1e-12 * N * M)

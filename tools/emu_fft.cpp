@@ -19,7 +19,6 @@
 
 #include "fft_io.h"
 #include "bluestein.h"
-#include "fft_spectral2.h"
 
 using namespace pm;
 typedef long double ld;
@@ -750,140 +749,9 @@ static void test_blue2d_fused(int n1, int n2, int in_rows, int in_cols, int offy
     report(buf, err / nrm, sizeof(T) == 4 ? 4e-6 : 1e-13);
 }
 
-// --- grouped wavelengths on the four-waves-per-SIMD kernels (fft_spectral2.h): row kernel (pairs of wavelengths per thread, the fold
-// through LDS between the halves of the workgroup) + accumulating column kernel, thread by thread, against
-// sum_b w_b |fft2(amp exp(2 pi i k2_b opd))|^2 scale^2 with the focus rotations.  The parameter blocks are filled as capi.hip
-// fft2_spectral2_group fills them.
-template <int LOGN, int LOGM, bool FOLD>
-static void test_spectral2(int in_rows, int in_cols, bool shifts, int nb, int log_k) {
-    using T = float;
-    constexpr int N = 1 << LOGN, M = 1 << LOGM, H = M / 2, LT = FOLD ? LOGM - 1 : LOGM, L = 1 << LT;
-    using CR = FftCfg<T, LOGN, 1, 2, FOLD ? 2 : 1, 1>;
-    using CC = FftCfg<T, LT, 4, 2, 1, 1>;
-    constexpr int TC = 8;
-    const int rows = FOLD ? M : in_rows;
-    const int offy = FOLD ? 0 : (M - in_rows + 1) / 2, offx = (N - in_cols + 1) / 2;
-    const int shy = shifts ? M / 2 : 0, shx = shifts ? N / 2 : 0;
-    std::mt19937 rng(LOGN * 17 + LOGM + nb);
-    std::uniform_real_distribution<double> ud(0.0, 1.0);
-    std::normal_distribution<double> nd;
-    std::vector<cx<T>> map(size_t(rows) * in_cols);
-    for (auto& e : map) e = {T(ud(rng) > 0.2 ? ud(rng) : 0.0), T(30 * nd(rng))};
-    double k2[4], wt[4];
-    for (int b = 0; b < 4; ++b) { k2[b] = 0.0017 + 0.0003 * b; wt[b] = 0.5 + 0.25 * b; }
-    const T scale = T(1.0 / sqrt(double(M) * N));
-    auto twn = make_tw<T>(N);
-    auto twm = make_tw<T>(M);
-    auto twl = make_tw<T>(L);
-    const int tl = TC << log_k;
-    int ltl = 0;
-    while ((1 << ltl) < tl) ++ltl;
-    const int64_t ntl = (N + tl - 1) / tl;
-    const int64_t field = ntl * int64_t(FOLD ? M : rows) * tl;
-    std::vector<cx<T>> W(size_t(field) * nb, cx<T>{T(-9), T(-9)});
-    std::vector<T> img(size_t(M) * N), img0;
-    for (auto& e : img) e = T(ud(rng));
-    img0 = img;
-    Sp2Row<T> gr{};
-    gr.src = map.data(); gr.ld = in_cols; gr.off = offx; gr.len = in_cols; gr.rot = shx ? 8 : 0; gr.nrows = rows; gr.nt = 0;
-    gr.dst = W.data(); gr.fstride = field; gr.plane_stride = FOLD ? ntl * H * tl : 0; gr.drows = FOLD ? H : rows; gr.log_tl = ltl;
-    gr.swap = (FOLD && shy) ? 1 : 0; gr.twm = twm.data();
-    {   // row kernel
-        std::vector<Regs<CR>> regs(CR::NT);
-        std::vector<cx<T>> lds(CR::LDS_ELEMS + 1);
-        const int grid = FOLD ? H : (rows + CR::BO - 1) / CR::BO;
-        for (int blk = 0; blk < grid; ++blk)
-            for (int b = 0; b < nb; b += 2) {
-                const bool two = b + 1 < nb;
-                for (int tid = 0; tid < CR::NT; ++tid) {
-                    const int t = tid % CR::TPS, bo = tid / CR::TPS;
-                    const int memrow = FOLD ? blk + bo * H : blk * CR::BO + bo;
-                    cx<T> raw[CR::P];
-                    sp2_row_load_sel<CR>(gr, memrow, memrow < rows, t, raw);
-                    sp2_synth<CR>(raw, k2[b], k2[two ? b + 1 : b], regs[tid].v);
-                }
-                if (FOLD)
-                    for (int e = 0; e < 2; ++e) {
-                        for (int tid = 0; tid < CR::NT; ++tid) sp2_fold_write<CR>(regs[tid].v[e], tid % CR::TPS, tid / CR::TPS, lds.data());
-                        for (int tid = 0; tid < CR::NT; ++tid)
-                            sp2_fold_combine<CR>(regs[tid].v[e], tid % CR::TPS, tid / CR::TPS, lds.data(), twm[blk], gr.swap);
-                    }
-                emu_stages<CR, 0>(regs, lds, twn.data());
-                for (int tid = 0; tid < CR::NT; ++tid) {
-                    const int t = tid % CR::TPS, bo = tid / CR::TPS;
-                    const int memrow = FOLD ? blk + bo * H : blk * CR::BO + bo;
-                    if (memrow >= rows) continue;
-                    const int unit = FOLD ? blk : memrow;
-                    sp2_row_store<CR>(gr, unit, FOLD ? bo : 0, b, t, regs[tid].v[0]);
-                    if (two) sp2_row_store<CR>(gr, unit, FOLD ? bo : 0, b + 1, t, regs[tid].v[1]);
-                }
-            }
-    }
-    Sp2Col<T> gc{};
-    gc.src = W.data(); gc.fstride = field; gc.plane_stride = gr.plane_stride; gc.log_k = log_k; gc.dst = img.data();
-    gc.qshift = shx; gc.ncols = N; gc.s2 = scale * scale;
-    if (FOLD) { gc.nrows = H; gc.off = 0; gc.len = H; gc.rot = 0; gc.ld = 2 * N; gc.out_plane = N; gc.orot = shy ? 8 : 0; }
-    else { gc.nrows = rows; gc.off = offy; gc.len = rows; gc.rot = shy ? 8 : 0; gc.ld = N; gc.out_plane = 0; gc.orot = shy ? 8 : 0; }
-    {   // column kernel
-        std::vector<Regs<CC>> regs(CC::NT);
-        std::vector<cx<T>> lds(CC::LDS_ELEMS + 1);
-        std::vector<T> acc(size_t(CC::NT) * 32);
-        for (int plane = 0; plane < (FOLD ? 2 : 1); ++plane)
-            for (int tile = 0; tile < N / TC; ++tile) {
-                std::fill(acc.begin(), acc.end(), T(0));
-                for (int b = 0; b < nb; ++b) {
-                    const cx<T>* src = gc.src + plane * gc.plane_stride + b * gc.fstride;
-                    for (int tid = 0; tid < CC::NT; ++tid) {
-                        const ThreadPos pos = thread_pos<CC>(tid);
-                        const Sp2Addr<CC> A(pos, gc.log_k);
-                        if (gc.rot) sp2_col_load<CC, 8>(gc, src, tile, A, regs[tid].v);
-                        else sp2_col_load<CC, 0>(gc, src, tile, A, regs[tid].v);
-                    }
-                    emu_stages<CC, 0>(regs, lds, twl.data());
-                    for (int tid = 0; tid < CC::NT; ++tid) {
-                        T(&a)[2][16] = *reinterpret_cast<T(*)[2][16]>(&acc[size_t(tid) * 32]);
-                        sp2_accumulate<CC>(a, regs[tid].v, T(wt[b]), gc.s2);
-                    }
-                }
-                for (int tid = 0; tid < CC::NT; ++tid) {
-                    const ThreadPos pos = thread_pos<CC>(tid);
-                    T(&a)[2][16] = *reinterpret_cast<T(*)[2][16]>(&acc[size_t(tid) * 32]);
-                    if (gc.orot) sp2_col_store<CC, 8>(gc, gc.dst + plane * gc.out_plane, tile, pos, a);
-                    else sp2_col_store<CC, 0>(gc, gc.dst + plane * gc.out_plane, tile, pos, a);
-                }
-            }
-    }
-    // reference
-    std::vector<ld> ref(size_t(M) * N, 0);
-    const ld pi = acosl(-1.0L);
-    for (int b = 0; b < nb; ++b) {
-        std::vector<cx<double>> pup(map.size());
-        for (size_t i = 0; i < map.size(); ++i) {
-            const ld ang = 2 * pi * ld(double(map[i].y) * k2[b]);
-            pup[i] = {double(map[i].x * cosl(ang)), double(map[i].x * sinl(ang))};
-        }
-        auto B = naive_2d<double>(pup, rows, in_cols, M, N, offy, offx, shy, shx, false);
-        for (int k = 0; k < M; ++k)
-            for (int c = 0; c < N; ++c) ref[size_t((k + shy) % M) * N + (c + shx) % N] += ld(wt[b]) * std::norm(B[size_t(k) * N + c]);
-    }
-    double err = 0, nrm = 0;
-    for (size_t i = 0; i < ref.size(); ++i) {
-        err = fmax(err, fabs(double(img[i]) - double(img0[i]) - double(ref[i])));
-        nrm = fmax(nrm, double(ref[i]));
-    }
-    char buf[160];
-    snprintf(buf, sizeof buf, "spectral2 %dx%d%s in %dx%d %s nb=%d log_k=%d", M, N, FOLD ? " fold" : "", rows, in_cols, shifts ? "shifted" : "plain", nb,
-             log_k);
-    report(buf, err / nrm, 3e-6);
-}
+// (the emulation of the grouped-wavelength kernels of round 4 went with fft_spectral2.h: experiments/README.md)
 
 int main() {
-    test_spectral2<6, 6, false>(64, 64, true, 2, 0);
-    test_spectral2<6, 7, true>(128, 64, true, 4, 1);
-    test_spectral2<7, 6, false>(32, 64, true, 3, 2);      // Q = 2 pad, odd group
-    test_spectral2<6, 6, true>(64, 40, false, 1, 0);
-    test_spectral2<8, 6, false>(64, 256, true, 4, 3);      // TPS (16) wider than ... and narrower than the layout tile (64)
-    test_spectral2<8, 6, false>(64, 256, false, 2, 0);     // TPS (16) wider than the layout tile (8)
     test_blue2d_fused<float, 6, 7, 32, 1, 4, 2, 16, 1>(20, 50, 20, 50, 0, 0, 10, 25, false, false, 20, 50, 0, 0, 10, 25, 0, 1);      // focus-like: both rotations
     test_blue2d_fused<float, 7, 6, 64, 2, 4, 2, 8, 1>(50, 24, 25, 12, 13, 6, 25, 12, false, true, 30, 20, 10, 2, 25, 12, 0, 0);     // Q = 2 pad, inverse, crop, 2 rows / thread
     test_blue2d_fused<float, 6, 6, 64, 1, 4, 2, 16, 1>(30, 30, 30, 30, 0, 0, 0, 0, true, false, 30, 30, 0, 0, 15, 15, 1, 1);          // real input, |.|^2

@@ -288,6 +288,46 @@ def fuzz_spectral(ncases, rng, lib):
     return nfail
 
 
+def fuzz_real_any(ncases, rng, lib):
+    """_ops.fft2_real (round 5): a real array of any height and EVEN width read as complex pairs, a half-size pm_fft2 on whatever route
+    its lengths take, pm_r2c_untangle with arbitrary input / output rotations, the DC normalisation and the four epilogues."""
+    heights = [1, 2, 3, 8, 30, 64, 100, 127, 250, 323, 512, 1000, 1001, 1536, 2048]
+    widths = [2, 4, 6, 30, 64, 100, 126, 250, 360, 512, 1000, 1020, 1538, 1994, 2048, 4096]
+    nfail, worst = 0, 0.0
+    for case in range(ncases):
+        M, N = int(rng.choice(heights)), int(rng.choice(widths))
+        rdt = np.float32 if rng.random() < 0.5 else np.float64
+        x = (rng.random((M, N)) + 0.1).astype(rdt)
+        sh = lambda n: int(rng.choice([0, n // 2, int(rng.integers(0, n))]))
+        ins, outs = (sh(M), sh(N)), (sh(M), sh(N))
+        epi = int(rng.choice([L.PM_EPI_NONE, L.PM_EPI_NONE, L.PM_EPI_ABS, L.PM_EPI_ABS2, L.PM_EPI_ARG]))
+        norm = bool(rng.random() < 0.5)
+        scale = float(rng.choice([1.0, 0.5, 1.0 / np.sqrt(M * N)]))
+        xt = torch.from_numpy(x).cuda()
+        if rng.random() < 0.3:          # a view with a row pitch wider than the row
+            wide = torch.zeros((M, N + 4), dtype=xt.dtype, device='cuda')
+            wide[:, 2:N + 2] = xt
+            xt = wide[:, 2:N + 2]
+        got = _ops.fft2_real(xt, scale=scale, in_shift=ins, out_shift=outs, epilogue=epi, norm_dc=norm).cpu().numpy()
+        F = np.fft.fft2(np.roll(x.astype(np.float64), (-ins[0], -ins[1]), axis=(0, 1)))
+        if norm:
+            F = F / F[0, 0]
+        F = np.roll(F * scale, outs, axis=(0, 1))
+        tol = 1e-10 if rdt == np.float64 else 3e-5
+        if epi == L.PM_EPI_ARG:
+            strong = np.abs(F) > 1e-3 * np.abs(F).max()
+            err = np.max(np.abs(np.angle(np.exp(1j * (got - np.angle(F))))[strong])) / (1e-7 if rdt == np.float64 else 3e-3)
+        else:
+            ref = {L.PM_EPI_NONE: F, L.PM_EPI_ABS: np.abs(F), L.PM_EPI_ABS2: np.abs(F) ** 2}[epi]
+            err = np.max(np.abs(got - ref)) / (np.max(np.abs(ref)) * tol * (2 if epi == L.PM_EPI_ABS2 else 1))
+        worst = max(worst, err)
+        if err > 1:
+            nfail += 1
+            print('FAIL real_any', M, N, rdt.__name__, ins, outs, epi, norm, scale, err)
+    print(f'fuzz_real_any: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
+    return nfail
+
+
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -383,6 +423,7 @@ def main():
     nfail += fuzz_fft1(max(30, ncases // 2), rng, lib)
     nfail += fuzz_real_conv(max(20, ncases // 3), rng, lib)
     nfail += fuzz_spectral(max(12, ncases // 4), rng, lib)
+    nfail += fuzz_real_any(max(30, ncases // 3), rng, lib)
     return 1 if nfail else 0
 
 if __name__ == '__main__':

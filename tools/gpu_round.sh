@@ -6,6 +6,9 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
 ( timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 ) > $O/pytest_gpu.log 2>&1
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
+( timeout 600 python tools/fuzz_fft2.py ${FUZZ_CASES:-400} ${FUZZ_SEED:-707} 2>&1 | tail -5 ) > $O/fuzz.log 2>&1
+# the driver's form of the bench (20 steps) next to the default one
+( timeout 600 python bench.py --steps 20 --warmup 5 --no-poly --no-cpu-baseline ) > $O/bench_steps20.log 2>&1
 prof() {   # name, bench arguments...
   n=$1; shift
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$n -- python $R/bench.py "$@" ) > $O/rocprof_$n.log 2>&1
