@@ -1,0 +1,294 @@
+// Composite lengths on the register engine: 1000, 1500, 2000, 3000 ... -- the decimal grids and Q = 1.5 pads of the reference's users
+// (prysm/propagation/fft.py:7-25 through prysm/fttools.py:23-31) -- as the power-of-two engine runs them (fft_engine.h): the sequence
+// lives in the REGISTERS of its threads from the global load to the global store, the LDS is only the exchange fabric between stages,
+// and every index is a compile-time constant of the plan.  The general kernel (fft_mixed.h) keeps the sequence in LDS, reads its plan at
+// run time and pays ~20 integer instructions per point and stage for it (an all-off ablation of its 3000-point kernels ran 17 us of the
+// 62; profiles/r04/exp_mix_ablate.log); it stays the route of every length that has no plan here.
+//
+// Plan: N = R0 R1 .. R_{S-1}, every later factor a divisor of the first one, P = R0 points per thread, TS = N / P threads per sequence.
+// Decimation in frequency.  Thread t loads v[m] = x[t + TS m].  Before stage s the thread holds P / R_s butterflies u of R_s points m:
+//
+//     v[m Q_s + u] = A_{s-1}[c = g + G_s u][i' + M_s m],      i' = t mod M_s,  g = t div M_s,  Q_s = P / R_s,  G_s = TS / M_s
+//
+// with M_s = N / (R0 .. R_s) the length that is left after stage s and A_{s-1}[c][.] the M_{s-1}-point sub-problem of the output bins
+// congruent to c.  The stage is a twiddle-free DFT over m, then the twiddle W_{M_{s-1}}^{i' k}; register k Q_s + u then holds
+// A_s[c + C_s k][i'] (C_s = R0 .. R_{s-1}).  Because C_s = G_s Q_s, the REGISTER INDEX r = k Q_s + u is exactly the part of the new
+// bin prefix the thread index does not carry, so the exchange is
+//
+//     write:  lds[r SB + T] = v[r]                                   (T: the thread's index in the workgroup -- consecutive lanes)
+//     read :  v[m Q + u]   = lds[(r1 + R u) SB + pos(gw M_{s-1} + i'' + M_s m)]     g' = t div M_s = gw + G_{s-1} r1
+//
+// and after the last stage v[r] = X[t + TS r]: natural order in the layout of the input, stores as coalesced as the loads.
+// SB (slots between the rows of the exchange) is chosen per exchange so that the reads spread over the banks (tools/ce_banks.py).
+//
+// Small DFTs: 2, 4, 8, 16 from the engine, 3 and 5 by the symmetric half sums (fft_mixed.h), and the composite factors 6 .. 30 by the
+// prime-factor map (Good-Thomas: their factors are coprime, so there are NO inner twiddles, only a renaming of registers).
+//
+// Everything here is __host__ __device__: tools/emu_ce.cpp runs the same functions on the CPU, thread by thread and phase by phase.
+#pragma once
+#include "fft_mixed.h"
+
+namespace pm {
+
+template <int R0_, int R1_, int R2_ = 1, int R3_ = 1>
+struct CePlan {
+    static constexpr int S = R3_ > 1 ? 4 : (R2_ > 1 ? 3 : 2);
+    static constexpr int P = R0_, N = R0_ * R1_ * R2_ * R3_, TS = N / R0_;
+    static constexpr int radix(int s) { return s == 0 ? R0_ : (s == 1 ? R1_ : (s == 2 ? R2_ : R3_)); }
+    static constexpr int m(int s) {      // points left after stage s
+        int v = N;
+        for (int i = 0; i <= s; ++i) v /= radix(i);
+        return v;
+    }
+    static constexpr int g(int s) { return TS / m(s); }
+    static constexpr int q(int s) { return P / radix(s); }
+    static constexpr int tw_step(int s) { return s == 0 ? 1 : N / m(s - 1); }     // W_{M_{s-1}} = W_N^step
+    static_assert(R0_ % R1_ == 0 && R0_ % R2_ == 0 && R0_ % R3_ == 0, "later factors divide the first one");
+    static_assert(R1_ > 1 && (R3_ == 1 || R2_ > 1), "factors in order");
+};
+
+// ---------------------------------------------------------------------------
+// small DFTs
+// ---------------------------------------------------------------------------
+template <typename T, int R>
+struct CeDft {
+    static PM_HD void run(cx<T>* a) { MixDft<T, R>::run(a); }      // 2 4 8 16 (engine), 3 5 7 (half sums)
+};
+constexpr int ce_inv_mod(int a, int m) {
+    for (int x = 1; x < m; ++x)
+        if ((a * x) % m == 1) return x;
+    return 1;
+}
+// R = R1 R2 coprime: n = (R2 n1 + R1 n2) mod R, k = (E1 k1 + E2 k2) mod R with E1 = 1 (mod R1), 0 (mod R2) -- W_R^{nk} = W_R1^{n1 k1} W_R2^{n2 k2}
+template <typename T, int R1, int R2>
+PM_HD void ce_dft_pfa(cx<T>* a) {
+    constexpr int R = R1 * R2;
+    constexpr int E1 = R2 * ce_inv_mod(R2 % R1, R1), E2 = R1 * ce_inv_mod(R1 % R2, R2);
+    cx<T> t[R1 > R2 ? R1 : R2];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) {
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) t[n1] = a[(R2 * n1 + R1 * n2) % R];
+        CeDft<T, R1>::run(t);
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) a[(R2 * k1 + R1 * n2) % R] = t[k1];
+    }
+    cx<T> o[R];
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) t[n2] = a[(R2 * k1 + R1 * n2) % R];
+        CeDft<T, R2>::run(t);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) o[(E1 * k1 + E2 * k2) % R] = t[k2];
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) a[k] = o[k];
+}
+template <typename T> struct CeDft<T, 6> { static PM_HD void run(cx<T>* a) { ce_dft_pfa<T, 2, 3>(a); } };
+template <typename T> struct CeDft<T, 10> { static PM_HD void run(cx<T>* a) { ce_dft_pfa<T, 2, 5>(a); } };
+template <typename T> struct CeDft<T, 12> { static PM_HD void run(cx<T>* a) { ce_dft_pfa<T, 4, 3>(a); } };
+template <typename T> struct CeDft<T, 15> { static PM_HD void run(cx<T>* a) { ce_dft_pfa<T, 3, 5>(a); } };
+template <typename T> struct CeDft<T, 20> { static PM_HD void run(cx<T>* a) { ce_dft_pfa<T, 4, 5>(a); } };
+template <typename T> struct CeDft<T, 24> { static PM_HD void run(cx<T>* a) { ce_dft_pfa<T, 8, 3>(a); } };
+template <typename T> struct CeDft<T, 30> { static PM_HD void run(cx<T>* a) { ce_dft_pfa<T, 5, 6>(a); } };
+
+// The twiddles w^k, k < R <= 32, of a thread's butterflies in one stage: w, w^4 and w^16 from the table, the others as at most three
+// products (fft_mixed.h MixTw, extended to 32)
+template <typename T, int R>
+struct CeTw {
+    cx<T> lo[4], hi[8];
+    PM_HD CeTw(const cx<T>* __restrict__ tw, uint32_t idx) {
+        lo[0] = hi[0] = cx<T>{T(1), T(0)};
+        lo[1] = mix_ld(tw + idx);
+        hi[1] = R > 4 ? mix_ld(tw + 4u * idx) : lo[1];
+        hi[4] = R > 16 ? mix_ld(tw + 16u * idx) : lo[1];
+        if (R > 2) lo[2] = cmul(lo[1], lo[1]);
+        if (R > 3) lo[3] = cmul(lo[2], lo[1]);
+        if (R > 8) hi[2] = cmul(hi[1], hi[1]);
+        if (R > 12) hi[3] = cmul(hi[2], hi[1]);
+        if (R > 20) hi[5] = cmul(hi[4], hi[1]);
+        if (R > 24) hi[6] = cmul(hi[4], hi[2]);
+        if (R > 28) hi[7] = cmul(hi[4], hi[3]);
+    }
+    PM_HD cx<T> operator()(int k) const {     // k is a constant after unrolling
+        if (k < 4) return lo[k];
+        if ((k & 3) == 0) return hi[k >> 2];
+        return cmul(hi[k >> 2], lo[k & 3]);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// shape of a workgroup: SEQS sequences, rows ([sequence][point]: lanes run along one sequence) or columns (lanes across the SEQS
+// adjacent columns first); COMP 1: complex exchange, 2: real parts then imaginary parts through half the LDS.  PAD_s: slots added to the
+// row stride of the exchange INTO stage s.
+// ---------------------------------------------------------------------------
+template <typename T_, typename PL_, int SEQS_, bool COL_, int COMP_, int PAD1_ = 0, int PAD2_ = 0, int PAD3_ = 0>
+struct CeCfg {
+    using T = T_;
+    using PL = PL_;
+    static constexpr int SEQS = SEQS_, COMP = COMP_, NT = SEQS_ * PL_::TS, P = PL_::P;
+    static constexpr bool COL = COL_;
+    static constexpr int sb(int s) { return NT + (s == 1 ? PAD1_ : (s == 2 ? PAD2_ : PAD3_)); }
+    static constexpr int lds_elems() {
+        int v = 0;
+        for (int s = 1; s < PL_::S; ++s) v = sb(s) > v ? sb(s) : v;
+        return v * P;
+    }
+    static constexpr size_t LDS_BYTES = size_t(lds_elems()) * sizeof(T_) * (COMP_ == 1 ? 2 : 1);
+};
+template <typename C> struct CeLds { using type = cx<typename C::T>; };
+template <typename T, typename PL, int SEQS, bool COL, int P1, int P2, int P3>
+struct CeLds<CeCfg<T, PL, SEQS, COL, 2, P1, P2, P3>> { using type = T; };
+
+struct CePos {
+    int tid, t, sl;     // thread of the workgroup, thread of its sequence, sequence slot
+};
+template <typename C>
+PM_HD CePos ce_pos(int tid) {
+    return C::COL ? CePos{tid, tid / C::SEQS, tid % C::SEQS} : CePos{tid, tid % C::PL::TS, tid / C::PL::TS};
+}
+
+// stage s on the registers of a thread
+template <typename C, int s>
+PM_HD void ce_stage(cx<typename C::T> (&v)[C::P], int t, const cx<typename C::T>* __restrict__ tw) {
+    using T = typename C::T;
+    using PL = typename C::PL;
+    constexpr int R = PL::radix(s), Q = PL::q(s);
+    constexpr bool last = s + 1 == PL::S;
+    if constexpr (last) {
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+            cx<T> a[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) a[k] = v[k * Q + u];
+            CeDft<T, R>::run(a);
+#pragma unroll
+            for (int k = 0; k < R; ++k) v[k * Q + u] = a[k];
+        }
+    } else {
+        const CeTw<T, R> w(tw, uint32_t(t % PL::m(s)) * uint32_t(PL::tw_step(s)));
+#pragma unroll
+        for (int u = 0; u < Q; ++u) {
+            cx<T> a[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) a[k] = v[k * Q + u];
+            CeDft<T, R>::run(a);
+            v[u] = a[0];
+#pragma unroll
+            for (int k = 1; k < R; ++k) v[k * Q + u] = cmul(a[k], w(k));
+        }
+    }
+}
+
+// exchange into stage s (1 <= s < S): every register to row r of the fabric at the thread's own slot ...
+template <typename C, int s, typename LT>
+PM_HD void ce_exch_write(const cx<typename C::T> (&v)[C::P], int comp, CePos pos, LT* lds) {
+#pragma unroll
+    for (int r = 0; r < C::P; ++r) {
+        const int a = r * C::sb(s) + pos.tid;
+        if constexpr (C::COMP == 1)
+            lds[a] = v[r];
+        else
+            lds[a] = comp == 0 ? v[r].x : v[r].y;
+    }
+}
+// ... and the butterflies of stage s gathered from it
+template <typename C, int s, typename LT>
+PM_HD void ce_exch_read(cx<typename C::T> (&v)[C::P], int comp, CePos pos, const LT* lds) {
+    using PL = typename C::PL;
+    constexpr int R = PL::radix(s), Q = PL::q(s), M = PL::m(s), MP = PL::m(s - 1), GP = PL::g(s - 1);
+    const int g = pos.t / M, i2 = pos.t % M, gw = g % GP, r1 = g / GP;
+    const int tw0 = gw * MP + i2;
+    const int base = r1 * C::sb(s) + (C::COL ? tw0 * C::SEQS + pos.sl : pos.sl * PL::TS + tw0);
+#pragma unroll
+    for (int u = 0; u < Q; ++u) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) {
+            const int a = base + R * u * C::sb(s) + M * m * (C::COL ? C::SEQS : 1);
+            if constexpr (C::COMP == 1) {
+                v[m * Q + u] = lds[a];
+            } else {
+                if (comp == 0)
+                    v[m * Q + u].x = lds[a];
+                else
+                    v[m * Q + u].y = lds[a];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// global side.  Rows: sequence `row` at src + row pitch, element q at [q].  Columns: column c at src + c, element q at [q pitch].
+// The view of the transform axis (window / rotation) is the library's AxisMap; WIN = false: the view keeps every element.
+// ---------------------------------------------------------------------------
+template <typename T>
+struct CeIn {
+    const cx<T>* src;
+    int64_t pitch;
+    AxisMap ax;
+    int nseq;
+    T ysign;        // -1: conjugated input
+};
+template <typename T>
+struct CeRowOut {
+    cx<T>* dst;
+    int64_t ld;
+};
+// the ColStoreNat view of the plain 2-D transform: every bin kept, rotations on both axes, scale, conjugation
+template <typename T>
+struct CeColOut {
+    cx<T>* dst;
+    int64_t ld;
+    int ny, sy, nx, sx;
+    T sr, si;
+};
+
+// v[m] = x[t + TS m] of sequence `seq` (clamped by the caller to one that exists)
+template <typename C, bool WIN>
+PM_HD void ce_load(cx<typename C::T> (&v)[C::P], const CeIn<typename C::T>& in, int seq, int t) {
+    using T = typename C::T;
+    using PL = typename C::PL;
+    const cx<T>* base = C::COL ? in.src + seq : in.src + int64_t(seq) * in.pitch;
+    int q0 = t + in.ax.shift;
+    q0 = q0 >= PL::N ? q0 - PL::N : q0;
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        int p = q0 + PL::TS * m;
+        p = p >= PL::N ? p - PL::N : p;
+        if (WIN) {
+            const int q = p - in.ax.off;
+            const bool ok = unsigned(q) < unsigned(in.ax.len);
+            const int64_t o = ok ? (C::COL ? int64_t(q) * in.pitch : int64_t(q)) : 0;
+            const cx<T> x = mix_ld(base + o);
+            v[m] = ok ? x : cx<T>{T(0), T(0)};
+        } else {
+            v[m] = mix_ld(base + (C::COL ? int64_t(p) * in.pitch : int64_t(p)));
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) v[m].y *= in.ysign;
+}
+template <typename C>
+PM_HD void ce_store_row(const cx<typename C::T> (&v)[C::P], const CeRowOut<typename C::T>& out, int row, int t) {
+    cx<typename C::T>* d = out.dst + int64_t(row) * out.ld + t;
+#pragma unroll
+    for (int r = 0; r < C::P; ++r) mix_st(d + C::PL::TS * r, v[r]);
+}
+template <typename C>
+PM_HD void ce_store_col(const cx<typename C::T> (&v)[C::P], const CeColOut<typename C::T>& out, int col, int t) {
+    using T = typename C::T;
+    int qx = col + out.sx;
+    qx = qx >= out.nx ? qx - out.nx : qx;
+    int k0 = t + out.sy;
+    k0 = k0 >= out.ny ? k0 - out.ny : k0;
+    cx<T>* d = out.dst + qx;
+#pragma unroll
+    for (int r = 0; r < C::P; ++r) {
+        int k = k0 + C::PL::TS * r;
+        k = k >= out.ny ? k - out.ny : k;
+        mix_st(d + int64_t(k) * out.ld, cx<T>{v[r].x * out.sr, v[r].y * out.si});
+    }
+}
+
+}  // namespace pm
