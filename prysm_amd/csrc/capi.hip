@@ -171,6 +171,10 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("fft_stagger_col")) t.fft_stagger_col = v < 0 ? -1 : (v > 164 ? 164 : v);
     else if (is("mix_fold")) t.mix_fold = v != 0;
     else if (is("mix_pers")) t.mix_pers = v != 0;
+    else if (is("mix_engine")) t.mix_engine = v ? 1 : 0;
+    else if (is("ce_rows_seqs")) t.ce_rows_seqs = v < 0 ? 0 : v;
+    else if (is("ce_cols_seqs")) t.ce_cols_seqs = v < 0 ? 0 : v;
+    else if (is("ce_log_g")) t.ce_log_g = v;
     else if (is("mix_stagger")) t.mix_stagger = v < 0 ? 0 : (v > 64 ? 64 : v);
     else if (is("engine_p8")) t.engine_p8 = v & 7;
     else if (is("mix_maxr")) t.mix_maxr = (v < 2 || v > 20) ? 20 : v;
@@ -1701,10 +1705,17 @@ int pm_plan_explain(const pm_fft2_desc* d, int32_t op, char* buf, size_t n) {
                  p.fold ? "-fold" : "", N / 2, p.fold ? M / 2 : M, p.fold ? "x2" : "", p.tc, p.log_k, p.ws_bytes);
     } else {
         const bool en = p.logn >= 0, em = p.logm >= 0;
+        // a composite axis whose length has a compile-time plan runs on the register engine (fft_ce.h) when the view is plain
+        const bool f32 = d->dtype == PM_C64;
+        const bool ce_n = p.mix_n && !p.mix_fold && tuning().mix_engine && !(d->flags & (PM_FLAG_REAL_INPUT | PM_FLAG_SYNTH_INPUT)) &&
+                          (f32 ? ce_has_plan<float>(int(N)) : ce_has_plan<double>(int(N)));
+        const bool whole_out = d->out_y.off == 0 && d->out_y.len == M && d->out_x.off == 0 && d->out_x.len == N;
+        const bool ce_m = p.mix_m && !p.mix_fold && tuning().mix_engine && whole_out && !d->mul && d->epilogue <= PM_EPI_ABS2_ACCUM &&
+                          (f32 ? ce_has_plan<float>(int(M)) : ce_has_plan<double>(int(M)));
         snprintf(buf, n, "fft2 %lldx%lld %s: route=%s rows=%s(%lld) cols=%s(%lld%s) tile=%d log_k=%d chunk=%lld ws=%zu", M, N, dt,
                  (en && em) ? (p.fold ? "engine-fold" : "engine") : ((p.mix_n || !p.blue_n) && (p.mix_m || !p.blue_m) && (p.mix_n || p.mix_m) ? "natural-mixed" : "natural"),
-                 axis_route(en, p.mix_n, p.blue_n), N, axis_route(em, p.mix_m, p.blue_m), p.fold ? M / 2 : M, p.fold ? "x2" : "", p.tc, p.log_k,
-                 (long long)p.chunk, p.ws_bytes);
+                 ce_n ? "mixed-radix-registers" : axis_route(en, p.mix_n, p.blue_n), N, ce_m ? "mixed-radix-registers" : axis_route(em, p.mix_m, p.blue_m),
+                 p.fold ? M / 2 : M, p.fold ? "x2" : "", p.tc, p.log_k, (long long)p.chunk, p.ws_bytes);
     }
     return 0;
 }

@@ -52,8 +52,52 @@ struct CePlan {
 // ---------------------------------------------------------------------------
 template <typename T, int R>
 struct CeDft {
-    static PM_HD void run(cx<T>* a) { MixDft<T, R>::run(a); }      // 2 4 8 16 (engine), 3 5 7 (half sums)
+    static PM_HD void run(cx<T>* a) { MixDft<T, R>::run(a); }      // 2 4 8 16 (engine)
 };
+// acc + a s, a -+ i b on whole complex values: one packed instruction each in the translation units built with PM_PACKED_F32
+template <typename T> PM_HD cx<T> ce_fma(cx<T> a, T s, cx<T> acc) { return {acc.x + a.x * s, acc.y + a.y * s}; }
+template <typename T> PM_HD cx<T> ce_add_mi(cx<T> a, cx<T> b) { return {a.x + b.y, a.y - b.x}; }
+template <typename T> PM_HD cx<T> ce_sub_mi(cx<T> a, cx<T> b) { return {a.x - b.y, a.y + b.x}; }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PM_PACKED_F32)
+__device__ __forceinline__ cx<float> ce_fma(cx<float> a, float s, cx<float> acc) {
+    pm_v2f r, k;      // s is a compile-time constant: the pair sits in scalar registers
+    k[0] = s;
+    k[1] = s;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(pm_pk(a)), "s"(k), "v"(pm_pk(acc)));
+    return pm_un(r);
+}
+__device__ __forceinline__ cx<float> ce_add_mi(cx<float> a, cx<float> b) { return add_mi(a, b); }
+__device__ __forceinline__ cx<float> ce_sub_mi(cx<float> a, cx<float> b) { return sub_mi(a, b); }
+#endif
+// odd primes by the symmetric half sums (fft_mixed.h mix_dft_odd) written on complex values
+template <typename T, int R>
+PM_HD void ce_dft_odd(cx<T>* a) {
+    constexpr int H = (R - 1) / 2;
+    cx<T> p[H + 1], q[H + 1];
+    cx<T> sum = a[0];
+#pragma unroll
+    for (int m = 1; m <= H; ++m) {
+        p[m] = a[m] + a[R - m];
+        q[m] = a[m] - a[R - m];
+        sum = sum + p[m];
+    }
+    const cx<T> x0 = a[0];
+    a[0] = sum;
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
+        cx<T> A = x0, B = cscale(q[1], T(MixRoots<R>::tab.s[k % R]));
+#pragma unroll
+        for (int m = 1; m <= H; ++m) {
+            A = ce_fma(p[m], T(MixRoots<R>::tab.c[(m * k) % R]), A);
+            if (m > 1) B = ce_fma(q[m], T(MixRoots<R>::tab.s[(m * k) % R]), B);
+        }
+        a[k] = ce_add_mi(A, B);
+        a[R - k] = ce_sub_mi(A, B);
+    }
+}
+template <typename T> struct CeDft<T, 3> { static PM_HD void run(cx<T>* a) { ce_dft_odd<T, 3>(a); } };
+template <typename T> struct CeDft<T, 5> { static PM_HD void run(cx<T>* a) { ce_dft_odd<T, 5>(a); } };
+template <typename T> struct CeDft<T, 7> { static PM_HD void run(cx<T>* a) { ce_dft_odd<T, 7>(a); } };
 constexpr int ce_inv_mod(int a, int m) {
     for (int x = 1; x < m; ++x)
         if ((a * x) % m == 1) return x;
@@ -123,8 +167,10 @@ struct CeTw {
 // adjacent columns first); COMP 1: complex exchange, 2: real parts then imaginary parts through half the LDS.  PAD_s: slots added to the
 // row stride of the exchange INTO stage s.
 // ---------------------------------------------------------------------------
-template <typename T_, typename PL_, int SEQS_, bool COL_, int COMP_, int PAD1_ = 0, int PAD2_ = 0, int PAD3_ = 0>
+template <typename T_, typename PL_, int SEQS_, bool COL_, int COMP_, int PAD1_ = 0, int PAD2_ = 0, int PAD3_ = 0, int WPE_ = 0, int ABL_ = 0>
 struct CeCfg {
+    static constexpr int ABL = ABL_;     // timing studies only (results wrong): 1 no global loads, 2 no stores, 4 no butterflies, 8 no exchanges
+    static constexpr int WPE = WPE_;     // waves per SIMD the kernels are compiled for (0: fft_ce_kernels.h ce_waves_per_eu)
     using T = T_;
     using PL = PL_;
     static constexpr int SEQS = SEQS_, COMP = COMP_, NT = SEQS_ * PL_::TS, P = PL_::P;
@@ -138,8 +184,8 @@ struct CeCfg {
     static constexpr size_t LDS_BYTES = size_t(lds_elems()) * sizeof(T_) * (COMP_ == 1 ? 2 : 1);
 };
 template <typename C> struct CeLds { using type = cx<typename C::T>; };
-template <typename T, typename PL, int SEQS, bool COL, int P1, int P2, int P3>
-struct CeLds<CeCfg<T, PL, SEQS, COL, 2, P1, P2, P3>> { using type = T; };
+template <typename T, typename PL, int SEQS, bool COL, int P1, int P2, int P3, int W, int A>
+struct CeLds<CeCfg<T, PL, SEQS, COL, 2, P1, P2, P3, W, A>> { using type = T; };
 
 struct CePos {
     int tid, t, sl;     // thread of the workgroup, thread of its sequence, sequence slot
@@ -235,13 +281,16 @@ struct CeRowOut {
     cx<T>* dst;
     int64_t ld;
 };
-// the ColStoreNat view of the plain 2-D transform: every bin kept, rotations on both axes, scale, conjugation
+// the ColStoreNat view of the 2-D transform without crop or multiplier: every bin kept, rotations on both axes, scale, conjugation, and the
+// library's epilogues (fft_io.h: complex, |.|^2 into a real array, weight |.|^2 added to a real array)
 template <typename T>
 struct CeColOut {
-    cx<T>* dst;
+    void* dst;      // cx<T>*, or T* under an epilogue
     int64_t ld;
     int ny, sy, nx, sx;
     T sr, si;
+    int epilogue;
+    T weight;
 };
 
 // v[m] = x[t + TS m] of sequence `seq` (clamped by the caller to one that exists)
@@ -282,12 +331,25 @@ PM_HD void ce_store_col(const cx<typename C::T> (&v)[C::P], const CeColOut<typen
     qx = qx >= out.nx ? qx - out.nx : qx;
     int k0 = t + out.sy;
     k0 = k0 >= out.ny ? k0 - out.ny : k0;
-    cx<T>* d = out.dst + qx;
+    if (out.epilogue == 0) {
+        cx<T>* d = reinterpret_cast<cx<T>*>(out.dst) + qx;
 #pragma unroll
-    for (int r = 0; r < C::P; ++r) {
-        int k = k0 + C::PL::TS * r;
-        k = k >= out.ny ? k - out.ny : k;
-        mix_st(d + int64_t(k) * out.ld, cx<T>{v[r].x * out.sr, v[r].y * out.si});
+        for (int r = 0; r < C::P; ++r) {
+            int k = k0 + C::PL::TS * r;
+            k = k >= out.ny ? k - out.ny : k;
+            mix_st(d + int64_t(k) * out.ld, cx<T>{v[r].x * out.sr, v[r].y * out.si});
+        }
+    } else {
+        T* d = reinterpret_cast<T*>(out.dst) + qx;
+        const T s2 = out.sr * out.sr * (out.epilogue == 2 ? out.weight : T(1));
+#pragma unroll
+        for (int r = 0; r < C::P; ++r) {
+            int k = k0 + C::PL::TS * r;
+            k = k >= out.ny ? k - out.ny : k;
+            const T i2 = (v[r].x * v[r].x + v[r].y * v[r].y) * s2;
+            T* o = d + int64_t(k) * out.ld;
+            *o = out.epilogue == 2 ? *o + i2 : i2;
+        }
     }
 }
 

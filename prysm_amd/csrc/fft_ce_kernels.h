@@ -1,0 +1,149 @@
+// Kernels and launchers of the composite register engine (fft_ce.h); the plans are instantiated per precision in fft_ce_f32.hip /
+// fft_ce_f64.hip.  Entry points ce_rows / ce_cols (pm_internal.h) answer -1 when the length has no plan here or the view needs what these
+// kernels do not do (real input, synthesis, multipliers, epilogues, mapped 1-D outputs): the caller then takes the general kernel.
+#pragma once
+#include "fft_ce.h"
+#include "fft_mixed_kernels.h"
+
+namespace pm {
+
+// twiddles of the NEXT stage requested before the exchange that feeds it (their latency then hides behind two barriers)
+template <typename C, int s>
+__device__ __forceinline__ void ce_run(cx<typename C::T> (&v)[C::P], CePos pos, void* lds_raw, const cx<typename C::T>* __restrict__ tw) {
+    using LT = typename CeLds<C>::type;
+    LT* lds = reinterpret_cast<LT*>(lds_raw);
+    if constexpr (s > 0 && !(C::ABL & 8)) {
+#pragma unroll
+        for (int comp = 0; comp < C::COMP; ++comp) {
+            if (s > 1 || comp > 0) __syncthreads();     // the previous gather has finished
+            ce_exch_write<C, s, LT>(v, comp, pos, lds);
+            __syncthreads();
+            ce_exch_read<C, s, LT>(v, comp, pos, lds);
+        }
+    }
+    if constexpr (!(C::ABL & 4)) ce_stage<C, s>(v, pos.t, tw);
+    if constexpr (s + 1 < C::PL::S) ce_run<C, s + 1>(v, pos, lds_raw, tw);
+}
+
+// waves per SIMD the kernel is compiled for: two workgroups per CU wherever two fit the LDS
+template <typename C>
+constexpr int ce_waves_per_eu() {
+    if (C::WPE > 0) return C::WPE;
+    constexpr int waves = (C::NT + 63) / 64;
+    constexpr int by_lds = int(size_t(160) * 1024 / (C::LDS_BYTES ? C::LDS_BYTES : 1));
+    constexpr int wgs = by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
+    constexpr int need = (waves * wgs + 3) / 4;            // waves per SIMD with `wgs` workgroups resident
+    constexpr int fit = 512 / (2 * C::P * int(sizeof(typename C::T)) / 4 + 44);     // ... that the data registers + ~40 allow
+    return need < fit ? need : (fit < 1 ? 1 : fit);
+}
+
+template <typename C, bool WIN>
+__global__ __launch_bounds__(C::NT, ce_waves_per_eu<C>()) void ce_rows_kernel(CeIn<typename C::T> in, CeRowOut<typename C::T> out,
+                                                                               const cx<typename C::T>* __restrict__ tw) {
+    using T = typename C::T;
+    extern __shared__ __align__(16) char ce_smem[];
+    const CePos pos = ce_pos<C>(threadIdx.x);
+    const int row = int(blockIdx.x) * C::SEQS + pos.sl;
+    cx<T> v[C::P];
+    if constexpr (C::ABL & 1) {
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) v[m] = cx<T>{T(pos.tid + m), T(row)};
+    } else {
+        ce_load<C, WIN>(v, in, row < in.nseq ? row : in.nseq - 1, pos.t);
+    }
+    ce_run<C, 0>(v, pos, ce_smem, tw);
+    if constexpr (C::ABL & 2) {
+        T acc = T(0);
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) acc += v[m].x * v[m].y;
+        if (acc == T(-12345.678)) ce_store_row<C>(v, out, row, pos.t);
+    } else {
+        if (row < in.nseq) ce_store_row<C>(v, out, row, pos.t);
+    }
+}
+
+template <typename C, bool WIN>
+__global__ __launch_bounds__(C::NT, ce_waves_per_eu<C>()) void ce_cols_kernel(CeIn<typename C::T> in, CeColOut<typename C::T> out,
+                                                                               const cx<typename C::T>* __restrict__ tw, int log_g) {
+    using T = typename C::T;
+    extern __shared__ __align__(16) char ce_smem[];
+    // tiles that share 128 B lines run on one XCD (fft_mixed_kernels.h mix_cols_kernel)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = ((slot >> log_g) << (log_g + 3)) + (xcd << log_g) + (slot & ((1 << log_g) - 1));
+    const int c0 = tile * C::SEQS;
+    if (c0 >= in.nseq) return;
+    const CePos pos = ce_pos<C>(threadIdx.x);
+    const int col = c0 + pos.sl;
+    cx<T> v[C::P];
+    if constexpr (C::ABL & 1) {
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) v[m] = cx<T>{T(pos.tid + m), T(col)};
+    } else {
+        ce_load<C, WIN>(v, in, col < in.nseq ? col : in.nseq - 1, pos.t);
+    }
+    ce_run<C, 0>(v, pos, ce_smem, tw);
+    if constexpr (C::ABL & 2) {
+        T acc = T(0);
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) acc += v[m].x * v[m].y;
+        if (acc == T(-12345.678)) ce_store_col<C>(v, out, col, pos.t);
+    } else {
+        if (col < in.nseq) ce_store_col<C>(v, out, col, pos.t);
+    }
+}
+
+template <typename C>
+int ce_rows_go(const CeIn<typename C::T>& in, const CeRowOut<typename C::T>& out, const cx<typename C::T>* tw, hipStream_t st) {
+    const bool win = !(in.ax.off == 0 && in.ax.len == in.ax.n);
+    const int groups = (in.nseq + C::SEQS - 1) / C::SEQS;
+    if (win) {
+        const int rc = mix_set_lds(ce_rows_kernel<C, true>, C::LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL((ce_rows_kernel<C, true>), dim3(groups), dim3(C::NT), C::LDS_BYTES, st, in, out, tw);
+    } else {
+        const int rc = mix_set_lds(ce_rows_kernel<C, false>, C::LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL((ce_rows_kernel<C, false>), dim3(groups), dim3(C::NT), C::LDS_BYTES, st, in, out, tw);
+    }
+    return int(hipGetLastError());
+}
+template <typename C>
+int ce_cols_go(const CeIn<typename C::T>& in, const CeColOut<typename C::T>& out, const cx<typename C::T>* tw, hipStream_t st, int log_g) {
+    const bool win = !(in.ax.off == 0 && in.ax.len == in.ax.n);
+    // adjacent tiles that run on one XCD: the measured best of the shape (tools/ce_gen.py), else as many as share a 128 B line
+    if (log_g < 0)
+        for (log_g = 0; (size_t(C::SEQS) << log_g) * sizeof(cx<typename C::T>) < 128 && log_g < 3;) ++log_g;
+    if (tuning().ce_log_g >= 0) log_g = tuning().ce_log_g > 8 ? 8 : tuning().ce_log_g;
+    const int tiles = (in.nseq + C::SEQS - 1) / C::SEQS, round = 8 << log_g, groups = (tiles + round - 1) / round * round;
+    if (win) {
+        const int rc = mix_set_lds(ce_cols_kernel<C, true>, C::LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL((ce_cols_kernel<C, true>), dim3(groups), dim3(C::NT), C::LDS_BYTES, st, in, out, tw, log_g);
+    } else {
+        const int rc = mix_set_lds(ce_cols_kernel<C, false>, C::LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL((ce_cols_kernel<C, false>), dim3(groups), dim3(C::NT), C::LDS_BYTES, st, in, out, tw, log_g);
+    }
+    return int(hipGetLastError());
+}
+
+// what the general entry points hand over (fft_mixed_kernels.h mix_rows_impl / mix_cols_impl)
+template <typename T>
+bool ce_rows_view(const DirectIn<T>& in, CeIn<T>& ci) {
+    if (in.real || in.synth || in.s_i != 1 || in.nseq <= 0) return false;
+    ci = CeIn<T>{in.src, in.s_seq, in.ax, in.nseq, in.conj ? T(-1) : T(1)};
+    return true;
+}
+template <typename T>
+bool ce_cols_view(const DirectIn<T>& in, const ColStoreNat<T>& out, CeIn<T>& ci, CeColOut<T>& co) {
+    if (in.real || in.synth || in.s_seq != 1 || in.nseq <= 0) return false;
+    const bool whole = out.ay.off == 0 && out.ay.len == out.ay.n && out.ax.off == 0 && out.ax.len == out.ax.n;
+    if (!whole || out.mul_kind != MUL_NONE || out.ay.n != in.ax.n || out.ax.n != in.nseq) return false;
+    if (out.epilogue != EPI_NONE && out.epilogue != EPI_ABS2 && out.epilogue != EPI_ABS2_ACCUM) return false;
+    ci = CeIn<T>{in.src, in.s_i, in.ax, in.nseq, in.conj ? T(-1) : T(1)};
+    co = CeColOut<T>{out.dst, out.ld, out.ay.n, out.ay.shift, out.ax.n, out.ax.shift, out.scale, out.conj ? -out.scale : out.scale,
+                     out.epilogue, out.weight};
+    return true;
+}
+
+}  // namespace pm

@@ -72,6 +72,11 @@ template <typename T>
 int mix_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o = nullptr, const MixFold<T>* fold = nullptr);
 template <typename T>
 int mix_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t st);
+// the composite register engine (fft_ce.h): lengths with a compile-time plan, plain views.  false: not taken (the general kernel runs);
+// true: launched, *rc holds the status
+template <typename T> bool ce_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, int* rc);
+template <typename T> bool ce_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t st, int* rc);
+template <typename T> bool ce_has_plan(int n);      // lengths with a built plan (tools/ce_gen.py)
 // middle pass of fft2 -> x H -> ifft2 on a composite column length: the columns of the natural intermediate `in` (sequence = column) come
 // back in dst[row * dst_pitch + column] as the unnormalised inverse column transform of (column spectrum x H); in place allowed
 template <typename T>
@@ -179,6 +184,8 @@ struct Tuning {
     int mix_fold = 0;         // removed in round 5 (experiments/README.md; the value is refused): a radix-2 step of a composite column transform folded into the mixed-radix row pass where the whole column's tile would
                               // take a CU's LDS (capi.hip plan_fft2 mix_fold)
     int mix_pers = 0;         // removed in round 5 (experiments/README.md; the value is refused): its column pass as persistent workgroups with the next tile prefetched where a CU holds one tile (mix_cols_pers_kernel)
+    int mix_engine = 1;       // composite lengths with a compile-time plan on the register engine (fft_ce.h); 0: the general kernel everywhere
+    int ce_rows_seqs = 0, ce_cols_seqs = 0, ce_log_g = -1;     // ... a built alternative of its rows / columns per workgroup (0: the default shape)
     int mix_stagger = 4;      // ... start-up stagger of the column kernel's workgroups in units of 512 cycles x 0 .. 7 where a CU holds one tile (fft_mixed.h MixShape::stagger); 0 = off
     int mix_ablate = 0;       // removed in round 5 (experiments/README.md; the value is refused): timing-only ablations of the mixed-radix kernels (fft_mixed.h MixShape::ablate; results are wrong)
     int two_units = 0;        // removed in round 5 (experiments/README.md; the value is refused): two units per workgroup in the passes of a 2048-point complex64 transform (bit 0 rows, bit 1 columns)

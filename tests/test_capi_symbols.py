@@ -235,14 +235,16 @@ ROUTES = [
     ((10000, 10000), ['route=radix-step', 'rows=2xmixed-radix(5000)', 'cols=2xmixed-radix(5000)']),
     ((9000, 12000), ['route=radix-step', 'rows=2xmixed-radix(6000)', 'cols=2xmixed-radix(4500)']),
     ((20000, 4096), ['route=radix-step', 'cols=4xmixed-radix(5000)']),
-    ((3000, 3000), ['route=natural-mixed', 'rows=mixed-radix(3000)', 'cols=mixed-radix(3000)', 'ws=72192000']),
-    ((3000, 3000, 'c128'), ['route=natural-mixed', 'rows=mixed-radix(3000)']),
-    ((1000, 1000), ['route=natural-mixed', 'ws=8064000']),
+    ((3000, 3000), ['route=natural-mixed', 'rows=mixed-radix-registers(3000)', 'cols=mixed-radix-registers(3000)', 'ws=72192000']),     # round 5: the composite register engine (fft_ce.h)
+    ((3000, 3000, 'c128'), ['route=natural-mixed', 'rows=mixed-radix-registers(3000)']),
+    ((1000, 1000), ['route=natural-mixed', 'rows=mixed-radix-registers(1000)', 'ws=8064000']),
+    ((1800, 4500), ['rows=mixed-radix-registers(4500)', 'cols=mixed-radix-registers(1800)']),
+    ((1200, 2400), ['rows=mixed-radix(2400)', 'cols=mixed-radix(1200)']),      # no compile-time plan: the general kernel
     ((6006, 6006), ['route=natural-mixed', 'cols=mixed-radix(6006)']),
     ((1020, 1900), ['route=natural-mixed', 'rows=mixed-radix(1900)', 'cols=mixed-radix(1020)']),
     ((323, 380), ['route=natural-mixed', 'rows=mixed-radix(380)', 'cols=mixed-radix(323)']),
-    ((4096, 3000), ['route=natural-mixed', 'rows=mixed-radix(3000)', 'cols=stockham(4096)']),
-    ((3000, 4096), ['route=natural-mixed', 'rows=stockham(4096)', 'cols=mixed-radix(3000)']),
+    ((4096, 3000), ['route=natural-mixed', 'rows=mixed-radix-registers(3000)', 'cols=stockham(4096)']),
+    ((3000, 4096), ['route=natural-mixed', 'rows=stockham(4096)', 'cols=mixed-radix-registers(3000)']),
     ((1536, 1536), ['route=natural-mixed', 'rows=mixed-radix(1536)']),
     ((36, 36), ['route=natural-mixed']),
     ((24, 24), ['route=natural ', 'rows=direct(24)', 'cols=direct(24)']),
@@ -257,10 +259,11 @@ ROUTES_KW = [
     (dict(m=8192, n=8192, real=True, epi=3), ['route=hermitian-fold', 'rows=stockham-r2c(4096)', 'cols=stockham(4096x2)', 'tile=8']),
     (dict(m=2048, n=2048, real=True), ['route=engine ']),               # a plain spectrum of a small real field stays on the complex path
     (dict(m=4096, n=4096, real=True), ['route=hermitian-fold']),
-    (dict(m=3000, n=3000, real=True), ['route=natural-mixed']),         # composite grids: no Hermitian path yet (the real array is read by the complex kernels)
+    (dict(m=3000, n=3000, real=True), ['route=natural-mixed', 'rows=mixed-radix(3000)', 'cols=mixed-radix-registers(3000)']),         # composite grids: no Hermitian path yet (the real array is read by the complex kernels)
     (dict(m=1024, n=1024, batch=100), ['route=engine ', 'chunk=16', 'ws=134217728']),
     (dict(m=4096, n=4096, synth=True), ['route=engine-fold']),
-    (dict(m=3000, n=3000, synth=True), ['rows=mixed-radix(3000)']),
+    (dict(m=3000, n=3000, synth=True), ['rows=mixed-radix(3000)']),      # the pupil is synthesised in the general kernel's loads
+    (dict(m=3000, n=3000, epi=1), ['cols=mixed-radix-registers(3000)']),    # |.|^2 in the engine's column store
     (dict(m=4096, n=4096, dt='c128', op=1, mul=True), ['route=fused ', 'passes=3', 'mid=stockham-pair fold', 'ws=268435456']),
     (dict(m=4096, n=4096, dt='c64', op=1, mul=True), ['route=fused ', 'fold']),
     (dict(m=2048, n=2048, dt='c128', op=1, mul=True), ['route=fused ', 'mid=stockham-pair ws=']),
@@ -304,3 +307,6 @@ def test_routes_follow_the_knobs_and_tuning_local_nests(lib):
     with L.tuning_local(log_k=0):
         assert 'log_k=0' in _route(lib, 4096, 4096)
     assert 'log_k=7' in _route(lib, 4096, 4096)
+    with L.tuning_local(mix_engine=0):      # round 5: composite lengths with a compile-time plan back on the general kernel
+        assert 'rows=mixed-radix(3000)' in _route(lib, 3000, 3000)
+    assert 'rows=mixed-radix-registers(3000)' in _route(lib, 3000, 3000)

@@ -354,3 +354,77 @@ def test_mtf_ptf_otf_on_composite_grids(pa, n, rdt):
     assert rel_max(tonp(data), F) < tol and abs(df - 1000 / n) < 1e-12
     mtf2, raw = otf.mtf_from_psf(psf, 1.0, return_more=True)      # the composed route still answers return_more
     assert np.max(np.abs(tonp(mtf2.data) - np.abs(nrm))) < tol and rel_max(tonp(raw), F) < tol
+
+
+# ---------------------------------------------------------------------------
+# composite register engine (csrc/fft_ce.h): every built plan against numpy fp64 and against the general mixed-radix kernel
+# ---------------------------------------------------------------------------
+CE_LENGTHS = [500, 900, 1000, 1500, 1600, 1800, 2000, 2500, 3000, 4000, 4500, 5000, 6000, 8000]
+
+
+def _ce_ref(x, shape, in_off, in_shift, out_shift, direction):
+    M, N = shape
+    full = np.zeros((M, N), dtype=np.complex128)
+    full[in_off[0]:in_off[0] + x.shape[0], in_off[1]:in_off[1] + x.shape[1]] = x
+    full = np.roll(full, (-in_shift[0], -in_shift[1]), (0, 1))
+    f = np.fft.fft2(full) if direction < 0 else np.fft.ifft2(full) * (M * N)
+    return np.roll(f, out_shift, (0, 1))
+
+
+@pytest.mark.parametrize('cdt', [np.complex64, np.complex128])
+@pytest.mark.parametrize('n', CE_LENGTHS)
+def test_composite_engine_plans_vs_numpy_and_general_kernel(pa, n, cdt):
+    """Each plan as the row pass (short columns beside it) and as the column pass (ragged tiles: a column count that is no multiple of
+    any tile width), plain / rotated / zero-padded / inverse, with the engine on and off (knob mix_engine)."""
+    from prysm_amd import _lib, _ops
+    rng = np.random.default_rng(n)
+    tol = TOL32 if cdt == np.complex64 else TOL64
+    other = 90 if n > 3000 else 250       # 90 and 250 run on the general kernel: one pass of each transform is the engine's
+    cases = [((other, n), None, (0, 0), (0, 0), (0, 0), -1),
+             ((n, other + 1), None, (0, 0), (n // 2, 3), (n // 2, 5), -1),
+             ((n, other + 1), None, (0, 0), (1, 0), (0, 2), +1),
+             ((other, n // 2), (other, n), (0, n // 4), (0, n // 2), (3, n // 2), -1),
+             ((n // 2 + 1, other), (n, other), (n // 4, 0), (n // 2, 0), (n // 2, 0), +1)]
+    if n <= 2000:
+        cases.append(((n, n), None, (0, 0), (n // 2, n // 2), (n // 2, n // 2), -1))
+    for xs, shape, in_off, in_shift, out_shift, direction in cases:
+        shape = shape or xs
+        x = (rng.standard_normal(xs) + 1j * rng.standard_normal(xs)).astype(cdt)
+        want = _ce_ref(x, shape, in_off, in_shift, out_shift, direction)
+        xd = torch.from_numpy(x).cuda()
+        got = {}
+        for eng in (1, 0):
+            with _lib.tuning_local(mix_engine=eng):
+                got[eng] = _ops.fft2(xd, direction=direction, scale=1.0, shape=shape, in_off=in_off, in_shift=in_shift, out_shift=out_shift).cpu().numpy()
+            assert rel_max(got[eng], want) < tol, (n, cdt.__name__, xs, shape, eng)
+        assert rel_max(got[1], got[0]) < tol
+
+
+@pytest.mark.parametrize('n,cdt', [(1000, np.complex64), (1500, np.complex128), (3000, np.complex64)])
+def test_composite_engine_intensity_epilogues(pa, n, cdt):
+    """|.|^2 and weight |.|^2 accumulated (Wavefront.intensity, the polychromatic sum) in the engine's column store."""
+    from prysm_amd import _lib, _ops
+    rng = np.random.default_rng(n + 1)
+    m = 300
+    x = (rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))).astype(cdt)
+    f = np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(x.astype(np.complex128)))) * 0.01
+    xd = torch.from_numpy(x).cuda()
+    kw = dict(direction=-1, scale=0.01, in_shift=(n // 2, m // 2), out_shift=(n // 2, m // 2))
+    i1 = _ops.fft2(xd, epilogue=_lib.PM_EPI_ABS2, **kw)
+    assert i1.dtype == (torch.float32 if cdt == np.complex64 else torch.float64)
+    assert rel_max(i1.cpu().numpy(), np.abs(f) ** 2) < (4e-5 if cdt == np.complex64 else 1e-10)
+    acc = i1.clone()
+    _ops.fft2(xd, epilogue=_lib.PM_EPI_ABS2_ACCUM, out=acc, weight=0.5, **kw)
+    assert rel_max(acc.cpu().numpy(), 1.5 * np.abs(f) ** 2) < (4e-5 if cdt == np.complex64 else 1e-10)
+
+
+def test_composite_engine_through_the_wavefront_api(pa):
+    """focus / unfocus of a 1000^2 and a 1500 x 2000 field (prysm/propagation/fft.py:7-45) against the oracle: the route the users take."""
+    from prysm_amd import propagation as P
+    rng = np.random.default_rng(5)
+    for shape, cdt, tol in (((1000, 1000), np.complex64, TOL32), ((1500, 2000), np.complex128, TOL64)):
+        x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(cdt)
+        got = tonp(P.focus(torch.from_numpy(x).cuda(), 1))
+        assert rel_max(got, O.focus(x.astype(np.complex128), 1)) < tol
+        back = tonp(P.unfocus(torch.from_numpy(got).cuda(), 1))
+        assert rel_max(back, x) < 4 * tol

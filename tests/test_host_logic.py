@@ -81,6 +81,18 @@ def test_mixed_radix_kernel_emulation():
     assert 'all ok' in out.stdout
 
 
+def test_composite_register_engine_emulation():
+    """tools/emu_ce.cpp: the per-thread code of the composite register engine (csrc/fft_ce.h: prime-factor small DFTs, stages, the
+    register-index exchange, row and column global access with windows and rotations) for every shipped plan and workgroup shape
+    (tools/emu_ce_plans.inc, written by tools/ce_gen.py) run thread by thread against a long-double DFT"""
+    exe = '/tmp/pm_emu_ce_test'
+    subprocess.run(['g++', '-O2', '-std=c++17', '-I', os.path.join(ROOT, 'prysm_amd', 'csrc'), '-I', os.path.join(ROOT, 'tools'),
+                    os.path.join(ROOT, 'tools', 'emu_ce.cpp'), '-o', exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert 'all ok' in out.stdout
+
+
 REF = '/root/reference'
 
 

@@ -1,6 +1,6 @@
 // CPU emulation of the composite register engine's per-thread logic (prysm_amd/csrc/fft_ce.h), test scaffolding like emu_fft.cpp /
 // emu_mix.cpp: every thread of a workgroup runs each phase in turn with a std::vector standing in for LDS, against a naive long-double DFT.
-// build: g++ -O2 -std=c++17 -I prysm_amd/csrc tools/emu_ce.cpp -o /tmp/emu_ce
+// build: g++ -O2 -std=c++17 -I prysm_amd/csrc -I tools tools/emu_ce.cpp -o /tmp/emu_ce
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -46,7 +46,7 @@ static double run_case(int nseq, int shift, int off, int len) {
     CeIn<T> in{x.data(), col ? nseq : len, AxisMap{n, len, off, shift}, nseq, T(1)};
     const int sy = 3 % n, sx = nseq > 2 ? 2 : 0;
     CeRowOut<T> ro{y.data(), n};
-    CeColOut<T> co{y.data(), nseq, n, sy, nseq, sx, T(0.5), T(0.5)};
+    CeColOut<T> co{y.data(), nseq, n, sy, nseq, sx, T(0.5), T(0.5), 0, T(1)};
     std::vector<typename CeLds<C>::type> lds(C::lds_elems() + 64);
     std::vector<cx<T>> regs(size_t(C::NT) * C::P);
     auto V = [&](int tid) -> cx<T>(&)[C::P] { return *reinterpret_cast<cx<T>(*)[C::P]>(regs.data() + size_t(tid) * C::P); };
@@ -76,7 +76,7 @@ static double run_case(int nseq, int shift, int off, int len) {
             const cx<T> v = col ? x[size_t(q) * nseq + s] : x[size_t(s) * len + q];
             xs[i] = cld(v.x, v.y);
         }
-        for (int k = (s * 5) % 37; k < n; k += (n > 600 ? 37 : 1)) {
+        for (int k = (s * 5) % 37; k < n; k += (n > 3000 ? 211 : (n > 600 ? 37 : 1))) {
             cld acc = 0;
             for (int i = 0; i < n; ++i) { const ld a = -2 * pi * ld((int64_t(i) * k) % n) / n; acc += xs[i] * cld(cosl(a), sinl(a)); }
             cx<T> v;
@@ -124,6 +124,8 @@ int main() {
     CHECK(CeCfg<float, CePlan<20, 20, 20>, 1, false, 2>);
     CHECK(CeCfg<float, CePlan<12, 6, 4>, 4, true, 1>);
     CHECK(CeCfg<double, CePlan<15, 15, 5>, 2, false, 1>);
+    // every shape the library ships (tools/ce_gen.py)
+#include "emu_ce_plans.inc"
     printf(fails ? "FAILED %d\n" : "all ok\n", fails);
     return fails ? 1 : 0;
 }

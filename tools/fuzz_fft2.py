@@ -333,7 +333,8 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     lib = L.load()
     sizes = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 3, 5, 9, 12, 20, 36, 100, 96, 127, 160, 200, 224, 384, 1000, 1536, 45, 77, 143, 250, 360, 729, 1001, 1250,
-             2592, 323, 1020, 1900]   # engine, direct, Bluestein, radix-R step and mixed-radix (composite; round 4: primes 17 / 19 too) lengths
+             2592, 323, 1020, 1900,   # engine, direct, Bluestein, radix-R step and mixed-radix (composite; round 4: primes 17 / 19 too) lengths
+             500, 900, 1500, 1600, 1800, 2000, 2500, 3000]   # round 5: lengths of the composite register engine (fft_ce.h)
     worst = 0.0
     nfail = 0
     for case in range(ncases):
@@ -345,7 +346,11 @@ def main():
             M = min(M, 4096) if N == 4096 else M
         if rng.random() < 0.04:     # round 4: a composite above 8192 beside a short axis (one radix-R step around mixed-radix sub-transforms)
             M, N = (int(rng.choice([9000, 10000, 12000])), int(rng.choice([64, 96, 100]))) if rng.random() < 0.5 else (int(rng.choice([64, 100])), int(rng.choice([10000, 20000])))
+        if rng.random() < 0.05:     # round 5: the long plans of the composite register engine beside a short axis
+            big_ce = int(rng.choice([4000, 4500, 5000, 6000, 8000]))
+            M, N = (big_ce, int(rng.choice([64, 100, 500]))) if rng.random() < 0.5 else (int(rng.choice([64, 100, 900])), big_ce)
         lib.pm_set_tuning(b'mix_pad', int(rng.random() < 0.7))
+        lib.pm_set_tuning(b'mix_engine', int(rng.random() < 0.75))     # ... whose lengths also keep running on the general kernel
         cdt = np.complex64 if rng.random() < 0.5 else np.complex128
         rdt = np.float32 if cdt == np.complex64 else np.float64
         m = M if rng.random() < 0.6 else int(rng.integers(1, M + 1))
@@ -415,7 +420,7 @@ def main():
         if not ok:
             nfail += 1
             print('case', case, 'FAIL err', err, (M, N, m, n, in_off, in_shift, (om, on), out_off, out_shift, direction, cdt.__name__, kind, B, epi, fold, route))
-    for key, val in ((b'fold', -1), (b'big_native_log', 13), (b'blue_min', 96), (b'blue_fuse', 1), (b'mix', 1), (b'mix_pad', 1)):
+    for key, val in ((b'fold', -1), (b'big_native_log', 13), (b'blue_min', 96), (b'blue_fuse', 1), (b'mix', 1), (b'mix_pad', 1), (b'mix_engine', 1)):
         lib.pm_set_tuning(key, val)
     print(f'fuzz_fft2: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
     nfail += fuzz_fused(max(20, ncases // 2), rng, lib)
