@@ -280,6 +280,18 @@ template <typename T>
 struct CeRowOut {
     cx<T>* dst;
     int64_t ld;
+    // mapped: the 1-D API's view of the bins (window / rotation, scale, conjugation -- fft_io.h RowStoreNat); else natural rows
+    int mapped;
+    AxisMap ax;
+    T sr, si;
+};
+// multiplier of the middle pass (fft_io.h MidMul): full H[k ld + c] or separable hy[k] hx[c], optionally conjugated
+template <typename T>
+struct CeMul {
+    int kind, conj;
+    const cx<T>* mul;
+    const cx<T>* mul_x;
+    int64_t ld;
 };
 // the ColStoreNat view of the 2-D transform without crop or multiplier: every bin kept, rotations on both axes, scale, conjugation, and the
 // library's epilogues (fft_io.h: complex, |.|^2 into a real array, weight |.|^2 added to a real array)
@@ -293,64 +305,156 @@ struct CeColOut {
     T weight;
 };
 
-// v[m] = x[t + TS m] of sequence `seq` (clamped by the caller to one that exists)
+// Addresses: a base that is uniform in the workgroup (scalar registers; the per-element constants of the plan fold into it) plus ONE
+// 32-bit byte offset per lane -- the saddr + voffset form of the global instructions, no 64-bit vector arithmetic per element.  The
+// launchers check that the arrays stay below 4 GiB (ce_fits32).  seq0: the first sequence of the workgroup, sl: the lane's sequence slot
+// (clamped by the caller to one that exists).
+template <typename T>
+PM_HD const cx<T>* ce_at(const cx<T>* ubase, int64_t uelems, uint32_t vbytes) {
+    return reinterpret_cast<const cx<T>*>(reinterpret_cast<const char*>(ubase + uelems) + vbytes);
+}
+template <typename T>
+PM_HD cx<T>* ce_at(cx<T>* ubase, int64_t uelems, uint32_t vbytes) {
+    return reinterpret_cast<cx<T>*>(reinterpret_cast<char*>(ubase + uelems) + vbytes);
+}
+// A rotated axis: logical index t + TS m sits at position p = q0 + TS m - (wrapped ? N : 0), q0 = (t + shift) mod N.  With `unit` elements
+// between positions: address = [base + (TS m - N) unit] + [q0 unit + (wrapped ? 0 : N unit)] -- uniform part, lane part (never negative).
+struct CeRot {
+    int q0;
+    uint32_t v0, vn;      // bytes: lane offset of position q0 (plus what the caller adds), N unit
+};
+template <int N>
+PM_HD int ce_rot0(int t, int shift) {
+    const int q = t + shift;
+    return q >= N ? q - N : q;
+}
+
+// v[m] = x[t + TS m] of sequence seq0 + sl
 template <typename C, bool WIN>
-PM_HD void ce_load(cx<typename C::T> (&v)[C::P], const CeIn<typename C::T>& in, int seq, int t) {
+PM_HD void ce_load(cx<typename C::T> (&v)[C::P], const CeIn<typename C::T>& in, int seq0, int sl, int t) {
     using T = typename C::T;
     using PL = typename C::PL;
-    const cx<T>* base = C::COL ? in.src + seq : in.src + int64_t(seq) * in.pitch;
-    int q0 = t + in.ax.shift;
-    q0 = q0 >= PL::N ? q0 - PL::N : q0;
+    constexpr uint32_t ES = sizeof(cx<T>);
+    const int q0 = ce_rot0<PL::N>(t, in.ax.shift);
+    if (WIN) {      // a window of the axis: positions outside it read as zero (64-bit addresses: the invalid lanes need a valid one)
+        const cx<T>* base = C::COL ? in.src + (seq0 + sl) : in.src + int64_t(seq0 + sl) * in.pitch;
 #pragma unroll
-    for (int m = 0; m < C::P; ++m) {
-        int p = q0 + PL::TS * m;
-        p = p >= PL::N ? p - PL::N : p;
-        if (WIN) {
+        for (int m = 0; m < C::P; ++m) {
+            int p = q0 + PL::TS * m;
+            p = p >= PL::N ? p - PL::N : p;
             const int q = p - in.ax.off;
             const bool ok = unsigned(q) < unsigned(in.ax.len);
             const int64_t o = ok ? (C::COL ? int64_t(q) * in.pitch : int64_t(q)) : 0;
             const cx<T> x = mix_ld(base + o);
             v[m] = ok ? x : cx<T>{T(0), T(0)};
-        } else {
-            v[m] = mix_ld(base + (C::COL ? int64_t(p) * in.pitch : int64_t(p)));
+        }
+    } else {
+        const int64_t unit = C::COL ? in.pitch : 1;
+        const cx<T>* ubase = C::COL ? in.src + seq0 : in.src + int64_t(seq0) * in.pitch;
+        const uint32_t vn = uint32_t(PL::N) * uint32_t(unit) * ES;
+        const uint32_t v0 = (uint32_t(q0) * uint32_t(unit) + uint32_t(sl) * uint32_t(C::COL ? 1 : in.pitch)) * ES;
+#pragma unroll
+        for (int m = 0; m < C::P; ++m) {
+            const bool wrapped = q0 >= PL::N - PL::TS * m;
+            v[m] = mix_ld(ce_at(ubase, int64_t(PL::TS * m - PL::N) * unit, v0 + (wrapped ? 0u : vn)));
         }
     }
 #pragma unroll
     for (int m = 0; m < C::P; ++m) v[m].y *= in.ysign;
 }
 template <typename C>
-PM_HD void ce_store_row(const cx<typename C::T> (&v)[C::P], const CeRowOut<typename C::T>& out, int row, int t) {
-    cx<typename C::T>* d = out.dst + int64_t(row) * out.ld + t;
-#pragma unroll
-    for (int r = 0; r < C::P; ++r) mix_st(d + C::PL::TS * r, v[r]);
-}
-template <typename C>
-PM_HD void ce_store_col(const cx<typename C::T> (&v)[C::P], const CeColOut<typename C::T>& out, int col, int t) {
+PM_HD void ce_store_row(const cx<typename C::T> (&v)[C::P], const CeRowOut<typename C::T>& out, int row0, int sl, int t) {
     using T = typename C::T;
-    int qx = col + out.sx;
-    qx = qx >= out.nx ? qx - out.nx : qx;
-    int k0 = t + out.sy;
-    k0 = k0 >= out.ny ? k0 - out.ny : k0;
-    if (out.epilogue == 0) {
-        cx<T>* d = reinterpret_cast<cx<T>*>(out.dst) + qx;
+    using PL = typename C::PL;
+    constexpr uint32_t ES = sizeof(cx<T>);
+    cx<T>* ubase = out.dst + int64_t(row0) * out.ld;
+    const uint32_t vrow = uint32_t(sl) * uint32_t(out.ld) * ES;
+    if (out.mapped) {
+        const int q0 = ce_rot0<PL::N>(t, out.ax.shift);
+        const uint32_t v0 = vrow + uint32_t(q0) * ES, vn = uint32_t(PL::N) * ES;
 #pragma unroll
         for (int r = 0; r < C::P; ++r) {
-            int k = k0 + C::PL::TS * r;
-            k = k >= out.ny ? k - out.ny : k;
-            mix_st(d + int64_t(k) * out.ld, cx<T>{v[r].x * out.sr, v[r].y * out.si});
+            const bool wrapped = q0 >= PL::N - PL::TS * r;
+            const int q = q0 + PL::TS * r - (wrapped ? PL::N : 0) - out.ax.off;
+            if (unsigned(q) < unsigned(out.ax.len))
+                mix_st(ce_at(ubase, int64_t(PL::TS * r - PL::N) - out.ax.off, v0 + (wrapped ? 0u : vn)), cx<T>{v[r].x * out.sr, v[r].y * out.si});
+        }
+        return;
+    }
+    const uint32_t v0 = vrow + uint32_t(t) * ES;
+#pragma unroll
+    for (int r = 0; r < C::P; ++r) mix_st(ce_at(ubase, PL::TS * r, v0), v[r]);
+}
+// column c0 + sl of the output view: rows rotated by sy, columns by sx
+template <typename C>
+PM_HD void ce_store_col(const cx<typename C::T> (&v)[C::P], const CeColOut<typename C::T>& out, int c0, int sl, int t) {
+    using T = typename C::T;
+    using PL = typename C::PL;
+    int qx = c0 + sl + out.sx;
+    qx = qx >= out.nx ? qx - out.nx : qx;
+    const int k0 = ce_rot0<PL::N>(t, out.sy);
+    if (out.epilogue == 0) {
+        constexpr uint32_t ES = sizeof(cx<T>);
+        cx<T>* ubase = reinterpret_cast<cx<T>*>(out.dst);
+        const uint32_t vn = uint32_t(PL::N) * uint32_t(out.ld) * ES, v0 = (uint32_t(k0) * uint32_t(out.ld) + uint32_t(qx)) * ES;
+#pragma unroll
+        for (int r = 0; r < C::P; ++r) {
+            const bool wrapped = k0 >= PL::N - PL::TS * r;
+            mix_st(ce_at(ubase, int64_t(PL::TS * r - PL::N) * out.ld, v0 + (wrapped ? 0u : vn)), cx<T>{v[r].x * out.sr, v[r].y * out.si});
         }
     } else {
-        T* d = reinterpret_cast<T*>(out.dst) + qx;
+        constexpr uint32_t ES = sizeof(T);
+        T* ubase = reinterpret_cast<T*>(out.dst);
+        const uint32_t vn = uint32_t(PL::N) * uint32_t(out.ld) * ES, v0 = (uint32_t(k0) * uint32_t(out.ld) + uint32_t(qx)) * ES;
         const T s2 = out.sr * out.sr * (out.epilogue == 2 ? out.weight : T(1));
 #pragma unroll
         for (int r = 0; r < C::P; ++r) {
-            int k = k0 + C::PL::TS * r;
-            k = k >= out.ny ? k - out.ny : k;
+            const bool wrapped = k0 >= PL::N - PL::TS * r;
+            T* o = reinterpret_cast<T*>(reinterpret_cast<char*>(ubase + int64_t(PL::TS * r - PL::N) * out.ld) + (v0 + (wrapped ? 0u : vn)));
             const T i2 = (v[r].x * v[r].x + v[r].y * v[r].y) * s2;
-            T* o = d + int64_t(k) * out.ld;
             *o = out.epilogue == 2 ? *o + i2 : i2;
         }
     }
+}
+// middle pass: v[r] = conj(v[r] h(k, col)), k = t + TS r -- the spectrum times the multiplier, conjugated for the inverse that follows
+// (KIND is a template argument: with both forms behind a run-time branch the register allocation of the tile spilled 50 .. 100 registers)
+template <typename C, int KIND>
+PM_HD void ce_mul_col(cx<typename C::T> (&v)[C::P], const CeMul<typename C::T>& mm, int c0, int sl, int t) {
+    using T = typename C::T;
+    using PL = typename C::PL;
+    constexpr uint32_t ES = sizeof(cx<T>);
+    const T sg = mm.conj ? T(-1) : T(1);      // a conjugated multiplier by the sign of its imaginary part: no second product to select from
+    if constexpr (KIND == 1) {       // MUL_FULL (the compiler hoists as many of the loads as the registers allow; batching them by hand spilled)
+        const cx<T>* ubase = mm.mul + c0;
+        const uint32_t v0 = (uint32_t(t) * uint32_t(mm.ld) + uint32_t(sl)) * ES;
+#pragma unroll
+        for (int r = 0; r < C::P; ++r) {
+            cx<T> h = mix_ld(ce_at(ubase, int64_t(PL::TS * r) * mm.ld, v0));
+            h.y *= sg;
+            const cx<T> x = cmul(v[r], h);
+            v[r] = cx<T>{x.x, -x.y};
+        }
+    } else {
+        cx<T> hx = mix_ld(mm.mul_x + c0 + sl);
+        const uint32_t v0 = uint32_t(t) * ES;
+#pragma unroll
+        for (int r = 0; r < C::P; ++r) {
+            cx<T> h = cmul(mix_ld(ce_at(mm.mul, PL::TS * r, v0)), hx);
+            h.y *= sg;
+            const cx<T> x = cmul(v[r], h);
+            v[r] = cx<T>{x.x, -x.y};
+        }
+    }
+}
+// ... and its store: conj(v) to natural rows of the intermediate, dst[k pitch + col]
+template <typename C>
+PM_HD void ce_store_mid(const cx<typename C::T> (&v)[C::P], cx<typename C::T>* dst, int64_t pitch, int c0, int sl, int t) {
+    using T = typename C::T;
+    constexpr uint32_t ES = sizeof(cx<T>);
+    cx<T>* ubase = dst + c0;
+    const uint32_t v0 = (uint32_t(t) * uint32_t(pitch) + uint32_t(sl)) * ES;
+#pragma unroll
+    for (int r = 0; r < C::P; ++r) mix_st(ce_at(ubase, int64_t(C::PL::TS * r) * pitch, v0), cx<T>{v[r].x, -v[r].y});
 }
 
 }  // namespace pm

@@ -43,22 +43,22 @@ __global__ __launch_bounds__(C::NT, ce_waves_per_eu<C>()) void ce_rows_kernel(Ce
     using T = typename C::T;
     extern __shared__ __align__(16) char ce_smem[];
     const CePos pos = ce_pos<C>(threadIdx.x);
-    const int row = int(blockIdx.x) * C::SEQS + pos.sl;
+    const int row0 = int(blockIdx.x) * C::SEQS, row = row0 + pos.sl, slc = row < in.nseq ? pos.sl : in.nseq - 1 - row0;
     cx<T> v[C::P];
     if constexpr (C::ABL & 1) {
 #pragma unroll
         for (int m = 0; m < C::P; ++m) v[m] = cx<T>{T(pos.tid + m), T(row)};
     } else {
-        ce_load<C, WIN>(v, in, row < in.nseq ? row : in.nseq - 1, pos.t);
+        ce_load<C, WIN>(v, in, row0, slc, pos.t);
     }
     ce_run<C, 0>(v, pos, ce_smem, tw);
     if constexpr (C::ABL & 2) {
         T acc = T(0);
 #pragma unroll
         for (int m = 0; m < C::P; ++m) acc += v[m].x * v[m].y;
-        if (acc == T(-12345.678)) ce_store_row<C>(v, out, row, pos.t);
+        if (acc == T(-12345.678)) ce_store_row<C>(v, out, row0, pos.sl, pos.t);
     } else {
-        if (row < in.nseq) ce_store_row<C>(v, out, row, pos.t);
+        if (row < in.nseq) ce_store_row<C>(v, out, row0, pos.sl, pos.t);
     }
 }
 
@@ -73,23 +73,50 @@ __global__ __launch_bounds__(C::NT, ce_waves_per_eu<C>()) void ce_cols_kernel(Ce
     const int c0 = tile * C::SEQS;
     if (c0 >= in.nseq) return;
     const CePos pos = ce_pos<C>(threadIdx.x);
-    const int col = c0 + pos.sl;
+    const int col = c0 + pos.sl, slc = col < in.nseq ? pos.sl : in.nseq - 1 - c0;
     cx<T> v[C::P];
     if constexpr (C::ABL & 1) {
 #pragma unroll
         for (int m = 0; m < C::P; ++m) v[m] = cx<T>{T(pos.tid + m), T(col)};
     } else {
-        ce_load<C, WIN>(v, in, col < in.nseq ? col : in.nseq - 1, pos.t);
+        ce_load<C, WIN>(v, in, c0, slc, pos.t);
     }
     ce_run<C, 0>(v, pos, ce_smem, tw);
     if constexpr (C::ABL & 2) {
         T acc = T(0);
 #pragma unroll
         for (int m = 0; m < C::P; ++m) acc += v[m].x * v[m].y;
-        if (acc == T(-12345.678)) ce_store_col<C>(v, out, col, pos.t);
+        if (acc == T(-12345.678)) ce_store_col<C>(v, out, c0, pos.sl, pos.t);
     } else {
-        if (col < in.nseq) ce_store_col<C>(v, out, col, pos.t);
+        if (col < in.nseq) ce_store_col<C>(v, out, c0, pos.sl, pos.t);
     }
+}
+
+// Middle pass of fft2 -> x H -> ifft2 on a composite column length: forward transform, multiplier, inverse transform on the registers of
+// the tile -- the spectrum comes out of the forward stages in the layout the loads had, so the second run starts where the first ended
+// (ifft = conj fft conj: the multiplier step leaves conj(x h), the store conjugates).  What mix_cols_mul_kernel does in LDS.
+template <typename C, bool WIN, int KIND>
+__global__ __launch_bounds__(C::NT, ce_waves_per_eu<C>()) void ce_cols_mul_kernel(CeIn<typename C::T> in, CeMul<typename C::T> mm, cx<typename C::T>* dst,
+                                                                                   int64_t dst_pitch, const cx<typename C::T>* __restrict__ tw, int log_g) {
+    using T = typename C::T;
+    extern __shared__ __align__(16) char ce_smem[];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = ((slot >> log_g) << (log_g + 3)) + (xcd << log_g) + (slot & ((1 << log_g) - 1));
+    const int c0 = tile * C::SEQS;
+    if (c0 >= in.nseq) return;
+    const CePos pos = ce_pos<C>(threadIdx.x);
+    const int col = c0 + pos.sl, slc = col < in.nseq ? pos.sl : in.nseq - 1 - c0;
+    cx<T> v[C::P];
+    ce_load<C, WIN>(v, in, c0, slc, pos.t);
+    ce_run<C, 0>(v, pos, ce_smem, tw);
+    ce_mul_col<C, KIND>(v, mm, c0, slc, pos.t);
+    __syncthreads();        // the last gather of the forward run has finished in every wave
+    // the second run loads its twiddles again: through a pointer the compiler cannot identify with the first, or it keeps every stage's
+    // twiddles of the forward run alive for the inverse (60 .. 130 registers spilled)
+    const cx<T>* tw2 = tw;
+    asm volatile("" : "+s"(tw2));
+    ce_run<C, 0>(v, pos, ce_smem, tw2);
+    if (col < in.nseq) ce_store_mid<C>(v, dst, dst_pitch, c0, pos.sl, pos.t);
 }
 
 template <typename C>
@@ -127,11 +154,39 @@ int ce_cols_go(const CeIn<typename C::T>& in, const CeColOut<typename C::T>& out
     return int(hipGetLastError());
 }
 
+template <typename C>
+int ce_cols_mul_go(const CeIn<typename C::T>& in, const CeMul<typename C::T>& mm, cx<typename C::T>* dst, int64_t dst_pitch, const cx<typename C::T>* tw,
+                   hipStream_t st, int log_g) {
+    const bool win = !(in.ax.off == 0 && in.ax.len == in.ax.n);
+    if (log_g < 0)
+        for (log_g = 0; (size_t(C::SEQS) << log_g) * sizeof(cx<typename C::T>) < 128 && log_g < 3;) ++log_g;
+    if (tuning().ce_log_g >= 0) log_g = tuning().ce_log_g > 8 ? 8 : tuning().ce_log_g;
+    const int tiles = (in.nseq + C::SEQS - 1) / C::SEQS, round = 8 << log_g, groups = (tiles + round - 1) / round * round;
+    auto go = [&](auto kernel) {
+        const int rc = mix_set_lds(kernel, C::LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kernel, dim3(groups), dim3(C::NT), C::LDS_BYTES, st, in, mm, dst, dst_pitch, tw, log_g);
+        return int(hipGetLastError());
+    };
+    if (mm.kind == MUL_FULL) return win ? go(ce_cols_mul_kernel<C, true, MUL_FULL>) : go(ce_cols_mul_kernel<C, false, MUL_FULL>);
+    return win ? go(ce_cols_mul_kernel<C, true, MUL_SEPARABLE>) : go(ce_cols_mul_kernel<C, false, MUL_SEPARABLE>);
+}
+
 // what the general entry points hand over (fft_mixed_kernels.h mix_rows_impl / mix_cols_impl)
 template <typename T>
-bool ce_rows_view(const DirectIn<T>& in, CeIn<T>& ci) {
+bool ce_rows_view(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, const RowStoreNat<T>* o, CeIn<T>& ci, CeRowOut<T>& ro) {
     if (in.real || in.synth || in.s_i != 1 || in.nseq <= 0) return false;
+    if (o && (o->use_ay || o->bstride || o->ax.n != in.ax.n)) return false;
     ci = CeIn<T>{in.src, in.s_seq, in.ax, in.nseq, in.conj ? T(-1) : T(1)};
+    ro = o ? CeRowOut<T>{o->dst, o->ld, 1, o->ax, o->scale, o->conj ? -o->scale : o->scale} : CeRowOut<T>{out, out_ld, 0, AxisMap{in.ax.n, in.ax.n, 0, 0}, T(1), T(1)};
+    return true;
+}
+template <typename T>
+bool ce_mid_view(const DirectIn<T>& in, const MidMul<T>& m, CeIn<T>& ci, CeMul<T>& mm) {
+    if (in.real || in.synth || in.conj || in.s_seq != 1 || in.nseq <= 0) return false;
+    if ((m.kind != MUL_FULL && m.kind != MUL_SEPARABLE) || m.bstride || m.bstride_x || m.ystep > 1) return false;
+    ci = CeIn<T>{in.src, in.s_i, in.ax, in.nseq, T(1)};
+    mm = CeMul<T>{m.kind, m.conj, m.mul, m.mul_x, m.ld};
     return true;
 }
 template <typename T>

@@ -340,9 +340,9 @@ template <typename T>
 int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o, const MixFold<T>* fold) {
     const int n = in.ax.n, nseq = in.nseq;
     if (nseq <= 0 || n <= 0) return 0;
-    if (!o && !fold && tuning().mix_engine) {     // a length with a compile-time plan, a plain view: the register engine (fft_ce.h)
+    if (!fold && tuning().mix_engine) {     // a length with a compile-time plan, a plain view: the register engine (fft_ce.h)
         int rc = 0;
-        if (ce_rows<T>(in, out, out_ld, st, &rc)) return rc;
+        if (ce_rows<T>(in, out, out_ld, o, st, &rc)) return rc;
     }
     if (fold && (o || nseq != 2 * fold->H || !mix_fits(n, int64_t(fold->H) * in.s_seq, sizeof(cx<T>), false) ||
                  (in.amp && !mix_fits(n, int64_t(fold->H) * in.amp_ld, sizeof(cx<T>), false))))
@@ -481,6 +481,10 @@ template <typename T>
 int mix_cols_mul_impl(const DirectIn<T>& in, const MidMul<T>& m, cx<T>* dst, int64_t dst_pitch, hipStream_t st) {
     const int n = in.ax.n, ncols = in.nseq;
     if (ncols <= 0 || n <= 0) return 0;
+    if (tuning().mix_engine) {
+        int rc = 0;
+        if (ce_cols_mul<T>(in, m, dst, dst_pitch, st, &rc)) return rc;
+    }
     MixPlan p;
     if (!mix_plan_for(n, sizeof(cx<T>), p)) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);
     if (in.s_seq != 1 || in.conj || in.real || !mix_fits(n, in.s_i, sizeof(cx<T>), true) || !mix_fits(n, dst_pitch, sizeof(cx<T>), true))

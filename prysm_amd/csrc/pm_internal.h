@@ -74,7 +74,8 @@ template <typename T>
 int mix_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t st);
 // the composite register engine (fft_ce.h): lengths with a compile-time plan, plain views.  false: not taken (the general kernel runs);
 // true: launched, *rc holds the status
-template <typename T> bool ce_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, int* rc);
+template <typename T> bool ce_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, const RowStoreNat<T>* o, hipStream_t st, int* rc);
+template <typename T> bool ce_cols_mul(const DirectIn<T>& in, const MidMul<T>& mm, cx<T>* dst, int64_t dst_pitch, hipStream_t st, int* rc);
 template <typename T> bool ce_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t st, int* rc);
 template <typename T> bool ce_has_plan(int n);      // lengths with a built plan (tools/ce_gen.py)
 // middle pass of fft2 -> x H -> ifft2 on a composite column length: the columns of the natural intermediate `in` (sequence = column) come

@@ -45,7 +45,7 @@ static double run_case(int nseq, int shift, int off, int len) {
     for (auto& v : x) v = {T(U(rng)), T(U(rng))};
     CeIn<T> in{x.data(), col ? nseq : len, AxisMap{n, len, off, shift}, nseq, T(1)};
     const int sy = 3 % n, sx = nseq > 2 ? 2 : 0;
-    CeRowOut<T> ro{y.data(), n};
+    CeRowOut<T> ro{y.data(), n, 0, AxisMap{n, n, 0, 0}, T(1), T(1)};
     CeColOut<T> co{y.data(), nseq, n, sy, nseq, sx, T(0.5), T(0.5), 0, T(1)};
     std::vector<typename CeLds<C>::type> lds(C::lds_elems() + 64);
     std::vector<cx<T>> regs(size_t(C::NT) * C::P);
@@ -54,16 +54,15 @@ static double run_case(int nseq, int shift, int off, int len) {
     for (int g = 0; g * C::SEQS < nseq; ++g) {
         for (int tid = 0; tid < C::NT; ++tid) {
             const CePos pos = ce_pos<C>(tid);
-            int seq = g * C::SEQS + pos.sl;
-            seq = seq < nseq ? seq : nseq - 1;
-            if (win) ce_load<C, true>(V(tid), in, seq, pos.t); else ce_load<C, false>(V(tid), in, seq, pos.t);
+            const int seq0 = g * C::SEQS, slc = seq0 + pos.sl < nseq ? pos.sl : nseq - 1 - seq0;
+            if (win) ce_load<C, true>(V(tid), in, seq0, slc, pos.t); else ce_load<C, false>(V(tid), in, seq0, slc, pos.t);
         }
         run_stages<C, 0>(regs, lds, tw.data());
         for (int tid = 0; tid < C::NT; ++tid) {
             const CePos pos = ce_pos<C>(tid);
             const int seq = g * C::SEQS + pos.sl;
             if (seq >= nseq) continue;
-            if (col) ce_store_col<C>(V(tid), co, seq, pos.t); else ce_store_row<C>(V(tid), ro, seq, pos.t);
+            if (col) ce_store_col<C>(V(tid), co, g * C::SEQS, pos.sl, pos.t); else ce_store_row<C>(V(tid), ro, g * C::SEQS, pos.sl, pos.t);
         }
     }
     double err = 0, ref = 0;

@@ -35,13 +35,15 @@ def fuzz_fused(ncases, rng, lib):
     """window(ifft2(fft2(pad(x)) * H)) * scale: fused 3-pass chain (powers of two) or two-call composition."""
     # (round 4: composite column lengths -- 96, 100, 323 = 17 x 19, 360, 1000, 1020, 1536 -- take the three-pass chain with the mixed-radix
     # middle pass; the knobs mix_fused / mix_pad flip between it and the composition, padded and unpadded LDS slots)
-    sizes = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 12, 20, 100, 96, 323, 360, 1000, 1020, 1536]
+    sizes = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 12, 20, 100, 96, 323, 360, 1000, 1020, 1536,
+             500, 900, 1500, 1600, 1800, 2000, 2500, 3000]      # round 5: lengths of the composite register engine (middle pass in registers)
     nfail, worst = 0, 0.0
     for case in range(ncases):
         big = rng.random() < 0.2
         M = int(rng.choice([2048, 4096] if big else sizes))
         N = int(rng.choice([2048, 4096] if big else sizes))
         lib.pm_set_tuning(b'mix_fused', int(rng.random() < 0.8))
+        lib.pm_set_tuning(b'mix_engine', int(rng.random() < 0.75))
         lib.pm_set_tuning(b'mix_pad', int(rng.random() < 0.7))
         if M * N > (1 << 23):
             N = 2048
@@ -97,7 +99,7 @@ def fuzz_fused(ncases, rng, lib):
         if not err < tol:
             nfail += 1
             print('fused case', case, 'FAIL err', err, (M, N, m, n, in_off, in_shift, (om, on), out_off, out_shift, cdt.__name__, B, sep, per_field, conj, fold))
-    for key, val in ((b'fold', -1), (b'mix_fused', 1), (b'mix_pad', 1)):
+    for key, val in ((b'fold', -1), (b'mix_fused', 1), (b'mix_pad', 1), (b'mix_engine', 1)):
         lib.pm_set_tuning(key, val)
     print(f'fuzz_fused: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
     return nfail
@@ -194,13 +196,15 @@ def fuzz_real_conv(ncases, rng, lib):
 def fuzz_fft1(ncases, rng, lib):
     """pm_fft1_ws through _ops.fft1: engine, direct, Bluestein, mixed-radix (3 / 5 / 7 x 2^k) and -- with the native length lowered --
     radix-2 / radix-4 lengths, both axes and directions, zero-padded inputs at an offset, windows of the bins, a scale."""
-    sizes = [2, 8, 64, 256, 1024, 4096, 3, 12, 36, 96, 100, 127, 160, 192, 224, 384, 640, 1000, 1536, 2560, 3584, 6144, 45, 250, 1001, 2592, 3000, 5000, 6000, 8190]
+    sizes = [2, 8, 64, 256, 1024, 4096, 3, 12, 36, 96, 100, 127, 160, 192, 224, 384, 640, 1000, 1536, 2560, 3584, 6144, 45, 250, 1001, 2592, 3000, 5000, 6000, 8190,
+             500, 900, 1500, 1800, 2500, 4000, 4500, 8000]
     nfail, worst = 0, 0.0
     for case in range(ncases):
         n = int(rng.choice(sizes))
         small = rng.random() < 0.3 and n in (64, 256)
         lib.pm_set_tuning(b'big_native_log', 5 if small else 13)      # 64 / 128 then take the radix-2 / radix-4 step; 256 goes direct
         lib.pm_set_tuning(b'mix', int(rng.choice([0, 2, 1, 1, 1, 1])))     # composite lengths: mostly their own kernel, sometimes round 2's routes
+        lib.pm_set_tuning(b'mix_engine', int(rng.random() < 0.75))
         if small:
             n = int(rng.choice([64, 128]))
         cdt = np.complex64 if rng.random() < 0.5 else np.complex128
@@ -233,6 +237,7 @@ def fuzz_fft1(ncases, rng, lib):
             print('fft1 case', case, 'FAIL err', err, (n, batch, ln, off, olen, ooff, axis, direction, cdt.__name__, small))
     lib.pm_set_tuning(b'big_native_log', 13)
     lib.pm_set_tuning(b'mix', 1)
+    lib.pm_set_tuning(b'mix_engine', 1)
     print(f'fuzz_fft1: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
     return nfail
 
