@@ -136,13 +136,15 @@ template <typename T> struct CeDft<T, 15> { static PM_HD void run(cx<T>* a) { ce
 template <typename T> struct CeDft<T, 20> { static PM_HD void run(cx<T>* a) { ce_dft_pfa<T, 4, 5>(a); } };
 template <typename T> struct CeDft<T, 24> { static PM_HD void run(cx<T>* a) { ce_dft_pfa<T, 8, 3>(a); } };
 template <typename T> struct CeDft<T, 30> { static PM_HD void run(cx<T>* a) { ce_dft_pfa<T, 5, 6>(a); } };
+template <typename T> struct CeDft<T, 40> { static PM_HD void run(cx<T>* a) { ce_dft_pfa<T, 8, 5>(a); } };
 
-// The twiddles w^k, k < R <= 32, of a thread's butterflies in one stage: w, w^4 and w^16 from the table, the others as at most three
-// products (fft_mixed.h MixTw, extended to 32)
+// The twiddles w^k, k < R <= 48, of a thread's butterflies in one stage: w, w^4 and w^16 from the table, the others as at most three
+// products (fft_mixed.h MixTw, extended)
 template <typename T, int R>
 struct CeTw {
-    cx<T> lo[4], hi[8];
+    cx<T> lo[4], hi[12];
     PM_HD CeTw(const cx<T>* __restrict__ tw, uint32_t idx) {
+        static_assert(R <= 48, "twiddle powers up to w^47");
         lo[0] = hi[0] = cx<T>{T(1), T(0)};
         lo[1] = mix_ld(tw + idx);
         hi[1] = R > 4 ? mix_ld(tw + 4u * idx) : lo[1];
@@ -154,6 +156,10 @@ struct CeTw {
         if (R > 20) hi[5] = cmul(hi[4], hi[1]);
         if (R > 24) hi[6] = cmul(hi[4], hi[2]);
         if (R > 28) hi[7] = cmul(hi[4], hi[3]);
+        if (R > 32) hi[8] = cmul(hi[4], hi[4]);
+        if (R > 36) hi[9] = cmul(hi[8], hi[1]);
+        if (R > 40) hi[10] = cmul(hi[8], hi[2]);
+        if (R > 44) hi[11] = cmul(hi[8], hi[3]);
     }
     PM_HD cx<T> operator()(int k) const {     // k is a constant after unrolling
         if (k < 4) return lo[k];

@@ -433,6 +433,9 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     // tiles that share a 128 B line run on one XCD (mix_cols_kernel): 2^log_g adjacent tiles, the grid padded to whole rounds of them
     int log_g = 0;
     while ((size_t(tc) << log_g) * sizeof(cx<T>) < 128 && log_g < 3) ++log_g;
+    // ... sixteen above 4096 points (round 5, one workgroup per CU, rotated outputs: 6006^2 558 -> 515 us, 4200^2 194 -> 182, 4800^2 / 7200^2
+    // 1 - 2 %; nothing either way below -- profiles/r05/exp_knob_mix_log_g.log)
+    if (n > 4096 && log_g < 4) log_g = 4;
     if (tuning().mix_log_g >= 0) log_g = tuning().mix_log_g > 4 ? 4 : tuning().mix_log_g;
     const int tiles = (ncols + tc - 1) / tc, round = 8 << log_g;
     // threads: one butterfly per thread of the busiest stage up to 512 -- and 1024 where the tile takes more than half the LDS (ONE

@@ -245,7 +245,7 @@ ROUTES = [
     ((323, 380), ['route=natural-mixed', 'rows=mixed-radix(380)', 'cols=mixed-radix(323)']),
     ((4096, 3000), ['route=natural-mixed', 'rows=mixed-radix-registers(3000)', 'cols=stockham(4096)']),
     ((3000, 4096), ['route=natural-mixed', 'rows=stockham(4096)', 'cols=mixed-radix-registers(3000)']),
-    ((1536, 1536), ['route=natural-mixed', 'rows=mixed-radix(1536)']),
+    ((1536, 1536), ['route=natural-mixed', 'rows=mixed-radix-registers(1536)']),
     ((36, 36), ['route=natural-mixed']),
     ((24, 24), ['route=natural ', 'rows=direct(24)', 'cols=direct(24)']),
     ((997, 997), ['route=bluestein-2d', 'conv=2048x2048']),

@@ -359,7 +359,7 @@ def test_mtf_ptf_otf_on_composite_grids(pa, n, rdt):
 # ---------------------------------------------------------------------------
 # composite register engine (csrc/fft_ce.h): every built plan against numpy fp64 and against the general mixed-radix kernel
 # ---------------------------------------------------------------------------
-CE_LENGTHS = [500, 900, 1000, 1500, 1600, 1800, 2000, 2500, 3000, 4000, 4500, 5000, 6000, 8000]
+CE_LENGTHS = [384, 500, 768, 900, 1000, 1152, 1280, 1500, 1536, 1600, 1800, 2000, 2304, 2500, 2560, 3000, 3072, 3600, 4000, 4500, 5000, 5120, 6000, 6144, 8000]
 
 
 def _ce_ref(x, shape, in_off, in_shift, out_shift, direction):

@@ -16,6 +16,17 @@ from ce_banks import pads  # noqa: E402
 # length: plan, shipped (rows, cols) shape, alternatives for sweeps
 TABLE = {
     'f32': {
+        384: ((24, 4, 4), (8, 1, 0), (4, 1, 0, 4), [], []),
+        768: ((24, 8, 4), (2, 1, 0), (4, 1, 0, 2), [], []),
+        1152: ((24, 8, 6), (1, 1, 0), (8, 1, 0, -1), [], []),
+        1280: ((20, 4, 4, 4), (1, 1, 0), (8, 1, 0, -1), [], []),
+        1536: ((24, 8, 8), (1, 1, 0), (8, 1, 0, 3), [], []),
+        2304: ((24, 12, 8), (2, 2, 0), (4, 1, 0, 3), [], []),
+        2560: ((40, 8, 8), (1, 2, 0), (4, 1, 3, 4), [], []),
+        3072: ((24, 8, 4, 4), (1, 2, 0), (4, 2, 0, 4), [], []),
+        3600: ((30, 30, 2, 2), (1, 2, 0), (4, 2, 4, 3), [], []),
+        5120: ((40, 8, 4, 4), (1, 2, 0), (4, 2, 3, 5), [], []),
+        6144: ((24, 8, 8, 4), (1, 2, 0), (4, 2, 0, 5), [], []),
         500: ((10, 10, 5), (4, 1, 0), (8, 1, 0, 2), [], []),
         900: ((30, 30), (2, 1, 0), (4, 1, 0, 2), [], []),
         1000: ((10, 10, 10), (2, 1, 0), (4, 1, 0, 5), [], []),
@@ -32,6 +43,17 @@ TABLE = {
         8000: ((20, 20, 20), (1, 2, 0), (2, 1, 0, 4), [], []),
     },
     'f64': {
+        384: ((24, 4, 4), (4, 1, 0), (4, 1, 0, -1), [], []),
+        768: ((24, 8, 4), (1, 1, 0), (4, 1, 0, -1), [], []),
+        1152: ((24, 8, 6), (1, 1, 0), (8, 2, 0, -1), [], []),
+        1280: ((20, 4, 4, 4), (1, 1, 3), (4, 1, 3, 3), [], []),
+        1536: ((24, 8, 8), (1, 2, 3), (4, 2, 3, 3), [], []),
+        2304: ((24, 12, 8), (2, 2, 3), (2, 2, 3, 4), [], []),
+        2560: ((40, 8, 8), (1, 2, 2), (4, 2, 2, 3), [], []),
+        3072: ((24, 8, 4, 4), (1, 2, 3), (4, 2, 3, 5), [], []),
+        3600: ((30, 30, 2, 2), (1, 2, 2), (4, 2, 2, 4), [], []),
+        5120: ((40, 8, 4, 4), (1, 2, 2), (2, 2, 2, 6), [], []),
+        6144: ((24, 8, 8, 4), (1, 2, 3), (2, 2, 3, 5), [], []),
         500: ((10, 10, 5), (2, 1, 0), (4, 1, 0, 4), [], []),
         900: ((30, 30), (2, 2, 2), (4, 2, 2, 2), [], []),
         1000: ((10, 10, 10), (1, 1, 0), (4, 1, 0, 1), [], []),
@@ -53,6 +75,12 @@ CT = {'f32': 'float', 'f64': 'double'}
 
 def cfg(ct, plan, col, shape):
     seqs, comp, wpe = shape[:3]
+    n = 1
+    for r in plan:
+        n *= r
+    lds = n * seqs * (4 if ct == 'float' else 8) * (2 if comp == 1 else 1) * 1.06
+    assert lds <= 150 * 1024, ('LDS of %s x %d (comp %d): %.0f KiB' % (plan, seqs, comp, lds / 1024))
+    assert n // plan[0] * seqs <= 1024, ('threads', plan, seqs)
     es = (4 if ct == 'float' else 8) * (2 if comp == 1 else 1)
     pp = [p[0][1] for p in pads(list(plan), seqs, col, min(es, 8))] + [0, 0, 0]
     return 'CeCfg<%s, CePlan<%s>, %d, %s, %d, %d, %d, %d, %d>' % (ct, ', '.join(map(str, plan)), seqs, 'true' if col else 'false', comp, pp[0], pp[1], pp[2], wpe)

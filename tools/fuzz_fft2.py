@@ -36,7 +36,7 @@ def fuzz_fused(ncases, rng, lib):
     # (round 4: composite column lengths -- 96, 100, 323 = 17 x 19, 360, 1000, 1020, 1536 -- take the three-pass chain with the mixed-radix
     # middle pass; the knobs mix_fused / mix_pad flip between it and the composition, padded and unpadded LDS slots)
     sizes = [4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 12, 20, 100, 96, 323, 360, 1000, 1020, 1536,
-             500, 900, 1500, 1600, 1800, 2000, 2500, 3000]      # round 5: lengths of the composite register engine (middle pass in registers)
+             500, 900, 1500, 1600, 1800, 2000, 2500, 3000, 768, 1152, 1280, 2304, 3072]      # round 5: lengths of the composite register engine (middle pass in registers)
     nfail, worst = 0, 0.0
     for case in range(ncases):
         big = rng.random() < 0.2
@@ -339,7 +339,7 @@ def main():
     lib = L.load()
     sizes = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 3, 5, 9, 12, 20, 36, 100, 96, 127, 160, 200, 224, 384, 1000, 1536, 45, 77, 143, 250, 360, 729, 1001, 1250,
              2592, 323, 1020, 1900,   # engine, direct, Bluestein, radix-R step and mixed-radix (composite; round 4: primes 17 / 19 too) lengths
-             500, 900, 1500, 1600, 1800, 2000, 2500, 3000]   # round 5: lengths of the composite register engine (fft_ce.h)
+             500, 900, 1500, 1600, 1800, 2000, 2500, 3000, 384, 768, 1152, 1280, 2304, 2560, 3072]   # round 5: lengths of the composite register engine (fft_ce.h)
     worst = 0.0
     nfail = 0
     for case in range(ncases):
@@ -352,7 +352,7 @@ def main():
         if rng.random() < 0.04:     # round 4: a composite above 8192 beside a short axis (one radix-R step around mixed-radix sub-transforms)
             M, N = (int(rng.choice([9000, 10000, 12000])), int(rng.choice([64, 96, 100]))) if rng.random() < 0.5 else (int(rng.choice([64, 100])), int(rng.choice([10000, 20000])))
         if rng.random() < 0.05:     # round 5: the long plans of the composite register engine beside a short axis
-            big_ce = int(rng.choice([4000, 4500, 5000, 6000, 8000]))
+            big_ce = int(rng.choice([3600, 4000, 4500, 5000, 5120, 6000, 6144, 8000]))
             M, N = (big_ce, int(rng.choice([64, 100, 500]))) if rng.random() < 0.5 else (int(rng.choice([64, 100, 900])), big_ce)
         lib.pm_set_tuning(b'mix_pad', int(rng.random() < 0.7))
         lib.pm_set_tuning(b'mix_engine', int(rng.random() < 0.75))     # ... whose lengths also keep running on the general kernel
