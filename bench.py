@@ -359,13 +359,25 @@ def other_configs(only=''):
         x6 = torch.from_numpy(make_field(8192, np.complex64, 8192)).cuda()
         out['focus_8192_c64'] = _hbm_entry(_event_ms(lambda: P.focus(x6, 1), 20), 4 * 8192 ** 2 * 8)
         del x6
-    def sec_composite():   # lengths scipy factors natively (prysm/propagation/fft.py:24): the mixed-radix kernel (csrc/fft_mixed.h), 4 N^2 s bytes
+    def sec_composite():
+        # lengths scipy factors natively (prysm/propagation/fft.py:24): the composite register engine (csrc/fft_ce.h, round 5) where the
+        # length has a compile-time plan, else the general mixed-radix kernel (csrc/fft_mixed.h); 4 N^2 s bytes
+        from prysm_amd import _lib as L_
         for n, cdt, key in ((3000, np.complex64, 'focus_3000_c64_mixed_radix'), (1000, np.complex64, 'focus_1000_c64_mixed_radix'),
                             (3000, np.complex128, 'focus_3000_c128_mixed_radix')):
             xc = torch.from_numpy(make_field(n, cdt, n)).cuda()
             out[key] = _hbm_entry(_event_ms(lambda: P.focus(xc, 1), 50), 4 * n ** 2 * xc.element_size(),
-                                  'composite length on its own factors (LDS-resident mixed radix, one kernel per axis); round 2 convolved these at '
-                                  'the next power of two above 2 N (Bluestein)')
+                                  'composite length on its own factors, register-resident with a compile-time plan (round 5; until round 4 '
+                                  'LDS-resident with a run-time plan: general_kernel_ms)')
+            with L_.tuning_local(mix_engine=0):
+                out[key]['general_kernel_ms'] = _event_ms(lambda: P.focus(xc, 1), 50)
+            del xc
+        # round 5: the Q = 1.5 pad of a 1024^2 pupil (prysm/propagation/fft.py:7-25 with Q = 1.5 -> 1536^2, plan 24 x 8 x 8) and a 2000^2 grid
+        for n, cdt, key in ((1536, np.complex64, 'focus_1536_c64_composite'), (2000, np.complex128, 'focus_2000_c128_composite')):
+            xc = torch.from_numpy(make_field(n, cdt, n)).cuda()
+            out[key] = _hbm_entry(_event_ms(lambda: P.focus(xc, 1), 50), 4 * n ** 2 * xc.element_size())
+            with L_.tuning_local(mix_engine=0):
+                out[key]['general_kernel_ms'] = _event_ms(lambda: P.focus(xc, 1), 50)
             del xc
         # 6006 = 6 x 7 x 11 x 13 (the mixed-radix kernel as it is) and 10000 = 2 x 5000 (round 4: one radix-2 step around
         # mixed-radix sub-transforms; rounds 1 - 3 convolved it at 32768 points per axis)
@@ -374,16 +386,18 @@ def other_configs(only=''):
             out[key] = _hbm_entry(_event_ms(lambda: P.focus(xc, 1), 10, warm=2), 4 * n ** 2 * xc.element_size())
             del xc
         # the free-space step on a composite grid (prysm/propagation/angular_spectrum.py:9-42 takes any size): three passes with the
-        # mixed-radix middle pass (round 4), graded like config 3 on 8 N^2 s; `composed_ms`: two pm_fft2 calls (rounds 1 - 3)
-        from prysm_amd import _lib as L_
+        # middle pass resident on chip (round 4: in LDS; round 5: in registers), graded like config 3 on 8 N^2 s; `composed_ms`: two pm_fft2
+        # calls (rounds 1 - 3)
         for n, cdt, prec_, key in ((3000, np.complex128, 64, 'angular_spectrum_3000_c128_composite'), (3000, np.complex64, 32, 'angular_spectrum_3000_c64_composite')):
             xa = torch.from_numpy(make_field(n, cdt, n + 1)).cuda()
             prec0 = config.precision
             config.precision = prec_
             try:
                 e = _hbm_entry(_event_ms(lambda: P.angular_spectrum(xa, 0.6328, 0.01, 10.0, Q=1), 30), 8 * n ** 2 * xa.element_size(),
-                               'fft2 x H ifft2 on a 3000^2 grid: mixed-radix row pass, middle pass with the column resident in LDS (forward stages, '
-                               'x H, transposed stages), mixed-radix inverse row pass; graded on 8 N^2 s, moves 6 N^2 s')
+                               'fft2 x H ifft2 on a 3000^2 grid: row pass, middle pass with the column tile resident in registers (forward transform, '
+                               'x H, inverse transform), inverse row pass; graded on 8 N^2 s, moves 6 N^2 s')
+                with L_.tuning_local(mix_engine=0):
+                    e['general_kernel_ms'] = _event_ms(lambda: P.angular_spectrum(xa, 0.6328, 0.01, 10.0, Q=1), 30)
                 with L_.tuning_local(mix_fused=0):
                     e['composed_ms'] = _event_ms(lambda: P.angular_spectrum(xa, 0.6328, 0.01, 10.0, Q=1), 30)
             finally:
