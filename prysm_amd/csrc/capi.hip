@@ -1707,11 +1707,14 @@ int pm_plan_explain(const pm_fft2_desc* d, int32_t op, char* buf, size_t n) {
         const bool en = p.logn >= 0, em = p.logm >= 0;
         // a composite axis whose length has a compile-time plan runs on the register engine (fft_ce.h) when the view is plain
         const bool f32 = d->dtype == PM_C64;
+        const size_t es = f32 ? 8 : 16;
         const bool ce_n = p.mix_n && !p.mix_fold && tuning().mix_engine && !(d->flags & (PM_FLAG_REAL_INPUT | PM_FLAG_SYNTH_INPUT)) &&
-                          (f32 ? ce_has_plan<float>(int(N)) : ce_has_plan<double>(int(N)));
+                          (f32 ? ce_has_plan<float>(int(N)) : ce_has_plan<double>(int(N))) && ce_fits32(kCeMaxSeqs * d->in_ld + 2 * N, es) &&
+                          ce_fits32(kCeMaxSeqs * p.w_ld + 2 * N, es);
         const bool whole_out = d->out_y.off == 0 && d->out_y.len == M && d->out_x.off == 0 && d->out_x.len == N;
         const bool ce_m = p.mix_m && !p.mix_fold && tuning().mix_engine && whole_out && !d->mul && d->epilogue <= PM_EPI_ABS2_ACCUM &&
-                          (f32 ? ce_has_plan<float>(int(M)) : ce_has_plan<double>(int(M)));
+                          (f32 ? ce_has_plan<float>(int(M)) : ce_has_plan<double>(int(M))) && ce_fits32(2 * M * p.w_ld + kCeMaxSeqs, es) &&
+                          ce_fits32(2 * M * d->out_ld + N, es);
         snprintf(buf, n, "fft2 %lldx%lld %s: route=%s rows=%s(%lld) cols=%s(%lld%s) tile=%d log_k=%d chunk=%lld ws=%zu", M, N, dt,
                  (en && em) ? (p.fold ? "engine-fold" : "engine") : ((p.mix_n || !p.blue_n) && (p.mix_m || !p.blue_m) && (p.mix_n || p.mix_m) ? "natural-mixed" : "natural"),
                  ce_n ? "mixed-radix-registers" : axis_route(en, p.mix_n, p.blue_n), N, ce_m ? "mixed-radix-registers" : axis_route(em, p.mix_m, p.blue_m),

@@ -172,21 +172,19 @@ int ce_cols_mul_go(const CeIn<typename C::T>& in, const CeMul<typename C::T>& mm
     return win ? go(ce_cols_mul_kernel<C, true, MUL_SEPARABLE>) : go(ce_cols_mul_kernel<C, false, MUL_SEPARABLE>);
 }
 
-// what the general entry points hand over (fft_mixed_kernels.h mix_rows_impl / mix_cols_impl)
+// what the general entry points hand over (fft_mixed_kernels.h mix_rows_impl / mix_cols_impl / mix_cols_mul_impl).  The kernels address
+// with one unsigned 32-bit BYTE offset per lane (fft_ce.h ce_at): the largest one a view can produce must fit, else the general kernel runs.
+// (ce_fits32, kCeMaxSeqs: pm_internal.h)
+
 template <typename T>
 bool ce_rows_view(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, const RowStoreNat<T>* o, CeIn<T>& ci, CeRowOut<T>& ro) {
     if (in.real || in.synth || in.s_i != 1 || in.nseq <= 0) return false;
     if (o && (o->use_ay || o->bstride || o->ax.n != in.ax.n)) return false;
+    const int64_t n = in.ax.n, old_ = o ? o->ld : out_ld;
+    // loads: (sl pitch + q0 + N) elements; stores: (sl ld + q0 + N)
+    if (in.s_seq < 0 || old_ < 0 || !ce_fits32(kCeMaxSeqs * in.s_seq + 2 * n, sizeof(cx<T>)) || !ce_fits32(kCeMaxSeqs * old_ + 2 * n, sizeof(cx<T>))) return false;
     ci = CeIn<T>{in.src, in.s_seq, in.ax, in.nseq, in.conj ? T(-1) : T(1)};
     ro = o ? CeRowOut<T>{o->dst, o->ld, 1, o->ax, o->scale, o->conj ? -o->scale : o->scale} : CeRowOut<T>{out, out_ld, 0, AxisMap{in.ax.n, in.ax.n, 0, 0}, T(1), T(1)};
-    return true;
-}
-template <typename T>
-bool ce_mid_view(const DirectIn<T>& in, const MidMul<T>& m, CeIn<T>& ci, CeMul<T>& mm) {
-    if (in.real || in.synth || in.conj || in.s_seq != 1 || in.nseq <= 0) return false;
-    if ((m.kind != MUL_FULL && m.kind != MUL_SEPARABLE) || m.bstride || m.bstride_x || m.ystep > 1) return false;
-    ci = CeIn<T>{in.src, in.s_i, in.ax, in.nseq, T(1)};
-    mm = CeMul<T>{m.kind, m.conj, m.mul, m.mul_x, m.ld};
     return true;
 }
 template <typename T>
@@ -195,9 +193,24 @@ bool ce_cols_view(const DirectIn<T>& in, const ColStoreNat<T>& out, CeIn<T>& ci,
     const bool whole = out.ay.off == 0 && out.ay.len == out.ay.n && out.ax.off == 0 && out.ax.len == out.ax.n;
     if (!whole || out.mul_kind != MUL_NONE || out.ay.n != in.ax.n || out.ax.n != in.nseq) return false;
     if (out.epilogue != EPI_NONE && out.epilogue != EPI_ABS2 && out.epilogue != EPI_ABS2_ACCUM) return false;
+    const int64_t n = in.ax.n;
+    // loads: (q0 + N) pitch + sl elements; stores: (k0 + N) ld + qx
+    if (in.s_i < 0 || out.ld < 0 || !ce_fits32(2 * n * in.s_i + kCeMaxSeqs, sizeof(cx<T>)) || !ce_fits32(2 * n * out.ld + out.ax.n, sizeof(cx<T>))) return false;
     ci = CeIn<T>{in.src, in.s_i, in.ax, in.nseq, in.conj ? T(-1) : T(1)};
     co = CeColOut<T>{out.dst, out.ld, out.ay.n, out.ay.shift, out.ax.n, out.ax.shift, out.scale, out.conj ? -out.scale : out.scale,
                      out.epilogue, out.weight};
+    return true;
+}
+template <typename T>
+bool ce_mid_view(const DirectIn<T>& in, const MidMul<T>& m, int64_t dst_pitch, CeIn<T>& ci, CeMul<T>& mm) {
+    if (in.real || in.synth || in.conj || in.s_seq != 1 || in.nseq <= 0) return false;
+    if ((m.kind != MUL_FULL && m.kind != MUL_SEPARABLE) || m.bstride || m.bstride_x || m.ystep > 1) return false;
+    const int64_t n = in.ax.n;
+    if (in.s_i < 0 || dst_pitch < 0 || !ce_fits32(2 * n * in.s_i + kCeMaxSeqs, sizeof(cx<T>)) || !ce_fits32(n * dst_pitch + kCeMaxSeqs, sizeof(cx<T>)) ||
+        (m.kind == MUL_FULL && (m.ld < 0 || !ce_fits32(n * m.ld + kCeMaxSeqs, sizeof(cx<T>)))))
+        return false;
+    ci = CeIn<T>{in.src, in.s_i, in.ax, in.nseq, T(1)};
+    mm = CeMul<T>{m.kind, m.conj, m.mul, m.mul_x, m.ld};
     return true;
 }
 

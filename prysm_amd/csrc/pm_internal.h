@@ -78,6 +78,9 @@ template <typename T> bool ce_rows(const DirectIn<T>& in, cx<T>* out, int64_t ou
 template <typename T> bool ce_cols_mul(const DirectIn<T>& in, const MidMul<T>& mm, cx<T>* dst, int64_t dst_pitch, hipStream_t st, int* rc);
 template <typename T> bool ce_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t st, int* rc);
 template <typename T> bool ce_has_plan(int n);      // lengths with a built plan (tools/ce_gen.py)
+// its kernels address with one unsigned 32-bit byte offset per lane: the largest offset of a view must fit
+static inline bool ce_fits32(int64_t elems, size_t es) { return elems >= 0 && uint64_t(elems) * es < (uint64_t(1) << 32); }
+constexpr int kCeMaxSeqs = 16;      // sequences per workgroup of any built shape
 // middle pass of fft2 -> x H -> ifft2 on a composite column length: the columns of the natural intermediate `in` (sequence = column) come
 // back in dst[row * dst_pitch + column] as the unnormalised inverse column transform of (column spectrum x H); in place allowed
 template <typename T>

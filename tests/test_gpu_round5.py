@@ -428,3 +428,21 @@ def test_composite_engine_through_the_wavefront_api(pa):
         assert rel_max(got, O.focus(x.astype(np.complex128), 1)) < tol
         back = tonp(P.unfocus(torch.from_numpy(got).cuda(), 1))
         assert rel_max(back, x) < 4 * tol
+
+
+def test_composite_engine_hands_wide_arrays_to_the_general_kernel(pa):
+    """The engine's kernels address with one unsigned 32-bit byte offset per lane (2 n pitch s < 2^32, csrc/pm_internal.h ce_fits32); a
+    column transform of 8000 points down a 20000-wide complex128 array is past that and inside the general kernel's range: both widths
+    against numpy on sampled columns."""
+    from prysm_amd import _ops
+    n = 8000
+    for width in (16000, 20000):        # 4.1e9 and 5.1e9 bytes of 2 n pitch s
+        g = torch.Generator(device='cuda').manual_seed(width)
+        x = torch.randn(n, width, dtype=torch.float64, device='cuda', generator=g).to(torch.complex128)
+        x += 1j * torch.randn(n, width, dtype=torch.float64, device='cuda', generator=g)
+        y = _ops.fft1(x, n, axis=0)
+        cols = [0, 3, width // 2 + 1, width - 1]
+        want = np.fft.fft(x[:, cols].cpu().numpy(), axis=0)
+        assert rel_max(y[:, cols].cpu().numpy(), want) < TOL64, width
+        del x, y
+        torch.cuda.empty_cache()

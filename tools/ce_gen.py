@@ -81,6 +81,7 @@ def cfg(ct, plan, col, shape):
     lds = n * seqs * (4 if ct == 'float' else 8) * (2 if comp == 1 else 1) * 1.06
     assert lds <= 150 * 1024, ('LDS of %s x %d (comp %d): %.0f KiB' % (plan, seqs, comp, lds / 1024))
     assert n // plan[0] * seqs <= 1024, ('threads', plan, seqs)
+    assert seqs <= 16, 'fft_ce_kernels.h kCeMaxSeqs'
     es = (4 if ct == 'float' else 8) * (2 if comp == 1 else 1)
     pp = [p[0][1] for p in pads(list(plan), seqs, col, min(es, 8))] + [0, 0, 0]
     return 'CeCfg<%s, CePlan<%s>, %d, %s, %d, %d, %d, %d, %d>' % (ct, ', '.join(map(str, plan)), seqs, 'true' if col else 'false', comp, pp[0], pp[1], pp[2], wpe)
@@ -152,7 +153,7 @@ def emit(prec, col, exp, mid=False):
         L.append('template <> bool ce_cols_mul<%s>(const DirectIn<%s>& in, const MidMul<%s>& m, cx<%s>* dst, int64_t dst_pitch, hipStream_t st, int* rc) {' % (ct, ct, ct, ct))
         L.append('    CeIn<%s> ci;' % ct)
         L.append('    CeMul<%s> mm;' % ct)
-        L.append('    if (!ce_mid_view(in, m, ci, mm)) return false;')
+        L.append('    if (!ce_mid_view(in, m, dst_pitch, ci, mm)) return false;')
         L.append('    const int n = in.ax.n;')
         L.append('    if (%s) return false;' % ' && '.join('n != %d' % n for n in lens))
         L.append('    int err = 0;')
