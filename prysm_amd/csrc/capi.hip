@@ -1708,7 +1708,7 @@ int pm_plan_explain(const pm_fft2_desc* d, int32_t op, char* buf, size_t n) {
         // a composite axis whose length has a compile-time plan runs on the register engine (fft_ce.h) when the view is plain
         const bool f32 = d->dtype == PM_C64;
         const size_t es = f32 ? 8 : 16;
-        const bool ce_n = p.mix_n && !p.mix_fold && tuning().mix_engine && !(d->flags & (PM_FLAG_REAL_INPUT | PM_FLAG_SYNTH_INPUT)) &&
+        const bool ce_n = p.mix_n && !p.mix_fold && tuning().mix_engine && !(d->flags & PM_FLAG_REAL_INPUT) && (f32 || !(d->flags & PM_FLAG_SYNTH_INPUT)) &&
                           (f32 ? ce_has_plan<float>(int(N)) : ce_has_plan<double>(int(N))) && ce_fits32(kCeMaxSeqs * d->in_ld + 2 * N, es) &&
                           ce_fits32(kCeMaxSeqs * p.w_ld + 2 * N, es);
         const bool whole_out = d->out_y.off == 0 && d->out_y.len == M && d->out_x.off == 0 && d->out_x.len == N;

@@ -282,6 +282,16 @@ struct CeIn {
     int nseq;
     T ysign;        // -1: conjugated input
 };
+// pupil synthesis in the row loads (DirectIn::synth, fft_io.h synth_value): the element is amp exp(2 pi i k2 opd) from packed (amplitude, OPD)
+// pairs (kind 3) or from the OPD map and a separate amplitude array (kind 2) -- Wavefront.from_amp_and_phase(...).focus() on a composite
+// grid never writes the complex pupil (prysm/propagation/wavefront.py:58-79)
+struct CeSynth {
+    int kind;
+    double k2;
+    const void* amp;
+    int amp_kind;
+    int64_t amp_ld;
+};
 template <typename T>
 struct CeRowOut {
     cx<T>* dst;
@@ -367,6 +377,36 @@ PM_HD void ce_load(cx<typename C::T> (&v)[C::P], const CeIn<typename C::T>& in, 
     }
 #pragma unroll
     for (int m = 0; m < C::P; ++m) v[m].y *= in.ysign;
+}
+// ... synthesised: the raw pairs first (all loads in flight), then the sine / cosine
+template <typename C, int SYN>
+PM_HD void ce_load_synth(cx<typename C::T> (&v)[C::P], const CeIn<typename C::T>& in, const CeSynth& sy, int seq0, int sl, int t) {
+    using T = typename C::T;
+    using PL = typename C::PL;
+    const int64_t row = seq0 + sl;
+    const int q0 = ce_rot0<PL::N>(t, in.ax.shift);
+    const cx<T>* pk = in.src + row * in.pitch;                                        // SYN 3: packed pairs, pitch in pairs
+    const T* od = reinterpret_cast<const T*>(in.src) + row * in.pitch;                // SYN 2: OPD map, pitch in real elements
+    bool ok[C::P];
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        int p = q0 + PL::TS * m;
+        p = p >= PL::N ? p - PL::N : p;
+        const int q = p - in.ax.off;
+        ok[m] = unsigned(q) < unsigned(in.ax.len);
+        const int qq = ok[m] ? q : 0;
+        if (SYN == 3) {
+            v[m] = mix_ld(pk + qq);
+        } else {
+            v[m].y = od[qq];
+            v[m].x = synth_amp<T>(sy.amp, sy.amp_kind, row * sy.amp_ld + qq);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < C::P; ++m) {
+        const cx<T> x = synth_value<T>(v[m].y, v[m].x, sy.k2);
+        v[m] = ok[m] ? x : cx<T>{T(0), T(0)};
+    }
 }
 template <typename C>
 PM_HD void ce_store_row(const cx<typename C::T> (&v)[C::P], const CeRowOut<typename C::T>& out, int row0, int sl, int t) {

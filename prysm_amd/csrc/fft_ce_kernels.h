@@ -37,9 +37,10 @@ constexpr int ce_waves_per_eu() {
     return need < fit ? need : (fit < 1 ? 1 : fit);
 }
 
-template <typename C, bool WIN>
+// SYN 0: the rows are read; 2 / 3: synthesised from the OPD map + amplitude / from packed pairs (complex64 only: CeSynth)
+template <typename C, bool WIN, int SYN = 0>
 __global__ __launch_bounds__(C::NT, ce_waves_per_eu<C>()) void ce_rows_kernel(CeIn<typename C::T> in, CeRowOut<typename C::T> out,
-                                                                               const cx<typename C::T>* __restrict__ tw) {
+                                                                               const cx<typename C::T>* __restrict__ tw, CeSynth sy) {
     using T = typename C::T;
     extern __shared__ __align__(16) char ce_smem[];
     const CePos pos = ce_pos<C>(threadIdx.x);
@@ -48,6 +49,8 @@ __global__ __launch_bounds__(C::NT, ce_waves_per_eu<C>()) void ce_rows_kernel(Ce
     if constexpr (C::ABL & 1) {
 #pragma unroll
         for (int m = 0; m < C::P; ++m) v[m] = cx<T>{T(pos.tid + m), T(row)};
+    } else if constexpr (SYN != 0) {
+        ce_load_synth<C, SYN>(v, in, sy, row0, slc, pos.t);
     } else {
         ce_load<C, WIN>(v, in, row0, slc, pos.t);
     }
@@ -120,19 +123,20 @@ __global__ __launch_bounds__(C::NT, ce_waves_per_eu<C>()) void ce_cols_mul_kerne
 }
 
 template <typename C>
-int ce_rows_go(const CeIn<typename C::T>& in, const CeRowOut<typename C::T>& out, const cx<typename C::T>* tw, hipStream_t st) {
+int ce_rows_go(const CeIn<typename C::T>& in, const CeRowOut<typename C::T>& out, const cx<typename C::T>* tw, hipStream_t st, const CeSynth& sy) {
     const bool win = !(in.ax.off == 0 && in.ax.len == in.ax.n);
     const int groups = (in.nseq + C::SEQS - 1) / C::SEQS;
-    if (win) {
-        const int rc = mix_set_lds(ce_rows_kernel<C, true>, C::LDS_BYTES);
+    auto go = [&](auto kernel) {
+        const int rc = mix_set_lds(kernel, C::LDS_BYTES);
         if (rc) return rc;
-        hipLaunchKernelGGL((ce_rows_kernel<C, true>), dim3(groups), dim3(C::NT), C::LDS_BYTES, st, in, out, tw);
-    } else {
-        const int rc = mix_set_lds(ce_rows_kernel<C, false>, C::LDS_BYTES);
-        if (rc) return rc;
-        hipLaunchKernelGGL((ce_rows_kernel<C, false>), dim3(groups), dim3(C::NT), C::LDS_BYTES, st, in, out, tw);
+        hipLaunchKernelGGL(kernel, dim3(groups), dim3(C::NT), C::LDS_BYTES, st, in, out, tw, sy);
+        return int(hipGetLastError());
+    };
+    if constexpr (sizeof(typename C::T) == 4) {
+        if (sy.kind == 3) return go(ce_rows_kernel<C, true, 3>);
+        if (sy.kind == 2) return go(ce_rows_kernel<C, true, 2>);
     }
-    return int(hipGetLastError());
+    return win ? go(ce_rows_kernel<C, true>) : go(ce_rows_kernel<C, false>);
 }
 template <typename C>
 int ce_cols_go(const CeIn<typename C::T>& in, const CeColOut<typename C::T>& out, const cx<typename C::T>* tw, hipStream_t st, int log_g) {
@@ -177,8 +181,10 @@ int ce_cols_mul_go(const CeIn<typename C::T>& in, const CeMul<typename C::T>& mm
 // (ce_fits32, kCeMaxSeqs: pm_internal.h)
 
 template <typename T>
-bool ce_rows_view(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, const RowStoreNat<T>* o, CeIn<T>& ci, CeRowOut<T>& ro) {
-    if (in.real || in.synth || in.s_i != 1 || in.nseq <= 0) return false;
+bool ce_rows_view(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, const RowStoreNat<T>* o, CeIn<T>& ci, CeRowOut<T>& ro, CeSynth& sy) {
+    if (in.real || in.s_i != 1 || in.nseq <= 0) return false;
+    if (in.synth && (sizeof(T) != 4 || (in.synth != 2 && in.synth != 3))) return false;      // synthesis: complex64 only (the fp64 sincospi does not fit the tile's registers)
+    sy = CeSynth{in.synth, in.k2, in.amp, in.amp ? in.amp_kind : 0, in.amp_ld};
     if (o && (o->use_ay || o->bstride || o->ax.n != in.ax.n)) return false;
     const int64_t n = in.ax.n, old_ = o ? o->ld : out_ld;
     // loads: (sl pitch + q0 + N) elements; stores: (sl ld + q0 + N)

@@ -446,3 +446,29 @@ def test_composite_engine_hands_wide_arrays_to_the_general_kernel(pa):
         assert rel_max(y[:, cols].cpu().numpy(), want) < TOL64, width
         del x, y
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('n,Q', [(1000, 1), (750, 2), (1536, 1), (2000, 1)])
+def test_composite_engine_synthesises_the_pupil_in_its_row_loads(pa, n, Q):
+    """Wavefront.from_amp_and_phase(amp, opd, wvl).focus(efl, Q) on composite grids (prysm/propagation/wavefront.py:58-79, 478-504): the
+    complex64 pupil is formed in the register engine's row loads from the OPD map + amplitude and from packed pairs, padded by Q, against
+    the oracle -- and equal to the general kernel's synthesis."""
+    from prysm_amd import _lib, _ops
+    rng = np.random.default_rng(n + Q)
+    amp = (rng.random((n, n)) > 0.25).astype(np.float32)
+    opd = (150 * rng.standard_normal((n, n))).astype(np.float32)
+    wvl = 0.6328
+    want = O.focus(O.from_amp_and_phase(amp, opd.astype(np.float64), wvl), Q)
+    N = n * Q
+    off = (N - n) // 2
+    k = 2 * np.pi / wvl / 1e3
+    kw = dict(direction=-1, scale=1.0 / np.sqrt(N * N), shape=(N, N), in_off=(off, off), in_shift=(N // 2, N // 2), out_shift=(N // 2, N // 2))
+    od, ad = torch.from_numpy(opd).cuda(), torch.from_numpy(amp).cuda()
+    got = {}
+    for eng in (1, 0):
+        with _lib.tuning_local(mix_engine=eng):
+            got[eng] = _ops.fft2(od, synth=(ad, k), **kw).cpu().numpy()
+            packed = _ops.fft2(_ops.pack_amp_opd(ad, od), synth=('packed', k), **kw).cpu().numpy()
+        assert got[eng].dtype == np.complex64
+        assert rel_max(got[eng], want) < 2e-5 and rel_max(packed, want) < 2e-5, (n, Q, eng)
+    assert rel_max(got[1], got[0]) < 2e-5

@@ -2,7 +2,7 @@
 
     python tools/exp_knob_ab.py stagger_group 0,1 focus/c64/8192 mtf/f32/4096 as/c128/4096 [rounds]
 
-workloads: focus/<c64|c128>/<n>[/Q]  unfocus/...  as/<c64|c128>/<n>  mtf/<f32|f64>/<n>  mdft/<c64|c128>/<n>"""
+workloads: focus/<c64|c128>/<n>[/Q]  unfocus/...  as/<c64|c128>/<n>  mtf/<f32|f64>/<n>  mdft/<c64|c128>/<n>  synth/f32/<n>[/Q]"""
 import sys
 
 import torch
@@ -47,6 +47,15 @@ def make(spec):
         x = torch.randn(n, n, dtype=cd, device='cuda')
         ex = P.prepare_executor(10 / n, (n, n), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0)
         return (lambda: P.focus_dft(x, ex)), 30
+    if kind == 'synth':     # Wavefront.from_amp_and_phase(amp, opd).focus(Q): the pupil synthesised in the row loads, |.|^2 not taken
+        from prysm_amd import _ops
+        q = int(parts[3]) if len(parts) > 3 else 1
+        opd = (300 * torch.randn(n, n, dtype=cd, device='cuda'))
+        amp = (torch.rand(n, n, device='cuda') > 0.2).to(cd)
+        N = n * q
+        off = (N - n) // 2
+        return (lambda: _ops.fft2(opd, direction=-1, scale=1.0, shape=(N, N), in_off=(off, off), in_shift=(N // 2, N // 2), out_shift=(N // 2, N // 2),
+                                  synth=(amp, 2 * 3.141592653589793 / 0.55 / 1e3))), reps
     if kind == 'mtf':
         psf = torch.rand(n, n, dtype=cd, device='cuda') + 0.01
         return (lambda: otf.mtf_from_psf(psf, 1.0)), reps
