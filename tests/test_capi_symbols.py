@@ -262,7 +262,8 @@ ROUTES_KW = [
     (dict(m=3000, n=3000, real=True), ['route=natural-mixed', 'rows=mixed-radix(3000)', 'cols=mixed-radix-registers(3000)']),         # composite grids: no Hermitian path yet (the real array is read by the complex kernels)
     (dict(m=1024, n=1024, batch=100), ['route=engine ', 'chunk=16', 'ws=134217728']),
     (dict(m=4096, n=4096, synth=True), ['route=engine-fold']),
-    (dict(m=3000, n=3000, synth=True), ['rows=mixed-radix(3000)']),      # the pupil is synthesised in the general kernel's loads
+    (dict(m=3000, n=3000, synth=True), ['rows=mixed-radix-registers(3000)']),      # the complex64 pupil is synthesised in the register engine's loads
+    (dict(m=3000, n=3000, synth=True, dt='c128'), ['rows=mixed-radix(3000)']),       # ... the complex128 one in the general kernel's
     (dict(m=3000, n=3000, epi=1), ['cols=mixed-radix-registers(3000)']),    # |.|^2 in the engine's column store
     (dict(m=4096, n=4096, dt='c128', op=1, mul=True), ['route=fused ', 'passes=3', 'mid=stockham-pair fold', 'ws=268435456']),
     (dict(m=4096, n=4096, dt='c64', op=1, mul=True), ['route=fused ', 'fold']),

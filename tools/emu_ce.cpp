@@ -76,7 +76,7 @@ static double run_case(int nseq, int shift, int off, int len) {
             const cx<T> v = col ? x[size_t(q) * nseq + s] : x[size_t(s) * len + q];
             xs[i] = cld(v.x, v.y);
         }
-        for (int k = (s * 5) % 37; k < n; k += (n > 3000 ? 211 : (n > 600 ? 37 : 1))) {
+        for (int k = (s * 5) % 37; k < n; k += (n > 3000 ? 401 : (n > 600 ? 101 : 1))) {
             cld acc = 0;
             for (int i = 0; i < n; ++i) { const ld a = -2 * pi * ld((int64_t(i) * k) % n) / n; acc += xs[i] * cld(cosl(a), sinl(a)); }
             cx<T> v;
