@@ -97,7 +97,9 @@ def _summary(line):
         'mtf_4096_ms': get(oc + 'mtf_from_psf_4096_f32/ms'), 'mtf_3000_ms': get(oc + 'mtf_from_psf_3000_f32/ms'),
         'mtf_3000_composed_ms': get(oc + 'mtf_from_psf_3000_f32/composed_ms'), 'conv_4096_ms': get(oc + 'conv_real_4096_f32/ms'),
         'f3000_c64_ms': get(oc + 'focus_3000_c64_mixed_radix/ms'), 'f3000_c128_ms': get(oc + 'focus_3000_c128_mixed_radix/ms'),
-        'f1000_c64_ms': get(oc + 'focus_1000_c64_mixed_radix/ms'),
+        'f1000_c64_ms': get(oc + 'focus_1000_c64_mixed_radix/ms'), 'f3000_c64_general_ms': get(oc + 'focus_3000_c64_mixed_radix/general_kernel_ms'),
+        'f1536_c64_ms': get(oc + 'focus_1536_c64_composite/ms'), 'as3000_c64_ms': get(oc + 'angular_spectrum_3000_c64_composite/ms'),
+        'as3000_c128_ms': get(oc + 'angular_spectrum_3000_c128_composite/ms'),
         'c5F_psf_ms': get('polychromatic/variant_F_fft_focus/psf_ms'), 'c5F_ms_per_wvl': get('polychromatic/variant_F_fft_focus/per_wavelength_ms_per_gpu'),
         'c5F_psf_ms_by_reduce': get('polychromatic/variant_F_fft_focus/psf_ms_by_reduce_method'),
         'c5F_pipelined_ms': get('polychromatic/variant_F_fft_focus/pipelined_ms_per_psf'), 'c5M_psf_ms': get('polychromatic/variant_M_mdft_512/psf_ms'), 'c5M_czt_psf_ms': get('polychromatic/variant_M_czt_512/psf_ms'),
