@@ -16,6 +16,7 @@ prof() {   # name, bench arguments...
   ( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$n -- python $R/bench.py "$@" ) > $O/rocprof_pmcw_$n.log 2>&1
   python tools/pmc_summary.py $O/pmc_fetch_$n $O/pmc_write_$n $O/pmc_${n}_summary.json "bench.py $*" > $O/pmc_${n}_summary.txt 2>&1
   cp "$(ls $O/prof_$n/*/*kernel_stats.csv | tail -1)" $O/${n}_kernel_stats.csv
+  rm -rf $O/prof_$n $O/pmc_fetch_$n $O/pmc_write_$n      # the raw traces: gpurun copies at most 64 MiB back
 }
 prof bench --steps 40 --warmup 5 --no-cpu-baseline --no-poly
 # the default bench line AFTER the PMC passes of the same sources: its roofline.traffic comes from the summary just collected
@@ -24,6 +25,7 @@ cp $O/pmc_bench_summary.json $R/profiles/pmc_bench_summary.json
 for c in config2 config3 config4 c128 n8192 padded composite mtf conv adjoint poly2048; do prof $c --only $c; done
 ( cd /tmp && timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq_config4 -- python $R/bench.py --only config4 ) > $O/rocprof_sq_config4.log 2>&1
 python tools/pmc_clock.py $O/pmc_sq_config4 2>&1 | grep pm:: > $O/config4_mfma_busy.txt
+rm -rf $O/pmc_sq_config4
 # SQ counters of the headline's two kernels (two passes of eight counters)
 ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --output-format csv -d $O/pmc_sq1 -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-poly ) > $O/rocprof_sq1.log 2>&1
 ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_sq2 -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-poly ) > $O/rocprof_sq2.log 2>&1
