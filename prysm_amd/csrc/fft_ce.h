@@ -352,17 +352,17 @@ PM_HD void ce_load(cx<typename C::T> (&v)[C::P], const CeIn<typename C::T>& in, 
     using PL = typename C::PL;
     constexpr uint32_t ES = sizeof(cx<T>);
     const int q0 = ce_rot0<PL::N>(t, in.ax.shift);
-    if (WIN) {      // a window of the axis: positions outside it read as zero (64-bit addresses: the invalid lanes need a valid one)
-        const cx<T>* base = C::COL ? in.src + (seq0 + sl) : in.src + int64_t(seq0 + sl) * in.pitch;
+    if (WIN) {      // a window of the axis (zero padding, Q > 1): positions outside it are zero and their loads are not issued
+        const int64_t unit = C::COL ? in.pitch : 1;
+        const cx<T>* ubase = C::COL ? in.src + seq0 : in.src + int64_t(seq0) * in.pitch;
+        const uint32_t vn = uint32_t(PL::N) * uint32_t(unit) * ES;
+        const uint32_t v0 = (uint32_t(q0) * uint32_t(unit) + uint32_t(sl) * uint32_t(C::COL ? 1 : in.pitch)) * ES;
 #pragma unroll
         for (int m = 0; m < C::P; ++m) {
-            int p = q0 + PL::TS * m;
-            p = p >= PL::N ? p - PL::N : p;
-            const int q = p - in.ax.off;
-            const bool ok = unsigned(q) < unsigned(in.ax.len);
-            const int64_t o = ok ? (C::COL ? int64_t(q) * in.pitch : int64_t(q)) : 0;
-            const cx<T> x = mix_ld(base + o);
-            v[m] = ok ? x : cx<T>{T(0), T(0)};
+            const bool wrapped = q0 >= PL::N - PL::TS * m;
+            const int q = q0 + PL::TS * m - (wrapped ? PL::N : 0) - in.ax.off;
+            v[m] = cx<T>{T(0), T(0)};
+            if (unsigned(q) < unsigned(in.ax.len)) v[m] = mix_ld(ce_at(ubase, int64_t(PL::TS * m - PL::N - in.ax.off) * unit, v0 + (wrapped ? 0u : vn)));
         }
     } else {
         const int64_t unit = C::COL ? in.pitch : 1;
@@ -387,26 +387,24 @@ PM_HD void ce_load_synth(cx<typename C::T> (&v)[C::P], const CeIn<typename C::T>
     const int q0 = ce_rot0<PL::N>(t, in.ax.shift);
     const cx<T>* pk = in.src + row * in.pitch;                                        // SYN 3: packed pairs, pitch in pairs
     const T* od = reinterpret_cast<const T*>(in.src) + row * in.pitch;                // SYN 2: OPD map, pitch in real elements
-    bool ok[C::P];
+    // positions outside the stored window: amplitude 0 (their loads are not issued)
 #pragma unroll
     for (int m = 0; m < C::P; ++m) {
         int p = q0 + PL::TS * m;
         p = p >= PL::N ? p - PL::N : p;
         const int q = p - in.ax.off;
-        ok[m] = unsigned(q) < unsigned(in.ax.len);
-        const int qq = ok[m] ? q : 0;
-        if (SYN == 3) {
-            v[m] = mix_ld(pk + qq);
-        } else {
-            v[m].y = od[qq];
-            v[m].x = synth_amp<T>(sy.amp, sy.amp_kind, row * sy.amp_ld + qq);
+        v[m] = cx<T>{T(0), T(0)};
+        if (unsigned(q) < unsigned(in.ax.len)) {
+            if (SYN == 3) {
+                v[m] = mix_ld(pk + q);
+            } else {
+                v[m].y = od[q];
+                v[m].x = synth_amp<T>(sy.amp, sy.amp_kind, row * sy.amp_ld + q);
+            }
         }
     }
 #pragma unroll
-    for (int m = 0; m < C::P; ++m) {
-        const cx<T> x = synth_value<T>(v[m].y, v[m].x, sy.k2);
-        v[m] = ok[m] ? x : cx<T>{T(0), T(0)};
-    }
+    for (int m = 0; m < C::P; ++m) v[m] = synth_value<T>(v[m].y, v[m].x, sy.k2);
 }
 template <typename C>
 PM_HD void ce_store_row(const cx<typename C::T> (&v)[C::P], const CeRowOut<typename C::T>& out, int row0, int sl, int t) {

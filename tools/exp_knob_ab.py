@@ -40,7 +40,11 @@ def make(spec):
         return (lambda: f(x, q)), reps
     if kind == 'as':
         x = torch.randn(n, n, dtype=cd, device='cuda')
-        return (lambda: P.angular_spectrum(x, 0.6328, 0.01, 10.0, Q=1)), reps
+        q = int(parts[3]) if len(parts) > 3 else 1
+        if dt == 'c64':
+            from prysm_amd.conf import config
+            config.precision = 32
+        return (lambda: P.angular_spectrum(x, 0.6328, 0.01, 10.0, Q=q)), reps
     if kind == 'mdft':     # config 4: matrix-DFT focus n^2 -> 512^2 (two complex GEMMs on MFMA)
         from prysm_amd.conf import config
         config.precision = 32 if dt == 'c64' else 64
