@@ -93,6 +93,37 @@ def test_composite_register_engine_emulation():
     assert 'all ok' in out.stdout
 
 
+def test_generated_plan_tables_match_the_generator():
+    """The composite register engine's instantiation files are generated (tools/ce_gen.py): the committed csrc/fft_ce_*.hip and
+    tools/emu_ce_plans.inc are what the table produces, every plan satisfies the engine's constraint (later factors divide the first),
+    fits the LDS and at most kCeMaxSeqs sequences per workgroup, and the first exchange of every shipped shape is free of bank conflicts
+    under the model of tools/ce_banks.py."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        gen = importlib.import_module('ce_gen')
+        banks = importlib.import_module('ce_banks')
+    finally:
+        sys.path.pop(0)
+    csrc = os.path.join(ROOT, 'prysm_amd', 'csrc')
+    for prec in gen.TABLE:
+        for col, mid, name in ((False, False, 'rows'), (True, False, 'cols'), (True, True, 'mid')):
+            want = gen.emit(prec, col, False, mid=mid)
+            assert open(os.path.join(csrc, 'fft_ce_%s_%s.hip' % (name, prec))).read() == want, (prec, name)
+        for n, (plan, rs, cs, _, _) in gen.TABLE[prec].items():
+            prod = 1
+            for r in plan:
+                prod *= r
+                assert plan[0] % r == 0 and 2 <= r <= 48
+            assert prod == n and len(plan) <= 4
+    inc = open(os.path.join(ROOT, 'tools', 'emu_ce_plans.inc')).read()
+    assert inc.count('CHECK(') == 2 * sum(len(t) for t in gen.TABLE.values())
+    for plan, seqs, col, es in (((30, 10, 10), 1, False, 4), ((30, 10, 10), 4, True, 4), ((24, 8, 8), 1, False, 8), ((20, 20, 20), 2, True, 8)):
+        (best, pad), _ = banks.pads(list(plan), seqs, col, es)[0]
+        assert best <= 1.0 + 1e-9, (plan, seqs, col, es, best, pad)
+
+
 REF = '/root/reference'
 
 
