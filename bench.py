@@ -100,6 +100,8 @@ def _summary(line):
         'f1000_c64_ms': get(oc + 'focus_1000_c64_mixed_radix/ms'), 'f3000_c64_general_ms': get(oc + 'focus_3000_c64_mixed_radix/general_kernel_ms'),
         'f1536_c64_ms': get(oc + 'focus_1536_c64_composite/ms'), 'as3000_c64_ms': get(oc + 'angular_spectrum_3000_c64_composite/ms'),
         'as3000_c128_ms': get(oc + 'angular_spectrum_3000_c128_composite/ms'),
+        'stack16x500_ms_per_field': get(oc + 'focus_stack_16x500_c64_composite/ms_per_field'),
+        'stack16x500_loop_ms_per_field': get(oc + 'focus_stack_16x500_c64_composite/loop_ms_per_field'),
         'c5F_psf_ms': get('polychromatic/variant_F_fft_focus/psf_ms'), 'c5F_ms_per_wvl': get('polychromatic/variant_F_fft_focus/per_wavelength_ms_per_gpu'),
         'c5F_psf_ms_by_reduce': get('polychromatic/variant_F_fft_focus/psf_ms_by_reduce_method'),
         'c5F_pipelined_ms': get('polychromatic/variant_F_fft_focus/pipelined_ms_per_psf'), 'c5M_psf_ms': get('polychromatic/variant_M_mdft_512/psf_ms'), 'c5M_czt_psf_ms': get('polychromatic/variant_M_czt_512/psf_ms'),
@@ -381,6 +383,14 @@ def other_configs(only=''):
             with L_.tuning_local(mix_engine=0):
                 out[key]['general_kernel_ms'] = _event_ms(lambda: P.focus(xc, 1), 50)
             del xc
+        # round 5: (B, m, n) stacks of small composite fields (the reference's multi-field batches, prysm/x/polarization.py:478-553) run as ONE
+        # launch pair on the register engine (grid.y = fields); `loop_ms_per_field`: the same fields as B calls
+        for n, B, key in ((500, 16, 'focus_stack_16x500_c64_composite'), (1000, 8, 'focus_stack_8x1000_c64_composite')):
+            xs = torch.from_numpy(np.stack([make_field(n, np.complex64, n + b) for b in range(B)])).cuda()
+            t = _event_ms(lambda: P.focus(xs, 1), 50)
+            out[key] = {'ms': t, 'ms_per_field': t / B, 'fields': B, 'algorithmic_GBps': 4 * B * n ** 2 * 8 / t / 1e6,
+                        'loop_ms_per_field': _event_ms(lambda: [P.focus(xs[b], 1) for b in range(B)], 20) / B}
+            del xs
         # 6006 = 6 x 7 x 11 x 13 (the mixed-radix kernel as it is) and 10000 = 2 x 5000 (round 4: one radix-2 step around
         # mixed-radix sub-transforms; rounds 1 - 3 convolved it at 32768 points per axis)
         for n, key in ((6006, 'focus_6006_c64_mixed_radix'), (10000, 'focus_10000_c64_radix2_x_mixed_radix')):

@@ -631,7 +631,9 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
                 const MixFold<T> mf{int(M / 2), d->in_y.shift == M / 2 ? 1 : 0, twm};
                 rc = mix_rows<T>(di, W, p.w_ld, st, nullptr, &mf);
             } else if (p.mix_n) {
-                rc = mix_rows<T>(di, W, p.w_ld, st);
+                di.nb = nb;                 // a stack (fft2_run: only where both passes are mixed-radix and the view is plain)
+                di.bstride = d->in_bstride;
+                rc = mix_rows<T>(di, W, p.w_ld, st, nullptr, nullptr, wstride);
             } else if (p.blue_n) {
                 rc = blue_rows<T>(di, W, p.w_ld, static_cast<char*>(ws) + p.blue_off, st);
             } else {
@@ -690,7 +692,11 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
         return 0;
     }
     DirectIn<T> di{W, 1, p.w_ld, to_map(d->in_y), int(N), 0};   // sequence = column c at W[c], element stride = the pitch of the intermediate
-    if (p.mix_m) return mix_cols<T>(di, cs, st);
+    if (p.mix_m) {
+        di.nb = nb;
+        di.bstride = wstride;
+        return mix_cols<T>(di, cs, st);
+    }
     if (p.blue_m) return blue_cols<T>(di, cs, static_cast<char*>(ws) + p.blue_off, st);
     const cx<double>* tw = twiddles_f64(M, &err);
     if (!tw) return err;
@@ -707,7 +713,15 @@ template <typename T>
 static int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out, void* ws, hipStream_t st) {
     if (p.nbatch <= 1) return fft2_run_chunk<T>(d, p, in, out, ws, st, 1);
     const bool engine = p.tc != 0;
-    const int64_t step = engine ? p.chunk : 1;
+    // ... and composite grids whose two passes both run on the composite register engine (fft_ce.h: grid.y = fields; round 5)
+    const bool f32 = d->dtype == PM_C64;
+    const bool ce_stack = p.mix_n && p.mix_m && !p.mix_fold && !p.big_rn && !p.blue2d && tuning().mix_engine &&
+                          !(d->flags & (PM_FLAG_REAL_INPUT | PM_FLAG_SYNTH_INPUT | PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY)) && d->mul_kind == PM_MUL_NONE &&
+                          d->out_y.off == 0 && d->out_y.len == d->out_y.n && d->out_x.off == 0 && d->out_x.len == d->out_x.n &&
+                          d->epilogue <= PM_EPI_ABS2_ACCUM &&
+                          (f32 ? ce_has_plan<float>(int(d->in_x.n)) && ce_has_plan<float>(int(d->in_y.n))
+                               : ce_has_plan<double>(int(d->in_x.n)) && ce_has_plan<double>(int(d->in_y.n)));
+    const int64_t step = (engine || ce_stack) ? p.chunk : 1;
     const size_t oes = d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T);
     for (int64_t b0 = 0; b0 < p.nbatch; b0 += step) {
         const int nb = int(p.nbatch - b0 < step ? p.nbatch - b0 : step);

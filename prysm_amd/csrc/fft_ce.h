@@ -281,6 +281,7 @@ struct CeIn {
     AxisMap ax;
     int nseq;
     T ysign;        // -1: conjugated input
+    int64_t bstride;      // a stack of fields (grid.y): elements between their inputs
 };
 // pupil synthesis in the row loads (DirectIn::synth, fft_io.h synth_value): the element is amp exp(2 pi i k2 opd) from packed (amplitude, OPD)
 // pairs (kind 3) or from the OPD map and a separate amplitude array (kind 2) -- Wavefront.from_amp_and_phase(...).focus() on a composite
@@ -300,6 +301,7 @@ struct CeRowOut {
     int mapped;
     AxisMap ax;
     T sr, si;
+    int64_t bstride;      // ... between the outputs of the fields of a stack
 };
 // multiplier of the middle pass (fft_io.h MidMul): full H[k ld + c] or separable hy[k] hx[c], optionally conjugated
 template <typename T>
@@ -319,6 +321,7 @@ struct CeColOut {
     T sr, si;
     int epilogue;
     T weight;
+    int64_t bstride;      // output elements (complex, or real under an epilogue) between the fields of a stack
 };
 
 // Addresses: a base that is uniform in the workgroup (scalar registers; the per-element constants of the plan fold into it) plus ONE

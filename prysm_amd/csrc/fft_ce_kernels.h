@@ -45,6 +45,8 @@ __global__ __launch_bounds__(C::NT, ce_waves_per_eu<C>()) void ce_rows_kernel(Ce
     extern __shared__ __align__(16) char ce_smem[];
     const CePos pos = ce_pos<C>(threadIdx.x);
     const int row0 = int(blockIdx.x) * C::SEQS, row = row0 + pos.sl, slc = row < in.nseq ? pos.sl : in.nseq - 1 - row0;
+    in.src += int64_t(blockIdx.y) * in.bstride;        // field of a stack
+    out.dst += int64_t(blockIdx.y) * out.bstride;
     cx<T> v[C::P];
     if constexpr (C::ABL & 1) {
 #pragma unroll
@@ -77,6 +79,8 @@ __global__ __launch_bounds__(C::NT, ce_waves_per_eu<C>()) void ce_cols_kernel(Ce
     if (c0 >= in.nseq) return;
     const CePos pos = ce_pos<C>(threadIdx.x);
     const int col = c0 + pos.sl, slc = col < in.nseq ? pos.sl : in.nseq - 1 - c0;
+    in.src += int64_t(blockIdx.y) * in.bstride;        // field of a stack
+    out.dst = static_cast<char*>(out.dst) + int64_t(blockIdx.y) * out.bstride * int64_t(out.epilogue == 0 ? sizeof(cx<T>) : sizeof(T));
     cx<T> v[C::P];
     if constexpr (C::ABL & 1) {
 #pragma unroll
@@ -123,13 +127,13 @@ __global__ __launch_bounds__(C::NT, ce_waves_per_eu<C>()) void ce_cols_mul_kerne
 }
 
 template <typename C>
-int ce_rows_go(const CeIn<typename C::T>& in, const CeRowOut<typename C::T>& out, const cx<typename C::T>* tw, hipStream_t st, const CeSynth& sy) {
+int ce_rows_go(const CeIn<typename C::T>& in, const CeRowOut<typename C::T>& out, const cx<typename C::T>* tw, hipStream_t st, const CeSynth& sy, int nb) {
     const bool win = !(in.ax.off == 0 && in.ax.len == in.ax.n);
     const int groups = (in.nseq + C::SEQS - 1) / C::SEQS;
     auto go = [&](auto kernel) {
         const int rc = mix_set_lds(kernel, C::LDS_BYTES);
         if (rc) return rc;
-        hipLaunchKernelGGL(kernel, dim3(groups), dim3(C::NT), C::LDS_BYTES, st, in, out, tw, sy);
+        hipLaunchKernelGGL(kernel, dim3(groups, nb), dim3(C::NT), C::LDS_BYTES, st, in, out, tw, sy);
         return int(hipGetLastError());
     };
     if constexpr (sizeof(typename C::T) == 4) {
@@ -139,7 +143,7 @@ int ce_rows_go(const CeIn<typename C::T>& in, const CeRowOut<typename C::T>& out
     return win ? go(ce_rows_kernel<C, true>) : go(ce_rows_kernel<C, false>);
 }
 template <typename C>
-int ce_cols_go(const CeIn<typename C::T>& in, const CeColOut<typename C::T>& out, const cx<typename C::T>* tw, hipStream_t st, int log_g) {
+int ce_cols_go(const CeIn<typename C::T>& in, const CeColOut<typename C::T>& out, const cx<typename C::T>* tw, hipStream_t st, int log_g, int nb) {
     const bool win = !(in.ax.off == 0 && in.ax.len == in.ax.n);
     // adjacent tiles that run on one XCD: the measured best of the shape (tools/ce_gen.py), else as many as share a 128 B line
     if (log_g < 0)
@@ -149,11 +153,11 @@ int ce_cols_go(const CeIn<typename C::T>& in, const CeColOut<typename C::T>& out
     if (win) {
         const int rc = mix_set_lds(ce_cols_kernel<C, true>, C::LDS_BYTES);
         if (rc) return rc;
-        hipLaunchKernelGGL((ce_cols_kernel<C, true>), dim3(groups), dim3(C::NT), C::LDS_BYTES, st, in, out, tw, log_g);
+        hipLaunchKernelGGL((ce_cols_kernel<C, true>), dim3(groups, nb), dim3(C::NT), C::LDS_BYTES, st, in, out, tw, log_g);
     } else {
         const int rc = mix_set_lds(ce_cols_kernel<C, false>, C::LDS_BYTES);
         if (rc) return rc;
-        hipLaunchKernelGGL((ce_cols_kernel<C, false>), dim3(groups), dim3(C::NT), C::LDS_BYTES, st, in, out, tw, log_g);
+        hipLaunchKernelGGL((ce_cols_kernel<C, false>), dim3(groups, nb), dim3(C::NT), C::LDS_BYTES, st, in, out, tw, log_g);
     }
     return int(hipGetLastError());
 }
@@ -181,16 +185,18 @@ int ce_cols_mul_go(const CeIn<typename C::T>& in, const CeMul<typename C::T>& mm
 // (ce_fits32, kCeMaxSeqs: pm_internal.h)
 
 template <typename T>
-bool ce_rows_view(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, const RowStoreNat<T>* o, CeIn<T>& ci, CeRowOut<T>& ro, CeSynth& sy) {
+bool ce_rows_view(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, int64_t out_bstride, const RowStoreNat<T>* o, CeIn<T>& ci, CeRowOut<T>& ro, CeSynth& sy) {
     if (in.real || in.s_i != 1 || in.nseq <= 0) return false;
-    if (in.synth && (sizeof(T) != 4 || (in.synth != 2 && in.synth != 3))) return false;      // synthesis: complex64 only (the fp64 sincospi does not fit the tile's registers)
+    if (in.synth && (sizeof(T) != 4 || (in.synth != 2 && in.synth != 3))) return false;
+    if (in.nb > 1 && (in.synth || o)) return false;      // stacks: plain complex fields to natural rows      // synthesis: complex64 only (the fp64 sincospi does not fit the tile's registers)
     sy = CeSynth{in.synth, in.k2, in.amp, in.amp ? in.amp_kind : 0, in.amp_ld};
     if (o && (o->use_ay || o->bstride || o->ax.n != in.ax.n)) return false;
     const int64_t n = in.ax.n, old_ = o ? o->ld : out_ld;
     // loads: (sl pitch + q0 + N) elements; stores: (sl ld + q0 + N)
     if (in.s_seq < 0 || old_ < 0 || !ce_fits32(kCeMaxSeqs * in.s_seq + 2 * n, sizeof(cx<T>)) || !ce_fits32(kCeMaxSeqs * old_ + 2 * n, sizeof(cx<T>))) return false;
-    ci = CeIn<T>{in.src, in.s_seq, in.ax, in.nseq, in.conj ? T(-1) : T(1)};
-    ro = o ? CeRowOut<T>{o->dst, o->ld, 1, o->ax, o->scale, o->conj ? -o->scale : o->scale} : CeRowOut<T>{out, out_ld, 0, AxisMap{in.ax.n, in.ax.n, 0, 0}, T(1), T(1)};
+    ci = CeIn<T>{in.src, in.s_seq, in.ax, in.nseq, in.conj ? T(-1) : T(1), in.bstride};
+    ro = o ? CeRowOut<T>{o->dst, o->ld, 1, o->ax, o->scale, o->conj ? -o->scale : o->scale, 0}
+           : CeRowOut<T>{out, out_ld, 0, AxisMap{in.ax.n, in.ax.n, 0, 0}, T(1), T(1), out_bstride};
     return true;
 }
 template <typename T>
@@ -202,9 +208,9 @@ bool ce_cols_view(const DirectIn<T>& in, const ColStoreNat<T>& out, CeIn<T>& ci,
     const int64_t n = in.ax.n;
     // loads: (q0 + N) pitch + sl elements; stores: (k0 + N) ld + qx
     if (in.s_i < 0 || out.ld < 0 || !ce_fits32(2 * n * in.s_i + kCeMaxSeqs, sizeof(cx<T>)) || !ce_fits32(2 * n * out.ld + out.ax.n, sizeof(cx<T>))) return false;
-    ci = CeIn<T>{in.src, in.s_i, in.ax, in.nseq, in.conj ? T(-1) : T(1)};
+    ci = CeIn<T>{in.src, in.s_i, in.ax, in.nseq, in.conj ? T(-1) : T(1), in.bstride};
     co = CeColOut<T>{out.dst, out.ld, out.ay.n, out.ay.shift, out.ax.n, out.ax.shift, out.scale, out.conj ? -out.scale : out.scale,
-                     out.epilogue, out.weight};
+                     out.epilogue, out.weight, out.bstride};
     return true;
 }
 template <typename T>
@@ -215,7 +221,8 @@ bool ce_mid_view(const DirectIn<T>& in, const MidMul<T>& m, int64_t dst_pitch, C
     if (in.s_i < 0 || dst_pitch < 0 || !ce_fits32(2 * n * in.s_i + kCeMaxSeqs, sizeof(cx<T>)) || !ce_fits32(n * dst_pitch + kCeMaxSeqs, sizeof(cx<T>)) ||
         (m.kind == MUL_FULL && (m.ld < 0 || !ce_fits32(n * m.ld + kCeMaxSeqs, sizeof(cx<T>)))))
         return false;
-    ci = CeIn<T>{in.src, in.s_i, in.ax, in.nseq, T(1)};
+    if (in.nb > 1) return false;
+    ci = CeIn<T>{in.src, in.s_i, in.ax, in.nseq, T(1), 0};
     mm = CeMul<T>{m.kind, m.conj, m.mul, m.mul_x, m.ld};
     return true;
 }

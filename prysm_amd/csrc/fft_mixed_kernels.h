@@ -337,12 +337,23 @@ int mix_cols_launch_impl(const MixPlan* p, MixShape sh, const DirectIn<T>& in, c
 }
 
 template <typename T>
-int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o, const MixFold<T>* fold) {
+int mix_rows_impl(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o, const MixFold<T>* fold, int64_t out_bstride) {
     const int n = in.ax.n, nseq = in.nseq;
     if (nseq <= 0 || n <= 0) return 0;
     if (!fold && tuning().mix_engine) {     // a length with a compile-time plan, a plain view: the register engine (fft_ce.h)
         int rc = 0;
-        if (ce_rows<T>(in, out, out_ld, o, st, &rc)) return rc;
+        if (ce_rows<T>(in, out, out_ld, o, st, &rc, out_bstride)) return rc;
+    }
+    if (in.nb > 1) {      // a stack on the general kernel: field by field (complex fields, natural outputs: capi.hip fft2_run)
+        if (o || fold || in.real || in.synth) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: a stack with a view it does not take");
+        for (int b = 0; b < in.nb; ++b) {
+            DirectIn<T> one = in;
+            one.src = in.src + int64_t(b) * in.bstride;
+            one.nb = 1;
+            const int rc = mix_rows_impl<T>(one, out + int64_t(b) * out_bstride, out_ld, st, nullptr, nullptr, 0);
+            if (rc) return rc;
+        }
+        return 0;
     }
     if (fold && (o || nseq != 2 * fold->H || !mix_fits(n, int64_t(fold->H) * in.s_seq, sizeof(cx<T>), false) ||
                  (in.amp && !mix_fits(n, int64_t(fold->H) * in.amp_ld, sizeof(cx<T>), false))))
@@ -400,6 +411,20 @@ int mix_cols_impl(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t 
     if (tuning().mix_engine) {
         int rc = 0;
         if (ce_cols<T>(in, out, st, &rc)) return rc;
+    }
+    if (in.nb > 1) {      // a stack on the general kernel: field by field
+        if (in.real || out.mul_kind != MUL_NONE) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: a stack with a view it does not take");
+        const size_t oes = out.epilogue == EPI_NONE ? sizeof(cx<T>) : sizeof(T);
+        for (int b = 0; b < in.nb; ++b) {
+            DirectIn<T> one = in;
+            one.src = in.src + int64_t(b) * in.bstride;
+            one.nb = 1;
+            ColStoreNat<T> oo = out;
+            oo.dst = static_cast<char*>(out.dst) + size_t(b) * size_t(out.bstride) * oes;
+            const int rc = mix_cols_impl<T>(one, oo, st);
+            if (rc) return rc;
+        }
+        return 0;
     }
     MixPlan p;
     if (!mix_plan_for(n, sizeof(cx<T>), p)) return fail(PM_ERR_UNSUPPORTED, "mixed-radix path: length %d has no plan", n);

@@ -10,8 +10,8 @@ template <> int mix_rows_launch<float, 16>(const MixPlan* p, MixShape sh, const 
     return mix_rows_launch_impl<float, 16>(p, sh, in, ro, tw, groups, nt, lds, st);
 }
 
-template <> int mix_rows<float>(const DirectIn<float>& in, cx<float>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<float>* o, const MixFold<float>* fold) {
-    return mix_rows_impl<float>(in, out, out_ld, st, o, fold);
+template <> int mix_rows<float>(const DirectIn<float>& in, cx<float>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<float>* o, const MixFold<float>* fold, int64_t out_bstride) {
+    return mix_rows_impl<float>(in, out, out_ld, st, o, fold, out_bstride);
 }
 
 }  // namespace pm

@@ -10,8 +10,8 @@ template <> int mix_rows_launch<double, 16>(const MixPlan* p, MixShape sh, const
     return mix_rows_launch_impl<double, 16>(p, sh, in, ro, tw, groups, nt, lds, st);
 }
 
-template <> int mix_rows<double>(const DirectIn<double>& in, cx<double>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<double>* o, const MixFold<double>* fold) {
-    return mix_rows_impl<double>(in, out, out_ld, st, o, fold);
+template <> int mix_rows<double>(const DirectIn<double>& in, cx<double>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<double>* o, const MixFold<double>* fold, int64_t out_bstride) {
+    return mix_rows_impl<double>(in, out, out_ld, st, o, fold, out_bstride);
 }
 
 }  // namespace pm

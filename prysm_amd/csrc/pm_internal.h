@@ -36,6 +36,10 @@ struct DirectIn {
     int amp_kind;
     int64_t amp_ld;
     double k2;
+    // a stack of fields in ONE launch (round 5, mixed-radix entry points): nb fields, `bstride` elements between their inputs; the
+    // composite register engine runs them as grid.y, the general kernels field by field
+    int nb = 1;
+    int64_t bstride = 0;
 };
 // rows: out[seq*ld + k] (natural complex intermediate, k in [0,n))
 template <typename T>
@@ -69,12 +73,13 @@ struct MixFold {
     const cx<T>* tw;
 };
 template <typename T>
-int mix_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o = nullptr, const MixFold<T>* fold = nullptr);
+int mix_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, hipStream_t st, const RowStoreNat<T>* o = nullptr, const MixFold<T>* fold = nullptr,
+             int64_t out_bstride = 0);      // out_bstride: elements between the natural outputs of the fields of a stack (in.nb > 1)
 template <typename T>
 int mix_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t st);
 // the composite register engine (fft_ce.h): lengths with a compile-time plan, plain views.  false: not taken (the general kernel runs);
 // true: launched, *rc holds the status
-template <typename T> bool ce_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, const RowStoreNat<T>* o, hipStream_t st, int* rc);
+template <typename T> bool ce_rows(const DirectIn<T>& in, cx<T>* out, int64_t out_ld, const RowStoreNat<T>* o, hipStream_t st, int* rc, int64_t out_bstride = 0);
 template <typename T> bool ce_cols_mul(const DirectIn<T>& in, const MidMul<T>& mm, cx<T>* dst, int64_t dst_pitch, hipStream_t st, int* rc);
 template <typename T> bool ce_cols(const DirectIn<T>& in, const ColStoreNat<T>& out, hipStream_t st, int* rc);
 template <typename T> bool ce_has_plan(int n);      // lengths with a built plan (tools/ce_gen.py)

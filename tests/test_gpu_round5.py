@@ -472,3 +472,30 @@ def test_composite_engine_synthesises_the_pupil_in_its_row_loads(pa, n, Q):
         assert got[eng].dtype == np.complex64
         assert rel_max(got[eng], want) < 2e-5 and rel_max(packed, want) < 2e-5, (n, Q, eng)
     assert rel_max(got[1], got[0]) < 2e-5
+
+
+@pytest.mark.parametrize('shape,cdt,B', [((500, 768), np.complex64, 5), ((1000, 900), np.complex128, 3), ((384, 384), np.complex64, 17)])
+def test_composite_engine_runs_a_stack_as_one_launch_pair(pa, shape, cdt, B):
+    """(B, m, n) stacks on composite grids (the reference's multi-field batches, prysm/x/polarization.py:478-553): both passes of every
+    field in ONE launch pair on the register engine (grid.y = fields), with rotations and the |.|^2 epilogue, equal to numpy per field and
+    to the same stack with the engine off (field by field on the general kernel)."""
+    from prysm_amd import _lib, _ops
+    rng = np.random.default_rng(B)
+    m, n = shape
+    tol = TOL32 if cdt == np.complex64 else TOL64
+    x = (rng.standard_normal((B, m, n)) + 1j * rng.standard_normal((B, m, n))).astype(cdt)
+    want = np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(x.astype(np.complex128), axes=(1, 2))), axes=(1, 2)) / np.sqrt(m * n)
+    xd = torch.from_numpy(x).cuda()
+    kw = dict(direction=-1, scale=1.0 / np.sqrt(m * n), in_shift=(m // 2, n // 2), out_shift=(m // 2, n // 2))
+    got = {}
+    for eng in (1, 0):
+        with _lib.tuning_local(mix_engine=eng):
+            got[eng] = _ops.fft2(xd, **kw).cpu().numpy()
+            inten = _ops.fft2(xd, epilogue=_lib.PM_EPI_ABS2, **kw).cpu().numpy()
+        assert rel_max(got[eng], want) < tol and rel_max(inten, np.abs(want) ** 2) < 8 * tol, (shape, eng)
+    assert rel_max(got[1], got[0]) < tol
+    # a strided stack (every other field of a larger one)
+    big = torch.from_numpy(np.concatenate([x, x[::-1]], axis=0)).cuda()
+    sub = _ops.fft2(big[::2], **kw).cpu().numpy()
+    ref = np.concatenate([x, x[::-1]], axis=0)[::2]
+    assert rel_max(sub, np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(ref.astype(np.complex128), axes=(1, 2))), axes=(1, 2)) / np.sqrt(m * n)) < tol

@@ -111,14 +111,14 @@ def emit(prec, col, exp, mid=False):
         L.append('    CeIn<%s> ci;' % ct)
         L.append('    CeColOut<%s> co;' % ct)
         L.append('    if (!ce_cols_view(in, out, ci, co)) return false;')
-        knob, go, args = 'ce_cols_seqs', 'ce_cols_go', 'ci, co, tw, st, %d'
+        knob, go, args = 'ce_cols_seqs', 'ce_cols_go', 'ci, co, tw, st, %d, in.nb'
     else:
-        L.append('template <> bool ce_rows<%s>(const DirectIn<%s>& in, cx<%s>* out, int64_t out_ld, const RowStoreNat<%s>* o, hipStream_t st, int* rc) {' % (ct, ct, ct, ct))
+        L.append('template <> bool ce_rows<%s>(const DirectIn<%s>& in, cx<%s>* out, int64_t out_ld, const RowStoreNat<%s>* o, hipStream_t st, int* rc, int64_t out_bstride) {' % (ct, ct, ct, ct))
         L.append('    CeIn<%s> ci;' % ct)
         L.append('    CeRowOut<%s> ro;' % ct)
         L.append('    CeSynth sy;')
-        L.append('    if (!ce_rows_view(in, out, out_ld, o, ci, ro, sy)) return false;')
-        knob, go, args = 'ce_rows_seqs', 'ce_rows_go', 'ci, ro, tw, st, sy'
+        L.append('    if (!ce_rows_view(in, out, out_ld, out_bstride, o, ci, ro, sy)) return false;')
+        knob, go, args = 'ce_rows_seqs', 'ce_rows_go', 'ci, ro, tw, st, sy, in.nb'
     if not mid:
         L.append('    const int n = in.ax.n;')
         L.append('    if (%s) return false;' % ' && '.join('n != %d' % n for n in lens))
