@@ -11,7 +11,14 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from ce_banks import pads  # noqa: E402
+import functools  # noqa: E402
+
+from ce_banks import pads as _pads  # noqa: E402
+
+
+@functools.lru_cache(maxsize=None)
+def pads(plan, seqs, col, es):
+    return _pads(list(plan), seqs, col, es)
 
 # length: plan, shipped (rows, cols) shape, alternatives for sweeps
 TABLE = {
@@ -83,7 +90,7 @@ def cfg(ct, plan, col, shape):
     assert n // plan[0] * seqs <= 1024, ('threads', plan, seqs)
     assert seqs <= 16, 'fft_ce_kernels.h kCeMaxSeqs'
     es = (4 if ct == 'float' else 8) * (2 if comp == 1 else 1)
-    pp = [p[0][1] for p in pads(list(plan), seqs, col, min(es, 8))] + [0, 0, 0]
+    pp = [p[0][1] for p in pads(tuple(plan), seqs, col, min(es, 8))] + [0, 0, 0]
     return 'CeCfg<%s, CePlan<%s>, %d, %s, %d, %d, %d, %d, %d>' % (ct, ', '.join(map(str, plan)), seqs, 'true' if col else 'false', comp, pp[0], pp[1], pp[2], wpe)
 
 
