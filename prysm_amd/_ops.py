@@ -255,6 +255,29 @@ def fft2_real(x, *, scale=1.0, in_shift=(0, 0), out_shift=(0, 0), epilogue=L.PM_
     return out
 
 
+_REGISTER_ROUTES = {}
+
+
+def on_register_engine(M, N, cdtype):
+    """Whether BOTH passes of a plain complex (M, N) transform run on the composite register engine (csrc/fft_ce.h) -- the composite
+    grids whose (B, M, N) stacks go out as one launch pair.  Asked of the library's planner (pm_plan_explain: host logic, no GPU work),
+    once per shape and precision."""
+    key = (int(M), int(N), cdtype)
+    hit = _REGISTER_ROUTES.get(key)
+    if hit is None:
+        lib = L.load()
+        d = L.pm_fft2_desc()
+        d.dtype, d.direction = L._COMPLEX_CODE[cdtype], -1
+        d.in_y, d.in_x, d.in_ld = L.pm_axis(M, M, 0, 0), L.pm_axis(N, N, 0, 0), N
+        d.out_y, d.out_x, d.out_ld = L.pm_axis(M, M, 0, 0), L.pm_axis(N, N, 0, 0), N
+        buf = ctypes.create_string_buffer(256)
+        hit = lib.pm_plan_explain(ctypes.byref(d), 0, buf, 256) == 0 and buf.value.count(b'mixed-radix-registers') == 2
+        if len(_REGISTER_ROUTES) > 256:
+            _REGISTER_ROUTES.clear()
+        _REGISTER_ROUTES[key] = hit
+    return hit
+
+
 def pack_amp_opd(amp, opd):
     """(amplitude, OPD) pairs in the OPD map's precision as a complex tensor -- the input of fft2(..., synth=('packed', k)).  A loop
     over wavelengths packs its two maps once and then reads ONE element per sample in every transform."""

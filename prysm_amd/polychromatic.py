@@ -207,6 +207,14 @@ def _local_sum(amplitude, opd, wavelengths, weights, lo, hi, dx, efl, Q, focal_d
     phs = L.as_device(opd)
 
     packed = None
+    if Q is not None and batched is None and len(wavelengths) > 1:
+        # small composite grids whose stacks run as ONE launch pair on the composite register engine (round 5): 16 wavelengths of a 500^2
+        # grid 160 us as stacks against 202 us for per-wavelength launch pairs, 1000^2 220 / 281, 1536^2 a tie
+        # (profiles/r05/exp_poly_composite.log)
+        MN = (math.ceil(amp.shape[-2] * Q), math.ceil(amp.shape[-1] * Q))
+        if MN[0] * MN[1] <= 1400 * 1400 and phs.dtype in (torch.float32, torch.float64) and \
+                _ops.on_register_engine(MN[0], MN[1], torch.complex128 if phs.dtype == torch.float64 else torch.complex64):
+            batched = True
     if Q is not None and not batched:
         # the pupil is synthesised inside every wavelength's transform (float maps, power-of-two width): pack (amplitude, OPD)
         # once -- per pair of maps, not per call (packed_pupil) -- so each of those row passes reads one 8-byte element per sample

@@ -499,3 +499,21 @@ def test_composite_engine_runs_a_stack_as_one_launch_pair(pa, shape, cdt, B):
     sub = _ops.fft2(big[::2], **kw).cpu().numpy()
     ref = np.concatenate([x, x[::-1]], axis=0)[::2]
     assert rel_max(sub, np.fft.fftshift(np.fft.fft2(np.fft.ifftshift(ref.astype(np.complex128), axes=(1, 2))), axes=(1, 2)) / np.sqrt(m * n)) < tol
+
+
+def test_polychromatic_psf_on_small_composite_grids_takes_stacks_by_default(pa):
+    """A 500^2 pupil, 12 wavelengths (docs/source/how-tos/Polychromatic Propagation.ipynb on a decimal grid): the default now runs the
+    wavelengths as stacks on the composite register engine (one launch pair per stack); same image as the per-wavelength loop and as
+    the oracle's sum."""
+    from prysm_amd import _ops
+    from prysm_amd.polychromatic import polychromatic_psf
+    rng = np.random.default_rng(12)
+    n = 500
+    amp = (rng.random((n, n)) > 0.3).astype(np.float32)
+    opd = (120 * rng.standard_normal((n, n))).astype(np.float32)
+    wv, wt = np.linspace(0.5, 0.7, 12), np.linspace(1.0, 2.0, 12)
+    assert _ops.on_register_engine(n, n, torch.complex64) and not _ops.on_register_engine(600, 600, torch.complex64)
+    got = tonp(polychromatic_psf(amp, opd, wv, wt, 0.04, 100.0, Q=1))
+    loop = tonp(polychromatic_psf(amp, opd, wv, wt, 0.04, 100.0, Q=1, batched=False, spectral=False))
+    want = sum(w * O.intensity(O.focus(O.from_amp_and_phase(amp, opd.astype(np.float64), float(l)), 1)) for l, w in zip(wv, wt))
+    assert rel_max(got, want) < 2e-5 and rel_max(loop, want) < 2e-5 and rel_max(got, loop) < 2e-5
