@@ -269,6 +269,7 @@ class tuning_local:
     first exit."""
 
     _tls = threading.local()
+    epoch = 0       # bumped whenever a block starts or ends: answers derived from the planner (e.g. _ops.on_register_engine) are cached per epoch
 
     def __init__(self, **knobs):
         self.knobs = knobs
@@ -291,6 +292,7 @@ class tuning_local:
         if not hasattr(self._tls, 'stack'):
             self._tls.stack = []
         self._tls.stack.append(dict(self.knobs))
+        tuning_local.epoch += 1
         return self
 
     def __exit__(self, *exc):
@@ -298,6 +300,7 @@ class tuning_local:
         if stack:
             stack.pop()
         self._replay(load())
+        tuning_local.epoch += 1
         return False
 
 

@@ -290,6 +290,19 @@ def test_routes_of_a_table_of_shapes(lib):
     assert lib.pm_plan_explain(ctypes.byref(d), 0, buf, 8) == L.PM_ERR_ARG
 
 
+def test_python_asks_the_planner_which_grids_stack_on_the_register_engine(lib):
+    """prysm_amd._ops.on_register_engine (what polychromatic_psf's default consults): both passes of a plain complex transform on the
+    composite register engine -- from pm_plan_explain, no GPU"""
+    import torch
+    from prysm_amd import _lib as L, _ops
+    assert _ops.on_register_engine(500, 500, torch.complex64) and _ops.on_register_engine(1000, 1536, torch.complex128)
+    assert not _ops.on_register_engine(600, 600, torch.complex64)        # no compile-time plan
+    assert not _ops.on_register_engine(1000, 1024, torch.complex64)      # one pass on the power-of-two engine
+    with L.tuning_local(mix_engine=0):          # the cache follows tuning_local blocks
+        assert not _ops.on_register_engine(500, 500, torch.complex64)
+    assert _ops.on_register_engine(500, 500, torch.complex64)
+
+
 def test_routes_follow_the_knobs_and_tuning_local_nests(lib):
     """leaving an inner tuning_local block used to discard the outer block's knobs; a block that fails to start (a knob the
     product build refuses) must leave nothing half-applied"""
