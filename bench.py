@@ -58,6 +58,7 @@ N_EDGE = 4096
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
 HBM_COPY_CEILING_GBS = 6290.0   # measured float4-copy ceiling quoted by the same guide (report both fractions)
 F32_MFMA_PEAK_TF = 157.3
+F64_MFMA_PEAK_TF = 78.6    # same guide: FP64 matrix (v_mfma_f64_16x16x4_f64)
 N_WAVELENGTHS = 64      # BASELINE config 5
 
 
@@ -83,9 +84,14 @@ def _summary(line):
         return float(f'{d:.4g}') if isinstance(d, float) else d
     oc = 'other_configs/'
     pairs = {
-        'psfs_per_s': get('value'), 'ms': get('ms_per_step'), 'row_ms': get('roofline/row_pass_ms'), 'col_ms': get('roofline/column_pass_ms'),
+        'psfs_per_s': get('value'), 'ms': get('ms_per_step'), 'repeat_ms': get('repeat_ms'), 'repeat_spread': get('repeat_spread'), 'prewarm_ms': get('prewarm_ms'),
+        'sclk_before': get('gpu_before/sclk_mhz'), 'sclk_after': get('gpu_after/sclk_mhz'), 'power_w_after': get('gpu_after/power_w'), 'row_ms': get('roofline/row_pass_ms'), 'col_ms': get('roofline/column_pass_ms'),
         'frac': get('roofline/frac'), 'two_copies_ms': get('roofline/two_plain_copies_ms'), 'n2048_per_s': get('n2048/value'),
         'psf_variant_ms': get('psf_variant/ms_per_psf'),
+        'm7_c64_eager_ms': get(oc + 'model_7plane_1024/c64/eager_ms_per_wavelength'), 'm7_c64_graph_ms': get(oc + 'model_7plane_1024/c64/graph_ms_per_wavelength'),
+        'm7_c64_9wvl_graph_ms': get(oc + 'model_7plane_1024/c64/graph_9wvl_ms'), 'm7_c64_9wvl_sequence_ms': get(oc + 'model_7plane_1024/c64/sequence_9wvl_ms'),
+        'm7_c128_eager_ms': get(oc + 'model_7plane_1024/c128/eager_ms_per_wavelength'), 'm7_c128_graph_ms': get(oc + 'model_7plane_1024/c128/graph_ms_per_wavelength'),
+        'm7_published_titan_xp_ms': get(oc + 'model_7plane_1024/published/titan_xp_cupy_ms_per_wavelength'),
         'c2_ms': get(oc + 'config2_focus_2048_c64/ms'), 'c2_two_streams_ms': get(oc + 'config2_focus_2048_c64/two_streams/ms'),
         'c2_sequence_ms': get(oc + 'config2_focus_2048_c64/sequence_block/ms'), 'f1000_sequence_ms': get(oc + 'focus_1000_c64_sequence_block/ms'),
         'c2_loop_ms': get(oc + 'config2_focus_2048_c64/sequence_block/loop_ms'), 'f1000_loop_ms': get(oc + 'focus_1000_c64_sequence_block/loop_ms'),
@@ -109,7 +115,7 @@ def _summary(line):
         'model_eff8_a2a': get('polychromatic/scaling_model/per_N/8/efficiency_single_shot/a2a'),
         'model_eff8_reduce': get('polychromatic/scaling_model/per_N/8/efficiency_single_shot/reduce'),
         'c5_2048_us_per_wvl': get('polychromatic_2048/spectral_groups/per_wavelength_us_per_gpu'),
-        'cpu_1core_per_s': get('cpu_baseline/value'), 'cpu_allcores_per_s': get('cpu_baseline/tuned/value'), 'cpu': get('cpu_baseline/host/cpu'),
+        'cpu_1core_per_s': get('cpu_baseline/value'), 'cpu_best_workers_per_s': get('cpu_baseline/tuned/value'), 'cpu_best_workers': get('cpu_baseline/tuned/cores'), 'cpu': get('cpu_baseline/host/cpu'),
     }
     return {k: v for k, v in pairs.items() if v is not None}
 
@@ -129,7 +135,7 @@ def parse():
     ap.add_argument('--dtype', default='c64', choices=['c64', 'c128'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-poly', action='store_true', help='only the headline loop (profiling runs)')
-    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (config2|config3|config4|c128|n8192|padded|composite|mtf|conv|adjoint|poly2048)')
+    ap.add_argument('--only', default='', help='profiling runs: time only this other_configs entry (model7|config2|config3|config4|c128|n8192|padded|composite|mtf|conv|adjoint|poly2048)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget for the CPU baseline sample')
     ap.add_argument('--reduce-method', default='auto', choices=['auto', 'reduce', 'a2a', 'rs'],
                     help='how the polychromatic image reaches rank 0: one torch.distributed.reduce, or all-to-all of slices + ordered local '
@@ -284,6 +290,133 @@ def _hbm_entry(ms, nbytes, note=None):
     if note:
         e['note'] = note
     return e
+
+
+# ---- the workload the reference publishes numbers for: a seven-plane Lyot-coronagraph model at 1024^2 per wavelength
+MODEL7 = {'n': 1024, 'fpm_samples': 256, 'det_samples': 256, 'efl': 1000.0, 'pupil_diameter': 10.0, 'fpm_radius_lod': 3.0, 'lyot_fraction': 0.9}
+MODEL7_PUBLISHED = {'titan_xp_cupy_ms_per_wavelength': 2.0, 'titan_xp_9_wavelengths_ms': 60.0, 'xeon_6248R_x2_ms_per_plane': 50.0,
+                    'lowfs_model_ms_per_wavelength': 0.43,
+                    'source': 'docs/source/how-tos/GPU and Exascale Computing.ipynb (file line 74); docs/source/releases/v0.20.rst:31-37'}
+
+
+def model7_inputs(n=MODEL7['n'], seed=7):
+    """Static data of the seven-plane model as float64 numpy arrays (cast by the caller): entrance-pupil amplitude (circle) and OPD
+    (nm, smooth random), a deformable-mirror surface (nm), a Lyot stop, and -- per focal grid -- the occulter: a hard-edged spot of
+    fpm_radius_lod lambda/D (real-valued, 0 inside), on the FPM grid of to_fpm_and_back."""
+    rng = np.random.default_rng(seed)
+    D = MODEL7['pupil_diameter']
+    dx = D / n
+    ax = (np.arange(n) - n // 2) * dx
+    r = np.hypot(ax[None, :], ax[:, None])
+    amp = (r <= D / 2).astype(np.float64)
+    yy, xx = ax[:, None] / (D / 2), ax[None, :] / (D / 2)
+    c = rng.standard_normal(6)
+    opd = 20.0 * (c[0] * xx + c[1] * yy + c[2] * (2 * (xx * xx + yy * yy) - 1) + c[3] * (xx * xx - yy * yy) + c[4] * 2 * xx * yy +
+                  c[5] * (3 * (xx * xx + yy * yy) - 2) * xx)
+    dm = 5.0 * np.cos(2 * np.pi * 6 * xx) * np.cos(2 * np.pi * 4 * yy)
+    lyot = (r <= MODEL7['lyot_fraction'] * D / 2).astype(np.float64)
+    return {'amp': amp, 'opd': opd, 'dm': dm, 'lyot': lyot, 'dx': dx}
+
+
+def model7_grids(wvl):
+    """(fpm_dx, det_dx) in um: the FPM plane sampled at 8 samples per lambda/D over +-16 lambda/D, the detector at 4 per lambda/D"""
+    lod = wvl * MODEL7['efl'] / MODEL7['pupil_diameter']        # um
+    return lod / 8.0, lod / 4.0
+
+
+def model7_fpm(wvl):
+    fpm_dx, _ = model7_grids(wvl)
+    m = MODEL7['fpm_samples']
+    ax = (np.arange(m) - m // 2) * fpm_dx
+    rr = np.hypot(ax[None, :], ax[:, None])
+    lod = wvl * MODEL7['efl'] / MODEL7['pupil_diameter']
+    return (rr > MODEL7['fpm_radius_lod'] * lod).astype(np.float64)
+
+
+def model7(P, amp, opd, dm, fpm, lyot, wvl, dx, ex_fpm, ex_det):
+    """The seven planes, written against the reference's Wavefront API (prysm/propagation/wavefront.py, coronagraph.py:12-43):
+    1 entrance pupil (from_amp_and_phase) -> 2 deformable mirror (phase_screen, multiply) -> 3 focal-plane-mask plane (focus_dft)
+    -> 4 after the mask (multiply) -> 5 Lyot plane (unfocus_dft) -> 6 after the Lyot stop (multiply) -> 7 detector (focus_dft,
+    intensity).  `P` is prysm_amd.propagation."""
+    wf = P.Wavefront.from_amp_and_phase(amp, opd, wvl, dx)
+    wf = wf * P.Wavefront.phase_screen(dm, wvl, dx)
+    at_lyot = wf.to_fpm_and_back(fpm, ex_fpm)
+    after_lyot = at_lyot * P.Wavefront(lyot, wvl, dx)
+    return after_lyot.focus_dft(ex_det).intensity.data
+
+
+def model7_flops():
+    n, a, b = MODEL7['n'], MODEL7['fpm_samples'], MODEL7['det_samples']
+    one = lambda m: 8.0 * m * n * (n + m)      # noqa: E731   two complex GEMMs of a (n x n) <-> (m x m) matrix DFT
+    return {'focus_to_fpm': one(a), 'unfocus_to_lyot': one(a), 'focus_to_detector': one(b), 'total': 2 * one(a) + one(b)}
+
+
+def model7_bytes(es):
+    """algorithmic HBM bytes of the pointwise planes (complex element size es): synthesis (2 maps in, field out), DM screen folded
+    into a multiply (map in, field in / out), mask multiply on the FPM grid, Lyot multiply, |.|^2"""
+    n, a, b = MODEL7['n'], MODEL7['fpm_samples'], MODEL7['det_samples']
+    r = es // 2
+    return {'pupil_synthesis': n * n * (2 * r + es), 'dm_screen_and_multiply': n * n * (r + es) + n * n * 3 * es, 'fpm_multiply': a * a * (2 * es + r),
+            'lyot_multiply': n * n * (2 * es + r), 'intensity': b * b * (es + r)}
+
+
+def sec_model7(out, wavelengths=9):
+    """model_7plane_1024: per wavelength -- eager, inside graph.sequence(), as one hipGraph replay -- at complex64
+    and complex128, plus the 9-wavelength aggregate the reference quotes; `published` = BASELINE.md's figures (other hardware)."""
+    from prysm_amd import propagation as P
+    from prysm_amd import graph as G
+    from prysm_amd.conf import config
+    res = {'planes': 7, 'pupil': f"{MODEL7['n']}^2", 'fpm_grid': f"{MODEL7['fpm_samples']}^2", 'detector': f"{MODEL7['det_samples']}^2",
+           'flops_per_wavelength': model7_flops(), 'published': MODEL7_PUBLISHED}
+    wvls = list(np.linspace(0.55, 0.65, wavelengths))
+    prec0 = config.precision
+    try:
+        for prec, tag in ((32, 'c64'), (64, 'c128')):
+            config.precision = prec
+            rdt = torch.float32 if prec == 32 else torch.float64
+            inp = model7_inputs()
+            dev = {k: torch.from_numpy(v).to(rdt).cuda() for k, v in inp.items() if k != 'dx'}
+            dx = inp['dx']
+            per = []
+            for w in wvls:
+                fdx, ddx = model7_grids(w)
+                per.append((w, torch.from_numpy(model7_fpm(w)).to(rdt).cuda(),
+                            P.prepare_executor(dx, MODEL7['n'], fdx, MODEL7['fpm_samples'], w, MODEL7['efl']),
+                            P.prepare_executor(dx, MODEL7['n'], ddx, MODEL7['det_samples'], w, MODEL7['efl'])))
+
+            def one(k=0):
+                w, fpm, exa, exb = per[k]
+                return model7(P, dev['amp'], dev['opd'], dev['dm'], fpm, dev['lyot'], w, dx, exa, exb)
+
+            def all_wvls():
+                acc = None
+                for k in range(len(per)):
+                    i = one(k)
+                    acc = i if acc is None else acc + i
+                return acc
+
+            def all_wvls_block():
+                with G.sequence():
+                    return all_wvls()
+
+            e = {'bytes_pointwise_planes': model7_bytes(8 if prec == 32 else 16)}
+            e['eager_ms_per_wavelength'] = _event_ms(one, 50)
+            e['eager_9wvl_ms'] = _event_ms(all_wvls, 10)
+            e['sequence_9wvl_ms'] = _event_ms(all_wvls_block, 10)
+            g1 = G.capture(lambda a, o: model7(P, a, o, dev['dm'], per[0][1], dev['lyot'], per[0][0], dx, per[0][2], per[0][3]), dev['amp'], dev['opd'])
+            e['graph_ms_per_wavelength'] = _event_ms(g1.graph.replay, 100)
+            g9 = G.capture(lambda a, o: all_wvls(), dev['amp'], dev['opd'])
+            e['graph_9wvl_ms'] = _event_ms(g9.graph.replay, 20)
+            e['graph_identical_to_eager'] = bool(torch.equal(g1(dev['amp'], dev['opd']), one()))
+            fl = model7_flops()['total']
+            peak = F32_MFMA_PEAK_TF if prec == 32 else F64_MFMA_PEAK_TF
+            e['graph_frac_of_mfma_peak'] = fl / (e['graph_ms_per_wavelength'] * 1e-3) / 1e12 / peak
+            res[tag] = e
+            del g1, g9, per, dev
+            torch.cuda.empty_cache()
+    finally:
+        config.precision = prec0
+    out['model_7plane_1024'] = res
 
 
 def other_configs(only=''):
@@ -533,7 +666,7 @@ def other_configs(only=''):
             del x4, ex
         finally:
             config.precision = prec
-    for key, fn in (('config2', sec_config2), ('config3', sec_config3), ('c128', sec_c128), ('n8192', sec_n8192), ('padded', sec_padded), ('composite', sec_composite), ('mtf', sec_mtf), ('conv', sec_conv), ('adjoint', sec_adjoint), ('config4', sec_config4)):
+    for key, fn in (('model7', lambda: sec_model7(out)), ('config2', sec_config2), ('config3', sec_config3), ('c128', sec_c128), ('n8192', sec_n8192), ('padded', sec_padded), ('composite', sec_composite), ('mtf', sec_mtf), ('conv', sec_conv), ('adjoint', sec_adjoint), ('config4', sec_config4)):
         if not want(key):
             continue
         try:
@@ -569,19 +702,24 @@ def cpu_baseline(n, cdtype, budget_s):
         'sample': f'{len(times)} x oracle.focus({n}x{n} {np.dtype(cdtype).name}, Q=1), median {med * 1e3:.1f} ms, '
                   f'min {min(times) * 1e3:.1f} ms; scipy.fft workers=1 (as prysm ships), host has {os.cpu_count()} cores',
     }
-    # second arm, informational: the knob prysm's docs recommend (scipy.fft.set_workers), all host cores
+    # second arm, informational: the knob prysm's docs recommend (scipy.fft.set_workers), swept over worker counts up to the host's
+    # logical cores -- the best one is reported (256 workers on a 64-core part was a straw man: 60 ms)
     try:
         from scipy import fft as sfft
-        workers = os.cpu_count() or 1
-        with sfft.set_workers(workers):
-            O.focus(x, 1)
-            t2 = []
-            for _ in range(5):
-                t0 = time.perf_counter()
+        ncpu = os.cpu_count() or 1
+        sweep = {}
+        for workers in sorted({w for w in (8, 16, 32, 64, 128) if w <= ncpu} | ({ncpu} if ncpu < 8 else set())):
+            with sfft.set_workers(workers):
                 O.focus(x, 1)
-                t2.append(time.perf_counter() - t0)
-        out['tuned'] = {'value': 1.0 / float(np.median(t2)), 'cores': workers,
-                        'sample': f'5 x the same call under scipy.fft.set_workers({workers}), median {np.median(t2) * 1e3:.1f} ms'}
+                t2 = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    O.focus(x, 1)
+                    t2.append(time.perf_counter() - t0)
+            sweep[workers] = float(np.median(t2))
+        best = min(sweep, key=sweep.get)
+        out['tuned'] = {'value': 1.0 / sweep[best], 'cores': best, 'ms_by_workers': {str(k): v * 1e3 for k, v in sweep.items()},
+                        'sample': f'5 x the same call under scipy.fft.set_workers(w), w in {sorted(sweep)}; best w = {best}, median {sweep[best] * 1e3:.1f} ms'}
     except Exception as exc:   # pragma: no cover
         out['tuned'] = {'error': repr(exc)}
     return out
@@ -617,25 +755,91 @@ class Ranks:
         return self.max(time.perf_counter() - t0)
 
 
-PREWARM_MS = 60.0      # untimed: see propagation_loop
+PREWARM_MIN_MS = 60.0      # untimed run-in: at least this long ...
+PREWARM_CAP_MS = 2000.0    # ... at most this long, ended as soon as three consecutive batches agree within PREWARM_TOL
+PREWARM_TOL = 0.01
 
 
-def propagation_loop(ranks, x, steps, warmup, prewarm_ms=PREWARM_MS):
+def gpu_state(dev_index=0):
+    """Core / memory clock (MHz), power (W) and temperature of the device, read from sysfs (microseconds: cheap enough to take right
+    before and right after the timed region) -- so that a line measured on a throttled or not-yet-ramped box says so itself
+    (the driver's five headline readings spread 13 % and nothing in the lines could tell why)."""
+    out = {}
+    try:
+        cards = sorted(c for c in glob.glob('/sys/class/drm/card[0-9]*/device') if os.path.exists(os.path.join(c, 'pp_dpm_sclk')))
+        if not cards:
+            return {'error': 'no /sys/class/drm/card*/device/pp_dpm_sclk'}
+        card = cards[min(dev_index, len(cards) - 1)]
+
+        def current_level(name):
+            try:
+                for ln in open(os.path.join(card, name)):
+                    if ln.rstrip().endswith('*'):
+                        return float(ln.split(':')[1].lower().replace('mhz', '').replace('*', '').strip())
+            except (OSError, ValueError, IndexError):
+                pass
+            return None
+
+        out['sclk_mhz'] = current_level('pp_dpm_sclk')
+        out['mclk_mhz'] = current_level('pp_dpm_mclk')
+        out['fclk_mhz'] = current_level('pp_dpm_fclk')
+        for hw in glob.glob(os.path.join(card, 'hwmon', 'hwmon*')):
+            for key, fname, scale in (('power_w', 'power1_average', 1e-6), ('power_w', 'power1_input', 1e-6),
+                                      ('temp_c', 'temp1_input', 1e-3), ('sclk_hwmon_mhz', 'freq1_input', 1e-6),
+                                      ('power_cap_w', 'power1_cap', 1e-6)):
+                if key in out and out[key] is not None:
+                    continue
+                try:
+                    out[key] = float(open(os.path.join(hw, fname)).read().strip()) * scale
+                except (OSError, ValueError):
+                    pass
+        try:
+            out['busy_pct'] = float(open(os.path.join(card, 'gpu_busy_percent')).read().strip())
+        except (OSError, ValueError):
+            pass
+    except Exception as exc:     # never lose a bench line to a sysfs surprise
+        out['error'] = repr(exc)
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def propagation_loop(ranks, x, steps, warmup, info=None, repeats=0):
     """warmup untimed + exactly `steps` timed focus(x, 1) per rank; returns seconds (MAX over ranks).
 
-    Before the W warm-up steps the same propagation runs untimed for about `prewarm_ms` of device time: a freshly leased GPU idles at a
-    low clock and a short run (the driver's --steps 20 --warmup 5 is 2.5 ms of work) would otherwise be timed on the clock ramp, not at
-    the steady state the metric (propagations per second) is about.  It is ordinary warm-up -- the same call on the same buffers,
-    nothing cached that a timed step reuses beyond what step 1 leaves for step 2 -- reported in the line as `prewarm_ms`."""
+    Before the W warm-up steps the same propagation runs untimed until the device has reached its steady state: batches of 40
+    propagations (synchronised one by one) are repeated until three consecutive batch times agree within 1 %, for at least
+    PREWARM_MIN_MS and at most PREWARM_CAP_MS.  A freshly leased GPU idles at a low clock and a short run (the driver's --steps 20
+    --warmup 5 is 2.5 ms of work) would otherwise be timed on the clock ramp, not at the steady state the metric (propagations per
+    second) is about; rounds 1 - 5 ran in for a fixed 60 ms, which on some boxes was not enough (driver readings 9.4 - 10.7 k/s).
+    It is ordinary warm-up -- the same call on the same buffers, nothing cached that a timed step reuses beyond what step 1 leaves
+    for step 2.  `info` (a dict) receives what was spent (`prewarm_ms`, `prewarm_batches`, the last batch times), the device's
+    clocks / power right before and right after the timed region (gpu_state), and -- AFTER the contract's one timed region --
+    `repeats` more batches of `steps` timed the same way (`repeat_ms`: ms per step of each), so a line shows its own spread."""
     from prysm_amd import propagation as P
     f = None
-    if prewarm_ms > 0:
+    info = {} if info is None else info
+
+    def batch(k):
+        nonlocal f
         t0 = time.perf_counter()
-        while (time.perf_counter() - t0) * 1e3 < prewarm_ms:
-            for _ in range(20):
-                f = None
-                f = P.focus(x, 1)
-            torch.cuda.synchronize()
+        for _ in range(k):
+            f = None
+            f = P.focus(x, 1)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    t_start = time.perf_counter()
+    hist = []
+    while True:
+        hist.append(batch(40))
+        spent = (time.perf_counter() - t_start) * 1e3
+        steady = len(hist) >= 3 and max(hist[-3:]) <= min(hist[-3:]) * (1.0 + PREWARM_TOL)
+        if (steady and spent >= PREWARM_MIN_MS) or spent >= PREWARM_CAP_MS:
+            break
+    info['prewarm_ms'] = (time.perf_counter() - t_start) * 1e3
+    info['prewarm_batches'] = len(hist)
+    info['prewarm_steady'] = bool(steady)
+    info['prewarm_first_batch_ms_per_step'] = hist[0] / 40 * 1e3
+    info['prewarm_last_batches_ms_per_step'] = [t / 40 * 1e3 for t in hist[-3:]]
     for _ in range(warmup):
         f = None
         f = P.focus(x, 1)
@@ -646,7 +850,13 @@ def propagation_loop(ranks, x, steps, warmup, prewarm_ms=PREWARM_MS):
             f = None       # release the previous focal field first: the caching allocator then hands the same block
             f = P.focus(x, 1)   # back, so the steady state touches in + workspace + out (not two alternating outputs)
 
-    return ranks.timed(run), f
+    dev = torch.cuda.current_device()
+    info['gpu_before'] = gpu_state(dev)
+    elapsed = ranks.timed(run)
+    info['gpu_after'] = gpu_state(dev)
+    if repeats:
+        info['repeat_ms'] = [ranks.timed(run) / steps * 1e3 for _ in range(repeats)]
+    return elapsed, f
 
 
 def polychromatic_config5(ranks, n, reduce_ms, method='auto', reps=3, frames=6):
@@ -842,7 +1052,8 @@ def main():
     x = torch.from_numpy(make_field(n, cdtype, 4096 + rank)).cuda()
     if world > 1:
         dist.all_reduce(torch.zeros(1, device='cuda'))     # create the communicator outside every timed region
-    elapsed, f = propagation_loop(ranks, x, args.steps, args.warmup)
+    loop_info = {}
+    elapsed, f = propagation_loop(ranks, x, args.steps, args.warmup, info=loop_info, repeats=4)
     del f
 
     # ---- the headline line, complete as the contract wants it, BEFORE any side measurement
@@ -880,8 +1091,12 @@ def main():
                                  'back-to-back loop of 100 launches on the launch stream (pm_fft2_time_passes); passes_over_step = '
                                  '(row + column) / ms_per_step; two_plain_copies_ms = torch copies in -> ws -> out of the same field, '
                                  'measured in this run'},
-            'prewarm_ms': PREWARM_MS,
         }
+        line.update(loop_info)
+        rep = loop_info.get('repeat_ms') or []
+        if rep:
+            allr = rep + [ms_step]
+            line['repeat_spread'] = (max(allr) - min(allr)) / min(allr)
 
     # The side measurements below include this code's collectives (config 5).  A hang or a crash there must not cost the run its
     # headline: after --extras-budget seconds rank 0 prints the line it already has and every rank leaves (one JSON line either way).

@@ -73,8 +73,27 @@ def _tensors_of(obj, out):
         d = getattr(obj, '__dict__', None)
         if d:
             t = d.get('_data', d.get('data'))
-            if isinstance(t, torch.Tensor) and t.is_cuda:
-                out.append(t)
+            if isinstance(t, torch.Tensor):
+                if t.is_cuda:
+                    out.append(t)
+            elif t is None and d.get('_synth') is not None:
+                # a lazy Wavefront (from_amp_and_phase: `_data` None, the maps held in `_synth`): whoever reads it reads the maps
+                # (an OPD summed inside the block on one ring stream must order the synthesis that reads it)
+                for o in d['_synth']:
+                    if isinstance(o, torch.Tensor) and o.is_cuda:
+                        out.append(o)
+    return out
+
+
+def _holders_of(obj, out):
+    """argument objects that may materialise an array DURING a call (lazy Wavefronts: `_data` None, `_synth` set)"""
+    if isinstance(obj, (list, tuple)):
+        for o in obj:
+            _holders_of(o, out)
+    elif obj is not None and not isinstance(obj, (torch.Tensor, int, float, complex, str, bytes, dict)):
+        d = getattr(obj, '__dict__', None)
+        if d and d.get('_data', 0) is None and d.get('_synth') is not None:
+            out.append(obj)
     return out
 
 
@@ -207,7 +226,11 @@ class Sequence:
         self.ring = StreamRing(streams, device)
         self.cache_budget = 200 << 20      # bytes of the 256 MiB Infinity Cache the concurrent propagations may claim
         self._producer = {}       # data pointer of a tensor made inside the block -> its stream
-        self._checked = set()     # data pointers of outside inputs already ordered behind the caller's stream
+        # outside inputs already ordered behind the caller's stream: data pointer -> (the tensor, its version counter).  The tensor is
+        # HELD until the next fork / join: a per-iteration temporary (amp.to(dtype), a mask built in the loop) that was dropped could
+        # otherwise hand its address to the next iteration's temporary, which would then count as ordered without being so;
+        # the version counter catches a buffer the caller rewrites in place between two calls.
+        self._checked = {}
         self._depth = 0
         self._caller = None
         self._set = getattr(torch._C, '_cuda_setStream', None)
@@ -259,10 +282,12 @@ class Sequence:
             k = _key(t)
             ps = prod.get(k)
             if ps is None:
-                if k not in checked:
-                    fresh = (fresh or []) + [k]
-                    for r in self.ring.streams:      # allocated elsewhere, read on the ring: its block must not be recycled under those reads
-                        t.record_stream(r)
+                seen = checked.get(k)
+                if seen is None or seen[1] != t._version:
+                    fresh = (fresh or []) + [(k, t)]
+                    if seen is None:
+                        for r in self.ring.streams:      # allocated elsewhere, read on the ring: its block must not be recycled under those reads
+                            t.record_stream(r)
             elif ps is not s:
                 if s is None:
                     s = ps
@@ -288,11 +313,15 @@ class Sequence:
         if fresh:
             # inputs that were not made inside the block: from before it (ordered by the fork) or from a plain torch operation on the
             # caller's stream since (amp.to(dtype), a mask built in the loop).  If the caller's stream is not idle, EVERY ring stream waits
-            # for it once; after that the tensor counts as ordered.
+            # for it once; after that THIS tensor at THIS version counts as ordered.
             if not self._caller.query():
                 for r in self.ring.streams:
                     r.wait_stream(self._caller)
-            checked.update(fresh)
+            if len(checked) > 256:              # a long block of temporaries: let the old ones go (they carry record_stream notes)
+                checked.clear()
+            for k, t in fresh:
+                checked[k] = (t if t._base is None else t._base, t._version)
+        lazy = _holders_of(args, [])
         self._depth = 1
         self._switch(s)
         try:
@@ -303,7 +332,12 @@ class Sequence:
         made = self.ring._made
         if len(made) > 4096:                # a long block: forget the results that are gone already
             made[:] = [r for r in made if r() is not None]
-        for t in _tensors_of(out, []):
+        news = _tensors_of(out, [])
+        for h in lazy:                      # a lazy Wavefront among the arguments that materialised its array inside this call: made on s
+            t = h.__dict__.get('_data')
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                news.append(t)
+        for t in news:
             made.append(weakref.ref(t))     # recorded on the caller's stream at the join if still alive (StreamRing.join)
             prod[_key(t)] = s
         return out

@@ -7,6 +7,7 @@
 #   ab:<libA>:<libB>[:rounds]  two builds against each other (exp_ab_libs)  -> ab.log
 #   knob:<knob>:<v0,v1>:<workload>[,<workload>...][:rounds]                 -> knob_<knob>.log
 #   py:<script.py>[:args]      any tools/ experiment script                 -> <script>.log
+#   sh:<script.sh>[:args]      a shell script, called with its output directory $O/<script> first -> <script>.log
 #   prof:<tag>:<bench.py args> rocprofv3 kernel stats + FETCH / WRITE passes + summary (tools/pmc_summary.py)
 #   sq:<tag>:<kernel substr>:<bench.py args>   two SQ counter passes -> <tag>_sq_counters.txt
 export TMPDIR=/tmp
@@ -21,6 +22,7 @@ for step in "$@"; do
     bench) ( timeout 900 python bench.py $a ) > $O/bench${b:+_$b}.log 2>&1; tail -1 $O/bench${b:+_$b}.log | cut -c1-600 ;;
     ab) ( timeout 900 python tools/exp_ab_libs.py $a $b ${c:-2} ) > $O/ab.log 2>&1; cat $O/ab.log ;;
     knob) ( timeout 600 python tools/exp_knob_ab.py $a $b ${c//,/ } ${d:-3} ) > $O/knob_$a.log 2>&1; cat $O/knob_$a.log ;;
+    sh) n=$(basename $a .sh); ( timeout 2400 bash $a $O/$n $b ) > $O/$n.log 2>&1; tail -15 $O/$n.log ;;
     py) n=$(basename $a .py); ( timeout 900 python $a $b ) > $O/$n.log 2>&1; tail -40 $O/$n.log ;;
     prof)
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$a -- python $R/bench.py $b ) > $O/rocprof_$a.log 2>&1
