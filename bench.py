@@ -89,7 +89,8 @@ def _summary(line):
         'frac': get('roofline/frac'), 'two_copies_ms': get('roofline/two_plain_copies_ms'), 'n2048_per_s': get('n2048/value'),
         'psf_variant_ms': get('psf_variant/ms_per_psf'),
         'm7_c64_eager_ms': get(oc + 'model_7plane_1024/c64/eager_ms_per_wavelength'), 'm7_c64_graph_ms': get(oc + 'model_7plane_1024/c64/graph_ms_per_wavelength'),
-        'm7_c64_9wvl_graph_ms': get(oc + 'model_7plane_1024/c64/graph_9wvl_ms'), 'm7_c64_9wvl_sequence_ms': get(oc + 'model_7plane_1024/c64/sequence_9wvl_ms'),
+        'm7_c64_9wvl_graph_ms': get(oc + 'model_7plane_1024/c64/graph_9wvl_ms'), 'm7_c64_9wvl_graph_branches_ms': get(oc + 'model_7plane_1024/c64/graph_branches_9wvl_ms'),
+        'm7_c64_czt_graph_ms': get(oc + 'model_7plane_1024/c64/czt/graph_ms_per_wavelength'), 'm7_c64_czt_9wvl_graph_branches_ms': get(oc + 'model_7plane_1024/c64/czt/graph_branches_9wvl_ms'),
         'm7_c128_eager_ms': get(oc + 'model_7plane_1024/c128/eager_ms_per_wavelength'), 'm7_c128_graph_ms': get(oc + 'model_7plane_1024/c128/graph_ms_per_wavelength'),
         'm7_published_titan_xp_ms': get(oc + 'model_7plane_1024/published/titan_xp_cupy_ms_per_wavelength'),
         'c2_ms': get(oc + 'config2_focus_2048_c64/ms'), 'c2_two_streams_ms': get(oc + 'config2_focus_2048_c64/two_streams/ms'),
@@ -377,42 +378,68 @@ def sec_model7(out, wavelengths=9):
             inp = model7_inputs()
             dev = {k: torch.from_numpy(v).to(rdt).cuda() for k, v in inp.items() if k != 'dx'}
             dx = inp['dx']
-            per = []
-            for w in wvls:
-                fdx, ddx = model7_grids(w)
-                per.append((w, torch.from_numpy(model7_fpm(w)).to(rdt).cuda(),
-                            P.prepare_executor(dx, MODEL7['n'], fdx, MODEL7['fpm_samples'], w, MODEL7['efl']),
-                            P.prepare_executor(dx, MODEL7['n'], ddx, MODEL7['det_samples'], w, MODEL7['efl'])))
+            def build(kind):
+                per = []
+                for w in wvls:
+                    fdx, ddx = model7_grids(w)
+                    per.append((w, torch.from_numpy(model7_fpm(w)).to(rdt).cuda(),
+                                P.prepare_executor(dx, MODEL7['n'], fdx, MODEL7['fpm_samples'], w, MODEL7['efl'], kind=kind),
+                                P.prepare_executor(dx, MODEL7['n'], ddx, MODEL7['det_samples'], w, MODEL7['efl'], kind=kind)))
+                return per
 
-            def one(k=0):
-                w, fpm, exa, exb = per[k]
-                return model7(P, dev['amp'], dev['opd'], dev['dm'], fpm, dev['lyot'], w, dx, exa, exb)
+            def measure(per, full):
+                def one(k=0):
+                    w, fpm, exa, exb = per[k]
+                    return model7(P, dev['amp'], dev['opd'], dev['dm'], fpm, dev['lyot'], w, dx, exa, exb)
 
-            def all_wvls():
-                acc = None
-                for k in range(len(per)):
-                    i = one(k)
-                    acc = i if acc is None else acc + i
-                return acc
+                def all_wvls():
+                    acc = None
+                    for k in range(len(per)):
+                        i = one(k)
+                        acc = i if acc is None else acc + i
+                    return acc
 
-            def all_wvls_block():
-                with G.sequence():
-                    return all_wvls()
+                def all_wvls_block():
+                    with G.sequence(streams=3):
+                        imgs = [one(k) for k in range(len(per))]
+                    acc = imgs[0]
+                    for i in imgs[1:]:
+                        acc = acc + i
+                    return acc
 
-            e = {'bytes_pointwise_planes': model7_bytes(8 if prec == 32 else 16)}
-            e['eager_ms_per_wavelength'] = _event_ms(one, 50)
-            e['eager_9wvl_ms'] = _event_ms(all_wvls, 10)
-            e['sequence_9wvl_ms'] = _event_ms(all_wvls_block, 10)
-            g1 = G.capture(lambda a, o: model7(P, a, o, dev['dm'], per[0][1], dev['lyot'], per[0][0], dx, per[0][2], per[0][3]), dev['amp'], dev['opd'])
-            e['graph_ms_per_wavelength'] = _event_ms(g1.graph.replay, 100)
-            g9 = G.capture(lambda a, o: all_wvls(), dev['amp'], dev['opd'])
-            e['graph_9wvl_ms'] = _event_ms(g9.graph.replay, 20)
-            e['graph_identical_to_eager'] = bool(torch.equal(g1(dev['amp'], dev['opd']), one()))
+                e = {}
+                e['eager_ms_per_wavelength'] = _event_ms(one, 50)
+                g1 = G.capture(lambda a, o: model7(P, a, o, dev['dm'], per[0][1], dev['lyot'], per[0][0], dx, per[0][2], per[0][3]), dev['amp'], dev['opd'])
+                e['graph_ms_per_wavelength'] = _event_ms(g1.graph.replay, 100)
+                e['graph_identical_to_eager'] = bool(torch.equal(g1(dev['amp'], dev['opd']), one()))
+                e['eager_9wvl_ms'] = _event_ms(all_wvls, 10)
+                if full:
+                    e['sequence_9wvl_ms'] = _event_ms(all_wvls_block, 10)
+                g9 = G.capture(lambda a, o: all_wvls(), dev['amp'], dev['opd'])
+                e['graph_9wvl_ms'] = _event_ms(g9.graph.replay, 20)
+                # the nine independent chains captured INSIDE a sequence block: the hipGraph gets one branch per ring stream, the chains
+                # overlap on the device (small GEMMs that fill a quarter of the CUs each) and no host dispatch is left to pay for it
+                g9s = G.capture(lambda a, o: all_wvls_block(), dev['amp'], dev['opd'])
+                e['graph_branches_9wvl_ms'] = _event_ms(g9s.graph.replay, 20)
+                e['graph_branches_identical'] = bool(torch.equal(g9s(dev['amp'], dev['opd']), g9(dev['amp'], dev['opd'])))
+                e['graph_branches_ms_per_wavelength'] = e['graph_branches_9wvl_ms'] / len(per)
+                del g1, g9, g9s
+                return e
+
+            per = build('mdft')
+            e = measure(per, True)
+            e['bytes_pointwise_planes'] = model7_bytes(8 if prec == 32 else 16)
             fl = model7_flops()['total']
             peak = F32_MFMA_PEAK_TF if prec == 32 else F64_MFMA_PEAK_TF
             e['graph_frac_of_mfma_peak'] = fl / (e['graph_ms_per_wavelength'] * 1e-3) / 1e12 / peak
+            e['graph_branches_frac_of_mfma_peak'] = fl / (e['graph_branches_ms_per_wavelength'] * 1e-3) / 1e12 / peak
+            del per
+            # the same planes through the chirp-Z executors the reference offers beside the matrix DFT (prepare_executor(kind='czt'),
+            # prysm/fttools.py:235-389): one fused convolution kernel per axis instead of two GEMMs
+            per = build('czt')
+            e['czt'] = measure(per, False)
             res[tag] = e
-            del g1, g9, per, dev
+            del per, dev
             torch.cuda.empty_cache()
     finally:
         config.precision = prec0
@@ -769,7 +796,21 @@ def gpu_state(dev_index=0):
         cards = sorted(c for c in glob.glob('/sys/class/drm/card[0-9]*/device') if os.path.exists(os.path.join(c, 'pp_dpm_sclk')))
         if not cards:
             return {'error': 'no /sys/class/drm/card*/device/pp_dpm_sclk'}
-        card = cards[min(dev_index, len(cards) - 1)]
+        # the box's sysfs shows every GPU of the host; the one this process computes on is found by its PCI address
+        card = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            bdf = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+            for c in cards:
+                if os.path.basename(os.path.realpath(c)).lower() == bdf:
+                    card = c
+                    out['pci'] = bdf
+        except Exception:
+            pass
+        if card is None:
+            if len(cards) > 1:
+                return {'error': f'{len(cards)} cards in sysfs and no PCI address to pick this device by'}
+            card = cards[0]
 
         def current_level(name):
             try:
@@ -785,7 +826,7 @@ def gpu_state(dev_index=0):
         out['fclk_mhz'] = current_level('pp_dpm_fclk')
         for hw in glob.glob(os.path.join(card, 'hwmon', 'hwmon*')):
             for key, fname, scale in (('power_w', 'power1_average', 1e-6), ('power_w', 'power1_input', 1e-6),
-                                      ('temp_c', 'temp1_input', 1e-3), ('sclk_hwmon_mhz', 'freq1_input', 1e-6),
+                                      ('temp_c', 'temp1_input', 1e-3), ('temp_c', 'temp2_input', 1e-3), ('sclk_hwmon_mhz', 'freq1_input', 1e-6),
                                       ('power_cap_w', 'power1_cap', 1e-6)):
                 if key in out and out[key] is not None:
                     continue

@@ -233,6 +233,7 @@ class Sequence:
         self._checked = {}
         self._depth = 0
         self._caller = None
+        self._capturing = False
         self._set = getattr(torch._C, '_cuda_setStream', None)
         self._ids = {}            # id(stream) -> the three integers of the raw setter
 
@@ -249,6 +250,10 @@ class Sequence:
         if active_sequence() is not None:
             raise RuntimeError('prysm_amd.graph.sequence() blocks do not nest')
         self._caller = torch.cuda.current_stream()
+        # inside a hipGraph capture (graph.capture of a function that opens a sequence block: the captured graph then has one branch
+        # per ring stream, and independent chains -- the wavelengths of a model -- overlap on the device at no host cost) a stream
+        # must not be queried: every outside input counts as "the caller's stream is busy"
+        self._capturing = torch.cuda.is_current_stream_capturing()
         _seq_state.seq = self
         self.ring.fork()
         return self
@@ -314,7 +319,7 @@ class Sequence:
             # inputs that were not made inside the block: from before it (ordered by the fork) or from a plain torch operation on the
             # caller's stream since (amp.to(dtype), a mask built in the loop).  If the caller's stream is not idle, EVERY ring stream waits
             # for it once; after that THIS tensor at THIS version counts as ordered.
-            if not self._caller.query():
+            if self._capturing or not self._caller.query():
                 for r in self.ring.streams:
                     r.wait_stream(self._caller)
             if len(checked) > 256:              # a long block of temporaries: let the old ones go (they carry record_stream notes)

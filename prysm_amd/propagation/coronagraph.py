@@ -4,25 +4,20 @@ Pure compositions of the fixed-sampling executors (MFMA GEMM pairs), pointwise c
 the workloads behind prysm's published speed figures.  Same signatures and return conventions as the reference.
 """
 import numbers
+import operator
 
 import torch
 
 from .. import _lib as L
 from .. import _ops
 from ..conf import config
-from ._kernels import _adjoint_multiply
+from ._kernels import _adjoint_multiply, field_multiply, field_combine
 from .dft import focus_dft, focus_dft_adjoint, unfocus_dft, unfocus_dft_adjoint
 
 
 def _mul(a, b):
-    """a * b with the complex x complex 2-D case on the HIP kernel, numpy-style promotion otherwise."""
-    if isinstance(b, numbers.Number):
-        return a * b
-    b = L.as_device(b)
-    if (a.is_complex() and b.is_complex() and a.dtype == b.dtype and a.dim() == 2 and a.shape == b.shape
-            and a.is_contiguous() and b.is_contiguous()):
-        return _ops.cmul(a, b)
-    return a * b
+    """a * b with the complex x complex and complex x real 2-D cases on the HIP kernels, numpy-style promotion otherwise."""
+    return field_multiply(a, b)
 
 
 def _one_minus(fpm):
@@ -109,9 +104,9 @@ def to_fpm_and_back_multiresolution(wavefunction, fpm, executor, return_more=Fal
     fields_at_fpm, fields_after_fpm = [], []
     for ex, win, xf, yf in zip(executor.executors, executor.windows, executor.xf, executor.yf):
         field_at_fpm = focus_dft(wavefunction, ex)
-        field_after_fpm = field_at_fpm * fpm(xf, yf) * win
+        field_after_fpm = _mul(_mul(field_at_fpm, fpm(xf, yf)), win)
         contribution = unfocus_dft(field_after_fpm, ex)
-        out = contribution if out is None else out + contribution
+        out = contribution if out is None else field_combine(operator.add, out, contribution)
         if return_more:
             fields_at_fpm.append(field_at_fpm)
             fields_after_fpm.append(field_after_fpm)
@@ -131,9 +126,9 @@ def to_fpm_and_back_multiresolution_adjoint(wavefunction, fpm, executor, return_
     for k, (ex, win, xf, yf) in enumerate(levels):
         m = L.as_device(fpm(xf, yf))
         Ebbar = unfocus_dft_adjoint(wavefunction, ex)
-        intermediate = _adjoint_multiply(Ebbar, m * win)
+        intermediate = _adjoint_multiply(Ebbar, _mul(m, win) if m.is_complex() else m * win)
         contribution = focus_dft_adjoint(intermediate, ex)
-        out = contribution if out is None else out + contribution
+        out = contribution if out is None else field_combine(operator.add, out, contribution)
         if return_more:
             Ebbars.append(Ebbar)
             intermediates.append(intermediate)
@@ -159,9 +154,9 @@ def babinet(wavefunction, lyot, fpm, executor, return_more=False):
         field = result
     if field.dtype != wavefunction.dtype:
         wavefunction = wavefunction.to(field.dtype)
-    field_at_lyot = wavefunction - field
+    field_at_lyot = field_combine(operator.sub, wavefunction, field)
     if lyot is not None:
-        field_after_lyot = L.as_device(lyot) * field_at_lyot
+        field_after_lyot = _mul(field_at_lyot, lyot)
     else:
         field_after_lyot = field_at_lyot
     if return_more:
@@ -186,7 +181,7 @@ def babinet_adjoint(wavefunction, lyot, fpm, executor, field_at_fpm=None,
         abar = to_fpm_and_back_adjoint(cbar, fpm=fpm, executor=executor)
     if cbar.dtype != abar.dtype:
         cbar = cbar.to(abar.dtype)
-    abar = cbar - abar
+    abar = field_combine(operator.sub, cbar, abar)
     if not (return_fpm_grad or return_lyot_grad):
         return abar
     out = [abar]

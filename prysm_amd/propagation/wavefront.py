@@ -15,6 +15,7 @@ import torch
 from .. import _lib as L
 from .. import _ops
 from ..graph import sequenced
+from ._kernels import field_multiply
 from .._richdata import RichData
 from ._kernels import phase_prefix
 from .fft import (
@@ -94,6 +95,14 @@ class Wavefront:
             a = np.asarray(self.data)
         return a.astype(dtype) if dtype is not None else a
 
+    def _lazy(self):
+        """(amp, opd, k, complex dtype) while the field has not been materialised, else None"""
+        return self._synth if self._data is None else None
+
+    def _shape(self):
+        lz = self._lazy()
+        return tuple(lz[1].shape) if lz is not None else tuple(self.data.shape)
+
     def _fusable(self, Q):
         """(amp, opd, k) when the pupil can be synthesised inside the FFT (not yet materialised, power-of-two padded width),
         else None."""
@@ -129,8 +138,9 @@ class Wavefront:
     def phase_screen(cls, phase, wavelength, dx):
         """exp(i 2 pi / (wavelength 1e3) * phase_nm) (wavefront.py:81-96)."""
         opd = _real_opd(phase)
-        E = _ops.pupil_synth(None, opd, 2 * math.pi / wavelength / 1e3, L._COMPLEX_OF[opd.dtype])
-        return cls(E, wavelength, dx)
+        wf = cls(None, wavelength, dx)           # lazy, like from_amp_and_phase: a screen is usually multiplied into a pupil at once,
+        wf._synth = (None, opd, 2 * math.pi / wavelength / 1e3, L._COMPLEX_OF[opd.dtype])     # see __numerical_operation__
+        return wf
 
     @classmethod
     def thin_lens(cls, f, wavelength, x, y):
@@ -250,21 +260,32 @@ class Wavefront:
         if isinstance(other, Wavefront):
             criteria = [
                 abs(self.dx - other.dx) / self.dx * 100 < 0.1,
-                tuple(self.data.shape) == tuple(other.data.shape),
+                self._shape() == other._shape(),
                 self.wavelength == other.wavelength,
                 self.space == other.space,
             ]
             if not all(criteria):
                 raise ValueError('all physicality criteria not met: sample spacing, shape, wavelength, or space different.')
-            a, b = self.data, other.data
-            if (op == 'mul' and a.is_complex() and b.is_complex() and a.dtype == b.dtype and a.dim() == 2
-                    and a.is_contiguous() and b.is_contiguous()):
-                data = _ops.cmul(a, b)   # the hot pointwise product runs in the HIP kernel
+            if op == 'mul':
+                la, lb = self._lazy(), other._lazy()
+                if la is not None and lb is not None and la[2] == lb[2] and la[3] == lb[3] and la[1].dtype == lb[1].dtype:
+                    # A1 exp(i k W1) * A2 exp(i k W2) = (A1 A2) exp(i k (W1 + W2)): two wavefronts that have not been materialised
+                    # (a pupil from from_amp_and_phase times a phase_screen -- a deformable mirror, an aberration, a lens) stay ONE
+                    # lazy wavefront: a real addition instead of two synthesis sweeps and a complex product (round 6)
+                    amp = la[0] if lb[0] is None else (lb[0] if la[0] is None else la[0] * lb[0])
+                    wf = Wavefront(None, self.wavelength, self.dx, self.space)
+                    wf._synth = (amp, la[1] + lb[1], la[2], la[3])
+                    return wf
+                data = field_multiply(self.data, other.data)   # the hot pointwise products run in the HIP kernels (pm_cmul, pm_rmul)
             else:
+                a, b = self.data, other.data
                 data = func(b, a) if reverse else func(a, b)
         elif isinstance(other, (torch.Tensor, np.ndarray)):
             o = L.as_device(other)
-            data = func(o, self.data) if reverse else func(self.data, o)
+            if op == 'mul' and isinstance(self.data, torch.Tensor):
+                data = field_multiply(self.data, o)
+            else:
+                data = func(o, self.data) if reverse else func(self.data, o)
         elif isinstance(other, numbers.Number):
             data = func(other, self.data) if reverse else func(self.data, other)
         else:

@@ -125,6 +125,16 @@ def test_model_7plane_1024_vs_oracle(pa, prec, tol):
         opd2 = dev['opd'] * 0.5
         want = bench.model7(P, dev['amp'], opd2, dev['dm'], per[0][1], dev['lyot'], per[0][0], inp['dx'], per[0][2], per[0][3])
         assert torch.equal(g(dev['amp'], opd2), want)
+        # both wavelengths captured INSIDE a sequence block: a hipGraph with one branch per ring stream, the same bits again
+
+        def both(a, o):
+            with G.sequence():
+                imgs = [bench.model7(P, a, o, dev['dm'], p_[1], dev['lyot'], p_[0], inp['dx'], p_[2], p_[3]) for p_ in per]
+            return imgs[0] + imgs[1]
+
+        gb = G.capture(both, dev['amp'], dev['opd'])
+        for _ in range(3):
+            assert torch.equal(gb(dev['amp'], dev['opd']), eager[0] + eager[1])
     finally:
         config.precision = prec0
 
