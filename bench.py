@@ -99,7 +99,7 @@ def _summary(line):
         'c128_2048_loop_ms': get(oc + 'focus_2048_c128_sequence_block/loop_ms'), 'c128_2048_sequence_ms': get(oc + 'focus_2048_c128_sequence_block/ms'),
         'c3_ms': get(oc + 'config3_angular_spectrum_4096_c128/ms'), 'c3_moved_frac': get(oc + 'config3_angular_spectrum_4096_c128/moved_frac_of_hbm_peak'),
         'c4_ms': get(oc + 'config4_mdft_2048_to_512_c64/ms'), 'c4_build_ms': get(oc + 'config4_mdft_2048_to_512_c64/prepare_executor_ms'),
-        'c4_frac_mfma': get(oc + 'config4_mdft_2048_to_512_c64/frac_of_f32_mfma_peak'),
+        'c4_frac_mfma': get(oc + 'config4_mdft_2048_to_512_c64/frac_of_f32_mfma_peak'), 'c4_mfma_busy': get(oc + 'config4_mdft_2048_to_512_c64/mfma_busy'),
         'c128_4096_ms': get(oc + 'focus_4096_c128/ms'), 'c64_8192_ms': get(oc + 'focus_8192_c64/ms'),
         'mtf_4096_ms': get(oc + 'mtf_from_psf_4096_f32/ms'), 'mtf_3000_ms': get(oc + 'mtf_from_psf_3000_f32/ms'),
         'mtf_3000_composed_ms': get(oc + 'mtf_from_psf_3000_f32/composed_ms'), 'conv_4096_ms': get(oc + 'conv_real_4096_f32/ms'),
@@ -666,6 +666,21 @@ def other_configs(only=''):
                 'ms': ms, 'prepare_executor_ms': build_ms, 'algorithmic_TFLOPs': fl / (ms * 1e-3) / 1e12,
                 'frac_of_f32_mfma_peak': fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
                 'bound': 'mfma', 'note': 'two complex GEMMs on v_mfma_f32_32x32x2_f32; peak 157.3 TFLOP/s (MI355X_MICROARCH.md)'}
+            # the graded flops are the four-product form's; the kernels run the 3M form (three real products per complex one), so they
+            # EXECUTE 0.75 of them: `frac_of_f32_mfma_peak` is an accounting fraction, `executed_frac_of_f32_mfma_peak` and the counters'
+            # `mfma_busy` (SQ_VALU_MFMA_BUSY_CYCLES over SIMD-cycles, from the committed PMC pass of this command while the kernel
+            # sources are unchanged) are utilisation
+            e4 = out['config4_mdft_2048_to_512_c64']
+            e4['executed_TFLOPs'] = 0.75 * e4['algorithmic_TFLOPs']
+            e4['executed_frac_of_f32_mfma_peak'] = 0.75 * e4['frac_of_f32_mfma_peak']
+            try:
+                tab = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_config4_mfma_busy.json')))
+                if tab.get('_meta', {}).get('source_fingerprint') == source_fingerprint():
+                    e4['mfma_busy'] = tab.get('mfma_busy_time_weighted_over_the_two_products')
+                else:
+                    e4['mfma_busy_note'] = 'stale: counters collected at other kernel sources'
+            except (OSError, ValueError):
+                pass
             if not only:
                 # the same focal grid by the chirp-Z executor (prysm/fttools.py:235-389), for comparison
                 exz = P.prepare_executor(10 / 2048, (2048, 2048), 0.6328 * 10 / 8, (512, 512), 0.6328, 100.0, kind='czt')

@@ -24,7 +24,8 @@ cp $O/pmc_bench_summary.json $R/profiles/pmc_bench_summary.json
 ( timeout 900 python bench.py ) > $O/bench.log 2>&1
 for c in config2 config3 config4 c128 n8192 padded composite mtf conv adjoint poly2048; do prof $c --only $c; done
 ( cd /tmp && timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq_config4 -- python $R/bench.py --only config4 ) > $O/rocprof_sq_config4.log 2>&1
-python tools/pmc_clock.py $O/pmc_sq_config4 2>&1 | grep pm:: > $O/config4_mfma_busy.txt
+python tools/pmc_clock.py $O/pmc_sq_config4 $O/pmc_config4_mfma_busy.json 2>&1 | grep pm:: > $O/config4_mfma_busy.txt
+cp $O/pmc_config4_mfma_busy.json $R/profiles/pmc_config4_mfma_busy.json
 rm -rf $O/pmc_sq_config4
 # SQ counters of the headline's two kernels (two passes of eight counters)
 ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --output-format csv -d $O/pmc_sq1 -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-poly ) > $O/rocprof_sq1.log 2>&1
