@@ -13,6 +13,7 @@
 #include "fft_mixed.h"
 #include "pm_internal.h"
 #include "fft_r2c_types.h"
+#include "fft_hermt_types.h"
 #include "fft_conv1_types.h"
 #include "fft_spectral_types.h"
 #include "fft_c2r_types.h"
@@ -187,6 +188,9 @@ static void tune_set(Tuning& t, const char* key, size_t klen, int v) {
     else if (is("batch_ws_mib")) t.batch_ws_mib = v < 1 ? 1 : v;
     else if (is("colmul_mode")) t.colmul_mode = v;
     else if (is("herm_wide")) t.herm_wide = v;
+    else if (is("herm_t")) t.herm_t = v < 0 ? -1 : (v ? 1 : 0);
+    else if (is("herm_t_fold")) t.herm_t_fold = v < 0 ? -1 : (v ? 1 : 0);
+    else if (is("herm_t_rowvar")) t.herm_t_rowvar = v;
     else if (is("spectral")) t.spectral = v;
     else if (is("spectral_mode")) t.spectral_mode = v & 3;
     else if (is("spectral_area_log")) t.spectral_area_log = v;
@@ -276,6 +280,8 @@ struct Fft2Plan {
     int logn, logm;       // engine log2 sizes or -1 (direct)
     int tc;               // column-pass tile width when both passes run on the engine, else 0 (natural intermediate)
     bool r2c;             // real input on the Hermitian path (fft_r2c.h): N/2-point row transforms, N/2 + 1 columns, mirrored stores
+    bool r2c_t;           // ... in its transposed form (fft_hermt.h, round 6): real-input COLUMN transforms into an M/2 x N natural intermediate,
+                          // then full-length row transforms that store every row and its mirror image as whole lines
     int col_var;          // column-pass tiling (ColCfgSel): 2 = 128 B tiles for the planes of a folded 4096-row complex128 transform
     int log_k;            // layout tile width TL = tc << log_k
     size_t ws_bytes;      // total
@@ -329,6 +335,25 @@ static bool r2c_legal(const pm_fft2_desc* d, int logn, int logm) {
     return true;
 }
 
+// Transposed Hermitian form (fft_hermt.h): what r2c_legal accepts, with every rotation 0 or half a length (the input's become signs) and
+// lengths the two kernels exist for.  Auto (knob herm_t < 0), from profiles/r06/exp_herm_rule.log (mtf_from_psf, us, round-2 form /
+// transposed): fp32 128^2 20.5 / 14.8, 1024^2 29.9 / 19.1, 2048^2 38.8 / 34.2, 4096 x 1024 51.8 / 31.3, 4096^2 72.4 / 68.1 -- and
+// 2048 x 8192 65.2 / 67.5, 4096 x 8192 123.5 / 170.7, 8192 rows 82.3 / 82.4 .. 139 / 172: rows of 8192 samples and columns of 8192 stay
+// on the round-2 form; fp64 1024^2 29.4 / 21.6, 2048^2 41.9 / 36.3, 4096 x 2048 68.1 / 56.1 -- and 2048 x 4096 64.2 / 68.4, 4096^2
+// 117.4 / 155.5: rows of 4096 complex128 points stay too.
+static bool hermt_legal(const pm_fft2_desc* d, int logn, int logm) {
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    const int ht = tuning().herm_t;
+    if (ht == 0) return false;
+    if (logm < 5 || logm > 13 || logn < 5 || logn > (d->dtype == PM_C64 ? 13 : 12)) return false;
+    if (logm == 13 && tuning().herm_t_fold == 0) return false;     // 8192-point columns exist as planes of 4096-point tiles only
+    if (ht < 0 && (logm > 12 || logn > (d->dtype == PM_C64 ? 12 : 11))) return false;
+    if (!(d->in_y.shift == 0 || d->in_y.shift == M / 2) || !(d->out_y.shift == 0 || d->out_y.shift == M / 2) ||
+        !(d->out_x.shift == 0 || d->out_x.shift == N / 2))
+        return false;
+    return d->in_y.off == 0 && d->out_y.off == 0 && d->out_x.off == 0;
+}
+
 static int64_t batch_chunk(int64_t nb, size_t ws_field) {
     const size_t budget = size_t(tuning().batch_ws_mib) << 20;
     int64_t c = int64_t(budget / (ws_field ? ws_field : 1));
@@ -346,7 +371,13 @@ static Fft2Plan plan_fft2(const pm_fft2_desc* d, bool allow_r2c = true) {
     p.fold = false;
     p.w_ld = N;
     p.r2c = allow_r2c && p.logn >= 0 && p.logm >= 0 && r2c_legal(d, p.logn, p.logm);
-    if (p.r2c) {
+    p.r2c_t = p.r2c && hermt_legal(d, p.logn, p.logm);
+    if (p.r2c_t) {
+        p.col_var = 0;
+        p.tc = 0;
+        p.log_k = 0;
+        p.ws_bytes = size_t(M / 2) * size_t(N) * es;      // rows u < M/2 of the column spectra, row-major (row 0 carries u = 0 and u = M/2)
+    } else if (p.r2c) {
         p.col_var = 0;
         p.tc = col_tile_width_for(d->dtype, p.logm, 0);
         // layout tiles of 8 column tiles: mtf_from_psf 4096^2 fp32 73.6 -> 72.0 us against 4 (profiles/r05/exp_layout_sweep.log)
@@ -525,6 +556,46 @@ static int fft2_run_chunk(const pm_fft2_desc* d, const Fft2Plan& p, const void* 
     const bool run1 = !(d->flags & PM_FLAG_PASS2_ONLY), run2 = !(d->flags & PM_FLAG_PASS1_ONLY);
     if (p.big_rn) return big2d_run<T>(d, p, in, out, ws, st);
     if (p.blue2d) return blue2d_run<T>(d, p, in, out, ws, st);
+    if (p.r2c_t) {
+        // pass A: M-point transforms down the N/2 packed columns of the real array, separated into the N column spectra (rows u < M/2)
+        const cx<T>* twm = twiddles<T>(M, &err);
+        if (!twm) return err;
+        const cx<T>* twn = twiddles<T>(N, &err);
+        if (!twn) return err;
+        const int64_t n2 = N / 2;
+        const int tc = col_tile_width_for(d->dtype, p.logm, 0);
+        const int ntiles = int((n2 + tc - 1) / tc);
+        const int64_t ld2 = d->in_ld / 2;
+        ColLoadNat<T> cl{reinterpret_cast<const cx<T>*>(in), ld2, AxisMap{int(M), int(M), 0, 0}, int(n2), 0,
+                         (ld2 % 2 == 0 && reinterpret_cast<uintptr_t>(in) % 16 == 0) ? 1 : 0, 0};
+        // fold (a radix-2 step of the column transform in the load, planes of M/2-point tiles: two workgroups per CU): from 4096 rows
+        const int hf = tuning().herm_t_fold;
+        const bool fold = (hf > 0 && p.logm >= 11) || (hf < 0 && p.logm >= 12);
+        HermTColStore<T> cs{W, N, int(n2), d->in_y.shift == M / 2 ? 1 : 0, fold ? 1 : 0, twm, 0};
+        const cx<T>* twa = twm;
+        int tiles = ntiles;
+        if (fold) {
+            twa = twiddles<T>(M / 2, &err);
+            if (!twa) return err;
+            const int tcf = col_tile_width_for(d->dtype, p.logm - 1, 0);
+            tiles = int((n2 + tcf - 1) / tcf);
+        }
+        cs.ntiles = tiles;
+        // adjacent tiles read the two halves of the input's 128 B lines and write adjacent lines of the intermediate: siblings on one XCD
+        // (profiles/r06/exp_herm_t_log_g.log, mtf_from_psf us at col_log_g 0 .. 5: 4096^2 fp32 folded 75.9 68.5 69.7 69.3 67.9 68.1 -- the pass reads
+        // 64 B pieces of a row-major array, neighbours share its 128 B lines --; 2048^2 (128 tiles, half the CUs) 31.9 33.6 33.7 33.8 34.2 34.4)
+        int lg = tuning().col_log_g >= 0 ? tuning().col_log_g : (p.logm >= 12 ? 4 : 0);
+        while (lg > 0 && ((fold ? 2 * tiles : tiles) % (8 << (lg + (fold ? 1 : 0)))) != 0) --lg;
+        int rc = launch_col_hermt<T>(p.logm, cl, cs, twa, tiles, lg, st);
+        if (rc) return rc < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: no transposed Hermitian column kernel for %lld points", (long long)M) : rc;
+        // pass B: N-point transforms of the M/2 rows, each stored with its mirror image
+        RowLoadNat<T> lp{W, N, AxisMap{int(N), int(N), 0, 0}, int(M / 2), 0, 0, 0};
+        HermTRowStore<T> rs{out, d->out_ld, int(M), int(N), int(d->out_y.shift), int(d->out_x.shift), d->epilogue, T(d->scale),
+                            (d->flags & PM_FLAG_NORM_DC) ? 1 : 0, W, d->in_x.shift == N / 2 ? 1 : 0, int(M / 2)};
+        rc = launch_row_hermt<T>(p.logn, tuning().herm_t_rowvar >= 0 ? tuning().herm_t_rowvar : row_variant(d->dtype, p.logn), lp, rs, twn, tuning().row_log_g, st);
+        if (rc) return rc < 0 ? fail(PM_ERR_UNSUPPORTED, "pm_fft2: internal: no transposed Hermitian row kernel for %lld points", (long long)N) : rc;
+        return 0;
+    }
     if (p.r2c) {
         // rows: the real array read as N/2 complex points per row -> N/2 columns of the tiled intermediate (column 0 = X[0] + i X[N/2])
         const int64_t n2 = N / 2, tl = int64_t(p.tc) << p.log_k;
@@ -1714,6 +1785,8 @@ int pm_plan_explain(const pm_fft2_desc* d, int32_t op, char* buf, size_t n) {
     } else if (p.blue2d) {
         snprintf(buf, n, "fft2 %lldx%lld %s: route=%s conv=%lldx%lld ws=%zu", M, N, dt, p.blue_big ? "bluestein-2d-big" : "bluestein-2d",
                  (long long)blue_conv_len(M), (long long)blue_conv_len(N), p.ws_bytes);
+    } else if (p.r2c_t) {
+        snprintf(buf, n, "fft2 %lldx%lld %s: route=hermitian-transposed cols=stockham-r2c(%lld) rows=stockham(%lld)x%lld ws=%zu", M, N, dt, M, N, M / 2, p.ws_bytes);
     } else if (p.r2c) {
         snprintf(buf, n, "fft2 %lldx%lld %s: route=hermitian%s rows=stockham-r2c(%lld) cols=stockham(%lld%s) tile=%d log_k=%d ws=%zu", M, N, dt,
                  p.fold ? "-fold" : "", N / 2, p.fold ? M / 2 : M, p.fold ? "x2" : "", p.tc, p.log_k, p.ws_bytes);

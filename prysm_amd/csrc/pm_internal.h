@@ -171,6 +171,10 @@ struct Tuning {
                              // path on small arrays.
     int herm_wide = 1;        // Hermitian column pass: tiles of 16 complex64 / 8 complex128 columns for 2048-point columns -- its real epilogues then
                               // write 64 B pieces, direct and mirrored (MTF 4096^2 fp32 88.4 -> 81.4 us, fp64 176 -> 168; profiles/r02/exp_mtf_wide.log)
+    int herm_t = -1;          // the TRANSPOSED Hermitian form (fft_hermt.h: real-input column transforms, then row transforms that store each row and its
+                              // mirror image as whole lines): -1 auto (capi.hip hermt_legal: where it measured faster), 0 never, 1 wherever legal
+    int herm_t_rowvar = -1;   // ... tiling of its row pass at 4096 complex64 points: 4 two rows per thread, 0 one row per workgroup; -1: the complex path's
+    int herm_t_fold = -1;     // ... its column pass folded (planes of M/2-point tiles): -1 auto (from 4096 rows), 0 never, 1 from 2048 rows
     int spectral = 8;         // pm_fft2_spectral: wavelengths per launch pair (fft_spectral.h; <= 8); 1: the plain loop of pm_fft2 calls
     int spectral_area_log = 24;   // ... for transforms of fewer than 2^this bins (capi.hip spectral_fast has the measurements)
     int spectral2 = 0;        // removed in round 5 (experiments/README.md; the value is refused): groups of this many (2 .. 4) on the kernels that keep four waves per SIMD (fft_spectral2.h) where

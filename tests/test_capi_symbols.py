@@ -255,10 +255,15 @@ ROUTES = [
 ]
 ROUTES_KW = [
     (dict(m=4096, n=4096, Q=2), ['route=engine ', 'cols=stockham(4096)', 'log_k=2', 'ws=67108864']),      # padded: unfolded, stored rows only
-    (dict(m=4096, n=4096, real=True, epi=3), ['route=hermitian-fold', 'rows=stockham-r2c(2048)', 'cols=stockham(2048x2)', 'tile=16']),
+    # round 6: the transposed Hermitian form (real-input column transforms, then rows stored with their mirror image) where it measured faster
+    (dict(m=4096, n=4096, real=True, epi=3), ['route=hermitian-transposed', 'cols=stockham-r2c(4096)', 'rows=stockham(4096)x2048', 'ws=67108864']),
+    (dict(m=1024, n=1024, real=True, epi=3), ['route=hermitian-transposed', 'rows=stockham(1024)x512']),
+    (dict(m=4096, n=4096, dt='c128', real=True, epi=3), ['route=hermitian-fold', 'rows=stockham-r2c(2048)']),      # rows of 4096 complex128 points: the round-2 form
+    (dict(m=2048, n=2048, dt='c128', real=True, epi=3), ['route=hermitian-transposed']),
+    (dict(m=4096, n=8192, real=True, epi=3), ['route=hermitian-fold']),
     (dict(m=8192, n=8192, real=True, epi=3), ['route=hermitian-fold', 'rows=stockham-r2c(4096)', 'cols=stockham(4096x2)', 'tile=8']),
     (dict(m=2048, n=2048, real=True), ['route=engine ']),               # a plain spectrum of a small real field stays on the complex path
-    (dict(m=4096, n=4096, real=True), ['route=hermitian-fold']),
+    (dict(m=4096, n=4096, real=True), ['route=hermitian-transposed']),
     (dict(m=3000, n=3000, real=True), ['route=natural-mixed', 'rows=mixed-radix(3000)', 'cols=mixed-radix-registers(3000)']),         # composite grids: no Hermitian path yet (the real array is read by the complex kernels)
     (dict(m=1024, n=1024, batch=100), ['route=engine ', 'chunk=16', 'ws=134217728']),
     (dict(m=4096, n=4096, synth=True), ['route=engine-fold']),
