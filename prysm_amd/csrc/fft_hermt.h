@@ -248,6 +248,9 @@ __global__ void __launch_bounds__(C::NT, MINW) fft_row_hermt_kernel(const RowLoa
             }
         }
     }
+    // the centre sample of a normalised transform is data[c] / data[c] in the reference (prysm/otf.py:11-13, 36-74): exactly 1 -- the thread
+    // that owns F[0][0] writes the scale itself, not F[0][0] times the reciprocal of the (re-summed, differently rounded) DC value
+    const bool dc_here = sp.norm_dc && unit == 0 && threadIdx.x == 0;
 #pragma unroll
     for (int e = 0; e < C::E; ++e) {
         const int u = (unit * C::BO + pos.bo) * C::E + e;
@@ -255,7 +258,8 @@ __global__ void __launch_bounds__(C::NT, MINW) fft_row_hermt_kernel(const RowLoa
         const int64_t rowd = int64_t((u + sp.sy) & (M - 1)) * sp.ld, rowm = int64_t((M - u + sp.sy) & (M - 1)) * sp.ld;
 #pragma unroll
         for (int m = 0; m < C::P; ++m) {
-            const cx<T> x = cscale(v[e][m], s);
+            cx<T> x = cscale(v[e][m], s);
+            if (e == 0 && m == 0 && dc_here) x = {sp.scale, T(0)};
             const int pd = pos.t + ((m * C::TPS + sp.sx) & (N - 1));
             hermt_put<T, EPI>(sp.dst, rowd + pd, x, false);
             if (u != 0) {

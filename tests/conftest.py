@@ -84,3 +84,40 @@ def rel_max(a, b):
     if mb == 0:
         return float(np.max(np.abs(a)))
     return float(np.max(np.abs(a - b)) / mb)
+
+
+# ---- fixtures of the GPU parity tests (tests/test_gpu_*.py)
+@pytest.fixture(scope='module')
+def pa():
+    import torch
+    import prysm_amd
+    from prysm_amd import _lib
+    _lib.load()   # fails loudly when the HIP library is missing
+    assert torch.cuda.is_available()
+    return prysm_amd
+
+
+@pytest.fixture(scope='module')
+def config5():
+    """4096^2 circular amplitude, 500 nm of W040, 64 wavelengths in [0.5, 0.7] um, uniform weights; fp32
+    maps.  The oracle sums are computed once (scipy.fft on all host cores -- the checker, not the thing measured)."""
+    from scipy import fft as sfft
+    from oracle import prysm_oracle as O
+    n = 4096
+    x, y = O.make_xy_grid(n, diameter=10)
+    r, _ = O.cart_to_polar(x, y)
+    amp = O.circle(5, r).astype(np.float32)
+    opd = O.hopkins_w040(r / 5, 500.0).astype(np.float32)
+    dx = float(x[0, 1] - x[0, 0])
+    del x, y, r
+    wvls = np.linspace(0.5, 0.7, 64)
+    wts = np.ones(64)
+    want_f = np.zeros((n, n))
+    want_m = np.zeros((512, 512))
+    opd64 = opd.astype(np.float64)
+    with sfft.set_workers(os.cpu_count() or 1):
+        for w in wvls:
+            P = O.from_amp_and_phase(amp.astype(np.float64), opd64, float(w))
+            want_f += O.intensity(O.focus(P, 1))
+            want_m += O.intensity(O.prepare_executor(dx, P.shape, 0.55 * 10 / 4, (512, 512), float(w), 100.0)(P))
+    return dict(amp=amp, opd=opd, dx=dx, wvls=wvls, wts=wts, want_f=want_f, want_m=want_m)

@@ -4,10 +4,7 @@
   the Airy pattern (the reference's own physics test, tests/test_physics.py:20-34, restated);
 * the seven-plane Lyot-coronagraph model at 1024^2 that bench.py times as `model_7plane_1024` (the workload BASELINE.md's published
   figures are about: docs/source/how-tos/GPU and Exascale Computing.ipynb file line 74, prysm/propagation/coronagraph.py:12-43) --
-  eager, inside graph.sequence() and as a hipGraph replay, against the oracle's restatement of the same planes;
-* graph.sequence() with per-iteration temporaries of DIFFERENT content made by plain torch operations on the caller's stream
-  (a dropped temporary's address handed to the next iteration's temporary), and lazy wavefronts whose maps were made
-  inside the block.
+  eager, inside graph.sequence() and as a hipGraph replay, against the oracle's restatement of the same planes.
 
 Tolerances (max error / max magnitude against the fp64 oracle): complex128 1e-9, complex64 3e-5 on the matrix-DFT chains (the
 tolerance of config 4, tests/test_gpu_parity.py); north_star asks 1e-5 / 1e-3.
@@ -18,25 +15,10 @@ import torch
 
 import bench
 from conftest import rel_max
+from gpu_common import tonp
 from oracle import prysm_oracle as O
 
 pytestmark = pytest.mark.gpu
-
-
-@pytest.fixture(scope='module')
-def pa():
-    import prysm_amd
-    from prysm_amd import _lib
-    _lib.load()   # fails loudly when the HIP library is missing
-    assert torch.cuda.is_available()
-    return prysm_amd
-
-
-def tonp(x):
-    from prysm_amd.mathops import array_to_true_numpy
-    if hasattr(x, 'data') and not isinstance(x, (np.ndarray, torch.Tensor)):
-        x = x.data
-    return array_to_true_numpy(x)
 
 
 # ----------------------------------------------------------------------------- config 1 at 512^2
@@ -137,80 +119,3 @@ def test_model_7plane_1024_vs_oracle(pa, prec, tol):
             assert torch.equal(gb(dev['amp'], dev['opd']), eager[0] + eager[1])
     finally:
         config.precision = prec0
-
-
-# ----------------------------------------------------------------------------- sequence blocks and temporaries
-
-def test_sequence_block_with_fresh_temporaries_each_iteration(pa):
-    """every iteration builds its pupil amplitude with a plain torch operation on the caller's stream (different content each time),
-    drops it, and the caching allocator hands the same address to the next iteration's temporary: each must be ordered behind the
-    caller's stream on its own (the once-per-address shortcut of round 5 let iteration k + 1 read iteration k's bytes or
-    half-written ones)"""
-    from prysm_amd import graph as G
-    P = pa.propagation
-    n = 1024
-    g = torch.Generator(device='cuda').manual_seed(11)
-    base = torch.rand((n, n), device='cuda', generator=g, dtype=torch.float32)
-    opd = torch.randn((n, n), device='cuda', generator=g, dtype=torch.float32) * 30
-    ks = list(range(1, 13))
-
-    def psf(k):
-        amp = (base * k).sin().abs()            # a temporary made on the caller's stream: several kernels, different content per k
-        amp = amp + 0.25 * (base > 0.1 * k)     # (the intermediate temporaries are dropped at once: their blocks are recycled)
-        return P.Wavefront.from_amp_and_phase(amp, opd, 0.6, 0.01).focus(100.0, Q=1).intensity.data
-
-    want = [psf(k).clone() for k in ks]
-    torch.cuda.synchronize()
-    for _ in range(3):       # the race is a matter of timing: a few trips
-        with G.sequence():
-            outs = [psf(k) for k in ks]
-        torch.cuda.synchronize()
-        assert all(torch.equal(o, w) for o, w in zip(outs, want))
-    # ... and an input the caller REWRITES in place between two calls (same tensor, same address, new version)
-    buf = torch.empty((n, n), device='cuda', dtype=torch.float32)
-    want2 = []
-    for k in ks[:6]:
-        buf.copy_((base * k).cos().abs())
-        want2.append(P.Wavefront.from_amp_and_phase(buf, opd, 0.6, 0.01).focus(100.0, Q=1).intensity.data.clone())
-    torch.cuda.synchronize()
-    with G.sequence() as seq:
-        outs2 = []
-        for k in ks[:6]:
-            seq.join()                     # the caller rewrites a buffer the ring may still be reading: join first (the documented rule)
-            buf.copy_((base * k).cos().abs())
-            outs2.append(P.Wavefront.from_amp_and_phase(buf, opd, 0.6, 0.01).focus(100.0, Q=1).intensity.data)
-    torch.cuda.synchronize()
-    assert all(torch.equal(o, w) for o, w in zip(outs2, want2))
-
-
-def test_sequence_block_orders_lazy_wavefronts_behind_their_maps(pa):
-    """a lazy wavefront (from_amp_and_phase: no array yet, the maps held) whose OPD was summed INSIDE the block on one ring stream:
-    .intensity / arithmetic on it must follow that stream, and the array it materialises inside a call belongs to that call's
-    stream"""
-    from prysm_amd import graph as G
-    from prysm_amd import _ops
-    P = pa.propagation
-    n = 768      # a composite grid without a synthesising loader at this precision mix: the pupil is materialised
-    g = torch.Generator(device='cuda').manual_seed(5)
-    modes = torch.randn((6, n, n), device='cuda', generator=g, dtype=torch.float64)
-    amp = (torch.rand((n, n), device='cuda', generator=g) > 0.2).double()
-    ws = [torch.randn(6, generator=torch.Generator().manual_seed(i), dtype=torch.float64) * 20 for i in range(8)]
-
-    def chain(w):
-        opd = _ops.sum_modes(modes, w.tolist())                       # made on a ring stream inside the block
-        wf = P.Wavefront.from_amp_and_phase(amp, opd, 0.6, 0.01)      # lazy
-        i0 = wf.intensity.data                                        # materialises wf's array inside a sequenced call
-        psf = (wf * wf).focus(100.0, Q=1).intensity.data              # reads the materialised array
-        return i0, psf
-
-    want = [tuple(t.clone() for t in chain(w)) for w in ws]
-    torch.cuda.synchronize()
-    for _ in range(3):
-        with G.sequence():
-            outs = [chain(w) for w in ws]
-        torch.cuda.synchronize()
-        for (a, b), (wa, wb) in zip(outs, want):
-            assert torch.equal(a, wa) and torch.equal(b, wb)
-    ref_opd = np.tensordot(ws[0].numpy(), tonp(modes), axes=1)
-    ref = O.from_amp_and_phase(tonp(amp), ref_opd, 0.6)
-    assert rel_max(tonp(want[0][1]), O.intensity(O.focus(ref * ref, 1))) < 1e-9
