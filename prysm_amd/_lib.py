@@ -275,6 +275,11 @@ class tuning_local:
         self.knobs = knobs
 
     @classmethod
+    def signature(cls):
+        """the calling thread's open blocks as a hashable value: what a cached planner answer is valid for"""
+        return tuple(tuple(sorted(b.items())) for b in getattr(cls._tls, 'stack', ()))
+
+    @classmethod
     def _replay(cls, lib):
         lib.pm_reset_tuning_local()
         for outer in getattr(cls._tls, 'stack', []):

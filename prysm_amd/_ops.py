@@ -261,9 +261,10 @@ _REGISTER_ROUTES = {}
 def on_register_engine(M, N, cdtype):
     """Whether BOTH passes of a plain complex (M, N) transform run on the composite register engine (csrc/fft_ce.h) -- the composite
     grids whose (B, M, N) stacks go out as one launch pair.  Asked of the library's planner (pm_plan_explain: host logic, no GPU work),
-    once per shape, precision and tuning_local block (a process-wide pm_set_tuning after the first question is not seen: call
-    _REGISTER_ROUTES.clear())."""
-    key = (int(M), int(N), cdtype, L.tuning_local.epoch)
+    once per shape, precision and set of open tuning_local blocks OF THE CALLING THREAD (the knobs are per thread: an answer cached
+    under another thread's block, or under a process-wide epoch, could be wrong for this one -- ADVICE r5).  A process-wide
+    pm_set_tuning after the first question is not seen: call _REGISTER_ROUTES.clear()."""
+    key = (int(M), int(N), cdtype, L.tuning_local.signature())
     hit = _REGISTER_ROUTES.get(key)
     if hit is None:
         lib = L.load()

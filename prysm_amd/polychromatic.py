@@ -88,6 +88,7 @@ def _group_info(group):
 
 
 _SCRATCH = {}
+_SCRATCH_LOCK = threading.Lock()
 
 
 def _scratch(tag, shape, dtype, device):
@@ -99,12 +100,21 @@ def _scratch(tag, shape, dtype, device):
         from . import _lib as L
         st = L._cur_stream()
     key = (tag, tuple(shape), dtype, device, st)
-    t = _SCRATCH.get(key)
-    if t is None:
-        if len(_SCRATCH) >= 8:
-            _SCRATCH.clear()
-        t = _SCRATCH[key] = torch.empty(shape, dtype=dtype, device=device)
+    with _SCRATCH_LOCK:
+        t = _SCRATCH.pop(key, None)
+        if t is None:
+            while len(_SCRATCH) >= 8:           # least recently used first (dicts keep insertion order; a hit is re-inserted below)
+                _SCRATCH.pop(next(iter(_SCRATCH)))
+            t = torch.empty(shape, dtype=dtype, device=device)
+        _SCRATCH[key] = t
     return t
+
+
+def clear_scratch():
+    """Release the persistent receive buffers of the reduce forms (up to eight image-sized tensors, keyed by shape / dtype / device /
+    stream).  Call after destroying streams the driver ran on: a raw stream handle can be handed out again."""
+    with _SCRATCH_LOCK:
+        _SCRATCH.clear()
 
 
 REDUCE_METHODS = ('reduce', 'a2a', 'rs')
