@@ -22,7 +22,7 @@ prof bench --steps 40 --warmup 5 --no-cpu-baseline --no-poly
 # the default bench line AFTER the PMC passes of the same sources: its roofline.traffic comes from the summary just collected
 cp $O/pmc_bench_summary.json $R/profiles/pmc_bench_summary.json
 ( timeout 900 python bench.py ) > $O/bench.log 2>&1
-for c in config2 config3 config4 c128 n8192 padded composite mtf conv adjoint poly2048; do prof $c --only $c; done
+for c in model7 config2 config3 config4 c128 n8192 padded composite mtf conv adjoint poly2048; do prof $c --only $c; done
 ( cd /tmp && timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq_config4 -- python $R/bench.py --only config4 ) > $O/rocprof_sq_config4.log 2>&1
 python tools/pmc_clock.py $O/pmc_sq_config4 $O/pmc_config4_mfma_busy.json 2>&1 | grep pm:: > $O/config4_mfma_busy.txt
 cp $O/pmc_config4_mfma_busy.json $R/profiles/pmc_config4_mfma_busy.json
@@ -32,4 +32,9 @@ rm -rf $O/pmc_sq_config4
 ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_sq2 -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-poly ) > $O/rocprof_sq2.log 2>&1
 ( python tools/pmc_counters.py $O/pmc_sq1 fft_kernel; python tools/pmc_counters.py $O/pmc_sq2 fft_kernel ) > $O/headline_sq_counters.txt 2>&1
 rm -rf $O/pmc_sq1 $O/pmc_sq2
-tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; tail -1 $O/bench.log | cut -c1-400; cat $O/pmc_bench_summary.txt; cat $O/config4_mfma_busy.txt
+# the N > 1 rehearsal (two ranks share this GPU over gloo): bench.py --gpus 2, the sharded driver against the oracle, the 2-rank image against the 1-rank image
+( bash tools/gpu_multi_rank.sh $O/multi_rank ) > $O/multi_rank.log 2>&1
+( timeout 300 python tools/exp_graph_branches.py ) > $O/exp_graph_branches.log 2>&1
+( timeout 600 python tools/exp_herm_rule.py ) > $O/exp_herm_rule.log 2>&1
+( timeout 600 python tools/exp_herm_sweep.py ) > $O/exp_herm_t_log_g.log 2>&1
+tail -3 $O/pytest_gpu.log; tail -1 $O/smoke.log; cat $O/multi_rank/check_2rank.json; tail -1 $O/bench.log | cut -c1-400; cat $O/pmc_bench_summary.txt; cat $O/config4_mfma_busy.txt
