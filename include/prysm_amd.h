@@ -88,9 +88,12 @@ enum {
                              * in_bstride count real elements.  fft2 of a real PSF / object / actuator map
                              * (prysm/otf.py:31, prysm/convolution.py:27-28,82-85) without a complex copy: pass 1 reads
                              * half the bytes.  A FORWARD transform of an unpadded real field with power-of-two lengths (>= 32
-                             * per row) and an unwindowed output takes the Hermitian path: half-length row transforms, N/2 + 1
-                             * columns through the column pass, each result stored twice (at (u, k) and, conjugated, at
-                             * (-u, -k)); PM_EPI_ABS / PM_EPI_ARG / PM_FLAG_NORM_DC exist on that path */
+                             * per row) and an unwindowed output takes the Hermitian path: half the spectrum is computed and each
+                             * result stored twice (at (u, k) and, conjugated, at (-u, -k)) -- along x (half-length row transforms,
+                             * N/2 + 1 columns through the column pass) or, where every rotation is 0 or half a length and it
+                             * measured faster, along y (real-input column transforms, then M/2 row transforms that store each
+                             * row and its mirror image as whole lines; tuning key "herm_t");
+                             * PM_EPI_ABS / PM_EPI_ARG / PM_FLAG_NORM_DC exist on that path */
 };
 
 /* One axis of a windowed, rotated view.  A logical (transform-sized) axis of
@@ -411,7 +414,9 @@ void pm_shutdown(void);            /* free cached tables */
  * tilings, "nt_in" / "nt_out" in {0,1} make the input loads / output stores non-temporal, "fold", "log_k", "batch_ws_mib",
  * "gemm_3m", "gemm_min_wgs" tune the engine and the GEMM; routing of awkward lengths: "blue_min" (shortest length on the Bluestein
  * path, 0 = off), "blue_2d" / "blue_fuse" (both-axes form; chirp multiplies inside the chain), "big_native_log" (log2 of the longest
- * length given to the engine as it is; the GPU tests lower it to run the 16384-point path on small arrays).  The full list with
+ * length given to the engine as it is; the GPU tests lower it to run the 16384-point path on small arrays); real inputs: "r2c"
+ * (Hermitian path: 0 never, 1 where it pays, 2 wherever legal), "herm_t" (its transposed form, real-input column transforms first:
+ * -1 where it measured faster, 0 never, 1 wherever legal) with "herm_t_fold" (its column pass as planes of half-height tiles).  The full list with
  * defaults and measurements: struct Tuning in prysm_amd/csrc/pm_internal.h.  Also read once from the environment:
  * PM_TUNE="nt_in=1,fold=0". */
 int pm_set_tuning(const char* key, int32_t value);
@@ -424,7 +429,7 @@ int pm_set_tuning_local(const char* key, int32_t value);
 void pm_reset_tuning_local(void);
 /* Which route does this descriptor take?  Writes ONE line into buf (n >= 64 bytes; longer lines are cut) that names the planner's
  * decisions for op = 0 (pm_fft2) or op = 1 (pm_fft2_mul_ifft2) under the calling thread's knobs: the route ("engine", "engine-fold",
- * "hermitian[-fold]", "natural-mixed", "natural", "radix-step", "bluestein-2d[-big]"; "fused", "fused-composite", "hermitian-chain",
+ * "hermitian[-fold]", "hermitian-transposed", "natural-mixed", "natural", "radix-step", "bluestein-2d[-big]"; "fused", "fused-composite", "hermitian-chain",
  * "composed"), the kernel class of each axis ("stockham", "mixed-radix", "bluestein", "direct"), tile width, layout and workspace
  * bytes.  Host logic only -- no device is touched, so a table of shapes can be pinned to its routes on a machine without a GPU
  * (the reference reaches every size through one scipy call, prysm/fttools.py:23-31; here a shape that slips to a slow route

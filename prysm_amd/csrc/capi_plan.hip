@@ -51,17 +51,17 @@ static bool r2c_legal(const pm_fft2_desc* d, int logn, int logm) {
 
 // Transposed Hermitian form (fft_hermt.h): what r2c_legal accepts, with every rotation 0 or half a length (the input's become signs) and
 // lengths the two kernels exist for.  Auto (knob herm_t < 0), from profiles/r06/exp_herm_rule.log (mtf_from_psf, us, round-2 form /
-// transposed): fp32 128^2 20.5 / 14.8, 1024^2 29.9 / 19.1, 2048^2 38.8 / 34.2, 4096 x 1024 51.8 / 31.3, 4096^2 72.4 / 68.1 -- and
-// 2048 x 8192 65.2 / 67.5, 4096 x 8192 123.5 / 170.7, 8192 rows 82.3 / 82.4 .. 139 / 172: rows of 8192 samples and columns of 8192 stay
-// on the round-2 form; fp64 1024^2 29.4 / 21.6, 2048^2 41.9 / 36.3, 4096 x 2048 68.1 / 56.1 -- and 2048 x 4096 64.2 / 68.4, 4096^2
-// 117.4 / 155.5: rows of 4096 complex128 points stay too.
+// transposed): fp32 128^2 21.1 / 17.0, 1024^2 30.3 / 19.8, 2048^2 38.8 / 32.5, 4096 x 1024 52.2 / 31.7, 4096^2 71.9 / 59.7,
+// 8192 x 2048 80.7 / 69.1 -- and 2048 x 8192 64.9 / 70.5, 4096 x 8192 122.9 / 155.4, 8192 x 4096 140.0 / 158.5: rows of 8192 samples
+// stay on the round-2 form, columns of 8192 beyond 2048 rows' width too; fp64 1024^2 29.4 / 22.3, 2048^2 41.8 / 40.1, 4096 x 2048
+// 67.8 / 58.4 -- and 2048 x 4096 64.7 / 76.5, 4096^2 117.8 / 156.1, 8192 x 2048 138.2 / 155.7: rows of 4096 complex128 points stay too.
 static bool hermt_legal(const pm_fft2_desc* d, int logn, int logm) {
     const int64_t M = d->in_y.n, N = d->in_x.n;
     const int ht = tuning().herm_t;
     if (ht == 0) return false;
     if (logm < 5 || logm > 13 || logn < 5 || logn > (d->dtype == PM_C64 ? 13 : 12)) return false;
     if (logm == 13 && tuning().herm_t_fold == 0) return false;     // 8192-point columns exist as planes of 4096-point tiles only
-    if (ht < 0 && (logm > 12 || logn > (d->dtype == PM_C64 ? 12 : 11))) return false;
+    if (ht < 0 && (logn > (d->dtype == PM_C64 ? 12 : 11) || logm > (d->dtype == PM_C64 && logn <= 11 ? 13 : 12))) return false;
     if (!(d->in_y.shift == 0 || d->in_y.shift == M / 2) || !(d->out_y.shift == 0 || d->out_y.shift == M / 2) ||
         !(d->out_x.shift == 0 || d->out_x.shift == N / 2))
         return false;

@@ -261,6 +261,7 @@ ROUTES_KW = [
     (dict(m=4096, n=4096, dt='c128', real=True, epi=3), ['route=hermitian-fold', 'rows=stockham-r2c(2048)']),      # rows of 4096 complex128 points: the round-2 form
     (dict(m=2048, n=2048, dt='c128', real=True, epi=3), ['route=hermitian-transposed']),
     (dict(m=4096, n=8192, real=True, epi=3), ['route=hermitian-fold']),
+    (dict(m=8192, n=2048, real=True, epi=3), ['route=hermitian-transposed']),
     (dict(m=8192, n=8192, real=True, epi=3), ['route=hermitian-fold', 'rows=stockham-r2c(4096)', 'cols=stockham(4096x2)', 'tile=8']),
     (dict(m=2048, n=2048, real=True), ['route=engine ']),               # a plain spectrum of a small real field stays on the complex path
     (dict(m=4096, n=4096, real=True), ['route=hermitian-transposed']),

@@ -41,7 +41,7 @@ FORMS = {'r2c': dict(herm_t=0), 'transposed': dict(herm_t=1, herm_t_fold=0), 'tr
 
 
 @pytest.mark.parametrize('form', list(FORMS))
-@pytest.mark.parametrize('shape', [(32, 32), (64, 256), (256, 64), (512, 512), (2048, 512), (512, 4096), (4096, 2048)])
+@pytest.mark.parametrize('shape', [(32, 32), (64, 256), (256, 64), (512, 512), (2048, 512), (512, 4096), (4096, 2048), (8192, 256)])
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
 def test_real_input_forms_vs_numpy(pa, shape, dtype, form):
     from prysm_amd import _lib as L, _ops
