@@ -254,7 +254,8 @@ def pmc_traffic(kernel, n, dtype_name):
     return None, 'kernel not in the PMC summary'
 
 
-SIDE_PREWARM_MS = 40.0     # untimed run-in of every side measurement (the headline loop has its own, PREWARM_MS)
+SIDE_PREWARM_MS = 100.0    # untimed run-in of every side measurement (the headline loop has its own, PREWARM_MIN_MS): they follow each other with
+                           # host-side set-up in between, during which the device starts to drop the clock it had reached
 
 
 def _event_ms(fn, reps, warm=3, batches=3, prewarm_ms=SIDE_PREWARM_MS):
@@ -797,8 +798,8 @@ class Ranks:
         return self.max(time.perf_counter() - t0)
 
 
-PREWARM_MIN_MS = 60.0      # untimed run-in: at least this long ...
-PREWARM_CAP_MS = 2000.0    # ... at most this long, ended as soon as three consecutive batches agree within PREWARM_TOL
+PREWARM_MIN_MS = 400.0     # untimed run-in: at least this long ...
+PREWARM_CAP_MS = 2000.0    # ... at most this long, ended as soon as the batch times have stopped drifting (propagation_loop)
 PREWARM_TOL = 0.01
 
 
@@ -862,14 +863,17 @@ def propagation_loop(ranks, x, steps, warmup, info=None, repeats=0):
     """warmup untimed + exactly `steps` timed focus(x, 1) per rank; returns seconds (MAX over ranks).
 
     Before the W warm-up steps the same propagation runs untimed until the device has reached its steady state: batches of 40
-    propagations (synchronised one by one) are repeated until three consecutive batch times agree within 1 %, for at least
-    PREWARM_MIN_MS and at most PREWARM_CAP_MS.  A freshly leased GPU idles at a low clock and a short run (the driver's --steps 20
-    --warmup 5 is 2.5 ms of work) would otherwise be timed on the clock ramp, not at the steady state the metric (propagations per
-    second) is about; rounds 1 - 5 ran in for a fixed 60 ms, which on some boxes was not enough (driver readings 9.4 - 10.7 k/s).
-    It is ordinary warm-up -- the same call on the same buffers, nothing cached that a timed step reuses beyond what step 1 leaves
-    for step 2.  `info` (a dict) receives what was spent (`prewarm_ms`, `prewarm_batches`, the last batch times), the device's
-    clocks / power right before and right after the timed region (gpu_state), and -- AFTER the contract's one timed region --
-    `repeats` more batches of `steps` timed the same way (`repeat_ms`: ms per step of each), so a line shows its own spread."""
+    propagations (synchronised one by one) for at least PREWARM_MIN_MS, until the mean of the last five batches is within 1 % of the
+    mean of the five batches about 100 ms earlier (no drift), at most PREWARM_CAP_MS.  Why: a freshly leased MI355X raises its core
+    clock over several HUNDRED milliseconds of sustained load (profiles/r06/exp_warm_trajectory.log: 1990 MHz / 316 W at 100 ms,
+    2145 MHz at 190 ms, 2350 MHz / 1170 W at 400 ms), and the row + fold kernel follows it up to ~2150 MHz: 97.9 us per step at 120 ms,
+    94.0 from 190 ms on.  Rounds 1 - 5 ran in for a fixed 60 ms and the driver's 20-step run (2 ms of work) was timed on that ramp
+    (readings 9.4 - 10.7 k/s); three equal 4 ms batches are NOT a steady state either -- the ramp has plateaux (round 6's first form
+    stopped at 88 ms on one).  It is ordinary warm-up -- the same call on the same buffers, nothing cached that a timed step reuses
+    beyond what step 1 leaves for step 2 -- and what the metric (propagations per second) means: a loop that runs for a second.
+    `info` (a dict) receives what was spent (`prewarm_ms`, `prewarm_batches`, the trajectory of batch times), the device's clocks /
+    power right before and right after the timed region (gpu_state), and -- AFTER the contract's one timed region -- `repeats` more
+    batches of `steps` timed the same way (`repeat_ms`: ms per step of each), so a line shows its own spread."""
     from prysm_amd import propagation as P
     f = None
     info = {} if info is None else info
@@ -884,17 +888,27 @@ def propagation_loop(ranks, x, steps, warmup, info=None, repeats=0):
         return time.perf_counter() - t0
 
     t_start = time.perf_counter()
-    hist = []
+    hist, at = [], []
+    steady = False
     while True:
         hist.append(batch(40))
         spent = (time.perf_counter() - t_start) * 1e3
-        steady = len(hist) >= 3 and max(hist[-3:]) <= min(hist[-3:]) * (1.0 + PREWARM_TOL)
+        at.append(spent)
+        if len(hist) >= 10:
+            recent = sum(hist[-5:]) / 5
+            # the five batches that ended about 100 ms before the recent ones
+            j = max(i for i in range(len(at)) if at[i] <= at[-5] - 100.0) if at[-5] - 100.0 >= at[0] else None
+            if j is not None and j >= 4:
+                earlier = sum(hist[j - 4:j + 1]) / 5
+                steady = abs(recent - earlier) <= PREWARM_TOL * earlier and max(hist[-5:]) <= min(hist[-5:]) * (1.0 + 3 * PREWARM_TOL)
         if (steady and spent >= PREWARM_MIN_MS) or spent >= PREWARM_CAP_MS:
             break
     info['prewarm_ms'] = (time.perf_counter() - t_start) * 1e3
     info['prewarm_batches'] = len(hist)
     info['prewarm_steady'] = bool(steady)
-    info['prewarm_first_batch_ms_per_step'] = hist[0] / 40 * 1e3
+    # ms per step of the batch that ended nearest to each mark (the first batch carries the first call's one-off set-up)
+    info['prewarm_trajectory_ms_per_step'] = {f'{mark}ms': hist[min(range(len(at)), key=lambda i: abs(at[i] - mark))] / 40 * 1e3
+                                              for mark in (50, 100, 200, 400, 800, 1600) if at[-1] >= mark}
     info['prewarm_last_batches_ms_per_step'] = [t / 40 * 1e3 for t in hist[-3:]]
     for _ in range(warmup):
         f = None
