@@ -37,6 +37,10 @@ def short(n):
             kind += '_spectral'
         elif 'r2c' in n:
             kind = 'row_pass_r2c'
+        elif 'row_hermt' in n:
+            kind = 'row_pass_hermt'        # transposed Hermitian form, pass B (fft_hermt.h)
+        elif 'col_hermt' in n:
+            kind = 'column_pass_hermt'     # ... pass A (planes of N points when folded)
         elif 'herm' in n:
             kind = 'column_pass_herm'
         elif 'conv1' in n:
