@@ -333,6 +333,55 @@ def fuzz_real_any(ncases, rng, lib):
     return nfail
 
 
+def fuzz_hermitian(ncases, rng, lib):
+    """pm_fft2 of a REAL power-of-two field on the Hermitian path, both forms (round 6: knob herm_t -1 / 0 / 1, its fold -1 / 0 / 1):
+    rotations of 0 or half a length (sometimes arbitrary: the planner must then leave the transposed form), the DC normalisation, the four
+    epilogues, scales, row pitches wider than the row, both precisions -- against numpy."""
+    lens = [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192]
+    nfail, worst = 0, 0.0
+    lib.pm_set_tuning(b'r2c', 2)
+    for case in range(ncases):
+        M, N = int(rng.choice(lens)), int(rng.choice(lens[:-1]))
+        while M * N > (1 << 23):
+            M, N = (M // 2, N) if rng.random() < 0.5 else (M, N // 2)
+        rdt = np.float32 if rng.random() < 0.6 else np.float64
+        lib.pm_set_tuning(b'herm_t', int(rng.choice([-1, 0, 1, 1])))
+        lib.pm_set_tuning(b'herm_t_fold', int(rng.choice([-1, 0, 1])))
+        sh = lambda n: int(rng.choice([0, n // 2, n // 2, int(rng.integers(0, n))]))
+        ins, outs = (sh(M), int(rng.choice([0, N // 2]))), (sh(M), sh(N))
+        epi = int(rng.choice([L.PM_EPI_NONE, L.PM_EPI_ABS, L.PM_EPI_ABS2, L.PM_EPI_ARG]))
+        norm = bool(rng.random() < 0.5)
+        scale = float(rng.choice([1.0, 0.5, 1.0 / np.sqrt(M * N)]))
+        x = (rng.random((M, N)) + 0.1).astype(rdt)
+        xt = torch.from_numpy(x).cuda()
+        if rng.random() < 0.3:          # a view with a row pitch wider than the row (even offsets: the array is read as pairs)
+            wide = torch.zeros((M, N + 8), dtype=xt.dtype, device='cuda')
+            wide[:, 4:N + 4] = xt
+            xt = wide[:, 4:N + 4]
+        got = _ops.fft2(xt, direction=-1, scale=scale, in_shift=ins, out_shift=outs, epilogue=epi,
+                        flags=L.PM_FLAG_REAL_INPUT | (L.PM_FLAG_NORM_DC if norm else 0)).cpu().numpy()
+        F = np.fft.fft2(np.roll(x.astype(np.float64), (-ins[0], -ins[1]), axis=(0, 1)))
+        if norm:
+            F = F / F[0, 0]
+        F = np.roll(F * scale, outs, axis=(0, 1))
+        tol = 1e-10 if rdt == np.float64 else 3e-5
+        if epi == L.PM_EPI_ARG:
+            strong = np.abs(F) > 1e-3 * np.abs(F).max()
+            err = np.max(np.abs(np.angle(np.exp(1j * (got - np.angle(F))))[strong])) / (1e-7 if rdt == np.float64 else 3e-3)
+        else:
+            ref = {L.PM_EPI_NONE: F, L.PM_EPI_ABS: np.abs(F), L.PM_EPI_ABS2: np.abs(F) ** 2}[epi]
+            err = np.max(np.abs(got - ref)) / (np.max(np.abs(ref)) * tol * (2 if epi == L.PM_EPI_ABS2 else 1))
+        worst = max(worst, err)
+        if err > 1:
+            nfail += 1
+            print('FAIL hermitian', M, N, rdt.__name__, ins, outs, epi, norm, scale, err)
+    lib.pm_set_tuning(b'r2c', 1)
+    lib.pm_set_tuning(b'herm_t', -1)
+    lib.pm_set_tuning(b'herm_t_fold', -1)
+    print(f'fuzz_hermitian: {ncases} cases, {nfail} failures, worst err/tol {worst:.3f}')
+    return nfail
+
+
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -434,6 +483,7 @@ def main():
     nfail += fuzz_real_conv(max(20, ncases // 3), rng, lib)
     nfail += fuzz_spectral(max(12, ncases // 4), rng, lib)
     nfail += fuzz_real_any(max(30, ncases // 3), rng, lib)
+    nfail += fuzz_hermitian(max(30, ncases // 3), rng, lib)
     return 1 if nfail else 0
 
 if __name__ == '__main__':
