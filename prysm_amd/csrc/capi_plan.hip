@@ -383,7 +383,8 @@ bool herm_conv_plan(const pm_fft2_desc* d, HermConvPlan& p) {
              (p.logn == 12 || (p.logn == 13 && d->dtype == PM_C64)) &&
              (d->in_y.shift == 0 || d->in_y.shift == M / 2);
     p.tc = col_tile_width_for(d->dtype, p.fold ? p.logm - 1 : p.logm, 0);
-    p.log_k = tuning().log_k >= 0 ? tuning().log_k : 2;
+    // layout tiles of 8 column tiles for complex64 (profiles/r06/exp_conv_fold.log: 4096^2 fp32 126.3 -> 122.3 us, 2048^2 55.5 -> 54.8; fp64 within noise: 4)
+    p.log_k = tuning().log_k >= 0 ? tuning().log_k : (d->dtype == PM_C64 ? 3 : 2);
     while (p.log_k > 0 && ((N / 2) % (int64_t(p.tc) << p.log_k)) != 0) --p.log_k;
     if ((N / 2) % p.tc) return false;
     const size_t es = d->dtype == PM_C64 ? 8 : 16;

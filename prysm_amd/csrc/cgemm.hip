@@ -624,7 +624,12 @@ struct DmaPlan {
 static bool gemm_dma_plan(int64_t M, int64_t N, int64_t K, DmaPlan* out) {
     if (!tuning().gemm_dma || !tuning().gemm_3m || M < 64 || N < 64 || (M % 64) || (N % 64) || K < 16 || (K % 16)) return false;
     DmaPlan p{64, 64, 1, 1, K};
-    const int want = tuning().gemm_dma_wgs;
+    // workgroups the launch aims for (128 x 128 tiles from that many, else K split across workgroups until it is reached): 512 measured
+    // best on config 4's products (2^31 and 2^29 multiply-adds); the 2^26 .. 2^28 products of a 1024^2 <-> 256^2 model are launch bound and
+    // take 256 -- half the slabs for the reduce launch to add (profiles/r06/exp_model7_knobs.log: the seven-plane model 131.3 us at 512,
+    // 126.7 at 256, 189.8 at 128).  A knob set by hand is taken as it is.
+    int want = tuning().gemm_dma_wgs;
+    if (want == 512 && M * N * K <= (int64_t(1) << 28)) want = 256;
     const bool m128 = (M % 128) == 0, n128 = (N % 128) == 0;
     const int64_t t64 = (M / 64) * (N / 64);
     const int wkm = tuning().gemm_wk;     // bit 0: 64 x 64 with two K-groups (8 waves), bit 1: 64 x 32 with two, bit 2: 32 x 32 with four
