@@ -342,9 +342,14 @@ class Sequence:
             t = h.__dict__.get('_data')
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 news.append(t)
+        passed = {_key(t) for t in ins} if ins else ()
         for t in news:
+            k = _key(t)
+            if k in passed and k not in prod:
+                continue                    # an outside input handed through (the amplitude map of a lazy product): still an outside input,
+                                            # not something this stream made -- or every later chain that reads it would follow this stream
             made.append(weakref.ref(t))     # recorded on the caller's stream at the join if still alive (StreamRing.join)
-            prod[_key(t)] = s
+            prod[k] = s
         return out
 
 
