@@ -327,6 +327,7 @@ class Sequence:
             for k, t in fresh:
                 checked[k] = (t if t._base is None else t._base, t._version)
         lazy = _holders_of(args, [])
+        before = {_key(t): t._version for t in ins} if ins else {}
         self._depth = 1
         self._switch(s)
         try:
@@ -342,12 +343,12 @@ class Sequence:
             t = h.__dict__.get('_data')
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 news.append(t)
-        passed = {_key(t) for t in ins} if ins else ()
         for t in news:
             k = _key(t)
-            if k in passed and k not in prod:
-                continue                    # an outside input handed through (the amplitude map of a lazy product): still an outside input,
-                                            # not something this stream made -- or every later chain that reads it would follow this stream
+            if k not in prod and before.get(k) == t._version:
+                continue                    # an outside input handed through UNCHANGED (the amplitude map of a lazy product): still an outside
+                                            # input, not something this stream made -- or every later chain that reads it would follow this
+                                            # stream.  (An `out=` accumulator is written: its version counter moved, it is registered.)
             made.append(weakref.ref(t))     # recorded on the caller's stream at the join if still alive (StreamRing.join)
             prod[k] = s
         return out
