@@ -859,6 +859,21 @@ def gpu_state(dev_index=0):
     return {k: v for k, v in out.items() if v is not None}
 
 
+def run_in_is_steady(hist, at, tol=PREWARM_TOL, lookback_ms=100.0):
+    """The run-in's stopping rule (pure: tests/test_host_logic.py runs it on synthetic trajectories).  `hist`: seconds per batch, `at`: ms
+    since the start at which each batch ended.  Steady = the mean of the last five batches is within `tol` of the mean of the five
+    batches that ended about `lookback_ms` earlier (no drift over 100 ms: a plateau of the clock ramp is shorter than that) and the
+    last five agree with each other within 3 tol."""
+    if len(hist) < 10 or at[-5] - lookback_ms < at[0]:
+        return False
+    j = max(i for i in range(len(at)) if at[i] <= at[-5] - lookback_ms)
+    if j < 4:
+        return False
+    recent = sum(hist[-5:]) / 5
+    earlier = sum(hist[j - 4:j + 1]) / 5
+    return abs(recent - earlier) <= tol * earlier and max(hist[-5:]) <= min(hist[-5:]) * (1.0 + 3 * tol)
+
+
 def propagation_loop(ranks, x, steps, warmup, info=None, repeats=0):
     """warmup untimed + exactly `steps` timed focus(x, 1) per rank; returns seconds (MAX over ranks).
 
@@ -894,13 +909,7 @@ def propagation_loop(ranks, x, steps, warmup, info=None, repeats=0):
         hist.append(batch(40))
         spent = (time.perf_counter() - t_start) * 1e3
         at.append(spent)
-        if len(hist) >= 10:
-            recent = sum(hist[-5:]) / 5
-            # the five batches that ended about 100 ms before the recent ones
-            j = max(i for i in range(len(at)) if at[i] <= at[-5] - 100.0) if at[-5] - 100.0 >= at[0] else None
-            if j is not None and j >= 4:
-                earlier = sum(hist[j - 4:j + 1]) / 5
-                steady = abs(recent - earlier) <= PREWARM_TOL * earlier and max(hist[-5:]) <= min(hist[-5:]) * (1.0 + 3 * PREWARM_TOL)
+        steady = run_in_is_steady(hist, at)
         if (steady and spent >= PREWARM_MIN_MS) or spent >= PREWARM_CAP_MS:
             break
     info['prewarm_ms'] = (time.perf_counter() - t_start) * 1e3

@@ -392,3 +392,38 @@ def test_untangle_formula_of_the_real_input_route():
         sy, sx = M // 2, 3 % N
         ph = np.exp(2j * np.pi * (np.arange(M)[:, None] * sy / M + np.arange(N)[None, :] * sx / N))
         assert np.allclose(F * ph, np.fft.fft2(np.roll(x, (-sy, -sx), axis=(0, 1))), atol=1e-12 * N * M)
+
+
+def test_bench_run_in_rule_and_device_state_without_a_gpu():
+    """bench.py's run-in stops on NO DRIFT, not on a plateau of the clock ramp (profiles/r06/exp_warm_trajectory.log: three equal 4 ms
+    batches at 120 ms were not the steady state); gpu_state() never raises; the summary carries the round-6 keys."""
+    import bench
+    dt = 4.0                                                       # ms per batch
+    at = [dt * (i + 1) for i in range(200)]
+    ramp = [98.0 - 4.0 * min(1.0, a / 200.0) for a in at]          # 98 us per step falling to 94 over 200 ms, flat afterwards
+    secs = [v * 40e-6 for v in ramp]
+    stops = [i for i in range(len(at)) if bench.run_in_is_steady(secs[:i + 1], at[:i + 1])]
+    assert stops and at[stops[0]] >= 250.0                         # not while the look-back window (100 ms earlier) is still more than 1 % up the ramp
+    # a plateau in the middle of the ramp (25 batches = 100 ms at one level, then the fall continues): never "steady" while it lasts less
+    # than look-back + five batches
+    stair = [98.0] * 20 + [96.0] * 20 + [94.0] * 160
+    secs2 = [v * 40e-6 for v in stair]
+    first = next(i for i in range(len(at)) if bench.run_in_is_steady(secs2[:i + 1], at[:i + 1]))
+    assert stair[first] == 94.0 and at[first] >= 160.0 + 100.0
+    # noise of +-0.3 % does not keep it from stopping; a 2 % sawtooth does
+    rng = np.random.default_rng(0)
+    quiet = [94.0 * (1 + 0.003 * rng.standard_normal()) * 40e-6 for _ in at]
+    assert any(bench.run_in_is_steady(quiet[:i + 1], at[:i + 1]) for i in range(len(at)))
+    saw = [94.0 * (1.05 if i % 2 else 1.0) * 40e-6 for i in range(len(at))]
+    assert not any(bench.run_in_is_steady(saw[:i + 1], at[:i + 1]) for i in range(len(at)))
+    st = bench.gpu_state(0)
+    assert isinstance(st, dict)                                    # sysfs of another machine, or none at all: a dict either way
+    line = {'value': 1.0, 'ms_per_step': 2.0, 'repeat_ms': [2.0, 2.1], 'repeat_spread': 0.05, 'prewarm_ms': 400.0,
+            'gpu_before': {'sclk_mhz': 2350.0}, 'gpu_after': {'sclk_mhz': 2340.0, 'power_w': 1200.0},
+            'roofline': {'frac': 0.7, 'row_pass_ms': 0.047, 'column_pass_ms': 0.046, 'two_plain_copies_ms': 0.087},
+            'other_configs': {'model_7plane_1024': {'c64': {'eager_ms_per_wavelength': 0.127, 'graph_ms_per_wavelength': 0.135}},
+                              'config4_mdft_2048_to_512_c64': {'ms': 0.141, 'frac_of_f32_mfma_peak': 0.96, 'mfma_busy': 0.68}}}
+    summ = bench._summary(line)
+    for key, want in (('repeat_ms', [2.0, 2.1]), ('sclk_before', 2350.0), ('power_w_after', 1200.0), ('m7_c64_eager_ms', 0.127), ('c4_mfma_busy', 0.68)):
+        assert summ[key] == want, key
+    assert bench.model7_flops()['total'] == 3 * 8.0 * 256 * 1024 * (1024 + 256)
