@@ -82,6 +82,9 @@ bool plan_fused(const pm_fft2_desc* d, FusedPlan& p);
 void blue2d_desc(pm_fft2_desc& dd, int dtype, int64_t M, int64_t N);
 size_t blue2d_fused_ws(int dtype, int64_t M, int64_t N);
 int check_fft2(const pm_fft2_desc* d);
+bool ce_rows_axis(const pm_fft2_desc* d, const Fft2Plan& p);
+bool ce_cols_axis(const pm_fft2_desc* d, const Fft2Plan& p);
+bool ce_both_axes_stack(const pm_fft2_desc* d, const Fft2Plan& p);
 size_t fft1_big_scratch(size_t es, int axis, int64_t batch, int64_t n);
 inline bool fft1_big_ok(const pm_axis* ti) { return big_split(ti->n) > 1 && ti->shift == 0; }
 bool herm_conv_plan(const pm_fft2_desc* d, HermConvPlan& p);

@@ -418,6 +418,31 @@ int spectral_group(int32_t count) {
 // One line that says which route a descriptor takes -- the planner's decisions (plan_fft2 / plan_fused / herm_conv_plan under the
 // calling thread's tuning knobs) in words.  Host logic only: callable without a GPU, so the routes of a table of shapes are pinned by
 // a CPU test (tests/test_host_logic.py) and a shape that falls to a slow route shows up there and not as a timing.
+// Does the row / column pass of this plan run on the composite register engine (fft_ce.h)?  The descriptor-level statement of what
+// ce_rows_view / ce_cols_view (fft_ce_kernels.h) accept, in ONE place (it was written out in pm_plan_explain, in fft2_run's
+// stack test and in the views): pm_plan_explain reports it, fft2_run sends (B, m, n) stacks out as grid.y by it.
+bool ce_rows_axis(const pm_fft2_desc* d, const Fft2Plan& p) {
+    const bool f32 = d->dtype == PM_C64;
+    const size_t es = f32 ? 8 : 16;
+    const int64_t N = d->in_x.n;
+    return p.mix_n && !p.mix_fold && tuning().mix_engine && !(d->flags & PM_FLAG_REAL_INPUT) && (f32 || !(d->flags & PM_FLAG_SYNTH_INPUT)) &&
+           (f32 ? ce_has_plan<float>(int(N)) : ce_has_plan<double>(int(N))) && ce_fits32(kCeMaxSeqs * d->in_ld + 2 * N, es) &&
+           ce_fits32(kCeMaxSeqs * p.w_ld + 2 * N, es);
+}
+bool ce_cols_axis(const pm_fft2_desc* d, const Fft2Plan& p) {
+    const bool f32 = d->dtype == PM_C64;
+    const size_t es = f32 ? 8 : 16;
+    const int64_t M = d->in_y.n, N = d->in_x.n;
+    const bool whole_out = d->out_y.off == 0 && d->out_y.len == M && d->out_x.off == 0 && d->out_x.len == N;
+    return p.mix_m && !p.mix_fold && tuning().mix_engine && whole_out && d->mul_kind == PM_MUL_NONE && d->epilogue <= PM_EPI_ABS2_ACCUM &&
+           (f32 ? ce_has_plan<float>(int(M)) : ce_has_plan<double>(int(M))) && ce_fits32(2 * M * p.w_ld + kCeMaxSeqs, es) &&
+           ce_fits32(2 * M * d->out_ld + N, es);
+}
+// ... both, for a stack of plain complex fields (no synthesis in the loads, whole transform in one call)
+bool ce_both_axes_stack(const pm_fft2_desc* d, const Fft2Plan& p) {
+    return !p.big_rn && !p.blue2d && !(d->flags & (PM_FLAG_SYNTH_INPUT | PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY)) && ce_rows_axis(d, p) && ce_cols_axis(d, p);
+}
+
 static const char* axis_route(bool engine, bool mix, bool blue) { return engine ? "stockham" : (mix ? "mixed-radix" : (blue ? "bluestein" : "direct")); }
 
 int check_fft1(int32_t dtype, int32_t direction, int32_t axis, int64_t batch, const pm_axis* t_in, const pm_axis* t_out) {
@@ -487,15 +512,7 @@ int pm_plan_explain(const pm_fft2_desc* d, int32_t op, char* buf, size_t n) {
     } else {
         const bool en = p.logn >= 0, em = p.logm >= 0;
         // a composite axis whose length has a compile-time plan runs on the register engine (fft_ce.h) when the view is plain
-        const bool f32 = d->dtype == PM_C64;
-        const size_t es = f32 ? 8 : 16;
-        const bool ce_n = p.mix_n && !p.mix_fold && tuning().mix_engine && !(d->flags & PM_FLAG_REAL_INPUT) && (f32 || !(d->flags & PM_FLAG_SYNTH_INPUT)) &&
-                          (f32 ? ce_has_plan<float>(int(N)) : ce_has_plan<double>(int(N))) && ce_fits32(kCeMaxSeqs * d->in_ld + 2 * N, es) &&
-                          ce_fits32(kCeMaxSeqs * p.w_ld + 2 * N, es);
-        const bool whole_out = d->out_y.off == 0 && d->out_y.len == M && d->out_x.off == 0 && d->out_x.len == N;
-        const bool ce_m = p.mix_m && !p.mix_fold && tuning().mix_engine && whole_out && !d->mul && d->epilogue <= PM_EPI_ABS2_ACCUM &&
-                          (f32 ? ce_has_plan<float>(int(M)) : ce_has_plan<double>(int(M))) && ce_fits32(2 * M * p.w_ld + kCeMaxSeqs, es) &&
-                          ce_fits32(2 * M * d->out_ld + N, es);
+        const bool ce_n = ce_rows_axis(d, p), ce_m = ce_cols_axis(d, p);
         snprintf(buf, n, "fft2 %lldx%lld %s: route=%s rows=%s(%lld) cols=%s(%lld%s) tile=%d log_k=%d chunk=%lld ws=%zu", M, N, dt,
                  (en && em) ? (p.fold ? "engine-fold" : "engine") : ((p.mix_n || !p.blue_n) && (p.mix_m || !p.blue_m) && (p.mix_n || p.mix_m) ? "natural-mixed" : "natural"),
                  ce_n ? "mixed-radix-registers" : axis_route(en, p.mix_n, p.blue_n), N, ce_m ? "mixed-radix-registers" : axis_route(em, p.mix_m, p.blue_m),

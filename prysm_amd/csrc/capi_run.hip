@@ -304,13 +304,7 @@ int fft2_run(const pm_fft2_desc* d, const Fft2Plan& p, const void* in, void* out
     if (p.nbatch <= 1) return fft2_run_chunk<T>(d, p, in, out, ws, st, 1);
     const bool engine = p.tc != 0;
     // ... and composite grids whose two passes both run on the composite register engine (fft_ce.h: grid.y = fields; round 5)
-    const bool f32 = d->dtype == PM_C64;
-    const bool ce_stack = p.mix_n && p.mix_m && !p.mix_fold && !p.big_rn && !p.blue2d && tuning().mix_engine &&
-                          !(d->flags & (PM_FLAG_REAL_INPUT | PM_FLAG_SYNTH_INPUT | PM_FLAG_PASS1_ONLY | PM_FLAG_PASS2_ONLY)) && d->mul_kind == PM_MUL_NONE &&
-                          d->out_y.off == 0 && d->out_y.len == d->out_y.n && d->out_x.off == 0 && d->out_x.len == d->out_x.n &&
-                          d->epilogue <= PM_EPI_ABS2_ACCUM &&
-                          (f32 ? ce_has_plan<float>(int(d->in_x.n)) && ce_has_plan<float>(int(d->in_y.n))
-                               : ce_has_plan<double>(int(d->in_x.n)) && ce_has_plan<double>(int(d->in_y.n)));
+    const bool ce_stack = ce_both_axes_stack(d, p);
     const int64_t step = (engine || ce_stack) ? p.chunk : 1;
     const size_t oes = d->epilogue == PM_EPI_NONE ? sizeof(cx<T>) : sizeof(T);
     for (int64_t b0 = 0; b0 < p.nbatch; b0 += step) {
